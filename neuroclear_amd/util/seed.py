@@ -1,0 +1,118 @@
+"""Deterministic parameter filler shared by the product path, the oracle and the golden-vector generator.
+
+The reference initialises networks with torch's global RNG (``models/networks.py:88-119`` ``init_weights``), which
+cannot be replayed across library versions.  Parity work therefore needs parameters that BOTH sides can rebuild from
+a seed without shipping tensors: ``weights_from_seed`` fills a state dict, in state-dict order, from
+``numpy.random.default_rng`` streams keyed by ``(seed, tensor index)``.  Weights follow the scale of the reference's
+``kaiming_normal_(a=0, mode='fan_in')`` (``networks.py:106-107``); biases are drawn non-zero on purpose (the reference
+zeroes them, ``networks.py:112-113``) so that every bias path is exercised by the parity tests.
+
+State-dict key names / shapes are the on-disk contract of ``models/base_model.py:146-162``.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+def unet_deconv_spec(dimension=3):
+    """(key, shape) list of ``Unet_deconv`` (``models/networks.py:478-510``), input_nc forced to 1 (``:174``)."""
+    k3 = (3,) * dimension
+    k2 = (2,) * dimension
+    k1 = (1,) * dimension
+    spec = []
+
+    def conv(name, cout, cin, k):
+        spec.append((name + '.weight', (cout, cin) + k))
+        spec.append((name + '.bias', (cout,)))
+
+    conv('double_conv1.convolution.0', 64, 1, k3)
+    conv('double_conv1.convolution.3', 64, 64, k3)
+    conv('double_conv2.convolution.0', 128, 64, k3)
+    conv('double_conv2.convolution.3', 128, 128, k3)
+    conv('bottom_layer.convolution.0', 256, 128, k3)
+    conv('bottom_layer.convolution.3', 256, 256, k3)
+    conv('bottom_layer.convolution.6', 256, 256, k3)
+    # ConvTranspose weight is (Cin, Cout, k, k, k)
+    spec.append(('t_conv2.weight', (256, 128) + k2))
+    spec.append(('t_conv2.bias', (128,)))
+    conv('ex_double_conv2.convolution.0', 128, 256, k3)
+    conv('ex_double_conv2.convolution.3', 128, 128, k3)
+    spec.append(('t_conv1.weight', (128, 64) + k2))
+    spec.append(('t_conv1.bias', (64,)))
+    conv('ex_conv1_1.convolution.0', 64, 128, k3)
+    conv('one_by_one', 1, 64, k1)
+    conv('one_by_one_2', 1, 1, k1)
+    return spec
+
+
+def deep_linear_spec():
+    """(key, shape) list of ``DeepLinearGenerator`` (``models/networks.py:893-911``); every conv is bias-free."""
+    return [
+        ('first_layer.weight', (64, 1, 7, 7, 7)),
+        ('feature_block.0.weight', (64, 64, 5, 5, 5)),
+        ('feature_block.1.weight', (64, 64, 3, 3, 3)),
+        ('feature_block.2.weight', (32, 64, 1, 1, 1)),
+        ('feature_block.3.weight', (16, 32, 1, 1, 1)),
+        ('final_layer.weight', (1, 16, 1, 1, 1)),
+    ]
+
+
+def patchgan_spec(dimension=2, input_nc=1, ndf=64, n_layers=3):
+    """(key, shape) list of ``NLayerDiscriminator`` (``models/networks.py:1009-1061``) with instance norm
+    (=> every conv carries a bias, ``:1025-1028``).  Sequential indices: conv at 0, then 2+3*(n-1) for the middle
+    blocks (conv, norm, lrelu), then the stride-1 block, then the 1-channel head."""
+    k = (4,) * dimension
+    spec = [('model.0.weight', (ndf, input_nc) + k), ('model.0.bias', (ndf,))]
+    idx = 2
+    nf_prev, nf = 1, 1
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        spec.append(('model.%d.weight' % idx, (ndf * nf, ndf * nf_prev) + k))
+        spec.append(('model.%d.bias' % idx, (ndf * nf,)))
+        idx += 3
+    nf_prev, nf = nf, min(2 ** n_layers, 8)
+    spec.append(('model.%d.weight' % idx, (ndf * nf, ndf * nf_prev) + k))
+    spec.append(('model.%d.bias' % idx, (ndf * nf,)))
+    idx += 3
+    spec.append(('model.%d.weight' % idx, (1, ndf * nf) + k))
+    spec.append(('model.%d.bias' % idx, (1,)))
+    return spec
+
+
+def _fan_in(key, shape):
+    # torch's _calculate_fan_in_and_fan_out: fan_in = size(1) * receptive field -- for ConvTranspose weights
+    # (Cin, Cout, k..) that is Cout * k^d, which is what kaiming_normal_ in the reference ends up using.
+    rf = 1
+    for s in shape[2:]:
+        rf *= s
+    return shape[1] * rf
+
+
+def weights_from_seed(spec, seed, bias_scale=0.1):
+    """Return an OrderedDict {key: float32 ndarray} for a (key, shape) spec.  Pure numpy: torch-free on purpose."""
+    out = OrderedDict()
+    for idx, (key, shape) in enumerate(spec):
+        rng = np.random.default_rng([int(seed), idx])
+        if key.endswith('.weight'):
+            std = np.sqrt(2.0 / _fan_in(key, shape))
+            out[key] = (rng.standard_normal(shape) * std).astype(np.float32)
+        else:
+            out[key] = rng.uniform(-bias_scale, bias_scale, size=shape).astype(np.float32)
+    return out
+
+
+def state_dict_from_seed(spec, seed, device='cpu', bias_scale=0.1):
+    """Same as weights_from_seed, as torch tensors (importing torch lazily)."""
+    import torch
+    sd = OrderedDict()
+    for k, v in weights_from_seed(spec, seed, bias_scale).items():
+        sd[k] = torch.from_numpy(v).to(device)
+    return sd
+
+
+def random_volume(seed, size, dtype=np.uint16):
+    """Seeded synthetic *random* volume of SURVEY.md §8(d): uniform integers over the dtype range."""
+    if isinstance(size, int):
+        size = (size, size, size)
+    hi = 65536 if np.dtype(dtype) == np.uint16 else 256
+    return np.random.default_rng(int(seed)).integers(0, hi, size=tuple(size), dtype=dtype)

@@ -1,0 +1,121 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of one Apollo / Athena optimisation step.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+
+Restates /root/reference/models/axial_to_lateral_gan_apollo_model.py:
+  set_input :142-160, forward :162-167, backward_G :255-283, backward_D_* :169-253, optimize_parameters :285-307,
+  Volume.get_slice / get_projection :322-351
+and /root/reference/models/axial_to_lateral_gan_athena_model.py:
+  __init__ plane wiring :93-148, backward_G :240-260, backward_D_* :190-238, iter_f :286-296, Volume :298-331
+
+All random indices come from ``np.random`` in the reference's own draw order, so ``np.random.seed(s)`` before a step
+replays the reference step exactly.  Autograd and Adam are torch's (the reference's dependency).
+
+Parity pin: tests/golden/apollo_step_*.npz / athena_step_*.npz (oracle/gen_golden.py).
+"""
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import nets
+
+APOLLO_D = ['D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']  # optimizer_D chain order, apollo:133-135
+
+
+class Nets:
+    """Parameter holder: {net name: {key: leaf tensor}}."""
+
+    def __init__(self, sds):
+        self.sd = OrderedDict((n, nets.to_torch(sd, requires_grad=True)) for n, sd in sds.items())
+
+    def params(self, names):
+        return list(itertools.chain(*[self.sd[n].values() for n in names]))
+
+    def set_requires_grad(self, names, flag):
+        for p in self.params(names):
+            p.requires_grad_(flag)
+
+
+def _slice(vol, axis):
+    """Volume.get_slice apollo:328-337 -- num_slice is vol.shape[-1] for every axis (:325)."""
+    i = np.random.randint(vol.shape[-1])
+    return [vol[:, :, i, :, :], vol[:, :, :, i, :], vol[:, :, :, :, i]][axis]
+
+
+def _mip(vol, depth, axis):
+    """Volume.get_projection apollo:339-351."""
+    s = np.random.randint(0, vol.shape[-1] - depth)
+    roi = [vol[:, :, s:s + depth], vol[:, :, :, s:s + depth], vol[:, :, :, :, s:s + depth]][axis]
+    return torch.max(roi, axis + 2)[0]
+
+
+class ApolloOracle:
+    def __init__(self, sds, lr=1e-4, beta1=0.1, lambda_A=5.0, lambda_plane=(1, 1, 1), projection_depth=10,
+                 randomize_projection_depth=True, min_projection_depth=2):
+        self.n = Nets(sds)
+        s = float(sum(lambda_plane))
+        self.w_target, self.w_slice, self.w_proj = [f / s for f in lambda_plane]  # apollo:81-82
+        self.lambda_A = lambda_A
+        self.randomize = randomize_projection_depth
+        self.max_depth, self.min_depth = projection_depth, min_projection_depth
+        self.opt_G = torch.optim.Adam(self.n.params(['G_A', 'G_B']), lr=lr, betas=(beta1, 0.999))
+        self.opt_D = torch.optim.Adam(self.n.params(APOLLO_D), lr=lr, betas=(beta1, 0.999))
+        self.losses = OrderedDict()
+
+    def D(self, name, x):
+        return nets.patchgan(self.n.sd[name], x)
+
+    def step(self, real):
+        if self.randomize:  # apollo:157-160
+            self.depth = np.random.randint(max(2, self.min_depth), self.max_depth + 1)
+        else:
+            self.depth = self.max_depth
+        L = self.losses
+        fake = nets.unet_deconv(self.n.sd['G_A'], real)
+        rec = nets.deep_linear(self.n.sd['G_B'], fake)
+        self.fake, self.rec = fake, rec
+
+        # ---- generators (apollo:255-283)
+        self.n.set_requires_grad(APOLLO_D, False)
+        self.opt_G.zero_grad()
+        L['G_A_lateral'] = nets.lsgan(self.D('D_A_lateral', _mip(fake, self.depth, 0)), True) * self.w_target
+        L['G_A_axial'] = nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 1)), True) * self.w_slice + \
+            nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 2)), True) * self.w_slice
+        L['G_A'] = L['G_A_lateral'] + L['G_A_axial'] * 0.5
+        L['G_B_lateral'] = nets.lsgan(self.D('D_B_lateral', _slice(rec, 0)), True) * self.w_target
+        L['G_B_axial'] = nets.lsgan(self.D('D_B_axial', _slice(rec, 1)), True) * self.w_slice + \
+            nets.lsgan(self.D('D_B_axial', _slice(rec, 2)), True) * self.w_slice
+        L['G_B'] = L['G_B_lateral'] + L['G_B_axial'] * 0.5
+        L['cycle'] = nets.l1(rec, real) * self.lambda_A
+        (L['G_A'] + L['G_B'] + L['cycle']).backward()
+        self.grads_G = [p.grad.clone() for p in self.n.params(['G_A', 'G_B'])]
+        self.opt_G.step()
+
+        # ---- discriminators (apollo:297-307)
+        self.n.set_requires_grad(APOLLO_D, True)
+        self.opt_D.zero_grad()
+        fd, rd = fake.detach(), rec.detach()
+
+        def d_proj(name, ax_real, ax_fake):  # backward_D_projection apollo:195-223
+            pr = self.D(name, _slice(real, ax_real))
+            pf = self.D(name, _mip(fd, self.depth, ax_fake))
+            loss = (nets.lsgan(pr, True) + nets.lsgan(pf, False)) * 0.5
+            loss.backward()
+            return loss
+
+        def d_slice(name, ax_real, ax_fake):  # backward_D_slice apollo:169-193
+            pr = self.D(name, _slice(real, ax_real))
+            pf = self.D(name, _slice(rd, ax_fake))
+            loss = (nets.lsgan(pr, True) + nets.lsgan(pf, False)) * 0.5
+            loss.backward()
+            return loss
+
+        L['D_A_lateral'] = d_proj('D_A_lateral', 0, 0)
+        L['D_A_axial'] = (d_proj('D_A_axial', 0, 1) + d_proj('D_A_axial', 0, 2)) * 0.5
+        L['D_B_lateral'] = d_slice('D_B_lateral', 0, 0)
+        L['D_B_axial'] = (d_slice('D_B_axial', 1, 1) + d_slice('D_B_axial', 2, 2)) * 0.5
+        self.grads_D = [p.grad.clone() for p in self.n.params(APOLLO_D)]
+        self.opt_D.step()
+        return OrderedDict((k, float(v.detach())) for k, v in L.items())

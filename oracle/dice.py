@@ -1,0 +1,92 @@
+"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of the reference's dice / assemble path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+
+Restates, as plain functions over numpy arrays:
+
+* ``pad_amounts`` / ``pad_for_dicing``  -- /root/reference/util/util.py:196-215
+* ``grid_steps``                        -- data/diceImage_dataset.py:91-93  (== util/assemble_dice.py:23-25)
+* ``index_to_zyx``                      -- data/diceImage_dataset.py:100-106 (== assemble_dice.py:60-66), x fastest
+* ``reflect_pad`` + ``cut_cube``        -- data/diceImage_dataset.py:95-96, 108-120
+* ``normalize``                         -- data/base_dataset.py:134-143 (+ float32 cast of :291-295)
+* ``assemble``                          -- util/assemble_dice.py:130-213 (crop border, overlap-add /8, count,
+                                           *8/count, scale, truncating cast, crop the dicing pad)
+
+Parity pin: tests/golden/dice_*.npz, produced by running the reference's own DiceImageDataSet + Assemble_Dice
+(oracle/gen_golden.py).  ``--normalize_intensity`` / ``--histogram_match`` (scikit-image arithmetic) are parity
+UNPINNED and are not restated here.
+"""
+import numpy as np
+
+
+def pad_amounts(shape, roi, overlap):
+    step = roi - overlap
+    return tuple(step * ((L + overlap) // step) + roi - L for L in shape)
+
+
+def pad_for_dicing(vol, roi, overlap):
+    pz, py, px = pad_amounts(vol.shape, roi, overlap)
+    return np.pad(vol, ((0, pz), (0, py), (0, px)))
+
+
+def grid_steps(padded_shape, roi, overlap):
+    step = roi - overlap
+    return tuple((L - overlap) // step for L in padded_shape)
+
+
+def index_to_zyx(index, steps):
+    zs, ys, xs = steps
+    return index // (xs * ys), (index % (xs * ys)) // xs, index % xs
+
+
+def reflect_pad(padded, border):
+    return np.pad(padded, ((border, border),) * 3, mode='reflect')
+
+
+def cut_cube(reflected, index, steps, roi, overlap, border):
+    step = roi - overlap
+    zi, yi, xi = index_to_zyx(index, steps)
+    e = roi + 2 * border
+    z0, y0, x0 = zi * step, yi * step, xi * step
+    return reflected[z0:z0 + e, y0:y0 + e, x0:x0 + e]
+
+
+def normalize(cube):
+    if cube.dtype == np.uint8:
+        den = 2 ** 8 * 1.0 - 1
+    elif cube.dtype == np.uint16:
+        den = 2 ** 16 * 1.0 - 1
+    else:
+        raise TypeError('dice input must be uint8/uint16 (reference leaves other dtypes unbound)')
+    return (cube / den).astype(float).astype(np.float32)
+
+
+def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_type='uint16'):
+    """cubes: iterable of (R+2b)^3 float32 arrays in index order.  Returns the cropped uint8/uint16 volume."""
+    if border < 1:
+        raise ValueError('border_cut must be >= 1 (reference slices [b:-b]; b=0 yields an empty cube)')
+    steps = grid_steps(padded_shape, roi, overlap)
+    step = roi - overlap
+    acc = np.zeros(padded_shape, dtype=np.float32)
+    cnt = np.zeros(padded_shape, dtype=np.float32)
+    n = 0
+    for index, cube in enumerate(cubes):
+        c = np.asarray(cube, dtype=np.float32)[border:-border, border:-border, border:-border]
+        assert c.shape == (roi, roi, roi)
+        zi, yi, xi = index_to_zyx(index, steps)
+        z0, y0, x0 = zi * step, yi * step, xi * step
+        if overlap > 0:
+            acc[z0:z0 + roi, y0:y0 + roi, x0:x0 + roi] += c / 8
+            cnt[z0:z0 + roi, y0:y0 + roi, x0:x0 + roi] += np.ones((roi, roi, roi), dtype=np.float32)
+        n += 1
+    assert n == steps[0] * steps[1] * steps[2]
+    if overlap > 0:
+        acc = (acc / cnt) * 8
+    if data_type == 'uint8':
+        acc *= 255
+        acc = acc.astype(np.uint8)
+    elif data_type == 'uint16':
+        acc *= 2 ** 16 - 1
+        acc = acc.astype(np.uint16)
+    pads = [padded_shape[i] - original_shape[i] for i in range(3)]
+    return acc[:-pads[0], :-pads[1], :-pads[2]]

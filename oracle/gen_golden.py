@@ -1,0 +1,321 @@
+"""Golden-vector generator: runs the REFERENCE itself (imported from /root/reference, CPU) and writes fixtures.
+
+Run in the build container only:   python -m oracle.gen_golden        (from the repo root)
+Outputs: tests/golden/*.npz -- numeric inputs/outputs only; no reference source travels.  Weights are NOT stored:
+both sides rebuild them with neuroclear_amd.util.seed.weights_from_seed(spec, seed).
+
+The reference's data/ and util/assemble_dice.py import skimage / torchvision / cv2 / tifffile, which are not installed
+here; tiny stand-in modules are injected into sys.modules for the *import only* (SURVEY.md 8c): skimage.io.imread ->
+np.load, torchvision.transforms.{Lambda,Compose}.  None of the arithmetic under test goes through a stand-in.
+"""
+import os
+import sys
+import tempfile
+import types
+from argparse import Namespace
+from collections import OrderedDict
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from neuroclear_amd.util import seed as S  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _install_stubs():
+    if not hasattr(np, 'float'):
+        np.float = float  # removed alias used at data/base_dataset.py:293
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Lambda:
+        def __init__(self, f):
+            self.f = f
+
+        def __call__(self, x):
+            return self.f(x)
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    sk = mod('skimage')
+    sk.io = mod('skimage.io', imread=lambda p: np.load(p))
+    sk.exposure = mod('skimage.exposure', match_histograms=None, rescale_intensity=None)
+    sk.transform = mod('skimage.transform')
+    tv = mod('torchvision')
+    tv.transforms = mod('torchvision.transforms', Lambda=Lambda, Compose=Compose)
+    mod('cv2')
+
+
+def ref_modules():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    from models import networks
+    return networks
+
+
+def load_sd(net, sd_np):
+    net.load_state_dict(OrderedDict((k, torch.from_numpy(v)) for k, v in sd_np.items()))
+
+
+def rand_input(seed, shape):
+    return np.random.default_rng(seed).random(shape, dtype=np.float32)
+
+
+def big_summary(a, n=4096, key=55):
+    """(l2, sum, n seeded samples) of a large array: keeps fixtures small without losing sensitivity."""
+    a = np.asarray(a).ravel()
+    idx = np.random.default_rng(key).integers(0, a.size, size=min(n, a.size))
+    return np.concatenate([[np.sqrt((a.astype(np.float64) ** 2).sum()), a.astype(np.float64).sum()],
+                           a[idx].astype(np.float64)])
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def grad_summary(named_grads):
+    """Per-parameter (l2, sum, 8 sampled elements) as arrays, in order."""
+    l2, sm, samp = [], [], []
+    for i, (k, g) in enumerate(named_grads):
+        g = g.detach().numpy().ravel()
+        l2.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        sm.append(g.astype(np.float64).sum())
+        idx = np.random.default_rng([77, i]).integers(0, g.size, size=8)
+        samp.append(g[idx])
+    return np.array(l2), np.array(sm), np.stack(samp)
+
+
+def gen_nets(networks):
+    import contextlib
+    import io
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    # ---- unet_deconv fwd + bwd
+    for size, seed in ((16, 1), (32, 2)):
+        with quiet:
+            net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [], dimension=3)
+        load_sd(net, S.weights_from_seed(S.unet_deconv_spec(), seed))
+        x = torch.from_numpy(rand_input(100 + seed, (1, 1, size, size, size))).requires_grad_(True)
+        taps = {}
+        hooks = []
+        for name, m in (('conv1', net.double_conv1), ('conv2', net.double_conv2), ('conv_bottom', net.bottom_layer),
+                        ('ex_conv2', net.ex_double_conv2), ('ex_conv1', net.ex_conv1_1)):
+            hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: taps.__setitem__(name, o.detach())))
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        stage = {('stage_' + k): np.array([v.mean().item(), v.abs().max().item(), v.norm().item()])
+                 for k, v in taps.items()}
+        np.savez_compressed(os.path.join(OUT, 'unet_deconv_%d.npz' % size), seed=seed, x_seed=100 + seed,
+                            r_seed=200 + seed, y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm,
+                            g_samp=samp, **stage)
+        print('unet_deconv', size, float(y.mean()))
+
+    # ---- deep_linear_gen fwd + bwd
+    for size, seed in ((16, 3), (24, 4)):
+        with quiet:
+            net = networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [], dimension=3)
+        load_sd(net, S.weights_from_seed(S.deep_linear_spec(), seed))
+        x = torch.from_numpy(rand_input(100 + seed, (1, 1, size, size, size))).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, 'deep_linear_%d.npz' % size), seed=seed, x_seed=100 + seed,
+                            r_seed=200 + seed, y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm,
+                            g_samp=samp)
+        print('deep_linear', size, float(y.abs().mean()))
+
+    # ---- PatchGAN 2D (36^2, 108^2, batch of 3 at 36^2) and 3D (36^3)
+    for tag, dim, shape, seed in (('2d_36', 2, (1, 1, 36, 36), 5), ('2d_108', 2, (1, 1, 108, 108), 6),
+                                  ('2d_36_b3', 2, (3, 1, 36, 36), 7), ('3d_36', 3, (1, 1, 36, 36, 36), 8)):
+        with quiet:
+            net = networks.define_D(1, 64, 'basic', 3, 'instance', 'kaiming', 0.02, False, [], dimension=dim)
+        load_sd(net, S.weights_from_seed(S.patchgan_spec(dim), seed))
+        x = torch.from_numpy(rand_input(100 + seed, shape)).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, 'patchgan_%s.npz' % tag), seed=seed, dim=dim, x_seed=100 + seed,
+                            r_seed=200 + seed, shape=np.array(shape), y=y.detach().numpy(), dx=x.grad.numpy(),
+                            g_l2=l2, g_sum=sm, g_samp=samp)
+        print('patchgan', tag, tuple(y.shape))
+
+    # ---- single building blocks with the real widths (reference's own modules)
+    norm = networks.get_norm_layer('instance', 3)
+    for tag, cin, cout, size, seed in (('dc_1_64', 1, 64, 12, 11), ('dc_64_128', 64, 128, 8, 12)):
+        blk = networks.double_conv(cin, cout, 3, 1, 1, norm, 3)
+        spec = [('convolution.0.weight', (cout, cin, 3, 3, 3)), ('convolution.0.bias', (cout,)),
+                ('convolution.3.weight', (cout, cout, 3, 3, 3)), ('convolution.3.bias', (cout,))]
+        load_sd(blk, S.weights_from_seed(spec, seed))
+        x = torch.from_numpy(rand_input(100 + seed, (1, cin, size, size, size))).requires_grad_(True)
+        y = blk(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        np.savez_compressed(os.path.join(OUT, 'block_%s.npz' % tag), seed=seed, cin=cin, cout=cout, size=size,
+                            y=y.detach().numpy(), dx=x.grad.numpy(),
+                            dw0=big_summary(blk.convolution[0].weight.grad.numpy()),
+                            dw3=big_summary(blk.convolution[3].weight.grad.numpy()))
+    # ConvTranspose3d(k2,s2) as built at networks.py:500,503
+    ct = torch.nn.ConvTranspose3d(128, 64, 2, 2)
+    load_sd(ct, S.weights_from_seed([('weight', (128, 64, 2, 2, 2)), ('bias', (64,))], 13))
+    x = torch.from_numpy(rand_input(113, (1, 128, 6, 6, 6))).requires_grad_(True)
+    y = ct(x)
+    r = torch.from_numpy(rand_input(213, y.shape))
+    (y * r).mean().backward()
+    np.savez_compressed(os.path.join(OUT, 'block_convT_128_64.npz'), seed=13, y=y.detach().numpy(),
+                        dx=x.grad.numpy(), dw=big_summary(ct.weight.grad.numpy()), db=ct.bias.grad.numpy())
+    # InstanceNorm3d + ReLU on a tensor with a large mean (stability of the statistics)
+    x = torch.from_numpy(rand_input(114, (1, 16, 20, 20, 20)) * 0.05 + 100.0).requires_grad_(True)
+    y = torch.nn.ReLU()(norm(16)(x))
+    r = torch.from_numpy(rand_input(214, y.shape))
+    (y * r).mean().backward()
+    np.savez_compressed(os.path.join(OUT, 'block_in_relu_bigmean.npz'), y=y.detach().numpy(), dx=x.grad.numpy())
+    print('blocks done')
+
+
+def _opt_train(model_name, extra=None):
+    o = dict(gpu_ids=[], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='golden',
+             preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
+             min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64, ndf=64,
+             netG='unet_deconv', netG_B='deep_linear_gen', netD='basic', n_layers_D=3, norm='instance',
+             no_dropout=True, init_type='kaiming', init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB',
+             model=model_name)
+    o.update(extra or {})
+    return Namespace(**o)
+
+
+APOLLO_NETS = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
+
+
+def apollo_specs():
+    return OrderedDict([('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] +
+                       [(n, S.patchgan_spec(2)) for n in APOLLO_NETS[2:]])
+
+
+def gen_apollo():
+    import contextlib
+    import io
+    from models.axial_to_lateral_gan_apollo_model import AxialToLateralGANApolloModel
+    size, step_seed = 36, 1234
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = AxialToLateralGANApolloModel(_opt_train('axial_to_lateral_gan_apollo'))
+    for i, (name, spec) in enumerate(apollo_specs().items()):
+        load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 40 + i))
+    real = torch.from_numpy(rand_input(321, (1, 1, size, size, size)))
+    losses_per_step, upd = [], {}
+    before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in APOLLO_NETS}
+    np.random.seed(step_seed)
+    draws = []
+    orig_randint = np.random.randint
+
+    def spy(*a, **k):
+        v = orig_randint(*a, **k)
+        draws.append(int(v))
+        return v
+    np.random.randint = spy
+    try:
+        for it in range(2):
+            model.set_input({'A': real, 'A_paths': 'x'})
+            model.optimize_parameters()
+            losses_per_step.append([model.get_current_losses()[k] for k in model.loss_names])
+            if it == 0:
+                fake0 = model.fake.detach().numpy().copy()
+                rec0 = model.rec.detach().numpy().copy()
+    finally:
+        np.random.randint = orig_randint
+    for n in APOLLO_NETS:
+        after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
+        upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
+    np.savez_compressed(os.path.join(OUT, 'apollo_step_36.npz'), size=size, step_seed=step_seed, real_seed=321,
+                        net_seed0=40, loss_names=np.array(model.loss_names), losses=np.array(losses_per_step),
+                        draws=np.array(draws), fake0=fake0, rec0=rec0,
+                        **{'upd_' + n: v for n, v in upd.items()})
+    print('apollo', dict(zip(model.loss_names, losses_per_step[0])))
+    print('draws', draws)
+
+
+def gen_dice():
+    import data as refdata  # noqa: F401  (registers the package the assembler imports)
+    from util.assemble_dice import Assemble_Dice
+    from data.diceImage_dataset import DiceImageDataSet
+    import contextlib
+    import io
+    for tag, L, R, ov, b, vseed in (('100_32_4_4', (100, 100, 100), 32, 4, 4, 9),
+                                    ('ragged_70_50_61', (70, 50, 61), 24, 6, 2, 10),
+                                    ('u8_64_24_4_2', (64, 64, 64), 24, 4, 2, 11)):
+        dtype = np.uint8 if tag.startswith('u8') else np.uint16
+        vol = S.random_volume(vseed, L, dtype)
+        with tempfile.TemporaryDirectory() as d:
+            np.save(os.path.join(d, 'vol.npy'), vol)
+            opt = Namespace(dataroot=d, dataset_mode='diceImage', dice_size=[R, R, R], overlap=ov, border_cut=b,
+                            preprocess='addColorChannel', image_dimension=3,
+                            data_type='uint8' if dtype == np.uint8 else 'uint16', skip_real=False,
+                            histogram_match=False, normalize_intensity=False, max_dataset_size=float('inf'))
+            with contextlib.redirect_stdout(io.StringIO()):
+                ds = DiceImageDataSet(opt)
+                asm_id = Assemble_Dice(opt)
+                asm_pos = Assemble_Dice(opt)
+            n = len(ds)
+            first = ds[0]['A'].numpy()
+            last = ds[n - 1]['A'].numpy()
+            mid = ds[n // 2]['A'].numpy()
+            for i in range(n):
+                a = ds[i]['A'].unsqueeze(0)  # DataLoader batch dim
+                asm_id.addToStack(OrderedDict(real=a, fake=a))
+                # position-dependent fake network: pins overlap averaging + truncating cast
+                asm_pos.addToStack(OrderedDict(real=a, fake=a * 0.5 + (i % 7) * 1e-3))
+            with contextlib.redirect_stdout(io.StringIO()):
+                asm_id.assemble_all()
+                asm_pos.assemble_all()
+            np.savez_compressed(os.path.join(OUT, 'dice_%s.npz' % tag), vol_seed=vseed, shape=np.array(L), roi=R,
+                                overlap=ov, border=b, dtype=str(np.dtype(dtype)), padded=np.array(ds.size()),
+                                steps=np.array(ds.shape()), n=n, first=first, mid=mid, last=last,
+                                sha_identity=sha(asm_id.getDict()['fake']), sha_real=sha(asm_pos.getDict()['real']),
+                                sha_pos=sha(asm_pos.getDict()['fake']),
+                                out_pos=asm_pos.getDict()['fake'] if vol.size < 300000 else np.zeros(0))
+            print('dice', tag, ds.size(), ds.shape(), n,
+                  int(np.abs(asm_id.getDict()['fake'].astype(np.int64) - vol).max()))
+    # closed-form geometry rows (cross-checked against the reference screenshot: 960^3, (9,9,9), 729)
+    from util.util import pad_for_dicing
+    rows = []
+    for L, R, ov in ((900, 120, 15), (256, 64, 8), (100, 32, 4), (148, 64, 8)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            p = pad_for_dicing(np.zeros((L, 1, 1), np.uint8), R, ov).shape[0]
+        rows.append((L, R, ov, p, (p - ov) // (R - ov)))
+    np.savez_compressed(os.path.join(OUT, 'dice_geometry.npz'), rows=np.array(rows))
+    print('geometry', rows)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    networks = ref_modules()
+    which = sys.argv[1:] or ['nets', 'apollo', 'dice']
+    if 'nets' in which:
+        gen_nets(networks)
+    if 'apollo' in which:
+        gen_apollo()
+    if 'dice' in which:
+        gen_dice()

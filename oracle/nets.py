@@ -1,0 +1,105 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the reference's network arithmetic.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.  The
+product path (``neuroclear_amd``) never does; it fails loudly when the HIP library is missing.
+
+What is restated (plain ``torch.nn.functional`` calls on CPU fp32, parameters passed as a state dict with the
+reference's key names):
+
+* ``unet_deconv``   -- ``Unet_deconv.forward``           /root/reference/models/networks.py:512-538
+                       built from ``double_conv`` :413-432, ``triple_conv`` :452-476, ``last_conv`` :434-450
+* ``deep_linear``   -- ``DeepLinearGenerator.forward``   models/networks.py:913-917 (layers :899-911)
+* ``patchgan``      -- ``NLayerDiscriminator.forward``   models/networks.py:1063-1066 (layers :1030-1061)
+* ``lsgan`` / L1    -- ``GANLoss('lsgan')`` :252-319 ; ``torch.nn.L1Loss`` apollo_model.py:128
+
+Parity pin: ``tests/test_oracle_golden.py`` checks every function here against ``tests/golden/*.npz``, which were
+produced by importing the reference itself in the build container (``oracle/gen_golden.py``).
+"""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5  # torch default of nn.InstanceNorm{2,3}d, used unchanged by networks.py:34
+
+
+def _in_act(x, slope):
+    # get_norm_layer('instance'): affine=False, track_running_stats=False (networks.py:33-34) => same in train/eval
+    x = F.instance_norm(x, eps=EPS)
+    return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+
+
+def _conv(x, sd, name, stride=1, padding=0):
+    w = sd[name + '.weight']
+    b = sd.get(name + '.bias')
+    fn = F.conv3d if w.dim() == 5 else F.conv2d
+    return fn(x, w, b, stride=stride, padding=padding)
+
+
+def _convT(x, sd, name):
+    w = sd[name + '.weight']
+    fn = F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d
+    return fn(x, w, sd[name + '.bias'], stride=2)
+
+
+def _block(x, sd, prefix, idxs):
+    for i in idxs:
+        x = _in_act(_conv(x, sd, '%s.convolution.%d' % (prefix, i), padding=1), 0.0)
+    return x
+
+
+def unet_deconv(sd, x, taps=None):
+    """networks.py:512-538.  ``taps`` (optional dict) receives the five stage outputs named as in the reference."""
+    pool = F.max_pool3d if x.dim() == 5 else F.max_pool2d
+    conv1 = _block(x, sd, 'double_conv1', (0, 3))
+    conv2 = _block(pool(conv1, 2), sd, 'double_conv2', (0, 3))
+    bottom = _block(pool(conv2, 2), sd, 'bottom_layer', (0, 3, 6))
+    cat2 = torch.cat([conv2, _convT(bottom, sd, 't_conv2')], 1)
+    ex2 = _block(cat2, sd, 'ex_double_conv2', (0, 3))
+    cat1 = torch.cat([conv1, _convT(ex2, sd, 't_conv1')], 1)
+    ex1 = _block(cat1, sd, 'ex_conv1_1', (0,))
+    y = _conv(_conv(ex1, sd, 'one_by_one'), sd, 'one_by_one_2')
+    if taps is not None:
+        taps.update(conv1=conv1, conv2=conv2, conv_bottom=bottom, ex_conv2=ex2, ex_conv1=ex1)
+    return torch.sigmoid(y)
+
+
+def deep_linear(sd, x):
+    """networks.py:913-917: bias-free linear chain 7^3 -> 5^3 -> 3^3 -> 1x1 -> 1x1 -> 1x1, each layer zero-padding
+    its own input (:899-902)."""
+    x = _conv(x, sd, 'first_layer', padding=3)
+    x = _conv(x, sd, 'feature_block.0', padding=2)
+    x = _conv(x, sd, 'feature_block.1', padding=1)
+    x = _conv(x, sd, 'feature_block.2')
+    x = _conv(x, sd, 'feature_block.3')
+    return _conv(x, sd, 'final_layer')
+
+
+def patchgan(sd, x, n_layers=3):
+    """networks.py:1030-1066 with instance norm: conv(s2)+LReLU, (conv(s2)+IN+LReLU)x(n_layers-1),
+    conv(s1)+IN+LReLU, conv(s1) head.  kernel 4, padding 1 everywhere."""
+    x = F.leaky_relu(_conv(x, sd, 'model.0', stride=2, padding=1), 0.2)
+    idx = 2
+    for _ in range(1, n_layers):
+        x = _in_act(_conv(x, sd, 'model.%d' % idx, stride=2, padding=1), 0.2)
+        idx += 3
+    x = _in_act(_conv(x, sd, 'model.%d' % idx, stride=1, padding=1), 0.2)
+    idx += 3
+    return _conv(x, sd, 'model.%d' % idx, stride=1, padding=1)
+
+
+def lsgan(pred, target_is_real):
+    """GANLoss('lsgan').__call__ (networks.py:299-319): MSE against a constant 1.0 / 0.0 expanded to pred's shape."""
+    t = torch.full_like(pred, 1.0 if target_is_real else 0.0)
+    return F.mse_loss(pred, t)
+
+
+def l1(a, b):
+    return F.l1_loss(a, b)
+
+
+def to_torch(sd_np, requires_grad=False):
+    out = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(v).clone()
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out
