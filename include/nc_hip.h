@@ -1,0 +1,126 @@
+/*
+ * nc_hip.h -- C ABI of libnc_hip.so: the MI355X (gfx950) hot path of Neuroclear.
+ *
+ * The reference (peterhpark/neuroclear) has NO native / FFI interface: its hot path is torch.nn modules executed by
+ * cuDNN/ATen.  Each entry point below therefore cites the reference *call site* it replaces
+ * (paths relative to the reference checkout), and INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors on the Python side), dense, fp32 unless
+ *    the name says otherwise; activations are NCDHW (2-D data: D = 1, kd = 1);
+ *  - `stream` is a hipStream_t passed as void*; nothing here synchronises, allocates or frees (graph-capture safe);
+ *  - scratch memory comes from the caller: `ws` / `ws_bytes`; query the size with the matching *_ws_bytes();
+ *  - return value: 0 = ok, negative = NC_ERR_*; nc_last_error() gives a thread-local message.
+ */
+#ifndef NC_HIP_H
+#define NC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NC_OK 0
+#define NC_ERR_SHAPE (-1)  /* unsupported / inconsistent dimensions                       */
+#define NC_ERR_WS (-2)     /* workspace missing or too small                              */
+#define NC_ERR_HIP (-3)    /* a HIP runtime call failed (message has hipGetErrorString)   */
+#define NC_ERR_ARG (-4)    /* null pointer / bad enum                                     */
+
+const char* nc_last_error(void);
+int nc_version(void);
+/* Which implementation nc_conv_* would pick for a shape: 0 = direct (VALU), 1 = MFMA implicit GEMM. */
+int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
+int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
+/* Force the direct path everywhere (tests cross-check MFMA vs direct on the GPU). 0 = auto (default), 1 = force. */
+void nc_set_force_direct(int on);
+
+/* ---- Convolution: nn.Conv3d / nn.Conv2d (models/networks.py:361-369; used at :420-425,:442,:460-469 (U-Net 3^3),
+ *      :899-911 (deep_linear 7^3/5^3/3^3/1^3), :507-508 (1x1 tail), :1030-1057 (PatchGAN 4x4 s2/s1)).
+ *      x[N,C,D,H,W], w[K,C,kd,kh,kw], bias[K] or NULL, y[N,K,Do,Ho,Wo]; Do = (D+2p-kd)/s+1 (p,s apply to depth only
+ *      when kd > 1).  dgrad / wgrad are the autograd backward of the same call (loss.backward(), apollo:283).      */
+size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
+int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
+                int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd,
+                  int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */, int N, int C, int D, int H,
+                  int W, int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- ConvTranspose3d(k=2, s=2) (networks.py:500,503): x[N,C,D,H,W], w[C,K,2,2,2], bias[K], y[N,K,2D,2H,2W].   */
+size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K);
+int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
+                      int K, void* stream);
+int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
+                        void* stream);
+int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W,
+                        int K, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- InstanceNorm{2,3}d(affine=False, track_running_stats=False) + ReLU / LeakyReLU(slope)
+ *      (networks.py:33-34 with :422-423 (slope 0) and :1042-1046 (slope 0.2)).  One instance = one (n, c) plane of S
+ *      elements; biased variance, eps inside the sqrt.  `stats` computes mean / rstd (fp64 accumulation), `fwd`
+ *      applies y = act((x-mean)*rstd), `bwd` is the backward of the pair given the pre-norm x.                   */
+size_t nc_instnorm_ws_bytes(int NC, long S);
+int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                      void* stream);
+int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, float slope, float* y, int NC, long S,
+                        void* stream);
+int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                        int NC, long S, void* ws, size_t ws_bytes, void* stream);
+/* LeakyReLU alone (PatchGAN first block, networks.py:1030) */
+int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream);
+int nc_leaky_relu_bwd(const float* dy, const float* x, float slope, float* dx, long n, void* stream);
+
+/* ---- MaxPool3d(2) (networks.py:491,494): floor mode; first maximum wins on ties (scan order d,h,w).             */
+int nc_maxpool2_fwd(const float* x, float* y, int NC, int D, int H, int W, void* stream);
+int nc_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int D, int H, int W, void* stream);
+
+/* ---- Sigmoid (networks.py:510,536) */
+int nc_sigmoid_fwd(const float* x, float* y, long n, void* stream);
+int nc_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, void* stream);
+
+/* ---- Volume.get_slice / get_projection (apollo_model.py:328-351): vol[N,C,D,H,W], axis in {0,1,2} = (D,H,W).
+ *      slice: out = vol[..., index, ...]; mip: out = max over [start, start+depth) along axis (+ int32 argmax).
+ *      The *_bwd kernels write the FULL dvol (zeros elsewhere).                                                   */
+int nc_slice_fwd(const float* vol, float* out, int NC, int D, int H, int W, int axis, int index, void* stream);
+int nc_slice_bwd(const float* dout, float* dvol, int NC, int D, int H, int W, int axis, int index, void* stream);
+int nc_mip_fwd(const float* vol, float* out, int32_t* arg, int NC, int D, int H, int W, int axis, int start, int depth,
+               void* stream);
+int nc_mip_bwd(const float* dout, const int32_t* arg, float* dvol, int NC, int D, int H, int W, int axis,
+               void* stream);
+
+/* ---- GANLoss('lsgan') = MSELoss against a constant (networks.py:276,299-313) and L1Loss (apollo:128,279).
+ *      out[0] = mean; backward scales by the device scalar gscale[0] (autograd's incoming gradient).              */
+size_t nc_loss_ws_bytes(long n);
+int nc_mse_const_fwd(const float* pred, long n, float target, float* out, void* ws, size_t ws_bytes, void* stream);
+int nc_mse_const_bwd(const float* pred, long n, float target, const float* gscale, float* dpred, void* stream);
+int nc_l1_fwd(const float* a, const float* b, long n, float* out, void* ws, size_t ws_bytes, void* stream);
+int nc_l1_bwd(const float* a, const float* b, long n, const float* gscale, float* da, void* stream);
+
+/* ---- torch.optim.Adam step over one flat parameter buffer (apollo:131-136, step at :295,:307).                  */
+int nc_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 int step, void* stream);
+
+/* ---- Dice / assemble (data/diceImage_dataset.py:95-120 + base_dataset.py:134-143; util/assemble_dice.py:130-213).
+ *      vol: ORIGINAL (unpadded) uint16 / uint8 volume [L0,L1,L2] resident in HBM.  cut_cube writes cube `index` of
+ *      edge E = roi + 2*border, float32 in [0,1]: zero dicing pad (util/util.py:196-215) then reflect border.
+ *      scatter_add: acc[P0,P1,P2] += cube[border:-border]^3 / 8 at the cube's origin; finalize: (acc/cnt)*8*scale,
+ *      truncating cast, crop to the original size; cnt is computed analytically from the grid.                    */
+int nc_dice_cut_cube(const void* vol, int is_u16, int L0, int L1, int L2, int roi, int overlap, int border, int index,
+                     float* cube, void* stream);
+int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P2, int roi, int overlap, int border,
+                            int index, void* stream);
+int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2,
+                         int roi, int overlap, void* stream);
+
+/* ---- Whole-network forward of Unet_deconv (networks.py:512-538; called from TestModel.forward test_model.py:60-62):
+ *      params = the 28 tensors in state-dict order, packed back to back (see neuroclear_amd.models.networks).       */
+size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2);
+int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int S0, int S1, int S2, void* ws,
+                       size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NC_HIP_H */

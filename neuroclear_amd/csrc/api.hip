@@ -1,0 +1,201 @@
+// C-ABI glue: error reporting, convolution dispatch (MFMA implicit GEMM vs direct), and the whole-network forward of
+// Unet_deconv used by diced inference (reference models/networks.py:512-538 via models/test_model.py:60-62).
+#include <cstring>
+
+#include "common.hpp"
+
+namespace nc {
+
+static thread_local char g_err[512] = "";
+int g_force_direct = 0;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace nc
+
+using namespace nc;
+
+extern "C" {
+
+const char* nc_last_error(void) { return g_err; }
+int nc_version(void) { return 100; }
+void nc_set_force_direct(int on) { g_force_direct = on; }
+
+int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
+  ConvDims d;
+  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
+  return (!g_force_direct && mfma_fwd_supported(d)) ? 1 : 0;
+}
+int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
+  ConvDims d;
+  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
+  return (!g_force_direct && mfma_wgrad_supported(d)) ? 1 : 0;
+}
+
+size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
+  ConvDims d;
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return 0;
+  size_t b = mfma_ws_bytes(d);
+  return (b + 255) & ~(size_t)255;
+}
+
+static int conv_args(const char* what, ConvDims& d, const void* a, const void* b, const void* c, int N, int C, int D,
+                     int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
+  if (!a || !b || !c) { set_error("%s: null pointer", what); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad) || N > 65535) {
+    set_error("%s: bad shape N=%d C=%d D=%d H=%d W=%d K=%d k=(%d,%d,%d) s=%d p=%d", what, N, C, D, H, W, K, kd, kh, kw,
+              stride, pad);
+    return NC_ERR_SHAPE;
+  }
+  return NC_OK;
+}
+
+int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K,
+                int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = conv_args("conv_fwd", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
+  return conv_fwd_direct(x, w, bias, y, d, s);
+}
+
+int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd, int kh,
+                  int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
+  return conv_dgrad_direct(dy, w, dx, d, s);
+}
+
+int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W, int K,
+                  int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = conv_args("conv_wgrad", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  int e;
+  if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
+  else e = conv_wgrad_direct(x, dy, dw, d, s);
+  if (e) return e;
+  if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, s);
+  return NC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Whole-network forward of Unet_deconv.  Parameter blob = state-dict order, fp32, back to back.
+namespace {
+struct UnetOff {
+  size_t w[14], b[14];  // 10 convs (0..9), t_conv2 (10), t_conv1 (11), one_by_one (12), one_by_one_2 (13)
+  size_t total;
+};
+UnetOff unet_offsets() {
+  // order: dc1.0 dc1.3 dc2.0 dc2.3 bot.0 bot.3 bot.6 t_conv2 ex2.0 ex2.3 t_conv1 ex1.0 1x1 1x1_2
+  struct L { int id; size_t wn, bn; };
+  const L order[14] = {{0, 64 * 1 * 27, 64},       {1, 64 * 64 * 27, 64},     {2, 128 * 64 * 27, 128},
+                       {3, 128 * 128 * 27, 128},   {4, 256 * 128 * 27, 256},  {5, 256 * 256 * 27, 256},
+                       {6, 256 * 256 * 27, 256},   {10, 256 * 128 * 8, 128},  {7, 128 * 256 * 27, 128},
+                       {8, 128 * 128 * 27, 128},   {11, 128 * 64 * 8, 64},    {9, 64 * 128 * 27, 64},
+                       {12, 64, 1},                {13, 1, 1}};
+  UnetOff o{};
+  size_t off = 0;
+  for (const L& l : order) {
+    o.w[l.id] = off; off += l.wn;
+    o.b[l.id] = off; off += l.bn;
+  }
+  o.total = off;
+  return o;
+}
+struct UnetWs {
+  size_t raw, cat1, a1, p1, cat2, a2, a2b, p2, b1, b2, t1, t2, mean, rstd, in_ws, conv_ws, total;
+  size_t in_ws_bytes, conv_ws_bytes;
+};
+UnetWs unet_ws(int S0, int S1, int S2) {
+  const size_t S = (size_t)S0 * S1 * S2, Sh = S / 8, Sq = S / 64;
+  UnetWs u{};
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t r = off; off += (n + 63) & ~(size_t)63; return r; };
+  u.raw = take(64 * S); u.cat1 = take(128 * S); u.a1 = take(64 * S); u.p1 = take(64 * Sh); u.cat2 = take(256 * Sh);
+  u.a2 = take(128 * Sh); u.a2b = take(128 * Sh); u.p2 = take(128 * Sq); u.b1 = take(256 * Sq); u.b2 = take(256 * Sq);
+  u.t1 = take(S); u.t2 = take(S); u.mean = take(256); u.rstd = take(256);
+  u.in_ws_bytes = nc_instnorm_ws_bytes(256, (long)S);
+  u.in_ws = take(u.in_ws_bytes / 4);
+  size_t cw = 0;
+  auto upd = [&](int C, int D, int H, int W, int K) {
+    size_t b = nc_conv_ws_bytes(1, C, D, H, W, K, 3, 3, 3, 1, 1);
+    if (b > cw) cw = b;
+  };
+  upd(64, S0, S1, S2, 64); upd(128, S0, S1, S2, 64);
+  upd(64, S0 / 2, S1 / 2, S2 / 2, 128); upd(128, S0 / 2, S1 / 2, S2 / 2, 128); upd(256, S0 / 2, S1 / 2, S2 / 2, 128);
+  upd(128, S0 / 4, S1 / 4, S2 / 4, 256); upd(256, S0 / 4, S1 / 4, S2 / 4, 256);
+  u.conv_ws_bytes = cw;
+  u.conv_ws = take(cw / 4 + 64);
+  u.total = off;
+  return u;
+}
+}  // namespace
+
+size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2) {
+  (void)N;
+  if (S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return 0;
+  return unet_ws(S0, S1, S2).total * sizeof(float);
+}
+
+#define NC_TRY(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
+
+int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int S0, int S1, int S2, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!params || !x || !y) { set_error("unet_deconv_fwd: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) {
+    set_error("unet_deconv_fwd: every edge must be a positive multiple of 4 (got %d,%d,%d): MaxPool3d floors and the "
+              "skip concat would not line up (reference networks.py:526,531)", S0, S1, S2);
+    return NC_ERR_SHAPE;
+  }
+  const UnetWs u = unet_ws(S0, S1, S2);
+  if (!ws || ws_bytes < u.total * sizeof(float)) { set_error("unet_deconv_fwd: workspace too small"); return NC_ERR_WS; }
+  const UnetOff o = unet_offsets();
+  float* W = (float*)ws;
+  const float* P = params;
+  const long S = (long)S0 * S1 * S2, Sh = S / 8, Sq = S / 64;
+  const int h0 = S0 / 2, h1 = S1 / 2, h2 = S2 / 2, q0 = S0 / 4, q1 = S1 / 4, q2 = S2 / 4;
+  void* cws = W + u.conv_ws;
+  void* iws = W + u.in_ws;
+  float *mean = W + u.mean, *rstd = W + u.rstd;
+  // conv (3^3, pad 1) + InstanceNorm + ReLU: in -> raw -> out
+  auto block = [&](int id, const float* in, float* out, int C, int K, int D, int H, int Wd) -> int {
+    const long Sl = (long)D * H * Wd;
+    NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes,
+                       stream));
+    NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
+    return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+  };
+  for (int n = 0; n < N; ++n) {
+    const float* xn = x + (long)n * S;
+    float* yn = y + (long)n * S;
+    NC_TRY(block(0, xn, W + u.a1, 1, 64, S0, S1, S2));
+    NC_TRY(block(1, W + u.a1, W + u.cat1, 64, 64, S0, S1, S2));
+    NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
+    NC_TRY(block(2, W + u.p1, W + u.a2, 64, 128, h0, h1, h2));
+    NC_TRY(block(3, W + u.a2, W + u.cat2, 128, 128, h0, h1, h2));
+    NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
+    NC_TRY(block(4, W + u.p2, W + u.b1, 128, 256, q0, q1, q2));
+    NC_TRY(block(5, W + u.b1, W + u.b2, 256, 256, q0, q1, q2));
+    NC_TRY(block(6, W + u.b2, W + u.b1, 256, 256, q0, q1, q2));
+    NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
+    NC_TRY(block(7, W + u.cat2, W + u.a2, 256, 128, h0, h1, h2));
+    NC_TRY(block(8, W + u.a2, W + u.a2b, 128, 128, h0, h1, h2));
+    NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
+    NC_TRY(block(9, W + u.cat1, W + u.a1, 128, 64, S0, S1, S2));
+    NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, nullptr, 0, stream));
+    NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, nullptr, 0, stream));
+    NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S, stream));
+  }
+  (void)Sq;
+  return NC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Shared host-side helpers for libnc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/nc_hip.h"
+
+namespace nc {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return NC_ERR_HIP;
+  }
+  return NC_OK;
+}
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// Conv geometry shared by the direct and MFMA paths.
+struct ConvDims {
+  int N, C, D, H, W, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, Do, Ho, Wo;
+};
+
+inline bool make_dims(ConvDims& d, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride,
+                      int pad) {
+  d.N = N; d.C = C; d.D = D; d.H = H; d.W = W; d.K = K; d.kd = kd; d.kh = kh; d.kw = kw;
+  d.sd = kd > 1 ? stride : 1; d.sh = stride; d.sw = stride;
+  d.pd = kd > 1 ? pad : 0; d.ph = pad; d.pw = pad;
+  if (N < 1 || C < 1 || K < 1 || D < 1 || H < 1 || W < 1 || kd < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0)
+    return false;
+  d.Do = (D + 2 * d.pd - kd) / d.sd + 1;
+  d.Ho = (H + 2 * d.ph - kh) / d.sh + 1;
+  d.Wo = (W + 2 * d.pw - kw) / d.sw + 1;
+  return d.Do >= 1 && d.Ho >= 1 && d.Wo >= 1 && (D + 2 * d.pd >= kd) && (H + 2 * d.ph >= kh) && (W + 2 * d.pw >= kw);
+}
+
+// ---- direct (VALU) kernels, conv_direct.hip
+int conv_fwd_direct(const float* x, const float* w, const float* b, float* y, const ConvDims& d, hipStream_t s);
+int conv_dgrad_direct(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+int conv_wgrad_direct(const float* x, const float* dy, float* dw, const ConvDims& d, hipStream_t s);
+int bias_grad(const float* dy, float* db, int N, int K, long S, hipStream_t s);
+
+// ---- MFMA implicit-GEMM kernels, conv_mfma.hip
+bool mfma_fwd_supported(const ConvDims& d);
+bool mfma_dgrad_supported(const ConvDims& d);
+bool mfma_wgrad_supported(const ConvDims& d);
+size_t mfma_ws_bytes(const ConvDims& d);
+int conv_fwd_mfma(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                  hipStream_t s);
+int conv_dgrad_mfma(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s);
+int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s);
+
+extern int g_force_direct;
+
+}  // namespace nc

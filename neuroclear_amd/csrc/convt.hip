@@ -1,0 +1,209 @@
+// ConvTranspose3d(kernel 2, stride 2) forward / dgrad / wgrad (reference models/networks.py:500,503: t_conv2 256->128,
+// t_conv1 128->64).  With k == s the op is a per-voxel matrix product: every output voxel depends on exactly one
+// input voxel, out[k, 2z+a, 2y+b, 2x+c] = bias[k] + sum_c x[c, z, y, x] * w[c, k, a, b, c'].
+// One lane owns one INPUT voxel and KT output channels x 8 taps of accumulators; weights are wave-uniform (scalar
+// cache).  1.9 % of the U-Net's FLOPs -- kept on the VALU for round 1.
+#include "common.hpp"
+
+namespace nc {
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int C, int D,
+                                                   int H, int W, int K) {
+  const long S = (long)D * H * W;
+  const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * KT, n = blockIdx.z;
+  const bool valid = pos < S;
+  const long p = valid ? pos : 0;
+  const int ix = (int)(p % W), iy = (int)((p / W) % H), iz = (int)(p / ((long)W * H));
+  float acc[KT][8];
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[j][t] = bias ? bias[k0 + j] : 0.f;
+  const float* xn = x + (long)n * C * S + p;
+  for (int c = 0; c < C; ++c) {
+    const float xv = xn[(long)c * S];
+    const float* wc = w + ((long)c * K + k0) * 8;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[j][t] = fmaf(xv, wc[j * 8 + t], acc[j][t]);
+  }
+  if (!valid) return;
+  const int H2 = 2 * H, W2 = 2 * W;
+  const long S2 = 8 * S;
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    float* yk = y + ((long)n * K + k0 + j) * S2;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float2* dst = reinterpret_cast<float2*>(yk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
+        *dst = make_float2(acc[j][(a * 2 + b) * 2], acc[j][(a * 2 + b) * 2 + 1]);
+      }
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void k_convT_dgrad(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     float* __restrict__ dx, int C, int D, int H, int W, int K) {
+  const long S = (long)D * H * W;
+  const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * CT, n = blockIdx.z;
+  const bool valid = pos < S;
+  const long p = valid ? pos : 0;
+  const int ix = (int)(p % W), iy = (int)((p / W) % H), iz = (int)(p / ((long)W * H));
+  const int H2 = 2 * H, W2 = 2 * W;
+  const long S2 = 8 * S;
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float* dyk = dy + ((long)n * K + k) * S2;
+    float g[8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float2 v = *reinterpret_cast<const float2*>(dyk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
+        g[(a * 2 + b) * 2] = v.x;
+        g[(a * 2 + b) * 2 + 1] = v.y;
+      }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const float* wc = w + ((long)(c0 + j) * K + k) * 8;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[j] = fmaf(g[t], wc[t], acc[j]);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) dx[((long)n * C + c0 + j) * S + pos] = acc[j];
+  }
+}
+
+// dw[c][k][t] = sum_{n,pos} x[n][c][pos] * dy[n][k][2pos+t].  Workgroup = (CB input channels) x (KB output channels);
+// lanes stride over positions.  CB*KB*8 accumulators per lane.
+template <int CB, int KB>
+__global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     float* __restrict__ dw, int N, int C, int D, int H, int W,
+                                                     int K) {
+  const int c0 = blockIdx.x * CB, k0 = blockIdx.y * KB;
+  const long S = (long)D * H * W, S2 = 8 * S;
+  const int H2 = 2 * H, W2 = 2 * W;
+  float acc[CB][KB][8];
+#pragma unroll
+  for (int i = 0; i < CB; ++i)
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[i][j][t] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    for (long pos = threadIdx.x; pos < S; pos += 256) {
+      const int ix = (int)(pos % W), iy = (int)((pos / W) % H), iz = (int)(pos / ((long)W * H));
+      float xv[CB];
+#pragma unroll
+      for (int i = 0; i < CB; ++i) xv[i] = x[((long)n * C + c0 + i) * S + pos];
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        const float* dyk = dy + ((long)n * K + k0 + j) * S2;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float2 v =
+                *reinterpret_cast<const float2*>(dyk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+              acc[i][j][(a * 2 + b) * 2] = fmaf(xv[i], v.x, acc[i][j][(a * 2 + b) * 2]);
+              acc[i][j][(a * 2 + b) * 2 + 1] = fmaf(xv[i], v.y, acc[i][j][(a * 2 + b) * 2 + 1]);
+            }
+          }
+      }
+    }
+  }
+  __shared__ float red[4][CB * KB * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < CB; ++i)
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v = acc[i][j][t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0) red[wv][(i * KB + j) * 8 + t] = v;
+      }
+  __syncthreads();
+  if (threadIdx.x < CB * KB * 8) {
+    const int e = threadIdx.x, t = e & 7, j = (e >> 3) % KB, i = (e >> 3) / KB;
+    dw[((long)(c0 + i) * K + k0 + j) * 8 + t] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+}
+
+static int pick(int n, int a, int b, int c) { return n % a == 0 ? a : n % b == 0 ? b : c; }
+
+}  // namespace nc
+
+using namespace nc;
+
+extern "C" {
+
+size_t nc_convT_ws_bytes(int, int, int, int, int, int) { return 0; }
+
+static int convT_check(const char* what, int N, int C, int D, int H, int W, int K) {
+  if (N < 1 || C < 1 || D < 1 || H < 1 || W < 1 || K < 1 || K > 65535 * 4 || N > 65535) {
+    set_error("%s: bad shape N=%d C=%d D=%d H=%d W=%d K=%d", what, N, C, D, H, W, K);
+    return NC_ERR_SHAPE;
+  }
+  return NC_OK;
+}
+
+int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
+                      int K, void* stream) {
+  if (!x || !w || !y) { set_error("convT_fwd: null pointer"); return NC_ERR_ARG; }
+  if (int e = convT_check("convT_fwd", N, C, D, H, W, K)) return e;
+  const long S = (long)D * H * W;
+  const int kt = pick(K, 4, 2, 1);
+  dim3 grid((unsigned)cdiv(S, 256), K / kt, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (kt == 4) hipLaunchKernelGGL(k_convT_fwd<4>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
+  else if (kt == 2) hipLaunchKernelGGL(k_convT_fwd<2>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
+  else hipLaunchKernelGGL(k_convT_fwd<1>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
+  return check_launch("convT_fwd");
+}
+
+int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
+                        void* stream) {
+  if (!dy || !w || !dx) { set_error("convT_dgrad: null pointer"); return NC_ERR_ARG; }
+  if (int e = convT_check("convT_dgrad", N, C, D, H, W, K)) return e;
+  const long S = (long)D * H * W;
+  const int ct = pick(C, 8, 4, 1);
+  dim3 grid((unsigned)cdiv(S, 256), C / ct, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (ct == 8) hipLaunchKernelGGL(k_convT_dgrad<8>, grid, dim3(256), 0, s, dy, w, dx, C, D, H, W, K);
+  else if (ct == 4) hipLaunchKernelGGL(k_convT_dgrad<4>, grid, dim3(256), 0, s, dy, w, dx, C, D, H, W, K);
+  else hipLaunchKernelGGL(k_convT_dgrad<1>, grid, dim3(256), 0, s, dy, w, dx, C, D, H, W, K);
+  return check_launch("convT_dgrad");
+}
+
+int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W,
+                        int K, void* ws, size_t ws_bytes, void* stream) {
+  (void)ws; (void)ws_bytes;
+  if (!x || !dy || !dw) { set_error("convT_wgrad: null pointer"); return NC_ERR_ARG; }
+  if (int e = convT_check("convT_wgrad", N, C, D, H, W, K)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 4 == 0 && K % 4 == 0) {
+    hipLaunchKernelGGL((k_convT_wgrad<4, 4>), dim3(C / 4, K / 4), dim3(256), 0, s, x, dy, dw, N, C, D, H, W, K);
+  } else {
+    hipLaunchKernelGGL((k_convT_wgrad<1, 1>), dim3(C, K), dim3(256), 0, s, x, dy, dw, N, C, D, H, W, K);
+  }
+  if (int e = check_launch("convT_wgrad")) return e;
+  if (dbias) return bias_grad(dy, dbias, N, K, 8L * D * H * W, s);
+  return NC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Dice / assemble on the device (reference data/diceImage_dataset.py:95-120, data/base_dataset.py:134-143,
+// util/util.py:196-215, util/assemble_dice.py:130-213).  Integer / index work plus three fp32 roundings whose order
+// is kept exactly as numpy does them, so the result is bit-identical to the reference on one GPU:
+//   cube   = float32( double(v) / 65535.0 )                 (base_dataset.py:134-143, :291-295)
+//   acc   += cube / 8   in cube-index order                  (assemble_dice.py:167-173)
+//   out    = uint16( ((acc / cnt) * 8) * 65535 )  truncating (assemble_dice.py:183, :202-207)
+// The volume stays resident in HBM as uint16/uint8; the zero dicing pad and the reflect border are index arithmetic.
+#include "common.hpp"
+
+namespace nc {
+
+__device__ __forceinline__ int reflect_idx(int q, int P) {  // np.pad(mode='reflect') for |overhang| < P
+  if (q < 0) q = -q;
+  if (q >= P) q = 2 * (P - 1) - q;
+  return q;
+}
+
+struct DiceGeom {
+  int L0, L1, L2, P0, P1, P2, n0, n1, n2, roi, overlap, border, step;
+};
+
+__host__ __device__ inline int pad_len(int L, int roi, int overlap) {
+  const int step = roi - overlap;
+  return step * ((L + overlap) / step) + roi;  // L + pad
+}
+
+template <typename T>
+__global__ void k_cut_cube(const T* __restrict__ vol, DiceGeom g, int z0, int y0, int x0, double den,
+                           float* __restrict__ cube) {
+  const int E = g.roi + 2 * g.border;
+  const long total = (long)E * E * E;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cx = (int)(i % E), cy = (int)((i / E) % E), cz = (int)(i / ((long)E * E));
+    const int qz = reflect_idx(z0 + cz - g.border, g.P0);
+    const int qy = reflect_idx(y0 + cy - g.border, g.P1);
+    const int qx = reflect_idx(x0 + cx - g.border, g.P2);
+    float v = 0.f;
+    if (qz < g.L0 && qy < g.L1 && qx < g.L2) v = (float)((double)vol[((long)qz * g.L1 + qy) * g.L2 + qx] / den);
+    cube[i] = v;
+  }
+}
+
+__global__ void k_scatter_add(const float* __restrict__ cube, float* __restrict__ acc, DiceGeom g, int z0, int y0,
+                              int x0) {
+  const int R = g.roi, E = g.roi + 2 * g.border;
+  const long total = (long)R * R * R;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % R), y = (int)((i / R) % R), z = (int)(i / ((long)R * R));
+    const float c = cube[((long)(z + g.border) * E + (y + g.border)) * E + x + g.border];
+    float* a = acc + ((long)(z0 + z) * g.P1 + (y0 + y)) * g.P2 + (x0 + x);
+    *a = *a + c / 8;
+  }
+}
+
+__device__ __forceinline__ int cover_count(int p, int n, int step, int roi) {
+  // number of cube indices i in [0, n) with i*step <= p < i*step + roi
+  int hi = p / step;
+  if (hi > n - 1) hi = n - 1;
+  int lo = p - roi + 1;
+  lo = lo <= 0 ? 0 : (lo + step - 1) / step;
+  return hi - lo + 1;
+}
+
+template <typename T>
+__global__ void k_finalize(const float* __restrict__ acc, T* __restrict__ out, DiceGeom g, float scale) {
+  const long total = (long)g.L0 * g.L1 * g.L2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % g.L2), y = (int)((i / g.L2) % g.L1), z = (int)(i / ((long)g.L2 * g.L1));
+    float v = acc[((long)z * g.P1 + y) * g.P2 + x];
+    if (g.overlap > 0) {
+      const float cnt = (float)(cover_count(z, g.n0, g.step, g.roi) * cover_count(y, g.n1, g.step, g.roi) *
+                                cover_count(x, g.n2, g.step, g.roi));
+      v = (v / cnt) * 8;
+    }
+    v = v * scale;
+    out[i] = (T)v;  // truncation toward zero == ndarray.astype for in-range values
+  }
+}
+
+static bool make_geom(DiceGeom& g, int L0, int L1, int L2, int roi, int overlap, int border) {
+  if (L0 < 1 || L1 < 1 || L2 < 1 || roi < 1 || overlap < 0 || overlap >= roi || border < 1) return false;
+  g.L0 = L0; g.L1 = L1; g.L2 = L2; g.roi = roi; g.overlap = overlap; g.border = border; g.step = roi - overlap;
+  g.P0 = pad_len(L0, roi, overlap); g.P1 = pad_len(L1, roi, overlap); g.P2 = pad_len(L2, roi, overlap);
+  g.n0 = (g.P0 - overlap) / g.step; g.n1 = (g.P1 - overlap) / g.step; g.n2 = (g.P2 - overlap) / g.step;
+  // np.pad(mode='reflect') with border >= padded length is multi-fold; the reference never gets there
+  return border < g.P0 && border < g.P1 && border < g.P2;
+}
+
+static unsigned flat_grid(long n) {
+  long b = cdiv(n, 256);
+  if (b > 8192) b = 8192;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace nc
+
+using namespace nc;
+
+extern "C" {
+
+int nc_dice_cut_cube(const void* vol, int is_u16, int L0, int L1, int L2, int roi, int overlap, int border, int index,
+                     float* cube, void* stream) {
+  if (!vol || !cube) { set_error("dice_cut_cube: null pointer"); return NC_ERR_ARG; }
+  DiceGeom g;
+  if (!make_geom(g, L0, L1, L2, roi, overlap, border)) { set_error("dice_cut_cube: bad geometry (border_cut must be >= 1)"); return NC_ERR_SHAPE; }
+  const long n = (long)g.n0 * g.n1 * g.n2;
+  if (index < 0 || index >= n) { set_error("dice_cut_cube: cube index %d out of [0,%ld)", index, n); return NC_ERR_SHAPE; }
+  const int xi = index % g.n2, yi = (index % (g.n2 * g.n1)) / g.n2, zi = index / (g.n2 * g.n1);
+  const long E = roi + 2 * border;
+  hipStream_t s = (hipStream_t)stream;
+  if (is_u16)
+    hipLaunchKernelGGL(k_cut_cube<uint16_t>, dim3(flat_grid(E * E * E)), dim3(256), 0, s, (const uint16_t*)vol, g,
+                       zi * g.step, yi * g.step, xi * g.step, 65535.0, cube);
+  else
+    hipLaunchKernelGGL(k_cut_cube<uint8_t>, dim3(flat_grid(E * E * E)), dim3(256), 0, s, (const uint8_t*)vol, g,
+                       zi * g.step, yi * g.step, xi * g.step, 255.0, cube);
+  return check_launch("dice_cut_cube");
+}
+
+int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P2, int roi, int overlap, int border,
+                            int index, void* stream) {
+  if (!cube || !acc) { set_error("assemble_scatter_add: null pointer"); return NC_ERR_ARG; }
+  if (overlap < 1) { set_error("assemble_scatter_add: overlap must be >= 1 (the reference assembler adds nothing for overlap 0, util/assemble_dice.py:170)"); return NC_ERR_SHAPE; }
+  if (roi < 1 || overlap >= roi || border < 1) { set_error("assemble_scatter_add: bad geometry (border_cut must be >= 1)"); return NC_ERR_SHAPE; }
+  DiceGeom g{};
+  g.roi = roi; g.overlap = overlap; g.border = border; g.step = roi - overlap;
+  g.P0 = P0; g.P1 = P1; g.P2 = P2;
+  g.n0 = (P0 - overlap) / g.step; g.n1 = (P1 - overlap) / g.step; g.n2 = (P2 - overlap) / g.step;
+  const long n = (long)g.n0 * g.n1 * g.n2;
+  if (g.n0 < 1 || g.n1 < 1 || g.n2 < 1 || index < 0 || index >= n) { set_error("assemble_scatter_add: cube index out of range"); return NC_ERR_SHAPE; }
+  const int xi = index % g.n2, yi = (index % (g.n2 * g.n1)) / g.n2, zi = index / (g.n2 * g.n1);
+  if (zi * g.step + roi > P0 || yi * g.step + roi > P1 || xi * g.step + roi > P2) { set_error("assemble_scatter_add: cube outside the volume"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_scatter_add, dim3(flat_grid((long)roi * roi * roi)), dim3(256), 0, (hipStream_t)stream, cube, acc,
+                     g, zi * g.step, yi * g.step, xi * g.step);
+  return check_launch("assemble_scatter_add");
+}
+
+int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2,
+                         int roi, int overlap, void* stream) {
+  if (!acc || !out) { set_error("assemble_finalize: null pointer"); return NC_ERR_ARG; }
+  if (overlap < 1) { set_error("assemble_finalize: overlap must be >= 1 (util/assemble_dice.py:170)"); return NC_ERR_SHAPE; }
+  DiceGeom g;
+  if (!make_geom(g, L0, L1, L2, roi, overlap, 1) || g.P0 != P0 || g.P1 != P1 || g.P2 != P2) {
+    set_error("assemble_finalize: padded size does not match pad_for_dicing of the original size");
+    return NC_ERR_SHAPE;
+  }
+  const long total = (long)L0 * L1 * L2;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_u16)
+    hipLaunchKernelGGL(k_finalize<uint16_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc, (uint16_t*)out, g, 65535.f);
+  else
+    hipLaunchKernelGGL(k_finalize<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc, (uint8_t*)out, g, 255.f);
+  return check_launch("assemble_finalize");
+}
+
+}  // extern "C"

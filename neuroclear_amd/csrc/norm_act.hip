@@ -1,0 +1,328 @@
+// InstanceNorm(affine=False) + ReLU/LeakyReLU (forward, backward), LeakyReLU, Sigmoid, MaxPool(2): the HBM-bound
+// elementwise / reduction part of the hot path (reference models/networks.py:33-34,:422-423,:1042-1046,:491,:510).
+// All of these are pure streams: 16-byte loads where the instance length allows it, fp64 accumulation for every
+// statistic (1.26 M elements per instance at 108^3 -- fp32 sums would not hold the stated tolerance).
+#include "common.hpp"
+
+namespace nc {
+
+static constexpr int kMaxSplits = 64;
+
+static int pick_splits(int NC, long S) {
+  long want = cdiv(2048, NC);
+  long cap = cdiv(S, 8192);
+  long s = want < cap ? want : cap;
+  if (s < 1) s = 1;
+  if (s > kMaxSplits) s = kMaxSplits;
+  return (int)s;
+}
+
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double* out2) {
+  __shared__ double red[2][4];
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_down(a, o);
+    b += __shfl_down(b, o);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wv] = a;
+    red[1][wv] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    out2[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__device__ __forceinline__ void chunk_range(long S, int splits, int sp, long& b, long& e) {
+  long chunk = (S + splits - 1) / splits;
+  chunk = (chunk + 3) & ~3L;
+  b = (long)sp * chunk;
+  e = b + chunk < S ? b + chunk : S;
+  if (b > S) b = S;
+}
+
+__global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x, long S, int splits,
+                                                  double* __restrict__ part) {
+  const int inst = blockIdx.y, sp = blockIdx.x;
+  long b, e;
+  chunk_range(S, splits, sp, b, e);
+  const float* p = x + (long)inst * S;
+  double s = 0.0, q = 0.0;
+  if ((S & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (long i = b / 4 + threadIdx.x; i < e / 4; i += 256) {
+      const float4 v = p4[i];
+      const double a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+      s += (a0 + a1) + (a2 + a3);
+      q = fma(a0, a0, q); q = fma(a1, a1, q); q = fma(a2, a2, q); q = fma(a3, a3, q);
+    }
+  } else {
+    for (long i = b + threadIdx.x; i < e; i += 256) {
+      const double a = p[i];
+      s += a;
+      q = fma(a, a, q);
+    }
+  }
+  block_reduce2(s, q, part + ((long)inst * splits + sp) * 2);
+}
+
+__global__ void k_in_finalize(const double* __restrict__ part, int NC, int splits, long S, float eps,
+                              float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NC) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < splits; ++k) {
+    s += part[((long)i * splits + k) * 2];
+    q += part[((long)i * splits + k) * 2 + 1];
+  }
+  const double m = s / (double)S;
+  double var = q / (double)S - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void k_in_act_fwd(const float* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, float slope,
+                                                    float* __restrict__ y, long S) {
+  const int inst = blockIdx.y;
+  const float m = mean[inst], r = rstd[inst];
+  const float* p = x + (long)inst * S;
+  float* o = y + (long)inst * S;
+  if ((S & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S / 4; i += (long)gridDim.x * 256) {
+      float4 v = p4[i];
+      v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      o4[i] = v;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+      const float v = (p[i] - m) * r;
+      o[i] = v > 0.f ? v : v * slope;
+    }
+  }
+}
+
+// pass 1 of the backward: s1 = sum(g), s2 = sum(g * xhat), g = dy * act'(xhat)
+__global__ __launch_bounds__(256) void k_in_bwd_sums(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float slope, long S, int splits, double* __restrict__ part) {
+  const int inst = blockIdx.y, sp = blockIdx.x;
+  long b, e;
+  chunk_range(S, splits, sp, b, e);
+  const float m = mean[inst], r = rstd[inst];
+  const float* px = x + (long)inst * S;
+  const float* pg = dy + (long)inst * S;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = b + threadIdx.x; i < e; i += 256) {
+    const float xh = (px[i] - m) * r;
+    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
+    s1 += (double)g;
+    s2 = fma((double)g, (double)xh, s2);
+  }
+  block_reduce2(s1, s2, part + ((long)inst * splits + sp) * 2);
+}
+
+__global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      float slope, long S, int splits,
+                                                      const double* __restrict__ part, float* __restrict__ dx) {
+  const int inst = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < splits; ++k) {
+    s1 += part[((long)inst * splits + k) * 2];
+    s2 += part[((long)inst * splits + k) * 2 + 1];
+  }
+  const float m1 = (float)(s1 / (double)S), m2 = (float)(s2 / (double)S);
+  const float m = mean[inst], r = rstd[inst];
+  const float* px = x + (long)inst * S;
+  const float* pg = dy + (long)inst * S;
+  float* o = dx + (long)inst * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    const float xh = (px[i] - m) * r;
+    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
+    o[i] = r * (g - m1 - xh * m2);
+  }
+}
+
+__global__ void k_lrelu_fwd(const float* __restrict__ x, float slope, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : v * slope;
+  }
+}
+__global__ void k_lrelu_bwd(const float* __restrict__ dy, const float* __restrict__ x, float slope,
+                            float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+__global__ void k_sigmoid_fwd(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ void k_sigmoid_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                              long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float s = y[i];
+    dx[i] = dy[i] * s * (1.f - s);
+  }
+}
+
+// MaxPool(2), floor mode.  H2 = 1 turns it into a 2-D pool is NOT needed: the reference only pools 3-D volumes
+// in Unet_deconv; D may still be 1 for a 2-D U-Net (pool window 1x2x2).
+__global__ void k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ y, int NC, int D, int H, int W, int Do,
+                               int Ho, int Wo, int wd) {
+  const long total = (long)NC * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % Wo), oh = (int)((i / Wo) % Ho), od = (int)((i / ((long)Wo * Ho)) % Do);
+    const long nc = i / ((long)Wo * Ho * Do);
+    const float* p = x + nc * D * H * W;
+    float best = -INFINITY;
+    for (int a = 0; a < wd; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c) {
+          const float v = p[((long)(od * wd + a) * H + (oh * 2 + b)) * W + ow * 2 + c];
+          if (v > best || v != v) best = v;
+        }
+    y[i] = best;
+  }
+}
+
+__global__ void k_maxpool2_bwd(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                               int NC, int D, int H, int W, int Do, int Ho, int Wo, int wd) {
+  const long total = (long)NC * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % Wo), oh = (int)((i / Wo) % Ho), od = (int)((i / ((long)Wo * Ho)) % Do);
+    const long nc = i / ((long)Wo * Ho * Do);
+    const float* p = x + nc * D * H * W;
+    float* q = dx + nc * D * H * W;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int a = 0; a < wd; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c) {
+          const float v = p[((long)(od * wd + a) * H + (oh * 2 + b)) * W + ow * 2 + c];
+          if (v > best || v != v) {
+            best = v;
+            arg = (a * 2 + b) * 2 + c;
+          }
+        }
+    const float g = dy[i];
+    for (int a = 0; a < wd; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
+          q[((long)(od * wd + a) * H + (oh * 2 + b)) * W + ow * 2 + c] = ((a * 2 + b) * 2 + c) == arg ? g : 0.f;
+  }
+}
+
+static unsigned flat_grid(long n, int per_block = 256) {
+  long b = cdiv(n, per_block);
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace nc
+
+using namespace nc;
+
+extern "C" {
+
+size_t nc_instnorm_ws_bytes(int NC, long S) {
+  (void)S;
+  return (size_t)NC * kMaxSplits * 2 * sizeof(double);
+}
+
+int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                      void* stream) {
+  if (!x || !mean || !rstd) { set_error("instnorm_stats: null pointer"); return NC_ERR_ARG; }
+  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_stats: bad shape NC=%d S=%ld", NC, S); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_instnorm_ws_bytes(NC, S)) { set_error("instnorm_stats: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(NC, S);
+  hipLaunchKernelGGL(k_in_stats, dim3(splits, NC), dim3(256), 0, s, x, S, splits, (double*)ws);
+  hipLaunchKernelGGL(k_in_finalize, dim3((unsigned)cdiv(NC, 128)), dim3(128), 0, s, (const double*)ws, NC, splits, S, eps,
+                     mean, rstd);
+  return check_launch("instnorm_stats");
+}
+
+int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, float slope, float* y, int NC, long S,
+                        void* stream) {
+  if (!x || !mean || !rstd || !y) { set_error("instnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
+  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
+  long bx = cdiv(S, 1024 * 4);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_in_act_fwd, dim3((unsigned)bx, NC), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, slope, y, S);
+  return check_launch("instnorm_act_fwd");
+}
+
+int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                        int NC, long S, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !dx) { set_error("instnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
+  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_instnorm_ws_bytes(NC, S)) { set_error("instnorm_act_bwd: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(NC, S);
+  hipLaunchKernelGGL(k_in_bwd_sums, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws);
+  long bx = cdiv(S, 1024);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)bx, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                     (const double*)ws, dx);
+  return check_launch("instnorm_act_bwd");
+}
+
+int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream) {
+  if (!x || !y) { set_error("leaky_relu_fwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_lrelu_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, slope, y, n);
+  return check_launch("leaky_relu_fwd");
+}
+int nc_leaky_relu_bwd(const float* dy, const float* x, float slope, float* dx, long n, void* stream) {
+  if (!dy || !x || !dx) { set_error("leaky_relu_bwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_lrelu_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, x, slope, dx, n);
+  return check_launch("leaky_relu_bwd");
+}
+int nc_sigmoid_fwd(const float* x, float* y, long n, void* stream) {
+  if (!x || !y) { set_error("sigmoid_fwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_sigmoid_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return check_launch("sigmoid_fwd");
+}
+int nc_sigmoid_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {
+  if (!dy || !y || !dx) { set_error("sigmoid_bwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+  return check_launch("sigmoid_bwd");
+}
+
+int nc_maxpool2_fwd(const float* x, float* y, int NC, int D, int H, int W, void* stream) {
+  if (!x || !y) { set_error("maxpool2_fwd: null pointer"); return NC_ERR_ARG; }
+  const int wd = D > 1 ? 2 : 1;
+  const int Do = D / wd, Ho = H / 2, Wo = W / 2;
+  if (NC < 1 || Do < 1 || Ho < 1 || Wo < 1) { set_error("maxpool2_fwd: bad shape"); return NC_ERR_SHAPE; }
+  const long total = (long)NC * Do * Ho * Wo;
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, NC, D, H, W, Do, Ho, Wo, wd);
+  return check_launch("maxpool2_fwd");
+}
+
+int nc_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int D, int H, int W, void* stream) {
+  if (!dy || !x || !dx) { set_error("maxpool2_bwd: null pointer"); return NC_ERR_ARG; }
+  const int wd = D > 1 ? 2 : 1;
+  const int Do = D / wd, Ho = H / 2, Wo = W / 2;
+  if (NC < 1 || Do < 1 || Ho < 1 || Wo < 1) { set_error("maxpool2_bwd: bad shape"); return NC_ERR_SHAPE; }
+  hipStream_t s = (hipStream_t)stream;
+  if ((D % wd) || (H & 1) || (W & 1)) {
+    if (hipMemsetAsync(dx, 0, (size_t)NC * D * H * W * sizeof(float), s) != hipSuccess) {
+      set_error("maxpool2_bwd: memset failed");
+      return NC_ERR_HIP;
+    }
+  }
+  const long total = (long)NC * Do * Ho * Wo;
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(flat_grid(total)), dim3(256), 0, s, dy, x, dx, NC, D, H, W, Do, Ho, Wo, wd);
+  return check_launch("maxpool2_bwd");
+}
+
+}  // extern "C"

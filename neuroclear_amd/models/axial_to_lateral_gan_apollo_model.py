@@ -1,0 +1,226 @@
+"""Apollo training step on MI355X (reference: models/axial_to_lateral_gan_apollo_model.py:7-353).
+
+Same option surface, loss names, loss weights, np.random draw order and optimizer grouping as the
+reference; what changes is underneath:
+  * G_A / G_B / the four 2-D PatchGANs, slices, MIPs, LSGAN / L1 losses all run HIP kernels (neuroclear_amd.ops);
+  * each optimizer owns ONE flat parameter buffer (+ flat grad, exp_avg, exp_avg_sq): Adam is a single fused launch
+    and, with torch.distributed initialised, the gradient all-reduce is a single RCCL call per optimizer phase
+    (G before optimizer_G.step at apollo:295, the Ds before optimizer_D.step at :307).
+"""
+import itertools
+
+import numpy as np
+import torch
+
+from .. import ops
+from . import networks
+from .base_model import BaseModel
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (lr, betas, eps=1e-8, no weight decay / amsgrad) over parameters that are views
+    into one flat fp32 buffer; step() is one nc_adam_step launch.  Exposes param_groups[0]['lr'] so that
+    torch's LambdaLR-style schedulers (networks.get_scheduler) keep working."""
+
+    def __init__(self, params, lr, betas, eps=1e-8):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p.data)
+            p.grad = self.grad[off:off + k].view_as(p.data)
+            off += k
+        self.defaults = dict(lr=lr, betas=betas, eps=eps)
+        self.param_groups = [dict(params=self.params, lr=lr, initial_lr=lr, betas=betas, eps=eps)]
+        self.state_step = 0
+        self._step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:  # re-attach the views if autograd replaced / dropped .grad
+            k = p.numel()
+            g = self.grad[off:off + k].view_as(p.data)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+            off += k
+
+    def all_reduce_mean(self):
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            ws = torch.distributed.get_world_size()
+            if ws > 1:
+                torch.distributed.all_reduce(self.grad)
+                self.grad.div_(ws)
+
+    def step(self):
+        self.state_step += 1
+        self._step_count += 1
+        g = self.param_groups[0]
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
+                      g['eps'], self.state_step)
+
+
+class AxialToLateralGANApolloModel(BaseModel):
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        parser.set_defaults(no_dropout=True)
+        if is_train:
+            parser.add_argument('--lambda_A', type=float, default=10.0, help='weight for cycle loss (A -> B -> A)')
+            parser.add_argument('--gan_mode', type=str, default='vanilla', help='[vanilla| lsgan | wgangp]')
+            parser.add_argument('--lambda_plane', type=int, nargs='+', default=[1, 1, 1])
+            parser.add_argument('--randomize_projection_depth', action='store_true')
+            parser.add_argument('--projection_depth', type=int, default=10)
+            parser.add_argument('--min_projection_depth', type=int, default=2)
+        parser.add_argument('--netG_B', type=str, default='deep_linear_gen')
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        self.loss_names = ['D_A_lateral', 'D_A_axial', 'G_A', 'G_A_lateral', 'G_A_axial', 'cycle',
+                           'D_B_lateral', 'D_B_axial', 'G_B', 'G_B_lateral', 'G_B_axial']
+        self.gan_mode = opt.gan_mode
+        self.gen_dimension, self.dis_dimension = 3, 2  # apollo:66-67
+        self.randomize_projection_depth = opt.randomize_projection_depth
+        if not self.randomize_projection_depth:
+            self.projection_depth_custom = opt.projection_depth
+        else:
+            self.max_projection_depth = opt.projection_depth
+            self.min_projection_depth = opt.min_projection_depth
+        self.visual_names = ['real', 'fake', 'rec'] * 2
+        tot = float(opt.lambda_plane[0] + opt.lambda_plane[1] + opt.lambda_plane[2])
+        self.lambda_plane_target, self.lambda_slice, self.lambda_proj = [f / tot for f in opt.lambda_plane]
+        self.lateral_axis, self.axial_1_axis, self.axial_2_axis = 0, 1, 2
+        self.model_names = ['G_A', 'G_B', 'D_A_lateral', 'D_A_axial', 'D_B_lateral', 'D_B_axial'] if self.isTrain \
+            else ['G_A', 'G_B']
+        G = networks.define_G
+        self.netG_A = G(opt.input_nc, opt.output_nc, opt.ngf, opt.netG, opt.norm, not opt.no_dropout, opt.init_type,
+                        opt.init_gain, self.gpu_ids, dimension=self.gen_dimension)
+        self.netG_B = G(opt.output_nc, opt.input_nc, opt.ngf, opt.netG_B, opt.norm, not opt.no_dropout, opt.init_type,
+                        opt.init_gain, self.gpu_ids, dimension=self.gen_dimension)
+        if self.isTrain:
+            def D(nc):
+                return networks.define_D(nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, opt.init_type,
+                                         opt.init_gain, False, self.gpu_ids, dimension=self.dis_dimension)
+            self.netD_A_axial = D(opt.output_nc)
+            self.netD_A_lateral = D(opt.output_nc)
+            self.netD_B_axial = D(opt.input_nc)
+            self.netD_B_lateral = D(opt.input_nc)
+            self.criterionGAN = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionCycle = ops.l1_loss
+            self._make_optimizers(opt)
+
+    def _make_optimizers(self, opt):
+        """apollo:131-138.  Call again after loading new parameter tensors (load_state_dict copies in place, so the
+        flat views stay valid)."""
+        self.optimizer_G = FlatAdam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
+                                    lr=opt.lr, betas=(opt.beta1, 0.999))
+        self.optimizer_D = FlatAdam(
+            itertools.chain(self.netD_A_axial.parameters(), self.netD_A_lateral.parameters(),
+                            self.netD_B_axial.parameters(), self.netD_B_lateral.parameters()),
+            lr=opt.lr, betas=(opt.beta1, 0.999))
+        self.optimizers = [self.optimizer_G, self.optimizer_D]
+
+    def set_input(self, input):
+        AtoB = self.opt.direction == 'AtoB'
+        self.real = input['A' if AtoB else 'B'].to(self.device)
+        self.image_paths = input['A_paths' if AtoB else 'B_paths']
+        self.cube_shape = self.real.shape
+        self.num_slice = self.cube_shape[-3]
+        if not self.randomize_projection_depth:
+            self.projection_depth = self.projection_depth_custom
+        else:
+            self.projection_depth = np.random.randint(max(2, self.min_projection_depth),
+                                                      self.max_projection_depth + 1)
+
+    def forward(self):
+        self.fake = self.netG_A(self.real)
+        self.rec = self.netG_B(self.fake)
+
+    # -- Volume.get_slice / get_projection (apollo:322-351); num_slice = shape[-1] for every axis (:325)
+    def iter_f(self, input, function, slice_axis):
+        idx = np.random.randint(input.shape[-1])
+        return function(ops.volume_slice(input, slice_axis, idx))
+
+    def proj_f(self, input, function, slice_axis):
+        start = np.random.randint(0, input.shape[-1] - self.projection_depth)
+        return function(ops.volume_mip(input, slice_axis, start, self.projection_depth))
+
+    def backward_D_slice(self, netD, real, fake, slice_axis_real, slice_axis_fake):
+        pred_real = self.iter_f(real, netD, slice_axis_real)
+        pred_fake = self.iter_f(fake.detach(), netD, slice_axis_fake)
+        loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
+        loss_D.backward()
+        return loss_D
+
+    def backward_D_projection(self, netD, real, fake, slice_axis_real, slice_axis_fake):
+        pred_real = self.iter_f(real, netD, slice_axis_real)
+        pred_fake = self.proj_f(fake.detach(), netD, slice_axis_fake)
+        loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
+        loss_D.backward()
+        return loss_D
+
+    def backward_D_A_lateral(self):
+        self.loss_D_A_lateral = self.backward_D_projection(self.netD_A_lateral, self.real, self.fake,
+                                                           self.lateral_axis, self.lateral_axis)
+
+    def backward_D_A_axial(self):
+        self.loss_D_A_axial_1 = self.backward_D_projection(self.netD_A_axial, self.real, self.fake,
+                                                           self.lateral_axis, self.axial_1_axis)
+        self.loss_D_A_axial_2 = self.backward_D_projection(self.netD_A_axial, self.real, self.fake,
+                                                           self.lateral_axis, self.axial_2_axis)
+        self.loss_D_A_axial = (self.loss_D_A_axial_1 + self.loss_D_A_axial_2) * 0.5
+
+    def backward_D_B_lateral(self):
+        self.loss_D_B_lateral = self.backward_D_slice(self.netD_B_lateral, self.real, self.rec, self.lateral_axis,
+                                                      self.lateral_axis)
+
+    def backward_D_B_axial(self):
+        self.loss_D_B_axial_1 = self.backward_D_slice(self.netD_B_axial, self.real, self.rec, self.axial_1_axis,
+                                                      self.axial_1_axis)
+        self.loss_D_B_axial_2 = self.backward_D_slice(self.netD_B_axial, self.real, self.rec, self.axial_2_axis,
+                                                      self.axial_2_axis)
+        self.loss_D_B_axial = (self.loss_D_B_axial_1 + self.loss_D_B_axial_2) * 0.5
+
+    def backward_G(self):
+        """apollo:255-283"""
+        lambda_A = self.opt.lambda_A
+        self.loss_G_A_lateral = self.criterionGAN(self.proj_f(self.fake, self.netD_A_lateral, self.lateral_axis),
+                                                  True) * self.lambda_plane_target
+        self.loss_G_A_axial = \
+            self.criterionGAN(self.proj_f(self.fake, self.netD_A_axial, self.axial_1_axis), True) * self.lambda_slice + \
+            self.criterionGAN(self.proj_f(self.fake, self.netD_A_axial, self.axial_2_axis), True) * self.lambda_slice
+        self.loss_G_A = self.loss_G_A_lateral + self.loss_G_A_axial * 0.5
+        self.loss_G_B_lateral = self.criterionGAN(self.iter_f(self.rec, self.netD_B_lateral, self.lateral_axis),
+                                                  True) * self.lambda_plane_target
+        self.loss_G_B_axial = \
+            self.criterionGAN(self.iter_f(self.rec, self.netD_B_axial, self.axial_1_axis), True) * self.lambda_slice + \
+            self.criterionGAN(self.iter_f(self.rec, self.netD_B_axial, self.axial_2_axis), True) * self.lambda_slice
+        self.loss_G_B = self.loss_G_B_lateral + self.loss_G_B_axial * 0.5
+        self.loss_cycle = self.criterionCycle(self.rec, self.real) * lambda_A
+        self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        """apollo:285-307"""
+        Ds = [self.netD_A_lateral, self.netD_A_axial, self.netD_B_lateral, self.netD_B_axial]
+        self.forward()
+        self.set_requires_grad(Ds, False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.optimizer_G.all_reduce_mean()
+        self.optimizer_G.step()
+        self.set_requires_grad(Ds, True)
+        self.optimizer_D.zero_grad()
+        self.backward_D_A_lateral()
+        self.backward_D_A_axial()
+        self.backward_D_B_lateral()
+        self.backward_D_B_axial()
+        self.optimizer_D.all_reduce_mean()
+        self.optimizer_D.step()

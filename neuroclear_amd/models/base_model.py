@@ -1,0 +1,139 @@
+"""BaseModel API the entry scripts drive (reference: models/base_model.py:19-232): set_input / forward /
+optimize_parameters / test / setup / eval / get_current_visuals / get_current_losses / save_networks / load_networks /
+update_learning_rate / set_requires_grad -- same names, same semantics, same checkpoint file naming
+(`<checkpoints_dir>/<name>/<epoch>_net_<Name>.pth`, plain state dicts with the reference's keys)."""
+import os
+from abc import ABC, abstractmethod
+from collections import OrderedDict
+
+import torch
+
+from . import networks
+
+
+class BaseModel(ABC):
+    def __init__(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        self.dimension = opt.image_dimension
+        if not self.gpu_ids:
+            raise RuntimeError('neuroclear_amd runs the hot path on MI355X only: pass --gpu_ids 0 (there is no CPU '
+                               'fallback; the CPU restatement lives in oracle/ and is test infrastructure)')
+        self.device = torch.device('cuda:{}'.format(self.gpu_ids[0]))
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.loss_names = []
+        self.model_names = []
+        self.visual_names = []
+        self.optimizers = []
+        self.image_paths = []
+        self.metric = 0
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        return parser
+
+    @abstractmethod
+    def set_input(self, input):
+        pass
+
+    @abstractmethod
+    def forward(self):
+        pass
+
+    @abstractmethod
+    def optimize_parameters(self):
+        pass
+
+    def setup(self, opt):
+        """base_model.py:81-92"""
+        if self.isTrain:
+            self.schedulers = [networks.get_scheduler(optimizer, opt) for optimizer in self.optimizers]
+        if not self.isTrain or opt.continue_train:
+            load_suffix = 'iter_%d' % opt.load_iter if opt.load_iter > 0 else opt.epoch
+            self.load_networks(load_suffix)
+        self.print_networks(opt.verbose)
+
+    def eval(self):
+        for name in self.model_names:
+            if isinstance(name, str):
+                getattr(self, 'net' + name).eval()
+
+    def test(self):
+        """base_model.py:101-109: forward under no_grad."""
+        with torch.no_grad():
+            self.forward()
+            self.compute_visuals()
+
+    def compute_visuals(self):
+        pass
+
+    def get_image_paths(self):
+        return self.image_paths
+
+    def update_learning_rate(self):
+        for scheduler in self.schedulers:
+            if self.opt.lr_policy == 'plateau':
+                scheduler.step(self.metric)
+            else:
+                scheduler.step()
+
+    def get_current_visuals(self):
+        visual_ret = OrderedDict()
+        for name in self.visual_names:
+            if isinstance(name, str):
+                visual_ret[name] = getattr(self, name)
+        return visual_ret
+
+    def get_current_losses(self):
+        """base_model.py:138-144 (float() synchronises, as in the reference)."""
+        errors_ret = OrderedDict()
+        for name in self.loss_names:
+            if isinstance(name, str):
+                errors_ret[name] = float(getattr(self, 'loss_' + name))
+        return errors_ret
+
+    def save_networks(self, epoch):
+        os.makedirs(self.save_dir, exist_ok=True)
+        for name in self.model_names:
+            if isinstance(name, str):
+                save_path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
+                net = getattr(self, 'net' + name)
+                torch.save(OrderedDict((k, v.detach().cpu()) for k, v in net.state_dict().items()), save_path)
+
+    def load_networks(self, epoch):
+        """base_model.py:178-201; legacy InstanceNorm buffers (running_mean/var, num_batches_tracked) are dropped."""
+        for name in self.model_names:
+            if isinstance(name, str):
+                load_path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
+                net = getattr(self, 'net' + name)
+                print('loading the model from %s' % load_path)
+                state_dict = torch.load(load_path, map_location=str(self.device))
+                if hasattr(state_dict, '_metadata'):
+                    del state_dict._metadata
+                for key in list(state_dict.keys()):
+                    if key.startswith('module.'):
+                        state_dict[key[len('module.'):]] = state_dict.pop(key)
+                for key in list(state_dict.keys()):
+                    if key.split('.')[-1] in ('running_mean', 'running_var', 'num_batches_tracked'):
+                        state_dict.pop(key)
+                net.load_state_dict(state_dict)
+
+    def print_networks(self, verbose):
+        print('---------- Networks initialized -------------')
+        for name in self.model_names:
+            if isinstance(name, str):
+                net = getattr(self, 'net' + name)
+                num_params = sum(p.numel() for p in net.parameters())
+                if verbose:
+                    print(net)
+                print('[Network %s] Total number of parameters : %.3f M' % (name, num_params / 1e6))
+        print('-----------------------------------------------')
+
+    def set_requires_grad(self, nets, requires_grad=False):
+        if not isinstance(nets, list):
+            nets = [nets]
+        for net in nets:
+            if net is not None:
+                for param in net.parameters():
+                    param.requires_grad = requires_grad

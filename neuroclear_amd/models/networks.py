@@ -1,0 +1,357 @@
+"""Host-side mirror of the reference's network zoo for the hot path (reference: models/networks.py).
+
+Same factory names, argument meaning, state-dict keys and error behaviour as the reference for the networks that
+BASELINE.json's north_star names -- `unet_deconv` (:478-538), `deep_linear_gen` (:893-917), `basic` / `n_layers`
+PatchGAN (:1009-1067), InstanceNorm (:20-44), `GANLoss('lsgan')` (:252-319), `init_net` (:122-137),
+`get_scheduler` (:50-86).  Every forward/backward runs HIP kernels from libnc_hip.so through neuroclear_amd.ops;
+there is no torch.nn.functional compute and no CPU fallback.  Networks outside the scope table (SURVEY.md 8a:
+resnet, VGG, linear kernels, spectral-norm D, ...) raise NotImplementedError exactly like an unknown name does in
+the reference (:196, :246).
+"""
+import functools
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+from torch.optim import lr_scheduler
+
+from .. import ops
+from .._lib import F, I, P, Z, check, lib
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class InstanceNormAct(nn.Module):
+    """InstanceNorm{2,3}d(affine=False, track_running_stats=False) fused with the activation that follows it in the
+    reference's Sequential (ReLU at networks.py:422-423, LeakyReLU(0.2) at :1042-1046).  Holds no parameters, so the
+    state-dict keys of the enclosing Sequential are unchanged."""
+
+    def __init__(self, num_features, slope=0.0, eps=1e-5):
+        super().__init__()
+        self.num_features, self.slope, self.eps = num_features, slope, eps
+
+    def forward(self, x):
+        return ops.instance_norm_act(x, self.slope, self.eps)
+
+    def extra_repr(self):
+        return '%d, slope=%g (HIP fused IN+act)' % (self.num_features, self.slope)
+
+
+class FusedActivation(nn.Module):
+    """Placeholder at the Sequential index where the reference has nn.ReLU()/nn.LeakyReLU(): the activation is
+    applied by the preceding InstanceNormAct kernel, this module is the identity."""
+
+    def forward(self, x):
+        return x
+
+
+class LeakyReLU(nn.Module):
+    def __init__(self, slope):
+        super().__init__()
+        self.slope = slope
+
+    def forward(self, x):
+        return ops.leaky_relu(x, self.slope)
+
+
+def get_norm_layer(norm_type='instance', dimension=3):
+    """networks.py:20-44.  Returns a constructor norm_layer(num_features, slope) -> module."""
+    if norm_type == 'instance':
+        return functools.partial(InstanceNormAct)
+    if norm_type in ('none', 'spectral'):
+        return None
+    if norm_type == 'batch':
+        raise NotImplementedError('normalization layer [batch] is outside the MI355X hot path (SURVEY.md 8a); '
+                                  'the reference configs use --norm instance')
+    raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
+
+
+def get_scheduler(optimizer, opt):
+    """networks.py:50-86 (unknown policy RAISES here; the reference returns the exception object, a bug)."""
+    if opt.lr_policy == 'linear':
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.epoch_count - opt.n_epochs) / float(opt.n_epochs_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.lr_policy == 'constant':
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 1.0)
+    if opt.lr_policy == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    if opt.lr_policy == 'plateau':
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2, threshold=0.01, patience=5)
+    if opt.lr_policy == 'cosine':
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.n_epochs, eta_min=0)
+    raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)
+
+
+def init_weights(net, init_type='normal', init_gain=0.02):
+    """networks.py:88-119: every module whose class name contains 'Conv' (ConvTranspose included)."""
+    def init_func(m):
+        classname = m.__class__.__name__
+        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
+            if init_type == 'normal':
+                init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+            if hasattr(m, 'bias') and m.bias is not None:
+                init.constant_(m.bias.data, 0.0)
+    net.apply(init_func)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """networks.py:122-137.  One process drives one GPU here (torch.distributed over RCCL does the scaling), so the
+    reference's nn.DataParallel wrapper is not reproduced: only gpu_ids[0] is used."""
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(torch.device('cuda', gpu_ids[0]))
+    init_weights(net, init_type, init_gain=init_gain)
+    return net
+
+
+class Conv(nn.Module):
+    """nn.Conv2d / nn.Conv3d parameter layout (weight (K,C,k..), bias (K,)) on the HIP conv kernels."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, dimension=3):
+        super().__init__()
+        self.stride, self.padding, self.dimension = stride, padding, dimension
+        self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + (kernel_size,) * dimension))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            init.zeros_(self.bias)
+
+    def forward(self, x):
+        return ops.conv(x, self.weight, self.bias, self.stride, self.padding)
+
+    def extra_repr(self):
+        return '%s, stride=%d, padding=%d' % (tuple(self.weight.shape), self.stride, self.padding)
+
+
+class ConvTranspose(nn.Module):
+    """nn.ConvTranspose3d(C, K, kernel 2, stride 2): weight (C,K,2,2,2), bias (K,)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2, dimension=3):
+        super().__init__()
+        if kernel_size != 2 or stride != 2 or dimension != 3:
+            raise NotImplementedError('only ConvTranspose3d(k=2, s=2) is on the hot path (networks.py:500,503)')
+        self.weight = nn.Parameter(torch.empty((in_channels, out_channels, 2, 2, 2)))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def forward(self, x):
+        return ops.conv_transpose_k2s2(x, self.weight, self.bias)
+
+
+def conv(dimension):
+    if dimension not in (2, 3):
+        raise Exception('Invalid image dimension.')
+    return functools.partial(Conv, dimension=dimension)
+
+
+def _conv_norm_relu(cin, cout, k, s, p, norm_layer, dimension):
+    mods = [Conv(cin, cout, k, s, p, dimension=dimension)]
+    if norm_layer is not None:
+        mods += [norm_layer(cout, 0.0), FusedActivation()]
+    else:
+        mods += [Identity(), LeakyReLU(0.0)]
+    return mods
+
+
+class double_conv(nn.Module):
+    """networks.py:413-432: Sequential indices 0 / 3 carry the convs."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, norm_layer=None, dimension=3):
+        super().__init__()
+        self.convolution = nn.Sequential(
+            *(_conv_norm_relu(in_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension) +
+              _conv_norm_relu(out_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension)))
+
+    def forward(self, x):
+        return self.convolution(x)
+
+
+class last_conv(nn.Module):
+    """networks.py:434-450."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, norm_layer=None, dimension=3):
+        super().__init__()
+        self.convolution = nn.Sequential(
+            *_conv_norm_relu(in_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension))
+
+    def forward(self, x):
+        return self.convolution(x)
+
+
+class triple_conv(nn.Module):
+    """networks.py:452-476: Sequential indices 0 / 3 / 6 carry the convs."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, norm_layer=None, dimension=3):
+        super().__init__()
+        self.convolution = nn.Sequential(
+            *(_conv_norm_relu(in_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension) +
+              _conv_norm_relu(out_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension) +
+              _conv_norm_relu(out_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension)))
+
+    def forward(self, x):
+        return self.convolution(x)
+
+
+class Unet_deconv(nn.Module):
+    """networks.py:478-538.  Training (grad enabled) runs layer by layer through neuroclear_amd.ops; inference
+    (torch.no_grad, as BaseModel.test does at base_model.py:101-109) takes the whole-network C entry point
+    nc_unet_deconv_fwd with the parameters packed in state-dict order."""
+
+    def __init__(self, input_nc, output_nc, norm_layer=None, dimension=3):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError('Unet_deconv: the hot path is the 3-D generator (apollo_model.py:66)')
+        start_nc = input_nc * 64
+        self.input_nc, self.output_nc = input_nc, output_nc
+        self.double_conv1 = double_conv(input_nc, start_nc, 3, 1, 1, norm_layer, dimension)
+        self.double_conv2 = double_conv(start_nc, start_nc * 2, 3, 1, 1, norm_layer, dimension)
+        self.bottom_layer = triple_conv(start_nc * 2, start_nc * 4, 3, 1, 1, norm_layer, dimension)
+        self.t_conv2 = ConvTranspose(start_nc * 4, start_nc * 2, 2, 2, dimension)
+        self.ex_double_conv2 = double_conv(start_nc * 4, start_nc * 2, 3, 1, 1, norm_layer, dimension)
+        self.t_conv1 = ConvTranspose(start_nc * 2, start_nc, 2, 2, dimension)
+        self.ex_conv1_1 = last_conv(start_nc * 2, start_nc, 3, 1, 1, norm_layer, dimension)
+        self.one_by_one = Conv(start_nc, output_nc, 1, 1, 0, dimension=dimension)
+        self.one_by_one_2 = Conv(output_nc, output_nc, 1, 1, 0, dimension=dimension)
+        self._fusable = norm_layer is not None and input_nc == 1 and output_nc == 1
+        self._packed = None
+        self._packed_key = None
+
+    def _packed_params(self):
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or key != self._packed_key:
+            self._packed = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
+            self._packed_key = key
+        return self._packed
+
+    def _forward_fused(self, x):
+        x = x.contiguous()
+        N, _, S0, S1, S2 = x.shape
+        nb = lib().nc_unet_deconv_fwd_ws_bytes(I(N), I(S0), I(S1), I(S2))
+        if nb == 0:
+            raise ValueError('Unet_deconv: every edge must be a positive multiple of 4, got %s '
+                             '(MaxPool3d floors, torch.cat at networks.py:526,531 would fail)' % ((S0, S1, S2),))
+        ws = ops.workspace(nb, x.device, 'unet')
+        y = torch.empty_like(x)
+        check(lib().nc_unet_deconv_fwd(P(self._packed_params().data_ptr()), P(x.data_ptr()), P(y.data_ptr()), I(N),
+                                       I(S0), I(S1), I(S2), P(ws.data_ptr()), Z(ws.numel()),
+                                       P(torch.cuda.current_stream().cuda_stream)), 'nc_unet_deconv_fwd')
+        return y
+
+    def forward(self, inputs):
+        if any(s % 4 for s in inputs.shape[2:]):
+            raise ValueError('Unet_deconv: every edge must be a multiple of 4, got %s' % (tuple(inputs.shape[2:]),))
+        if self._fusable and not torch.is_grad_enabled() and inputs.is_cuda:
+            return self._forward_fused(inputs)
+        conv1 = self.double_conv1(inputs)
+        conv2 = self.double_conv2(ops.maxpool2(conv1))
+        conv_bottom = self.bottom_layer(ops.maxpool2(conv2))
+        cat2 = torch.cat([conv2, self.t_conv2(conv_bottom)], 1)
+        ex_conv2 = self.ex_double_conv2(cat2)
+        cat1 = torch.cat([conv1, self.t_conv1(ex_conv2)], 1)
+        ex_conv1 = self.ex_conv1_1(cat1)
+        return ops.sigmoid(self.one_by_one_2(self.one_by_one(ex_conv1)))
+
+
+class DeepLinearGenerator(nn.Module):
+    """networks.py:893-917: bias-free linear chain, each layer zero-pads its own input."""
+
+    def __init__(self, input_nc, output_nc):
+        super().__init__()
+        c = input_nc * 64
+        self.first_layer = Conv(input_nc, c, 7, 1, 3, bias=False)
+        self.feature_block = nn.Sequential(
+            Conv(c, c, 5, 1, 2, bias=False), Conv(c, c, 3, 1, 1, bias=False),
+            Conv(c, c // 2, 1, 1, 0, bias=False), Conv(c // 2, c // 4, 1, 1, 0, bias=False))
+        self.final_layer = Conv(c // 4, output_nc, 1, 1, 0, bias=False)
+
+    def forward(self, input):
+        return self.final_layer(self.feature_block(self.first_layer(input)))
+
+
+class NLayerDiscriminator(nn.Module):
+    """networks.py:1009-1067 (PatchGAN).  With instance norm every conv carries a bias (:1025-1028)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, dimension=3):
+        super().__init__()
+        if use_sigmoid:
+            raise NotImplementedError('use_sigmoid=True is never set by the hot-path models (apollo:108-123)')
+        use_bias = norm_layer is not None  # InstanceNorm -> bias (reference: use_bias = norm is InstanceNorm)
+        kw, padw = 4, 1
+        seq = [Conv(input_nc, ndf, kw, 2, padw, dimension=dimension), LeakyReLU(0.2)]
+        nf_mult = 1
+        for n in range(1, n_layers):
+            nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+            seq += [Conv(ndf * nf_prev, ndf * nf_mult, kw, 2, padw, bias=use_bias, dimension=dimension)]
+            seq += [norm_layer(ndf * nf_mult, 0.2), FusedActivation()] if norm_layer else [Identity(), LeakyReLU(0.2)]
+        nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+        seq += [Conv(ndf * nf_prev, ndf * nf_mult, kw, 1, padw, bias=use_bias, dimension=dimension)]
+        seq += [norm_layer(ndf * nf_mult, 0.2), FusedActivation()] if norm_layer else [Identity(), LeakyReLU(0.2)]
+        seq += [Conv(ndf * nf_mult, 1, kw, 1, padw, dimension=dimension)]
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, input):
+        return self.model(input)
+
+
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02,
+             gpu_ids=[], kernel_size=9, given_psf=None, noise_setting=None, dimension=3):
+    """networks.py:140-197 (same signature)."""
+    norm_layer = get_norm_layer(norm_type=norm, dimension=dimension)
+    if netG == 'unet_deconv':
+        net = Unet_deconv(1, output_nc, norm_layer=norm_layer, dimension=dimension)  # input_nc forced to 1 (:174)
+    elif netG == 'deep_linear_gen':
+        net = DeepLinearGenerator(input_nc, output_nc)
+    elif netG in ('unet_twoouts', 'unet_vanilla', 'resnet_9blocks', 'resnet_6blocks', 'VGG', 'linearkernel',
+                  'linearkernel_double', 'linearkernel_LK31', 'linearkernel_NC', 'fixed_kernel'):
+        raise NotImplementedError('Generator [%s] is outside the MI355X hot path (SURVEY.md 8a)' % netG)
+    else:
+        raise NotImplementedError('Generator model name [%s] is not recognized' % netG)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, use_sigmoid=False,
+             gpu_ids=[], dimension=3):
+    """networks.py:199-247 (same signature)."""
+    norm_layer = get_norm_layer(norm_type=norm, dimension=dimension)
+    if netD == 'basic':
+        net = NLayerDiscriminator(input_nc, ndf, 3, norm_layer, use_sigmoid, dimension)
+    elif netD == 'n_layers':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer, use_sigmoid, dimension)
+    elif netD in ('basic_SN', 'n_layers_SN', 'pixel', 'kernelGAN'):
+        raise NotImplementedError('Discriminator [%s] is outside the MI355X hot path (SURVEY.md 8a)' % netD)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+class GANLoss(nn.Module):
+    """networks.py:252-319.  'lsgan' (the README configuration) runs on the fused MSE-vs-constant kernel."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self.gan_mode = gan_mode
+        self._real, self._fake = float(target_real_label), float(target_fake_label)
+        if gan_mode == 'lsgan':
+            pass
+        elif gan_mode == 'vanilla' or 'wgan' in gan_mode:
+            raise NotImplementedError('gan mode %s is outside the MI355X hot path (north_star: LSGAN)' % gan_mode)
+        else:
+            raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+
+    def __call__(self, prediction, target_is_real):
+        return ops.mse_const(prediction, self._real if target_is_real else self._fake)

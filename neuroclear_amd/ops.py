@@ -1,0 +1,443 @@
+"""torch.autograd.Function wrappers over the C ABI (include/nc_hip.h).  PyTorch provides device memory, streams and
+the autograd tape only -- every forward/backward below is one or more HIP kernels from libnc_hip.so.
+
+Each op mirrors the torch.nn call the reference makes on its hot path (models/networks.py, apollo_model.py); see the
+header for the file:line of every call site."""
+import torch
+
+from . import _lib
+from ._lib import F, I, L_, P, Z, check, lib
+
+_ws_cache = {}
+
+
+def _stream():
+    return P(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.NcError('neuroclear_amd ops need CUDA(HIP) tensors; there is no CPU fallback')
+        if not t.is_contiguous():
+            raise _lib.NcError('tensor must be contiguous')
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.NcError('expected float32, got %s' % t.dtype)
+
+
+def _ptr(t):
+    return P(t.data_ptr()) if t is not None else P(0)
+
+
+def workspace(nbytes, device, tag='ws'):
+    """Grow-only scratch buffer per (device, tag); stream-ordered reuse is safe because every op runs on one stream."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _dims5(shape):
+    if len(shape) == 5:
+        return tuple(shape)
+    if len(shape) == 4:
+        n, c, h, w = shape
+        return n, c, 1, h, w
+    raise _lib.NcError('expected NCDHW or NCHW tensor')
+
+
+def _kdims(wshape):
+    if len(wshape) == 5:
+        return wshape[2], wshape[3], wshape[4]
+    return 1, wshape[2], wshape[3]
+
+
+def _conv_out_shape(xs, ws, stride, pad):
+    nsp = len(xs) - 2
+    return (xs[0], ws[0]) + tuple((xs[2 + i] + 2 * pad - ws[2 + i]) // stride + 1 for i in range(nsp))
+
+
+def _conv_ws(dims, K, k3, stride, pad, device):
+    N, C, D, H, W = dims
+    nb = lib().nc_conv_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
+    return workspace(nb, device)
+
+
+def conv_fwd_raw(x, w, b, stride, pad):
+    _chk(x, w, b)
+    _f32(x, w, b)
+    dims = _dims5(x.shape)
+    N, C, D, H, W = dims
+    k3 = _kdims(w.shape)
+    K = w.shape[0]
+    if w.shape[1] != C:
+        raise _lib.NcError('conv: weight expects %d input channels, got %d' % (w.shape[1], C))
+    y = torch.empty(_conv_out_shape(x.shape, w.shape, stride, pad), dtype=torch.float32, device=x.device)
+    ws = _conv_ws(dims, K, k3, stride, pad, x.device)
+    check(lib().nc_conv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                            I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_fwd')
+    return y
+
+
+def conv_dgrad_raw(dy, w, x_shape, stride, pad):
+    _chk(dy, w)
+    _f32(dy, w)
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    dims = _dims5(x_shape)
+    N, C, D, H, W = dims
+    k3 = _kdims(w.shape)
+    K = w.shape[0]
+    ws = _conv_ws(dims, K, k3, stride, pad, dy.device)
+    check(lib().nc_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]),
+                              I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_dgrad')
+    return dx
+
+
+def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias):
+    _chk(x, dy)
+    _f32(x, dy)
+    dims = _dims5(x.shape)
+    N, C, D, H, W = dims
+    K = w_shape[0]
+    k3 = _kdims(w_shape)
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
+    ws = _conv_ws(dims, K, k3, stride, pad, x.device)
+    check(lib().nc_conv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                              I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()),
+          'nc_conv_wgrad')
+    return dw, db
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, b is not None)
+        return conv_fwd_raw(x, w, b, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_b = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
+        want_b = has_b and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b)
+        return dx, dw, db, None, None
+
+
+def conv(x, w, b=None, stride=1, padding=0):
+    """nn.Conv3d / nn.Conv2d (models/networks.py:361-369)."""
+    return _Conv.apply(x, w, b, int(stride), int(padding))
+
+
+class _ConvT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        _chk(x, w, b)
+        _f32(x, w, b)
+        if x.dim() != 5 or tuple(w.shape[2:]) != (2, 2, 2):
+            raise _lib.NcError('convT_k2s2: only ConvTranspose3d(kernel 2, stride 2) is on the hot path')
+        N, C, D, H, W = x.shape
+        K = w.shape[1]
+        y = torch.empty((N, K, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        check(lib().nc_convT_k2s2_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K),
+                                      _stream()), 'nc_convT_k2s2_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C, D, H, W = x.shape
+        K = w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().nc_convT_k2s2_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K),
+                                            _stream()), 'nc_convT_k2s2_dgrad')
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            db = torch.empty(K, dtype=torch.float32, device=x.device) if ctx.has_b else None
+            check(lib().nc_convT_k2s2_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K),
+                                            P(0), Z(0), _stream()), 'nc_convT_k2s2_wgrad')
+        return dx, dw, db
+
+
+def conv_transpose_k2s2(x, w, b=None):
+    """nn.ConvTranspose3d(C, K, 2, 2) (models/networks.py:500,503)."""
+    return _ConvT.apply(x, w, b)
+
+
+def instnorm_stats(x, eps=1e-5):
+    _chk(x)
+    _f32(x)
+    NC = x.shape[0] * x.shape[1]
+    S = x.numel() // NC
+    mean = torch.empty(NC, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(NC, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().nc_instnorm_ws_bytes(I(NC), L_(S)), x.device, 'in')
+    check(lib().nc_instnorm_stats(_ptr(x), I(NC), L_(S), F(eps), _ptr(mean), _ptr(rstd), _ptr(ws), Z(ws.numel()),
+                                  _stream()), 'nc_instnorm_stats')
+    return mean, rstd
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope, eps):
+        x = x.contiguous()
+        mean, rstd = instnorm_stats(x, eps)
+        NC = mean.numel()
+        S = x.numel() // NC
+        y = torch.empty_like(x)
+        check(lib().nc_instnorm_act_fwd(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), I(NC), L_(S), _stream()),
+              'nc_instnorm_act_fwd')
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        NC = mean.numel()
+        S = x.numel() // NC
+        dx = torch.empty_like(x)
+        ws = workspace(lib().nc_instnorm_ws_bytes(I(NC), L_(S)), x.device, 'in')
+        check(lib().nc_instnorm_act_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), F(ctx.slope), _ptr(dx), I(NC),
+                                        L_(S), _ptr(ws), Z(ws.numel()), _stream()), 'nc_instnorm_act_bwd')
+        return dx, None, None
+
+
+def instance_norm_act(x, slope=0.0, eps=1e-5):
+    """InstanceNorm{2,3}d(affine=False) followed by ReLU (slope 0) / LeakyReLU(slope) -- networks.py:33-34,422-423."""
+    return _InstNormAct.apply(x, float(slope), float(eps))
+
+
+class _LeakyReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        _chk(x)
+        _f32(x)
+        y = torch.empty_like(x)
+        check(lib().nc_leaky_relu_fwd(_ptr(x), F(slope), _ptr(y), L_(x.numel()), _stream()), 'nc_leaky_relu_fwd')
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib().nc_leaky_relu_bwd(_ptr(dy), _ptr(x), F(ctx.slope), _ptr(dx), L_(x.numel()), _stream()),
+              'nc_leaky_relu_bwd')
+        return dx, None
+
+
+def leaky_relu(x, slope):
+    return _LeakyReLU.apply(x, float(slope))
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x)
+        _f32(x)
+        y = torch.empty_like(x)
+        check(lib().nc_sigmoid_fwd(_ptr(x), _ptr(y), L_(x.numel()), _stream()), 'nc_sigmoid_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(lib().nc_sigmoid_bwd(_ptr(dy), _ptr(y), _ptr(dx), L_(y.numel()), _stream()), 'nc_sigmoid_bwd')
+        return dx
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x)
+        _f32(x)
+        N, C, D, H, W = _dims5(x.shape)
+        wd = 2 if D > 1 else 1
+        oshape = (N, C, D // wd, H // 2, W // 2) if x.dim() == 5 else (N, C, H // 2, W // 2)
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        check(lib().nc_maxpool2_fwd(_ptr(x), _ptr(y), I(N * C), I(D), I(H), I(W), _stream()), 'nc_maxpool2_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C, D, H, W = _dims5(x.shape)
+        dx = torch.empty_like(x)
+        check(lib().nc_maxpool2_bwd(_ptr(dy), _ptr(x), _ptr(dx), I(N * C), I(D), I(H), I(W), _stream()),
+              'nc_maxpool2_bwd')
+        return dx
+
+
+def maxpool2(x):
+    """nn.MaxPool3d(2) (models/networks.py:491,494)."""
+    return _MaxPool2.apply(x)
+
+
+_PLANE = [lambda N, C, D, H, W: (N, C, H, W), lambda N, C, D, H, W: (N, C, D, W), lambda N, C, D, H, W: (N, C, D, H)]
+
+
+class _Slice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, axis, index):
+        vol = vol.contiguous()
+        _chk(vol)
+        _f32(vol)
+        N, C, D, H, W = vol.shape
+        out = torch.empty(_PLANE[axis](N, C, D, H, W), dtype=torch.float32, device=vol.device)
+        check(lib().nc_slice_fwd(_ptr(vol), _ptr(out), I(N * C), I(D), I(H), I(W), I(axis), I(index), _stream()),
+              'nc_slice_fwd')
+        ctx.cfg = (tuple(vol.shape), axis, index)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, axis, index = ctx.cfg
+        dout = dout.contiguous()
+        N, C, D, H, W = shape
+        dvol = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        check(lib().nc_slice_bwd(_ptr(dout), _ptr(dvol), I(N * C), I(D), I(H), I(W), I(axis), I(index), _stream()),
+              'nc_slice_bwd')
+        return dvol, None, None
+
+
+def volume_slice(vol, axis, index):
+    """Volume.get_slice (apollo_model.py:328-337)."""
+    return _Slice.apply(vol, int(axis), int(index))
+
+
+class _Mip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, axis, start, depth):
+        vol = vol.contiguous()
+        _chk(vol)
+        _f32(vol)
+        N, C, D, H, W = vol.shape
+        oshape = _PLANE[axis](N, C, D, H, W)
+        out = torch.empty(oshape, dtype=torch.float32, device=vol.device)
+        arg = torch.empty(oshape, dtype=torch.int32, device=vol.device)
+        check(lib().nc_mip_fwd(_ptr(vol), _ptr(out), _ptr(arg), I(N * C), I(D), I(H), I(W), I(axis), I(start),
+                               I(depth), _stream()), 'nc_mip_fwd')
+        ctx.save_for_backward(arg)
+        ctx.cfg = (tuple(vol.shape), axis)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        shape, axis = ctx.cfg
+        dout = dout.contiguous()
+        N, C, D, H, W = shape
+        dvol = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        check(lib().nc_mip_bwd(_ptr(dout), _ptr(arg), _ptr(dvol), I(N * C), I(D), I(H), I(W), I(axis), _stream()),
+              'nc_mip_bwd')
+        return dvol, None, None, None
+
+
+def volume_mip(vol, axis, start, depth):
+    """Volume.get_projection (apollo_model.py:339-351)."""
+    return _Mip.apply(vol, int(axis), int(start), int(depth))
+
+
+class _MseConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        _chk(pred)
+        _f32(pred)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        ws = workspace(lib().nc_loss_ws_bytes(L_(pred.numel())), pred.device, 'loss')
+        check(lib().nc_mse_const_fwd(_ptr(pred), L_(pred.numel()), F(target), _ptr(out), _ptr(ws), Z(ws.numel()),
+                                     _stream()), 'nc_mse_const_fwd')
+        ctx.save_for_backward(pred)
+        ctx.target = target
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (pred,) = ctx.saved_tensors
+        g = g.contiguous()
+        dp = torch.empty_like(pred)
+        check(lib().nc_mse_const_bwd(_ptr(pred), L_(pred.numel()), F(ctx.target), _ptr(g), _ptr(dp), _stream()),
+              'nc_mse_const_bwd')
+        return dp, None
+
+
+def mse_const(pred, target):
+    """GANLoss('lsgan') (models/networks.py:276,299-313): mean((pred - target)^2), target a constant."""
+    return _MseConst.apply(pred, float(target))
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        _f32(a, b)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = workspace(lib().nc_loss_ws_bytes(L_(a.numel())), a.device, 'loss')
+        check(lib().nc_l1_fwd(_ptr(a), _ptr(b), L_(a.numel()), _ptr(out), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_l1_fwd')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        check(lib().nc_l1_bwd(_ptr(a), _ptr(b), L_(a.numel()), _ptr(g), _ptr(da), _stream()), 'nc_l1_bwd')
+        return da, None
+
+
+def l1_loss(a, b):
+    """torch.nn.L1Loss()(a, b) with b treated as a constant (apollo_model.py:128,279: rec vs real)."""
+    return _L1.apply(a, b)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    """torch.optim.Adam.step over one flat buffer (apollo_model.py:131-136)."""
+    _chk(p, g, m, v)
+    _f32(p, g, m, v)
+    check(lib().nc_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), L_(p.numel()), F(lr), F(beta1), F(beta2), F(eps),
+                             I(step), _stream()), 'nc_adam_step')
+
+
+def set_force_direct(on):
+    lib().nc_set_force_direct(I(1 if on else 0))

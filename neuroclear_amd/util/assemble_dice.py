@@ -1,0 +1,98 @@
+"""Assemble_Dice on the device (reference: util/assemble_dice.py:11-213).
+
+Same interface -- Assemble_Dice(opt), addToStack(visuals), assemble_all(), getDict() -- but the cubes never leave HBM:
+addToStack crops the border and overlap-adds cube/8 into a padded fp32 accumulator right away (nc_assemble_scatter_add,
+in arrival = index order, exactly the reference's summation order), assemble_all runs nc_assemble_finalize
+((acc / count) * 8 * 65535, truncating cast, crop of the dicing pad) with the count computed analytically.
+`--histogram_match` / `--normalize_intensity` are scikit-image arithmetic (parity unpinned) and raise."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .._lib import I, P, check, lib
+from . import util
+
+
+class Assemble_Dice:
+    def __init__(self, opt, image_size_original=None):
+        """image_size_original: (z, y, x) of the un-padded volume; when omitted it is taken from opt.volume_shape."""
+        if image_size_original is None:
+            image_size_original = opt.volume_shape
+        self.image_size_original = tuple(int(s) for s in image_size_original)
+        self.border_cut = opt.border_cut
+        self.roi_size = opt.dice_size[0]
+        self.overlap = opt.overlap
+        if self.border_cut < 1:
+            raise ValueError('border_cut must be >= 1 (util/assemble_dice.py:143-145 crops cube[b:-b])')
+        if self.overlap < 1:
+            raise ValueError('overlap must be >= 1: the reference assembler adds nothing for overlap 0 '
+                             '(util/assemble_dice.py:170) and returns an all-zero volume')
+        if getattr(opt, 'histogram_match', False) or getattr(opt, 'normalize_intensity', False):
+            raise NotImplementedError('--histogram_match / --normalize_intensity are third-party (scikit-image) '
+                                      'post-processing outside the pinned hot path (SURVEY.md 8c/8f)')
+        self.step = self.roi_size - self.overlap
+        self.image_size = util.padded_shape(self.image_size_original, self.roi_size, self.overlap)
+        self.z_steps, self.y_steps, self.x_steps = util.grid_steps(self.image_size, self.roi_size, self.overlap)
+        self.len_cube_queue = self.z_steps * self.y_steps * self.x_steps
+        self.visual_names = ['real', 'fake']
+        self.imtype = opt.data_type
+        if self.imtype not in ('uint8', 'uint16'):
+            raise ValueError('data_type must be uint8 or uint16')
+        self.skip_real = opt.skip_real
+        self.device = torch.device('cuda', opt.gpu_ids[0]) if getattr(opt, 'gpu_ids', None) else torch.device('cuda')
+        self.acc = OrderedDict()
+        self.count = OrderedDict()
+        self.visual_ret = OrderedDict()
+        for name in self.visual_names:
+            if self.skip_real and name == 'real':
+                continue
+            self.acc[name] = torch.zeros(self.image_size, dtype=torch.float32, device=self.device)
+            self.count[name] = 0
+
+    def indexTo3DIndex(self, index):
+        return (index // (self.x_steps * self.y_steps), (index % (self.x_steps * self.y_steps)) // self.x_steps,
+                index % self.x_steps)
+
+    def indexToCoordinates(self, index):
+        z, y, x = self.indexTo3DIndex(index)
+        return z * self.step, y * self.step, x * self.step
+
+    def add_cube(self, name, cube, index):
+        """Overlap-add one (R+2b)^3 network output at cube position `index`."""
+        E = self.roi_size + 2 * self.border_cut
+        cube = cube.reshape(-1)
+        if cube.numel() != E * E * E:
+            raise AssertionError('the cube dimensions are invalid.')
+        if cube.dtype != torch.float32 or not cube.is_cuda:
+            cube = cube.to(self.device, torch.float32)
+        cube = cube.contiguous()
+        P0, P1, P2 = self.image_size
+        check(lib().nc_assemble_scatter_add(P(cube.data_ptr()), P(self.acc[name].data_ptr()), I(P0), I(P1), I(P2),
+                                            I(self.roi_size), I(self.overlap), I(self.border_cut), I(int(index)),
+                                            P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_scatter_add')
+
+    def addToStack(self, cube):
+        """cube: OrderedDict {'real': [1,1,E,E,E], 'fake': ...} as returned by model.get_current_visuals()."""
+        for name in self.visual_names:
+            if self.skip_real and name == 'real':
+                continue
+            self.add_cube(name, cube[name], self.count[name])
+            self.count[name] += 1
+
+    def assemble_all(self):
+        L0, L1, L2 = self.image_size_original
+        P0, P1, P2 = self.image_size
+        for name, acc in self.acc.items():
+            if self.count[name] != self.len_cube_queue:
+                raise Exception('expected %d cubes for %s, got %d' % (self.len_cube_queue, name, self.count[name]))
+            u16 = self.imtype == 'uint16'
+            out = torch.empty((L0, L1, L2), dtype=torch.int16 if u16 else torch.uint8, device=self.device)
+            check(lib().nc_assemble_finalize(P(acc.data_ptr()), P(out.data_ptr()), I(1 if u16 else 0), I(P0), I(P1),
+                                             I(P2), I(L0), I(L1), I(L2), I(self.roi_size), I(self.overlap),
+                                             P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_finalize')
+            host = out.cpu().numpy()
+            self.visual_ret[name] = host.view(np.uint16) if u16 else host
+
+    def getDict(self):
+        return self.visual_ret

@@ -1,0 +1,214 @@
+"""GPU parity tests, network level (-m gpu): the HIP path (through the C ABI) against
+  * the golden vectors generated from the reference itself (tests/golden/*.npz), and
+  * the oracle (oracle/*.py, CPU) on the same seeded inputs.
+Stated fp32 tolerances: generator outputs (after sigmoid) |err| <= 2e-5; linear-chain outputs 2e-4 relative;
+gradients 1e-3 relative to the largest reference magnitude; Apollo losses 1e-3 relative after two optimiser steps."""
+import hashlib
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from neuroclear_amd import ops  # noqa: E402
+from neuroclear_amd.models import networks  # noqa: E402
+from neuroclear_amd.util import seed as S  # noqa: E402
+
+DEV = 'cuda'
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def rnd(seed, shape):
+    return np.random.default_rng(int(seed)).random(tuple(int(s) for s in shape), dtype=np.float32)
+
+
+def load(net, spec, seed):
+    net.load_state_dict(S.state_dict_from_seed(spec, seed, DEV))
+    return net
+
+
+def relmax(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
+
+
+def check_grads(g, net, tol):
+    for i, (k, p) in enumerate(net.named_parameters()):
+        gr = p.grad.detach().cpu().numpy().ravel()
+        l2 = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(l2 - g['g_l2'][i]) <= tol * max(g['g_l2'][i], 1e-7), (k, l2, g['g_l2'][i])
+        idx = np.random.default_rng([77, i]).integers(0, gr.size, size=8)
+        np.testing.assert_allclose(gr[idx], g['g_samp'][i], rtol=5e-3, atol=tol * l2 / np.sqrt(gr.size) + 1e-9,
+                                   err_msg=k)
+
+
+@pytest.mark.parametrize('size', [16, 32])
+def test_unet_deconv(golden_dir, size):
+    g = G(golden_dir, 'unet_deconv_%d.npz' % size)
+    net = load(networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0]),
+               S.unet_deconv_spec(), int(g['seed']))
+    x = torch.from_numpy(rnd(g['x_seed'], (1, 1, size, size, size))).to(DEV).requires_grad_(True)
+    y = net(x)
+    assert float(np.abs(y.detach().cpu().numpy() - g['y']).max()) < 2e-5
+    with torch.no_grad():  # whole-network C entry point (nc_unet_deconv_fwd)
+        yf = net(x.detach())
+    assert float((yf - y.detach()).abs().max()) < 1e-5
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert relmax(x.grad.cpu().numpy(), g['dx']) < 1e-3
+    check_grads(g, net, 1e-3)
+
+
+@pytest.mark.parametrize('size', [16, 24])
+def test_deep_linear(golden_dir, size):
+    g = G(golden_dir, 'deep_linear_%d.npz' % size)
+    net = load(networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0]),
+               S.deep_linear_spec(), int(g['seed']))
+    x = torch.from_numpy(rnd(g['x_seed'], (1, 1, size, size, size))).to(DEV).requires_grad_(True)
+    y = net(x)
+    assert relmax(y.detach().cpu().numpy(), g['y']) < 2e-4
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert relmax(x.grad.cpu().numpy(), g['dx']) < 1e-3
+    check_grads(g, net, 1e-3)
+
+
+@pytest.mark.parametrize('tag', ['2d_36', '2d_108', '2d_36_b3', '3d_36'])
+def test_patchgan(golden_dir, tag):
+    g = G(golden_dir, 'patchgan_%s.npz' % tag)
+    dim = int(g['dim'])
+    net = load(networks.define_D(1, 64, 'basic', 3, 'instance', 'kaiming', 0.02, False, [0], dimension=dim),
+               S.patchgan_spec(dim), int(g['seed']))
+    x = torch.from_numpy(rnd(g['x_seed'], g['shape'])).to(DEV).requires_grad_(True)
+    y = net(x)
+    assert relmax(y.detach().cpu().numpy(), g['y']) < 5e-4
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert relmax(x.grad.cpu().numpy(), g['dx']) < 2e-3
+    check_grads(g, net, 3e-3)
+
+
+def test_blocks(golden_dir):
+    norm = networks.get_norm_layer('instance', 3)
+    for tag in ('dc_1_64', 'dc_64_128'):
+        g = G(golden_dir, 'block_%s.npz' % tag)
+        cin, cout, size, seed = int(g['cin']), int(g['cout']), int(g['size']), int(g['seed'])
+        blk = networks.double_conv(cin, cout, 3, 1, 1, norm, 3).to(DEV)
+        spec = [('convolution.0.weight', (cout, cin, 3, 3, 3)), ('convolution.0.bias', (cout,)),
+                ('convolution.3.weight', (cout, cout, 3, 3, 3)), ('convolution.3.bias', (cout,))]
+        load(blk, spec, seed)
+        x = torch.from_numpy(rnd(100 + seed, (1, cin, size, size, size))).to(DEV).requires_grad_(True)
+        y = blk(x)
+        assert relmax(y.detach().cpu().numpy(), g['y']) < 1e-4, tag
+        r = torch.from_numpy(rnd(200 + seed, y.shape)).to(DEV)
+        (y * r).mean().backward()
+        assert relmax(x.grad.cpu().numpy(), g['dx']) < 1e-3, tag
+        for key, conv in (('dw0', blk.convolution[0]), ('dw3', blk.convolution[3])):
+            a = conv.weight.grad.cpu().numpy().ravel()
+            idx = np.random.default_rng(55).integers(0, a.size, size=min(4096, a.size))
+            got = np.concatenate([[np.sqrt((a.astype(np.float64) ** 2).sum()), a.astype(np.float64).sum()], a[idx]])
+            assert abs(got[0] - g[key][0]) < 1e-3 * g[key][0], (tag, key)
+            assert relmax(got[2:], g[key][2:]) < 2e-3, (tag, key)
+    g = G(golden_dir, 'block_in_relu_bigmean.npz')
+    x = torch.from_numpy(rnd(114, (1, 16, 20, 20, 20)) * 0.05 + 100.0).to(DEV).requires_grad_(True)
+    y = ops.instance_norm_act(x, 0.0)
+    # inputs of magnitude 100 carry an fp32 representation error of ~4e-6 = 3e-4 sigma: both sides are noisy
+    assert float(np.abs(y.detach().cpu().numpy() - g['y']).max()) < 5e-3
+
+
+def _apollo_opt():
+    return Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t',
+                     preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
+                     min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64,
+                     ndf=64, netG='unet_deconv', netG_B='deep_linear_gen', netD='basic', n_layers_D=3,
+                     norm='instance', no_dropout=True, init_type='kaiming', init_gain=0.02, lr=1e-4, beta1=0.1,
+                     direction='AtoB', model='axial_to_lateral_gan_apollo')
+
+
+APOLLO_NETS = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
+
+
+def test_apollo_step(golden_dir):
+    from neuroclear_amd.models import create_model
+    g = G(golden_dir, 'apollo_step_36.npz')
+    size = int(g['size'])
+    model = create_model(_apollo_opt())
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 4
+    for i, (n, sp) in enumerate(zip(APOLLO_NETS, specs)):
+        load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
+    before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in APOLLO_NETS}
+    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    np.random.seed(int(g['step_seed']))
+    names = [str(s) for s in g['loss_names']]
+    for it in range(2):
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+        L = model.get_current_losses()
+        got = np.array([L[k] for k in names])
+        print(it, dict(zip(names, got)), g['losses'][it])
+        np.testing.assert_allclose(got, g['losses'][it], rtol=1e-3, err_msg='step %d' % it)
+        if it == 0:
+            assert float(np.abs(model.fake.detach().cpu().numpy() - g['fake0']).max()) < 2e-5
+            assert relmax(model.rec.detach().cpu().numpy(), g['rec0']) < 2e-4
+    for n in APOLLO_NETS:
+        upd = np.array([float((a.detach() - b).double().norm())
+                        for a, b in zip(getattr(model, 'net' + n).parameters(), before[n])])
+        np.testing.assert_allclose(upd, g['upd_' + n], rtol=2e-2, err_msg=n)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('tag', ['100_32_4_4', 'ragged_70_50_61', 'u8_64_24_4_2'])
+def test_dice_assemble_bit_exact(golden_dir, tag):
+    from neuroclear_amd.data.diceImage_dataset import DiceImageDataSet
+    from neuroclear_amd.util.assemble_dice import Assemble_Dice
+    g = G(golden_dir, 'dice_%s.npz' % tag)
+    shape, R, ov, b = tuple(int(v) for v in g['shape']), int(g['roi']), int(g['overlap']), int(g['border'])
+    dtype = np.dtype(str(g['dtype']))
+    vol = S.random_volume(int(g['vol_seed']), shape, dtype)
+    opt = Namespace(dice_size=[R, R, R], overlap=ov, border_cut=b, gpu_ids=[0], skip_real=False,
+                    data_type='uint8' if dtype == np.uint8 else 'uint16', histogram_match=False,
+                    normalize_intensity=False)
+    ds = DiceImageDataSet(opt, volume=vol)
+    assert ds.size() == tuple(g['padded']) and ds.shape() == tuple(g['steps']) and len(ds) == int(g['n'])
+    n = len(ds)
+    np.testing.assert_array_equal(ds[0]['A'].cpu().numpy(), g['first'])
+    np.testing.assert_array_equal(ds[n // 2]['A'].cpu().numpy(), g['mid'])
+    np.testing.assert_array_equal(ds[n - 1]['A'].cpu().numpy(), g['last'])
+    asm_id = Assemble_Dice(opt, shape)
+    asm_pos = Assemble_Dice(opt, shape)
+    for i in range(n):
+        a = ds[i]['A'].unsqueeze(0)
+        asm_id.addToStack(dict(real=a, fake=a))
+        # same arithmetic as the generator script: fp32 mul, then add of a double constant rounded to fp32 tensor op
+        asm_pos.addToStack(dict(real=a, fake=a * 0.5 + (i % 7) * 1e-3))
+    asm_id.assemble_all()
+    asm_pos.assemble_all()
+    assert _sha(asm_id.getDict()['fake']) == str(g['sha_identity'])
+    assert _sha(asm_pos.getDict()['real']) == str(g['sha_real'])
+    assert int(np.abs(asm_id.getDict()['fake'].astype(np.int64) - vol).max()) <= 1
+    assert _sha(asm_pos.getDict()['fake']) == str(g['sha_pos'])
+    if g['out_pos'].size:
+        np.testing.assert_array_equal(asm_pos.getDict()['fake'], g['out_pos'])
+
+
+def test_error_behaviour():
+    from neuroclear_amd._lib import NcError
+    with pytest.raises(NotImplementedError):
+        networks.define_G(1, 1, 64, 'no_such_net', 'instance')
+    with pytest.raises(NotImplementedError):
+        networks.define_D(1, 64, 'no_such_net', norm='instance')
+    with pytest.raises(NotImplementedError):
+        networks.GANLoss('bogus')
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 10, 12, 12, device=DEV))
+    with pytest.raises(NcError):  # CPU tensors are refused: no fallback
+        ops.conv(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 3, 3, 3), None, 1, 1)

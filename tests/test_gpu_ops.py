@@ -1,0 +1,189 @@
+"""GPU parity tests, op level (run with -m gpu on the MI355X box).  Every op of libnc_hip.so is called through the
+C ABI (neuroclear_amd.ops -> ctypes) and compared with
+  * torch's own fp32 implementation of the same op on the GPU (a plain fp32 reference, any size), and
+  * the MFMA path against the direct path of this library (nc_set_force_direct).
+Tolerances are relative to the largest reference magnitude: fp32 accumulation order differs from MIOpen's."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from neuroclear_amd import ops  # noqa: E402
+
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def T(seed, shape, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g) - 0.5) * 2 * scale + shift).to(DEV)
+
+
+CONV_CASES = [
+    # N, C, K, spatial, k, stride, pad
+    (1, 1, 64, (12, 12, 12), 3, 1, 1),
+    (1, 64, 64, (12, 14, 20), 3, 1, 1),      # MFMA
+    (2, 64, 128, (9, 10, 27), 3, 1, 1),      # MFMA, odd sizes, batch 2
+    (1, 128, 256, (7, 7, 7), 3, 1, 1),       # MFMA small
+    (1, 256, 128, (8, 12, 12), 3, 1, 1),     # MFMA
+    (1, 128, 64, (6, 20, 36), 3, 1, 1),      # MFMA (ex_conv1_1 shape class)
+    (1, 64, 64, (10, 12, 16), 5, 1, 2),      # MFMA 5^3
+    (1, 1, 64, (12, 12, 12), 7, 1, 3),
+    (1, 64, 1, (10, 10, 10), 1, 1, 0),
+    (1, 1, 1, (8, 8, 8), 1, 1, 0),
+    (1, 64, 32, (6, 6, 6), 1, 1, 0),
+    (3, 1, 64, (36, 36), 4, 2, 1),           # PatchGAN 2-D
+    (1, 64, 128, (18, 18), 4, 2, 1),
+    (1, 256, 512, (4, 4), 4, 1, 1),
+    (1, 512, 1, (3, 3), 4, 1, 1),
+    (1, 1, 64, (12, 12, 12), 4, 2, 1),       # PatchGAN 3-D
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'N%dC%dK%d_%s_k%ds%dp%d' % (c[0], c[1], c[2], 'x'.join(map(str, c[3])), c[4], c[5], c[6]))
+@pytest.mark.parametrize('force_direct', [False, True], ids=['auto', 'direct'])
+def test_conv(case, force_direct):
+    N, C, K, sp, k, s, p = case
+    nd = len(sp)
+    x = T(1, (N, C) + sp).requires_grad_(True)
+    w = T(2, (K, C) + (k,) * nd, scale=(2.0 / (C * k ** nd)) ** 0.5 * 1.7).requires_grad_(True)
+    b = T(3, (K,), scale=0.1).requires_grad_(True)
+    fn = F.conv3d if nd == 3 else F.conv2d
+    yr = fn(x, w, b, stride=s, padding=p)
+    r = T(4, yr.shape)
+    gx, gw, gb = torch.autograd.grad((yr * r).sum(), (x, w, b))
+    ops.set_force_direct(force_direct)
+    try:
+        x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+        y = ops.conv(x2, w2, b2, s, p)
+        hx, hw, hb = torch.autograd.grad((y * r).sum(), (x2, w2, b2))
+    finally:
+        ops.set_force_direct(False)
+    torch.cuda.synchronize()
+    assert y.shape == yr.shape
+    errs = dict(y=rel(y, yr), dx=rel(hx, gx), dw=rel(hw, gw), db=rel(hb, gb))
+    print(case, 'direct' if force_direct else 'auto', errs)
+    assert all(e < 2e-5 for e in errs.values()), errs
+
+
+def test_conv_paths_reported():
+    from neuroclear_amd._lib import I, lib
+    L = lib()
+    assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
+    assert L.nc_conv_fwd_path(I(64), I(64), I(5), I(5), I(5), I(1), I(2)) == 1
+    assert L.nc_conv_wgrad_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
+    assert L.nc_conv_fwd_path(I(1), I(64), I(3), I(3), I(3), I(1), I(1)) == 0
+    assert L.nc_conv_fwd_path(I(64), I(128), I(1), I(4), I(4), I(2), I(1)) == 0
+
+
+@pytest.mark.parametrize('shape', [(1, 256, 4, 5, 6), (2, 128, 3, 4, 4)])
+def test_convT(shape):
+    N, C = shape[:2]
+    K = C // 2
+    x = T(5, shape).requires_grad_(True)
+    w = T(6, (C, K, 2, 2, 2), scale=0.1).requires_grad_(True)
+    b = T(7, (K,), scale=0.1).requires_grad_(True)
+    yr = F.conv_transpose3d(x, w, b, stride=2)
+    r = T(8, yr.shape)
+    g = torch.autograd.grad((yr * r).sum(), (x, w, b))
+    x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    y = ops.conv_transpose_k2s2(x2, w2, b2)
+    h = torch.autograd.grad((y * r).sum(), (x2, w2, b2))
+    errs = [rel(y, yr)] + [rel(a, c) for a, c in zip(h, g)]
+    print(errs)
+    assert all(e < 1e-5 for e in errs), errs
+
+
+@pytest.mark.parametrize('shape,slope,shift', [((1, 64, 20, 20, 20), 0.0, 0.0), ((2, 16, 9, 9, 9), 0.0, 0.0),
+                                               ((3, 128, 17, 17), 0.2, 0.0), ((1, 16, 20, 20, 20), 0.0, 100.0)])
+def test_instnorm_act(shape, slope, shift):
+    x = (T(9, shape, scale=0.05 if shift else 1.0, shift=shift)).requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(x.double(), eps=1e-5), slope) if slope else F.relu(F.instance_norm(x.double(), eps=1e-5))
+    r = T(10, shape)
+    (gx,) = torch.autograd.grad((yr * r.double()).sum(), x)
+    x2 = x.detach().clone().requires_grad_(True)
+    y = ops.instance_norm_act(x2, slope)
+    (hx,) = torch.autograd.grad((y * r).sum(), x2)
+    e = (rel(y, yr), rel(hx, gx))
+    print(shape, e)
+    assert e[0] < (2e-3 if shift else 2e-6) and e[1] < (2e-3 if shift else 2e-5), e
+
+
+def test_pool_sigmoid_lrelu():
+    for shape in [(1, 64, 12, 12, 12), (1, 8, 13, 11, 9), (2, 4, 10, 10)]:
+        x = T(11, shape).requires_grad_(True)
+        pool = F.max_pool3d if len(shape) == 5 else F.max_pool2d
+        yr = pool(x, 2)
+        r = T(12, yr.shape)
+        (gx,) = torch.autograd.grad((yr * r).sum(), x)
+        x2 = x.detach().clone().requires_grad_(True)
+        y = ops.maxpool2(x2)
+        (hx,) = torch.autograd.grad((y * r).sum(), x2)
+        assert torch.equal(y, yr) and torch.equal(hx, gx), shape
+    x = T(13, (5, 7, 33), scale=6).requires_grad_(True)
+    for mine, ref in ((ops.sigmoid, torch.sigmoid), (lambda t: ops.leaky_relu(t, 0.2), lambda t: F.leaky_relu(t, 0.2))):
+        yr = ref(x)
+        (gx,) = torch.autograd.grad(yr.sum(), x)
+        x2 = x.detach().clone().requires_grad_(True)
+        y = mine(x2)
+        (hx,) = torch.autograd.grad(y.sum(), x2)
+        assert rel(y, yr) < 1e-6 and rel(hx, gx) < 1e-6
+
+
+def test_slice_mip():
+    vol = T(14, (2, 1, 10, 12, 14)).requires_grad_(True)
+    for axis in range(3):
+        idx = [3, 7, 13][axis]
+        ref = [vol[:, :, idx], vol[:, :, :, idx], vol[:, :, :, :, idx]][axis]
+        r = T(15, ref.shape)
+        (g,) = torch.autograd.grad((ref * r).sum(), vol)
+        v2 = vol.detach().clone().requires_grad_(True)
+        out = ops.volume_slice(v2, axis, idx)
+        (h,) = torch.autograd.grad((out * r).sum(), v2)
+        assert torch.equal(out, ref) and torch.equal(h, g)
+        start, depth = 2, 5
+        roi = [vol[:, :, start:start + depth], vol[:, :, :, start:start + depth], vol[..., start:start + depth]][axis]
+        ref = torch.max(roi, axis + 2)[0]
+        (g,) = torch.autograd.grad((ref * r).sum(), vol)
+        v2 = vol.detach().clone().requires_grad_(True)
+        out = ops.volume_mip(v2, axis, start, depth)
+        (h,) = torch.autograd.grad((out * r).sum(), v2)
+        assert torch.equal(out, ref) and torch.equal(h, g)
+
+
+def test_losses_and_adam():
+    p = T(16, (1, 1, 11, 11)).requires_grad_(True)
+    for tgt in (1.0, 0.0):
+        ref = F.mse_loss(p, torch.full_like(p, tgt)) * 0.37
+        (g,) = torch.autograd.grad(ref, p)
+        p2 = p.detach().clone().requires_grad_(True)
+        out = ops.mse_const(p2, tgt) * 0.37
+        (h,) = torch.autograd.grad(out, p2)
+        assert abs(float(out) - float(ref)) < 1e-6 * abs(float(ref)) + 1e-9 and rel(h, g) < 1e-6
+    a = T(17, (1, 1, 20, 20, 20)).requires_grad_(True)
+    b = T(18, (1, 1, 20, 20, 20))
+    ref = F.l1_loss(a, b) * 5.0
+    (g,) = torch.autograd.grad(ref, a)
+    a2 = a.detach().clone().requires_grad_(True)
+    out = ops.l1_loss(a2, b) * 5.0
+    (h,) = torch.autograd.grad(out, a2)
+    assert abs(float(out) - float(ref)) < 1e-6 * abs(float(ref)) and rel(h, g) < 1e-6
+    # Adam: 3 steps against torch.optim.Adam (lr 1e-4, betas (0.1, 0.999) -- options/train_options.py:35-36)
+    w = T(19, (1000,))
+    wr = w.clone().requires_grad_(True)
+    opt = torch.optim.Adam([wr], lr=1e-4, betas=(0.1, 0.999))
+    m = torch.zeros_like(w)
+    v = torch.zeros_like(w)
+    for step in range(1, 4):
+        g = T(20 + step, (1000,))
+        wr.grad = g.clone()
+        opt.step()
+        ops.adam_step(w, g, m, v, 1e-4, 0.1, 0.999, 1e-8, step)
+    assert rel(w, wr.detach()) < 1e-6
+    assert float((w - wr.detach()).abs().max()) < 1e-7
