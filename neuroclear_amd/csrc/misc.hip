@@ -18,18 +18,6 @@ __device__ __forceinline__ long vol_index(int D, int H, int W, int axis, int a, 
   return ((long)a * H + b) * W + s;
 }
 
-__global__ void k_slice_fwd(const float* __restrict__ vol, float* __restrict__ out, int NC, int D, int H, int W,
-                            int axis, int index) {
-  int A, B;
-  plane_dims(D, H, W, axis, A, B);
-  const long total = (long)NC * A * B;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i % B), a = (int)((i / B) % A);
-    const long nc = i / ((long)A * B);
-    out[i] = vol[nc * D * H * W + vol_index(D, H, W, axis, a, b, index)];
-  }
-}
-
 __global__ void k_slice_bwd(const float* __restrict__ dout, float* __restrict__ dvol, int NC, int D, int H, int W,
                             int axis, int index) {
   int A, B;
@@ -64,7 +52,7 @@ __global__ void k_mip_fwd(const float* __restrict__ vol, float* __restrict__ out
       }
     }
     out[i] = best;
-    arg[i] = bi;
+    if (arg) arg[i] = bi;
   }
 }
 
@@ -164,8 +152,9 @@ int nc_slice_fwd(const float* vol, float* out, int NC, int D, int H, int W, int 
   if (!vol || !out) { set_error("slice_fwd: null pointer"); return NC_ERR_ARG; }
   if (int e = vol_check("slice_fwd", NC, D, H, W, axis)) return e;
   if (index < 0 || index >= axis_len(D, H, W, axis)) { set_error("slice_fwd: index out of range"); return NC_ERR_SHAPE; }
-  hipLaunchKernelGGL(k_slice_fwd, dim3(flat_grid((long)NC * D * H * W / axis_len(D, H, W, axis))), dim3(256), 0,
-                     (hipStream_t)stream, vol, out, NC, D, H, W, axis, index);
+  // a slice is a depth-1 projection: one gather kernel serves both
+  hipLaunchKernelGGL(k_mip_fwd, dim3(flat_grid((long)NC * D * H * W / axis_len(D, H, W, axis))), dim3(256), 0,
+                     (hipStream_t)stream, vol, out, (int32_t*)nullptr, NC, D, H, W, axis, index, 1);
   return check_launch("slice_fwd");
 }
 int nc_slice_bwd(const float* dout, float* dvol, int NC, int D, int H, int W, int axis, int index, void* stream) {
