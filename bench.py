@@ -1,0 +1,220 @@
+"""bench.py -- headline benchmark of the MI355X hot path (contract: see the task statement / DESIGN.md 'Measurement').
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload at every N (BASELINE.json configs[1]): one *step* = one `optimize_parameters()` of the Apollo model
+(axial_to_lateral_gan_apollo: unet_deconv G_A + deep_linear_gen G_B + four 2-D PatchGANs, LSGAN + InstanceNorm,
+fp32) on one 108^3 crop, batch 1, per GPU.  Inputs are synthetic random uint16 crops already resident in HBM; weights
+are random-init (kaiming), as the reference would start.  Scaling is WEAK: every rank trains on its own crop and the
+gradients are all-reduced (RCCL) once per optimizer phase.  value = voxels fed to G_A per second over all ranks.
+
+Extra objects on the JSON line:
+  roofline     -- for the kernel class that took most of the timed region: algorithmic FLOP / launch, measured with HIP
+                  events on the launch stream inside the timed steps (neuroclear_amd.ops.prof), against the dense fp32
+                  MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s).
+  cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32, all host cores) on a
+                  bounded sample (one step on a smaller crop), rank 0 and N = 1 only.
+`--workload infer` benches BASELINE.json configs[2] instead (900^3 diced inference, cubes sharded over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
+KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
+    'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
+    'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_mfma<3,2>', 'wgrad_mfma_k5': 'k_wgrad_mfma<5,1>',
+}
+
+
+def apollo_opt(gpu):
+    """The README training command (reference README.md:123-133) reduced to what the step uses."""
+    return Namespace(gpu_ids=[gpu], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='bench',
+                     preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
+                     min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64,
+                     ndf=64, netG='unet_deconv', netG_B='deep_linear_gen', netD='basic', n_layers_D=3,
+                     norm='instance', no_dropout=True, init_type='kaiming', init_gain=0.02, lr=1e-4, beta1=0.1,
+                     direction='AtoB', model='axial_to_lateral_gan_apollo')
+
+
+def cpu_baseline_train(crop=32):
+    """Oracle Apollo step on the host cores, one step on a crop^3 volume (bounded: ~10-30 s)."""
+    import torch
+    from neuroclear_amd.util import seed as S
+    from oracle import apollo as oapollo
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    specs = [('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] + \
+        [(n, S.patchgan_spec(2)) for n in oapollo.APOLLO_D]
+    sds = {n: S.weights_from_seed(sp, 7 + i, bias_scale=0.0) for i, (n, sp) in enumerate(specs)}
+    model = oapollo.ApolloOracle(sds)
+    real = torch.from_numpy((S.random_volume(11, crop).astype(np.float64) / 65535.0).astype(np.float32))[None, None]
+    np.random.seed(0)
+    t0 = time.time()
+    model.step(real)
+    dt = time.time() - t0
+    return dict(value=crop ** 3 / dt, unit='voxels/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 Apollo optimize_parameters() step on a %d^3 crop (oracle/apollo.py, torch-CPU fp32), '
+                       '%.1f s' % (crop, dt))
+
+
+def run_train(args, rank, world, dev):
+    import torch
+    import torch.distributed as dist
+    from neuroclear_amd import ops
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.util import seed as S
+
+    crop = args.crop
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(apollo_opt(dev.index))
+    if world > 1:  # identical replicas: broadcast rank 0's parameters (one flat buffer per optimizer)
+        for opt in model.optimizers:
+            dist.broadcast(opt.flat, 0)
+    vol = S.random_volume(100 + rank, crop)  # synthetic uint16 crop, normalised as data/base_dataset.py:134-143
+    real = torch.from_numpy((vol.astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev)
+    data = {'A': real, 'A_paths': 'synthetic'}
+
+    def step():
+        model.set_input(data)
+        model.optimize_parameters()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.prof = ops.prof, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # ---- per-kernel-class event statistics of the timed region (rank-local)
+    stats = {}
+    for tag, flop, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        s = stats.setdefault(tag, [0, 0.0, 0.0])
+        s[0] += 1
+        s[1] += ms
+        s[2] += flop
+    conv_ms = sum(s[1] for s in stats.values())
+    top = max((t for t in stats if 'mfma' in t), key=lambda t: stats[t][1], default=None)
+    roof = None
+    if top:
+        n, ms, flop = stats[top]
+        ach = flop / ms / 1e9
+        roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
+                    peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    traffic=None, launches=n, avg_launch_ms=round(ms / n, 4),
+                    gflop_per_launch=round(flop / n / 1e9, 2),
+                    share_of_step=round(ms / (dt * 1e3), 4),
+                    classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
+                                     tflops=round(s[2] / s[1] / 1e9, 2)) for t, s in sorted(stats.items())},
+                    conv_ms_per_step=round(conv_ms / args.steps, 2))
+    losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
+    return dt, crop ** 3 * args.steps * world, roof, dict(workload='apollo_train_step_108cube_bs1', crop=crop,
+                                                           batch_size=1, parallelism='dp%d' % world,
+                                                           gan_mode='lsgan', norm='instance', losses=losses)
+
+
+def run_infer(args, rank, world, dev):
+    """configs[2]: 900^3 synthetic volume, dice 120 / overlap 15 / border_cut 10 -> 729 cubes of 140^3, cube i on rank
+    i % world; every rank scatter-adds its own cubes, partial accumulators are summed on rank 0 (one reduce)."""
+    import torch
+    import torch.distributed as dist
+    from neuroclear_amd.test_dice import diced_inference
+    from neuroclear_amd.models import networks
+    from neuroclear_amd.util import seed as S
+    L = args.volume
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [dev.index])
+    vol = S.random_volume(5, L)
+    opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[dev.index], skip_real=True,
+                    data_type='uint16', histogram_match=False, normalize_intensity=False)
+    for _ in range(args.warmup):
+        diced_inference(net, vol, opt, rank, world, max_cubes=world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = diced_inference(net, vol, opt, rank, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    del out
+    return dt, L ** 3 * args.steps, None, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
+                                               parallelism='cubes%%%d' % world)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--crop', type=int, default=108)
+    ap.add_argument('--volume', type=int, default=900)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs the MI355X (no CPU fallback)')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    if args.gpus != world:
+        if rank == 0:
+            print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+
+    run = run_train if args.workload == 'train' else run_infer
+    dt, units, roof, cfg = run(args, rank, world, dev)
+    out = dict(metric='voxels/sec', value=units / dt, unit='voxels/s', n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='f32', data='synthetic', config=cfg)
+    if roof:
+        out['roofline'] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train':
+        try:
+            out['cpu_baseline'] = cpu_baseline_train()
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            out['cpu_baseline'] = dict(error=str(e))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

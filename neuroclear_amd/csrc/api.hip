@@ -29,18 +29,22 @@ void nc_set_force_direct(int on) { g_force_direct = on; }
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
-  return (!g_force_direct && mfma_fwd_supported(d)) ? 1 : 0;
+  if (g_force_direct) return 0;
+  return mfma_fwd_supported(d) ? 1 : gemm_fwd_supported(d) ? 2 : 0;
 }
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
-  return (!g_force_direct && mfma_wgrad_supported(d)) ? 1 : 0;
+  if (g_force_direct) return 0;
+  return mfma_wgrad_supported(d) ? 1 : gemm_wgrad_supported(d) ? 2 : 0;
 }
 
 size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return 0;
   size_t b = mfma_ws_bytes(d);
+  const size_t g = gemm_ws_bytes(d);
+  if (g > b) b = g;
   return (b + 255) & ~(size_t)255;
 }
 
@@ -61,6 +65,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   if (int e = conv_args("conv_fwd", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
+  if (!g_force_direct && gemm_fwd_supported(d)) return conv_fwd_gemm(x, w, bias, y, d, ws, ws_bytes, s);
   return conv_fwd_direct(x, w, bias, y, d, s);
 }
 
@@ -70,6 +75,8 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
+  if (!g_force_direct && to1_dgrad_supported(d)) return conv_dgrad_to1(dy, w, dx, d, s);
+  if (!g_force_direct && gemm_dgrad_supported(d)) return conv_dgrad_gemm(dy, w, dx, d, ws, ws_bytes, s);
   return conv_dgrad_direct(dy, w, dx, d, s);
 }
 
@@ -80,6 +87,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   hipStream_t s = (hipStream_t)stream;
   int e;
   if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
+  else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
   if (e) return e;
   if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, s);

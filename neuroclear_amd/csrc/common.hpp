@@ -58,6 +58,22 @@ int conv_dgrad_mfma(const float* dy, const float* w, float* dx, const ConvDims& 
 int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s);
 
+// ---- generic gather-GEMM MFMA kernels, conv_gemm.hip
+bool gemm_fwd_supported(const ConvDims& d);
+bool gemm_dgrad_supported(const ConvDims& d);
+bool gemm_wgrad_supported(const ConvDims& d);
+size_t gemm_ws_bytes(const ConvDims& d);
+int conv_fwd_gemm(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                  hipStream_t s);
+int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s);
+int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s);
+
+// ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
+bool to1_dgrad_supported(const ConvDims& d);
+int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+
 extern int g_force_direct;
 
 }  // namespace nc

@@ -1,0 +1,318 @@
+// Generic implicit-GEMM convolution on the fp32 matrix cores (gfx950): any kernel size, stride, padding, 2-D or 3-D.
+// Covers what the brick kernels (conv_mfma_*.hip) do not: the strided 4x4 PatchGAN convs (reference
+// models/networks.py:1030-1057), the 1x1 tails (:507-508, :905-911) and the Cin = 1 first layers (:420, :899).
+//
+//   FWD   : Y[k][p]      = sum_r  W[k][r]        * Xcol[r][p]      r = (c, tap), p = (n, od, oh, ow)
+//   DGRAD : dX[c][q]     = sum_r' W'[c][r']      * dYcol[r'][q]    r' = (k, tap), q = (n, iz, iy, ix)
+//   WGRAD : dW[k][r]     = sum_p  dY[k][p]       * Xcol[r][p]      (reduction over positions, split over grid.z)
+//
+// One workgroup = 4 waves = a 64 x 64 output tile, v_mfma_f32_32x32x2_f32 (one 32x32 accumulator per wave); the
+// reduction runs in chunks of 16 staged through LDS as [r][64] images (32 consecutive floats per half-wave read:
+// conflict-free).  The B image is gathered (im2col on the fly): the reduction index of a gathered element is
+// wave-uniform, so its (channel, tap) decode lives on the scalar unit; the per-lane output position is decoded once.
+// Register-staged double buffering (global loads of chunk i+1 are issued before the MFMAs of chunk i).
+#include "common.hpp"
+
+namespace nc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { G_FWD = 0, G_DGRAD = 1, G_WGRAD = 2 };
+
+struct GemmParams {
+  const float* a;   // FWD/DGRAD: weights; WGRAD: dy
+  const float* b;   // FWD: x; DGRAD: dy; WGRAD: x
+  const float* bias;
+  float* out;       // FWD: y; DGRAD: dx; WGRAD: slab[split][K][R]
+  ConvDims d;
+  int M, N, R;      // GEMM sizes (rows, columns, reduction)
+  int taps, khw;    // kd*kh*kw, kh*kw
+  long S, So;       // input / output positions per image
+  int splits, rper; // WGRAD: reduction range per split (multiple of 16)
+};
+
+static constexpr int kAP = 65;  // pitch of the A image (floats)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
+  __shared__ float As[2][16 * kAP];
+  __shared__ float Bs[2][16 * 64];
+  const ConvDims& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  // the reduction may be split over grid.z (small outputs with a long reduction: PatchGAN tail layers, wgrad)
+  const int r_begin = p.splits > 1 ? blockIdx.z * p.rper : 0;
+  const int r_end = p.splits > 1 ? min(p.R, r_begin + p.rper) : p.R;
+  const int HW = d.H * d.W, HoWo = d.Ho * d.Wo;
+
+  // ---- per-lane column (n) decode for the gathered B image: n_l = tid & 63
+  const int ncol = n0 + (tid & 63);
+  const bool ncol_ok = ncol < p.N;
+  int nb = 0, c0 = 0, c1 = 0, c2 = 0;  // FWD: (n, od, oh, ow); DGRAD: (n, iz, iy, ix); WGRAD: (c, tz, ty, tx)
+  if (ncol_ok) {
+    if (MODE == G_FWD) {
+      nb = ncol / (int)p.So;
+      const int pos = ncol - nb * (int)p.So;
+      c0 = pos / HoWo; c1 = (pos - c0 * HoWo) / d.Wo; c2 = pos - c0 * HoWo - c1 * d.Wo;
+    } else if (MODE == G_DGRAD) {
+      nb = ncol / (int)p.S;
+      const int pos = ncol - nb * (int)p.S;
+      c0 = pos / HW; c1 = (pos - c0 * HW) / d.W; c2 = pos - c0 * HW - c1 * d.W;
+    } else {
+      nb = ncol / p.taps;  // channel c
+      const int tap = ncol - nb * p.taps;
+      c0 = tap / p.khw; c1 = (tap - c0 * p.khw) / d.kw; c2 = tap - c0 * p.khw - c1 * d.kw;
+    }
+  }
+  // ---- A image assignment: r_l = tid & 15 (fast, contiguous in memory), m_l = (tid >> 4) + 16 j
+  const int ar = tid & 15, am = tid >> 4;
+
+  float ra[4], rb[4];
+  auto load_chunk = [&](int r0) {
+    // A
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + am + 16 * j, r = r0 + ar;
+      float v = 0.f;
+      if (m < p.M && r < r_end) {
+        if (MODE == G_FWD) {
+          v = p.a[(long)m * p.R + r];
+        } else if (MODE == G_DGRAD) {
+          const int k = r / p.taps, tap = r - k * p.taps;
+          v = p.a[((long)k * d.C + m) * p.taps + tap];
+        } else {
+          const int b = d.N > 1 ? r / (int)p.So : 0;
+          const int pos = r - b * (int)p.So;
+          v = p.a[((long)b * d.K + m) * p.So + pos];
+        }
+      }
+      ra[j] = v;
+    }
+    // B (gathered): reduction index is wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + wave + 4 * j;
+      float v = 0.f;
+      if (r < r_end && ncol_ok) {
+        if (MODE == G_FWD) {
+          const int c = r / p.taps, tap = r - c * p.taps;
+          const int tz = tap / p.khw, ty = (tap - tz * p.khw) / d.kw, tx = tap - tz * p.khw - ty * d.kw;
+          const int iz = c0 * d.sd - d.pd + tz, iy = c1 * d.sh - d.ph + ty, ix = c2 * d.sw - d.pw + tx;
+          if ((unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
+            v = p.b[((long)nb * d.C + c) * p.S + (long)iz * HW + iy * d.W + ix];
+        } else if (MODE == G_DGRAD) {
+          const int k = r / p.taps, tap = r - k * p.taps;
+          const int tz = tap / p.khw, ty = (tap - tz * p.khw) / d.kw, tx = tap - tz * p.khw - ty * d.kw;
+          const int uz = c0 + d.pd - tz, uy = c1 + d.ph - ty, ux = c2 + d.pw - tx;
+          if (uz >= 0 && uy >= 0 && ux >= 0) {
+            const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
+            if (od * d.sd == uz && oh * d.sh == uy && ow * d.sw == ux && od < d.Do && oh < d.Ho && ow < d.Wo)
+              v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
+          }
+        } else {
+          const int b = d.N > 1 ? r / (int)p.So : 0;
+          const int pos = r - b * (int)p.So;
+          const int od = pos / HoWo, oh = (pos - od * HoWo) / d.Wo, ow = pos - od * HoWo - oh * d.Wo;
+          const int iz = od * d.sd - d.pd + c0, iy = oh * d.sh - d.ph + c1, ix = ow * d.sw - d.pw + c2;
+          if ((unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
+            v = p.b[((long)b * d.C + nb) * p.S + (long)iz * HW + iy * d.W + ix];
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) As[buf][ar * kAP + am + 16 * j] = ra[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[buf][(wave + 4 * j) * 64 + (tid & 63)] = rb[j];
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  int buf = 0;
+  if (r_begin < r_end) {
+    load_chunk(r_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int r0 = r_begin; r0 < r_end; r0 += 16) {
+    const bool more = r0 + 16 < r_end;
+    if (more) load_chunk(r0 + 16);
+    const float* A = As[buf] + wm * 32 + li + h * kAP;
+    const float* B = Bs[buf] + wn * 32 + li + h * 64;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2 * kk * kAP], B[2 * kk * 64], acc, 0, 0, 0);
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: row (m) = (r&3) + 8*(r>>2) + 4*h, column (n) = li
+  const int n = n0 + wn * 32 + li;
+  if (n < p.N) {
+    long base;
+    long mstride;
+    if (MODE == G_FWD) {
+      const int b = n / (int)p.So;
+      base = (long)blockIdx.z * d.N * d.K * p.So + (long)b * d.K * p.So + (n - (long)b * p.So);
+      mstride = p.So;
+    } else if (MODE == G_DGRAD) {
+      const int b = n / (int)p.S;
+      base = (long)blockIdx.z * d.N * d.C * p.S + (long)b * d.C * p.S + (n - (long)b * p.S);
+      mstride = p.S;
+    } else {
+      base = (long)blockIdx.z * p.M * p.N + n;
+      mstride = p.N;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < p.M) {
+        float v = acc[r];
+        if (MODE == G_FWD && p.bias && p.splits == 1) v += p.bias[m];
+        p.out[base + (long)m * mstride] = v;
+      }
+    }
+  }
+}
+
+// out[i] = bias[(i / inner) % K] + sum_k slab[k][i]   (fixed order: deterministic)
+__global__ void k_gemm_split_reduce(const float* __restrict__ slab, float* __restrict__ out, long n, int splits,
+                                    const float* __restrict__ bias, long inner, int K) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = bias ? bias[(i / inner) % K] : 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[(long)k * n + i];
+    out[i] = s;
+  }
+}
+
+static void gemm_common(GemmParams& p, const ConvDims& d) {
+  p.d = d;
+  p.taps = d.kd * d.kh * d.kw;
+  p.khw = d.kh * d.kw;
+  p.S = (long)d.D * d.H * d.W;
+  p.So = (long)d.Do * d.Ho * d.Wo;
+  p.splits = 1;
+  p.rper = 0;
+}
+
+static bool gemm_range_ok(const ConvDims& d) {
+  const long S = (long)d.D * d.H * d.W, So = (long)d.Do * d.Ho * d.Wo;
+  return (long)d.N * S < (1L << 31) && (long)d.N * So < (1L << 31) && (long)d.C * d.kd * d.kh * d.kw < (1L << 31) &&
+         (long)d.K * d.kd * d.kh * d.kw < (1L << 31);
+}
+
+// MFMA tiles are 64 x 64: a GEMM with fewer than 16 rows wastes most of the matrix core, which only pays when the
+// whole (padded) problem is small and the reduction is long enough to want the split-R parallelism anyway.
+static bool padded_ok(long M, long N, long R) {
+  if (M >= 16) return true;
+  const double padded = 2.0 * cdiv(M, 64) * 64 * cdiv(N, 64) * 64 * (double)R;
+  return R >= 256 && padded <= 30e9;
+}
+static long Rf(const ConvDims& d) { return (long)d.C * d.kd * d.kh * d.kw; }
+static long Rd(const ConvDims& d) { return (long)d.K * d.kd * d.kh * d.kw; }
+static long Po(const ConvDims& d) { return (long)d.N * d.Do * d.Ho * d.Wo; }
+static long Pi(const ConvDims& d) { return (long)d.N * d.D * d.H * d.W; }
+
+bool gemm_fwd_supported(const ConvDims& d) { return gemm_range_ok(d) && padded_ok(d.K, Po(d), Rf(d)); }
+bool gemm_dgrad_supported(const ConvDims& d) { return gemm_range_ok(d) && padded_ok(d.C, Pi(d), Rd(d)); }
+bool gemm_wgrad_supported(const ConvDims& d) { return gemm_range_ok(d) && padded_ok(d.K, Rf(d), Po(d)); }
+
+static int pick_splits(long M, long N, long R) {
+  const long tiles = cdiv(M, 64) * cdiv(N, 64);
+  if (tiles >= 256) return 1;
+  long s = cdiv(512, tiles);      // aim at >= 512 workgroups
+  const long cap = cdiv(R, 128);  // at least 8 chunks of 16 per split
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  return (int)(s < 1 ? 1 : s);
+}
+static int fwd_splits(const ConvDims& d) { return pick_splits(d.K, Po(d), Rf(d)); }
+static int dgrad_splits(const ConvDims& d) { return pick_splits(d.C, Pi(d), Rd(d)); }
+static int wgrad_splits(const ConvDims& d) { return pick_splits(d.K, Rf(d), Po(d)); }
+
+size_t gemm_ws_bytes(const ConvDims& d) {
+  size_t need = 0;
+  auto upd = [&](bool ok, int splits, size_t elems) {
+    if (ok && splits > 1 && (size_t)splits * elems * sizeof(float) > need) need = (size_t)splits * elems * sizeof(float);
+  };
+  upd(gemm_fwd_supported(d), fwd_splits(d), (size_t)d.K * Po(d));
+  upd(gemm_dgrad_supported(d), dgrad_splits(d), (size_t)d.C * Pi(d));
+  upd(gemm_wgrad_supported(d), wgrad_splits(d), (size_t)d.K * Rf(d));
+  return need;
+}
+
+static int split_setup(GemmParams& p, int splits, float* out, void* ws, size_t wsb, size_t out_elems,
+                       const char* what) {
+  p.splits = splits;
+  p.rper = (int)(cdiv(cdiv(p.R, splits), 16) * 16);
+  if (splits > 1) {
+    if (!ws || wsb < (size_t)splits * out_elems * sizeof(float)) {
+      set_error("%s: workspace too small", what);
+      return NC_ERR_WS;
+    }
+    p.out = (float*)ws;
+  } else {
+    p.out = out;
+  }
+  return NC_OK;
+}
+static int split_reduce(const GemmParams& p, float* out, long n, const float* bias, long inner, int K,
+                        hipStream_t s) {
+  if (p.splits == 1) return NC_OK;
+  const long nb = cdiv(n, 256);
+  hipLaunchKernelGGL(k_gemm_split_reduce, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s,
+                     (const float*)p.out, out, n, p.splits, bias, inner, K);
+  return check_launch("gemm_split_reduce");
+}
+
+int conv_fwd_gemm(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                  hipStream_t s) {
+  GemmParams p{};
+  gemm_common(p, d);
+  p.a = w; p.b = x; p.bias = b;
+  p.M = d.K; p.N = (int)Po(d); p.R = (int)Rf(d);
+  const long n = (long)d.K * Po(d);
+  if (int e = split_setup(p, fwd_splits(d), y, ws, wsb, n, "conv_fwd_gemm")) return e;
+  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+  hipLaunchKernelGGL(k_conv_gemm<G_FWD>, grid, dim3(256), 0, s, p);
+  if (int e = check_launch("conv_fwd_gemm")) return e;
+  return split_reduce(p, y, n, b, p.So, d.K, s);
+}
+
+int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s) {
+  GemmParams p{};
+  gemm_common(p, d);
+  p.a = w; p.b = dy; p.bias = nullptr;
+  p.M = d.C; p.N = (int)Pi(d); p.R = (int)Rd(d);
+  const long n = (long)d.C * Pi(d);
+  if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
+  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+  hipLaunchKernelGGL(k_conv_gemm<G_DGRAD>, grid, dim3(256), 0, s, p);
+  if (int e = check_launch("conv_dgrad_gemm")) return e;
+  return split_reduce(p, dx, n, nullptr, 1, 1, s);
+}
+
+int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                    hipStream_t s) {
+  GemmParams p{};
+  gemm_common(p, d);
+  p.a = dy; p.b = x; p.bias = nullptr;
+  p.M = d.K; p.N = (int)Rf(d); p.R = (int)Po(d);
+  const long n = (long)p.M * p.N;
+  if (int e = split_setup(p, wgrad_splits(d), dw, ws, wsb, n, "conv_wgrad_gemm")) return e;
+  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+  hipLaunchKernelGGL(k_conv_gemm<G_WGRAD>, grid, dim3(256), 0, s, p);
+  if (int e = check_launch("conv_wgrad_gemm")) return e;
+  return split_reduce(p, dw, n, nullptr, 1, 1, s);
+}
+
+}  // namespace nc

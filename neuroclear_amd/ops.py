@@ -10,6 +10,35 @@ from ._lib import F, I, L_, P, Z, check, lib
 
 _ws_cache = {}
 
+# Optional live profiler (bench.py): when `prof` is a list, every convolution C call is bracketed by HIP events on the
+# stream it is launched on and (tag, algorithmic FLOP, start, end) is appended.
+prof = None
+
+
+def _prof_begin():
+    if prof is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, tag, flop):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((tag, flop, e0, e1))
+
+
+def _conv_tag(op, C, K, k3, stride, pad, out_vox):
+    mf = lib().nc_conv_wgrad_path if op == 'wgrad' else lib().nc_conv_fwd_path
+    if op == 'dgrad':
+        path = lib().nc_conv_fwd_path(I(K), I(C), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
+    else:
+        path = mf(I(C), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
+    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm'}.get(path, 'direct'), k3[1])
+    return tag, 2.0 * C * K * k3[0] * k3[1] * k3[2] * out_vox
+
 
 def _stream():
     return P(torch.cuda.current_stream().cuda_stream)
@@ -82,8 +111,11 @@ def conv_fwd_raw(x, w, b, stride, pad):
         raise _lib.NcError('conv: weight expects %d input channels, got %d' % (w.shape[1], C))
     y = torch.empty(_conv_out_shape(x.shape, w.shape, stride, pad), dtype=torch.float32, device=x.device)
     ws = _conv_ws(dims, K, k3, stride, pad, x.device)
+    e0 = _prof_begin()
     check(lib().nc_conv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                             I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_fwd')
+    if e0 is not None:
+        _prof_end(e0, *_conv_tag('fwd', C, K, k3, stride, pad, y.numel() // K))
     return y
 
 
@@ -96,8 +128,11 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     k3 = _kdims(w.shape)
     K = w.shape[0]
     ws = _conv_ws(dims, K, k3, stride, pad, dy.device)
+    e0 = _prof_begin()
     check(lib().nc_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]),
                               I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_dgrad')
+    if e0 is not None:
+        _prof_end(e0, *_conv_tag('dgrad', C, K, k3, stride, pad, dy.numel() // K))
     return dx
 
 
@@ -111,9 +146,12 @@ def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias):
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
     ws = _conv_ws(dims, K, k3, stride, pad, x.device)
+    e0 = _prof_begin()
     check(lib().nc_conv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                               I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()),
           'nc_conv_wgrad')
+    if e0 is not None:
+        _prof_end(e0, *_conv_tag('wgrad', C, K, k3, stride, pad, dy.numel() // K))
     return dw, db
 
 

@@ -1,0 +1,104 @@
+"""Diced-volume inference on MI355X (reference: test_dice.py:50-157 -- the loop `for data in dataset: set_input; test;
+addToStack` followed by `assemble_all`).
+
+`diced_inference` is the loop itself, sharded over ranks the way SURVEY.md 8(e) describes: cube i belongs to rank
+i % world (cubes are independent units; no data-path collective is needed to COMPUTE them).  To keep the assembled
+volume bit-identical to the single-GPU / reference summation order, the cube outputs of each round are gathered to
+rank 0 over RCCL (one 11 MB tile per rank per round -- xGMI point-to-point) and overlap-added there in index order.
+`main()` keeps the reference's command line for the flags that matter on this path."""
+import numpy as np
+import torch
+
+from .data.diceImage_dataset import DiceImageDataSet
+from .util.assemble_dice import Assemble_Dice
+
+
+def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None):
+    """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0."""
+    import torch.distributed as dist
+    ds = DiceImageDataSet(opt, volume=volume)
+    n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
+    asm = Assemble_Dice(opt, ds.size_original()) if rank == 0 else None
+    E = opt.dice_size[0] + 2 * opt.border_cut
+    rounds = (n + world - 1) // world
+    with torch.no_grad():
+        for t in range(rounds):
+            i = t * world + rank
+            if i < n:
+                fake = netG(ds[i]['A'].unsqueeze(0)).reshape(E, E, E)
+            else:
+                fake = torch.zeros((E, E, E), dtype=torch.float32, device=ds.device)
+            if world == 1:
+                asm.add_cube('fake', fake, i)
+                continue
+            tiles = [torch.empty_like(fake) for _ in range(world)] if rank == 0 else None
+            dist.gather(fake, tiles, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    j = t * world + r
+                    if j < n:
+                        asm.add_cube('fake', tiles[r], j)
+    if rank != 0:
+        return None
+    asm.count['fake'] = asm.len_cube_queue if max_cubes is not None else n  # warm-up runs assemble a partial volume
+    asm.assemble_all()
+    return asm.getDict()['fake']
+
+
+def main(argv=None):
+    import argparse
+    import os
+    from . import models
+    p = argparse.ArgumentParser(description='test_dice.py on MI355X (reference README.md:150-157)')
+    p.add_argument('--dataroot', required=True)
+    p.add_argument('--name', default='experiment_name')
+    p.add_argument('--checkpoints_dir', default='./checkpoints')
+    p.add_argument('--results_dir', default='./results/')
+    p.add_argument('--gpu_ids', default='0')
+    p.add_argument('--model', default='test')
+    p.add_argument('--model_suffix', default='')
+    p.add_argument('--netG', default='unet_deconv')
+    p.add_argument('--norm', default='instance')
+    p.add_argument('--init_type', default='normal')
+    p.add_argument('--init_gain', type=float, default=0.02)
+    p.add_argument('--input_nc', type=int, default=1)
+    p.add_argument('--output_nc', type=int, default=1)
+    p.add_argument('--ngf', type=int, default=64)
+    p.add_argument('--image_dimension', type=int, default=3)
+    p.add_argument('--dice_size', type=int, nargs='+', default=[120, 120, 120])
+    p.add_argument('--overlap', type=int, default=15)
+    p.add_argument('--border_cut', type=int, default=10)
+    p.add_argument('--data_type', default='uint16')
+    p.add_argument('--epoch', default='latest')
+    p.add_argument('--load_iter', type=int, default=0)
+    p.add_argument('--skip_real', action='store_true')
+    p.add_argument('--no_dropout', action='store_true')
+    p.add_argument('--histogram_match', action='store_true')
+    p.add_argument('--normalize_intensity', action='store_true')
+    p.add_argument('--verbose', action='store_true')
+    opt = p.parse_args(argv)
+    opt.gpu_ids = [int(g) for g in opt.gpu_ids.split(',') if int(g) >= 0]
+    opt.isTrain, opt.continue_train, opt.preprocess = False, False, 'addColorChannel'
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        opt.gpu_ids = [int(os.environ.get('LOCAL_RANK', '0'))]
+        torch.cuda.set_device(opt.gpu_ids[0])
+        dist.init_process_group('nccl')
+    model = models.create_model(opt)
+    model.setup(opt)
+    from .data.diceImage_dataset import _load_volume
+    names = sorted(f for f in os.listdir(opt.dataroot) if f.endswith(('.npy', '.tif', '.tiff')))
+    vol = _load_volume(os.path.join(opt.dataroot, names[0]))
+    opt.skip_real = True
+    out = diced_inference(model.netG, vol, opt, rank, world)
+    if rank == 0:
+        d = os.path.join(opt.results_dir, opt.name, 'volumes')
+        os.makedirs(d, exist_ok=True)
+        np.save(os.path.join(d, 'output_volume.npy'), out)
+        print('re-merged image shape: {}'.format(out.shape))
+
+
+if __name__ == '__main__':
+    main()

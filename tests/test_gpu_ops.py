@@ -40,6 +40,7 @@ CONV_CASES = [
     (1, 128, 64, (6, 20, 36), 3, 1, 1),      # MFMA (ex_conv1_1 shape class)
     (1, 64, 64, (10, 12, 16), 5, 1, 2),      # MFMA 5^3
     (1, 1, 64, (12, 12, 12), 7, 1, 3),
+    (2, 1, 64, (9, 10, 70), 7, 1, 3),        # 7^3, ragged: exercises tile edges of the many->one dgrad kernel
     (1, 64, 1, (10, 10, 10), 1, 1, 0),
     (1, 1, 1, (8, 8, 8), 1, 1, 0),
     (1, 64, 32, (6, 6, 6), 1, 1, 0),
@@ -83,8 +84,9 @@ def test_conv_paths_reported():
     assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
     assert L.nc_conv_fwd_path(I(64), I(64), I(5), I(5), I(5), I(1), I(2)) == 1
     assert L.nc_conv_wgrad_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
-    assert L.nc_conv_fwd_path(I(1), I(64), I(3), I(3), I(3), I(1), I(1)) == 0
-    assert L.nc_conv_fwd_path(I(64), I(128), I(1), I(4), I(4), I(2), I(1)) == 0
+    assert L.nc_conv_fwd_path(I(1), I(64), I(3), I(3), I(3), I(1), I(1)) == 2
+    assert L.nc_conv_fwd_path(I(64), I(128), I(1), I(4), I(4), I(2), I(1)) == 2
+    assert L.nc_conv_fwd_path(I(64), I(1), I(1), I(1), I(1), I(1), I(0)) == 0
 
 
 @pytest.mark.parametrize('shape', [(1, 256, 4, 5, 6), (2, 128, 3, 4, 4)])
