@@ -3,24 +3,24 @@
 // models/networks.py:420-425,442,460-469,900-902.
 //
 // GEMM view:  dW[co][(ci,tap)] = sum_{n,v} dY[co][v] * X[ci][v + tap]        (M = co, N = ci x taps, K = voxels)
-//   * "weight stationary": a workgroup owns the accumulators of ONE dz plane of the kernel for a 64 x CIW block of
-//     (co, ci) -- KS^2 taps x (AB x 16 co) x 16 ci per wave in registers -- and walks over its share of voxel tiles.
-//     The kernel's dz planes / channel blocks are separate workgroup groups (grid.y); voxel partitions are grid.x.
-//   * v_mfma_f32_16x16x4_f32 (exact fp32): A = dY[16 co][4 voxels], B = X[4 voxels][16 ci], 4 accumulator registers per
-//     tile, so 9 (25) taps x AB co-blocks fit a wave.
-//   * tiles: Ty rows x Tx columns of one z plane, flattened with pitch Pp = Tx+2p (as in the forward kernel) so a tap is
-//     a constant LDS offset.  dY pad positions are staged as ZERO, so whatever X holds there contributes nothing.
-//   * LDS images are channel-major with pitch == 2 (mod 32) floats: the 16 channels x 2 voxels of a half-wave hit 32
-//     distinct banks for any tap shift (ds_read_b32).
-//   * register-staged double buffering across tiles (global loads for tile t+1 are issued before the MFMA loop of t).
-//   * deterministic: partial slabs per workgroup + a fixed-order reduce kernel; no atomics.
+//   * weight stationary: a workgroup owns the accumulators of ONE dz plane of the kernel for a 64 x CIW block of
+//     (co, ci) -- KS^2 taps x (AB x 16 co) x 16 ci per wave in registers (v_mfma_f32_16x16x4_f32, exact fp32) -- and
+//     streams its share of the volume through LDS.  dz planes / channel blocks are workgroup groups (grid.y), voxel
+//     partitions are grid.x; partial slabs + a fixed-order reduce kernel (deterministic, no atomics).
+//   * ROW STREAMING: the unit of work is one full image row (fixed n, z, y; all W columns).  Each step stages ONE new
+//     dY row [64 co][W] and ONE new X row [CIW ci][W] (row y+PAD of plane z+dz-PAD) into a ring of KS rows, so X is
+//     read once per dz group with no halo re-reads, and tile y's taps (dy, dx) are ring-slot + column offsets.
+//     Staging needs no per-lane index arithmetic at all: a wave copies whole rows, lane = column, the row's base
+//     address is wave-uniform (scalar unit).  Global loads of step s+1 are issued before the MFMA loop of step s.
+//   * LDS images are channel-major with pitch == 2 (mod 32): the 16 channels x 2 voxels of a half-wave hit 32 distinct
+//     banks for every tap shift (ds_read_b32); dY pad columns stay zero, so the 4-voxel k-steps may run past W.
 #include "common.hpp"
 
 namespace nc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int kNLDW = 32;
+static constexpr int kNSEG = 3;  // 64-column segments per row: W <= 192
 static constexpr int kLdsMaxW = 160 * 1024;
 
 struct WgParams {
@@ -28,24 +28,17 @@ struct WgParams {
   const float* dy;
   float* slab;
   int C, K, N, D, H, W;
-  int Ty, Tx, nty, ntx, Pp;
-  int QT, QT4, RX, PA, PB, NEdy, NEx, nDy;  // floats: dy real region, rounded, x real region, pitches, element counts
-  unsigned mPp, mQT, mRX;
+  int PR, PAr, QT4;    // X row pitch per channel, dY pitch per channel (floats), W rounded up to 4
   int CB, KBK, parts;  // channel blocks (C/CIW, K/64), voxel partitions
-  unsigned mNyx, mNx;  // magics for nty*ntx and ntx
 };
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
-// divisor may be 1 (magic would overflow): d is wave-uniform, so the select is a scalar branch
-__device__ __forceinline__ unsigned fdivd(unsigned n, unsigned m, unsigned d) { return d == 1 ? n : __umulhi(n, m); }
 
 template <int KS, int AB>
 __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
-  constexpr int NT = 512;
   constexpr int PAD = KS / 2;
   constexpr int T = KS * KS;
-  constexpr int CIW = 32 * AB;     // input channels per workgroup
-  constexpr int NCIB = CIW / 16;   // ci blocks (waves along ci)
+  constexpr int CIW = 32 * AB;    // input channels per workgroup
+  constexpr int NCIB = CIW / 16;  // ci blocks (waves along ci)
+  constexpr int XR = CIW / 8;     // X rows staged per wave per step
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -57,74 +50,17 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
   const int g = blockIdx.y;
   const int kbk = g % p.KBK, cb = (g / p.KBK) % p.CB, dz = g / (p.KBK * p.CB);
   const int part = blockIdx.x;
-
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
-  // valid output planes z for this dz: z + dz - PAD in [0, D)
+  // output planes z whose input plane z + dz - PAD exists
   const int zlo = max(0, PAD - dz), zhi = min(p.D, p.D + PAD - dz);
   const int Dv = max(0, zhi - zlo);
-  const int nyx = p.nty * p.ntx;
-  const long ntiles = (long)p.N * Dv * nyx;
-  const long t0 = ntiles * part / p.parts, t1 = ntiles * (part + 1) / p.parts;
+  const long nrows = (long)p.N * Dv * p.H;
+  const long r0 = nrows * part / p.parts, r1 = nrows * (part + 1) / p.parts;
 
-  const int bufsz = 64 * p.PA + CIW * p.PB;
-  float* buf0 = lds;
-  float* buf1 = lds + bufsz;
-  for (int i = tid; i < 2 * bufsz; i += NT) lds[i] = 0.f;
-  __syncthreads();
-
-  float st[kNLDW];
-  auto stage_load = [&](long t) {
-    const unsigned tt = (unsigned)t;
-    const unsigned nz = fdivd(tt, p.mNyx, nyx);
-    const unsigned yx = tt - nz * nyx;
-    const unsigned tyi = fdivd(yx, p.mNx, p.ntx), txi = yx - tyi * p.ntx;
-    const int n = (int)(nz / (unsigned)max(Dv, 1)), z = zlo + (int)(nz % (unsigned)max(Dv, 1));
-    const int y0 = tyi * p.Ty, x0 = txi * p.Tx;
-    const float* dyb = p.dy + ((long)n * p.K + kbk * 64) * S + (long)z * HW;
-    const float* xb = p.x + ((long)n * p.C + cb * CIW) * S + (long)(z + dz - PAD) * HW;
-    const int Si = (int)S;
-    // buffer descriptors: an invalid element uses offset -1 and reads back 0 from the range check
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dyb, 0, (int)(64 * S * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)(CIW * S * 4), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < kNLDW; ++i) {
-      // iteration i is entirely dY (i < nDy) or entirely X: the choice is wave-uniform
-      if (i < p.nDy) {
-        const int e = tid + i * NT;
-        const unsigned co = fdiv(e, p.mQT);
-        const unsigned q = e - co * p.QT;
-        const unsigned ty = fdiv(q, p.mPp), xx = q - ty * p.Pp;
-        const int y = y0 + (int)ty, x = x0 + (int)xx;
-        const bool ok = e < p.NEdy && (int)xx < p.Tx && x < p.W && y < p.H;
-        const int off = ok ? ((int)co * Si + y * p.W + x) * 4 : -1;
-        st[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, off, 0, 0));
-      } else {
-        const int e2 = tid + (i - p.nDy) * NT;
-        const unsigned ci = fdiv(e2, p.mRX);
-        const unsigned f = e2 - ci * p.RX;
-        const unsigned yy = fdiv(f, p.mPp), xx = f - yy * p.Pp;
-        const int y = y0 + (int)yy - PAD, x = x0 + (int)xx - PAD;
-        const bool ok = e2 < p.NEx && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        const int off = ok ? ((int)ci * Si + y * p.W + x) * 4 : -1;
-        st[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep decode_i -> load_i together: 32 hoisted decodes would spill
-    }
-  };
-  auto stage_store = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < kNLDW; ++i) {
-      if (i < p.nDy) {
-        const int e = tid + i * NT;
-        const unsigned co = fdiv(e, p.mQT);
-        if (e < p.NEdy) buf[e + co * (p.PA - p.QT)] = st[i];
-      } else {
-        const int e2 = tid + (i - p.nDy) * NT;
-        const unsigned ci = fdiv(e2, p.mRX);
-        if (e2 < p.NEx) buf[64 * p.PA + e2 + ci * (p.PB - p.RX)] = st[i];
-      }
-    }
-  };
+  const int SLOT = CIW * p.PR;  // one ring slot = one X row of all CIW channels
+  float* xT = lds;
+  float* dyT = lds + KS * SLOT;
+  for (int i = tid; i < KS * SLOT + 64 * p.PAr; i += 512) lds[i] = 0.f;
 
   f32x4 acc[AB][T];
 #pragma unroll
@@ -132,38 +68,110 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (t0 < t1) {
-    stage_load(t0);
-    stage_store(buf0);
-  }
-  __syncthreads();
+  // ---- staging registers: XR x-rows and 8 dY-rows per wave, kNSEG segments of 64 columns each
+  float sx[XR][kNSEG], sd[8][kNSEG];
+  const bool c0 = lane < p.W, c1 = lane + 64 < p.W, c2 = lane + 128 < p.W;
 
-  const int a_off = (cog * 16 * AB + l15) * p.PA + kq;
-  const int b_off = 64 * p.PA + (cib * 16 + l15) * p.PB + kq;
-  for (long t = t0; t < t1; ++t) {
-    const float* cur = ((t - t0) & 1) ? buf1 : buf0;
-    float* nxt = ((t - t0) & 1) ? buf0 : buf1;
-    const bool more = t + 1 < t1;
-    if (more) stage_load(t + 1);
-    const float* pa = cur + a_off;
-    const float* pb = cur + b_off;
-#pragma unroll 1
-    for (int q4 = 0; q4 < p.QT4; q4 += 4) {
-      float a[AB];
+  // a "load step" brings X row yy (plane z + dz - PAD) into the ring and, when it completes a tile, dY row yy - PAD.
+  auto issue_loads = [&](int n, int z, int yy, bool with_dy) {
+    const bool xrow_ok = yy >= 0 && yy < p.H;
+    const float* xb = p.x + ((long)n * p.C + cb * CIW + wave) * S + (long)(z + dz - PAD) * HW + (long)yy * p.W + lane;
 #pragma unroll
-      for (int k = 0; k < AB; ++k) a[k] = pa[q4 + k * 16 * p.PA];
-#pragma unroll
-      for (int ty = 0; ty < KS; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < KS; ++tx) {
-          const float b = pb[q4 + ty * p.Pp + tx];
-#pragma unroll
-          for (int k = 0; k < AB; ++k)
-            acc[k][ty * KS + tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b, acc[k][ty * KS + tx], 0, 0, 0);
-        }
+    for (int j = 0; j < XR; ++j) {
+      const float* r = xb + (long)(8 * j) * S;
+      sx[j][0] = (xrow_ok && c0) ? r[0] : 0.f;
+      sx[j][1] = (xrow_ok && c1) ? r[64] : 0.f;
+      sx[j][2] = (xrow_ok && c2) ? r[128] : 0.f;
     }
-    if (more) stage_store(nxt);
+    if (with_dy) {
+      const float* db = p.dy + ((long)n * p.K + kbk * 64 + wave) * S + (long)z * HW + (long)(yy - PAD) * p.W + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* r = db + (long)(8 * j) * S;
+        sd[j][0] = c0 ? r[0] : 0.f;
+        sd[j][1] = c1 ? r[64] : 0.f;
+        sd[j][2] = c2 ? r[128] : 0.f;
+      }
+    }
+  };
+  auto write_lds = [&](int yy, bool with_dy) {
+    const int slot = (yy + 8 * KS) % KS;
+    float* xs = xT + slot * SLOT + wave * p.PR + PAD + lane;
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      float* r = xs + (8 * j) * p.PR;
+      if (c0) r[0] = sx[j][0];
+      if (c1) r[64] = sx[j][1];
+      if (c2) r[128] = sx[j][2];
+    }
+    if (with_dy) {
+      float* ds = dyT + wave * p.PAr + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float* r = ds + (8 * j) * p.PAr;
+        if (c0) r[0] = sd[j][0];
+        if (c1) r[64] = sd[j][1];
+        if (c2) r[128] = sd[j][2];
+      }
+    }
+  };
+
+  // ---- walk the rows [r0, r1): per (n, z) plane segment [ya, yb) the load steps run yy = ya-PAD .. yb-1+PAD
+  long r = r0;
+  int n = 0, z = 0, ya = 0, yb = 0, yy = 0;
+  bool have = false;
+  auto next_segment = [&]() {
+    if (r >= r1) {
+      have = false;
+      return;
+    }
+    const long plane = r / p.H;
+    ya = (int)(r - plane * p.H);
+    const long rem = r1 - r;
+    yb = (int)min((long)p.H, ya + rem);
+    n = (int)(plane / Dv);
+    z = zlo + (int)(plane - (long)n * Dv);
+    yy = ya - PAD;
+    r += yb - ya;
+    have = true;
+  };
+  next_segment();
+  if (have) issue_loads(n, z, yy, yy - PAD >= ya);
+
+  const int a_off = (cog * 16 * AB + l15) * p.PAr + kq;
+  const int b_off = (cib * 16 + l15) * p.PR + kq;
+  while (have) {
+    const int cyy = yy, cya = ya;
+    const bool cdy = cyy - PAD >= cya;  // this step completes tile y = cyy - PAD
+    __syncthreads();                    // the previous tile's MFMAs are done: ring slot and dY buffer are free
+    write_lds(cyy, cdy);
     __syncthreads();
+    // advance and prefetch the next step's rows while this tile is being multiplied
+    ++yy;
+    if (yy > yb - 1 + PAD) next_segment();
+    if (have) issue_loads(n, z, yy, yy - PAD >= ya);
+    if (cdy) {
+      const int y = cyy - PAD;
+      const float* pa = dyT + a_off;
+      int soff[KS];
+#pragma unroll
+      for (int ty = 0; ty < KS; ++ty) soff[ty] = ((y - PAD + ty + 8 * KS) % KS) * SLOT + b_off;
+#pragma unroll 1
+      for (int q4 = 0; q4 < p.QT4; q4 += 4) {
+        float a[AB];
+#pragma unroll
+        for (int k = 0; k < AB; ++k) a[k] = pa[q4 + k * 16 * p.PAr];
+#pragma unroll
+        for (int ty = 0; ty < KS; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < KS; ++tx) {
+            const float b = xT[soff[ty] + q4 + tx];
+#pragma unroll
+            for (int k = 0; k < AB; ++k)
+              acc[k][ty * KS + tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b, acc[k][ty * KS + tx], 0, 0, 0);
+          }
+      }
+    }
   }
 
   // ---- partial slab: slab[part][g][co 64][ci CIW][T];  C/D layout of 16x16 MFMA: col (ci) = lane & 15,
@@ -174,10 +182,10 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = cog * 16 * AB + k * 16 + 4 * kq + r;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = cog * 16 * AB + k * 16 + 4 * kq + rr;
         const int ci = cib * 16 + l15;
-        sl[((long)co * CIW + ci) * T + t] = acc[k][t][r];
+        sl[((long)co * CIW + ci) * T + t] = acc[k][t][rr];
       }
 }
 
@@ -200,53 +208,12 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict
 }
 
 struct WgPlan {
-  int AB, Ty, Tx, nty, ntx, Pp, QT, QT4, RX, PA, PB, NEdy, NEx, nDy, lds_bytes, G, parts;
-  double score;
+  int AB, PR, PAr, QT4, lds_bytes, G, parts;
 };
 
-static unsigned magicw(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
 static int pitch2(int n) {  // smallest p >= n with p % 32 == 2
   int p = (n / 32) * 32 + 2;
   return p >= n ? p : p + 32;
-}
-
-static bool plan_wgrad(const ConvDims& d, WgPlan& best) {
-  const int KS = d.kd, pad = KS / 2;
-  const int AB = KS == 3 ? 2 : 1;
-  const int CIW = 32 * AB;
-  if (d.C % CIW || d.K % 64) return false;
-  bool found = false;
-  for (int Ty = 1; Ty <= 8 && Ty <= d.H; ++Ty) {
-    for (int ntx = 1; ntx <= 32; ++ntx) {
-      const int Tx = (d.W + ntx - 1) / ntx;
-      const int Pp = Tx + 2 * pad;
-      const int QT = Ty * Pp, QT4 = (QT + 3) & ~3;
-      const int RX = (Ty + 2 * pad) * Pp;
-      const int PA = pitch2(QT4 + 4);
-      const int PB = pitch2(QT4 + (KS - 1) * Pp + KS + 4 > RX ? QT4 + (KS - 1) * Pp + KS + 4 : RX);
-      const int NEdy = 64 * QT, NEx = CIW * RX;
-      const int nDy = (NEdy + 511) / 512, nX = (NEx + 511) / 512;
-      const long bytes = 2L * (64 * PA + CIW * PB) * 4;
-      if (nDy + nX > kNLDW || bytes > kLdsMaxW) continue;
-      const int nty = (d.H + Ty - 1) / Ty;
-      const int ntx2 = (d.W + Tx - 1) / Tx;
-      // MFMA efficiency of the k loop x a mild preference for fewer, larger tiles (less staging per MFMA)
-      const double eff = (double)d.H * d.W / ((double)nty * ntx2 * QT4);
-      const double score = eff * (1.0 - 1.5 / (QT4 / 4 + 2));
-      if (!found || score > best.score) {
-        found = true;
-        best = WgPlan{AB, Ty, Tx, nty, ntx2, Pp, QT, QT4, RX, PA, PB, NEdy, NEx, nDy, (int)bytes, 0, 0, score};
-      }
-    }
-  }
-  if (!found) return false;
-  best.G = KS * (d.C / CIW) * (d.K / 64);
-  int parts = 256 / best.G;
-  if (parts < 1) parts = 1;
-  const long tiles = (long)d.N * d.D * best.nty * best.ntx;
-  if (parts > tiles) parts = (int)tiles;
-  best.parts = parts;
-  return true;
 }
 
 static bool wg_shape_ok(const ConvDims& d) {
@@ -254,26 +221,46 @@ static bool wg_shape_ok(const ConvDims& d) {
   if (d.kd != 3 && d.kd != 5) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (d.pd != d.kd / 2 || d.ph != d.kd / 2 || d.pw != d.kd / 2) return false;
-  if ((long)d.N * d.D * d.H * d.W >= (1L << 31) || 64L * d.D * d.H * d.W * 4 >= (1L << 31)) return false;
+  if (d.W > 64 * kNSEG || d.K % 64) return false;
   return true;
+}
+
+static bool plan_wgrad(const ConvDims& d, WgPlan& pl) {
+  if (!wg_shape_ok(d)) return false;
+  const int KS = d.kd;
+  const int QT4 = (d.W + 3) & ~3;
+  const int PR = pitch2(QT4 + KS + 1), PAr = pitch2(QT4 + 1);
+  const int abList[2] = {KS == 3 ? 2 : 1, 1};
+  for (int i = 0; i < 2; ++i) {
+    const int AB = abList[i], CIW = 32 * AB;
+    if (d.C % CIW) continue;
+    const long bytes = ((long)KS * CIW * PR + 64L * PAr) * 4;
+    if (bytes > kLdsMaxW) continue;
+    pl.AB = AB; pl.PR = PR; pl.PAr = PAr; pl.QT4 = QT4; pl.lds_bytes = (int)bytes;
+    pl.G = KS * (d.C / CIW) * (d.K / 64);
+    int parts = 256 / pl.G;
+    if (parts < 1) parts = 1;
+    const long rows = (long)d.N * d.D * d.H;
+    if (parts > rows) parts = (int)rows;
+    pl.parts = parts;
+    return true;
+  }
+  return false;
 }
 
 bool mfma_wgrad_supported(const ConvDims& d) {
   WgPlan pl;
-  return wg_shape_ok(d) && plan_wgrad(d, pl);
+  return plan_wgrad(d, pl);
 }
 
 size_t mfma_ws_bytes(const ConvDims& d) {
   size_t need = 0;
-  if (wg_shape_ok(d)) {
-    const size_t pack = (size_t)d.C * d.K * d.kd * d.kh * d.kw * sizeof(float);
-    need = pack;
-    WgPlan pl;
-    if (plan_wgrad(d, pl)) {
-      const int CIW = 32 * pl.AB;
-      const size_t slab = (size_t)pl.parts * pl.G * 64 * CIW * d.kd * d.kd * sizeof(float);
-      if (slab > need) need = slab;
-    }
+  if (d.kd == d.kh && d.kh == d.kw && (d.kd == 3 || d.kd == 5))
+    need = (size_t)d.C * d.K * d.kd * d.kh * d.kw * sizeof(float);  // packed weights of the fwd/dgrad kernels
+  WgPlan pl;
+  if (plan_wgrad(d, pl)) {
+    const size_t slab = (size_t)pl.parts * pl.G * 64 * (32 * pl.AB) * d.kd * d.kd * sizeof(float);
+    if (slab > need) need = slab;
   }
   return need;
 }
@@ -297,7 +284,7 @@ static int launch_wg(const WgParams& p, dim3 grid, int lds_bytes, hipStream_t s)
 int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s) {
   WgPlan pl;
-  if (!wg_shape_ok(d) || !plan_wgrad(d, pl)) {
+  if (!plan_wgrad(d, pl)) {
     set_error("wgrad_mfma: unsupported shape");
     return NC_ERR_SHAPE;
   }
@@ -310,14 +297,12 @@ int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& 
   WgParams p{};
   p.x = x; p.dy = dy; p.slab = (float*)ws;
   p.C = d.C; p.K = d.K; p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
-  p.Ty = pl.Ty; p.Tx = pl.Tx; p.nty = pl.nty; p.ntx = pl.ntx; p.Pp = pl.Pp;
-  p.QT = pl.QT; p.QT4 = pl.QT4; p.RX = pl.RX; p.PA = pl.PA; p.PB = pl.PB; p.NEdy = pl.NEdy; p.NEx = pl.NEx; p.nDy = pl.nDy;
-  p.mPp = magicw(pl.Pp); p.mQT = magicw(pl.QT); p.mRX = magicw(pl.RX);
+  p.PR = pl.PR; p.PAr = pl.PAr; p.QT4 = pl.QT4;
   p.CB = d.C / CIW; p.KBK = d.K / 64; p.parts = pl.parts;
-  p.mNyx = magicw(pl.nty * pl.ntx); p.mNx = magicw(pl.ntx);
   dim3 grid(pl.parts, pl.G);
   int e;
-  if (d.kd == 3) e = launch_wg<3, 2>(p, grid, pl.lds_bytes, s);
+  if (d.kd == 3 && pl.AB == 2) e = launch_wg<3, 2>(p, grid, pl.lds_bytes, s);
+  else if (d.kd == 3) e = launch_wg<3, 1>(p, grid, pl.lds_bytes, s);
   else e = launch_wg<5, 1>(p, grid, pl.lds_bytes, s);
   if (e) return e;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(1024), dim3(256), 0, s, (const float*)ws, dw, d.C, d.K, d.kd, CIW, pl.parts,
