@@ -45,6 +45,7 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   size_t b = mfma_ws_bytes(d);
   const size_t g = gemm_ws_bytes(d);
   if (g > b) b = g;
+  if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
 
@@ -90,7 +91,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
   if (e) return e;
-  if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, s);
+  if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);
   return NC_OK;
 }
 

@@ -44,7 +44,8 @@ inline bool make_dims(ConvDims& d, int N, int C, int D, int H, int W, int K, int
 int conv_fwd_direct(const float* x, const float* w, const float* b, float* y, const ConvDims& d, hipStream_t s);
 int conv_dgrad_direct(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
 int conv_wgrad_direct(const float* x, const float* dy, float* dw, const ConvDims& d, hipStream_t s);
-int bias_grad(const float* dy, float* db, int N, int K, long S, hipStream_t s);
+int bias_grad(const float* dy, float* db, int N, int K, long S, void* ws, size_t wsb, hipStream_t s);
+static constexpr size_t kBiasGradWsBytes = 64 * 1024 * sizeof(double);  // K * splits <= 65536 partial sums
 
 // ---- MFMA implicit-GEMM kernels, conv_mfma.hip
 bool mfma_fwd_supported(const ConvDims& d);
@@ -73,6 +74,9 @@ int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& 
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
 bool to1_dgrad_supported(const ConvDims& d);
 int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+
+// the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
+static constexpr size_t kPackSlackBytes = 128 * 1024;
 
 extern int g_force_direct;
 

@@ -146,20 +146,39 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ x,
   }
 }
 
-// db[k] = sum over n and positions of dy[n][k][:]
-__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy, float* __restrict__ db, int N, int K,
-                                                   long S) {
-  const int k = blockIdx.x;
+// db[k] = sum over n and positions of dy[n][k][:]  -- two-stage, fixed order (deterministic): grid (splits, K)
+// partial sums in fp64, then one lane per k adds the partials.
+__global__ __launch_bounds__(256) void k_bias_grad_part(const float* __restrict__ dy, double* __restrict__ part, int N,
+                                                        int K, long S, int splits) {
+  const int k = blockIdx.y, sp = blockIdx.x;
+  long chunk = (S + splits - 1) / splits;
+  chunk = (chunk + 3) & ~3L;
+  const long b = (long)sp * chunk, e = b + chunk < S ? b + chunk : S;
   double acc = 0.0;
   for (int n = 0; n < N; ++n) {
     const float* p = dy + ((long)n * K + k) * S;
-    for (long i = threadIdx.x; i < S; i += 256) acc += (double)p[i];
+    if ((S & 3) == 0 && ((uintptr_t)dy & 15) == 0) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      for (long i = b / 4 + threadIdx.x; i < e / 4; i += 256) {
+        const float4 v = p4[i];
+        acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      }
+    } else {
+      for (long i = b + threadIdx.x; i < e; i += 256) acc += (double)p[i];
+    }
   }
   __shared__ double red[4];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) db[k] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) part[(long)k * splits + sp] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void k_bias_grad_final(const double* __restrict__ part, float* __restrict__ db, int K, int splits) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int i = 0; i < splits; ++i) s += part[(long)k * splits + i];
+  db[k] = (float)s;
 }
 
 static int pick_tile(int n) { return n % 8 == 0 ? 8 : n % 4 == 0 ? 4 : n % 2 == 0 ? 2 : 1; }
@@ -206,8 +225,20 @@ int conv_wgrad_direct(const float* x, const float* dy, float* dw, const ConvDims
   return check_launch("conv_wgrad_direct");
 }
 
-int bias_grad(const float* dy, float* db, int N, int K, long S, hipStream_t s) {
-  hipLaunchKernelGGL(k_bias_grad, dim3(K), dim3(256), 0, s, dy, db, N, K, S);
+int bias_grad(const float* dy, float* db, int N, int K, long S, void* ws, size_t wsb, hipStream_t s) {
+  long splits = cdiv(1024, K);
+  const long cap = cdiv(S, 4096);
+  if (splits > cap) splits = cap;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  if (!ws || wsb < (size_t)K * splits * sizeof(double)) {
+    set_error("bias_grad: workspace too small");
+    return NC_ERR_WS;
+  }
+  hipLaunchKernelGGL(k_bias_grad_part, dim3((unsigned)splits, K), dim3(256), 0, s, dy, (double*)ws, N, K, S,
+                     (int)splits);
+  hipLaunchKernelGGL(k_bias_grad_final, dim3((unsigned)cdiv(K, 128)), dim3(128), 0, s, (const double*)ws, db, K,
+                     (int)splits);
   return check_launch("bias_grad");
 }
 

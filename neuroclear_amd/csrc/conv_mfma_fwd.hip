@@ -22,7 +22,7 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int kNLD = 32;
+static constexpr int kRMAX = 18;  // brick rows staged per wave per chunk (x 3 column segments of 64)
 static constexpr bool kFuseNorm = false;  // normalize-on-load is wired but not enabled in round 1  // staging registers per lane (elements of the brick per lane per chunk)
 
 struct FwdParams {
@@ -37,7 +37,9 @@ struct FwdParams {
   int Tz, Ty, nty;
   int P, RW, planes, CP;  // row pitch, floats per plane (= (Ty+2p)*P), planes per channel, floats per channel
   int nelem;              // CK * CP
-  unsigned mP, mRW, mCP;  // magic multipliers: n / d == __umulhi(n, m) for the ranges used here
+  unsigned mP;            // magic multiplier: n / P == __umulhi(n, mP)
+  int nrows, rowsY, PRows;  // brick rows per chunk (CK*planes*rowsY), rows per plane (Ty+2p), rows per channel
+  unsigned mRowsY, mPR;
   int nchunks;
 };
 
@@ -47,7 +49,6 @@ template <int KS, int CK, int WM, int WN, int VB>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int PAD = KS / 2;
-  constexpr int TAPS = KS * KS * KS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -60,46 +61,57 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   const int cot = blockIdx.y, n = blockIdx.z;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
-  // ---- staging: element e of the brick -> (channel, plane, row, column) by magic-number division; loads go through
-  //      a buffer descriptor so that out-of-volume elements (offset -1) come back as 0 from the range check -- no
-  //      exec-masked regions, no per-lane masks kept alive across the MFMA loop.
+  // ---- staging by ROWS: the brick is CK x planes x rowsY rows of W floats; a wave copies whole rows, lane = column,
+  //      so the (channel, plane, row) decode and the global row base are wave-uniform (scalar unit) and no per-lane
+  //      index arithmetic is left.  Rows outside the volume are written as zeros; the 2p pad columns of every LDS row
+  //      are zeroed once and never written again.
+  constexpr int NWV = NT / 64;
   const float* xn = p.x + (long)n * p.C * S;
-  float st[kNLD];
+  float st[kRMAX][3];
+  const bool cm0 = lane < p.W, cm1 = lane + 64 < p.W, cm2 = lane + 128 < p.W;
   auto stage_load = [&](int chunk) {
-    const float* xc = xn + (long)chunk * CK * S;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, (int)((p.C - chunk * CK) * S * 4), 0x00020000);
+    const float* xc = xn + (long)chunk * CK * S + lane;
 #pragma unroll
-    for (int i = 0; i < kNLD; ++i) {
-      const unsigned e = tid + i * NT;
-      const unsigned cic = fastdiv(e, p.mCP);
-      const unsigned r1 = e - cic * p.CP;
-      const unsigned pz = fastdiv(r1, p.mRW);
-      const unsigned f = r1 - pz * p.RW;
-      const unsigned yy = fastdiv(f, p.mP);
-      const unsigned xx = f - yy * p.P;
-      const int z = z0 + (int)pz - PAD, y = y0 + (int)yy - PAD, x = (int)xx - PAD;
-      const bool ok = (int)e < p.nelem && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
-                      (unsigned)x < (unsigned)p.W;
-      const int off = ok ? (int)(((int)cic * (int)S + z * (int)HW + y * p.W + x) * 4) : -1;
-      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+    for (int i = 0; i < kRMAX; ++i) {
+      const unsigned row = wave + NWV * i;
+      const unsigned cic = fastdiv(row, p.mPR);
+      const unsigned r1 = row - cic * p.PRows;
+      const unsigned pz = fastdiv(r1, p.mRowsY);
+      const unsigned yy = r1 - pz * p.rowsY;
+      const int z = z0 + (int)pz - PAD, y = y0 + (int)yy - PAD;
+      const bool rok = (int)row < p.nrows && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
+      const float* r = xc + (long)cic * S + (long)z * HW + (long)y * p.W;
+      float v0 = (rok && cm0) ? r[0] : 0.f;
+      float v1 = (rok && cm1) ? r[64] : 0.f;
+      float v2 = (rok && cm2) ? r[128] : 0.f;
       if (kFuseNorm && p.mean) {  // wave-uniform: fused InstanceNorm + activation of the producer layer
         const int c = chunk * CK + min((int)cic, CK - 1);
-        v = (v - p.mean[(long)n * p.C + c]) * p.rstd[(long)n * p.C + c];
-        v = v > 0.f ? v : v * p.slope;
-        v = off >= 0 ? v : 0.f;
+        const float m = p.mean[(long)n * p.C + c], rs = p.rstd[(long)n * p.C + c];
+        v0 = (v0 - m) * rs; v1 = (v1 - m) * rs; v2 = (v2 - m) * rs;
+        v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; v2 = v2 > 0.f ? v2 : v2 * p.slope;
+        v0 = rok ? v0 : 0.f; v1 = rok ? v1 : 0.f; v2 = rok ? v2 : 0.f;
       }
-      st[i] = v;
-      __builtin_amdgcn_sched_barrier(0);  // keep decode_i -> load_i together: 32 hoisted decodes would spill
+      st[i][0] = v0; st[i][1] = v1; st[i][2] = v2;
     }
   };
   auto stage_store = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < kNLD; ++i) {
-      const int e = tid + i * NT;
-      if (e < p.nelem) buf[e] = st[i];
+    for (int i = 0; i < kRMAX; ++i) {
+      const unsigned row = wave + NWV * i;
+      if ((int)row < p.nrows) {
+        const unsigned cic = fastdiv(row, p.mPR);
+        const unsigned r1 = row - cic * p.PRows;
+        const unsigned pz = fastdiv(r1, p.mRowsY);
+        const unsigned yy = r1 - pz * p.rowsY;
+        float* r = buf + cic * p.CP + pz * p.RW + yy * p.P + PAD + lane;
+        if (cm0) r[0] = st[i][0];
+        if (cm1) r[64] = st[i][1];
+        if (cm2) r[128] = st[i][2];
+      }
     }
   };
+  for (int i = tid; i < 2 * p.nelem; i += NT) lds[i] = 0.f;  // pad columns (and everything else) start at zero
+  __syncthreads();
 
   // ---- this wave's output sub-tile: VB column blocks of 32 flattened positions in plane tzl, 64 output channels
   const int GP = WM / p.Tz;
@@ -123,27 +135,39 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   stage_store(buf0);
   __syncthreads();
 
+  // The packed weights are ONE linear stream over the whole kernel: k-step s reads rows 2s, 2s+1 (lane half h picks
+  // the row), chunk after chunk, tap after tap.  They are software-pipelined by hand one (dz, dy) row of the kernel
+  // ahead -- U = KS * CK/2 k-steps, 3-6 k cycles of MFMA -- so no MFMA ever waits for its L2 round trip.  (The last
+  // prefetch runs past the end of the stream into the workspace slack the host reserves.)
+  constexpr int U = KS * (CK / 2);
+  const long kstep = 2L * p.K;  // floats per k-step
+  const float* aptr = wlane;
+  float2 a_cur[U], a_nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) a_cur[u] = *reinterpret_cast<const float2*>(aptr + u * kstep);
+  aptr += U * kstep;
+
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     const float* cur = (chunk & 1) ? buf1 : buf0;
     float* nxt = (chunk & 1) ? buf0 : buf1;
     const bool more = chunk + 1 < p.nchunks;
     if (more) stage_load(chunk + 1);
-    const float* wchunk = wlane + (long)chunk * TAPS * CK * p.K;
 #pragma unroll 1
     for (int dz = 0; dz < KS; ++dz) {
 #pragma unroll 1
       for (int dy = 0; dy < KS; ++dy) {
 #pragma unroll
+        for (int u = 0; u < U; ++u) a_nxt[u] = *reinterpret_cast<const float2*>(aptr + u * kstep);
+        aptr += U * kstep;
+        const float* brow = cur + b_base + dz * p.RW + dy * p.P;
+#pragma unroll
         for (int dx = 0; dx < KS; ++dx) {
-          const int tap = (dz * KS + dy) * KS + dx;
-          const float* bt = cur + b_base + dz * p.RW + dy * p.P + dx;
-          const float* wt = wchunk + (long)tap * CK * p.K;
 #pragma unroll
           for (int cp = 0; cp < CK / 2; ++cp) {
-            const float2 a = *reinterpret_cast<const float2*>(wt + (long)(2 * cp) * p.K);
+            const float2 a = a_cur[dx * (CK / 2) + cp];
             float b[VB];
 #pragma unroll
-            for (int v = 0; v < VB; ++v) b[v] = bt[2 * cp * p.CP + v * 32];
+            for (int v = 0; v < VB; ++v) b[v] = brow[dx + 2 * cp * p.CP + v * 32];
 #pragma unroll
             for (int v = 0; v < VB; ++v) {
               acc[0][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[v], acc[0][v], 0, 0, 0);
@@ -151,6 +175,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
             }
           }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a_cur[u] = a_nxt[u];
       }
     }
     if (more) stage_store(nxt);
@@ -246,7 +272,8 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         // slack: garbage columns of the last blocks read up to maxpos + (KS-1)*(P+1) past the last plane's start
         const long slack = maxpos + (long)(KS - 1) * (P + 1) + 64;
         const long bytes = (2 * nelem + slack) * 4;
-        if (bytes > kLdsMax || nelem > (long)kNLD * NT) continue;
+        const int nrows = CK * planes * (Ty + 2 * pad);
+        if (bytes > kLdsMax || (nrows + NT / 64 - 1) / (NT / 64) > kRMAX) continue;
         const long tiles = (long)ntz * nty * (Cout / (g.WN * 64)) * N;
         const long rounds = (tiles + 255) / 256;
         // time per tile ~ VB MFMA pairs per k-step; small penalty for more barriers with small CK
@@ -297,7 +324,7 @@ static bool shape_ok(const ConvDims& d, int Cin, int Cout) {
   if (Cin % 4 != 0 || Cout % 64 != 0) return false;
   if (d.kd == 5 && Cin % 2 != 0) return false;
   if ((long)Cin * d.D * d.H * d.W * 4 >= (1L << 31)) return false;  // int32 byte offsets in the staging loads
-  if (d.W + d.kd > 1024) return false;
+  if (d.W > 192) return false;  // rows are staged as up to three 64-column segments
   return true;
 }
 
@@ -318,7 +345,7 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
     return NC_ERR_SHAPE;
   }
   const int taps = d.kd * d.kh * d.kw;
-  const size_t need = (size_t)Cin * Cout * taps * sizeof(float);
+  const size_t need = (size_t)Cin * Cout * taps * sizeof(float) + kPackSlackBytes;
   if (!ws || wsb < need) {
     set_error("conv_mfma: workspace too small (%zu < %zu)", wsb, need);
     return NC_ERR_WS;
@@ -330,7 +357,9 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.mean = nullptr; p.rstd = nullptr; p.slope = 0.f;
   p.C = Cin; p.K = Cout; p.D = d.D; p.H = d.H; p.W = d.W;
   p.Tz = pl.Tz; p.Ty = pl.Ty; p.nty = pl.nty; p.P = pl.P; p.RW = pl.RW; p.planes = pl.planes; p.CP = pl.CP;
-  p.nelem = pl.nelem; p.mP = magic(pl.P); p.mRW = magic(pl.RW); p.mCP = magic(pl.CP);
+  p.nelem = pl.nelem; p.mP = magic(pl.P);
+  p.rowsY = pl.Ty + 2 * (d.kd / 2); p.PRows = pl.planes * p.rowsY; p.nrows = pl.CK * p.PRows;
+  p.mRowsY = magic(p.rowsY); p.mPR = magic(p.PRows);
   p.nchunks = Cin / pl.CK;
   const Cfg& g = kCfgs[pl.cfg];
   dim3 grid(pl.ntz * pl.nty, Cout / (g.WN * 64), d.N);

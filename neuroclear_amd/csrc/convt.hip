@@ -152,7 +152,7 @@ using namespace nc;
 
 extern "C" {
 
-size_t nc_convT_ws_bytes(int, int, int, int, int, int) { return 0; }
+size_t nc_convT_ws_bytes(int, int, int, int, int, int) { return kBiasGradWsBytes; }
 
 static int convT_check(const char* what, int N, int C, int D, int H, int W, int K) {
   if (N < 1 || C < 1 || D < 1 || H < 1 || W < 1 || K < 1 || K > 65535 * 4 || N > 65535) {
@@ -192,7 +192,6 @@ int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C
 
 int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W,
                         int K, void* ws, size_t ws_bytes, void* stream) {
-  (void)ws; (void)ws_bytes;
   if (!x || !dy || !dw) { set_error("convT_wgrad: null pointer"); return NC_ERR_ARG; }
   if (int e = convT_check("convT_wgrad", N, C, D, H, W, K)) return e;
   hipStream_t s = (hipStream_t)stream;
@@ -202,7 +201,7 @@ int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias
     hipLaunchKernelGGL((k_convT_wgrad<1, 1>), dim3(C, K), dim3(256), 0, s, x, dy, dw, N, C, D, H, W, K);
   }
   if (int e = check_launch("convT_wgrad")) return e;
-  if (dbias) return bias_grad(dy, dbias, N, K, 8L * D * H * W, s);
+  if (dbias) return bias_grad(dy, dbias, N, K, 8L * D * H * W, ws, ws_bytes, s);
   return NC_OK;
 }
 

@@ -213,8 +213,9 @@ class _ConvT(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             db = torch.empty(K, dtype=torch.float32, device=x.device) if ctx.has_b else None
+            ws = workspace(lib().nc_convT_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K)), x.device)
             check(lib().nc_convT_k2s2_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K),
-                                            P(0), Z(0), _stream()), 'nc_convT_k2s2_wgrad')
+                                            _ptr(ws), Z(ws.numel()), _stream()), 'nc_convT_k2s2_wgrad')
         return dx, dw, db
 
 
