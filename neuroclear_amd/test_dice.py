@@ -13,34 +13,43 @@ from .data.diceImage_dataset import DiceImageDataSet
 from .util.assemble_dice import Assemble_Dice
 
 
+def sharded_cube_loop(n, rank, world, produce, consume, empty_like):
+    """The N > 1 schedule of the diced loop, free of device code so that it can be exercised with gloo on CPU:
+    round t hands cube t*world + r to rank r; `produce(i)` returns that cube's network output (a tensor), tiles of a
+    round are gathered to rank 0, which calls `consume(j, tile)` in increasing j -- the reference's summation order
+    (util/assemble_dice.py:167-173).  `empty_like()` makes the placeholder a rank sends when it has no cube left."""
+    import torch.distributed as dist
+    rounds = (n + world - 1) // world
+    for t in range(rounds):
+        i = t * world + rank
+        tile = produce(i) if i < n else empty_like()
+        if world == 1:
+            consume(i, tile)
+            continue
+        tiles = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
+        dist.gather(tile, tiles, dst=0)
+        if rank == 0:
+            for r in range(world):
+                j = t * world + r
+                if j < n:
+                    consume(j, tiles[r])
+
+
 def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None):
     """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0."""
-    import torch.distributed as dist
     ds = DiceImageDataSet(opt, volume=volume)
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
     asm = Assemble_Dice(opt, ds.size_original()) if rank == 0 else None
     E = opt.dice_size[0] + 2 * opt.border_cut
-    rounds = (n + world - 1) // world
     with torch.no_grad():
-        for t in range(rounds):
-            i = t * world + rank
-            if i < n:
-                fake = netG(ds[i]['A'].unsqueeze(0)).reshape(E, E, E)
-            else:
-                fake = torch.zeros((E, E, E), dtype=torch.float32, device=ds.device)
-            if world == 1:
-                asm.add_cube('fake', fake, i)
-                continue
-            tiles = [torch.empty_like(fake) for _ in range(world)] if rank == 0 else None
-            dist.gather(fake, tiles, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    j = t * world + r
-                    if j < n:
-                        asm.add_cube('fake', tiles[r], j)
+        sharded_cube_loop(
+            n, rank, world,
+            produce=lambda i: netG(ds[i]['A'].unsqueeze(0)).reshape(E, E, E),
+            consume=lambda j, tile: asm.add_cube('fake', tile, j),
+            empty_like=lambda: torch.zeros((E, E, E), dtype=torch.float32, device=ds.device))
     if rank != 0:
         return None
-    asm.count['fake'] = asm.len_cube_queue if max_cubes is not None else n  # warm-up runs assemble a partial volume
+    asm.count['fake'] = asm.len_cube_queue  # warm-up runs (max_cubes) assemble a partial volume on purpose
     asm.assemble_all()
     return asm.getDict()['fake']
 

@@ -1,0 +1,97 @@
+"""CPU, world_size 2, gloo: the N > 1 paths that need no GPU code --
+ * the cube sharding + gather-to-rank-0 schedule of diced inference (neuroclear_amd.test_dice.sharded_cube_loop),
+   checked against the oracle's single-process assemble;
+ * the gradient exchange of the flat optimizer buffers (FlatAdam.all_reduce_mean)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _dice_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    from neuroclear_amd.test_dice import sharded_cube_loop
+    from neuroclear_amd.util import seed as S
+    from oracle import dice as odice
+    vol = S.random_volume(3, (50, 50, 50))  # 5 x 5 x 5 = 125 cubes: an odd count leaves rank 1 idle in the last round
+    R, ov, b = 16, 4, 2
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    n = steps[0] * steps[1] * steps[2]
+    refl = odice.reflect_pad(padded, b)
+
+    def net(c):  # stand-in network: position independent, non-trivial
+        return c * 0.75 + 0.01
+
+    got = {}
+    E = R + 2 * b
+    sharded_cube_loop(n, rank, world,
+                      produce=lambda i: net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b)))),
+                      consume=lambda j, t: got.__setitem__(j, t.numpy().copy()),
+                      empty_like=lambda: torch.zeros((E, E, E)))
+    if rank == 0:
+        assert sorted(got) == list(range(n))
+        assert list(got) == list(range(n)), 'rank 0 must consume the cubes in index order'
+        out = odice.assemble([got[j] for j in range(n)], padded.shape, vol.shape, R, ov, b, 'uint16')
+        ref = odice.assemble([net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b)))).numpy()
+                              for i in range(n)], padded.shape, vol.shape, R, ov, b, 'uint16')
+        np.save(out_path, np.array([int(np.array_equal(out, ref)), n]))
+    else:
+        assert not got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_dice_loop_two_ranks(tmp_path):
+    port = _free_port()
+    out = str(tmp_path / 'r.npy')
+    mp.spawn(_dice_worker, args=(2, port, out), nprocs=2, join=True)
+    eq, n = np.load(out)
+    assert eq == 1 and n == 125
+
+
+def _adam_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    from neuroclear_amd.models.axial_to_lateral_gan_apollo_model import FlatAdam
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    opt = FlatAdam(params, lr=1e-4, betas=(0.1, 0.999))
+    assert params[0].data.data_ptr() == opt.flat.data_ptr()  # parameters are views into the flat buffer
+    opt.zero_grad()
+    loss = (params[0] * (rank + 1)).sum() + (params[1] ** 2).sum() * (rank + 1)
+    loss.backward()
+    g_local = opt.grad.clone()
+    opt.all_reduce_mean()
+    gathered = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    want = sum(gathered) / world
+    ok = torch.allclose(opt.grad, want, rtol=0, atol=1e-7) and torch.equal(params[0].grad.reshape(-1), opt.grad[:15])
+    if rank == 0:
+        np.save(out_path, np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_gradient_exchange_two_ranks(tmp_path):
+    port = _free_port()
+    out = str(tmp_path / 'a.npy')
+    mp.spawn(_adam_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
