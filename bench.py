@@ -46,7 +46,7 @@ def apollo_opt(gpu):
                      direction='AtoB', model='axial_to_lateral_gan_apollo')
 
 
-def cpu_baseline_train(crop=32):
+def cpu_baseline_train(crop=96):
     """Oracle Apollo step on the host cores, one step on a crop^3 volume (bounded: ~10-30 s)."""
     import torch
     from neuroclear_amd.util import seed as S
@@ -96,7 +96,7 @@ def run_train(args, rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.prof = []
+    ops.prof = None if args.no_prof else []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -104,7 +104,7 @@ def run_train(args, rank, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, ops.prof = ops.prof, None
+    prof, ops.prof = (ops.prof or []), None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,6 +180,7 @@ def main():
     ap.add_argument('--crop', type=int, default=108)
     ap.add_argument('--volume', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP events (A/B runs)')
     args = ap.parse_args()
 
     import torch

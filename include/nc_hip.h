@@ -91,6 +91,11 @@ int nc_mip_fwd(const float* vol, float* out, int32_t* arg, int NC, int D, int H,
 int nc_mip_bwd(const float* dout, const int32_t* arg, float* dvol, int NC, int D, int H, int W, int axis,
                void* stream);
 
+/* ---- Athena's iter_f (axial_to_lateral_gan_athena_model.py:286-296): every slice along `axis` as one batch.
+ *      to_volume = 0: slices[(n*L+s), c, a, b] = vol[n, c, ...s...]; to_volume = 1: the inverse permutation (backward). */
+int nc_volume_slices(const float* src, float* dst, int N, int C, int D, int H, int W, int axis, int to_volume,
+                     void* stream);
+
 /* ---- GANLoss('lsgan') = MSELoss against a constant (networks.py:276,299-313) and L1Loss (apollo:128,279).
  *      out[0] = mean; backward scales by the device scalar gscale[0] (autograd's incoming gradient).              */
 size_t nc_loss_ws_bytes(long n);

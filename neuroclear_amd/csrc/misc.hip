@@ -72,6 +72,29 @@ __global__ void k_mip_bwd(const float* __restrict__ dout, const int32_t* __restr
   }
 }
 
+// ---------------------------------------------------------------- all slices along an axis, as a batch
+// Athena's iter_f (axial_to_lateral_gan_athena_model.py:286-296) applies the 2-D discriminator to EVERY slice along
+// an axis in a Python loop and stacks the outputs; InstanceNorm is per instance, so the same numbers come out of one
+// batched call on slices[(n*L + s)][c][a][b] = vol[n][c][...axis index s...].  dir 0: vol -> slices, 1: slices -> vol
+// (the backward: a pure permutation).
+__global__ void k_slices(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int D, int H, int W,
+                         int axis, int dir) {
+  int A, B;
+  plane_dims(D, H, W, axis, A, B);
+  const int L = axis == 0 ? D : axis == 1 ? H : W;
+  const long S = (long)D * H * W, total = (long)N * C * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // i enumerates the slices tensor: [(n, s)][c][a][b]
+    const int b = (int)(i % B), a = (int)((i / B) % A);
+    const int c = (int)((i / ((long)A * B)) % C);
+    const long ns = i / ((long)A * B * C);
+    const int s = (int)(ns % L), n = (int)(ns / L);
+    const long v = ((long)n * C + c) * S + vol_index(D, H, W, axis, a, b, s);
+    if (dir == 0) dst[i] = src[v];
+    else dst[v] = src[i];
+  }
+}
+
 // ---------------------------------------------------------------- losses
 // mode 0: (p - target)^2 ; mode 1: |a - b|.  Two-stage deterministic reduction (fp64 partials, fixed order).
 __global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ a, const float* __restrict__ b,
@@ -181,6 +204,16 @@ int nc_mip_bwd(const float* dout, const int32_t* arg, float* dvol, int NC, int D
   hipLaunchKernelGGL(k_mip_bwd, dim3(flat_grid((long)NC * D * H * W)), dim3(256), 0, (hipStream_t)stream, dout, arg,
                      dvol, NC, D, H, W, axis);
   return check_launch("mip_bwd");
+}
+
+int nc_volume_slices(const float* src, float* dst, int N, int C, int D, int H, int W, int axis, int to_volume,
+                     void* stream) {
+  if (!src || !dst) { set_error("volume_slices: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 1) { set_error("volume_slices: bad shape"); return NC_ERR_SHAPE; }
+  if (int e = vol_check("volume_slices", N * C, D, H, W, axis)) return e;
+  hipLaunchKernelGGL(k_slices, dim3(flat_grid((long)N * C * D * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                     C, D, H, W, axis, to_volume ? 1 : 0);
+  return check_launch("volume_slices");
 }
 
 size_t nc_loss_ws_bytes(long n) { (void)n; return kLossBlocks * sizeof(double); }

@@ -1,0 +1,126 @@
+"""Athena (artifact-correction) training step on MI355X (reference: models/axial_to_lateral_gan_athena_model.py:6-331).
+
+Same option surface, loss names and weights, plane wiring and optimizer grouping as the reference.  The one structural
+change: the reference's `iter_f` runs the 2-D discriminator on every slice of the volume in a Python loop and stacks
+the results (:286-296 -- 18*S discriminator passes per step); InstanceNorm is per instance, so the identical numbers
+come out of ONE batched pass over all S slices (`ops.volume_all_slices` -> [S, C, A, B]), and the LSGAN mean over the
+stacked volume equals the mean over the batch.
+"""
+import itertools
+
+from .. import ops
+from . import networks
+from .axial_to_lateral_gan_apollo_model import FlatAdam
+from .base_model import BaseModel
+
+
+class AxialToLateralGANAthenaModel(BaseModel):
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        parser.set_defaults(no_dropout=True)
+        if is_train:
+            parser.add_argument('--lambda_A', type=float, default=10.0, help='weight for cycle loss (A -> B -> A)')
+            parser.add_argument('--pool_size', type=int, default=50)
+            parser.add_argument('--gan_mode', type=str, default='vanilla', help='[vanilla| lsgan | wgangp]')
+        parser.add_argument('--conversion_plane', type=str, nargs='+', default=['yz', 'xy'])
+        parser.add_argument('--lambda_plane', type=int, nargs='+', default=[1, 1, 1])
+        parser.add_argument('--netG_B', type=str, default='deep_linear_gen')
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        self.loss_names = ['D_A_xy', 'D_A_xz', 'D_A_yz', 'G_A', 'G_A_xy', 'G_A_xz', 'G_A_yz', 'cycle_A', 'D_B_xy',
+                           'D_B_xz', 'D_B_yz', 'G_B', 'G_B_xy', 'G_B_xz', 'G_B_yz']
+        self.gan_mode = opt.gan_mode
+        self.gen_dimension, self.dis_dimension = 3, 2  # athena:93-94
+        plane_to_slice_axis = {'xy': 0, 'xz': 1, 'yz': 2}
+        remain = [a for a in plane_to_slice_axis if a != opt.conversion_plane[0] and a != opt.conversion_plane[1]][0]
+        self.source_sl_axis = plane_to_slice_axis[opt.conversion_plane[0]]
+        self.target_sl_axis = plane_to_slice_axis[opt.conversion_plane[1]]
+        self.remain_sl_axis = plane_to_slice_axis[remain]
+        tot = float(opt.lambda_plane[0] + opt.lambda_plane[1] + opt.lambda_plane[2])
+        self.lambda_plane_target, self.lambda_plane_source, self.lambda_plane_ref = [f / tot for f in opt.lambda_plane]
+        self.visual_names = ['real', 'fake', 'rec'] * 2
+        self.model_names = ['G_A', 'G_B', 'D_A_xy', 'D_A_xz', 'D_A_yz', 'D_B_xy', 'D_B_xz', 'D_B_yz'] \
+            if self.isTrain else ['G_A', 'G_B']
+        G = networks.define_G
+        self.netG_A = G(opt.input_nc, opt.output_nc, opt.ngf, opt.netG, opt.norm, not opt.no_dropout, opt.init_type,
+                        opt.init_gain, self.gpu_ids, dimension=self.gen_dimension)
+        self.netG_B = G(opt.output_nc, opt.input_nc, opt.ngf, opt.netG_B, opt.norm, not opt.no_dropout, opt.init_type,
+                        opt.init_gain, self.gpu_ids, dimension=self.gen_dimension)
+        if self.isTrain:
+            def D(nc):
+                return networks.define_D(nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm, opt.init_type,
+                                         opt.init_gain, False, self.gpu_ids, dimension=self.dis_dimension)
+            self.netD_A_yz, self.netD_A_xy, self.netD_A_xz = D(opt.output_nc), D(opt.output_nc), D(opt.output_nc)
+            self.netD_B_yz, self.netD_B_xy, self.netD_B_xz = D(opt.input_nc), D(opt.input_nc), D(opt.input_nc)
+            self.criterionGAN = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionCycle = ops.l1_loss
+            self.optimizer_G = FlatAdam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
+                                        lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D = FlatAdam(  # chain order of athena:163-164
+                itertools.chain(self.netD_A_yz.parameters(), self.netD_A_xy.parameters(), self.netD_A_xz.parameters(),
+                                self.netD_B_yz.parameters(), self.netD_B_xy.parameters(), self.netD_B_xz.parameters()),
+                lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizers = [self.optimizer_G, self.optimizer_D]
+
+    def set_input(self, input):
+        AtoB = self.opt.direction == 'AtoB'
+        self.real = input['A' if AtoB else 'B'].to(self.device)
+        self.image_paths = input['A_paths' if AtoB else 'B_paths']
+        self.cube_shape = self.real.shape
+        self.num_slice = self.cube_shape[-3]
+
+    def forward(self):
+        self.fake = self.netG_A(self.real)
+        self.rec = self.netG_B(self.fake)
+
+    def iter_f(self, input, function, slice_axis):
+        """athena:286-296, batched.  The reference iterates range(self.num_slice) = shape[-3] slices for every axis
+        (cubes are cubic); a non-cubic crop is refused rather than silently sliced differently."""
+        if not (input.shape[-1] == input.shape[-2] == input.shape[-3]):
+            raise ValueError('Athena assumes cubic crops (num_slice = shape[-3] is used for every axis)')
+        return function(ops.volume_all_slices(input, slice_axis))
+
+    def backward_D_basic(self, netD, real, fake, slice_axis_real, slice_axis_fake):
+        pred_real = self.iter_f(real, netD, slice_axis_real)
+        pred_fake = self.iter_f(fake.detach(), netD, slice_axis_fake)
+        loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
+        loss_D.backward()
+        return loss_D
+
+    def backward_G(self):
+        """athena:240-260"""
+        g, f, r = self.criterionGAN, self.fake, self.rec
+        self.loss_G_A_xy = g(self.iter_f(f, self.netD_A_xy, self.target_sl_axis), True) * self.lambda_plane_target
+        self.loss_G_A_yz = g(self.iter_f(f, self.netD_A_yz, self.source_sl_axis), True) * self.lambda_plane_source
+        self.loss_G_A_xz = g(self.iter_f(f, self.netD_A_xz, self.remain_sl_axis), True) * self.lambda_plane_ref
+        self.loss_G_A = self.loss_G_A_xy + self.loss_G_A_yz + self.loss_G_A_xz
+        self.loss_G_B_xy = g(self.iter_f(r, self.netD_B_xy, self.target_sl_axis), True) * (1 / 3)
+        self.loss_G_B_yz = g(self.iter_f(r, self.netD_B_yz, self.source_sl_axis), True) * (1 / 3)
+        self.loss_G_B_xz = g(self.iter_f(r, self.netD_B_xz, self.remain_sl_axis), True) * (1 / 3)
+        self.loss_G_B = self.loss_G_B_xy + self.loss_G_B_yz + self.loss_G_B_xz
+        self.loss_cycle_A = self.criterionCycle(self.rec, self.real) * self.opt.lambda_A
+        self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle_A
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        """athena:262-283"""
+        Ds = [self.netD_A_xy, self.netD_A_yz, self.netD_A_xz, self.netD_B_xy, self.netD_B_yz, self.netD_B_xz]
+        t, s, r = self.target_sl_axis, self.source_sl_axis, self.remain_sl_axis
+        self.forward()
+        self.set_requires_grad(Ds, False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.optimizer_G.all_reduce_mean()
+        self.optimizer_G.step()
+        self.set_requires_grad(Ds, True)
+        self.optimizer_D.zero_grad()
+        self.loss_D_A_xy = self.backward_D_basic(self.netD_A_xy, self.real, self.fake, t, t)
+        self.loss_D_A_yz = self.backward_D_basic(self.netD_A_yz, self.real, self.fake, t, s)
+        self.loss_D_A_xz = self.backward_D_basic(self.netD_A_xz, self.real, self.fake, t, r)
+        self.loss_D_B_xy = self.backward_D_basic(self.netD_B_xy, self.real, self.rec, t, t)
+        self.loss_D_B_yz = self.backward_D_basic(self.netD_B_yz, self.real, self.rec, s, s)
+        self.loss_D_B_xz = self.backward_D_basic(self.netD_B_xz, self.real, self.rec, r, r)
+        self.optimizer_D.all_reduce_mean()
+        self.optimizer_D.step()

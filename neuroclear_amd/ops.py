@@ -3,6 +3,8 @@ the autograd tape only -- every forward/backward below is one or more HIP kernel
 
 Each op mirrors the torch.nn call the reference makes on its hot path (models/networks.py, apollo_model.py); see the
 header for the file:line of every call site."""
+import os
+
 import torch
 
 from . import _lib
@@ -94,10 +96,24 @@ def _conv_out_shape(xs, ws, stride, pad):
     return (xs[0], ws[0]) + tuple((xs[2 + i] + 2 * pad - ws[2 + i]) // stride + 1 for i in range(nsp))
 
 
-def _conv_ws(dims, K, k3, stride, pad, device):
+def _conv_ws(dims, K, k3, stride, pad, device, tag='ws'):
     N, C, D, H, W = dims
     nb = lib().nc_conv_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
-    return workspace(nb, device)
+    return workspace(nb, device, tag)
+
+
+# Backward runs the weight gradient of a layer on a side stream, concurrently with the data gradient of the same layer
+# (they are independent given dy): the two kernels' workgroups interleave on the 256 CUs, which fills the idle tail
+# each of them leaves when its tile count is not a multiple of the CU count (e.g. 1296 tiles = 5.06 rounds at 108^3).
+overlap_wgrad = os.environ.get('NC_WGRAD_STREAM', '1') != '0'
+_side_streams = {}
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 def conv_fwd_raw(x, w, b, stride, pad):
@@ -136,7 +152,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias):
+def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws'):
     _chk(x, dy)
     _f32(x, dy)
     dims = _dims5(x.shape)
@@ -145,7 +161,7 @@ def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias):
     k3 = _kdims(w_shape)
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
-    ws = _conv_ws(dims, K, k3, stride, pad, x.device)
+    ws = _conv_ws(dims, K, k3, stride, pad, x.device, ws_tag)
     e0 = _prof_begin()
     check(lib().nc_conv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                               I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()),
@@ -169,10 +185,23 @@ class _Conv(torch.autograd.Function):
         stride, pad, has_b = ctx.cfg
         dy = dy.contiguous()
         dx = dw = db = None
+        want_b = has_b and ctx.needs_input_grad[2]
+        want_w = ctx.needs_input_grad[1] or want_b
+        big = x.numel() >= (1 << 20)  # small layers gain nothing from a second stream
+        if want_w and ctx.needs_input_grad[0] and overlap_wgrad and big and prof is None:
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)  # dy (and x) were produced on the main stream
+            with torch.cuda.stream(side):
+                dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b, 'ws_side')
+            dy.record_stream(side)
+            x.record_stream(side)
+            dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
+            main.wait_stream(side)  # dw / db are consumed (accumulated into .grad) on the main stream
+            return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
-        want_b = has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_b:
+        if want_w:
             dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b)
         return dx, dw, db, None, None
 
@@ -412,6 +441,38 @@ class _Mip(torch.autograd.Function):
 def volume_mip(vol, axis, start, depth):
     """Volume.get_projection (apollo_model.py:339-351)."""
     return _Mip.apply(vol, int(axis), int(start), int(depth))
+
+
+class _AllSlices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, axis):
+        vol = vol.contiguous()
+        _chk(vol)
+        _f32(vol)
+        N, C, D, H, W = vol.shape
+        L = (D, H, W)[axis]
+        pn, pc, pa, pb = _PLANE[axis](N, C, D, H, W)
+        out = torch.empty((N * L, C, pa, pb), dtype=torch.float32, device=vol.device)
+        check(lib().nc_volume_slices(_ptr(vol), _ptr(out), I(N), I(C), I(D), I(H), I(W), I(axis), I(0), _stream()),
+              'nc_volume_slices')
+        ctx.cfg = (tuple(vol.shape), axis)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, axis = ctx.cfg
+        dout = dout.contiguous()
+        N, C, D, H, W = shape
+        dvol = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        check(lib().nc_volume_slices(_ptr(dout), _ptr(dvol), I(N), I(C), I(D), I(H), I(W), I(axis), I(1), _stream()),
+              'nc_volume_slices')
+        return dvol, None
+
+
+def volume_all_slices(vol, axis):
+    """Every slice along `axis` as a batch [(n, s), C, A, B] -- the batched form of Athena's iter_f loop
+    (axial_to_lateral_gan_athena_model.py:286-296)."""
+    return _AllSlices.apply(vol, int(axis))
 
 
 class _MseConst(torch.autograd.Function):

@@ -119,3 +119,69 @@ class ApolloOracle:
         self.grads_D = [p.grad.clone() for p in self.n.params(APOLLO_D)]
         self.opt_D.step()
         return OrderedDict((k, float(v.detach())) for k, v in L.items())
+
+
+ATHENA_D = ['D_A_yz', 'D_A_xy', 'D_A_xz', 'D_B_yz', 'D_B_xy', 'D_B_xz']  # optimizer_D chain order, athena:163-164
+
+
+class AthenaOracle:
+    """One Athena step (axial_to_lateral_gan_athena_model.py:183-296).  iter_f is restated as the reference writes
+    it: a loop over the S slices along the axis, discriminator per slice, outputs stacked along dim 2."""
+
+    def __init__(self, sds, lr=1e-4, beta1=0.1, lambda_A=5.0, lambda_plane=(1, 1, 1), conversion_plane=('yz', 'xy')):
+        self.n = Nets(sds)
+        axis = {'xy': 0, 'xz': 1, 'yz': 2}
+        remain = [a for a in axis if a not in conversion_plane][0]
+        self.src, self.tgt, self.rem = axis[conversion_plane[0]], axis[conversion_plane[1]], axis[remain]
+        s = float(sum(lambda_plane))
+        self.w_target, self.w_source, self.w_ref = [f / s for f in lambda_plane]  # athena:110
+        self.lambda_A = lambda_A
+        self.opt_G = torch.optim.Adam(self.n.params(['G_A', 'G_B']), lr=lr, betas=(beta1, 0.999))
+        self.opt_D = torch.optim.Adam(self.n.params(ATHENA_D), lr=lr, betas=(beta1, 0.999))
+        self.losses = OrderedDict()
+
+    def iter_f(self, vol, name, axis):
+        S = vol.shape[-3]
+        outs = []
+        for i in range(S):
+            sl = [vol[:, :, i, :, :], vol[:, :, :, i, :], vol[:, :, :, :, i]][axis]
+            outs.append(nets.patchgan(self.n.sd[name], sl))
+        return torch.stack(outs, dim=2)
+
+    def step(self, real):
+        L = self.losses
+        fake = nets.unet_deconv(self.n.sd['G_A'], real)
+        rec = nets.deep_linear(self.n.sd['G_B'], fake)
+        self.fake, self.rec = fake, rec
+        t, s, r = self.tgt, self.src, self.rem
+        self.n.set_requires_grad(ATHENA_D, False)
+        self.opt_G.zero_grad()
+        L['G_A_xy'] = nets.lsgan(self.iter_f(fake, 'D_A_xy', t), True) * self.w_target
+        L['G_A_yz'] = nets.lsgan(self.iter_f(fake, 'D_A_yz', s), True) * self.w_source
+        L['G_A_xz'] = nets.lsgan(self.iter_f(fake, 'D_A_xz', r), True) * self.w_ref
+        L['G_A'] = L['G_A_xy'] + L['G_A_yz'] + L['G_A_xz']
+        L['G_B_xy'] = nets.lsgan(self.iter_f(rec, 'D_B_xy', t), True) * (1 / 3)
+        L['G_B_yz'] = nets.lsgan(self.iter_f(rec, 'D_B_yz', s), True) * (1 / 3)
+        L['G_B_xz'] = nets.lsgan(self.iter_f(rec, 'D_B_xz', r), True) * (1 / 3)
+        L['G_B'] = L['G_B_xy'] + L['G_B_yz'] + L['G_B_xz']
+        L['cycle_A'] = nets.l1(rec, real) * self.lambda_A
+        (L['G_A'] + L['G_B'] + L['cycle_A']).backward()
+        self.opt_G.step()
+        self.n.set_requires_grad(ATHENA_D, True)
+        self.opt_D.zero_grad()
+        fd, rd = fake.detach(), rec.detach()
+
+        def d_basic(name, other, ax_real, ax_fake):
+            loss = (nets.lsgan(self.iter_f(real, name, ax_real), True) +
+                    nets.lsgan(self.iter_f(other, name, ax_fake), False)) * 0.5
+            loss.backward()
+            return loss
+
+        L['D_A_xy'] = d_basic('D_A_xy', fd, t, t)
+        L['D_A_yz'] = d_basic('D_A_yz', fd, t, s)
+        L['D_A_xz'] = d_basic('D_A_xz', fd, t, r)
+        L['D_B_xy'] = d_basic('D_B_xy', rd, t, t)
+        L['D_B_yz'] = d_basic('D_B_yz', rd, s, s)
+        L['D_B_xz'] = d_basic('D_B_xz', rd, r, r)
+        self.opt_D.step()
+        return OrderedDict((k, float(v.detach())) for k, v in L.items())

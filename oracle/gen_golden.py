@@ -257,6 +257,37 @@ def gen_apollo():
     print('draws', draws)
 
 
+ATHENA_NETS = ['G_A', 'G_B', 'D_A_yz', 'D_A_xy', 'D_A_xz', 'D_B_yz', 'D_B_xy', 'D_B_xz']
+
+
+def gen_athena():
+    import contextlib
+    import io
+    from models.axial_to_lateral_gan_athena_model import AxialToLateralGANAthenaModel
+    size = 36
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = AxialToLateralGANAthenaModel(_opt_train('axial_to_lateral_gan_athena',
+                                                        dict(conversion_plane=['yz', 'xy'], pool_size=50)))
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 6
+    for i, (name, spec) in enumerate(zip(ATHENA_NETS, specs)):
+        load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 60 + i))
+    real = torch.from_numpy(rand_input(654, (1, 1, size, size, size)))
+    before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in ATHENA_NETS}
+    losses = []
+    for it in range(2):
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+        losses.append([model.get_current_losses()[k] for k in model.loss_names])
+    upd = {}
+    for n in ATHENA_NETS:
+        after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
+        upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
+    np.savez_compressed(os.path.join(OUT, 'athena_step_36.npz'), size=size, real_seed=654, net_seed0=60,
+                        loss_names=np.array(model.loss_names), losses=np.array(losses),
+                        **{'upd_' + n: v for n, v in upd.items()})
+    print('athena', dict(zip(model.loss_names, losses[0])))
+
+
 def gen_dice():
     import data as refdata  # noqa: F401  (registers the package the assembler imports)
     from util.assemble_dice import Assemble_Dice
@@ -312,10 +343,12 @@ def gen_dice():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     networks = ref_modules()
-    which = sys.argv[1:] or ['nets', 'apollo', 'dice']
+    which = sys.argv[1:] or ['nets', 'apollo', 'athena', 'dice']
     if 'nets' in which:
         gen_nets(networks)
     if 'apollo' in which:
         gen_apollo()
+    if 'athena' in which:
+        gen_athena()
     if 'dice' in which:
         gen_dice()

@@ -228,3 +228,48 @@ def test_error_behaviour():
         net(torch.zeros(1, 1, 10, 12, 12, device=DEV))
     with pytest.raises(NcError):  # CPU tensors are refused: no fallback
         ops.conv(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 3, 3, 3), None, 1, 1)
+
+
+ATHENA_NETS = ['G_A', 'G_B', 'D_A_yz', 'D_A_xy', 'D_A_xz', 'D_B_yz', 'D_B_xy', 'D_B_xz']
+
+
+def test_all_slices_op():
+    vol = torch.rand(2, 3, 5, 6, 7, device=DEV).requires_grad_(True)
+    for axis in range(3):
+        ref = vol.movedim(axis + 2, 1).reshape((2 * vol.shape[axis + 2], 3) + tuple(
+            s for i, s in enumerate(vol.shape[2:]) if i != axis))
+        r = torch.rand_like(ref)
+        (gr,) = torch.autograd.grad((ref * r).sum(), vol)
+        v2 = vol.detach().clone().requires_grad_(True)
+        out = ops.volume_all_slices(v2, axis)
+        (h,) = torch.autograd.grad((out * r).sum(), v2)
+        assert torch.equal(out, ref.contiguous()) and torch.equal(h, gr), axis
+
+
+def test_athena_step(golden_dir):
+    from neuroclear_amd.models import create_model
+    g = G(golden_dir, 'athena_step_36.npz')
+    size = int(g['size'])
+    opt = _apollo_opt()
+    opt.model = 'axial_to_lateral_gan_athena'
+    opt.conversion_plane = ['yz', 'xy']
+    opt.pool_size = 50
+    model = create_model(opt)
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 6
+    for i, (n, sp) in enumerate(zip(ATHENA_NETS, specs)):
+        load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
+    before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in ATHENA_NETS}
+    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    names = [str(s) for s in g['loss_names']]
+    for it in range(2):
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+        L = model.get_current_losses()
+        got = np.array([L[k] for k in names])
+        print(it, got, g['losses'][it])
+        np.testing.assert_allclose(got, g['losses'][it], rtol=2e-5 if it == 0 else 5e-3, err_msg='step %d' % it)
+    for n in ATHENA_NETS:
+        ps = list(getattr(model, 'net' + n).parameters())
+        upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(ps, before[n])])
+        sel = np.array([a.dim() > 1 for a in ps])
+        np.testing.assert_allclose(upd[sel], g['upd_' + n][sel], rtol=5e-2, err_msg=n)

@@ -141,3 +141,17 @@ def test_dice_geometry(golden_dir):
 def test_border_zero_rejected():
     with pytest.raises(ValueError):
         dice.assemble([], (8, 8, 8), (8, 8, 8), 4, 0, 0)
+
+
+def test_athena_step(golden_dir):
+    g = G(golden_dir, 'athena_step_36.npz')
+    size = int(g['size'])
+    names_n = ['G_A', 'G_B'] + apollo.ATHENA_D
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 6
+    sds = {n: S.weights_from_seed(sp, int(g['net_seed0']) + i) for i, (n, sp) in enumerate(zip(names_n, specs))}
+    model = apollo.AthenaOracle(sds)
+    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    names = [str(s) for s in g['loss_names']]
+    for it in range(2):
+        L = model.step(real)
+        np.testing.assert_allclose(np.array([L[k] for k in names]), g['losses'][it], rtol=2e-4, err_msg='step %d' % it)
