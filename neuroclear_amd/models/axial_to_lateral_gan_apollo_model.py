@@ -17,30 +17,30 @@ from . import networks
 from .base_model import BaseModel
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (lr, betas, eps=1e-8, no weight decay / amsgrad) over parameters that are views
-    into one flat fp32 buffer; step() is one nc_adam_step launch.  Exposes param_groups[0]['lr'] so that
-    torch's LambdaLR-style schedulers (networks.get_scheduler) keep working."""
+    into one flat fp32 buffer; step() is one nc_adam_step launch and the data-parallel gradient exchange is one
+    all-reduce.  A real torch Optimizer subclass, so torch's lr schedulers (networks.get_scheduler) drive
+    param_groups[0]['lr'] as usual."""
 
     def __init__(self, params, lr, betas, eps=1e-8):
-        self.params = [p for p in params]
-        dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.params = params
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        for p in self.params:
+        for p in params:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
             p.grad = self.grad[off:off + k].view_as(p.data)
             off += k
-        self.defaults = dict(lr=lr, betas=betas, eps=eps)
-        self.param_groups = [dict(params=self.params, lr=lr, initial_lr=lr, betas=betas, eps=eps)]
         self.state_step = 0
-        self._step_count = 0
 
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()
@@ -59,9 +59,9 @@ class FlatAdam:
                 torch.distributed.all_reduce(self.grad)
                 self.grad.div_(ws)
 
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
         self.state_step += 1
-        self._step_count += 1
         g = self.param_groups[0]
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], self.state_step)

@@ -273,3 +273,41 @@ def test_athena_step(golden_dir):
         upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(ps, before[n])])
         sel = np.array([a.dim() > 1 for a in ps])
         np.testing.assert_allclose(upd[sel], g['upd_' + n][sel], rtol=5e-2, err_msg=n)
+
+
+def test_train_onecube_and_checkpoint_roundtrip(tmp_path):
+    """Entry-script level: two iterations of train_onecube on a synthetic volume (option parsing, on-device crops,
+    schedulers, checkpoint files with the reference's names), then the generator is reloaded through TestModel /
+    load_networks and must reproduce the training model's output bit for bit."""
+    from neuroclear_amd import train_onecube
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.options import TestOptions
+    d = tmp_path / 'data'
+    d.mkdir()
+    np.save(str(d / 'vol.npy'), S.random_volume(21, 48))
+    ck = str(tmp_path / 'ckpt')
+    argv = ['--dataroot', str(d), '--checkpoints_dir', ck, '--name', 'm', '--model', 'axial_to_lateral_gan_apollo',
+            '--preprocess', 'randomcrop_randomflip_addColorChannel_addBatchChannel', '--crop_size', '36', '36', '36',
+            '--gan_mode', 'lsgan', '--init_type', 'kaiming', '--norm', 'instance', '--lambda_A', '5',
+            '--lambda_plane', '1', '1', '1', '--lr_policy', 'constant', '--randomize_projection_depth',
+            '--projection_depth', '10', '--save_by_iter', '--save_latest_freq', '2', '--print_freq', '1',
+            '--max_iters', '2', '--gpu_ids', '0']
+    np.random.seed(3)
+    import random
+    random.seed(3)
+    model = train_onecube.main(argv)
+    assert os.path.exists(os.path.join(ck, 'm', 'iter_2_net_G_A.pth'))
+    assert os.path.exists(os.path.join(ck, 'm', 'iter_2_net_D_B_axial.pth'))
+    sd = torch.load(os.path.join(ck, 'm', 'iter_2_net_G_A.pth'))
+    assert list(sd.keys()) == [k for k, _ in S.unet_deconv_spec()]
+    topt = TestOptions().parse(['--dataroot', str(d), '--checkpoints_dir', ck, '--name', 'm', '--model_suffix', '_A',
+                                '--load_iter', '2', '--gpu_ids', '0', '--init_type', 'kaiming', '--no_dropout'])
+    topt.continue_train = False
+    tm = create_model(topt)
+    tm.setup(topt)
+    x = torch.rand(1, 1, 36, 36, 36, device=DEV)
+    tm.set_input({'A': x, 'A_paths': 'x'})
+    tm.test()
+    with torch.no_grad():
+        ref = model.netG_A(x)
+    assert torch.equal(tm.fake, ref)
