@@ -152,7 +152,19 @@ using namespace nc;
 
 extern "C" {
 
-size_t nc_convT_ws_bytes(int, int, int, int, int, int) { return kBiasGradWsBytes; }
+// ConvTranspose(k=2,s=2) is the adjoint of a stride-2 2x2x2 convolution with the SAME weight memory layout
+// (w[Cin_T][Cout_T][2][2][2] == conv weight [K][C][taps] with K = Cin_T, C = Cout_T): its weight gradient is that
+// convolution's weight gradient with the roles of the two tensors swapped, which puts it on the MFMA gather-GEMM.
+static bool convT_as_conv(ConvDims& d, int N, int C, int D, int H, int W, int K) {
+  return make_dims(d, N, K, 2 * D, 2 * H, 2 * W, C, 2, 2, 2, 2, 0) && gemm_wgrad_supported(d);
+}
+
+size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K) {
+  size_t b = kBiasGradWsBytes;
+  ConvDims d;
+  if (convT_as_conv(d, N, C, D, H, W, K) && gemm_ws_bytes(d) > b) b = gemm_ws_bytes(d);
+  return (b + 255) & ~(size_t)255;
+}
 
 static int convT_check(const char* what, int N, int C, int D, int H, int W, int K) {
   if (N < 1 || C < 1 || D < 1 || H < 1 || W < 1 || K < 1 || K > 65535 * 4 || N > 65535) {
@@ -195,7 +207,11 @@ int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias
   if (!x || !dy || !dw) { set_error("convT_wgrad: null pointer"); return NC_ERR_ARG; }
   if (int e = convT_check("convT_wgrad", N, C, D, H, W, K)) return e;
   hipStream_t s = (hipStream_t)stream;
-  if (C % 4 == 0 && K % 4 == 0) {
+  ConvDims cd;
+  if (!g_force_direct && convT_as_conv(cd, N, C, D, H, W, K) && ws && ws_bytes >= gemm_ws_bytes(cd)) {
+    // dW_T[ci][co][t] = sum_pos x[ci][pos] * dy[co][2 pos + t]  ==  conv_wgrad(input = dy, grad_output = x)
+    if (int e = conv_wgrad_gemm(dy, x, dw, cd, ws, ws_bytes, s)) return e;
+  } else if (C % 4 == 0 && K % 4 == 0) {
     hipLaunchKernelGGL((k_convT_wgrad<4, 4>), dim3(C / 4, K / 4), dim3(256), 0, s, x, dy, dw, N, C, D, H, W, K);
   } else {
     hipLaunchKernelGGL((k_convT_wgrad<1, 1>), dim3(C, K), dim3(256), 0, s, x, dy, dw, N, C, D, H, W, K);

@@ -143,26 +143,40 @@ class AxialToLateralGANApolloModel(BaseModel):
         self.fake = self.netG_A(self.real)
         self.rec = self.netG_B(self.fake)
 
-    # -- Volume.get_slice / get_projection (apollo:322-351); num_slice = shape[-1] for every axis (:325)
+    # -- Volume.get_slice / get_projection (apollo:322-351); num_slice = shape[-1] for every axis (:325).
+    #    The random draw happens here, in the reference's order; the discriminator call is deferred so that several
+    #    planes going through the SAME network are evaluated as one batch (InstanceNorm is per instance and the LSGAN
+    #    means are taken per plane, so every number is unchanged -- only the launch count drops from 18 to 8 passes).
+    def _slice(self, input, slice_axis):
+        return ops.volume_slice(input, slice_axis, np.random.randint(input.shape[-1]))
+
+    def _proj(self, input, slice_axis):
+        start = np.random.randint(0, input.shape[-1] - self.projection_depth)
+        return ops.volume_mip(input, slice_axis, start, self.projection_depth)
+
+    @staticmethod
+    def _D(netD, planes):
+        pred = netD(planes[0] if len(planes) == 1 else torch.cat(planes, 0))
+        return [pred[i:i + 1] for i in range(len(planes))]
+
     def iter_f(self, input, function, slice_axis):
-        idx = np.random.randint(input.shape[-1])
-        return function(ops.volume_slice(input, slice_axis, idx))
+        return function(self._slice(input, slice_axis))
 
     def proj_f(self, input, function, slice_axis):
-        start = np.random.randint(0, input.shape[-1] - self.projection_depth)
-        return function(ops.volume_mip(input, slice_axis, start, self.projection_depth))
+        return function(self._proj(input, slice_axis))
+
+    def _d_loss(self, pred_real, pred_fake):
+        return (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
 
     def backward_D_slice(self, netD, real, fake, slice_axis_real, slice_axis_fake):
-        pred_real = self.iter_f(real, netD, slice_axis_real)
-        pred_fake = self.iter_f(fake.detach(), netD, slice_axis_fake)
-        loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
+        pr, pf = self._D(netD, [self._slice(real, slice_axis_real), self._slice(fake.detach(), slice_axis_fake)])
+        loss_D = self._d_loss(pr, pf)
         loss_D.backward()
         return loss_D
 
     def backward_D_projection(self, netD, real, fake, slice_axis_real, slice_axis_fake):
-        pred_real = self.iter_f(real, netD, slice_axis_real)
-        pred_fake = self.proj_f(fake.detach(), netD, slice_axis_fake)
-        loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
+        pr, pf = self._D(netD, [self._slice(real, slice_axis_real), self._proj(fake.detach(), slice_axis_fake)])
+        loss_D = self._d_loss(pr, pf)
         loss_D.backward()
         return loss_D
 
@@ -171,10 +185,14 @@ class AxialToLateralGANApolloModel(BaseModel):
                                                            self.lateral_axis, self.lateral_axis)
 
     def backward_D_A_axial(self):
-        self.loss_D_A_axial_1 = self.backward_D_projection(self.netD_A_axial, self.real, self.fake,
-                                                           self.lateral_axis, self.axial_1_axis)
-        self.loss_D_A_axial_2 = self.backward_D_projection(self.netD_A_axial, self.real, self.fake,
-                                                           self.lateral_axis, self.axial_2_axis)
+        """apollo:225-239: two (real slice, fake MIP) pairs through netD_A_axial -- one batch of four planes."""
+        fd = self.fake.detach()
+        planes = [self._slice(self.real, self.lateral_axis), self._proj(fd, self.axial_1_axis),
+                  self._slice(self.real, self.lateral_axis), self._proj(fd, self.axial_2_axis)]
+        p = self._D(self.netD_A_axial, planes)
+        self.loss_D_A_axial_1 = self._d_loss(p[0], p[1])
+        self.loss_D_A_axial_2 = self._d_loss(p[2], p[3])
+        (self.loss_D_A_axial_1 + self.loss_D_A_axial_2).backward()
         self.loss_D_A_axial = (self.loss_D_A_axial_1 + self.loss_D_A_axial_2) * 0.5
 
     def backward_D_B_lateral(self):
@@ -182,26 +200,31 @@ class AxialToLateralGANApolloModel(BaseModel):
                                                       self.lateral_axis)
 
     def backward_D_B_axial(self):
-        self.loss_D_B_axial_1 = self.backward_D_slice(self.netD_B_axial, self.real, self.rec, self.axial_1_axis,
-                                                      self.axial_1_axis)
-        self.loss_D_B_axial_2 = self.backward_D_slice(self.netD_B_axial, self.real, self.rec, self.axial_2_axis,
-                                                      self.axial_2_axis)
+        """apollo:241-253"""
+        rd = self.rec.detach()
+        planes = [self._slice(self.real, self.axial_1_axis), self._slice(rd, self.axial_1_axis),
+                  self._slice(self.real, self.axial_2_axis), self._slice(rd, self.axial_2_axis)]
+        p = self._D(self.netD_B_axial, planes)
+        self.loss_D_B_axial_1 = self._d_loss(p[0], p[1])
+        self.loss_D_B_axial_2 = self._d_loss(p[2], p[3])
+        (self.loss_D_B_axial_1 + self.loss_D_B_axial_2).backward()
         self.loss_D_B_axial = (self.loss_D_B_axial_1 + self.loss_D_B_axial_2) * 0.5
 
     def backward_G(self):
         """apollo:255-283"""
         lambda_A = self.opt.lambda_A
-        self.loss_G_A_lateral = self.criterionGAN(self.proj_f(self.fake, self.netD_A_lateral, self.lateral_axis),
-                                                  True) * self.lambda_plane_target
-        self.loss_G_A_axial = \
-            self.criterionGAN(self.proj_f(self.fake, self.netD_A_axial, self.axial_1_axis), True) * self.lambda_slice + \
-            self.criterionGAN(self.proj_f(self.fake, self.netD_A_axial, self.axial_2_axis), True) * self.lambda_slice
+        g = self.criterionGAN
+        (p_lat,) = self._D(self.netD_A_lateral, [self._proj(self.fake, self.lateral_axis)])
+        p_ax = self._D(self.netD_A_axial, [self._proj(self.fake, self.axial_1_axis),
+                                           self._proj(self.fake, self.axial_2_axis)])
+        self.loss_G_A_lateral = g(p_lat, True) * self.lambda_plane_target
+        self.loss_G_A_axial = g(p_ax[0], True) * self.lambda_slice + g(p_ax[1], True) * self.lambda_slice
         self.loss_G_A = self.loss_G_A_lateral + self.loss_G_A_axial * 0.5
-        self.loss_G_B_lateral = self.criterionGAN(self.iter_f(self.rec, self.netD_B_lateral, self.lateral_axis),
-                                                  True) * self.lambda_plane_target
-        self.loss_G_B_axial = \
-            self.criterionGAN(self.iter_f(self.rec, self.netD_B_axial, self.axial_1_axis), True) * self.lambda_slice + \
-            self.criterionGAN(self.iter_f(self.rec, self.netD_B_axial, self.axial_2_axis), True) * self.lambda_slice
+        (q_lat,) = self._D(self.netD_B_lateral, [self._slice(self.rec, self.lateral_axis)])
+        q_ax = self._D(self.netD_B_axial, [self._slice(self.rec, self.axial_1_axis),
+                                           self._slice(self.rec, self.axial_2_axis)])
+        self.loss_G_B_lateral = g(q_lat, True) * self.lambda_plane_target
+        self.loss_G_B_axial = g(q_ax[0], True) * self.lambda_slice + g(q_ax[1], True) * self.lambda_slice
         self.loss_G_B = self.loss_G_B_lateral + self.loss_G_B_axial * 0.5
         self.loss_cycle = self.criterionCycle(self.rec, self.real) * lambda_A
         self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle
