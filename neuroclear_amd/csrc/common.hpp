@@ -52,6 +52,7 @@ bool mfma_fwd_supported(const ConvDims& d);
 bool mfma_dgrad_supported(const ConvDims& d);
 bool mfma_wgrad_supported(const ConvDims& d);
 size_t mfma_ws_bytes(const ConvDims& d);
+size_t mfma_fwd_ws_bytes(const ConvDims& d);
 int conv_fwd_mfma(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s);
 int conv_dgrad_mfma(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,

@@ -6,15 +6,20 @@
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (fmaf chain), 64 cycles per instruction per SIMD -- the same peak as the
 //     fp32 VALU (157 TFLOP/s) but with ONE instruction per 4096 FLOP, so staging/address work hides behind it.
 //   * A operand (weights) : pre-packed [K-row][co-pair-interleaved] in HBM (a few 100 KB, L1/L2 resident); each lane
-//     loads one float2 per k-step = its two 32-wide co blocks.  No LDS for weights.
+//     loads one float2 per k-step = its two 32-wide co blocks.  No LDS for weights; the stream is software-pipelined
+//     by hand one kernel row (3-6 k MFMA cycles) ahead.
 //   * B operand (inputs)  : an input brick of CK channels x (Tz+2p) planes x (Ty+2p) rows x (W+2p) columns in LDS, rows
 //     FLATTENED with pitch P = W+2p.  A tap (dz,dy,dx) is then a constant LDS offset dz*RW + dy*P + dx, and one MFMA
 //     column block is 32 consecutive floats -> ds_read_b32, conflict-free for any alignment.  Output positions that
 //     fall on the 2p pad columns are computed and discarded (<= 2p/P waste) -- this is what makes 108/140/54/27-wide
 //     volumes tile without 32-alignment.
-//   * staging: global -> registers (issued BEFORE the MFMA loop of the current chunk) -> LDS (after it): the T14
-//     split; per-element global offsets are decoded once per tile (magic-number division) and kept in registers.
-//     Zero padding and (optionally) InstanceNorm+ReLU of the producer are applied while staging.
+//   * staging by ROWS: global -> registers (issued BEFORE the MFMA loop of the current unit) -> LDS (after it); a wave
+//     copies whole rows, lane = column, so the (channel, plane, row) decode and the row base are wave-uniform.
+//   * STREAM-K over (tile, channel-chunk) units: 256 persistent workgroups (one per CU) each take an equal, contiguous
+//     share of all units, so the wave of equal tiles that does not divide by the CU count (1296 tiles = 5.06 rounds at
+//     108^3) no longer costs a whole extra round.  A tile whose chunks are split between two workgroups is written
+//     as partial accumulators to a workspace slot and summed in chunk order by a fix-up kernel (deterministic, no
+//     atomics); complete tiles are stored directly.
 //   * epilogue: accumulator rows are co, lanes are voxels -> each store instruction writes 2 x 128 B contiguous.
 #include "common.hpp"
 
@@ -23,32 +28,85 @@ namespace nc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int kRMAX = 18;  // brick rows staged per wave per chunk (x 3 column segments of 64)
-static constexpr bool kFuseNorm = false;  // normalize-on-load is wired but not enabled in round 1  // staging registers per lane (elements of the brick per lane per chunk)
+static constexpr bool kFuseNorm = false;  // normalize-on-load is wired but not enabled in round 1
+static constexpr int kNumWG = 256;        // persistent workgroups = CUs of an MI355X
 
 struct FwdParams {
   const float* x;
   const float* wp;
   const float* bias;
   float* y;
+  float* part;        // partial-accumulator slots [2 * kNumWG][32 * VB][NT]
   const float* mean;  // optional fused normalize-on-load of the input: act((x - mean[c]) * rstd[c])
   const float* rstd;
   float slope;
   int C, K, D, H, W;
-  int Tz, Ty, nty;
+  int Tz, Ty, nty, ntz, ncot;
   int P, RW, planes, CP;  // row pitch, floats per plane (= (Ty+2p)*P), planes per channel, floats per channel
   int nelem;              // CK * CP
   unsigned mP;            // magic multiplier: n / P == __umulhi(n, mP)
   int nrows, rowsY, PRows;  // brick rows per chunk (CK*planes*rowsY), rows per plane (Ty+2p), rows per channel
   unsigned mRowsY, mPR;
   int nchunks;
+  long units;  // tiles * nchunks
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
 
+struct TileId {
+  int n, cot, z0, y0;
+};
+__device__ __forceinline__ TileId decode_tile(const FwdParams& p, long tile) {
+  const int nsp = p.ntz * p.nty;
+  const int sp = (int)(tile % nsp);
+  const long rest = tile / nsp;
+  TileId t;
+  t.cot = (int)(rest % p.ncot);
+  t.n = (int)(rest / p.ncot);
+  t.z0 = (sp / p.nty) * p.Tz;
+  t.y0 = (sp % p.nty) * p.Ty;
+  return t;
+}
+
+// C/D layout of 32x32 MFMA: column (voxel) = lane & 31, row (co) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int WM, int WN, int VB>
+__device__ __forceinline__ void store_tile(const FwdParams& p, const f32x16 (&acc)[2][VB], const TileId& t, int wm,
+                                           int wn, int li, int h) {
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int GP = WM / p.Tz;
+  const int tzl = wm / GP, blk0 = (wm % GP) * VB;
+  const int cob = (t.cot * WN + wn) * 64;
+  const int z = t.z0 + tzl;
+  if (z >= p.D) return;
+  float* yn = p.y + ((long)t.n * p.K + cob) * S + (long)z * HW;
+#pragma unroll
+  for (int v = 0; v < VB; ++v) {
+    const unsigned q = (blk0 + v) * 32 + li;
+    const unsigned ty = fastdiv(q, p.mP);
+    const unsigned x = q - ty * p.P;
+    const int y = t.y0 + (int)ty;
+    if ((int)ty < p.Ty && y < p.H && (int)x < p.W) {
+      float* yv = yn + (long)y * p.W + x;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float val = acc[a][v][r];
+          if (p.bias) val += p.bias[cob + co];
+          yv[(long)co * S] = val;
+        }
+    }
+  }
+}
+
 template <int KS, int CK, int WM, int WN, int VB>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   constexpr int NT = WM * WN * 64;
+  constexpr int NWV = NT / 64;
   constexpr int PAD = KS / 2;
+  constexpr int TAPS = KS * KS * KS;
+  constexpr int U = KS * (CK / 2);  // k-steps per (dz, dy) row of the kernel
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -56,21 +114,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
   const int li = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x;
-  const int z0 = (tile / p.nty) * p.Tz, y0 = (tile % p.nty) * p.Ty;
-  const int cot = blockIdx.y, n = blockIdx.z;
+  const int wg = blockIdx.x;
+  const long u0 = p.units * wg / kNumWG, u1 = p.units * (wg + 1) / kNumWG;
+  if (u0 >= u1) return;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
-  // ---- staging by ROWS: the brick is CK x planes x rowsY rows of W floats; a wave copies whole rows, lane = column,
-  //      so the (channel, plane, row) decode and the global row base are wave-uniform (scalar unit) and no per-lane
-  //      index arithmetic is left.  Rows outside the volume are written as zeros; the 2p pad columns of every LDS row
-  //      are zeroed once and never written again.
-  constexpr int NWV = NT / 64;
-  const float* xn = p.x + (long)n * p.C * S;
+  // ---- staging by rows (see header)
   float st[kRMAX][3];
   const bool cm0 = lane < p.W, cm1 = lane + 64 < p.W, cm2 = lane + 128 < p.W;
-  auto stage_load = [&](int chunk) {
-    const float* xc = xn + (long)chunk * CK * S + lane;
+  auto stage_load = [&](const TileId& t, int chunk) {
+    const float* xc = p.x + ((long)t.n * p.C + (long)chunk * CK) * S + lane;
 #pragma unroll
     for (int i = 0; i < kRMAX; ++i) {
       const unsigned row = wave + NWV * i;
@@ -78,7 +131,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
       const unsigned r1 = row - cic * p.PRows;
       const unsigned pz = fastdiv(r1, p.mRowsY);
       const unsigned yy = r1 - pz * p.rowsY;
-      const int z = z0 + (int)pz - PAD, y = y0 + (int)yy - PAD;
+      const int z = t.z0 + (int)pz - PAD, y = t.y0 + (int)yy - PAD;
       const bool rok = (int)row < p.nrows && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
       const float* r = xc + (long)cic * S + (long)z * HW + (long)y * p.W;
       float v0 = (rok && cm0) ? r[0] : 0.f;
@@ -86,7 +139,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
       float v2 = (rok && cm2) ? r[128] : 0.f;
       if (kFuseNorm && p.mean) {  // wave-uniform: fused InstanceNorm + activation of the producer layer
         const int c = chunk * CK + min((int)cic, CK - 1);
-        const float m = p.mean[(long)n * p.C + c], rs = p.rstd[(long)n * p.C + c];
+        const float m = p.mean[(long)t.n * p.C + c], rs = p.rstd[(long)t.n * p.C + c];
         v0 = (v0 - m) * rs; v1 = (v1 - m) * rs; v2 = (v2 - m) * rs;
         v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; v2 = v2 > 0.f ? v2 : v2 * p.slope;
         v0 = rok ? v0 : 0.f; v1 = rok ? v1 : 0.f; v2 = rok ? v2 : 0.f;
@@ -117,47 +170,70 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   const int GP = WM / p.Tz;
   const int tzl = wm / GP, blk0 = (wm % GP) * VB;
   const int b_base = h * p.CP + tzl * p.RW + blk0 * 32 + li;
-  const int cob = (cot * WN + wn) * 64;  // first output channel of this wave
-  const float* wlane = p.wp + cob + li * 2 + (long)h * p.K;
+  const long kstep = 2L * p.K;                     // floats of packed weights per k-step
+  const long chunk_stride = (long)TAPS * CK * p.K;  // floats of packed weights per channel chunk
+  auto wbase = [&](int cot, int chunk) {
+    return p.wp + (cot * WN + wn) * 64 + li * 2 + (long)h * p.K + chunk * chunk_stride;
+  };
 
   f32x16 acc[2][VB];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int v = 0; v < VB; ++v)
+      for (int v = 0; v < VB; ++v)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
+  };
+  zero_acc();
 
   float* buf0 = lds;
   float* buf1 = lds + p.nelem;
 
-  stage_load(0);
+  // ---- first unit
+  long tile = u0 / p.nchunks;
+  int chunk = (int)(u0 - tile * p.nchunks);
+  const long first_tile = tile;
+  int first_chunk = chunk;  // first chunk of the current tile that THIS workgroup accumulates
+  TileId tid_cur = decode_tile(p, tile);
+  stage_load(tid_cur, chunk);
   stage_store(buf0);
   __syncthreads();
 
-  // The packed weights are ONE linear stream over the whole kernel: k-step s reads rows 2s, 2s+1 (lane half h picks
-  // the row), chunk after chunk, tap after tap.  They are software-pipelined by hand one (dz, dy) row of the kernel
-  // ahead -- U = KS * CK/2 k-steps, 3-6 k cycles of MFMA -- so no MFMA ever waits for its L2 round trip.  (The last
-  // prefetch runs past the end of the stream into the workspace slack the host reserves.)
-  constexpr int U = KS * (CK / 2);
-  const long kstep = 2L * p.K;  // floats per k-step
-  const float* aptr = wlane;
+  // The packed weights of one tile are ONE linear stream: k-step s reads rows 2s, 2s+1 (lane half h picks the row),
+  // chunk after chunk, tap after tap; prefetched one (dz, dy) kernel row ahead (the last prefetch of the launch runs
+  // into the workspace slack the host reserves behind the packed weights).
+  const float* aptr = wbase(tid_cur.cot, chunk);
   float2 a_cur[U], a_nxt[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) a_cur[u] = *reinterpret_cast<const float2*>(aptr + u * kstep);
   aptr += U * kstep;
 
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    const float* cur = (chunk & 1) ? buf1 : buf0;
-    float* nxt = (chunk & 1) ? buf0 : buf1;
-    const bool more = chunk + 1 < p.nchunks;
-    if (more) stage_load(chunk + 1);
+  int parity = 0;
+  for (long u = u0; u < u1; ++u) {
+    const float* cur = parity ? buf1 : buf0;
+    float* nxt = parity ? buf0 : buf1;
+    // ---- next unit (uniform bookkeeping)
+    const bool more = u + 1 < u1;
+    long ntile = tile;
+    int nchunk = chunk + 1;
+    if (nchunk == p.nchunks) {
+      nchunk = 0;
+      ntile = tile + 1;
+    }
+    const bool tile_ends = !more || ntile != tile;
+    TileId tid_nxt = tid_cur;
+    if (more && ntile != tile) tid_nxt = decode_tile(p, ntile);
+    if (more) stage_load(tid_nxt, nchunk);
+    const float* next_aptr = more ? wbase(tid_nxt.cot, nchunk) : aptr;
+
 #pragma unroll 1
     for (int dz = 0; dz < KS; ++dz) {
 #pragma unroll 1
       for (int dy = 0; dy < KS; ++dy) {
+        if (dz == KS - 1 && dy == KS - 1) aptr = next_aptr;  // the row after this unit's last row
 #pragma unroll
-        for (int u = 0; u < U; ++u) a_nxt[u] = *reinterpret_cast<const float2*>(aptr + u * kstep);
+        for (int uu = 0; uu < U; ++uu) a_nxt[uu] = *reinterpret_cast<const float2*>(aptr + uu * kstep);
         aptr += U * kstep;
         const float* brow = cur + b_base + dz * p.RW + dy * p.P;
 #pragma unroll
@@ -176,37 +252,70 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
           }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) a_cur[u] = a_nxt[u];
+        for (int uu = 0; uu < U; ++uu) a_cur[uu] = a_nxt[uu];
       }
     }
     if (more) stage_store(nxt);
     __syncthreads();
-  }
+    parity ^= 1;
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: column (voxel) = lane & 31, row (co) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int z = z0 + tzl;
-  if (z < p.D) {
-    float* yn = p.y + ((long)n * p.K + cob) * S + (long)z * HW;
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      const unsigned q = (blk0 + v) * 32 + li;
-      const unsigned ty = fastdiv(q, p.mP);
-      const unsigned x = q - ty * p.P;
-      const int y = y0 + (int)ty;
-      if ((int)ty < p.Ty && y < p.H && (int)x < p.W) {
-        float* yv = yn + (long)y * p.W + x;
+    if (tile_ends) {
+      if (first_chunk == 0 && chunk == p.nchunks - 1) {
+        store_tile<WM, WN, VB>(p, acc, tid_cur, wm, wn, li, h);
+      } else {  // partial: slot 0 = this workgroup's first tile, slot 1 = its last tile
+        float* slot = p.part + ((long)(2 * wg + (tile == first_tile ? 0 : 1)) * (32 * VB)) * NT + tid;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float val = acc[a][v][r];
-            if (p.bias) val += p.bias[cob + co];
-            yv[(long)co * S] = val;
-          }
+          for (int v = 0; v < VB; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slot[(long)((a * VB + v) * 16 + r) * NT] = acc[a][v][r];
       }
+      zero_acc();
+      first_chunk = nchunk;
     }
+    tile = ntile;
+    chunk = nchunk;
+    tid_cur = tid_nxt;
   }
+}
+
+// Fix-up: one workgroup per boundary between two persistent workgroups; if that boundary is the first one that cuts
+// tile t, the workgroup adds the partial accumulators of every workgroup that touched t, in chunk order, and stores t.
+template <int WM, int WN, int VB>
+__global__ __launch_bounds__(WM* WN * 64) void k_conv_fixup(FwdParams p) {
+  constexpr int NT = WM * WN * 64;
+  const int b = blockIdx.x + 1;
+  const long ub = p.units * b / kNumWG;
+  if (ub % p.nchunks == 0) return;  // boundary on a tile edge: nothing is split here
+  const long t = ub / p.nchunks;
+  const long tb = t * p.nchunks, te = tb + p.nchunks;
+  const long uprev = p.units * (b - 1) / kNumWG;
+  if (b > 1 && uprev > tb) return;  // an earlier boundary already cuts this tile: that workgroup does the work
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  f32x16 acc[2][VB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int v = 0; v < VB; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][v][r] = 0.f;
+  for (int w = b - 1; w < kNumWG; ++w) {
+    const long w0 = p.units * w / kNumWG, w1 = p.units * (w + 1) / kNumWG;
+    if (w0 >= te) break;
+    if (w0 >= w1 || w1 <= tb) continue;
+    const float* slot = p.part + ((long)(2 * w + (w0 / p.nchunks == t ? 0 : 1)) * (32 * VB)) * NT + tid;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int v = 0; v < VB; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][v][r] += slot[(long)((a * VB + v) * 16 + r) * NT];
+  }
+  const TileId tidx = decode_tile(p, t);
+  store_tile<WM, WN, VB>(p, acc, tidx, wm, wn, lane & 31, lane >> 5);
 }
 
 // Weight packing.  Row = chunk*TAPS*CK + tap*CK + cic  (ci = chunk*CK + cic); inside a row: [K/64][32][2] with
@@ -230,7 +339,7 @@ __global__ void k_pack_w(const float* __restrict__ w, float* __restrict__ wp, in
 
 struct FwdPlan {
   int cfg, CK, Tz, Ty, nty, ntz, P, RW, planes, CP, nelem, lds_bytes;
-  long cost;
+  double cost;
 };
 
 struct Cfg { int WM, WN, VB; };
@@ -275,9 +384,10 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         const int nrows = CK * planes * (Ty + 2 * pad);
         if (bytes > kLdsMax || (nrows + NT / 64 - 1) / (NT / 64) > kRMAX) continue;
         const long tiles = (long)ntz * nty * (Cout / (g.WN * 64)) * N;
-        const long rounds = (tiles + 255) / 256;
-        // time per tile ~ VB MFMA pairs per k-step; small penalty for more barriers with small CK
-        const long cost = rounds * g.VB * 1000 + (8 / CK) * 5 * rounds;
+        // stream-K: every workgroup gets units/256 units, a unit costs ~ VB * CK MFMA groups (+ a barrier)
+        const long units = tiles * (Cin / CK);
+        const double per_wg = (double)((units + kNumWG - 1) / kNumWG);
+        const double cost = per_wg * (g.VB * CK + 0.15);
         if (!found || cost < best.cost) {
           found = true;
           best = FwdPlan{c, CK, Tz, Ty, nty, ntz, P, RW, planes, CP, (int)nelem, (int)bytes, cost};
@@ -289,8 +399,10 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
   return found;
 }
 
+static size_t part_bytes(const Cfg& g) { return (size_t)2 * kNumWG * 32 * g.VB * (g.WM * g.WN * 64) * sizeof(float); }
+
 template <int KS, int CK, int WM, int WN, int VB>
-static int launch_one(const FwdParams& p, dim3 grid, int lds_bytes, hipStream_t s) {
+static int launch_one(const FwdParams& p, int lds_bytes, hipStream_t s) {
   auto kern = k_conv_mfma<KS, CK, WM, WN, VB>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -301,18 +413,20 @@ static int launch_one(const FwdParams& p, dim3 grid, int lds_bytes, hipStream_t 
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds_bytes, s, p);
-  return check_launch("conv_mfma");
+  hipLaunchKernelGGL(kern, dim3(kNumWG), dim3(WM * WN * 64), lds_bytes, s, p);
+  if (int e = check_launch("conv_mfma")) return e;
+  hipLaunchKernelGGL((k_conv_fixup<WM, WN, VB>), dim3(kNumWG - 1), dim3(WM * WN * 64), 0, s, p);
+  return check_launch("conv_mfma_fixup");
 }
 
 template <int KS, int CK>
-static int launch_cfg(int cfg, const FwdParams& p, dim3 grid, int lds, hipStream_t s) {
+static int launch_cfg(int cfg, const FwdParams& p, int lds, hipStream_t s) {
   switch (cfg) {
-    case 0: return launch_one<KS, CK, 8, 1, 4>(p, grid, lds, s);
-    case 1: return launch_one<KS, CK, 8, 1, 2>(p, grid, lds, s);
-    case 2: return launch_one<KS, CK, 4, 2, 2>(p, grid, lds, s);
-    case 3: return launch_one<KS, CK, 2, 4, 2>(p, grid, lds, s);
-    default: return launch_one<KS, CK, 2, 4, 1>(p, grid, lds, s);
+    case 0: return launch_one<KS, CK, 8, 1, 4>(p, lds, s);
+    case 1: return launch_one<KS, CK, 8, 1, 2>(p, lds, s);
+    case 2: return launch_one<KS, CK, 4, 2, 2>(p, lds, s);
+    case 3: return launch_one<KS, CK, 2, 4, 2>(p, lds, s);
+    default: return launch_one<KS, CK, 2, 4, 1>(p, lds, s);
   }
 }
 
@@ -322,8 +436,6 @@ static bool shape_ok(const ConvDims& d, int Cin, int Cout) {
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (d.pd != d.kd / 2 || d.ph != d.kd / 2 || d.pw != d.kd / 2) return false;
   if (Cin % 4 != 0 || Cout % 64 != 0) return false;
-  if (d.kd == 5 && Cin % 2 != 0) return false;
-  if ((long)Cin * d.D * d.H * d.W * 4 >= (1L << 31)) return false;  // int32 byte offsets in the staging loads
   if (d.W > 192) return false;  // rows are staged as up to three 64-column segments
   return true;
 }
@@ -337,6 +449,20 @@ bool mfma_dgrad_supported(const ConvDims& d) {
   return shape_ok(d, d.K, d.C) && plan_fwd(d.kd, d.K, d.C, d.N, d.D, d.H, d.W, pl);
 }
 
+// bytes of workspace the fwd / dgrad MFMA kernels need for this shape: packed weights + prefetch slack + partial slots
+size_t mfma_fwd_ws_bytes(const ConvDims& d) {
+  size_t need = 0;
+  FwdPlan pl;
+  const size_t pack = ((size_t)d.C * d.K * d.kd * d.kh * d.kw * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
+  if (shape_ok(d, d.C, d.K) && plan_fwd(d.kd, d.C, d.K, d.N, d.D, d.H, d.W, pl))
+    need = pack + part_bytes(kCfgs[pl.cfg]);
+  if (shape_ok(d, d.K, d.C) && plan_fwd(d.kd, d.K, d.C, d.N, d.D, d.H, d.W, pl)) {
+    const size_t b = pack + part_bytes(kCfgs[pl.cfg]);
+    if (b > need) need = b;
+  }
+  return need;
+}
+
 static int run(const float* x, const float* w, const float* bias, float* y, int Cin, int Cout, const ConvDims& d,
                int mode, void* ws, size_t wsb, hipStream_t s) {
   FwdPlan pl;
@@ -344,8 +470,10 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
     set_error("conv_mfma: no tile plan for this shape");
     return NC_ERR_SHAPE;
   }
+  const Cfg& g = kCfgs[pl.cfg];
   const int taps = d.kd * d.kh * d.kw;
-  const size_t need = (size_t)Cin * Cout * taps * sizeof(float) + kPackSlackBytes;
+  const size_t pack = ((size_t)Cin * Cout * taps * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
+  const size_t need = pack + part_bytes(g);
   if (!ws || wsb < need) {
     set_error("conv_mfma: workspace too small (%zu < %zu)", wsb, need);
     return NC_ERR_WS;
@@ -354,21 +482,22 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
   hipLaunchKernelGGL(k_pack_w, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, taps, pl.CK, mode);
   if (int e = check_launch("pack_w")) return e;
   FwdParams p{};
-  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.mean = nullptr; p.rstd = nullptr; p.slope = 0.f;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.part = (float*)((char*)ws + pack);
+  p.mean = nullptr; p.rstd = nullptr; p.slope = 0.f;
   p.C = Cin; p.K = Cout; p.D = d.D; p.H = d.H; p.W = d.W;
-  p.Tz = pl.Tz; p.Ty = pl.Ty; p.nty = pl.nty; p.P = pl.P; p.RW = pl.RW; p.planes = pl.planes; p.CP = pl.CP;
+  p.Tz = pl.Tz; p.Ty = pl.Ty; p.nty = pl.nty; p.ntz = pl.ntz; p.ncot = Cout / (g.WN * 64);
+  p.P = pl.P; p.RW = pl.RW; p.planes = pl.planes; p.CP = pl.CP;
   p.nelem = pl.nelem; p.mP = magic(pl.P);
   p.rowsY = pl.Ty + 2 * (d.kd / 2); p.PRows = pl.planes * p.rowsY; p.nrows = pl.CK * p.PRows;
   p.mRowsY = magic(p.rowsY); p.mPR = magic(p.PRows);
   p.nchunks = Cin / pl.CK;
-  const Cfg& g = kCfgs[pl.cfg];
-  dim3 grid(pl.ntz * pl.nty, Cout / (g.WN * 64), d.N);
+  p.units = (long)d.N * p.ncot * pl.ntz * pl.nty * p.nchunks;
   if (d.kd == 3) {
-    if (pl.CK == 8) return launch_cfg<3, 8>(pl.cfg, p, grid, pl.lds_bytes, s);
-    return launch_cfg<3, 4>(pl.cfg, p, grid, pl.lds_bytes, s);
+    if (pl.CK == 8) return launch_cfg<3, 8>(pl.cfg, p, pl.lds_bytes, s);
+    return launch_cfg<3, 4>(pl.cfg, p, pl.lds_bytes, s);
   }
-  if (pl.CK == 4) return launch_cfg<5, 4>(pl.cfg, p, grid, pl.lds_bytes, s);
-  return launch_cfg<5, 2>(pl.cfg, p, grid, pl.lds_bytes, s);
+  if (pl.CK == 4) return launch_cfg<5, 4>(pl.cfg, p, pl.lds_bytes, s);
+  return launch_cfg<5, 2>(pl.cfg, p, pl.lds_bytes, s);
 }
 
 int conv_fwd_mfma(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,

@@ -254,9 +254,7 @@ bool mfma_wgrad_supported(const ConvDims& d) {
 }
 
 size_t mfma_ws_bytes(const ConvDims& d) {
-  size_t need = 0;
-  if (d.kd == d.kh && d.kh == d.kw && (d.kd == 3 || d.kd == 5))
-    need = (size_t)d.C * d.K * d.kd * d.kh * d.kw * sizeof(float) + kPackSlackBytes;  // packed fwd/dgrad weights
+  size_t need = mfma_fwd_ws_bytes(d);  // packed weights + stream-K partial slots of the fwd / dgrad kernels
   WgPlan pl;
   if (plan_wgrad(d, pl)) {
     const size_t slab = (size_t)pl.parts * pl.G * 64 * (32 * pl.AB) * d.kd * d.kd * sizeof(float);
