@@ -36,6 +36,21 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 }
 
 
+PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
+             'dgrad_mfma_k5': 'conv_mfma_k5', 'wgrad_mfma_k3': 'wgrad_mfma_k3', 'wgrad_mfma_k5': 'wgrad_mfma_k5'}
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    read from inside the process).  None when the file or the class is missing."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            return round(json.load(f)['classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def apollo_opt(gpu):
     """The README training command (reference README.md:123-133) reduced to what the step uses."""
     return Namespace(gpu_ids=[gpu], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='bench',
@@ -125,7 +140,7 @@ def run_train(args, rank, world, dev):
         ach = flop / ms / 1e9
         roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
                     peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                    traffic=None, launches=n, avg_launch_ms=round(ms / n, 4),
+                    traffic=pmc_traffic(top), launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
