@@ -387,7 +387,8 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         // stream-K: every workgroup gets units/256 units, a unit costs ~ VB * CK MFMA groups (+ a barrier)
         const long units = tiles * (Cin / CK);
         const double per_wg = (double)((units + kNumWG - 1) / kNumWG);
-        const double cost = per_wg * (g.VB * CK + 0.15);
+        // + a fixed per-unit overhead (barrier, staging write, loop set-up) that favours fatter units
+        const double cost = per_wg * (g.VB * CK + 1.5);
         if (!found || cost < best.cost) {
           found = true;
           best = FwdPlan{c, CK, Tz, Ty, nty, ntz, P, RW, planes, CP, (int)nelem, (int)bytes, cost};
