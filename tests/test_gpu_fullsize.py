@@ -1,0 +1,82 @@
+"""GPU parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot run these sizes in
+seconds): adjointness of fwd / dgrad / wgrad of the MFMA convolutions at 108^3, linearity of deep_linear_gen at 108^3,
+whole-network C entry point vs the layer-by-layer path at 140^3, and the dice -> identity -> assemble round trip on a
+900^3 uint16 volume (729 cubes of 140^3, the reference screenshot's geometry)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from neuroclear_amd import ops  # noqa: E402
+from neuroclear_amd.models import networks  # noqa: E402
+from neuroclear_amd.util import seed as S  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize('C,K,k,E', [(64, 64, 3, 108), (128, 64, 3, 108), (64, 64, 5, 108), (256, 128, 3, 54)])
+def test_conv_adjoint_identities(C, K, k, E):
+    """<conv(x, w), r> = <x, dgrad(r, w)> = <w, wgrad(x, r)>: the three kernels compute one bilinear form."""
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand((1, C, E, E, E), generator=g) - 0.5).to(DEV)
+    w = ((torch.rand((K, C, k, k, k), generator=g) - 0.5) * 0.1).to(DEV)
+    y = ops.conv_fwd_raw(x, w, None, 1, k // 2)
+    r = (torch.rand(y.shape, generator=g) - 0.5).to(DEV)
+    a = _dot(y, r)
+    b = _dot(x, ops.conv_dgrad_raw(r, w, x.shape, 1, k // 2))
+    dw, _ = ops.conv_wgrad_raw(x, r, w.shape, 1, k // 2, False)
+    c = _dot(w, dw)
+    scale = float(y.double().norm() * r.double().norm())
+    print(C, K, k, E, a, b, c, scale)
+    assert abs(a - b) < 1e-5 * scale and abs(a - c) < 1e-5 * scale
+
+
+def test_deep_linear_is_linear_at_108():
+    net = networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.deep_linear_spec(), 9, DEV))
+    g = torch.Generator().manual_seed(2)
+    x1 = torch.rand((1, 1, 108, 108, 108), generator=g).to(DEV)
+    x2 = torch.rand((1, 1, 108, 108, 108), generator=g).to(DEV)
+    with torch.no_grad():
+        y1, y2, y12 = net(x1), net(x2), net(0.25 * x1 - 1.5 * x2)
+    err = float((y12 - (0.25 * y1 - 1.5 * y2)).abs().max() / y12.abs().max())
+    assert err < 2e-5, err
+
+
+def test_unet_fused_entry_matches_layerwise_at_140():
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 4, DEV))
+    x = torch.rand((1, 1, 140, 140, 140), generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        fused = net(x)                    # nc_unet_deconv_fwd
+    with torch.enable_grad():
+        layerwise = net(x.clone().requires_grad_(True)).detach()
+    assert float((fused - layerwise).abs().max()) < 1e-5
+    assert 0.0 < float(fused.min()) and float(fused.max()) < 1.0
+
+
+def test_dice_identity_roundtrip_900():
+    from neuroclear_amd.data.diceImage_dataset import DiceImageDataSet
+    from neuroclear_amd.util.assemble_dice import Assemble_Dice
+    vol = S.random_volume(0, 900)
+    opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[0], skip_real=True, data_type='uint16',
+                    histogram_match=False, normalize_intensity=False)
+    ds = DiceImageDataSet(opt, volume=vol)
+    assert ds.size() == (960, 960, 960) and ds.shape() == (9, 9, 9) and len(ds) == 729
+    asm = Assemble_Dice(opt, vol.shape)
+    for i in range(len(ds)):
+        c = ds[i]['A']
+        assert c.shape == (1, 140, 140, 140)
+        asm.addToStack(dict(fake=c.unsqueeze(0)))
+    asm.assemble_all()
+    out = asm.getDict()['fake']
+    assert out.shape == vol.shape and out.dtype == np.uint16
+    d = np.abs(out.astype(np.int32) - vol.astype(np.int32))
+    assert int(d.max()) <= 1  # identity network: the reference's own round trip is within 1 LSB
