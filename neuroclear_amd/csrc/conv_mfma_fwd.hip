@@ -27,8 +27,8 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int kRMAX = 18;  // brick rows staged per wave per chunk (x 3 column segments of 64)
-static constexpr bool kFuseNorm = false;  // normalize-on-load is wired but not enabled in round 1
+static constexpr int kRMAX = 34;  // brick rows per wave per unit (x 3 column segments of 64), LDS-DMA issue slots
+
 static constexpr int kNumWG = 256;        // persistent workgroups = CUs of an MI355X
 
 struct FwdParams {
@@ -119,35 +119,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   if (u0 >= u1) return;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
-  // ---- staging by rows (see header)
-  float st[kRMAX][3];
+  // ---- staging by rows, straight into LDS (LDS-DMA, global_load_lds): a wave copies whole rows, lane = column, the
+  //      (channel, plane, row) decode and both row bases are wave-uniform.  No staging registers, no LDS store pass:
+  //      the loads of unit u+1 are issued before the MFMA loop of unit u and land in the other buffer meanwhile.
+  //      Rows outside the volume are written as zeros by ordinary stores (the target buffer is idle during the
+  //      unit); the 2p pad columns of every LDS row are zeroed once and never written again.
   const bool cm0 = lane < p.W, cm1 = lane + 64 < p.W, cm2 = lane + 128 < p.W;
-  auto stage_load = [&](const TileId& t, int chunk) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage_dma = [&](const TileId& t, int chunk, float* buf) {
     const float* xc = p.x + ((long)t.n * p.C + (long)chunk * CK) * S + lane;
-#pragma unroll
-    for (int i = 0; i < kRMAX; ++i) {
-      const unsigned row = wave + NWV * i;
-      const unsigned cic = fastdiv(row, p.mPR);
-      const unsigned r1 = row - cic * p.PRows;
-      const unsigned pz = fastdiv(r1, p.mRowsY);
-      const unsigned yy = r1 - pz * p.rowsY;
-      const int z = t.z0 + (int)pz - PAD, y = t.y0 + (int)yy - PAD;
-      const bool rok = (int)row < p.nrows && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
-      const float* r = xc + (long)cic * S + (long)z * HW + (long)y * p.W;
-      float v0 = (rok && cm0) ? r[0] : 0.f;
-      float v1 = (rok && cm1) ? r[64] : 0.f;
-      float v2 = (rok && cm2) ? r[128] : 0.f;
-      if (kFuseNorm && p.mean) {  // wave-uniform: fused InstanceNorm + activation of the producer layer
-        const int c = chunk * CK + min((int)cic, CK - 1);
-        const float m = p.mean[(long)t.n * p.C + c], rs = p.rstd[(long)t.n * p.C + c];
-        v0 = (v0 - m) * rs; v1 = (v1 - m) * rs; v2 = (v2 - m) * rs;
-        v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; v2 = v2 > 0.f ? v2 : v2 * p.slope;
-        v0 = rok ? v0 : 0.f; v1 = rok ? v1 : 0.f; v2 = rok ? v2 : 0.f;
-      }
-      st[i][0] = v0; st[i][1] = v1; st[i][2] = v2;
-    }
-  };
-  auto stage_store = [&](float* buf) {
 #pragma unroll
     for (int i = 0; i < kRMAX; ++i) {
       const unsigned row = wave + NWV * i;
@@ -156,10 +137,19 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
         const unsigned r1 = row - cic * p.PRows;
         const unsigned pz = fastdiv(r1, p.mRowsY);
         const unsigned yy = r1 - pz * p.rowsY;
-        float* r = buf + cic * p.CP + pz * p.RW + yy * p.P + PAD + lane;
-        if (cm0) r[0] = st[i][0];
-        if (cm1) r[64] = st[i][1];
-        if (cm2) r[128] = st[i][2];
+        const int z = t.z0 + (int)pz - PAD, y = t.y0 + (int)yy - PAD;
+        const bool rok = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
+        float* lrow = buf + cic * p.CP + pz * p.RW + yy * p.P + PAD;  // wave-uniform
+        if (rok) {
+          const float* r = xc + (long)cic * S + (long)z * HW + (long)y * p.W;
+          if (cm0) __builtin_amdgcn_global_load_lds((gptr_t)r, (lptr_t)lrow, 4, 0, 0);
+          if (cm1) __builtin_amdgcn_global_load_lds((gptr_t)(r + 64), (lptr_t)(lrow + 64), 4, 0, 0);
+          if (cm2) __builtin_amdgcn_global_load_lds((gptr_t)(r + 128), (lptr_t)(lrow + 128), 4, 0, 0);
+        } else {
+          if (cm0) lrow[lane] = 0.f;
+          if (cm1) lrow[lane + 64] = 0.f;
+          if (cm2) lrow[lane + 128] = 0.f;
+        }
       }
     }
   };
@@ -196,8 +186,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   const long first_tile = tile;
   int first_chunk = chunk;  // first chunk of the current tile that THIS workgroup accumulates
   TileId tid_cur = decode_tile(p, tile);
-  stage_load(tid_cur, chunk);
-  stage_store(buf0);
+  stage_dma(tid_cur, chunk, buf0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // The packed weights of one tile are ONE linear stream: k-step s reads rows 2s, 2s+1 (lane half h picks the row),
@@ -224,7 +214,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
     const bool tile_ends = !more || ntile != tile;
     TileId tid_nxt = tid_cur;
     if (more && ntile != tile) tid_nxt = decode_tile(p, ntile);
-    if (more) stage_load(tid_nxt, nchunk);
+    if (more) stage_dma(tid_nxt, nchunk, nxt);
     const float* next_aptr = more ? wbase(tid_nxt.cot, nchunk) : aptr;
 
 #pragma unroll 1
@@ -255,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
         for (int uu = 0; uu < U; ++uu) a_cur[uu] = a_nxt[uu];
       }
     }
-    if (more) stage_store(nxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every LDS-DMA row of the next unit has landed
     __syncthreads();
     parity ^= 1;
 
