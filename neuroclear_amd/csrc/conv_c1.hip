@@ -18,6 +18,9 @@ __global__ __launch_bounds__(256) void k_conv_to1(const float* __restrict__ x, c
   constexpr int TAPS = KS * KS * KS;
   static_assert(PXU <= PITCH, "pitch");
   __shared__ __attribute__((aligned(16))) float lds[PZ * PY * PITCH];
+  // this channel's kernel in the order the loop uses it, one 8-float (32-byte) row per (dz, dy): broadcast
+  // ds_read_b128 instead of KS dependent scalar loads per row (the scalar-load latency was exposed)
+  __shared__ __attribute__((aligned(16))) float wl[KS * KS * 8];
   const int tid = threadIdx.x;
   const int xb = tid & 7, ty = (tid >> 3) & 7, tzp = tid >> 6;
   const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
@@ -43,8 +46,9 @@ __global__ __launch_bounds__(256) void k_conv_to1(const float* __restrict__ x, c
         v = xc[(long)gz * HW + (long)gy * W + gx];
       lds[(pz * PY + yy) * PITCH + xx] = v;
     }
-    __syncthreads();
     const float* wc = w + (long)c * TAPS;
+    for (int e = tid; e < TAPS; e += 256) wl[(e / KS) * 8 + e % KS] = wc[flip ? TAPS - 1 - e : e];
+    __syncthreads();
 #pragma unroll 1
     for (int pz = 0; pz <= KS; ++pz) {
       const float* plane = lds + ((2 * tzp + pz) * PY + ty) * PITCH + xb * XB;
@@ -57,22 +61,22 @@ __global__ __launch_bounds__(256) void k_conv_to1(const float* __restrict__ x, c
           row[4 * v4] = t.x; row[4 * v4 + 1] = t.y; row[4 * v4 + 2] = t.z; row[4 * v4 + 3] = t.w;
         }
         if (pz < KS) {  // output plane z0 + 2 tzp uses tap dz = pz
+          const float4 wa = *reinterpret_cast<const float4*>(wl + (pz * KS + dy) * 8);
+          const float4 wb = *reinterpret_cast<const float4*>(wl + (pz * KS + dy) * 8 + 4);
+          const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-          for (int dx = 0; dx < KS; ++dx) {
-            const int t = (pz * KS + dy) * KS + dx;
-            const float wv = wc[flip ? TAPS - 1 - t : t];
+          for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-            for (int i = 0; i < XB; ++i) acc[0][i] = fmaf(wv, row[i + dx], acc[0][i]);
-          }
+            for (int i = 0; i < XB; ++i) acc[0][i] = fmaf(wv[dx], row[i + dx], acc[0][i]);
         }
         if (pz >= 1) {  // output plane z0 + 2 tzp + 1 uses tap dz = pz - 1
+          const float4 wa = *reinterpret_cast<const float4*>(wl + ((pz - 1) * KS + dy) * 8);
+          const float4 wb = *reinterpret_cast<const float4*>(wl + ((pz - 1) * KS + dy) * 8 + 4);
+          const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-          for (int dx = 0; dx < KS; ++dx) {
-            const int t = ((pz - 1) * KS + dy) * KS + dx;
-            const float wv = wc[flip ? TAPS - 1 - t : t];
+          for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-            for (int i = 0; i < XB; ++i) acc[1][i] = fmaf(wv, row[i + dx], acc[1][i]);
-          }
+            for (int i = 0; i < XB; ++i) acc[1][i] = fmaf(wv[dx], row[i + dx], acc[1][i]);
         }
       }
     }
