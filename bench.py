@@ -147,7 +147,7 @@ def run_train(args, rank, world, dev):
                                      tflops=round(s[2] / s[1] / 1e9, 2)) for t, s in sorted(stats.items())},
                     conv_ms_per_step=round(conv_ms / args.steps, 2))
     losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
-    return dt, crop ** 3 * args.steps * world, roof, dict(workload='apollo_train_step_108cube_bs1', crop=crop,
+    return dt, crop ** 3 * args.steps * world, roof, dict(workload='apollo_train_step_%dcube_bs1' % crop, crop=crop,
                                                            batch_size=1, parallelism='dp%d' % world,
                                                            gan_mode='lsgan', norm='instance', losses=losses)
 
@@ -205,11 +205,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs the MI355X (no CPU fallback)')
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % torch.cuda.device_count())  # (single-GPU dry runs of the N > 1 path)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('NC_DIST_BACKEND', 'nccl')  # 'nccl' IS RCCL on ROCm; gloo only for dry runs
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         if rank == 0:
             print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
@@ -217,7 +221,8 @@ def main():
     run = run_train if args.workload == 'train' else run_infer
     dt, units, roof, cfg = run(args, rank, world, dev)
     out = dict(metric='voxels/sec', value=units / dt, unit='voxels/s', n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+               warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling='weak' if args.workload == 'train' else 'strong',
                vs_baseline=None, dtype='f32', data='synthetic', config=cfg)
     if roof:
         out['roofline'] = roof

@@ -90,7 +90,8 @@ class BaseModel(ABC):
         errors_ret = OrderedDict()
         for name in self.loss_names:
             if isinstance(name, str):
-                errors_ret[name] = float(getattr(self, 'loss_' + name))
+                v = getattr(self, 'loss_' + name)
+                errors_ret[name] = float(v.detach()) if hasattr(v, 'detach') else float(v)
         return errors_ret
 
     def save_networks(self, epoch):
