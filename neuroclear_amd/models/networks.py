@@ -2,7 +2,8 @@
 
 Same factory names, argument meaning, state-dict keys and error behaviour as the reference for the networks that
 BASELINE.json's north_star names -- `unet_deconv` (:478-538), `deep_linear_gen` (:893-917), `basic` / `n_layers`
-PatchGAN (:1009-1067), InstanceNorm (:20-44), `GANLoss('lsgan')` (:252-319), `init_net` (:122-137),
+PatchGAN (:1009-1067) -- plus, as the first widening row, `unet_vanilla` (:540-608) and the `pixel`
+discriminator (:1147-1179), which are built from the same kernels; InstanceNorm (:20-44), `GANLoss('lsgan')` (:252-319), `init_net` (:122-137),
 `get_scheduler` (:50-86).  Every forward/backward runs HIP kernels from libnc_hip.so through neuroclear_amd.ops;
 there is no torch.nn.functional compute and no CPU fallback.  Networks outside the scope table (SURVEY.md 8a:
 resnet, VGG, linear kernels, spectral-norm D, ...) raise NotImplementedError exactly like an unknown name does in
@@ -265,6 +266,42 @@ class Unet_deconv(nn.Module):
         return ops.sigmoid(self.one_by_one_2(self.one_by_one(ex_conv1)))
 
 
+class Unet_vanilla(nn.Module):
+    """networks.py:540-608: the four-level U-Net behind --netG unet_vanilla (double_conv on every level, 512-channel
+    bottom, one 1x1 head + sigmoid).  Layer by layer through neuroclear_amd.ops in both modes (the whole-network C
+    entry point covers unet_deconv only)."""
+
+    def __init__(self, input_nc, output_nc, norm_layer=None, dimension=3):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError('Unet_vanilla: 3-D only (ConvTranspose3d k2 s2 is the upsampling kernel)')
+        c = input_nc * 64
+        dc = functools.partial(double_conv, kernel_size=3, stride=1, padding=1, norm_layer=norm_layer,
+                               dimension=dimension)
+        self.double_conv1, self.double_conv2, self.double_conv3 = dc(input_nc, c), dc(c, c * 2), dc(c * 2, c * 4)
+        self.bottom_layer = dc(c * 4, c * 8)
+        self.t_conv3 = ConvTranspose(c * 8, c * 4, 2, 2, dimension)
+        self.ex_double_conv3 = dc(c * 8, c * 4)
+        self.t_conv2 = ConvTranspose(c * 4, c * 2, 2, 2, dimension)
+        self.ex_double_conv2 = dc(c * 4, c * 2)
+        self.t_conv1 = ConvTranspose(c * 2, c, 2, 2, dimension)
+        self.ex_conv1_1 = dc(c * 2, c)
+        self.one_by_one = Conv(c, output_nc, 1, 1, 0, dimension=dimension)
+
+    def forward(self, inputs):
+        if any(s % 8 for s in inputs.shape[2:]):
+            raise ValueError('Unet_vanilla: every edge must be a multiple of 8, got %s (MaxPool3d floors, torch.cat '
+                             'at networks.py:594,598,602 would fail)' % (tuple(inputs.shape[2:]),))
+        conv1 = self.double_conv1(inputs)
+        conv2 = self.double_conv2(ops.maxpool2(conv1))
+        conv3 = self.double_conv3(ops.maxpool2(conv2))
+        bottom = self.bottom_layer(ops.maxpool2(conv3))
+        ex3 = self.ex_double_conv3(torch.cat([conv3, self.t_conv3(bottom)], 1))
+        ex2 = self.ex_double_conv2(torch.cat([conv2, self.t_conv2(ex3)], 1))
+        ex1 = self.ex_conv1_1(torch.cat([conv1, self.t_conv1(ex2)], 1))
+        return ops.sigmoid(self.one_by_one(ex1))
+
+
 class DeepLinearGenerator(nn.Module):
     """networks.py:893-917: bias-free linear chain, each layer zero-pads its own input."""
 
@@ -306,6 +343,23 @@ class NLayerDiscriminator(nn.Module):
         return self.model(input)
 
 
+class PixelDiscriminator(nn.Module):
+    """networks.py:1147-1179 (1x1 PatchGAN): conv1x1(1->ndf) + LeakyReLU, conv1x1(ndf->2ndf) + norm + LeakyReLU,
+    conv1x1(2ndf->1); Sequential indices 0 / 2 / 5 carry the convs.  With instance norm all convs have a bias."""
+
+    def __init__(self, input_nc, ndf=64, norm_layer=None, dimension=3):
+        super().__init__()
+        use_bias = norm_layer is not None
+        seq = [Conv(input_nc, ndf, 1, 1, 0, dimension=dimension), LeakyReLU(0.2),
+               Conv(ndf, ndf * 2, 1, 1, 0, bias=use_bias, dimension=dimension)]
+        seq += [norm_layer(ndf * 2, 0.2), FusedActivation()] if norm_layer else [Identity(), LeakyReLU(0.2)]
+        seq += [Conv(ndf * 2, 1, 1, 1, 0, bias=use_bias, dimension=dimension)]
+        self.net = nn.Sequential(*seq)
+
+    def forward(self, input):
+        return self.net(input)
+
+
 def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02,
              gpu_ids=[], kernel_size=9, given_psf=None, noise_setting=None, dimension=3):
     """networks.py:140-197 (same signature)."""
@@ -314,7 +368,9 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
         net = Unet_deconv(1, output_nc, norm_layer=norm_layer, dimension=dimension)  # input_nc forced to 1 (:174)
     elif netG == 'deep_linear_gen':
         net = DeepLinearGenerator(input_nc, output_nc)
-    elif netG in ('unet_twoouts', 'unet_vanilla', 'resnet_9blocks', 'resnet_6blocks', 'VGG', 'linearkernel',
+    elif netG == 'unet_vanilla':
+        net = Unet_vanilla(1, output_nc, norm_layer=norm_layer, dimension=dimension)  # input_nc forced to 1 (:176)
+    elif netG in ('unet_twoouts', 'resnet_9blocks', 'resnet_6blocks', 'VGG', 'linearkernel',
                   'linearkernel_double', 'linearkernel_LK31', 'linearkernel_NC', 'fixed_kernel'):
         raise NotImplementedError('Generator [%s] is outside the MI355X hot path (SURVEY.md 8a)' % netG)
     else:
@@ -330,7 +386,9 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
         net = NLayerDiscriminator(input_nc, ndf, 3, norm_layer, use_sigmoid, dimension)
     elif netD == 'n_layers':
         net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer, use_sigmoid, dimension)
-    elif netD in ('basic_SN', 'n_layers_SN', 'pixel', 'kernelGAN'):
+    elif netD == 'pixel':
+        net = PixelDiscriminator(input_nc, ndf, norm_layer, dimension)
+    elif netD in ('basic_SN', 'n_layers_SN', 'kernelGAN'):
         raise NotImplementedError('Discriminator [%s] is outside the MI355X hot path (SURVEY.md 8a)' % netD)
     else:
         raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)

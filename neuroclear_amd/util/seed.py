@@ -79,6 +79,45 @@ def patchgan_spec(dimension=2, input_nc=1, ndf=64, n_layers=3):
     return spec
 
 
+def unet_vanilla_spec(dimension=3):
+    """(key, shape) list of ``Unet_vanilla`` (``models/networks.py:540-574``), input_nc forced to 1 (``:176``):
+    three double_conv levels, a double_conv bottom at 512 channels, three transposed convs, one 1x1 head."""
+    k3, k2, k1 = (3,) * dimension, (2,) * dimension, (1,) * dimension
+    spec = []
+
+    def dconv(name, cout, cin):
+        for i, ci in ((0, cin), (3, cout)):
+            spec.append(('%s.convolution.%d.weight' % (name, i), (cout, ci) + k3))
+            spec.append(('%s.convolution.%d.bias' % (name, i), (cout,)))
+
+    def tconv(name, cin, cout):
+        spec.append((name + '.weight', (cin, cout) + k2))
+        spec.append((name + '.bias', (cout,)))
+
+    dconv('double_conv1', 64, 1)
+    dconv('double_conv2', 128, 64)
+    dconv('double_conv3', 256, 128)
+    dconv('bottom_layer', 512, 256)
+    tconv('t_conv3', 512, 256)
+    dconv('ex_double_conv3', 256, 512)
+    tconv('t_conv2', 256, 128)
+    dconv('ex_double_conv2', 128, 256)
+    tconv('t_conv1', 128, 64)
+    dconv('ex_conv1_1', 64, 128)
+    spec.append(('one_by_one.weight', (1, 64) + k1))
+    spec.append(('one_by_one.bias', (1,)))
+    return spec
+
+
+def pixel_spec(dimension=2, input_nc=1, ndf=64):
+    """(key, shape) list of ``PixelDiscriminator`` (``models/networks.py:1147-1179``) with instance norm (every 1x1
+    conv carries a bias): net.0 (1->ndf), net.2 (ndf->2ndf) + norm + LeakyReLU, net.5 (2ndf->1)."""
+    k = (1,) * dimension
+    return [('net.0.weight', (ndf, input_nc) + k), ('net.0.bias', (ndf,)),
+            ('net.2.weight', (ndf * 2, ndf) + k), ('net.2.bias', (ndf * 2,)),
+            ('net.5.weight', (1, ndf * 2) + k), ('net.5.bias', (1,))]
+
+
 def _fan_in(key, shape):
     # torch's _calculate_fan_in_and_fan_out: fan_in = size(1) * receptive field -- for ConvTranspose weights
     # (Cin, Cout, k..) that is Cout * k^d, which is what kaiming_normal_ in the reference ends up using.

@@ -10,6 +10,8 @@ reference's key names):
                        built from ``double_conv`` :413-432, ``triple_conv`` :452-476, ``last_conv`` :434-450
 * ``deep_linear``   -- ``DeepLinearGenerator.forward``   models/networks.py:913-917 (layers :899-911)
 * ``patchgan``      -- ``NLayerDiscriminator.forward``   models/networks.py:1063-1066 (layers :1030-1061)
+* ``unet_vanilla``  -- ``Unet_vanilla.forward``          models/networks.py:576-608 (widening row)
+* ``pixel``         -- ``PixelDiscriminator.forward``    models/networks.py:1166-1179 (widening row)
 * ``lsgan`` / L1    -- ``GANLoss('lsgan')`` :252-319 ; ``torch.nn.L1Loss`` apollo_model.py:128
 
 Parity pin: ``tests/test_oracle_golden.py`` checks every function here against ``tests/golden/*.npz``, which were
@@ -84,6 +86,26 @@ def patchgan(sd, x, n_layers=3):
     x = _in_act(_conv(x, sd, 'model.%d' % idx, stride=1, padding=1), 0.2)
     idx += 3
     return _conv(x, sd, 'model.%d' % idx, stride=1, padding=1)
+
+
+def unet_vanilla(sd, x):
+    """networks.py:576-608: four-level U-Net, double_conv everywhere, single 1x1 head + sigmoid."""
+    pool = F.max_pool3d if x.dim() == 5 else F.max_pool2d
+    conv1 = _block(x, sd, 'double_conv1', (0, 3))
+    conv2 = _block(pool(conv1, 2), sd, 'double_conv2', (0, 3))
+    conv3 = _block(pool(conv2, 2), sd, 'double_conv3', (0, 3))
+    bottom = _block(pool(conv3, 2), sd, 'bottom_layer', (0, 3))
+    ex3 = _block(torch.cat([conv3, _convT(bottom, sd, 't_conv3')], 1), sd, 'ex_double_conv3', (0, 3))
+    ex2 = _block(torch.cat([conv2, _convT(ex3, sd, 't_conv2')], 1), sd, 'ex_double_conv2', (0, 3))
+    ex1 = _block(torch.cat([conv1, _convT(ex2, sd, 't_conv1')], 1), sd, 'ex_conv1_1', (0, 3))
+    return torch.sigmoid(_conv(ex1, sd, 'one_by_one'))
+
+
+def pixel(sd, x):
+    """networks.py:1166-1179 with instance norm: 1x1 conv + LReLU, 1x1 conv + IN + LReLU, 1x1 conv head."""
+    x = F.leaky_relu(_conv(x, sd, 'net.0'), 0.2)
+    x = _in_act(_conv(x, sd, 'net.2'), 0.2)
+    return _conv(x, sd, 'net.5')
 
 
 def lsgan(pred, target_is_real):
