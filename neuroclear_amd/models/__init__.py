@@ -10,7 +10,8 @@ def find_model_using_name(model_name):
         modellib = importlib.import_module(model_filename)
     except ImportError:
         raise NotImplementedError('model [%s] is not part of the MI355X hot path (available: test, '
-                                  'axial_to_lateral_gan_apollo)' % model_name)
+                                  'axial_to_lateral_gan_apollo, axial_to_lateral_gan_athena, '
+                                  'axial_to_lateral_gan_dryops)' % model_name)
     target = model_name.replace('_', '') + 'model'
     for name, cls in modellib.__dict__.items():
         if name.lower() == target.lower() and isinstance(cls, type) and issubclass(cls, BaseModel):

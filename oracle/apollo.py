@@ -5,6 +5,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 Restates /root/reference/models/axial_to_lateral_gan_apollo_model.py:
   set_input :142-160, forward :162-167, backward_G :255-283, backward_D_* :169-253, optimize_parameters :285-307,
   Volume.get_slice / get_projection :322-351
+/root/reference/models/axial_to_lateral_gan_dryops_model.py (Apollo without G_B / D_B): optimize_parameters :234-258
 and /root/reference/models/axial_to_lateral_gan_athena_model.py:
   __init__ plane wiring :93-148, backward_G :240-260, backward_D_* :190-238, iter_f :286-296, Volume :298-331
 
@@ -117,6 +118,62 @@ class ApolloOracle:
         L['D_B_lateral'] = d_slice('D_B_lateral', 0, 0)
         L['D_B_axial'] = (d_slice('D_B_axial', 1, 1) + d_slice('D_B_axial', 2, 2)) * 0.5
         self.grads_D = [p.grad.clone() for p in self.n.params(APOLLO_D)]
+        self.opt_D.step()
+        return OrderedDict((k, float(v.detach())) for k, v in L.items())
+
+
+DRYOPS_D = ['D_A_axial', 'D_A_lateral']  # optimizer_D chain order, dryops:103-104
+
+
+class DryopsOracle:
+    """One Dryops step (axial_to_lateral_gan_dryops_model.py:234-276): Apollo without the backward path -- G_A and
+    the two D_A discriminators only.  ``netG`` / ``netD`` pick the restated network ('unet_deconv' | 'unet_vanilla',
+    'basic' | 'pixel')."""
+
+    def __init__(self, sds, lr=1e-4, beta1=0.1, lambda_plane=(1, 1, 1), projection_depth=10,
+                 randomize_projection_depth=True, min_projection_depth=2, netG='unet_deconv', netD='basic'):
+        self.n = Nets(sds)
+        s = float(sum(lambda_plane))
+        self.w_target, self.w_slice, self.w_proj = [f / s for f in lambda_plane]  # dryops:83-84
+        self.randomize = randomize_projection_depth
+        self.max_depth, self.min_depth = projection_depth, min_projection_depth
+        self.G = {'unet_deconv': nets.unet_deconv, 'unet_vanilla': nets.unet_vanilla}[netG]
+        self.Dfn = {'basic': nets.patchgan, 'pixel': nets.pixel}[netD]
+        self.opt_G = torch.optim.Adam(self.n.params(['G_A']), lr=lr, betas=(beta1, 0.999))
+        self.opt_D = torch.optim.Adam(self.n.params(DRYOPS_D), lr=lr, betas=(beta1, 0.999))
+        self.losses = OrderedDict()
+
+    def D(self, name, x):
+        return self.Dfn(self.n.sd[name], x)
+
+    def step(self, real):
+        if self.randomize:  # dryops:127-130
+            self.depth = np.random.randint(max(2, self.min_depth), self.max_depth + 1)
+        else:
+            self.depth = self.max_depth
+        L = self.losses
+        fake = self.G(self.n.sd['G_A'], real)
+        self.fake = fake
+        self.n.set_requires_grad(DRYOPS_D, False)
+        self.opt_G.zero_grad()
+        L['G_A_lateral'] = nets.lsgan(self.D('D_A_lateral', _mip(fake, self.depth, 0)), True) * self.w_target
+        L['G_A_axial'] = nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 1)), True) * self.w_slice + \
+            nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 2)), True) * self.w_slice
+        L['G_A'] = L['G_A_lateral'] + L['G_A_axial'] * 0.5
+        L['G_A'].backward()
+        self.opt_G.step()
+        self.n.set_requires_grad(DRYOPS_D, True)
+        self.opt_D.zero_grad()
+        fd = fake.detach()
+
+        def d_proj(name, ax_real, ax_fake):  # backward_D_projection dryops:182-199
+            loss = (nets.lsgan(self.D(name, _slice(real, ax_real)), True) +
+                    nets.lsgan(self.D(name, _mip(fd, self.depth, ax_fake)), False)) * 0.5
+            loss.backward()
+            return loss
+
+        L['D_A_lateral'] = d_proj('D_A_lateral', 0, 0)
+        L['D_A_axial'] = (d_proj('D_A_axial', 0, 1) + d_proj('D_A_axial', 0, 2)) * 0.5
         self.opt_D.step()
         return OrderedDict((k, float(v.detach())) for k, v in L.items())
 

@@ -288,6 +288,91 @@ def gen_athena():
     print('athena', dict(zip(model.loss_names, losses[0])))
 
 
+def gen_nets_wide(networks):
+    """Widening row: unet_vanilla, the pixel discriminator and n_layers PatchGANs other than 3."""
+    import contextlib
+    import io
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    for size, seed in ((16, 21), (24, 22)):
+        with quiet:
+            net = networks.define_G(1, 1, 64, 'unet_vanilla', 'instance', False, 'kaiming', 0.02, [], dimension=3)
+        load_sd(net, S.weights_from_seed(S.unet_vanilla_spec(), seed))
+        x = torch.from_numpy(rand_input(100 + seed, (1, 1, size, size, size))).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, 'unet_vanilla_%d.npz' % size), seed=seed, x_seed=100 + seed,
+                            r_seed=200 + seed, y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm,
+                            g_samp=samp)
+        print('unet_vanilla', size, float(y.mean()))
+    for tag, dim, shape, seed in (('2d_36', 2, (2, 1, 36, 36), 23), ('3d_12', 3, (1, 1, 12, 12, 12), 24)):
+        with quiet:
+            net = networks.define_D(1, 64, 'pixel', 3, 'instance', 'kaiming', 0.02, False, [], dimension=dim)
+        load_sd(net, S.weights_from_seed(S.pixel_spec(dim), seed))
+        x = torch.from_numpy(rand_input(100 + seed, shape)).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, 'pixel_%s.npz' % tag), seed=seed, dim=dim, x_seed=100 + seed,
+                            r_seed=200 + seed, shape=np.array(shape), y=y.detach().numpy(), dx=x.grad.numpy(),
+                            g_l2=l2, g_sum=sm, g_samp=samp)
+        print('pixel', tag, tuple(y.shape))
+    for tag, nl, shape, seed in (('n2_2d_36', 2, (1, 1, 36, 36), 25), ('n4_2d_72', 4, (1, 1, 72, 72), 26)):
+        with quiet:
+            net = networks.define_D(1, 64, 'n_layers', nl, 'instance', 'kaiming', 0.02, False, [], dimension=2)
+        load_sd(net, S.weights_from_seed(S.patchgan_spec(2, n_layers=nl), seed))
+        x = torch.from_numpy(rand_input(100 + seed, shape)).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, 'patchgan_%s.npz' % tag), seed=seed, dim=2, n_layers=nl,
+                            x_seed=100 + seed, r_seed=200 + seed, shape=np.array(shape), y=y.detach().numpy(),
+                            dx=x.grad.numpy(), g_l2=l2, g_sum=sm, g_samp=samp)
+        print('patchgan', tag, tuple(y.shape))
+
+
+DRYOPS_NETS = ['G_A', 'D_A_axial', 'D_A_lateral']
+
+
+def dryops_specs(netG, netD):
+    g = {'unet_deconv': S.unet_deconv_spec, 'unet_vanilla': S.unet_vanilla_spec}[netG]()
+    d = {'basic': S.patchgan_spec, 'pixel': S.pixel_spec}[netD](2)
+    return OrderedDict([('G_A', g), ('D_A_axial', d), ('D_A_lateral', d)])
+
+
+def gen_dryops():
+    import contextlib
+    import io
+    from models.axial_to_lateral_gan_dryops_model import AxialToLateralGANDryopsModel
+    for tag, netG, netD, size, step_seed in (('deconv_basic_36', 'unet_deconv', 'basic', 36, 4321),
+                                             ('vanilla_pixel_32', 'unet_vanilla', 'pixel', 32, 977)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = AxialToLateralGANDryopsModel(_opt_train('axial_to_lateral_gan_dryops', dict(netG=netG, netD=netD)))
+        for i, (name, spec) in enumerate(dryops_specs(netG, netD).items()):
+            load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 80 + i))
+        real = torch.from_numpy(rand_input(987, (1, 1, size, size, size)))
+        before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in DRYOPS_NETS}
+        np.random.seed(step_seed)
+        losses = []
+        for it in range(2):
+            model.set_input({'A': real, 'A_paths': 'x'})
+            model.optimize_parameters()
+            losses.append([model.get_current_losses()[k] for k in model.loss_names])
+            if it == 0:
+                fake0 = model.fake.detach().numpy().copy()
+        upd = {}
+        for n in DRYOPS_NETS:
+            after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
+            upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
+        np.savez_compressed(os.path.join(OUT, 'dryops_step_%s.npz' % tag), size=size, step_seed=step_seed,
+                            real_seed=987, net_seed0=80, netG=netG, netD=netD, loss_names=np.array(model.loss_names),
+                            losses=np.array(losses), fake0=fake0, **{'upd_' + n: v for n, v in upd.items()})
+        print('dryops', tag, dict(zip(model.loss_names, losses[0])))
+
+
 def gen_dice():
     import data as refdata  # noqa: F401  (registers the package the assembler imports)
     from util.assemble_dice import Assemble_Dice
@@ -343,11 +428,15 @@ def gen_dice():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     networks = ref_modules()
-    which = sys.argv[1:] or ['nets', 'apollo', 'athena', 'dice']
+    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice']
     if 'nets' in which:
         gen_nets(networks)
+    if 'nets_wide' in which:
+        gen_nets_wide(networks)
     if 'apollo' in which:
         gen_apollo()
+    if 'dryops' in which:
+        gen_dryops()
     if 'athena' in which:
         gen_athena()
     if 'dice' in which:

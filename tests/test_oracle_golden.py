@@ -155,3 +155,67 @@ def test_athena_step(golden_dir):
     for it in range(2):
         L = model.step(real)
         np.testing.assert_allclose(np.array([L[k] for k in names]), g['losses'][it], rtol=2e-4, err_msg='step %d' % it)
+
+
+# ---- widening row: unet_vanilla, pixel / n_layers discriminators, the Dryops step
+
+@pytest.mark.parametrize('size', [16, 24])
+def test_unet_vanilla(golden_dir, size):
+    g = G(golden_dir, 'unet_vanilla_%d.npz' % size)
+    sd = nets.to_torch(S.weights_from_seed(S.unet_vanilla_spec(), int(g['seed'])), requires_grad=True)
+    x = torch.from_numpy(rnd(g['x_seed'], (1, 1, size, size, size))).requires_grad_(True)
+    y = nets.unet_vanilla(sd, x)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], atol=2e-6)
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape))
+    (y * r).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['dx'], atol=1e-4 * np.abs(g['dx']).max())
+    _check_grads(g, sd)
+
+
+@pytest.mark.parametrize('name,fn', [('pixel_2d_36', 'pixel'), ('pixel_3d_12', 'pixel'),
+                                     ('patchgan_n2_2d_36', 'patchgan'), ('patchgan_n4_2d_72', 'patchgan')])
+def test_discriminators_wide(golden_dir, name, fn):
+    g = G(golden_dir, name + '.npz')
+    dim = int(g['dim'])
+    if fn == 'pixel':
+        spec, f = S.pixel_spec(dim), nets.pixel
+    else:
+        nl = int(g['n_layers'])
+        spec, f = S.patchgan_spec(dim, n_layers=nl), lambda sd, x: nets.patchgan(sd, x, n_layers=nl)
+    sd = nets.to_torch(S.weights_from_seed(spec, int(g['seed'])), requires_grad=True)
+    x = torch.from_numpy(rnd(g['x_seed'], g['shape'])).requires_grad_(True)
+    y = f(sd, x)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], rtol=1e-4, atol=1e-5)
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape))
+    (y * r).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['dx'], atol=2e-4 * np.abs(g['dx']).max())
+    _check_grads(g, sd, tol=1e-3)
+
+
+def dryops_specs(netG, netD):
+    gs = {'unet_deconv': S.unet_deconv_spec, 'unet_vanilla': S.unet_vanilla_spec}[netG]()
+    ds = {'basic': S.patchgan_spec, 'pixel': S.pixel_spec}[netD](2)
+    return [('G_A', gs), ('D_A_axial', ds), ('D_A_lateral', ds)]
+
+
+@pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32'])
+def test_dryops_step(golden_dir, tag):
+    g = G(golden_dir, 'dryops_step_%s.npz' % tag)
+    size, netG, netD = int(g['size']), str(g['netG']), str(g['netD'])
+    sds = {n: S.weights_from_seed(sp, int(g['net_seed0']) + i) for i, (n, sp) in enumerate(dryops_specs(netG, netD))}
+    model = apollo.DryopsOracle(sds, netG=netG, netD=netD)
+    before = {n: [p.detach().clone() for p in model.n.sd[n].values()] for n in sds}
+    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    np.random.seed(int(g['step_seed']))
+    names = [str(s) for s in g['loss_names']]
+    for it in range(2):
+        L = model.step(real)
+        np.testing.assert_allclose(np.array([L[k] for k in names]), g['losses'][it], rtol=2e-4, err_msg='step %d' % it)
+        if it == 0:
+            np.testing.assert_allclose(model.fake.detach().numpy(), g['fake0'], atol=2e-6)
+    # update norms of the weight tensors only: a bias in front of an InstanceNorm has a true gradient of zero, what
+    # autograd leaves there is summation-order noise, and Adam's first steps turn any non-zero noise into +-lr
+    for n in sds:
+        w = [i for i, p in enumerate(before[n]) if p.dim() > 1]
+        upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(model.n.sd[n].values(), before[n])])
+        np.testing.assert_allclose(upd[w], g['upd_' + n][w], rtol=2e-3, err_msg=n)
