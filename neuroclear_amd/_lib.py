@@ -5,7 +5,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libnc_hip.so')
+# NC_HIP_LIB: load another build of the same library (kernel timing experiments, tools/ablate_*.py)
+LIB_PATH = os.environ.get('NC_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libnc_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'nc_hip.h')
 
 _lib = None
