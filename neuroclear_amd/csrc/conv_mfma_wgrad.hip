@@ -32,6 +32,12 @@ struct WgParams {
   int CB, KBK, parts;  // channel blocks (C/CIW, K/64), voxel partitions
 };
 
+// NC_WG_ABLATE (timing experiments only, tools/ablate_fwd.py; results are garbage when set): bit 0 no global loads,
+// bit 1 no LDS staging writes, bit 2 no barriers, bit 3 operands not read from LDS
+#ifndef NC_WG_ABLATE
+#define NC_WG_ABLATE 0
+#endif
+
 template <int KS, int AB>
 __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
   constexpr int PAD = KS / 2;
@@ -136,20 +142,20 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
     have = true;
   };
   next_segment();
-  if (have) issue_loads(n, z, yy, yy - PAD >= ya);
+  if (have && !(NC_WG_ABLATE & 1)) issue_loads(n, z, yy, yy - PAD >= ya);
 
   const int a_off = (cog * 16 * AB + l15) * p.PAr + kq;
   const int b_off = (cib * 16 + l15) * p.PR + kq;
   while (have) {
     const int cyy = yy, cya = ya;
     const bool cdy = cyy - PAD >= cya;  // this step completes tile y = cyy - PAD
-    __syncthreads();                    // the previous tile's MFMAs are done: ring slot and dY buffer are free
-    write_lds(cyy, cdy);
-    __syncthreads();
+    if (!(NC_WG_ABLATE & 4)) __syncthreads();  // the previous tile's MFMAs are done: ring slot and dY buffer are free
+    if (!(NC_WG_ABLATE & 2)) write_lds(cyy, cdy);
+    if (!(NC_WG_ABLATE & 4)) __syncthreads();
     // advance and prefetch the next step's rows while this tile is being multiplied
     ++yy;
     if (yy > yb - 1 + PAD) next_segment();
-    if (have) issue_loads(n, z, yy, yy - PAD >= ya);
+    if (have && !(NC_WG_ABLATE & 1)) issue_loads(n, z, yy, yy - PAD >= ya);
     if (cdy) {
       const int y = cyy - PAD;
       const float* pa = dyT + a_off;
@@ -160,12 +166,12 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
       for (int q4 = 0; q4 < p.QT4; q4 += 4) {
         float a[AB];
 #pragma unroll
-        for (int k = 0; k < AB; ++k) a[k] = pa[q4 + k * 16 * p.PAr];
+        for (int k = 0; k < AB; ++k) a[k] = (NC_WG_ABLATE & 8) ? (float)(q4 + k) : pa[q4 + k * 16 * p.PAr];
 #pragma unroll
         for (int ty = 0; ty < KS; ++ty)
 #pragma unroll
           for (int tx = 0; tx < KS; ++tx) {
-            const float b = xT[soff[ty] + q4 + tx];
+            const float b = (NC_WG_ABLATE & 8) ? (float)(q4 + tx) : xT[soff[ty] + q4 + tx];
 #pragma unroll
             for (int k = 0; k < AB; ++k)
               acc[k][ty * KS + tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b, acc[k][ty * KS + tx], 0, 0, 0);
@@ -176,6 +182,219 @@ __global__ __launch_bounds__(512) void k_wgrad_mfma(WgParams p) {
 
   // ---- partial slab: slab[part][g][co 64][ci CIW][T];  C/D layout of 16x16 MFMA: col (ci) = lane & 15,
   //      row (co) = 4 * (lane >> 4) + r
+  float* sl = p.slab + ((long)part * gridDim.y + g) * (64L * CIW * T);
+#pragma unroll
+  for (int k = 0; k < AB; ++k)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = cog * 16 * AB + k * 16 + 4 * kq + rr;
+        const int ci = cib * 16 + l15;
+        sl[((long)co * CIW + ci) * T + t] = acc[k][t][rr];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (W % 4 == 0): same GEMM view, same weight-stationary tiling and row streaming as k_wgrad_mfma, but
+//   * rows go global -> LDS directly (global_load_lds, 16 B per lane = 1 KiB per instruction, every lane with its own
+//     source address; pad columns, rows outside the volume and piece tails come from a zero page): no staging
+//     registers, no ds_write pass, ~5 DMA instructions per wave per step instead of 48 loads + 40 LDS stores;
+//   * the X ring has KS + 1 slots and dY two buffers, so the rows of step s+1 land while step s is multiplied and
+//     ONE barrier per step is enough;
+//   * a row is processed in NXB column blocks of XW columns (a step = one block of one row) so that ring + dY
+//     buffers fit 160 KB with 64 input channels per workgroup;
+//   * channel pitch = 4 * odd floats: 16-B aligned pieces, and the 16 channels x 2 voxels of a half-wave fall on 16
+//     distinct bank pairs (2-way conflict on ds_read_b32, 4 instead of 2 LDS cycles -- LDS is < 35 % busy);
+//   * the operand reads of k-step q+4 are issued in front of the MFMAs of k-step q (sched_group_barrier).
+struct WdParams {
+  const float* x;
+  const float* dy;
+  float* slab;
+  const float* zeros;  // >= 16 B of zeros in global memory
+  int C, K, N, D, H, W;
+  int PR, PAr;         // X / dY channel pitch in LDS (floats)
+  int SX, SD;          // floats per X ring slot / dY buffer (whole 256-float pieces)
+  int NXB, XW;         // column blocks per row, columns per block (multiple of 4)
+  int CB, KBK, parts;
+  unsigned mPR, mPAr;  // magic multipliers for / PR, / PAr
+};
+
+static constexpr int kMaxPX = 5, kMaxPD = 4;  // DMA pieces per wave per step (X slot / dY buffer)
+
+template <int KS, int AB>
+__global__ __launch_bounds__(512) void k_wgrad_dma(WdParams p) {
+  constexpr int PAD = KS / 2;
+  constexpr int T = KS * KS;
+  constexpr int CIW = 32 * AB;
+  constexpr int NCIB = CIW / 16;
+  constexpr int RING = KS + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cib = wave % NCIB, cog = wave / NCIB;
+  const int l15 = lane & 15, kq = lane >> 4;
+
+  const int g = blockIdx.y;
+  const int kbk = g % p.KBK, cb = (g / p.KBK) % p.CB, dz = g / (p.KBK * p.CB);
+  const int part = blockIdx.x;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int zlo = max(0, PAD - dz), zhi = min(p.D, p.D + PAD - dz);
+  const int Dv = max(0, zhi - zlo);
+  const long nrows = (long)p.N * Dv * p.H;
+  const long r0 = nrows * part / p.parts, r1 = nrows * (part + 1) / p.parts;
+
+  float* xT = lds;
+  float* dyT = lds + RING * p.SX;
+  const int npx = p.SX / 256, npd = p.SD / 256;
+
+  f32x4 acc[AB][T];
+#pragma unroll
+  for (int a = 0; a < AB; ++a)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = (cog * 16 * AB + l15) * p.PAr + 4 * kq;
+  const int b_off = (cib * 16 + l15) * p.PR + 4 * kq;
+
+  for (int xb = 0; xb < p.NXB; ++xb) {
+    const int x0 = xb * p.XW;
+    const int xw = min(p.XW, p.W - x0);  // multiple of 4
+    // per-lane source offsets of this wave's pieces (independent of the row): element offset from the row base of
+    // channel 0, or -1 for "zero page"
+    int gx[kMaxPX], gd[kMaxPD];
+#pragma unroll
+    for (int i = 0; i < kMaxPX; ++i) {
+      const unsigned f = (unsigned)((wave + 8 * i) * 64 + lane) * 4;
+      const unsigned c = __umulhi(f, p.mPR);
+      const int col = (int)(f - c * p.PR);
+      const int x = x0 - 4 + col;
+      gx[i] = ((int)c < CIW && x >= 0 && x < p.W && col < xw + 8) ? (int)(c * S + x) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxPD; ++i) {
+      const unsigned f = (unsigned)((wave + 8 * i) * 64 + lane) * 4;
+      const unsigned c = __umulhi(f, p.mPAr);
+      const int col = (int)(f - c * p.PAr);
+      gd[i] = (c < 64u && col < xw) ? (int)(c * S + x0 + col) : -1;
+    }
+
+    // a "load step" brings X row yy (plane z + dz - PAD) into ring slot cnt % RING and, when it completes a tile,
+    // dY row yy - PAD into dY buffer dcnt & 1
+    auto issue = [&](int n, int z, int yy, bool with_dy, int cnt, int dcnt) {
+      const bool row_ok = yy >= 0 && yy < p.H;
+      const float* xbse = p.x + ((long)n * p.C + cb * CIW) * S + (long)(z + dz - PAD) * HW + (long)yy * p.W;
+      float* xs = xT + (cnt % RING) * p.SX;
+#pragma unroll
+      for (int i = 0; i < kMaxPX; ++i) {
+        const int j = wave + 8 * i;
+        if (j < npx) {
+          const float* src = (row_ok && gx[i] >= 0) ? xbse + gx[i] : p.zeros;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + j * 256), 16, 0, 0);
+        }
+      }
+      if (with_dy) {
+        const float* dbse = p.dy + ((long)n * p.K + kbk * 64) * S + (long)z * HW + (long)(yy - PAD) * p.W;
+        float* ds = dyT + (dcnt & 1) * p.SD;
+#pragma unroll
+        for (int i = 0; i < kMaxPD; ++i) {
+          const int j = wave + 8 * i;
+          if (j < npd) {
+            const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+          }
+        }
+      }
+    };
+
+    // ---- walk the rows [r0, r1): per (n, z) plane segment [ya, yb) the load steps run yy = ya-PAD .. yb-1+PAD
+    long r = r0;
+    int n = 0, z = 0, ya = 0, yb = 0, yy = 0;
+    bool have = false;
+    auto next_segment = [&]() {
+      if (r >= r1) {
+        have = false;
+        return;
+      }
+      const long plane = r / p.H;
+      ya = (int)(r - plane * p.H);
+      const long rem = r1 - r;
+      yb = (int)min((long)p.H, ya + rem);
+      n = (int)(plane / Dv);
+      z = zlo + (int)(plane - (long)n * Dv);
+      yy = ya - PAD;
+      r += yb - ya;
+      have = true;
+    };
+    next_segment();
+    int cnt = 0, dcnt = 0;  // load steps issued so far / dY rows issued so far
+    __syncthreads();        // the previous column block's last MFMAs are done before its LDS is overwritten
+    if (have && !(NC_WG_ABLATE & 1)) issue(n, z, yy, yy - PAD >= ya, cnt, dcnt);
+
+    while (have) {
+      const bool cdy = yy - PAD >= ya;  // the step in flight completes tile y = yy - PAD
+      const int ccnt = cnt, cdc = dcnt;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the step have landed ...
+      if (!(NC_WG_ABLATE & 4)) __syncthreads();           // ... everybody's have, and the previous tile's MFMAs are done
+      // advance and start the next step's rows while this tile is being multiplied
+      ++cnt;
+      if (cdy) ++dcnt;
+      ++yy;
+      if (yy > yb - 1 + PAD) next_segment();
+      if (have && !(NC_WG_ABLATE & 1)) issue(n, z, yy, yy - PAD >= ya, cnt, dcnt);
+      if (cdy) {
+        // 16 output voxels per k-iteration; MFMA m of the iteration reduces over voxels q16 + 4*kq + m, so a lane's
+        // operands for m = 0..3 and every tap tx are consecutive floats: dY [q16 + 4kq, +4) = one aligned
+        // ds_read_b128, X (one ring row) [q16 + 4kq, +12) = three, used at offset m + tx + 4 - PAD.  The next ring
+        // row's reads are issued in front of this row's 4 * KS * AB MFMAs.
+        const float* pa = dyT + (cdc & 1) * p.SD + a_off;
+        const float* pb[KS];
+#pragma unroll
+        for (int ty = 0; ty < KS; ++ty) pb[ty] = xT + ((ccnt - (KS - 1) + ty + 8 * RING) % RING) * p.SX + b_off;
+        f32x4 av[AB], bc[3], bn[3];
+        auto ldb = [&](const float* q, f32x4 (&b)[3]) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            b[i] = (NC_WG_ABLATE & 8) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                                   : *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(q + 4 * i, 16));
+        };
+        ldb(pb[0], bc);
+#pragma unroll 1
+        for (int q16 = 0; q16 < xw; q16 += 16) {
+#pragma unroll
+          for (int k = 0; k < AB; ++k)
+            av[k] = (NC_WG_ABLATE & 8) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                                       : *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(pa + q16 + k * 16 * p.PAr, 16));
+          __builtin_amdgcn_sched_group_barrier(0x100, AB, 0);
+#pragma unroll
+          for (int ty = 0; ty < KS; ++ty) {
+            // next row of this iteration, or row 0 of the next iteration (the read past the last iteration stays
+            // inside the slot: PR >= XW + 24)
+            ldb(ty + 1 < KS ? pb[ty + 1] + q16 : pb[0] + q16 + 16, bn);
+            const float bw[12] = {bc[0][0], bc[0][1], bc[0][2], bc[0][3], bc[1][0], bc[1][1],
+                                  bc[1][2], bc[1][3], bc[2][0], bc[2][1], bc[2][2], bc[2][3]};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+                for (int k = 0; k < AB; ++k)
+                  acc[k][ty * KS + tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][m], bw[m + tx + 4 - PAD],
+                                                                              acc[k][ty * KS + tx], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * KS * AB, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bc[i] = bn[i];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial slab (same layout as k_wgrad_mfma)
   float* sl = p.slab + ((long)part * gridDim.y + g) * (64L * CIW * T);
 #pragma unroll
   for (int k = 0; k < AB; ++k)
@@ -248,6 +467,43 @@ static bool plan_wgrad(const ConvDims& d, WgPlan& pl) {
   return false;
 }
 
+struct WdPlan {
+  int AB, PR, PAr, SX, SD, NXB, XW, lds_bytes, G, parts;
+};
+
+static int pitch8(int n) {  // smallest m >= n with m % 16 == 8
+  int m = (n + 7) & ~7;
+  return (m & 8) ? m : m + 8;
+}
+
+// LDS-DMA variant: W % 4 == 0 (16-byte pieces never straddle the volume edge), per-lane offsets fit 32 bits
+static bool plan_wgrad_dma(const ConvDims& d, WdPlan& pl) {
+  if (!wg_shape_ok(d) || d.W % 4) return false;
+  if ((long)d.D * d.H * d.W * 64 >= (1L << 31)) return false;
+  const int KS = d.kd, RING = KS + 1;
+  const int AB = (KS == 3 && d.C % 64 == 0) ? 2 : 1, CIW = 32 * AB;
+  if (d.C % CIW) return false;
+  for (int NXB = 1; NXB <= 8; ++NXB) {
+    const int XW = ((d.W + NXB - 1) / NXB + 15) & ~15;  // k-iterations take 16 voxels
+    // pitch = 8 (mod 16): the 16 lanes of every ds_read_b128 lane group fall on 16 distinct 4-bank groups; the X row
+    // holds 4 halo columns, XW columns and the 12-float window of the read-ahead past the last iteration
+    const int PR = pitch8(XW + 24), PAr = pitch8(XW);
+    const int SX = (CIW * PR + 255) & ~255, SD = (64 * PAr + 255) & ~255;
+    const long bytes = ((long)RING * SX + 2L * SD) * 4;
+    if (bytes > kLdsMaxW || SX / 256 > 8 * kMaxPX || SD / 256 > 8 * kMaxPD) continue;
+    pl.AB = AB; pl.PR = PR; pl.PAr = PAr; pl.SX = SX; pl.SD = SD; pl.NXB = NXB; pl.XW = XW;
+    pl.lds_bytes = (int)bytes;
+    pl.G = KS * (d.C / CIW) * (d.K / 64);
+    int parts = 256 / pl.G;
+    if (parts < 1) parts = 1;
+    const long rows = (long)d.N * d.D * d.H;
+    if (parts > rows) parts = (int)rows;
+    pl.parts = parts;
+    return true;
+  }
+  return false;
+}
+
 bool mfma_wgrad_supported(const ConvDims& d) {
   WgPlan pl;
   return plan_wgrad(d, pl);
@@ -258,6 +514,11 @@ size_t mfma_ws_bytes(const ConvDims& d) {
   WgPlan pl;
   if (plan_wgrad(d, pl)) {
     const size_t slab = (size_t)pl.parts * pl.G * 64 * (32 * pl.AB) * d.kd * d.kd * sizeof(float);
+    if (slab > need) need = slab;
+  }
+  WdPlan pd;
+  if (plan_wgrad_dma(d, pd)) {
+    const size_t slab = (size_t)pd.parts * pd.G * 64 * (32 * pd.AB) * d.kd * d.kd * sizeof(float) + 256;
     if (slab > need) need = slab;
   }
   return need;
@@ -279,8 +540,57 @@ static int launch_wg(const WgParams& p, dim3 grid, int lds_bytes, hipStream_t s)
   return check_launch("wgrad_mfma");
 }
 
+template <int KS, int AB>
+static int launch_wd(const WdParams& p, dim3 grid, int lds_bytes, hipStream_t s) {
+  auto kern = k_wgrad_dma<KS, AB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsMaxW) != hipSuccess) {
+      set_error("wgrad_dma: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, s, p);
+  return check_launch("wgrad_dma");
+}
+
+static unsigned wmagic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+
+static int conv_wgrad_dma(const float* x, const float* dy, float* dw, const ConvDims& d, const WdPlan& pl, void* ws,
+                          size_t wsb, hipStream_t s) {
+  const int CIW = 32 * pl.AB;
+  const size_t slab = (size_t)pl.parts * pl.G * 64 * CIW * d.kd * d.kd * sizeof(float);
+  if (!ws || wsb < slab + 256) {
+    set_error("wgrad_dma: workspace too small (%zu < %zu)", wsb, slab + 256);
+    return NC_ERR_WS;
+  }
+  if (hipMemsetAsync((char*)ws + slab, 0, 256, s) != hipSuccess) {
+    set_error("wgrad_dma: memset of the zero page failed");
+    return NC_ERR_HIP;
+  }
+  WdParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + slab);
+  p.C = d.C; p.K = d.K; p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.PR = pl.PR; p.PAr = pl.PAr; p.SX = pl.SX; p.SD = pl.SD; p.NXB = pl.NXB; p.XW = pl.XW;
+  p.CB = d.C / CIW; p.KBK = d.K / 64; p.parts = pl.parts;
+  p.mPR = wmagic(pl.PR); p.mPAr = wmagic(pl.PAr);
+  dim3 grid(pl.parts, pl.G);
+  int e;
+  if (d.kd == 3 && pl.AB == 2) e = launch_wd<3, 2>(p, grid, pl.lds_bytes, s);
+  else if (d.kd == 3) e = launch_wd<3, 1>(p, grid, pl.lds_bytes, s);
+  else e = launch_wd<5, 1>(p, grid, pl.lds_bytes, s);
+  if (e) return e;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(1024), dim3(256), 0, s, (const float*)ws, dw, d.C, d.K, d.kd, CIW, pl.parts,
+                     pl.G);
+  return check_launch("wgrad_reduce");
+}
+
 int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s) {
+  WdPlan pd;
+  if (plan_wgrad_dma(d, pd)) return conv_wgrad_dma(x, dy, dw, d, pd, ws, wsb, s);
   WgPlan pl;
   if (!plan_wgrad(d, pl)) {
     set_error("wgrad_mfma: unsupported shape");
