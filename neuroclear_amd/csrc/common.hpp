@@ -72,6 +72,11 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
 int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s);
 
+// ---- 1x1 convolutions on the flat voxel axis (MFMA, HBM-bound), conv_1x1.hip
+bool wgrad_1x1_supported(const ConvDims& d);
+size_t wgrad_1x1_ws_bytes(const ConvDims& d);
+int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
 bool to1_dgrad_supported(const ConvDims& d);
 int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);

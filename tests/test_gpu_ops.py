@@ -44,6 +44,9 @@ CONV_CASES = [
     (1, 64, 1, (10, 10, 10), 1, 1, 0),
     (1, 1, 1, (8, 8, 8), 1, 1, 0),
     (1, 64, 32, (6, 6, 6), 1, 1, 0),
+    (1, 64, 32, (28, 28, 24), 1, 1, 0),      # 1x1 wgrad on the flat-voxel MFMA kernel (18816 voxels, ragged last chunk)
+    (2, 16, 1, (26, 26, 28), 1, 1, 0),       # same, channel padding on both sides, batch 2
+    (1, 1, 1, (32, 32, 32), 1, 1, 0),
     (3, 1, 64, (36, 36), 4, 2, 1),           # PatchGAN 2-D
     (1, 64, 128, (18, 18), 4, 2, 1),
     (1, 256, 512, (4, 4), 4, 1, 1),
