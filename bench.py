@@ -112,6 +112,7 @@ def run_train(args, rank, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     ops.prof = None if args.no_prof else []
+    ops.prof_min_flop = 0.0 if args.prof_all else 1e9
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -196,6 +197,9 @@ def main():
     ap.add_argument('--volume', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP events (A/B runs)')
+    ap.add_argument('--prof-all', action='store_true',
+                    help='bracket every convolution launch with HIP events (default: launches of >= 1 GFLOP only -- the '
+                         'events around the ~700 small PatchGAN launches of a step cost more than those kernels)')
     args = ap.parse_args()
 
     import torch

@@ -34,7 +34,8 @@ int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) 
 }
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
-  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
+  const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
+  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : gemm_wgrad_supported(d) ? 2 : 0;
 }

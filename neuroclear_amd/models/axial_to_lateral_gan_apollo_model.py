@@ -8,6 +8,7 @@ reference; what changes is underneath:
     (G before optimizer_G.step at apollo:295, the Ds before optimizer_D.step at :307).
 """
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -81,8 +82,11 @@ class AxialToLateralGANApolloModel(BaseModel):
         parser.add_argument('--netG_B', type=str, default='deep_linear_gen')
         return parser
 
+    _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
+        self._d_streams = []
         self.loss_names = ['D_A_lateral', 'D_A_axial', 'G_A', 'G_A_lateral', 'G_A_axial', 'cycle',
                            'D_B_lateral', 'D_B_axial', 'G_B', 'G_B_lateral', 'G_B_axial']
         self.gan_mode = opt.gan_mode
@@ -159,6 +163,29 @@ class AxialToLateralGANApolloModel(BaseModel):
         pred = netD(planes[0] if len(planes) == 1 else torch.cat(planes, 0))
         return [pred[i:i + 1] for i in range(len(planes))]
 
+    def _D_many(self, jobs, loss_fn):
+        """Evaluate independent discriminators concurrently: jobs = [(netD, planes)], loss_fn(i, preds) -> tensor (or
+        tuple of tensors) computed on the same stream.  The planes are cut on the calling stream in the reference's
+        np.random order beforehand; each network then runs forward -- and, because autograd replays every op on the
+        stream of its forward, backward -- on its own HIP stream, so the four chains of small 2-D kernels overlap
+        instead of queueing behind each other.  NC_D_STREAMS=0 runs them in sequence on the calling stream."""
+        if not self._d_streams_on or not jobs[0][1][0].is_cuda:
+            return [loss_fn(i, self._D(net, planes)) for i, (net, planes) in enumerate(jobs)]
+        main = torch.cuda.current_stream()
+        while len(self._d_streams) < len(jobs):
+            self._d_streams.append(torch.cuda.Stream(device=self.device))
+        out = []
+        for i, (net, planes) in enumerate(jobs):
+            st = self._d_streams[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for pl in planes:
+                    pl.record_stream(st)
+                out.append(loss_fn(i, self._D(net, planes)))
+        for i in range(len(jobs)):
+            main.wait_stream(self._d_streams[i])
+        return out
+
     def iter_f(self, input, function, slice_axis):
         return function(self._slice(input, slice_axis))
 
@@ -214,21 +241,49 @@ class AxialToLateralGANApolloModel(BaseModel):
         """apollo:255-283"""
         lambda_A = self.opt.lambda_A
         g = self.criterionGAN
-        (p_lat,) = self._D(self.netD_A_lateral, [self._proj(self.fake, self.lateral_axis)])
-        p_ax = self._D(self.netD_A_axial, [self._proj(self.fake, self.axial_1_axis),
-                                           self._proj(self.fake, self.axial_2_axis)])
-        self.loss_G_A_lateral = g(p_lat, True) * self.lambda_plane_target
-        self.loss_G_A_axial = g(p_ax[0], True) * self.lambda_slice + g(p_ax[1], True) * self.lambda_slice
+        # planes first, in the reference's draw order (A_lateral, A_axial x2, B_lateral, B_axial x2)
+        jobs = [(self.netD_A_lateral, [self._proj(self.fake, self.lateral_axis)]),
+                (self.netD_A_axial, [self._proj(self.fake, self.axial_1_axis), self._proj(self.fake, self.axial_2_axis)]),
+                (self.netD_B_lateral, [self._slice(self.rec, self.lateral_axis)]),
+                (self.netD_B_axial, [self._slice(self.rec, self.axial_1_axis), self._slice(self.rec, self.axial_2_axis)])]
+
+        def loss(i, p):
+            if i % 2 == 0:
+                return g(p[0], True) * self.lambda_plane_target
+            return g(p[0], True) * self.lambda_slice + g(p[1], True) * self.lambda_slice
+        (self.loss_G_A_lateral, self.loss_G_A_axial, self.loss_G_B_lateral, self.loss_G_B_axial) = \
+            self._D_many(jobs, loss)
         self.loss_G_A = self.loss_G_A_lateral + self.loss_G_A_axial * 0.5
-        (q_lat,) = self._D(self.netD_B_lateral, [self._slice(self.rec, self.lateral_axis)])
-        q_ax = self._D(self.netD_B_axial, [self._slice(self.rec, self.axial_1_axis),
-                                           self._slice(self.rec, self.axial_2_axis)])
-        self.loss_G_B_lateral = g(q_lat, True) * self.lambda_plane_target
-        self.loss_G_B_axial = g(q_ax[0], True) * self.lambda_slice + g(q_ax[1], True) * self.lambda_slice
         self.loss_G_B = self.loss_G_B_lateral + self.loss_G_B_axial * 0.5
         self.loss_cycle = self.criterionCycle(self.rec, self.real) * lambda_A
         self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle
         self.loss_G.backward()
+
+    def backward_D_all(self):
+        """apollo:297-305: backward_D_A_lateral, backward_D_A_axial, backward_D_B_lateral, backward_D_B_axial.  The four
+        losses touch disjoint parameter sets, so one backward over their sum leaves exactly the gradients of the four
+        separate loss.backward() calls of the reference; planes are cut in the reference's draw order."""
+        fd, rd = self.fake.detach(), self.rec.detach()
+        la, a1, a2 = self.lateral_axis, self.axial_1_axis, self.axial_2_axis
+        jobs = [(self.netD_A_lateral, [self._slice(self.real, la), self._proj(fd, la)]),
+                (self.netD_A_axial, [self._slice(self.real, la), self._proj(fd, a1),
+                                     self._slice(self.real, la), self._proj(fd, a2)]),
+                (self.netD_B_lateral, [self._slice(self.real, la), self._slice(rd, la)]),
+                (self.netD_B_axial, [self._slice(self.real, a1), self._slice(rd, a1),
+                                     self._slice(self.real, a2), self._slice(rd, a2)])]
+
+        def loss(i, p):
+            if i % 2 == 0:
+                return (self._d_loss(p[0], p[1]),)
+            return (self._d_loss(p[0], p[1]), self._d_loss(p[2], p[3]))
+        (l_al,), (l_a1, l_a2), (l_bl,), (l_b1, l_b2) = self._D_many(jobs, loss)
+        self.loss_D_A_lateral = l_al
+        self.loss_D_A_axial_1, self.loss_D_A_axial_2 = l_a1, l_a2
+        self.loss_D_A_axial = (l_a1 + l_a2) * 0.5
+        self.loss_D_B_lateral = l_bl
+        self.loss_D_B_axial_1, self.loss_D_B_axial_2 = l_b1, l_b2
+        self.loss_D_B_axial = (l_b1 + l_b2) * 0.5
+        (l_al + l_a1 + l_a2 + l_bl + l_b1 + l_b2).backward()
 
     def optimize_parameters(self):
         """apollo:285-307"""
@@ -241,9 +296,6 @@ class AxialToLateralGANApolloModel(BaseModel):
         self.optimizer_G.step()
         self.set_requires_grad(Ds, True)
         self.optimizer_D.zero_grad()
-        self.backward_D_A_lateral()
-        self.backward_D_A_axial()
-        self.backward_D_B_lateral()
-        self.backward_D_B_axial()
+        self.backward_D_all()
         self.optimizer_D.all_reduce_mean()
         self.optimizer_D.step()

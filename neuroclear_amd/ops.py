@@ -15,10 +15,11 @@ _ws_cache = {}
 # Optional live profiler (bench.py): when `prof` is a list, every convolution C call is bracketed by HIP events on the
 # stream it is launched on and (tag, algorithmic FLOP, start, end) is appended.
 prof = None
+prof_min_flop = 0.0  # launches below this many algorithmic FLOP are not bracketed (event cost ~ a small kernel's time)
 
 
-def _prof_begin():
-    if prof is None:
+def _prof_begin(flop=None):
+    if prof is None or (flop is not None and flop < prof_min_flop):
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -38,7 +39,7 @@ def _conv_tag(op, C, K, k3, stride, pad, out_vox):
         path = lib().nc_conv_fwd_path(I(K), I(C), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
     else:
         path = mf(I(C), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
-    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm'}.get(path, 'direct'), k3[1])
+    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm', 3: 'flat'}.get(path, 'direct'), k3[1])
     return tag, 2.0 * C * K * k3[0] * k3[1] * k3[2] * out_vox
 
 
@@ -67,8 +68,9 @@ def _ptr(t):
 
 
 def workspace(nbytes, device, tag='ws'):
-    """Grow-only scratch buffer per (device, tag); stream-ordered reuse is safe because every op runs on one stream."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer per (device, tag, current stream): reuse is stream-ordered, and independent networks
+    that run concurrently on different streams (the discriminators of the Apollo step) never share scratch."""
+    key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -127,7 +129,7 @@ def conv_fwd_raw(x, w, b, stride, pad):
         raise _lib.NcError('conv: weight expects %d input channels, got %d' % (w.shape[1], C))
     y = torch.empty(_conv_out_shape(x.shape, w.shape, stride, pad), dtype=torch.float32, device=x.device)
     ws = _conv_ws(dims, K, k3, stride, pad, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (y.numel() // K))
     check(lib().nc_conv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                             I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_fwd')
     if e0 is not None:
@@ -144,7 +146,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     k3 = _kdims(w.shape)
     K = w.shape[0]
     ws = _conv_ws(dims, K, k3, stride, pad, dy.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
     check(lib().nc_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]),
                               I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()), 'nc_conv_dgrad')
     if e0 is not None:
@@ -162,7 +164,7 @@ def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws'):
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
     ws = _conv_ws(dims, K, k3, stride, pad, x.device, ws_tag)
-    e0 = _prof_begin()
+    e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
     check(lib().nc_conv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                               I(k3[1]), I(k3[2]), I(stride), I(pad), _ptr(ws), Z(ws.numel()), _stream()),
           'nc_conv_wgrad')
