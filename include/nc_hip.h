@@ -31,8 +31,9 @@ extern "C" {
 const char* nc_last_error(void);
 int nc_version(void);
 /* Which implementation nc_conv_* would pick for a shape: 0 = direct (VALU), 1 = MFMA brick implicit GEMM (3^3/5^3,
- * stride 1), 2 = MFMA gather implicit GEMM (any kernel / stride), 3 = flat-voxel MFMA kernel of the 1x1 weight gradient
- * (<= 64 channels, planes of >= 16384 voxels; the path query assumes a 256^2 plane for pointwise kernels, 32^3 otherwise). */
+ * stride 1), 2 = MFMA gather implicit GEMM (any kernel / stride), 3 = flat-voxel MFMA kernel of the 1x1 weight
+ * gradient (<= 64 channels, planes of >= 16384 voxels), 4 = tap-axis MFMA kernel of the 1 -> 64 channel weight
+ * gradient (3^3 / 7^3, W % 4 == 0).  The query assumes a 256^2 plane for pointwise kernels, a 32^3 volume otherwise. */
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
 /* Force the direct path everywhere (tests cross-check MFMA vs direct on the GPU). 0 = auto (default), 1 = force. */

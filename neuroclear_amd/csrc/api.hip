@@ -37,7 +37,8 @@ int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
-  return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : gemm_wgrad_supported(d) ? 2 : 0;
+  return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4
+                                                                         : gemm_wgrad_supported(d) ? 2 : 0;
 }
 
 size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
@@ -48,6 +49,8 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   if (g > b) b = g;
   const size_t o = wgrad_1x1_ws_bytes(d);
   if (o > b) b = o;
+  const size_t c1 = c1_wgrad_ws_bytes(d);
+  if (c1 > b) b = c1;
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
@@ -92,6 +95,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   int e;
   if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
+  else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
   if (e) return e;

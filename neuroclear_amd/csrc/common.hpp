@@ -80,6 +80,10 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
 bool to1_dgrad_supported(const ConvDims& d);
 int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+// one channel -> 64 channels weight gradient (MFMA over the tap axis), conv_c1.hip
+bool c1_wgrad_supported(const ConvDims& d);
+size_t c1_wgrad_ws_bytes(const ConvDims& d);
+int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;

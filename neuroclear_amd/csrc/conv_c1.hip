@@ -8,6 +8,8 @@
 
 namespace nc {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int KS>
 __global__ __launch_bounds__(256) void k_conv_to1(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ y, int C, int D,
@@ -110,6 +112,262 @@ int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d
   dim3 grid((unsigned)(ntx * nty * ntz), d.N);
   hipLaunchKernelGGL(k_conv_to1<7>, grid, dim3(256), 0, s, dy, w, (const float*)nullptr, dx, d.K, d.D, d.H, d.W, 1);
   return check_launch("conv_dgrad_to1");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of a Conv3d with ONE input channel and 64 output channels (7^3: G_B.first_layer, networks.py:899;
+// 3^3: double_conv1.convolution.0, :420), stride 1, same padding, W % 4 == 0:
+//     dW[co][t] = sum_{n,v} dY[n][co][v] * X[n][0][v + t - p]          t = (dz, dy, dx)
+// GEMM with M = co (64), N = taps (KS^3, padded to 32 * NBW), K = voxels, v_mfma_f32_16x16x4_f32 (exact fp32).  With
+// a single input channel the "ci" axis of the generic wgrad kernel would be 1/16 full; here the MFMA N axis is the
+// tap axis instead: the B operand of tap t at voxel v is X[v + t], a shifted read of the same few image rows.
+//   * one workgroup owns ALL taps (4 co-blocks x 2 * NBW tap-blocks of 16 x 16 accumulators, NBW per wave x 8 waves),
+//     so dY -- the only large operand -- is read exactly once; the volume's rows (n, z, y) are split over 256
+//     workgroups, partial dW per workgroup + fixed-order reduce (deterministic, no atomics);
+//   * row streaming as in conv_mfma_wgrad.hip: a step = one output row; its dY row [64][W] and the KS new X rows
+//     (row y + p of the KS planes z - p .. z + p) arrive by LDS-DMA (16 B per lane, zero page for padding and
+//     out-of-volume rows) into a double buffer / a ring of KS + 1 row slots while the previous row is multiplied;
+//   * MFMA m of a 16-voxel iteration reduces over voxels q + 4*kq + m: the dY operand of four MFMAs is one aligned
+//     ds_read_b128, the X operand a ds_read_b32 at (tap offset of the lane) + q + 4*kq + m.
+struct C1wParams {
+  const float* x;
+  const float* dy;
+  float* slab;         // [parts][64][NT16]
+  const float* zeros;  // >= 16 B of zeros in global memory
+  int N, D, H, W;
+  int PAr, SD;         // dY LDS pitch per channel, floats per dY buffer (whole 256-float pieces)
+  int PRx;             // X row pitch in LDS (multiple of 4): [4 halo][W][>= pad], slot = 8 rows (KS planes + dummy)
+  int W16;             // W rounded up to 16
+  int parts;
+};
+
+template <int KS>
+__global__ __launch_bounds__(512) void k_wgrad_c1(C1wParams p) {
+  constexpr int PAD = KS / 2;
+  constexpr int TAPS = KS * KS * KS;
+  constexpr int NB = ((TAPS + 31) / 32) * 2;  // tap blocks of 16 (even)
+  constexpr int NBW = NB / 2;                 // tap blocks per wave
+  constexpr int RING = KS + 1;
+  constexpr int PLS = 8;                      // row slots per ring entry (KS planes, padded to 8)
+  constexpr int MAXPD = 5;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int mb = wave & 3, nb0 = wave >> 2;  // this wave: co block mb, tap blocks nb0 + 2 * j
+  const int part = blockIdx.x;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const long nrows = (long)p.N * p.D * p.H;
+  const long r0 = nrows * part / p.parts, r1 = nrows * (part + 1) / p.parts;
+
+  const int SXs = PLS * p.PRx;  // floats per ring entry
+  float* xT = lds;
+  float* dyT = lds + RING * SXs;
+  const int npd = p.SD / 256, npx = SXs / 256;
+
+  f32x4 acc[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane tap decode of this wave's blocks: (dz, dy) row selector and column shift dx + 4 - PAD
+  int tdz[NBW], tdy[NBW], tdx[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    int t = (nb0 + 2 * j) * 16 + l15;
+    if (t >= TAPS) t = 0;  // padded taps: any valid address, result dropped
+    tdz[j] = t / (KS * KS);
+    tdy[j] = (t / KS) % KS;
+    tdx[j] = t % KS + 4 - PAD;
+  }
+  // per-lane DMA sources of this wave's pieces (row independent): dY [64][PAr] and one ring entry [8][PRx]
+  int gd[MAXPD], gxp = -1, gxc = 0;
+#pragma unroll
+  for (int i = 0; i < MAXPD; ++i) {
+    const int f = ((wave + 8 * i) * 64 + lane) * 4;
+    const int c = f / p.PAr, col = f - c * p.PAr;
+    gd[i] = (c < 64 && col < p.W) ? (int)(c * S + col) : -1;
+  }
+  {
+    const int f = (wave * 64 + lane) * 4;  // piece `wave` of the ring entry (npx <= 8)
+    const int pl = f / p.PRx, col = f - pl * p.PRx;
+    const int x = col - 4;
+    if (wave < npx && pl < KS && x >= 0 && x < p.W) {
+      gxp = pl;
+      gxc = x;
+    }
+  }
+
+  auto issue = [&](int n, int z, int yy, bool with_dy, int cnt, int dcnt) {
+    if (wave < npx) {
+      const int zz = z + gxp - PAD;
+      const bool ok = gxp >= 0 && yy >= 0 && yy < p.H && zz >= 0 && zz < p.D;
+      const float* src = ok ? p.x + (long)n * S + (long)zz * HW + (long)yy * p.W + gxc : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xT + (cnt % RING) * SXs + wave * 256), 16, 0, 0);
+    }
+    if (with_dy) {
+      const float* dbse = p.dy + (long)n * 64 * S + (long)z * HW + (long)(yy - PAD) * p.W;
+      float* ds = dyT + (dcnt & 1) * p.SD;
+#pragma unroll
+      for (int i = 0; i < MAXPD; ++i) {
+        const int j = wave + 8 * i;
+        if (j < npd) {
+          const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- walk the rows [r0, r1): per (n, z) plane segment [ya, yb) the load steps run yy = ya-PAD .. yb-1+PAD
+  long r = r0;
+  int n = 0, z = 0, ya = 0, yb = 0, yy = 0;
+  bool have = false;
+  auto next_segment = [&]() {
+    if (r >= r1) {
+      have = false;
+      return;
+    }
+    const long plane = r / p.H;
+    ya = (int)(r - plane * p.H);
+    const long rem = r1 - r;
+    yb = (int)min((long)p.H, ya + rem);
+    n = (int)(plane / p.D);
+    z = (int)(plane - (long)n * p.D);
+    yy = ya - PAD;
+    r += yb - ya;
+    have = true;
+  };
+  next_segment();
+  int cnt = 0, dcnt = 0;
+  if (have) issue(n, z, yy, yy - PAD >= ya, cnt, dcnt);
+
+  const int a_off = (mb * 16 + l15) * p.PAr + 4 * kq;
+  while (have) {
+    const bool cdy = yy - PAD >= ya;
+    const int ccnt = cnt, cdc = dcnt;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++cnt;
+    if (cdy) ++dcnt;
+    ++yy;
+    if (yy > yb - 1 + PAD) next_segment();
+    if (have) issue(n, z, yy, yy - PAD >= ya, cnt, dcnt);
+    if (cdy) {
+      const float* pa = dyT + (cdc & 1) * p.SD + a_off;
+      // ring entry of kernel row dy: the step in flight loaded row y + PAD at entry ccnt
+      const float* pb[NBW];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const int e = (ccnt - (KS - 1) + tdy[j] + 8 * RING) % RING;
+        pb[j] = xT + e * SXs + tdz[j] * p.PRx + tdx[j] + 4 * kq;
+      }
+#pragma unroll 1
+      for (int q16 = 0; q16 < p.W16; q16 += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(pa + q16, 16));
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+          const float* q = pb[j] + q16;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], q[m], acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- partial slab[part][co][tap16]: C/D layout col (tap) = lane & 15, row (co) = 4 * (lane >> 4) + r
+  float* sl = p.slab + (long)part * 64 * (NB * 16);
+#pragma unroll
+  for (int j = 0; j < NBW; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      sl[(long)(mb * 16 + 4 * kq + rr) * (NB * 16) + (nb0 + 2 * j) * 16 + l15] = acc[j][rr];
+}
+
+__global__ void k_wgrad_c1_reduce(const float* __restrict__ slab, float* __restrict__ dw, int parts, int taps, int nt16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * taps) return;
+  const int co = i / taps, t = i - co * taps;
+  float s = 0.f;
+  for (int w = 0; w < parts; ++w) s += slab[((long)w * 64 + co) * nt16 + t];
+  dw[i] = s;
+}
+
+static int c1w_nt16(int KS) { return ((KS * KS * KS + 31) / 32) * 32; }
+
+bool c1_wgrad_supported(const ConvDims& d) {
+  if (d.C != 1 || d.K != 64 || d.kd != d.kh || d.kh != d.kw || (d.kd != 3 && d.kd != 7)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.kd / 2 || d.pw != d.kd / 2) return false;
+  if (d.W % 4 || d.W > 240 || d.W < 16) return false;
+  if ((long)d.D * d.H * d.W * 64 >= (1L << 31)) return false;
+  return true;
+}
+
+static int c1w_parts(const ConvDims& d) {
+  const long rows = (long)d.N * d.D * d.H;
+  return (int)(rows < 256 ? rows : 256);
+}
+
+size_t c1_wgrad_ws_bytes(const ConvDims& d) {
+  if (!c1_wgrad_supported(d)) return 0;
+  return (size_t)c1w_parts(d) * 64 * c1w_nt16(d.kd) * sizeof(float) + 256;
+}
+
+template <int KS>
+static int launch_c1w(const C1wParams& p, int lds_bytes, hipStream_t s) {
+  auto kern = k_wgrad_c1<KS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      set_error("wgrad_c1: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.parts), dim3(512), lds_bytes, s, p);
+  return check_launch("wgrad_c1");
+}
+
+int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  const size_t need = c1_wgrad_ws_bytes(d);
+  if (!need) {
+    set_error("wgrad_c1: unsupported shape");
+    return NC_ERR_SHAPE;
+  }
+  if (!ws || wsb < need) {
+    set_error("wgrad_c1: workspace too small (%zu < %zu)", wsb, need);
+    return NC_ERR_WS;
+  }
+  if (hipMemsetAsync((char*)ws + need - 256, 0, 256, s) != hipSuccess) {
+    set_error("wgrad_c1: memset of the zero page failed");
+    return NC_ERR_HIP;
+  }
+  C1wParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
+  p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.W16 = (d.W + 15) & ~15;
+  int pa = (p.W16 + 7) & ~7;
+  if (!(pa & 8)) pa += 8;  // = 8 (mod 16): conflict-free ds_read_b128
+  p.PAr = pa;
+  p.SD = (64 * p.PAr + 255) & ~255;
+  // X row: 4 halo columns + W16 + (KS - 1 + 3) columns of read-ahead, 8 rows per ring entry = whole 256-float pieces
+  p.PRx = (4 + p.W16 + d.kd + 2 + 31) & ~31;
+  p.parts = c1w_parts(d);
+  const int RING = d.kd + 1;
+  const int lds_bytes = (RING * 8 * p.PRx + 2 * p.SD) * (int)sizeof(float);
+  if (lds_bytes > 160 * 1024 || p.SD / 256 > 40 || 8 * p.PRx / 256 > 8) {
+    set_error("wgrad_c1: row too wide");
+    return NC_ERR_SHAPE;
+  }
+  const int e = d.kd == 7 ? launch_c1w<7>(p, lds_bytes, s) : launch_c1w<3>(p, lds_bytes, s);
+  if (e) return e;
+  const int taps = d.kd * d.kd * d.kd;
+  hipLaunchKernelGGL(k_wgrad_c1_reduce, dim3((64 * taps + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, p.parts,
+                     taps, c1w_nt16(d.kd));
+  return check_launch("wgrad_c1_reduce");
 }
 
 }  // namespace nc

@@ -39,7 +39,7 @@ def _conv_tag(op, C, K, k3, stride, pad, out_vox):
         path = lib().nc_conv_fwd_path(I(K), I(C), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
     else:
         path = mf(I(C), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
-    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm', 3: 'flat'}.get(path, 'direct'), k3[1])
+    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps'}.get(path, 'direct'), k3[1])
     return tag, 2.0 * C * K * k3[0] * k3[1] * k3[2] * out_vox
 
 
