@@ -115,7 +115,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   constexpr int NWV = NT / 64;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS * KS;
-  constexpr int U = KS * (CK / 2);  // k-steps per (dz, dy) row of the kernel
+  // k-steps per (dz, dy) row of the kernel.  CK == 1 (single input channel): the two k values of an MFMA are the
+  // taps dx = 2s, 2s + 1 of the row instead of two channels (dx = KS is a zero weight)
+  constexpr int U = CK == 1 ? (KS + 1) / 2 : KS * (CK / 2);
+  constexpr int WROWS = CK == 1 ? KS * KS * 2 * U : TAPS * CK;  // packed weight rows per channel chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -166,12 +169,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   // ---- this wave's output sub-tile: VB column blocks of 32 flattened positions in plane tzl, 64 output channels
   const int GP = WM / p.Tz;
   const int tzl = wm / GP, blk0 = (wm % GP) * VB;
-  const int b_base = h * p.CP + tzl * p.RW + blk0 * 32 + li;
+  const int b_base = (CK == 1 ? h : h * p.CP) + tzl * p.RW + blk0 * 32 + li;
   // Weights go through a buffer descriptor: 32-bit per-lane offset (constant), SCALAR offset for (tile, chunk, row,
   // k-step) -- the weight stream needs no vector address arithmetic in the MFMA loop.
   const int avoff = (li * 2 + h * p.K) * 4;  // bytes
   const int kstep4 = 2 * p.K * 4;            // bytes of packed weights per k-step
-  const int chunk_stride4 = TAPS * CK * p.K * 4;
+  const int chunk_stride4 = WROWS * p.K * 4;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
   auto wbase = [&](int cot, int chunk) { return (cot * WN + wn) * 64 * 4 + chunk * chunk_stride4; };
   auto wload = [&](int soff) {
@@ -255,12 +258,19 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
         const float* brow_nxt = last_row ? brow : (dy == KS - 1 ? brow + p.RW - (KS - 1) * p.P : brow + p.P);
 #pragma unroll
         for (int st = 0; st < U; ++st) {
-          const int dx = st / (CK / 2), cp = st % (CK / 2);
-          const int dxn = (st + 1) / (CK / 2), cpn = (st + 1) % (CK / 2);
-          const float* src = st + 1 < U ? brow + dxn + 2 * cpn * p.CP : brow_nxt;
+          const float* src;
+          float2 a;
+          if constexpr (CK == 1) {
+            src = st + 1 < U ? brow + 2 * (st + 1) : brow_nxt;
+            a = a_cur[st];
+          } else {
+            const int dx = st / (CK / 2), cp = st % (CK / 2);
+            const int dxn = (st + 1) / (CK / 2), cpn = (st + 1) % (CK / 2);
+            src = st + 1 < U ? brow + dxn + 2 * cpn * p.CP : brow_nxt;
+            a = a_cur[dx * (CK / 2) + cp];
+          }
 #pragma unroll
           for (int v = 0; v < VB; ++v) bn[v] = (NC_ABLATE & 4) ? bc[v] : src[v * 32];
-          const float2 a = a_cur[dx * (CK / 2) + cp];
 #pragma unroll
           for (int v = 0; v < VB; ++v) {
             acc[0][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[v], acc[0][v], 0, 0, 0);
@@ -363,6 +373,25 @@ __global__ void k_pack_w(const float* __restrict__ w, float* __restrict__ wp, in
   }
 }
 
+// Single-input-channel packing: row = (dz * KS + dy) * 2U + dx2, dx2 < 2U = KS + 1 (the odd tap out is a zero weight).
+__global__ void k_pack_w_c1(const float* __restrict__ w, float* __restrict__ wp, int Cout, int KS, long zofs) {
+  const int R2 = KS + 1;  // 2U, KS odd
+  const long total = (long)KS * KS * R2 * Cout;
+  if (blockIdx.x == 0 && threadIdx.x < 64) wp[zofs + threadIdx.x] = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Cout);
+    const int row = (int)(i / Cout);
+    const int dx = row % R2, zy = row / R2;
+    const int blk = col / 64, ii = (col % 64) / 2, s = col & 1;
+    const int co = blk * 64 + s * 32 + ii;
+    wp[i] = dx < KS ? w[((long)co * KS * KS + zy) * KS + dx] : 0.f;
+  }
+}
+
+static size_t packed_floats(int KS, int Cin, int Cout) {
+  return Cin == 1 ? (size_t)Cout * KS * KS * (KS + 1) : (size_t)Cin * Cout * KS * KS * KS;
+}
+
 struct FwdPlan {
   int cfg, CK, Tz, Ty, nty, ntz, P, RW, planes, CP, nelem, lds_bytes;
   double cost;
@@ -400,9 +429,11 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
       const int CP = planes * RW;
       const int ckList[3] = {8, 4, 2};
       for (int k = 0; k < 3; ++k) {
-        const int CK = ckList[k];
-        if (KS == 3 && CK == 2) continue;  // instantiated: KS=3 -> {8,4}; KS=5 -> {4,2}
-        if (KS == 5 && CK == 8) continue;
+        const int CK = Cin == 1 ? 1 : ckList[k];
+        if (Cin == 1 && k) break;
+        if (KS == 3 && CK == 2) continue;  // instantiated: KS=3 -> {8,4,1}; KS=5 -> {4,2}; KS=7 -> {1}
+        if (KS == 5 && (CK == 8 || CK == 1)) continue;
+        if (KS == 7 && CK != 1) continue;
         if (Cin % CK) continue;
         if (g.VB == 4 && CK > (KS == 3 ? 4 : 2)) continue;  // those instantiations spill
         const long nelem = (long)CK * CP;
@@ -416,7 +447,7 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         const long units = tiles * (Cin / CK);
         const double per_wg = (double)((units + kNumWG - 1) / kNumWG);
         // + a fixed per-unit overhead (barrier, staging write, loop set-up) that favours fatter units
-        const double cost = per_wg * (g.VB * CK + 1.5);
+        const double cost = per_wg * (g.VB * (CK == 1 ? 4 : CK) + 1.5);
         if (!found || cost < best.cost) {
           found = true;
           best = FwdPlan{c, CK, Tz, Ty, nty, ntz, P, RW, planes, CP, (int)nelem, (int)bytes, cost};
@@ -461,10 +492,14 @@ static int launch_cfg(int cfg, const FwdParams& p, int lds, hipStream_t s) {
 
 static bool shape_ok(const ConvDims& d, int Cin, int Cout) {
   if (d.kd != d.kh || d.kh != d.kw) return false;
-  if (d.kd != 3 && d.kd != 5) return false;
+  if (Cin == 1) {  // single input channel (fwd only): 3^3 and 7^3
+    if (d.kd != 3 && d.kd != 7) return false;
+  } else if (d.kd != 3 && d.kd != 5) {
+    return false;
+  }
   if (d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (d.pd != d.kd / 2 || d.ph != d.kd / 2 || d.pw != d.kd / 2) return false;
-  if (Cin % 4 != 0 || Cout % 64 != 0) return false;
+  if ((Cin != 1 && Cin % 4 != 0) || Cout % 64 != 0) return false;
   if (d.W > 192) return false;  // rows are staged as up to three 64-column segments
   return true;
 }
@@ -482,7 +517,7 @@ bool mfma_dgrad_supported(const ConvDims& d) {
 size_t mfma_fwd_ws_bytes(const ConvDims& d) {
   size_t need = 0;
   FwdPlan pl;
-  const size_t pack = ((size_t)d.C * d.K * d.kd * d.kh * d.kw * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
+  const size_t pack = (packed_floats(d.kd, d.C, d.K) * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
   if (shape_ok(d, d.C, d.K) && plan_fwd(d.kd, d.C, d.K, d.N, d.D, d.H, d.W, pl))
     need = pack + part_bytes(kCfgs[pl.cfg]);
   if (shape_ok(d, d.K, d.C) && plan_fwd(d.kd, d.K, d.C, d.N, d.D, d.H, d.W, pl)) {
@@ -501,15 +536,17 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
   }
   const Cfg& g = kCfgs[pl.cfg];
   const int taps = d.kd * d.kh * d.kw;
-  const size_t pack = ((size_t)Cin * Cout * taps * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
+  const size_t pfl = packed_floats(d.kd, Cin, Cout);
+  const size_t pack = (pfl * sizeof(float) + kPackSlackBytes + 255) & ~(size_t)255;
   const size_t need = pack + part_bytes(g);
   if (!ws || wsb < need) {
     set_error("conv_mfma: workspace too small (%zu < %zu)", wsb, need);
     return NC_ERR_WS;
   }
   float* wp = (float*)ws;
-  const long zofs = (long)((((size_t)Cin * Cout * taps * sizeof(float) + 255) & ~(size_t)255) / sizeof(float));
-  hipLaunchKernelGGL(k_pack_w, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, taps, pl.CK, mode, zofs);
+  const long zofs = (long)(((pfl * sizeof(float) + 255) & ~(size_t)255) / sizeof(float));
+  if (Cin == 1) hipLaunchKernelGGL(k_pack_w_c1, dim3(256), dim3(256), 0, s, w, wp, Cout, d.kd, zofs);
+  else hipLaunchKernelGGL(k_pack_w, dim3(1024), dim3(256), 0, s, w, wp, Cin, Cout, taps, pl.CK, mode, zofs);
   if (int e = check_launch("pack_w")) return e;
   FwdParams p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.part = (float*)((char*)ws + pack);
@@ -525,7 +562,9 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
   p.zeros = wp + zofs;
   p.nchunks = Cin / pl.CK;
   p.units = (long)d.N * p.ncot * pl.ntz * pl.nty * p.nchunks;
+  if (d.kd == 7) return launch_cfg<7, 1>(pl.cfg, p, pl.lds_bytes, s);
   if (d.kd == 3) {
+    if (pl.CK == 1) return launch_cfg<3, 1>(pl.cfg, p, pl.lds_bytes, s);
     if (pl.CK == 8) return launch_cfg<3, 8>(pl.cfg, p, pl.lds_bytes, s);
     return launch_cfg<3, 4>(pl.cfg, p, pl.lds_bytes, s);
   }
