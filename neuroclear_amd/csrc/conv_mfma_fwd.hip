@@ -26,6 +26,7 @@
 namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 
 static constexpr int kNumWG = 256;        // persistent workgroups = CUs of an MI355X
@@ -44,7 +45,9 @@ struct FwdParams {
   int P, RW, planes, CP;  // row pitch, floats per plane (= (Ty+2p)*P), planes per channel, floats per channel
   int nelem;              // CK * CP
   unsigned mP;            // magic multiplier: n / P == __umulhi(n, mP)
-  int V;                    // floats per lane of one LDS-DMA piece: 4 (W % 4 == 0) or 1
+  int nrows;                // brick rows per unit: CK * planes * (Ty + 2p)   (TAIL kernels: one row tail per thread slot)
+  unsigned mRowsY, mPRows;  // magic multipliers for / rowsY and / (planes * rowsY)
+  int rowsY, PRows;
   int npieces;              // pieces of 64*V floats that cover the brick (nelem rounded up)
   int SB;                   // floats between the two brick buffers (rounded nelem + 4 zero floats)
   unsigned mCP, mRW;        // magic multipliers for / CP and / RW
@@ -109,7 +112,7 @@ __device__ __forceinline__ void store_tile(const FwdParams& p, const f32x16 (&ac
 #define NC_ABLATE 0
 #endif
 
-template <int KS, int CK, int WM, int WN, int VB>
+template <int KS, int CK, int WM, int WN, int VB, bool TAIL>
 __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int NWV = NT / 64;
@@ -143,11 +146,37 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   //      108^3 instead of 34 row segments.
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // W % 4 != 0 (TAIL kernels): the group of 4 floats that holds a row's last W % 4 values would also pull the first
+  // floats of the next image row into the zero padding, so the DMA lane of that group is switched off (EXEC) and the
+  // group is written by an ordinary 16-byte LDS store -- [tail values, zeros] -- from registers that thread
+  // t (+ NT) loads for brick row t (+ NT) alongside the DMA; the store waits for the end of the unit.
+  const int tw = p.W & 3, wfull = p.W - tw;
+  constexpr int TR = TAIL ? 2 : 0;  // row tails per thread (nrows <= 2 * NT)
+  int tl_lofs[TR + 1], tl_gofs[TR + 1], tl_zy[TR + 1];
+  float tl_v[TR + 1][3];
+  if constexpr (TAIL) {
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const unsigned row = tid + NT * i;
+      tl_lofs[i] = -1;
+      tl_gofs[i] = 0;
+      tl_zy[i] = 0;
+      if ((int)row < p.nrows) {
+        const unsigned cic = fastdiv(row, p.mPRows);
+        const unsigned r1 = row - cic * p.PRows;
+        const unsigned pz = fastdiv(r1, p.mRowsY);
+        const unsigned yy = r1 - pz * p.rowsY;
+        tl_lofs[i] = (int)(cic * p.CP + pz * p.RW + yy * p.P) + wfull;
+        tl_gofs[i] = (int)((long)cic * S + ((long)pz - PAD) * HW + ((long)yy - PAD) * p.W) + wfull;
+        tl_zy[i] = (int)((pz << 16) | yy);
+      }
+    }
+  }
   auto stage_dma = [&](const TileId& t, int chunk, float* bd) {
     const float* xt = p.x + ((long)t.n * p.C + (long)chunk * CK) * S + (long)t.z0 * HW + (long)t.y0 * p.W;
 #pragma unroll 1
     for (int j = wave; j < p.npieces; j += NWV) {
-      const unsigned f = (unsigned)(j * 64 + lane) * p.V;
+      const unsigned f = (unsigned)(j * 64 + lane) * 4;
       const unsigned cic = fastdiv(f, p.mCP);
       const unsigned r1 = f - cic * p.CP;
       const unsigned pz = fastdiv(r1, p.mRW);
@@ -155,12 +184,31 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
       const unsigned yy = fastdiv(r2, p.mP);
       const unsigned x = r2 - yy * p.P;
       const int z = t.z0 + (int)pz - PAD, y = t.y0 + (int)yy - PAD;
-      const bool ok = cic < (unsigned)CK && (int)x < p.W && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
+      const bool ok = cic < (unsigned)CK && (int)x < wfull && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
       const long off = (long)cic * S + ((long)pz - PAD) * HW + ((long)yy - PAD) * p.W + x;
       const float* src = (NC_ABLATE & 16) ? p.x + lane * 4 : (ok ? xt + off : p.zeros);
-      float* dst = bd + j * 64 * p.V;  // wave-uniform
-      if (p.V == 4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
+      float* dst = bd + j * 64 * 4;  // wave-uniform
+      if (!TAIL || cic >= (unsigned)CK || (int)x != wfull)
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    }
+    if constexpr (TAIL) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int z = t.z0 + (tl_zy[i] >> 16) - PAD, y = t.y0 + (tl_zy[i] & 0xffff) - PAD;
+        const bool ok = tl_lofs[i] >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H;
+        const float* r = xt + tl_gofs[i];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) tl_v[i][e] = (ok && e < tw) ? r[e] : 0.f;
+      }
+    }
+  };
+  auto write_tails = [&](float* bd) {
+    if constexpr (TAIL) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+        if (tl_lofs[i] >= 0)
+          *reinterpret_cast<f32x4v*>(__builtin_assume_aligned(bd + tl_lofs[i], 16)) =
+              f32x4v{tl_v[i][0], tl_v[i][1], tl_v[i][2], 0.f};
     }
   };
   for (int i = tid; i < 4 + 2 * p.SB; i += NT) lds[i] = 0.f;  // the 4 zero floats in front of each buffer stay zero
@@ -205,6 +253,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   TileId tid_cur = decode_tile(p, tile);
   stage_dma(tid_cur, chunk, buf0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  write_tails(buf0);
   __syncthreads();
 
   // The packed weights of one tile are ONE linear stream: k-step s reads rows 2s, 2s+1 (lane half h picks the row),
@@ -288,6 +337,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
     }
     if (!(NC_ABLATE & 8)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every LDS-DMA row of the next unit has landed
+      if (more) write_tails(nxt);
       __syncthreads();
     }
     parity ^= 1;
@@ -407,8 +457,9 @@ static unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d
 // Cin = reduction channels, Cout = produced channels (for dgrad the roles of C and K are swapped by the caller).
 static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdPlan& best) {
   const int pad = KS / 2;
-  const int V = W % 4 == 0 ? 4 : 1;
+  const int V = 4;
   const int P = (W + pad + V - 1) / V * V;  // row pitch: W data floats + >= pad zeros, a whole number of DMA lanes
+  const bool tail = (W & 3) != 0;
   if ((long)D * H * W * 8 >= (1L << 31)) return false;
   bool found = false;
   for (int c = 0; c < kNumCfgs; ++c) {
@@ -436,6 +487,8 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         if (KS == 7 && CK != 1) continue;
         if (Cin % CK) continue;
         if (g.VB == 4 && CK > (KS == 3 ? 4 : 2)) continue;  // those instantiations spill
+        if (tail && (g.VB == 4 || CK == 1)) continue;         // tail kernels: VB <= 2 only (register room)
+        if (tail && CK * planes * (Ty + 2 * pad) > 2 * 64 * g.WM * g.WN) continue;  // <= 2 row tails per thread
         const long nelem = (long)CK * CP;
         // slack: garbage columns of the last blocks read up to maxpos + (KS-1)*(P+1) past the last plane's start
         const long slack = maxpos + (long)(KS - 1) * (P + 1) + 64;
@@ -461,9 +514,9 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
 
 static size_t part_bytes(const Cfg& g) { return (size_t)2 * kNumWG * 32 * g.VB * (g.WM * g.WN * 64) * sizeof(float); }
 
-template <int KS, int CK, int WM, int WN, int VB>
-static int launch_one(const FwdParams& p, int lds_bytes, hipStream_t s) {
-  auto kern = k_conv_mfma<KS, CK, WM, WN, VB>;
+template <int KS, int CK, int WM, int WN, int VB, bool TAIL>
+static int launch_one_t(const FwdParams& p, int lds_bytes, hipStream_t s) {
+  auto kern = k_conv_mfma<KS, CK, WM, WN, VB, TAIL>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -477,6 +530,19 @@ static int launch_one(const FwdParams& p, int lds_bytes, hipStream_t s) {
   if (int e = check_launch("conv_mfma")) return e;
   hipLaunchKernelGGL((k_conv_fixup<WM, WN, VB>), dim3(kNumWG - 1), dim3(WM * WN * 64), 0, s, p);
   return check_launch("conv_mfma_fixup");
+}
+
+template <int KS, int CK, int WM, int WN, int VB>
+static int launch_one(const FwdParams& p, int lds_bytes, hipStream_t s) {
+  if (p.W & 3) {
+    if constexpr (VB == 4 || CK == 1) {  // not instantiated: the planner keeps W % 4 != 0 off these
+      set_error("conv_mfma: no tail kernel for this configuration");
+      return NC_ERR_SHAPE;
+    } else {
+      return launch_one_t<KS, CK, WM, WN, VB, true>(p, lds_bytes, s);
+    }
+  }
+  return launch_one_t<KS, CK, WM, WN, VB, false>(p, lds_bytes, s);
 }
 
 template <int KS, int CK>
@@ -555,9 +621,10 @@ static int run(const float* x, const float* w, const float* bias, float* y, int 
   p.Tz = pl.Tz; p.Ty = pl.Ty; p.nty = pl.nty; p.ntz = pl.ntz; p.ncot = Cout / (g.WN * 64);
   p.P = pl.P; p.RW = pl.RW; p.planes = pl.planes; p.CP = pl.CP;
   p.nelem = pl.nelem; p.mP = magic(pl.P);
-  p.V = d.W % 4 == 0 ? 4 : 1;
-  p.npieces = (pl.nelem + 64 * p.V - 1) / (64 * p.V);
-  p.SB = p.npieces * 64 * p.V + 4;
+  p.npieces = (pl.nelem + 255) / 256;
+  p.SB = p.npieces * 256 + 4;
+  p.rowsY = pl.Ty + 2 * (d.kd / 2); p.PRows = pl.planes * p.rowsY; p.nrows = pl.CK * p.PRows;
+  p.mRowsY = magic(p.rowsY); p.mPRows = magic(p.PRows);
   p.mCP = magic(pl.CP); p.mRW = magic(pl.RW);
   p.zeros = wp + zofs;
   p.nchunks = Cin / pl.CK;
