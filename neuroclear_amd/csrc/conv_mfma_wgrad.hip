@@ -408,6 +408,209 @@ __global__ __launch_bounds__(512) void k_wgrad_dma(WdParams p) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow volumes (W <= 56: the 54^3 and 27^3 levels of the U-Net): a step of the row-streaming kernels above would be
+// a handful of MFMAs between two barriers.  k_wgrad_rows makes a step R consecutive rows of one plane, FLATTENED:
+// rows sit in LDS at pitch Wg = W + (>= p) zeros, so the R rows are one run of R * Wg voxels, a tap (ty, tx) is a
+// constant offset ty * Wg + tx - p, and 16-voxel k-iterations run across row boundaries (27 -> 4 rows of pitch 28 =
+// 112 voxels, 96 % useful).  Each step loads its own R + 2p input rows (no ring: the halo rows come from L2 again) and
+// R dY rows by LDS-DMA into a double buffer; one barrier per step.  64 co x 32 ci per workgroup, one 16 x 16 x KS^2
+// accumulator set per wave.  W % 4 != 0: the group of 4 floats that holds a row's tail is written from registers by
+// one thread per row (its DMA lane is masked), as in conv_mfma_fwd.hip.
+struct WrParams {
+  const float* x;
+  const float* dy;
+  float* slab;
+  const float* zeros;
+  int C, K, N, D, H, W;
+  int R, Wg;           // rows per step, row pitch in LDS (multiple of 4, >= W + p)
+  int PRc, PAc;        // channel pitch of the X window / dY rows (floats, = 8 mod 16)
+  int SX, SD;          // floats per X / dY buffer (whole 256-float pieces)
+  int CB, KBK, parts;
+  unsigned mPRc, mPAc, mWg;
+};
+
+static constexpr int kMaxRX = 4, kMaxRD = 4;  // DMA pieces per wave per step
+
+template <int KS>
+__global__ __launch_bounds__(512) void k_wgrad_rows(WrParams p) {
+  constexpr int PAD = KS / 2;
+  constexpr int T = KS * KS;
+  constexpr int CIW = 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cib = wave & 1, cog = wave >> 1;  // 2 ci blocks x 4 co blocks of 16
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int g = blockIdx.y;
+  const int kbk = g % p.KBK, cb = (g / p.KBK) % p.CB, dz = g / (p.KBK * p.CB);
+  const int part = blockIdx.x;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int zlo = max(0, PAD - dz), zhi = min(p.D, p.D + PAD - dz);
+  const int Dv = max(0, zhi - zlo);
+  // work units: (n, z, row group of R rows)
+  const int ngr = (p.H + p.R - 1) / p.R;
+  const long nunits = (long)p.N * Dv * ngr;
+  const long u0 = nunits * part / p.parts, u1 = nunits * (part + 1) / p.parts;
+  const int RX = p.R + 2 * PAD;
+  const int tw = p.W & 3, wfull = p.W - tw;
+  const int npx = p.SX / 256, npd = p.SD / 256;
+  float* xB = lds;               // two X windows
+  float* dB = lds + 2 * p.SX;    // two dY buffers
+
+  // per-lane DMA sources (step independent): element offset from (channel 0, first row of the window, x = 0) and the
+  // window row; -1 = zero page, -2 = masked (row tail group)
+  int gx[kMaxRX], gxr[kMaxRX], gd[kMaxRD], gdr[kMaxRD];
+#pragma unroll
+  for (int i = 0; i < kMaxRX; ++i) {
+    const unsigned f = (unsigned)((wave + 8 * i) * 64 + lane) * 4;
+    const unsigned c = __umulhi(f, p.mPRc);
+    const int col = (int)(f - c * p.PRc) - 4;  // 4 zero floats in front of every channel's window
+    const unsigned r = col >= 0 ? __umulhi((unsigned)col, p.mWg) : 0u;
+    const int x = col - (int)r * p.Wg;
+    gxr[i] = (int)r;
+    if ((int)c >= CIW || col < 0 || (int)r >= RX || x >= p.W) gx[i] = -1;
+    else if (x >= wfull) gx[i] = -2;
+    else gx[i] = (int)(c * S + (long)r * p.W + x);
+  }
+#pragma unroll
+  for (int i = 0; i < kMaxRD; ++i) {
+    const unsigned f = (unsigned)((wave + 8 * i) * 64 + lane) * 4;
+    const unsigned c = __umulhi(f, p.mPAc);
+    const int col = (int)(f - c * p.PAc);
+    const unsigned r = __umulhi((unsigned)col, p.mWg);
+    const int x = col - (int)r * p.Wg;
+    gdr[i] = (int)r;
+    if (c >= 64u || (int)r >= p.R || x >= p.W) gd[i] = -1;
+    else if (x >= wfull) gd[i] = -2;
+    else gd[i] = (int)(c * S + (long)r * p.W + x);
+  }
+  // row tails (W % 4 != 0): thread t < CIW * RX -> X row (ci, r); next 64 * R threads -> dY row (co, r)
+  int tl_lofs = -1, tl_gofs = 0, tl_r = 0;
+  bool tl_isx = false;
+  if (tw) {
+    if (tid < CIW * RX) {
+      const int c = tid / RX, r = tid - c * RX;
+      tl_isx = true; tl_r = r;
+      tl_lofs = c * p.PRc + 4 + r * p.Wg + wfull;
+      tl_gofs = (int)(c * S + (long)r * p.W + wfull);
+    } else if (tid - CIW * RX < 64 * p.R) {
+      const int t2 = tid - CIW * RX;
+      const int c = t2 / p.R, r = t2 - c * p.R;
+      tl_r = r;
+      tl_lofs = c * p.PAc + r * p.Wg + wfull;
+      tl_gofs = (int)(c * S + (long)r * p.W + wfull);
+    }
+  }
+  float tl_v[3] = {0.f, 0.f, 0.f};
+
+  auto decode = [&](long u, int& n, int& z, int& y0) {
+    const long pl = u / ngr;
+    y0 = (int)(u - pl * ngr) * p.R;
+    n = (int)(pl / Dv);
+    z = zlo + (int)(pl - (long)n * Dv);
+  };
+  auto issue = [&](long u, int buf) {
+    int n, z, y0;
+    decode(u, n, z, y0);
+    const float* xbse = p.x + ((long)n * p.C + cb * CIW) * S + (long)(z + dz - PAD) * HW + (long)(y0 - PAD) * p.W;
+    const float* dbse = p.dy + ((long)n * p.K + kbk * 64) * S + (long)z * HW + (long)y0 * p.W;
+    float* xs = xB + buf * p.SX;
+    float* ds = dB + buf * p.SD;
+#pragma unroll
+    for (int i = 0; i < kMaxRX; ++i) {
+      const int j = wave + 8 * i;
+      if (j < npx) {
+        const int yy = y0 - PAD + gxr[i];
+        const float* src = (gx[i] >= 0 && yy >= 0 && yy < p.H) ? xbse + gx[i] : p.zeros;
+        if (gx[i] != -2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + j * 256), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxRD; ++i) {
+      const int j = wave + 8 * i;
+      if (j < npd) {
+        const float* src = (gd[i] >= 0 && y0 + gdr[i] < p.H) ? dbse + gd[i] : p.zeros;
+        if (gd[i] != -2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+      }
+    }
+    if (tw && tl_lofs >= 0) {
+      const int yy = tl_isx ? y0 - PAD + tl_r : y0 + tl_r;
+      const bool ok = yy >= 0 && yy < p.H;
+      const float* r = (tl_isx ? xbse : dbse) + tl_gofs;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) tl_v[e] = (ok && e < tw) ? r[e] : 0.f;
+    }
+  };
+  auto write_tail = [&](int buf) {
+    if (tw && tl_lofs >= 0) {
+      float* q = (tl_isx ? xB + buf * p.SX : dB + buf * p.SD) + tl_lofs;
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(q, 16)) = f32x4{tl_v[0], tl_v[1], tl_v[2], 0.f};
+    }
+  };
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (cog * 16 + l15) * p.PAc + 4 * kq;
+  const int b_off = (cib * 16 + l15) * p.PRc + 4 * kq;  // window = 12 floats from column q - 4 + PAD ... see below
+  const int nq = p.R * p.Wg;                            // voxels per step (multiple of 4; iterations round up to 16)
+
+  if (u0 < u1) issue(u0, 0);
+  for (long u = u0; u < u1; ++u) {
+    const int buf = (int)((u - u0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    write_tail(buf);
+    __syncthreads();
+    if (u + 1 < u1) issue(u + 1, buf ^ 1);
+    // element (window row r, x) of channel c sits at c * PRc + 4 + r * Wg + x; output voxel q = r * Wg + x, tap
+    // (ty, tx) reads window row r + ty, column x + tx - PAD: offset (4 - PAD) + ty * Wg + q + tx.  A lane's 12-float
+    // window starts at ty * Wg + q16 + 4 * kq (16-byte aligned) and is indexed by m + tx + 4 - PAD.
+    const float* pa = dB + buf * p.SD + a_off;
+    const float* pb = xB + buf * p.SX + b_off;
+    f32x4 bc[3], bn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc[i] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(pb + 4 * i, 16));
+#pragma unroll 1
+    for (int q16 = 0; q16 < nq; q16 += 16) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(pa + q16, 16));
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int ty = 0; ty < KS; ++ty) {
+        const float* nx = ty + 1 < KS ? pb + (ty + 1) * p.Wg + q16 : pb + q16 + 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bn[i] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(nx + 4 * i, 16));
+        const float bw[12] = {bc[0][0], bc[0][1], bc[0][2], bc[0][3], bc[1][0], bc[1][1],
+                              bc[1][2], bc[1][3], bc[2][0], bc[2][1], bc[2][2], bc[2][3]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int tx = 0; tx < KS; ++tx)
+            acc[ty * KS + tx] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bw[m + tx + 4 - PAD], acc[ty * KS + tx], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * KS, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bc[i] = bn[i];
+      }
+    }
+  }
+
+  // ---- partial slab, layout of k_wgrad_mfma with CIW = 32: slab[part][g][co 64][ci 32][T]
+  float* sl = p.slab + ((long)part * gridDim.y + g) * (64L * CIW * T);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int co = cog * 16 + 4 * kq + rr;
+      const int ci = cib * 16 + l15;
+      sl[((long)co * CIW + ci) * T + t] = acc[t][rr];
+    }
+}
+
 // dw[k][c][dz*T + t] = sum_part slab[part][(dz*CB + c/CIW)*KBK + k/64][k%64][c%CIW][t]
 __global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int C, int K, int KS, int CIW,
                                int parts, int G) {
@@ -504,9 +707,41 @@ static bool plan_wgrad_dma(const ConvDims& d, WdPlan& pl) {
   return false;
 }
 
+struct WrPlan {
+  int R, Wg, PRc, PAc, SX, SD, lds_bytes, G, parts;
+};
+
+// multi-row kernel: 3^3, W <= 56, 32 | C, 64 | K
+static bool plan_wgrad_rows(const ConvDims& d, WrPlan& pl) {
+  if (!wg_shape_ok(d) || d.kd != 3 || d.W > 56 || d.C % 32) return false;
+  if ((long)d.D * d.H * d.W * 64 >= (1L << 31)) return false;
+  const int PAD = 1, KS = 3;
+  const int Wg = (d.W + PAD + 3) & ~3;
+  int R = 112 / Wg;
+  if (R > 4) R = 4;  // one row tail per thread: 32 * (R + 2) + 64 * R <= 512
+  if (R > d.H) R = d.H;
+  if (R < 1) return false;
+  const int nq16 = (R * Wg + 15) & ~15;
+  int need = 4 + (R + 2 * PAD) * Wg;
+  if ((KS - 1) * Wg + nq16 + 24 > need) need = (KS - 1) * Wg + nq16 + 24;
+  const int PRc = pitch8(need), PAc = pitch8(nq16);
+  const int SX = (32 * PRc + 255) & ~255, SD = (64 * PAc + 255) & ~255;
+  const long bytes = (2L * SX + 2L * SD) * 4;
+  if (bytes > kLdsMaxW || SX / 256 > 8 * kMaxRX || SD / 256 > 8 * kMaxRD) return false;
+  pl.R = R; pl.Wg = Wg; pl.PRc = PRc; pl.PAc = PAc; pl.SX = SX; pl.SD = SD; pl.lds_bytes = (int)bytes;
+  pl.G = KS * (d.C / 32) * (d.K / 64);
+  int parts = 256 / pl.G;
+  if (parts < 1) parts = 1;
+  const long units = (long)d.N * d.D * ((d.H + R - 1) / R);
+  if (parts > units) parts = (int)units;
+  pl.parts = parts;
+  return true;
+}
+
 bool mfma_wgrad_supported(const ConvDims& d) {
   WgPlan pl;
-  return plan_wgrad(d, pl);
+  WrPlan pr;
+  return plan_wgrad(d, pl) || plan_wgrad_rows(d, pr);
 }
 
 size_t mfma_ws_bytes(const ConvDims& d) {
@@ -519,6 +754,11 @@ size_t mfma_ws_bytes(const ConvDims& d) {
   WdPlan pd;
   if (plan_wgrad_dma(d, pd)) {
     const size_t slab = (size_t)pd.parts * pd.G * 64 * (32 * pd.AB) * d.kd * d.kd * sizeof(float) + 256;
+    if (slab > need) need = slab;
+  }
+  WrPlan pr;
+  if (plan_wgrad_rows(d, pr)) {
+    const size_t slab = (size_t)pr.parts * pr.G * 64 * 32 * d.kd * d.kd * sizeof(float) + 256;
     if (slab > need) need = slab;
   }
   return need;
@@ -587,8 +827,44 @@ static int conv_wgrad_dma(const float* x, const float* dy, float* dw, const Conv
   return check_launch("wgrad_reduce");
 }
 
+static int conv_wgrad_rows(const float* x, const float* dy, float* dw, const ConvDims& d, const WrPlan& pl, void* ws,
+                           size_t wsb, hipStream_t s) {
+  const size_t slab = (size_t)pl.parts * pl.G * 64 * 32 * d.kd * d.kd * sizeof(float);
+  if (!ws || wsb < slab + 256) {
+    set_error("wgrad_rows: workspace too small (%zu < %zu)", wsb, slab + 256);
+    return NC_ERR_WS;
+  }
+  if (hipMemsetAsync((char*)ws + slab, 0, 256, s) != hipSuccess) {
+    set_error("wgrad_rows: memset of the zero page failed");
+    return NC_ERR_HIP;
+  }
+  WrParams p{};
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + slab);
+  p.C = d.C; p.K = d.K; p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.R = pl.R; p.Wg = pl.Wg; p.PRc = pl.PRc; p.PAc = pl.PAc; p.SX = pl.SX; p.SD = pl.SD;
+  p.CB = d.C / 32; p.KBK = d.K / 64; p.parts = pl.parts;
+  p.mPRc = wmagic(pl.PRc); p.mPAc = wmagic(pl.PAc); p.mWg = wmagic(pl.Wg);
+  auto kern = k_wgrad_rows<3>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsMaxW) != hipSuccess) {
+      set_error("wgrad_rows: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.parts, pl.G), dim3(512), pl.lds_bytes, s, p);
+  if (int e = check_launch("wgrad_rows")) return e;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(1024), dim3(256), 0, s, (const float*)ws, dw, d.C, d.K, d.kd, 32, pl.parts,
+                     pl.G);
+  return check_launch("wgrad_reduce");
+}
+
 int conv_wgrad_mfma(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s) {
+  WrPlan pr;
+  if (plan_wgrad_rows(d, pr)) return conv_wgrad_rows(x, dy, dw, d, pr, ws, wsb, s);
   WdPlan pd;
   if (plan_wgrad_dma(d, pd)) return conv_wgrad_dma(x, dy, dw, d, pd, ws, wsb, s);
   WgPlan pl;
