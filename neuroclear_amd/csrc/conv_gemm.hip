@@ -17,7 +17,12 @@ namespace nc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { G_FWD = 0, G_DGRAD = 1, G_WGRAD = 2 };
+// G_DGRAD_P: data gradient of a STRIDED convolution, one output-parity class per grid.z slice.  An input position
+// (iz, iy, ix) only receives taps t = (i + pad) mod s, + s, + 2s ... in every strided dimension; the plain gather
+// multiplies the other (s^dims - 1) / s^dims of the reduction by zeros.  Positions are enumerated per class
+// (i = s * i' + parity), the reduction per class is r' = (k, sub-tap): 4x less work for the 4 x 4 stride-2 PatchGAN
+// layers (networks.py:1030-1046), 8x in 3-D.
+enum { G_FWD = 0, G_DGRAD = 1, G_WGRAD = 2, G_DGRAD_P = 3 };
 
 struct GemmParams {
   const float* a;   // FWD/DGRAD: weights; WGRAD: dy
@@ -29,6 +34,8 @@ struct GemmParams {
   int taps, khw;    // kd*kh*kw, kh*kw
   long S, So;       // input / output positions per image
   int splits, rper; // WGRAD: reduction range per split (multiple of 16)
+  // G_DGRAD_P: class grid (ceil(D/sd), ceil(H/sh), ceil(W/sw)), sub-taps per dimension (k / s), their product
+  int cd, ch, cw, td, th, tw, ptaps;
 };
 
 static constexpr int kAP = 65;  // pitch of the A image (floats)
@@ -44,15 +51,27 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   // the reduction may be split over grid.z (small outputs with a long reduction: PatchGAN tail layers, wgrad)
-  const int r_begin = p.splits > 1 ? blockIdx.z * p.rper : 0;
+  const int zsplit = MODE == G_DGRAD_P ? blockIdx.z % p.splits : blockIdx.z;
+  const int cls = MODE == G_DGRAD_P ? blockIdx.z / p.splits : 0;
+  const int r_begin = p.splits > 1 ? zsplit * p.rper : 0;
   const int r_end = p.splits > 1 ? min(p.R, r_begin + p.rper) : p.R;
+  // parity of this class and first valid tap per dimension
+  const int px = cls % d.sw, py = (cls / d.sw) % d.sh, pz = cls / (d.sw * d.sh);
+  const int t0x = (px + d.pw) % d.sw, t0y = (py + d.ph) % d.sh, t0z = (pz + d.pd) % d.sd;
   const int HW = d.H * d.W, HoWo = d.Ho * d.Wo;
 
   // ---- per-lane column (n) decode for the gathered B image: n_l = tid & 63
   const int ncol = n0 + (tid & 63);
-  const bool ncol_ok = ncol < p.N;
+  bool ncol_ok = ncol < p.N;
   int nb = 0, c0 = 0, c1 = 0, c2 = 0;  // FWD: (n, od, oh, ow); DGRAD: (n, iz, iy, ix); WGRAD: (c, tz, ty, tx)
-  if (ncol_ok) {
+  if (MODE == G_DGRAD_P && ncol_ok) {
+    const int cs = p.cd * p.ch * p.cw;
+    nb = ncol / cs;
+    const int pos = ncol - nb * cs;
+    const int z1 = pos / (p.ch * p.cw), y1 = (pos - z1 * p.ch * p.cw) / p.cw, x1 = pos - z1 * p.ch * p.cw - y1 * p.cw;
+    c0 = z1 * d.sd + pz; c1 = y1 * d.sh + py; c2 = x1 * d.sw + px;
+    ncol_ok = c0 < d.D && c1 < d.H && c2 < d.W;
+  } else if (ncol_ok) {
     if (MODE == G_FWD) {
       nb = ncol / (int)p.So;
       const int pos = ncol - nb * (int)p.So;
@@ -83,6 +102,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
         } else if (MODE == G_DGRAD) {
           const int k = r / p.taps, tap = r - k * p.taps;
           v = p.a[((long)k * d.C + m) * p.taps + tap];
+        } else if (MODE == G_DGRAD_P) {
+          const int k = r / p.ptaps, sub = r - k * p.ptaps;
+          const int jz = sub / (p.th * p.tw), jy = (sub - jz * p.th * p.tw) / p.tw, jx = sub - jz * p.th * p.tw - jy * p.tw;
+          const int tap = ((t0z + d.sd * jz) * d.kh + t0y + d.sh * jy) * d.kw + t0x + d.sw * jx;
+          v = p.a[((long)k * d.C + m) * p.taps + tap];
         } else {
           const int b = d.N > 1 ? r / (int)p.So : 0;
           const int pos = r - b * (int)p.So;
@@ -110,6 +134,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
           if (uz >= 0 && uy >= 0 && ux >= 0) {
             const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
             if (od * d.sd == uz && oh * d.sh == uy && ow * d.sw == ux && od < d.Do && oh < d.Ho && ow < d.Wo)
+              v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
+          }
+        } else if (MODE == G_DGRAD_P) {
+          const int k = r / p.ptaps, sub = r - k * p.ptaps;
+          const int jz = sub / (p.th * p.tw), jy = (sub - jz * p.th * p.tw) / p.tw, jx = sub - jz * p.th * p.tw - jy * p.tw;
+          const int uz = c0 + d.pd - t0z - d.sd * jz, uy = c1 + d.ph - t0y - d.sh * jy, ux = c2 + d.pw - t0x - d.sw * jx;
+          if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the stride by construction
+            const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
+            if (od < d.Do && oh < d.Ho && ow < d.Wo)
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
         } else {
@@ -166,6 +199,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     } else if (MODE == G_DGRAD) {
       const int b = n / (int)p.S;
       base = (long)blockIdx.z * d.N * d.C * p.S + (long)b * d.C * p.S + (n - (long)b * p.S);
+      mstride = p.S;
+    } else if (MODE == G_DGRAD_P) {
+      const int cs = p.cd * p.ch * p.cw;
+      const int b = n / cs;
+      const int pos = n - b * cs;
+      const int z1 = pos / (p.ch * p.cw), y1 = (pos - z1 * p.ch * p.cw) / p.cw, x1 = pos - z1 * p.ch * p.cw - y1 * p.cw;
+      const int iz = z1 * d.sd + pz, iy = y1 * d.sh + py, ix = x1 * d.sw + px;
+      if (iz >= d.D || iy >= d.H || ix >= d.W) return;
+      base = (long)zsplit * d.N * d.C * p.S + (long)b * d.C * p.S + (long)iz * HW + iy * d.W + ix;
       mstride = p.S;
     } else {
       base = (long)blockIdx.z * p.M * p.N + n;
@@ -235,7 +277,17 @@ static int pick_splits(long M, long N, long R) {
   return (int)(s < 1 ? 1 : s);
 }
 static int fwd_splits(const ConvDims& d) { return pick_splits(d.K, Po(d), Rf(d)); }
-static int dgrad_splits(const ConvDims& d) { return pick_splits(d.C, Pi(d), Rd(d)); }
+static bool dgrad_parity_ok(const ConvDims& d) {
+  return (d.sd > 1 || d.sh > 1 || d.sw > 1) && d.kd % d.sd == 0 && d.kh % d.sh == 0 && d.kw % d.sw == 0;
+}
+static int dgrad_splits(const ConvDims& d) {
+  if (dgrad_parity_ok(d)) {
+    const long ncls = (long)d.sd * d.sh * d.sw;
+    const long npar = (long)d.N * cdiv(d.D, d.sd) * cdiv(d.H, d.sh) * cdiv(d.W, d.sw);
+    return pick_splits(d.C, npar * ncls, Rd(d) / ncls);
+  }
+  return pick_splits(d.C, Pi(d), Rd(d));
+}
 static int wgrad_splits(const ConvDims& d) { return pick_splits(d.K, Rf(d), Po(d)); }
 
 size_t gemm_ws_bytes(const ConvDims& d) {
@@ -292,6 +344,19 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
   GemmParams p{};
   gemm_common(p, d);
   p.a = w; p.b = dy; p.bias = nullptr;
+  if (dgrad_parity_ok(d)) {
+    p.cd = (int)cdiv(d.D, d.sd); p.ch = (int)cdiv(d.H, d.sh); p.cw = (int)cdiv(d.W, d.sw);
+    p.td = d.kd / d.sd; p.th = d.kh / d.sh; p.tw = d.kw / d.sw;
+    p.ptaps = p.td * p.th * p.tw;
+    const int ncls = d.sd * d.sh * d.sw;
+    p.M = d.C; p.N = d.N * p.cd * p.ch * p.cw; p.R = d.K * p.ptaps;
+    const long n = (long)d.C * Pi(d);
+    if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), (unsigned)(p.splits * ncls));
+    hipLaunchKernelGGL(k_conv_gemm<G_DGRAD_P>, grid, dim3(256), 0, s, p);
+    if (int e = check_launch("conv_dgrad_gemm_parity")) return e;
+    return split_reduce(p, dx, n, nullptr, 1, 1, s);
+  }
   p.M = d.C; p.N = (int)Pi(d); p.R = (int)Rd(d);
   const long n = (long)d.C * Pi(d);
   if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
