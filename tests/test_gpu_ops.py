@@ -39,6 +39,10 @@ CONV_CASES = [
     (1, 256, 128, (8, 12, 12), 3, 1, 1),     # MFMA
     (1, 128, 64, (6, 20, 36), 3, 1, 1),      # MFMA (ex_conv1_1 shape class)
     (1, 64, 64, (10, 12, 16), 5, 1, 2),      # MFMA 5^3
+    (1, 64, 64, (6, 7, 60), 5, 1, 2),        # 5^3, W > 56, W % 4 == 0: k_wgrad_dma<5,1>
+    (1, 64, 64, (5, 6, 72), 3, 1, 1),        # 3^3, W > 56, W % 4 == 0: k_wgrad_dma<3,2>, two column blocks
+    (1, 32, 64, (5, 6, 70), 3, 1, 1),        # 3^3, W > 56, W % 4 != 0: register-staged k_wgrad_mfma, TAIL fwd kernel
+    (2, 32, 64, (6, 5, 54), 3, 1, 1),        # W = 54: k_wgrad_rows with 2 rows per step, row tails
     (1, 1, 64, (12, 12, 12), 7, 1, 3),
     (1, 1, 64, (10, 9, 20), 7, 1, 3),        # tap-axis MFMA wgrad (W % 4 == 0), ragged D/H
     (2, 1, 64, (7, 11, 36), 3, 1, 1),        # same, 3^3, batch 2
