@@ -43,8 +43,9 @@ class FlatAdam(torch.optim.Optimizer):
             off += k
         self.state_step = 0
 
-    def zero_grad(self, set_to_none=False):
-        self.grad.zero_()
+    def zero_grad(self, set_to_none=False, fill=True):
+        if fill:
+            self.grad.zero_()
         off = 0
         for p in self.params:  # re-attach the views if autograd replaced / dropped .grad
             k = p.numel()
@@ -87,6 +88,7 @@ class AxialToLateralGANApolloModel(BaseModel):
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
         self._d_streams = []
+        self._fwd_done = None
         self.loss_names = ['D_A_lateral', 'D_A_axial', 'G_A', 'G_A_lateral', 'G_A_axial', 'cycle',
                            'D_B_lateral', 'D_B_axial', 'G_B', 'G_B_lateral', 'G_B_axial']
         self.gan_mode = opt.gan_mode
@@ -163,25 +165,36 @@ class AxialToLateralGANApolloModel(BaseModel):
         pred = netD(planes[0] if len(planes) == 1 else torch.cat(planes, 0))
         return [pred[i:i + 1] for i in range(len(planes))]
 
-    def _D_many(self, jobs, loss_fn):
-        """Evaluate independent discriminators concurrently: jobs = [(netD, planes)], loss_fn(i, preds) -> tensor (or
-        tuple of tensors) computed on the same stream.  The planes are cut on the calling stream in the reference's
-        np.random order beforehand; each network then runs forward -- and, because autograd replays every op on the
-        stream of its forward, backward -- on its own HIP stream, so the four chains of small 2-D kernels overlap
-        instead of queueing behind each other.  NC_D_STREAMS=0 runs them in sequence on the calling stream."""
-        if not self._d_streams_on or not jobs[0][1][0].is_cuda:
-            return [loss_fn(i, self._D(net, planes)) for i, (net, planes) in enumerate(jobs)]
+    def _D_many(self, jobs, loss_fn, after=None, backward=False):
+        """Evaluate independent discriminators concurrently: jobs = [(netD, planes_fn)], loss_fn(i, preds) -> tensor or
+        tuple of tensors.  Job i cuts its planes (np.random draws: jobs are built one after the other, so the draw
+        order is the reference's), runs its network and its loss on HIP stream i -- and, because autograd replays
+        every op on the stream of its forward, the backward too -- so the four chains of small 2-D kernels overlap
+        instead of queueing behind each other.
+        after: an event instead of "everything queued on the calling stream so far" as the start condition;
+        backward=True: each job also calls backward() on the sum of its losses, on its own stream (the jobs touch
+        disjoint parameter sets, so this equals the reference's separate loss.backward() calls).  The calling stream
+        waits for all job streams before this returns.  NC_D_STREAMS=0: in sequence on the calling stream."""
+        def run(i, net, planes_fn):
+            res = loss_fn(i, self._D(net, planes_fn()))
+            if backward:
+                tot = res if torch.is_tensor(res) else sum(res[1:], res[0])
+                tot.backward()
+            return res
+        if not self._d_streams_on or not self.real.is_cuda:
+            return [run(i, net, fn) for i, (net, fn) in enumerate(jobs)]
         main = torch.cuda.current_stream()
         while len(self._d_streams) < len(jobs):
             self._d_streams.append(torch.cuda.Stream(device=self.device))
         out = []
-        for i, (net, planes) in enumerate(jobs):
+        for i, (net, fn) in enumerate(jobs):
             st = self._d_streams[i]
-            st.wait_stream(main)
+            if after is not None:
+                st.wait_event(after)
+            else:
+                st.wait_stream(main)
             with torch.cuda.stream(st):
-                for pl in planes:
-                    pl.record_stream(st)
-                out.append(loss_fn(i, self._D(net, planes)))
+                out.append(run(i, net, fn))
         for i in range(len(jobs)):
             main.wait_stream(self._d_streams[i])
         return out
@@ -241,11 +254,13 @@ class AxialToLateralGANApolloModel(BaseModel):
         """apollo:255-283"""
         lambda_A = self.opt.lambda_A
         g = self.criterionGAN
-        # planes first, in the reference's draw order (A_lateral, A_axial x2, B_lateral, B_axial x2)
-        jobs = [(self.netD_A_lateral, [self._proj(self.fake, self.lateral_axis)]),
-                (self.netD_A_axial, [self._proj(self.fake, self.axial_1_axis), self._proj(self.fake, self.axial_2_axis)]),
-                (self.netD_B_lateral, [self._slice(self.rec, self.lateral_axis)]),
-                (self.netD_B_axial, [self._slice(self.rec, self.axial_1_axis), self._slice(self.rec, self.axial_2_axis)])]
+        f, r = self.fake, self.rec
+        la, a1, a2 = self.lateral_axis, self.axial_1_axis, self.axial_2_axis
+        # draw order of the reference: A_lateral, A_axial x2, B_lateral, B_axial x2
+        jobs = [(self.netD_A_lateral, lambda: [self._proj(f, la)]),
+                (self.netD_A_axial, lambda: [self._proj(f, a1), self._proj(f, a2)]),
+                (self.netD_B_lateral, lambda: [self._slice(r, la)]),
+                (self.netD_B_axial, lambda: [self._slice(r, a1), self._slice(r, a2)])]
 
         def loss(i, p):
             if i % 2 == 0:
@@ -260,42 +275,50 @@ class AxialToLateralGANApolloModel(BaseModel):
         self.loss_G.backward()
 
     def backward_D_all(self):
-        """apollo:297-305: backward_D_A_lateral, backward_D_A_axial, backward_D_B_lateral, backward_D_B_axial.  The four
-        losses touch disjoint parameter sets, so one backward over their sum leaves exactly the gradients of the four
-        separate loss.backward() calls of the reference; planes are cut in the reference's draw order."""
+        """apollo:297-305: backward_D_A_lateral, backward_D_A_axial, backward_D_B_lateral, backward_D_B_axial, planes
+        cut in the reference's draw order.  The discriminator step only needs fake / rec (detached) and the
+        discriminators' own parameters, none of which the generators' backward pass or optimizer_G.step touch: the
+        four jobs start as soon as forward() is done on the GPU (self._fwd_done) and run -- forward, losses and
+        backward -- on the discriminator streams underneath the generators' backward pass."""
         fd, rd = self.fake.detach(), self.rec.detach()
+        real = self.real
         la, a1, a2 = self.lateral_axis, self.axial_1_axis, self.axial_2_axis
-        jobs = [(self.netD_A_lateral, [self._slice(self.real, la), self._proj(fd, la)]),
-                (self.netD_A_axial, [self._slice(self.real, la), self._proj(fd, a1),
-                                     self._slice(self.real, la), self._proj(fd, a2)]),
-                (self.netD_B_lateral, [self._slice(self.real, la), self._slice(rd, la)]),
-                (self.netD_B_axial, [self._slice(self.real, a1), self._slice(rd, a1),
-                                     self._slice(self.real, a2), self._slice(rd, a2)])]
+        sl, pj = self._slice, self._proj
+        jobs = [(self.netD_A_lateral, lambda: [sl(real, la), pj(fd, la)]),
+                (self.netD_A_axial, lambda: [sl(real, la), pj(fd, a1), sl(real, la), pj(fd, a2)]),
+                (self.netD_B_lateral, lambda: [sl(real, la), sl(rd, la)]),
+                (self.netD_B_axial, lambda: [sl(real, a1), sl(rd, a1), sl(real, a2), sl(rd, a2)])]
 
         def loss(i, p):
             if i % 2 == 0:
                 return (self._d_loss(p[0], p[1]),)
             return (self._d_loss(p[0], p[1]), self._d_loss(p[2], p[3]))
-        (l_al,), (l_a1, l_a2), (l_bl,), (l_b1, l_b2) = self._D_many(jobs, loss)
+        (l_al,), (l_a1, l_a2), (l_bl,), (l_b1, l_b2) = self._D_many(jobs, loss, after=self._fwd_done, backward=True)
         self.loss_D_A_lateral = l_al
         self.loss_D_A_axial_1, self.loss_D_A_axial_2 = l_a1, l_a2
         self.loss_D_A_axial = (l_a1 + l_a2) * 0.5
         self.loss_D_B_lateral = l_bl
         self.loss_D_B_axial_1, self.loss_D_B_axial_2 = l_b1, l_b2
         self.loss_D_B_axial = (l_b1 + l_b2) * 0.5
-        (l_al + l_a1 + l_a2 + l_bl + l_b1 + l_b2).backward()
 
     def optimize_parameters(self):
         """apollo:285-307"""
         Ds = [self.netD_A_lateral, self.netD_A_axial, self.netD_B_lateral, self.netD_B_axial]
         self.forward()
+        self._fwd_done = None
+        if self.real.is_cuda and self._d_streams_on:
+            self._fwd_done = torch.cuda.Event()
+            self._fwd_done.record()
         self.set_requires_grad(Ds, False)
         self.optimizer_G.zero_grad()
         self.backward_G()
         self.optimizer_G.all_reduce_mean()
         self.optimizer_G.step()
         self.set_requires_grad(Ds, True)
-        self.optimizer_D.zero_grad()
+        # the discriminators' flat gradient buffer is zeroed right after optimizer_D.step (below), i.e. before this
+        # step's forward(): zeroing it here, on the calling stream, would run after the early discriminator backward
+        self.optimizer_D.zero_grad(fill=False)  # (re-attaches the .grad views only; the buffer starts as zeros)
         self.backward_D_all()
         self.optimizer_D.all_reduce_mean()
         self.optimizer_D.step()
+        self.optimizer_D.grad.zero_()
