@@ -118,14 +118,19 @@ __global__ __launch_bounds__(512) void k_wgrad_1x1(W1Params p) {
   }
 }
 
+// one wave per output element: lane l adds the slabs l, l + 64, ... in order, then a fixed-order butterfly over the
+// 64 lanes (deterministic; a single thread walking 256 strided slabs was latency bound: 60 us)
 __global__ void k_wgrad_1x1_reduce(const float* __restrict__ slab, float* __restrict__ dw, int nwg, int K, int C,
                                    int Kp, int Cp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= K * C) return;
+  const int lane = threadIdx.x & 63;
   const int k = i / C, c = i - k * C;
   float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += slab[((long)w * Kp + k) * Cp + c];
-  dw[i] = s;
+  for (int w = lane; w < nwg; w += 64) s += slab[((long)w * Kp + k) * Cp + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) dw[i] = s;
 }
 
 bool wgrad_1x1_supported(const ConvDims& d) {
@@ -184,7 +189,7 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
   }
   hipLaunchKernelGGL(k_wgrad_1x1, dim3(nwg), dim3(512), lds_bytes, s, p);
   if (int e = check_launch("wgrad_1x1")) return e;
-  hipLaunchKernelGGL(k_wgrad_1x1_reduce, dim3((d.K * d.C + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, nwg, d.K,
+  hipLaunchKernelGGL(k_wgrad_1x1_reduce, dim3((d.K * d.C + 3) / 4), dim3(256), 0, s, (const float*)ws, dw, nwg, d.K,
                      d.C, p.Kp, p.Cp);
   return check_launch("wgrad_1x1_reduce");
 }

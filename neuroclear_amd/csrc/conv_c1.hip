@@ -286,13 +286,17 @@ __global__ __launch_bounds__(512) void k_wgrad_c1(C1wParams p) {
       sl[(long)(mb * 16 + 4 * kq + rr) * (NB * 16) + (nb0 + 2 * j) * 16 + l15] = acc[j][rr];
 }
 
+// one wave per output element, lanes over the workgroup slabs, fixed-order butterfly (deterministic)
 __global__ void k_wgrad_c1_reduce(const float* __restrict__ slab, float* __restrict__ dw, int parts, int taps, int nt16) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= 64 * taps) return;
+  const int lane = threadIdx.x & 63;
   const int co = i / taps, t = i - co * taps;
   float s = 0.f;
-  for (int w = 0; w < parts; ++w) s += slab[((long)w * 64 + co) * nt16 + t];
-  dw[i] = s;
+  for (int w = lane; w < parts; w += 64) s += slab[((long)w * 64 + co) * nt16 + t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) dw[i] = s;
 }
 
 static int c1w_nt16(int KS) { return ((KS * KS * KS + 31) / 32) * 32; }
@@ -365,7 +369,7 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
   const int e = d.kd == 7 ? launch_c1w<7>(p, lds_bytes, s) : launch_c1w<3>(p, lds_bytes, s);
   if (e) return e;
   const int taps = d.kd * d.kd * d.kd;
-  hipLaunchKernelGGL(k_wgrad_c1_reduce, dim3((64 * taps + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, p.parts,
+  hipLaunchKernelGGL(k_wgrad_c1_reduce, dim3((64 * taps + 3) / 4), dim3(256), 0, s, (const float*)ws, dw, p.parts,
                      taps, c1w_nt16(d.kd));
   return check_launch("wgrad_c1_reduce");
 }
