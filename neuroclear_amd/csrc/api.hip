@@ -51,6 +51,8 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   if (o > b) b = o;
   const size_t c1 = c1_wgrad_ws_bytes(d);
   if (c1 > b) b = c1;
+  const size_t t1 = to1_mfma_ws_bytes(d);
+  if (t1 > b) b = t1;
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
@@ -82,6 +84,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
+  if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_dgrad_supported(d)) return conv_dgrad_to1(dy, w, dx, d, s);
   if (!g_force_direct && gemm_dgrad_supported(d)) return conv_dgrad_gemm(dy, w, dx, d, ws, ws_bytes, s);
   return conv_dgrad_direct(dy, w, dx, d, s);

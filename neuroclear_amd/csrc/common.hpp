@@ -80,6 +80,10 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
 bool to1_dgrad_supported(const ConvDims& d);
 int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+bool to1_mfma_supported(const ConvDims& d);
+size_t to1_mfma_ws_bytes(const ConvDims& d);
+int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                        hipStream_t s);
 // one channel -> 64 channels weight gradient (MFMA over the tap axis), conv_c1.hip
 bool c1_wgrad_supported(const ConvDims& d);
 size_t c1_wgrad_ws_bytes(const ConvDims& d);

@@ -374,4 +374,224 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
   return check_launch("wgrad_c1_reduce");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of Conv3d(1, 64, 7, padding 3) on the matrix cores (the VALU kernel k_conv_to1 above stays as the
+// fallback): dX[u] = sum_{co,t} W[co][t] * dY[co][u + p - t].  One output channel leaves no M axis for an implicit
+// GEMM over voxels; instead, per input row of dY, the MFMA computes  Z[(dy,dx)][v] = sum_co W[co][dz,dy,dx] * dY[co][v]
+// (M = 2 dy x 7 dx of 16 rows, N = 16 voxels, K = 64 channels, v_mfma_f32_16x16x4_f32) and Z is folded back by index
+// arithmetic: Z[(dy,dx)][v] belongs to dX[v + (dz,dy,dx) - p].
+//   * a workgroup owns two kernel planes dz (waves 0-3 / 4-7), a wave two kernel rows dy; all read the same dY row
+//     [64][W] from LDS (LDS-DMA, double buffered, one barrier per row);
+//   * fold in x: the wave parks its Z rows in a private LDS strip and reads them back shifted, c_dy[x] = sum_dx
+//     Z[dy,dx][x + p - dx];  fold in y: c_dy of input row y' belongs to output row y' + dy - p -- the seven dy of a
+//     step hit seven DIFFERENT rows of a small LDS ring, so every ring row receives exactly one addend per step, from
+//     one wave, in step order: plain read-modify-write, deterministic, no atomics.  The row that just got its dy = 0
+//     addend is complete and is written out;  fold in z: one partial volume per dz + a fixed-order reduce kernel;
+//   * the volume's rows are split over workgroups with a 3-row halo of dY on either side (recomputed, 13 % at 108^3)
+//     so that every output row is completed inside one workgroup.
+struct T1Params {
+  const float* dy;
+  const float* w;
+  float* slab;         // [7 dz][N][D][H][W]
+  const float* zeros;
+  int N, D, H, W;
+  int PAr, SD;         // dY LDS pitch per channel (= 16 mod 32), floats per dY buffer (whole pieces)
+  int W16;
+  int parts;
+};
+
+static constexpr int kZsPitch = 124;  // Z strip pitch: 4 rows apart = 16 banks apart
+
+__global__ __launch_bounds__(512) void k_dgrad_to1(T1Params p) {
+  constexpr int KS = 7, PAD = 3, RINGR = 8, MAXPD = 5;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int dzi = wave >> 2, j2 = wave & 3;
+  const int dz = 2 * blockIdx.y + dzi;  // kernel plane of this half of the workgroup (7 = none)
+  const bool wave_on = dz < KS;
+  const int part = blockIdx.x;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const long nrows = (long)p.N * p.D * p.H;  // rows (n, z', y') of dY
+  const long r0 = nrows * part / p.parts, r1 = nrows * (part + 1) / p.parts;
+
+  float* dyT = lds;                                   // 2 x SD
+  float* zs = lds + 2 * p.SD + wave * 16 * kZsPitch;  // this wave's Z strip [16][4 + W16 + 4 .. pitch 124]
+  float* ring = lds + 2 * p.SD + 8 * 16 * kZsPitch + dzi * RINGR * 128;  // [8 rows][128] per dz half
+  for (int i = tid; i < 8 * 16 * kZsPitch + 2 * RINGR * 128; i += 512) lds[2 * p.SD + i] = 0.f;
+  const int npd = p.SD / 256;
+
+  // A operand: row m of the 16 x 4 tile is tap (dy, dx): m < 7 -> (2*j2, m), 8 <= m < 15 -> (2*j2 + 1, m - 8)
+  float aw[16];
+  {
+    const int dyy = 2 * j2 + (l15 >> 3), dx = l15 & 7;
+    const bool tap_ok = wave_on && dyy < KS && dx < KS;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      aw[ks] = tap_ok ? p.w[(long)(4 * ks + kq) * (KS * KS * KS) + (dz * KS + dyy) * KS + dx] : 0.f;
+  }
+  int gd[MAXPD];
+#pragma unroll
+  for (int i = 0; i < MAXPD; ++i) {
+    const int f = ((wave + 8 * i) * 64 + lane) * 4;
+    const int c = f / p.PAr, col = f - c * p.PAr;
+    gd[i] = (c < 64 && col < p.W) ? (int)(c * S + col) : -1;
+  }
+  auto issue = [&](int n, int z, int y, int buf) {
+    const float* dbse = p.dy + (long)n * 64 * S + (long)z * HW + (long)y * p.W;
+    float* ds = dyT + buf * p.SD;
+#pragma unroll
+    for (int i = 0; i < MAXPD; ++i) {
+      const int jj = wave + 8 * i;
+      if (jj < npd) {
+        const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + jj * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- walk the rows [r0, r1): per (n, z') plane segment [ya, yb) the input rows run yl = max(0, ya-3) .. min(H, yb+3)
+  long r = r0;
+  int n = 0, z = 0, ya = 0, yb = 0, yl = 0, yh = 0, y = 0;
+  bool have = false;
+  auto next_segment = [&]() {
+    if (r >= r1) {
+      have = false;
+      return;
+    }
+    const long plane = r / p.H;
+    ya = (int)(r - plane * p.H);
+    const long rem = r1 - r;
+    yb = (int)min((long)p.H, ya + rem);
+    n = (int)(plane / p.D);
+    z = (int)(plane - (long)n * p.D);
+    yl = max(0, ya - PAD);
+    yh = min(p.H, yb + PAD);
+    y = yl;
+    r += yb - ya;
+    have = true;
+  };
+  next_segment();
+  int cnt = 0;
+  __syncthreads();
+  if (have) issue(n, z, y, 0);
+  const int b_off = kq * p.PAr + l15;  // dY[4*ks + kq][q16 + l15]
+  while (have) {
+    const int cn = n, cz = z, cy = y, cya = ya, cyb = yb, cbuf = cnt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the row has landed; the previous step's ring updates are done
+    ++cnt;
+    ++y;
+    if (y >= yh) next_segment();
+    if (have) issue(n, z, y, cnt & 1);
+    const int oz = cz + dz - PAD;  // output plane of this wave's kernel plane
+    if (wave_on && oz >= 0 && oz < p.D) {
+      const float* pb = dyT + cbuf * p.SD + b_off;
+      // Z[(dy,dx)][v] for the whole row, 16 voxels at a time, parked in the wave's strip (columns 4 .. 4 + W16)
+#pragma unroll 1
+      for (int q16 = 0; q16 < p.W16; q16 += 16) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], pb[4 * ks * p.PAr + q16], acc, 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) zs[(4 * kq + rr) * kZsPitch + 4 + q16 + l15] = acc[rr];
+      }
+      // fold in x and y: kernel row dy of this input row goes to output row cy + dy - PAD
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int dyy = 2 * j2 + e;
+        const int oy = cy + dyy - PAD;
+        if (dyy < KS && oy >= cya && oy < cyb) {
+          float* rrow = ring + (oy & (RINGR - 1)) * 128;
+#pragma unroll 1
+          for (int x = lane; x < p.W; x += 64) {
+            float c = 0.f;
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) c += zs[(8 * e + dx) * kZsPitch + 4 + x + PAD - dx];
+            const float tot = rrow[x] + c;
+            if (dyy == 0 || cy == p.H - 1) {  // last addend of this output row (input row oy + 3, or the plane's last)
+              p.slab[(((long)dz * p.N + cn) * p.D + oz) * HW + (long)oy * p.W + x] = tot;
+              rrow[x] = 0.f;
+            } else {
+              rrow[x] = tot;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// dx[n][z][y][x] = sum over the kernel planes dz whose input plane z - dz + p exists, in dz order
+__global__ void k_dgrad_to1_reduce(const float* __restrict__ slab, float* __restrict__ dx, int N, int D, long HW) {
+  const long total = (long)N * D * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int z = (int)((i / HW) % D);
+    float s = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 7; ++dz) {
+      const int zi = z - dz + 3;
+      if (zi >= 0 && zi < D) s += slab[(long)dz * total + i];
+    }
+    dx[i] = s;
+  }
+}
+
+bool to1_mfma_supported(const ConvDims& d) {
+  return d.C == 1 && d.K == 64 && d.kd == 7 && d.kh == 7 && d.kw == 7 && d.sd == 1 && d.sh == 1 && d.sw == 1 &&
+         d.pd == 3 && d.ph == 3 && d.pw == 3 && d.W % 4 == 0 && d.W >= 16 && d.W <= 112 &&
+         (long)d.D * d.H * d.W * 64 < (1L << 31);
+}
+
+size_t to1_mfma_ws_bytes(const ConvDims& d) {
+  if (!to1_mfma_supported(d)) return 0;
+  return (size_t)7 * d.N * d.D * d.H * d.W * sizeof(float) + 256;
+}
+
+int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                        hipStream_t s) {
+  const size_t need = to1_mfma_ws_bytes(d);
+  if (!need) {
+    set_error("dgrad_to1: unsupported shape");
+    return NC_ERR_SHAPE;
+  }
+  if (!ws || wsb < need) {
+    set_error("dgrad_to1: workspace too small (%zu < %zu)", wsb, need);
+    return NC_ERR_WS;
+  }
+  if (hipMemsetAsync((char*)ws + need - 256, 0, 256, s) != hipSuccess) {
+    set_error("dgrad_to1: memset of the zero page failed");
+    return NC_ERR_HIP;
+  }
+  T1Params p{};
+  p.dy = dy; p.w = w; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
+  p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.W16 = (d.W + 15) & ~15;
+  int pa = (p.W16 + 15) & ~15;
+  if (pa % 32 != 16) pa += 16;  // = 16 (mod 32): the two k rows of a half-wave read disjoint banks
+  p.PAr = pa;
+  p.SD = (64 * p.PAr + 255) & ~255;
+  const long rows = (long)d.N * d.D * d.H;
+  p.parts = (int)(rows < 64 ? rows : 64);
+  const int lds_bytes = (2 * p.SD + 8 * 16 * kZsPitch + 2 * 8 * 128) * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad_to1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      set_error("dgrad_to1: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_dgrad_to1, dim3(p.parts, 4), dim3(512), lds_bytes, s, p);
+  if (int e = check_launch("dgrad_to1")) return e;
+  hipLaunchKernelGGL(k_dgrad_to1_reduce, dim3(2048), dim3(256), 0, s, (const float*)ws, dx, d.N, d.D,
+                     (long)d.H * d.W);
+  return check_launch("dgrad_to1_reduce");
+}
+
 }  // namespace nc

@@ -46,6 +46,7 @@ CONV_CASES = [
     (1, 1, 64, (12, 12, 12), 7, 1, 3),
     (1, 1, 64, (10, 9, 20), 7, 1, 3),        # tap-axis MFMA wgrad (W % 4 == 0), ragged D/H
     (2, 1, 64, (7, 11, 36), 3, 1, 1),        # same, 3^3, batch 2
+    (2, 1, 64, (5, 30, 24), 7, 1, 3),        # MFMA 64 -> 1 data gradient: row ranges that split planes (halo rows)
     (2, 1, 64, (9, 10, 70), 7, 1, 3),        # 7^3, ragged: exercises tile edges of the many->one dgrad kernel
     (1, 64, 1, (10, 10, 10), 1, 1, 0),
     (1, 1, 1, (8, 8, 8), 1, 1, 0),
