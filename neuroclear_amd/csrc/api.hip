@@ -28,9 +28,10 @@ void nc_set_force_direct(int on) { g_force_direct = on; }
 
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
-  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, 32, 32, K, kd, kh, kw, stride, pad)) return -1;
+  const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
+  if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
-  return mfma_fwd_supported(d) ? 1 : gemm_fwd_supported(d) ? 2 : 0;
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : gemm_fwd_supported(d) ? 2 : 0;
 }
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
@@ -74,6 +75,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   if (int e = conv_args("conv_fwd", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
+  if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && gemm_fwd_supported(d)) return conv_fwd_gemm(x, w, bias, y, d, ws, ws_bytes, s);
   return conv_fwd_direct(x, w, bias, y, d, s);
 }
@@ -84,6 +86,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
+  if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_dgrad_supported(d)) return conv_dgrad_to1(dy, w, dx, d, s);
   if (!g_force_direct && gemm_dgrad_supported(d)) return conv_dgrad_gemm(dy, w, dx, d, ws, ws_bytes, s);

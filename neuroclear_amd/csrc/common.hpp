@@ -76,6 +76,11 @@ int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& 
 bool wgrad_1x1_supported(const ConvDims& d);
 size_t wgrad_1x1_ws_bytes(const ConvDims& d);
 int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+bool flat_1x1_supported(const ConvDims& d);
+int conv_fwd_1x1(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                 hipStream_t s);
+int conv_dgrad_1x1(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                   hipStream_t s);
 
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
 bool to1_dgrad_supported(const ConvDims& d);

@@ -194,4 +194,161 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
   return check_launch("wgrad_1x1_reduce");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward and data gradient of the same pointwise layers: out[m][v] = sum_r A[m][r] * in[r][v] (+ bias[m]) with
+// A = W (forward: m = k, r = c) or W^T (data gradient: m = c, r = k), M, R <= 64, on the flat voxel axis.
+// HBM-bound (one read of `in`, one write of `out`): chunks of 128 voxels of every input channel arrive by LDS-DMA
+// (double buffered), v_mfma_f32_16x16x4_f32 with the weights held in registers as the A operand, and the output tile
+// goes through LDS so that every store instruction writes 1 KiB of one channel row.
+static constexpr int kPitchF = 144;  // input rows: 128 + 16, = 16 (mod 32): the two k rows of a half-wave read disjoint banks
+static constexpr int kPitchO = 132;  // output staging rows
+struct F1Params {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  const float* zeros;
+  int M, R, N;
+  int sm, sr;   // A[m][r] = w[m * sm + r * sr]
+  long S;
+  int Rp;       // R rounded up to 4
+  int npi;      // 256-float pieces of one input buffer
+  long nchunks, cps;
+};
+
+__global__ __launch_bounds__(512) void k_flat_1x1(F1Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int MB = (p.M + 15) / 16;
+  const int bufsz = p.npi * 256;
+  float* ost = lds + 2 * bufsz;  // [MB * 16][kPitchO]
+  const long c0 = p.nchunks * blockIdx.x / gridDim.x, c1 = p.nchunks * (blockIdx.x + 1) / gridDim.x;
+
+  int goff[5], gcol[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int f = ((wave + 8 * i) * 64 + lane) * 4;
+    const int row = f / kPitchF, col = f - row * kPitchF;
+    goff[i] = (col < kVC && row < p.R) ? (int)(row * p.S + col) : -1;
+    gcol[i] = col;
+  }
+  auto issue = [&](long chunk, float* buf) {
+    const long n = chunk / p.cps;
+    const long v0 = (chunk - n * p.cps) * kVC;
+    const float* xb = p.in + n * p.R * p.S + v0;
+    const int vleft = (int)min((long)kVC, p.S - v0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = wave + 8 * i;
+      if (j < p.npi) {
+        const float* src = (goff[i] >= 0 && gcol[i] < vleft) ? xb + goff[i] : p.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + j * 256), 16, 0, 0);
+      }
+    }
+  };
+  // this wave: output row block mb = wave % MB' and every (8 / waves-per-mb)-th voxel block; weights of the row block
+  // as the A operand of all k-steps
+  const int wpm = MB >= 4 ? 2 : MB == 2 ? 4 : 8;  // waves per row block (MB = 3 is served as 4)
+  const int mb = wave / wpm;
+  const bool mb_on = mb < MB;
+  float aw[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int m = mb * 16 + l15, r = 4 * ks + kq;
+    aw[ks] = (mb_on && m < p.M && r < p.R) ? p.w[(long)m * p.sm + (long)r * p.sr] : 0.f;
+  }
+  const int nks = p.Rp / 4;
+  const int b_off = kq * kPitchF + l15;
+
+  if (c0 < c1) issue(c0, lds);
+  for (long c = c0; c < c1; ++c) {
+    const int par = (int)((c - c0) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk landed; the previous chunk's output tile has been written out
+    if (c + 1 < c1) issue(c + 1, lds + (par ^ 1) * bufsz);
+    const float* buf = lds + par * bufsz + b_off;
+    if (mb_on) {
+      for (int nb = wave % wpm; nb < 8; nb += wpm) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[ks], buf[4 * ks * kPitchF + nb * 16], acc, 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ost[(mb * 16 + 4 * kq + rr) * kPitchO + nb * 16 + l15] = acc[rr];
+      }
+    }
+    __syncthreads();
+    // write the tile: one wave-instruction = two channel rows x 128 voxels (float4 per lane)
+    const long n = c / p.cps;
+    const long v0 = (c - n * p.cps) * kVC;
+    const int vleft = (int)min((long)kVC, p.S - v0);
+    for (int m = 2 * wave + (lane >> 5); m < p.M; m += 16) {
+      const int col = (lane & 31) * 4;
+      if (col < vleft) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(ost + m * kPitchO + col, 16));
+        if (p.bias) {
+          const float b = p.bias[m];
+          v += f32x4{b, b, b, b};
+        }
+        *reinterpret_cast<f32x4*>(p.out + (n * p.M + m) * p.S + v0 + col) = v;
+      }
+    }
+  }
+}
+
+static bool flat_1x1_shape(const ConvDims& d) {
+  if (d.kd != 1 || d.kh != 1 || d.kw != 1 || d.sh != 1 || d.sw != 1 || d.ph != 0 || d.pw != 0) return false;
+  if (d.K > 64 || d.C > 64) return false;
+  const long S = (long)d.D * d.H * d.W;
+  return S % 4 == 0 && S >= 16384 && S * 64 < (1L << 31);
+}
+bool flat_1x1_supported(const ConvDims& d) { return flat_1x1_shape(d); }
+
+static int launch_flat(const float* in, const float* w, const float* bias, float* out, int M, int R, int sm, int sr,
+                       const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  if (!ws || wsb < 256) {
+    set_error("flat_1x1: workspace too small");
+    return NC_ERR_WS;
+  }
+  if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) {
+    set_error("flat_1x1: memset of the zero page failed");
+    return NC_ERR_HIP;
+  }
+  F1Params p{};
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.zeros = (const float*)ws;
+  p.M = M; p.R = R; p.N = d.N; p.sm = sm; p.sr = sr;
+  p.S = (long)d.D * d.H * d.W;
+  p.Rp = (R + 3) & ~3;
+  p.npi = (p.Rp * kPitchF + 255) / 256;  // the k rows R .. Rp-1 of the last k-step are zero-page rows, not stale LDS
+  p.cps = (p.S + kVC - 1) / kVC;
+  p.nchunks = (long)d.N * p.cps;
+  const int nwg = (int)(p.nchunks < 512 ? p.nchunks : 512);
+  const int MB = (M + 15) / 16;
+  const int lds_bytes = (2 * p.npi * 256 + MB * 16 * kPitchO) * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_1x1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      set_error("flat_1x1: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_flat_1x1, dim3(nwg), dim3(512), lds_bytes, s, p);
+  return check_launch("flat_1x1");
+}
+
+int conv_fwd_1x1(const float* x, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                 hipStream_t s) {
+  return launch_flat(x, w, b, y, d.K, d.C, d.C, 1, d, ws, wsb, s);
+}
+int conv_dgrad_1x1(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
+                   hipStream_t s) {
+  return launch_flat(dy, w, nullptr, dx, d.C, d.K, 1, d.C, d, ws, wsb, s);
+}
+
 }  // namespace nc

@@ -97,7 +97,7 @@ def test_conv_paths_reported():
     assert L.nc_conv_fwd_path(I(1), I(64), I(3), I(3), I(3), I(1), I(1)) == 1  # single-channel mode of the brick kernel
     assert L.nc_conv_wgrad_path(I(1), I(64), I(7), I(7), I(7), I(1), I(3)) == 4
     assert L.nc_conv_fwd_path(I(64), I(128), I(1), I(4), I(4), I(2), I(1)) == 2
-    assert L.nc_conv_fwd_path(I(64), I(1), I(1), I(1), I(1), I(1), I(0)) == 0
+    assert L.nc_conv_fwd_path(I(64), I(1), I(1), I(1), I(1), I(1), I(0)) == 3  # flat-voxel pointwise kernel
 
 
 @pytest.mark.parametrize('shape', [(1, 256, 4, 5, 6), (2, 128, 3, 4, 4)])
