@@ -213,8 +213,8 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     NC_TRY(block(8, W + u.a2, W + u.a2b, 128, 128, h0, h1, h2));
     NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
     NC_TRY(block(9, W + u.cat1, W + u.a1, 128, 64, S0, S1, S2));
-    NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, nullptr, 0, stream));
-    NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, nullptr, 0, stream));
+    NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
+    NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
     NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S, stream));
   }
   (void)Sq;
