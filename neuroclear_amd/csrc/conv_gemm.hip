@@ -24,6 +24,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // layers (networks.py:1030-1046), 8x in 3-D.
 enum { G_FWD = 0, G_DGRAD = 1, G_WGRAD = 2, G_DGRAD_P = 3 };
 
+// n / d for 0 <= n < 2^31 with m = ceil(2^32 / d): the high product is floor(n / d) or one more
+struct Div {
+  unsigned m, d;
+};
+static Div mkdiv(long d) {
+  Div r;
+  r.d = (unsigned)(d < 1 ? 1 : d);
+  r.m = (unsigned)(((1ull << 32) + r.d - 1) / r.d);
+  return r;
+}
+__device__ __forceinline__ int qdiv(int n, const Div& v) {
+  if (v.d == 1) return n;
+  unsigned q = __umulhi((unsigned)n, v.m);
+  if ((unsigned long long)q * v.d > (unsigned)n) --q;
+  return (int)q;
+}
+
+
 struct GemmParams {
   const float* a;   // FWD/DGRAD: weights; WGRAD: dy
   const float* b;   // FWD: x; DGRAD: dy; WGRAD: x
@@ -36,6 +54,7 @@ struct GemmParams {
   int splits, rper; // WGRAD: reduction range per split (multiple of 16)
   // G_DGRAD_P: class grid (ceil(D/sd), ceil(H/sh), ceil(W/sw)), sub-taps per dimension (k / s), their product
   int cd, ch, cw, td, th, tw, ptaps;
+  Div dtaps, dkhw, dkw, dSo, dHoWo, dWo, dptaps, dthtw, dtw;  // divisors of the per-chunk index decodes
 };
 
 static constexpr int kAP = 65;  // pitch of the A image (floats)
@@ -100,15 +119,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
         if (MODE == G_FWD) {
           v = p.a[(long)m * p.R + r];
         } else if (MODE == G_DGRAD) {
-          const int k = r / p.taps, tap = r - k * p.taps;
+          const int k = qdiv(r, p.dtaps), tap = r - k * p.taps;
           v = p.a[((long)k * d.C + m) * p.taps + tap];
         } else if (MODE == G_DGRAD_P) {
-          const int k = r / p.ptaps, sub = r - k * p.ptaps;
-          const int jz = sub / (p.th * p.tw), jy = (sub - jz * p.th * p.tw) / p.tw, jx = sub - jz * p.th * p.tw - jy * p.tw;
+          const int k = qdiv(r, p.dptaps), sub = r - k * p.ptaps;
+          const int jz = qdiv(sub, p.dthtw), s2 = sub - jz * p.th * p.tw;
+          const int jy = qdiv(s2, p.dtw), jx = s2 - jy * p.tw;
           const int tap = ((t0z + d.sd * jz) * d.kh + t0y + d.sh * jy) * d.kw + t0x + d.sw * jx;
           v = p.a[((long)k * d.C + m) * p.taps + tap];
         } else {
-          const int b = d.N > 1 ? r / (int)p.So : 0;
+          const int b = d.N > 1 ? qdiv(r, p.dSo) : 0;
           const int pos = r - b * (int)p.So;
           v = p.a[((long)b * d.K + m) * p.So + pos];
         }
@@ -122,14 +142,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
       float v = 0.f;
       if (r < r_end && ncol_ok) {
         if (MODE == G_FWD) {
-          const int c = r / p.taps, tap = r - c * p.taps;
-          const int tz = tap / p.khw, ty = (tap - tz * p.khw) / d.kw, tx = tap - tz * p.khw - ty * d.kw;
+          const int c = qdiv(r, p.dtaps), tap = r - c * p.taps;
+          const int tz = qdiv(tap, p.dkhw), t2 = tap - tz * p.khw;
+          const int ty = qdiv(t2, p.dkw), tx = t2 - ty * d.kw;
           const int iz = c0 * d.sd - d.pd + tz, iy = c1 * d.sh - d.ph + ty, ix = c2 * d.sw - d.pw + tx;
           if ((unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
             v = p.b[((long)nb * d.C + c) * p.S + (long)iz * HW + iy * d.W + ix];
         } else if (MODE == G_DGRAD) {
-          const int k = r / p.taps, tap = r - k * p.taps;
-          const int tz = tap / p.khw, ty = (tap - tz * p.khw) / d.kw, tx = tap - tz * p.khw - ty * d.kw;
+          const int k = qdiv(r, p.dtaps), tap = r - k * p.taps;
+          const int tz = qdiv(tap, p.dkhw), t2 = tap - tz * p.khw;
+          const int ty = qdiv(t2, p.dkw), tx = t2 - ty * d.kw;
           const int uz = c0 + d.pd - tz, uy = c1 + d.ph - ty, ux = c2 + d.pw - tx;
           if (uz >= 0 && uy >= 0 && ux >= 0) {
             const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
@@ -137,8 +159,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
         } else if (MODE == G_DGRAD_P) {
-          const int k = r / p.ptaps, sub = r - k * p.ptaps;
-          const int jz = sub / (p.th * p.tw), jy = (sub - jz * p.th * p.tw) / p.tw, jx = sub - jz * p.th * p.tw - jy * p.tw;
+          const int k = qdiv(r, p.dptaps), sub = r - k * p.ptaps;
+          const int jz = qdiv(sub, p.dthtw), s2 = sub - jz * p.th * p.tw;
+          const int jy = qdiv(s2, p.dtw), jx = s2 - jy * p.tw;
           const int uz = c0 + d.pd - t0z - d.sd * jz, uy = c1 + d.ph - t0y - d.sh * jy, ux = c2 + d.pw - t0x - d.sw * jx;
           if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the stride by construction
             const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
@@ -146,9 +169,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
         } else {
-          const int b = d.N > 1 ? r / (int)p.So : 0;
+          const int b = d.N > 1 ? qdiv(r, p.dSo) : 0;
           const int pos = r - b * (int)p.So;
-          const int od = pos / HoWo, oh = (pos - od * HoWo) / d.Wo, ow = pos - od * HoWo - oh * d.Wo;
+          const int od = qdiv(pos, p.dHoWo), p2 = pos - od * HoWo;
+          const int oh = qdiv(p2, p.dWo), ow = p2 - oh * d.Wo;
           const int iz = od * d.sd - d.pd + c0, iy = oh * d.sh - d.ph + c1, ix = ow * d.sw - d.pw + c2;
           if ((unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
             v = p.b[((long)b * d.C + nb) * p.S + (long)iz * HW + iy * d.W + ix];
@@ -243,6 +267,9 @@ static void gemm_common(GemmParams& p, const ConvDims& d) {
   p.So = (long)d.Do * d.Ho * d.Wo;
   p.splits = 1;
   p.rper = 0;
+  p.dtaps = mkdiv(p.taps); p.dkhw = mkdiv(p.khw); p.dkw = mkdiv(d.kw);
+  p.dSo = mkdiv(p.So); p.dHoWo = mkdiv((long)d.Ho * d.Wo); p.dWo = mkdiv(d.Wo);
+  p.dptaps = mkdiv(1); p.dthtw = mkdiv(1); p.dtw = mkdiv(1);
 }
 
 static bool gemm_range_ok(const ConvDims& d) {
@@ -348,6 +375,7 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
     p.cd = (int)cdiv(d.D, d.sd); p.ch = (int)cdiv(d.H, d.sh); p.cw = (int)cdiv(d.W, d.sw);
     p.td = d.kd / d.sd; p.th = d.kh / d.sh; p.tw = d.kw / d.sw;
     p.ptaps = p.td * p.th * p.tw;
+    p.dptaps = mkdiv(p.ptaps); p.dthtw = mkdiv((long)p.th * p.tw); p.dtw = mkdiv(p.tw);
     const int ncls = d.sd * d.sh * d.sw;
     p.M = d.C; p.N = d.N * p.cd * p.ch * p.cw; p.R = d.K * p.ptaps;
     const long n = (long)d.C * Pi(d);
