@@ -107,7 +107,9 @@ def _conv_ws(dims, K, k3, stride, pad, device, tag='ws'):
 # Backward runs the weight gradient of a layer on a side stream, concurrently with the data gradient of the same layer
 # (they are independent given dy): the two kernels' workgroups interleave on the 256 CUs, which fills the idle tail
 # each of them leaves when its tile count is not a multiple of the CU count (e.g. 1296 tiles = 5.06 rounds at 108^3).
-overlap_wgrad = os.environ.get('NC_WGRAD_STREAM', '1') != '0'
+# NC_WGRAD_STREAM=1: weight gradients of the big layers on a side stream behind the data gradient.  Off by default:
+# once both kernels fill the chip by themselves (round-1 end state) running them side by side is 0.3 % slower.
+overlap_wgrad = os.environ.get('NC_WGRAD_STREAM', '0') != '0'
 _side_streams = {}
 
 
