@@ -32,7 +32,8 @@ if ROOT not in sys.path:
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
-    'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (W%4==0) | k_wgrad_mfma<3,*>', 'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
+    'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
+    'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
 }
 
 
