@@ -117,6 +117,12 @@ int nc_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
  *      truncating cast, crop to the original size; cnt is computed analytically from the grid.                    */
 int nc_dice_cut_cube(const void* vol, int is_u16, int L0, int L1, int L2, int roi, int overlap, int border, int index,
                      float* cube, void* stream);
+/* ---- Training augmentation "clean rotation" (data/base_dataset.py:306-460: rotate every z-slice with cv2.warpAffine,
+ *      crop to the inscribed rectangle) fused with the random crop (:187-206) and __normalize (:134-143): produces only
+ *      the crop.  inv_affine = 2x3 row-major map from rotated-image pixel (x, y) to source pixel; (x0, y0) = crop origin
+ *      in the rotated image (inscribed-rectangle offset + random crop offset); z0 = first source slice.           */
+int nc_rotate_crop(const void* vol, int is_u16, int D, int H, int W, int z0, int y0, int x0, int cz, int cy, int cx,
+                   const double* inv_affine, float* out, void* stream);
 int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P2, int roi, int overlap, int border,
                             int index, void* stream);
 int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2,

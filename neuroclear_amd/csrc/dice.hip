@@ -24,6 +24,35 @@ __host__ __device__ inline int pad_len(int L, int roi, int overlap) {
   return step * ((L + overlap) / step) + roi;  // L + pad
 }
 
+// ---- "clean rotation" training augmentation on the device (reference data/base_dataset.py:306-460): every z-slice is
+//      rotated about its centre (cv2.warpAffine, bilinear, zero border) and cropped to the inscribed rectangle; the
+//      reference rotates the WHOLE volume on the host for every training crop.  Here only the voxels of the requested
+//      crop are produced: out[z][y][x] = bilinear(vol[z0 + z], inv * (x0 + x, y0 + y, 1)), rounded to the source integer
+//      type and normalised (/65535 or /255 in fp64, then fp32) exactly like the crop-only path.
+template <typename T>
+__global__ void k_rotate_crop(const T* __restrict__ vol, int H, int W, int z0, int y0, int x0, int cz, int cy, int cx,
+                              double m00, double m01, double m02, double m10, double m11, double m12, double den,
+                              double vmax, float* __restrict__ out) {
+  const long total = (long)cz * cy * cx;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % cx), y = (int)((i / cx) % cy), z = (int)(i / ((long)cx * cy));
+    const double dx = (double)(x0 + x), dy = (double)(y0 + y);
+    const double sx = m00 * dx + m01 * dy + m02, sy = m10 * dx + m11 * dy + m12;
+    const double fx = floor(sx), fy = floor(sy);
+    const double ax = sx - fx, ay = sy - fy;
+    const long ix = (long)fx, iy = (long)fy;
+    const T* sl = vol + (long)(z0 + z) * H * W;
+    auto tap = [&](long yy, long xx) -> double {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (double)sl[yy * W + xx] : 0.0;
+    };
+    double v = (tap(iy, ix) * (1.0 - ax) + tap(iy, ix + 1) * ax) * (1.0 - ay) +
+               (tap(iy + 1, ix) * (1.0 - ax) + tap(iy + 1, ix + 1) * ax) * ay;
+    v = rint(v);
+    v = v < 0.0 ? 0.0 : (v > vmax ? vmax : v);
+    out[i] = (float)(v / den);
+  }
+}
+
 template <typename T>
 __global__ void k_cut_cube(const T* __restrict__ vol, DiceGeom g, int z0, int y0, int x0, double den,
                            float* __restrict__ cube) {
@@ -115,6 +144,25 @@ int nc_dice_cut_cube(const void* vol, int is_u16, int L0, int L1, int L2, int ro
     hipLaunchKernelGGL(k_cut_cube<uint8_t>, dim3(flat_grid(E * E * E)), dim3(256), 0, s, (const uint8_t*)vol, g,
                        zi * g.step, yi * g.step, xi * g.step, 255.0, cube);
   return check_launch("dice_cut_cube");
+}
+
+int nc_rotate_crop(const void* vol, int is_u16, int D, int H, int W, int z0, int y0, int x0, int cz, int cy, int cx,
+                   const double* inv_affine, float* out, void* stream) {
+  if (!vol || !out || !inv_affine) { set_error("rotate_crop: null pointer"); return NC_ERR_ARG; }
+  if (D < 1 || H < 1 || W < 1 || cz < 1 || cy < 1 || cx < 1 || z0 < 0 || z0 + cz > D) {
+    set_error("rotate_crop: bad shape D=%d H=%d W=%d crop=(%d,%d,%d) z0=%d", D, H, W, cz, cy, cx, z0);
+    return NC_ERR_SHAPE;
+  }
+  const double* m = inv_affine;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)cz * cy * cx;
+  if (is_u16)
+    hipLaunchKernelGGL(k_rotate_crop<uint16_t>, dim3(flat_grid(total)), dim3(256), 0, s, (const uint16_t*)vol, H, W, z0,
+                       y0, x0, cz, cy, cx, m[0], m[1], m[2], m[3], m[4], m[5], 65535.0, 65535.0, out);
+  else
+    hipLaunchKernelGGL(k_rotate_crop<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, (const uint8_t*)vol, H, W, z0,
+                       y0, x0, cz, cy, cx, m[0], m[1], m[2], m[3], m[4], m[5], 255.0, 255.0, out);
+  return check_launch("rotate_crop");
 }
 
 int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P2, int roi, int overlap, int border,

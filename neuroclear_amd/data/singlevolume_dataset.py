@@ -4,23 +4,31 @@ part of data/base_dataset.py:87-143,187-240,279-301).
 The volume is uploaded once as uint16/uint8 and every `__getitem__` cuts a fresh random crop ON THE GPU (the
 reference transforms the whole volume on the host for every iteration -- 1.67 s of its 3.64 s iteration).
 Random draws follow the reference's order: `random.randint` x3 for the crop origin (base_dataset.py:195-197), then
-`random.shuffle` + `np.random.uniform` x3 for the flips (:279-289).  `random3Drotate` (cv2 per-slice rotation,
-base_dataset.py:306-460) is a next-row item and raises."""
+`random.shuffle` + `np.random.uniform` x3 for the flips (:279-289).  `random3Drotate` / `random90rotate` (per-slice
+rotation + inscribed-rectangle crop of the whole volume, base_dataset.py:306-460) are folded into the crop: the
+rotation angle is drawn first (`random.randint(0, 359)` / `np.random.choice` of the six right angles), the crop origin
+is drawn against the shape the rotated volume would have, and nc_rotate_crop samples only the crop's voxels."""
 import os
 import random
 
 import numpy as np
 import torch
 
+from .._lib import I, P, check, lib
+from . import rotation
 from .diceImage_dataset import _load_volume
 
 
 class SingleVolumeDataset:
     def __init__(self, opt, volume=None):
         self.opt = opt
-        if 'random3Drotate' in opt.preprocess or 'random90rotate' in opt.preprocess:
-            raise NotImplementedError('rotation augmentation is outside the MI355X hot path (SURVEY.md 8f rank 1); '
-                                      'use --preprocess randomcrop_randomflip_addColorChannel_addBatchChannel')
+        self.rot3d = 'random3Drotate' in opt.preprocess
+        self.rot90 = 'random90rotate' in opt.preprocess
+        if self.rot3d and self.rot90:
+            raise NotImplementedError('random3Drotate and random90rotate together (two successive whole-volume '
+                                      'rotations) are not fused; use one of them')
+        if (self.rot3d or self.rot90) and 'randomcrop' not in opt.preprocess:
+            raise NotImplementedError('rotation augmentation is fused with randomcrop: add randomcrop to --preprocess')
         if volume is None:
             names = sorted(f for f in os.listdir(opt.dataroot) if f.endswith(('.npy', '.tif', '.tiff')))
             self.A_path = os.path.join(opt.dataroot, names[0])
@@ -33,21 +41,49 @@ class SingleVolumeDataset:
         self.device = torch.device('cuda', opt.gpu_ids[0])
         host = torch.from_numpy(volume.astype(np.int32))  # torch has no uint16 arithmetic
         self.volume = host.to(self.device)
+        # the rotation kernel reads the original integer type (as nc_dice_cut_cube does)
+        self.is_u16 = volume.dtype == np.uint16
+        self.raw = torch.from_numpy(np.ascontiguousarray(volume).view(np.uint8)).to(self.device) \
+            if (self.rot3d or self.rot90) else None
         self.isTrain = opt.isTrain
 
     def __len__(self):
         return 10  # singlevolume_dataset.py:55
 
+    def _rotated_crop(self):
+        """__randomrotate_clean_3D_xy / __random90rotate (base_dataset.py:144-151, 455-460) + __randomcrop (:187-206) +
+        __normalize (:134-143) in one kernel launch."""
+        D, H, W = self.volume.shape
+        angle = random.randint(0, 359) if self.rot3d else int(np.random.choice((-90, 90, -180, 180, -270, 270)))
+        inv, (x1, y1, x2, y2) = rotation.rotate_clean_plan(H, W, angle)
+        cz, cy, cx = self.opt.crop_size
+        if min(cz, cy, cx) < 1:
+            raise NotImplementedError('rotation augmentation needs a positive --crop_size on every axis')
+        rh, rw = y2 - y1, x2 - x1  # shape of the rotated, cleaned slices the reference would crop from
+        assert D - cz >= 0 and rh - cy >= 0 and rw - cx >= 0
+        z = random.randint(0, D - cz)
+        y = random.randint(0, rh - cy)
+        x = random.randint(0, rw - cx)
+        out = torch.empty((cz, cy, cx), dtype=torch.float32, device=self.device)
+        m = inv.ctypes.data_as(P)
+        check(lib().nc_rotate_crop(P(self.raw.data_ptr()), I(1 if self.is_u16 else 0), I(D), I(H), I(W), I(z), I(y1 + y),
+                                   I(x1 + x), I(cz), I(cy), I(cx), m, P(out.data_ptr()),
+                                   P(torch.cuda.current_stream().cuda_stream)), 'nc_rotate_crop')
+        return out
+
     def __getitem__(self, index):
         v = self.volume
-        if 'randomcrop' in self.opt.preprocess:
+        if self.rot3d or self.rot90:
+            a = self._rotated_crop()
+        elif 'randomcrop' in self.opt.preprocess:
             cz, cy, cx = self.opt.crop_size
             assert v.shape[0] >= cz and v.shape[1] >= cy and v.shape[2] >= cx
             z = random.randint(0, v.shape[0] - cz)
             y = random.randint(0, v.shape[1] - cy)
             x = random.randint(0, v.shape[2] - cx)
             v = v[z:z + cz if cz else None, y:y + cy if cy else None, x:x + cx if cx else None]
-        a = (v.to(torch.float64) / self.den).to(torch.float32)  # __normalize: float64 division, then .float()
+        if not (self.rot3d or self.rot90):
+            a = (v.to(torch.float64) / self.den).to(torch.float32)  # __normalize: float64 division, then .float()
         if 'randomflip' in self.opt.preprocess:
             axis_list = [0, 1, 2]
             random.shuffle(axis_list)
