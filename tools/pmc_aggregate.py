@@ -17,7 +17,7 @@ def kernel_class(name):
         return 'conv_mfma_k3'
     if 'k_conv_mfma<5' in name:
         return 'conv_mfma_k5'
-    if 'k_wgrad_mfma<3' in name or 'k_wgrad_dma<3' in name:
+    if 'k_wgrad_mfma<3' in name or 'k_wgrad_dma<3' in name or 'k_wgrad_rows<3' in name:
         return 'wgrad_mfma_k3'
     if 'k_wgrad_mfma<5' in name or 'k_wgrad_dma<5' in name:
         return 'wgrad_mfma_k5'
