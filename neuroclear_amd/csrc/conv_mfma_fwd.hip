@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
   // group is written by an ordinary 16-byte LDS store -- [tail values, zeros] -- from registers that thread
   // t (+ NT) loads for brick row t (+ NT) alongside the DMA; the store waits for the end of the unit.
   const int tw = p.W & 3, wfull = p.W - tw;
-  constexpr int TR = TAIL ? 2 : 0;  // row tails per thread (nrows <= 2 * NT)
+  constexpr int TR = TAIL ? (VB == 4 ? 1 : 2) : 0;  // row tails per thread (nrows <= TR * NT; VB = 4 has no spare registers)
   int tl_lofs[TR + 1], tl_gofs[TR + 1], tl_zy[TR + 1];
   float tl_v[TR + 1][3];
   if constexpr (TAIL) {
@@ -487,8 +487,8 @@ static bool plan_fwd(int KS, int Cin, int Cout, int N, int D, int H, int W, FwdP
         if (KS == 7 && CK != 1) continue;
         if (Cin % CK) continue;
         if (g.VB == 4 && CK > (KS == 3 ? 4 : 2)) continue;  // those instantiations spill
-        if (tail && (g.VB == 4 || CK == 1)) continue;         // tail kernels: VB <= 2 only (register room)
-        if (tail && CK * planes * (Ty + 2 * pad) > 2 * 64 * g.WM * g.WN) continue;  // <= 2 row tails per thread
+        if (tail && CK == 1) continue;
+        if (tail && CK * planes * (Ty + 2 * pad) > (g.VB == 4 ? 1 : 2) * 64 * g.WM * g.WN) continue;  // row tails per thread
         const long nelem = (long)CK * CP;
         // slack: garbage columns of the last blocks read up to maxpos + (KS-1)*(P+1) past the last plane's start
         const long slack = maxpos + (long)(KS - 1) * (P + 1) + 64;
@@ -535,7 +535,7 @@ static int launch_one_t(const FwdParams& p, int lds_bytes, hipStream_t s) {
 template <int KS, int CK, int WM, int WN, int VB>
 static int launch_one(const FwdParams& p, int lds_bytes, hipStream_t s) {
   if (p.W & 3) {
-    if constexpr (VB == 4 || CK == 1) {  // not instantiated: the planner keeps W % 4 != 0 off these
+    if constexpr (CK == 1 || (VB == 4 && CK == 8)) {  // not instantiated: the planner keeps W % 4 != 0 off these
       set_error("conv_mfma: no tail kernel for this configuration");
       return NC_ERR_SHAPE;
     } else {
