@@ -730,11 +730,20 @@ static bool plan_wgrad_rows(const ConvDims& d, WrPlan& pl) {
   if (bytes > kLdsMaxW || SX / 256 > 8 * kMaxRX || SD / 256 > 8 * kMaxRD) return false;
   pl.R = R; pl.Wg = Wg; pl.PRc = PRc; pl.PAc = PAc; pl.SX = SX; pl.SD = SD; pl.lds_bytes = (int)bytes;
   pl.G = KS * (d.C / 32) * (d.K / 64);
-  int parts = 256 / pl.G;
-  if (parts < 1) parts = 1;
+  // voxel partitions: one workgroup per CU (LDS), G * parts workgroups run in ceil(G * parts / 256) rounds of
+  // ceil(units / parts) steps -- e.g. G = 96 at 27^3: 2 parts leave a quarter of the CUs idle, 8 parts = 3 full rounds
   const long units = (long)d.N * d.D * ((d.H + R - 1) / R);
-  if (parts > units) parts = (int)units;
-  pl.parts = parts;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int parts = 1; parts <= 64 && parts <= units; ++parts) {
+    const double rounds = (double)cdiv((long)pl.G * parts, 256);
+    const double cost = rounds * ((double)cdiv(units, parts) + 2.0);  // + slab write / start-up per workgroup
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = parts;
+    }
+  }
+  pl.parts = best;
   return true;
 }
 
