@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void k_wgrad_c1(C1wParams p) {
   constexpr int NBW = NB / 2;                 // tap blocks per wave
   constexpr int RING = KS + 1;
   constexpr int PLS = 8;                      // row slots per ring entry (KS planes, padded to 8)
-  constexpr int MAXPD = 5;
+  constexpr int MAXPD = 6;  // = kC1wMaxPD
   extern __shared__ __attribute__((aligned(16))) float lds[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -301,12 +301,31 @@ __global__ void k_wgrad_c1_reduce(const float* __restrict__ slab, float* __restr
 
 static int c1w_nt16(int KS) { return ((KS * KS * KS + 31) / 32) * 32; }
 
-bool c1_wgrad_supported(const ConvDims& d) {
+static constexpr int kC1wMaxPD = 6;  // dY pieces per wave per step
+
+// geometry of k_wgrad_c1 for this shape; false if it does not fit (LDS, DMA pieces per wave)
+static bool c1w_plan(const ConvDims& d, C1wParams& p, int& lds_bytes) {
   if (d.C != 1 || d.K != 64 || d.kd != d.kh || d.kh != d.kw || (d.kd != 3 && d.kd != 7)) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.kd / 2 || d.pw != d.kd / 2) return false;
-  if (d.W % 4 || d.W > 240 || d.W < 16) return false;
+  if (d.W % 4 || d.W < 16) return false;
   if ((long)d.D * d.H * d.W * 64 >= (1L << 31)) return false;
-  return true;
+  p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.W16 = (d.W + 15) & ~15;
+  int pa = (p.W16 + 7) & ~7;
+  if (!(pa & 8)) pa += 8;  // = 8 (mod 16): conflict-free ds_read_b128
+  p.PAr = pa;
+  p.SD = (64 * p.PAr + 255) & ~255;
+  // X row: 4 halo columns + W16 + (KS - 1 + 3) columns of read-ahead, 8 rows per ring entry = whole 256-float pieces
+  p.PRx = (4 + p.W16 + d.kd + 2 + 31) & ~31;
+  const int RING = d.kd + 1;
+  lds_bytes = (RING * 8 * p.PRx + 2 * p.SD) * (int)sizeof(float);
+  return lds_bytes <= 160 * 1024 && p.SD / 256 <= 8 * kC1wMaxPD && 8 * p.PRx / 256 <= 8;
+}
+
+bool c1_wgrad_supported(const ConvDims& d) {
+  C1wParams p{};
+  int lds;
+  return c1w_plan(d, p, lds);
 }
 
 static int c1w_parts(const ConvDims& d) {
@@ -350,22 +369,13 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
     return NC_ERR_HIP;
   }
   C1wParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
-  p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
-  p.W16 = (d.W + 15) & ~15;
-  int pa = (p.W16 + 7) & ~7;
-  if (!(pa & 8)) pa += 8;  // = 8 (mod 16): conflict-free ds_read_b128
-  p.PAr = pa;
-  p.SD = (64 * p.PAr + 255) & ~255;
-  // X row: 4 halo columns + W16 + (KS - 1 + 3) columns of read-ahead, 8 rows per ring entry = whole 256-float pieces
-  p.PRx = (4 + p.W16 + d.kd + 2 + 31) & ~31;
-  p.parts = c1w_parts(d);
-  const int RING = d.kd + 1;
-  const int lds_bytes = (RING * 8 * p.PRx + 2 * p.SD) * (int)sizeof(float);
-  if (lds_bytes > 160 * 1024 || p.SD / 256 > 40 || 8 * p.PRx / 256 > 8) {
-    set_error("wgrad_c1: row too wide");
+  int lds_bytes = 0;
+  if (!c1w_plan(d, p, lds_bytes)) {
+    set_error("wgrad_c1: unsupported shape");
     return NC_ERR_SHAPE;
   }
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
+  p.parts = c1w_parts(d);
   const int e = d.kd == 7 ? launch_c1w<7>(p, lds_bytes, s) : launch_c1w<3>(p, lds_bytes, s);
   if (e) return e;
   const int taps = d.kd * d.kd * d.kd;

@@ -21,11 +21,15 @@ def _dot(a, b):
     return float((a.double() * b.double()).sum())
 
 
-@pytest.mark.parametrize('C,K,k,E', [(64, 64, 3, 108), (128, 64, 3, 108), (64, 64, 5, 108), (256, 128, 3, 54)])
-def test_conv_adjoint_identities(C, K, k, E):
-    """<conv(x, w), r> = <x, dgrad(r, w)> = <w, wgrad(x, r)>: the three kernels compute one bilinear form."""
+@pytest.mark.parametrize('C,K,k,E,N', [(64, 64, 3, 108, 1), (128, 64, 3, 108, 1), (64, 64, 5, 108, 1),
+                                       (256, 128, 3, 54, 1), (256, 256, 3, 27, 1), (1, 64, 7, 108, 1),
+                                       (64, 64, 3, 148, 2), (128, 128, 3, 74, 2), (64, 32, 1, 108, 1)])
+def test_conv_adjoint_identities(C, K, k, E, N):
+    """<conv(x, w), r> = <x, dgrad(r, w)> = <w, wgrad(x, r)>: the three kernels compute one bilinear form.  Sizes: the
+    108^3 / 54^3 / 27^3 levels of BASELINE configs[1], the single-channel 7^3 and pointwise layers of G_B, and the
+    148^3 / 74^3 levels of configs[3] with a batch of 2."""
     g = torch.Generator().manual_seed(1)
-    x = (torch.rand((1, C, E, E, E), generator=g) - 0.5).to(DEV)
+    x = (torch.rand((N, C, E, E, E), generator=g) - 0.5).to(DEV)
     w = ((torch.rand((K, C, k, k, k), generator=g) - 0.5) * 0.1).to(DEV)
     y = ops.conv_fwd_raw(x, w, None, 1, k // 2)
     r = (torch.rand(y.shape, generator=g) - 0.5).to(DEV)
@@ -80,3 +84,32 @@ def test_dice_identity_roundtrip_900():
     assert out.shape == vol.shape and out.dtype == np.uint16
     d = np.abs(out.astype(np.int32) - vol.astype(np.int32))
     assert int(d.max()) <= 1  # identity network: the reference's own round trip is within 1 LSB
+
+
+def test_apollo_step_148_batch2():
+    """BASELINE configs[3] shape class (148^3 crops, batch > 1) in fp32: one full optimisation step runs through
+    every kernel variant that a 148-wide, batched volume selects (two column blocks in k_wgrad_dma, 74 / 37-wide
+    levels with row tails), losses and every parameter update stay finite, and the batch really is processed (the
+    cycle loss of the batch lies between the per-sample cycle losses)."""
+    from neuroclear_amd.models import create_model
+    opt = Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t148',
+                    preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
+                    min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64,
+                    ndf=64, netG='unet_deconv', netG_B='deep_linear_gen', netD='basic', n_layers_D=3,
+                    norm='instance', no_dropout=True, init_type='kaiming', init_gain=0.02, lr=1e-4, beta1=0.1,
+                    direction='AtoB', model='axial_to_lateral_gan_apollo')
+    torch.manual_seed(11)
+    np.random.seed(12)
+    model = create_model(opt)
+    g = torch.Generator().manual_seed(13)
+    real = torch.rand((2, 1, 148, 148, 148), generator=g)
+    before = [p.detach().clone() for p in model.netG_A.parameters()]
+    model.set_input({'A': real, 'A_paths': 'x'})
+    model.optimize_parameters()
+    losses = model.get_current_losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    moved = [float((a.detach() - b).abs().max()) for a, b in zip(model.netG_A.parameters(), before)]
+    assert all(np.isfinite(m) for m in moved) and max(moved) > 0
+    with torch.no_grad():
+        per = [float((model.rec[i] - model.real[i]).abs().mean()) * 5.0 for i in range(2)]
+    assert min(per) - 1e-4 <= losses['cycle'] <= max(per) + 1e-4, (per, losses['cycle'])
