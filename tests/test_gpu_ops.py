@@ -207,3 +207,34 @@ def test_losses_and_adam():
         ops.adam_step(w, g, m, v, 1e-4, 0.1, 0.999, 1e-8, step)
     assert rel(w, wr.detach()) < 1e-6
     assert float((w - wr.detach()).abs().max()) < 1e-7
+
+
+def _sweep_cases():
+    """Seeded sweep over the shape space of nc_conv_*: every width class the planners distinguish (W % 4, W <= 56,
+    W > 56, W > 112, W > 192), channel counts on and off the MFMA grid, every kernel size the path dispatch knows."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    widths = [5, 8, 12, 16, 20, 27, 28, 36, 54, 57, 60, 70, 72, 108, 116, 130, 148, 196]
+    for i in range(44):
+        k, s, p = [(3, 1, 1), (3, 1, 1), (5, 1, 2), (7, 1, 3), (1, 1, 0), (4, 2, 1), (4, 1, 1)][int(rng.integers(0, 7))]
+        W = int(widths[int(rng.integers(0, len(widths)))])
+        if k == 4 and W < 8:
+            W = 8
+        C = int([1, 16, 32, 64, 128][int(rng.integers(0, 5))])
+        K = int([1, 32, 64, 64, 128][int(rng.integers(0, 5))])
+        if k == 7:
+            C, K = (1, 64) if rng.integers(0, 2) else (int(C), 64)
+        N = int(rng.integers(1, 3))
+        nd = 2 if (k == 4 and rng.integers(0, 2)) else 3
+        D = int(rng.integers(max(2, k), 7)) if k < 7 else int(rng.integers(7, 9))
+        H = int(rng.integers(max(3, k), 10)) if k < 7 else int(rng.integers(7, 10))
+        if C * K * k ** nd * W * D * H > 6e9:  # keep the torch reference quick
+            C, K = min(C, 32), min(K, 64)
+        sp = (D, H, W) if nd == 3 else (H * 3, W)
+        cases.append((N, C, K, sp, k, s, p))
+    return cases
+
+
+@pytest.mark.parametrize('case', _sweep_cases(), ids=lambda c: 'N%dC%dK%d_%s_k%ds%dp%d' % (c[0], c[1], c[2], 'x'.join(map(str, c[3])), c[4], c[5], c[6]))
+def test_conv_shape_sweep(case):
+    test_conv(case, False)
