@@ -113,3 +113,47 @@ def test_apollo_step_148_batch2():
     with torch.no_grad():
         per = [float((model.rec[i] - model.real[i]).abs().mean()) * 5.0 for i in range(2)]
     assert min(per) - 1e-4 <= losses['cycle'] <= max(per) + 1e-4, (per, losses['cycle'])
+
+
+def test_config0_diced_inference_256():
+    """BASELINE configs[0] on the product path: 256^3 volume, dice 64^3, overlap 8 (border_cut 8 -> 125 cubes of 80^3,
+    padded 288^3).  Every cube goes through the HIP network; the oracle checks (i) three cubes end to
+    end on the CPU (cut + normalise + Unet_deconv forward), (ii) the assembler: the oracle's overlap-add of the
+    product's own cube outputs must give the product's uint16 volume bit for bit."""
+    from neuroclear_amd.data.diceImage_dataset import DiceImageDataSet
+    from neuroclear_amd.util.assemble_dice import Assemble_Dice
+    from oracle import dice as odice
+    from oracle import nets as onets
+    vol = S.random_volume(7, 256)
+    R, ov, b = 64, 8, 8
+    opt = Namespace(dice_size=[R] * 3, overlap=ov, border_cut=b, gpu_ids=[0], skip_real=True, data_type='uint16',
+                    histogram_match=False, normalize_intensity=False)
+    sd_np = S.weights_from_seed(S.unet_deconv_spec(), 21)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict({k: torch.from_numpy(v).to(DEV) for k, v in sd_np.items()})
+    ds = DiceImageDataSet(opt, volume=vol)
+    assert ds.size() == (288, 288, 288) and ds.shape() == (5, 5, 5) and len(ds) == 125
+    asm = Assemble_Dice(opt, vol.shape)
+    outs = []
+    with torch.no_grad():
+        for i in range(len(ds)):
+            y = net(ds[i]['A'].unsqueeze(0))
+            outs.append(y.reshape(80, 80, 80).cpu().numpy())
+            asm.addToStack(dict(fake=y))
+    asm.assemble_all()
+    got = asm.getDict()['fake']
+    assert got.shape == vol.shape and got.dtype == np.uint16
+    # (i) three cubes against the CPU oracle
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    refl = odice.reflect_pad(padded, b)
+    sd_t = onets.to_torch(sd_np)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    for i in (0, 62, 124):
+        cube = odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b))
+        with torch.no_grad():
+            ref = onets.unet_deconv(sd_t, torch.from_numpy(cube)[None, None]).numpy()[0, 0]
+        assert float(np.abs(outs[i] - ref).max()) < 2e-5, i
+    # (ii) the oracle's assembler on the same cube values
+    ref_vol = odice.assemble(outs, padded.shape, vol.shape, R, ov, b, 'uint16')
+    assert np.array_equal(got, ref_vol)
