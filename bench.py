@@ -14,7 +14,8 @@ Extra objects on the JSON line:
                   MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s).
   cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32, all host cores) on a
                   bounded sample (one step on a smaller crop), rank 0 and N = 1 only.
-`--workload infer` benches BASELINE.json configs[2] instead (900^3 diced inference, cubes sharded over ranks).
+`--workload infer` benches BASELINE.json configs[2] instead (900^3 diced inference, cubes sharded over ranks);
+`--crop 148 --batch 4` is the shape of configs[3] (in fp32), `--model athena` the step of configs[4].
 """
 import argparse
 import json
@@ -52,8 +53,18 @@ def pmc_traffic(tag):
         return None
 
 
-def apollo_opt(gpu):
-    """The README training command (reference README.md:123-133) reduced to what the step uses."""
+def apollo_opt(gpu, model='apollo'):
+    """The README training command (reference README.md:123-133) reduced to what the step uses.  model='athena':
+    the artifact-correction variant of BASELINE configs[4] (--conversion_plane yz xy)."""
+    o = _apollo_opt(gpu)
+    if model == 'athena':
+        o.model = 'axial_to_lateral_gan_athena'
+        o.conversion_plane = ['yz', 'xy']
+        o.pool_size = 50
+    return o
+
+
+def _apollo_opt(gpu):
     return Namespace(gpu_ids=[gpu], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='bench',
                      preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
                      min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64,
@@ -95,12 +106,13 @@ def run_train(args, rank, world, dev):
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = create_model(apollo_opt(dev.index))
+        model = create_model(apollo_opt(dev.index, args.model))
     if world > 1:  # identical replicas: broadcast rank 0's parameters (one flat buffer per optimizer)
         for opt in model.optimizers:
             dist.broadcast(opt.flat, 0)
-    vol = S.random_volume(100 + rank, crop)  # synthetic uint16 crop, normalised as data/base_dataset.py:134-143
-    real = torch.from_numpy((vol.astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev)
+    # synthetic uint16 crops (one per batch element), normalised as data/base_dataset.py:134-143
+    vols = [S.random_volume(100 + rank + 1000 * b, crop) for b in range(args.batch)]
+    real = torch.stack([torch.from_numpy((v.astype(np.float64) / 65535.0).astype(np.float32))[None] for v in vols]).to(dev)
     data = {'A': real, 'A_paths': 'synthetic'}
 
     def step():
@@ -149,9 +161,9 @@ def run_train(args, rank, world, dev):
                                      tflops=round(s[2] / s[1] / 1e9, 2)) for t, s in sorted(stats.items())},
                     conv_ms_per_step=round(conv_ms / args.steps, 2))
     losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
-    return dt, crop ** 3 * args.steps * world, roof, dict(workload='apollo_train_step_%dcube_bs1' % crop, crop=crop,
-                                                           batch_size=1, parallelism='dp%d' % world,
-                                                           gan_mode='lsgan', norm='instance', losses=losses)
+    return dt, crop ** 3 * args.batch * args.steps * world, roof, dict(
+        workload='%s_train_step_%dcube_bs%d' % (args.model, crop, args.batch), crop=crop, batch_size=args.batch,
+        parallelism='dp%d' % world, gan_mode='lsgan', norm='instance', losses=losses)
 
 
 def run_infer(args, rank, world, dev):
@@ -195,6 +207,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='train', choices=['train', 'infer'])
     ap.add_argument('--crop', type=int, default=108)
+    ap.add_argument('--batch', type=int, default=1, help='crops per step and GPU (headline: 1; configs[3] shape: --crop 148 --batch 4)')
+    ap.add_argument('--model', default='apollo', choices=['apollo', 'athena'], help='athena = configs[4]')
     ap.add_argument('--volume', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP events (A/B runs)')
