@@ -280,7 +280,8 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
     const bool tile_ends = !more || ntile != tile;
     TileId tid_nxt = tid_cur;
     if (more && ntile != tile) tid_nxt = decode_tile(p, ntile);
-    // (staggering the two waves of a SIMD -- w stages at row 0, w+4 mid-unit -- was measured: no gain)
+    // (measured alternatives: staggering the two waves of a SIMD -- w stages at row 0, w+4 mid-unit -- no gain;
+    //  issuing one piece per kernel row instead of all eight here: 2 % slower)
     if (more && !(NC_ABLATE & 1)) stage_dma(tid_nxt, nchunk, nxt);
     const int next_aptr = more ? wbase(tid_nxt.cot, nchunk) : aptr;
 
