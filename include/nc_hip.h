@@ -128,6 +128,17 @@ int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P
 int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2,
                          int roi, int overlap, void* stream);
 
+/* ---- --normalize_intensity (util/assemble_dice.py:188-192): merged = (acc / count) * 8 on the padded volume;
+ *      nc_radix_hist = one pass of an exact radix select (order-preserving 32-bit key of a float: pass 0 bins key >> 20,
+ *      pass 1 bins (key >> 8) & 0xfff among key >> 20 == prefix, pass 2 bins key & 0xff among key >> 8 == prefix;
+ *      hist4096 is zeroed by the call) from which the host takes the order statistics np.percentile interpolates;
+ *      rescale_finalize = skimage.exposure.rescale_intensity(in_range=(lo, hi)) on a float32 image (clip to [lo, hi],
+ *      (v - lo) / range with range = float32(hi64 - lo64), output range (0, 1) or (-1, 1) if lo < 0) + cast + crop.     */
+int nc_assemble_merge(const float* acc, float* merged, int L0, int L1, int L2, int roi, int overlap, void* stream);
+int nc_radix_hist(const float* x, long n, int pass, unsigned prefix, unsigned* hist4096, void* stream);
+int nc_assemble_rescale_finalize(const float* merged, void* out, int out_is_u16, int L0, int L1, int L2, int roi,
+                                 int overlap, float lo, float hi, float range, void* stream);
+
 /* ---- Whole-network forward of Unet_deconv (networks.py:512-538; called from TestModel.forward test_model.py:60-62):
  *      params = the 28 tensors in state-dict order, packed back to back (see neuroclear_amd.models.networks).       */
 size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2);

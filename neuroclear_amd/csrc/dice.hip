@@ -106,6 +106,60 @@ __global__ void k_finalize(const float* __restrict__ acc, T* __restrict__ out, D
   }
 }
 
+// ---- intensity normalisation of the assembled volume (reference util/assemble_dice.py:188-192: np.percentile over the
+//      merged, still padded volume, then skimage.exposure.rescale_intensity(in_range=(p_lo, p_hi))).
+//      k_merge: merged = (acc / count) * 8 over the padded volume.  k_radix_hist: one pass of an exact radix select on
+//      the order-preserving integer key of a float (12 + 12 + 8 bits; the host picks the bucket between passes):
+//      workgroup-private LDS histogram, integer atomics only -- the counts, hence the selected order statistic, are
+//      exact and deterministic.  k_rescale_cast: clip to [lo, hi], (v - lo) / (hi - lo) mapped to [omin, 1], scale,
+//      truncating cast, crop of the dicing pad.
+__global__ void k_merge(const float* __restrict__ acc, float* __restrict__ out, DiceGeom g) {
+  const long total = (long)g.P0 * g.P1 * g.P2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % g.P2), y = (int)((i / g.P2) % g.P1), z = (int)(i / ((long)g.P2 * g.P1));
+    const float cnt = (float)(cover_count(z, g.n0, g.step, g.roi) * cover_count(y, g.n1, g.step, g.roi) *
+                              cover_count(x, g.n2, g.step, g.roi));
+    out[i] = (acc[i] / cnt) * 8;
+  }
+}
+
+__device__ __forceinline__ unsigned float_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// pass 0: bins = key >> 20 (4096); pass 1: (key >> 8) & 0xfff among keys with key >> 20 == prefix; pass 2: key & 0xff
+// among keys with key >> 8 == prefix
+__global__ void k_radix_hist(const float* __restrict__ x, long n, int pass, unsigned prefix, unsigned* __restrict__ hist) {
+  __shared__ unsigned h[4096];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned k = float_key(x[i]);
+    if (pass == 0) atomicAdd(&h[k >> 20], 1u);
+    else if (pass == 1) { if ((k >> 20) == prefix) atomicAdd(&h[(k >> 8) & 0xfffu], 1u); }
+    else { if ((k >> 8) == prefix) atomicAdd(&h[k & 0xffu], 1u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+template <typename T>
+__global__ void k_rescale_cast(const float* __restrict__ merged, T* __restrict__ out, DiceGeom g, float lo, float hi,
+                               float range, float omin, float scale) {
+  const long total = (long)g.L0 * g.L1 * g.L2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % g.L2), y = (int)((i / g.L2) % g.L1), z = (int)(i / ((long)g.L2 * g.L1));
+    float v = merged[((long)z * g.P1 + y) * g.P2 + x];
+    v = fminf(fmaxf(v, lo), hi);
+    v = (v - lo) / range;
+    v = v * (1.f - omin) + omin;
+    v = v * scale;
+    out[i] = (T)v;
+  }
+}
+
 static bool make_geom(DiceGeom& g, int L0, int L1, int L2, int roi, int overlap, int border) {
   if (L0 < 1 || L1 < 1 || L2 < 1 || roi < 1 || overlap < 0 || overlap >= roi || border < 1) return false;
   g.L0 = L0; g.L1 = L1; g.L2 = L2; g.roi = roi; g.overlap = overlap; g.border = border; g.step = roi - overlap;
@@ -199,6 +253,42 @@ int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, in
   else
     hipLaunchKernelGGL(k_finalize<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc, (uint8_t*)out, g, 255.f);
   return check_launch("assemble_finalize");
+}
+
+int nc_assemble_merge(const float* acc, float* merged, int L0, int L1, int L2, int roi, int overlap, void* stream) {
+  if (!acc || !merged) { set_error("assemble_merge: null pointer"); return NC_ERR_ARG; }
+  DiceGeom g;
+  if (overlap < 1 || !make_geom(g, L0, L1, L2, roi, overlap, 1)) { set_error("assemble_merge: bad geometry"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_merge, dim3(flat_grid((long)g.P0 * g.P1 * g.P2)), dim3(256), 0, (hipStream_t)stream, acc, merged, g);
+  return check_launch("assemble_merge");
+}
+
+int nc_radix_hist(const float* x, long n, int pass, unsigned prefix, unsigned* hist4096, void* stream) {
+  if (!x || !hist4096 || n < 1 || pass < 0 || pass > 2) { set_error("radix_hist: bad argument"); return NC_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(hist4096, 0, 4096 * sizeof(unsigned), s) != hipSuccess) { set_error("radix_hist: memset failed"); return NC_ERR_HIP; }
+  hipLaunchKernelGGL(k_radix_hist, dim3(flat_grid(n)), dim3(256), 0, s, x, n, pass, prefix, hist4096);
+  return check_launch("radix_hist");
+}
+
+int nc_assemble_rescale_finalize(const float* merged, void* out, int out_is_u16, int L0, int L1, int L2, int roi,
+                                 int overlap, float lo, float hi, float range, void* stream) {
+  if (!merged || !out) { set_error("assemble_rescale_finalize: null pointer"); return NC_ERR_ARG; }
+  DiceGeom g;
+  if (overlap < 1 || !make_geom(g, L0, L1, L2, roi, overlap, 1) || !(hi > lo) || !(range > 0.f)) {
+    set_error("assemble_rescale_finalize: bad geometry or empty intensity range");
+    return NC_ERR_SHAPE;
+  }
+  const float omin = lo >= 0.f ? 0.f : -1.f;  // skimage: float images map to (0, 1), or (-1, 1) if in_range[0] < 0
+  const long total = (long)L0 * L1 * L2;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_u16)
+    hipLaunchKernelGGL(k_rescale_cast<uint16_t>, dim3(flat_grid(total)), dim3(256), 0, s, merged, (uint16_t*)out, g, lo,
+                       hi, range, omin, 65535.f);
+  else
+    hipLaunchKernelGGL(k_rescale_cast<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, merged, (uint8_t*)out, g, lo, hi,
+                       range, omin, 255.f);
+  return check_launch("assemble_rescale_finalize");
 }
 
 }  // extern "C"

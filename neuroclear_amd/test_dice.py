@@ -84,6 +84,7 @@ def main(argv=None):
     p.add_argument('--no_dropout', action='store_true')
     p.add_argument('--histogram_match', action='store_true')
     p.add_argument('--normalize_intensity', action='store_true')
+    p.add_argument('--sat_level', type=float, nargs='+', default=[0.25, 99.75])
     p.add_argument('--verbose', action='store_true')
     opt = p.parse_args(argv)
     opt.gpu_ids = [int(g) for g in opt.gpu_ids.split(',') if int(g) >= 0]

@@ -4,7 +4,10 @@ Same interface -- Assemble_Dice(opt), addToStack(visuals), assemble_all(), getDi
 addToStack crops the border and overlap-adds cube/8 into a padded fp32 accumulator right away (nc_assemble_scatter_add,
 in arrival = index order, exactly the reference's summation order), assemble_all runs nc_assemble_finalize
 ((acc / count) * 8 * 65535, truncating cast, crop of the dicing pad) with the count computed analytically.
-`--histogram_match` / `--normalize_intensity` are scikit-image arithmetic (parity unpinned) and raise."""
+`--normalize_intensity` (:188-192) runs on the device too: exact percentiles of the merged, still padded volume by radix
+select (util/percentile.py restates np.percentile of the reference's numpy 1.21.2), then the arithmetic of
+skimage.exposure.rescale_intensity (0.18.3) on a float32 image -- third-party arithmetic restated from its source,
+parity unpinned (scikit-image is not installed here).  `--histogram_match` (skimage match_histograms per cube) raises."""
 from collections import OrderedDict
 
 import numpy as np
@@ -28,9 +31,11 @@ class Assemble_Dice:
         if self.overlap < 1:
             raise ValueError('overlap must be >= 1: the reference assembler adds nothing for overlap 0 '
                              '(util/assemble_dice.py:170) and returns an all-zero volume')
-        if getattr(opt, 'histogram_match', False) or getattr(opt, 'normalize_intensity', False):
-            raise NotImplementedError('--histogram_match / --normalize_intensity are third-party (scikit-image) '
+        if getattr(opt, 'histogram_match', False):
+            raise NotImplementedError('--histogram_match is third-party (scikit-image match_histograms) '
                                       'post-processing outside the pinned hot path (SURVEY.md 8c/8f)')
+        self.normalize_intensity = bool(getattr(opt, 'normalize_intensity', False))
+        self.p1, self.p99 = getattr(opt, 'sat_level', [0.25, 99.75])  # options/test_options.py:25
         self.step = self.roi_size - self.overlap
         self.image_size = util.padded_shape(self.image_size_original, self.roi_size, self.overlap)
         self.z_steps, self.y_steps, self.x_steps = util.grid_steps(self.image_size, self.roi_size, self.overlap)
@@ -88,11 +93,34 @@ class Assemble_Dice:
                 raise Exception('expected %d cubes for %s, got %d' % (self.len_cube_queue, name, self.count[name]))
             u16 = self.imtype == 'uint16'
             out = torch.empty((L0, L1, L2), dtype=torch.int16 if u16 else torch.uint8, device=self.device)
+            if self.normalize_intensity:
+                self._finalize_normalized(acc, out, u16)
+                host = out.cpu().numpy()
+                self.visual_ret[name] = host.view(np.uint16) if u16 else host
+                continue
             check(lib().nc_assemble_finalize(P(acc.data_ptr()), P(out.data_ptr()), I(1 if u16 else 0), I(P0), I(P1),
                                              I(P2), I(L0), I(L1), I(L2), I(self.roi_size), I(self.overlap),
                                              P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_finalize')
             host = out.cpu().numpy()
             self.visual_ret[name] = host.view(np.uint16) if u16 else host
+
+    def _finalize_normalized(self, acc, out, u16):
+        """util/assemble_dice.py:184-203 with --normalize_intensity: percentiles over the merged PADDED volume."""
+        from . import percentile as pct
+        L0, L1, L2 = self.image_size_original
+        stream = P(torch.cuda.current_stream().cuda_stream)
+        merged = torch.empty_like(acc)
+        check(lib().nc_assemble_merge(P(acc.data_ptr()), P(merged.data_ptr()), I(L0), I(L1), I(L2), I(self.roi_size),
+                                      I(self.overlap), stream), 'nc_assemble_merge')
+        p_lo, p_hi = pct.percentile(merged, (self.p1, self.p99))
+        if not p_hi > p_lo:
+            raise ValueError('normalize_intensity: empty intensity range (%g, %g)' % (p_lo, p_hi))
+        self.last_percentiles = (p_lo, p_hi)
+        from .._lib import F
+        check(lib().nc_assemble_rescale_finalize(P(merged.data_ptr()), P(out.data_ptr()), I(1 if u16 else 0), I(L0),
+                                                 I(L1), I(L2), I(self.roi_size), I(self.overlap),
+                                                 F(np.float32(p_lo)), F(np.float32(p_hi)), F(np.float32(p_hi - p_lo)),
+                                                 stream), 'nc_assemble_rescale_finalize')
 
     def getDict(self):
         return self.visual_ret

@@ -61,8 +61,39 @@ def normalize(cube):
     return (cube / den).astype(float).astype(np.float32)
 
 
-def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_type='uint16'):
-    """cubes: iterable of (R+2b)^3 float32 arrays in index order.  Returns the cropped uint8/uint16 volume."""
+def percentile_np121(a, q):
+    """np.percentile(a, q) (default linear method) of a float32 array with the arithmetic of numpy 1.21.2, the version
+    the reference pins (conda_environment/neuroclear_env.yml:155; numpy/lib/function_base.py _quantile_ureduce_func /
+    _lerp): index q/100 * (n-1) in float64, neighbours below / above, weight t; lerp = a + (b-a)*t, replaced by
+    b - (b-a)*(1-t) where t >= 0.5; (b - a) is a float32 subtraction, everything else float64.  (numpy >= 2 keeps
+    float32 throughout, which is why this is a restatement and not a call.)  PARITY UNPINNED against 1.21.2 itself;
+    tests pin the selection / interpolation logic against the installed numpy on float64 data, where both agree."""
+    s = np.sort(np.asarray(a).ravel())
+    n = s.size
+    h = (q / 100.0) * (n - 1)
+    lo = int(np.floor(h))
+    hi = min(lo + 1, n - 1)
+    t = h - lo
+    A, B = s[lo], s[hi]
+    d = np.float64(B - A)  # B - A in the array's own precision
+    return float(np.float64(B) - d * (1.0 - t)) if t >= 0.5 else float(np.float64(A) + d * t)
+
+
+def rescale_intensity_f32(image, imin, imax):
+    """skimage.exposure.rescale_intensity(image, in_range=(imin, imax)) for a float32 image, restated from scikit-image
+    0.18.3 (skimage/exposure/exposure.py; the version pinned at neuroclear_env.yml:203): out_range 'dtype' of a float
+    image is (0, 1) when imin >= 0, else (-1, 1); clip, (image - imin) / (imax - imin), * (omax - omin) + omin, with the
+    python-float scalars cast to the array's float32 (numpy 1.x value-based casting).  PARITY UNPINNED (not installed)."""
+    imin, imax = float(imin), float(imax)
+    omin, omax = (0.0, 1.0) if imin >= 0 else (-1.0, 1.0)
+    image = np.clip(image, np.float32(imin), np.float32(imax))
+    image = (image - np.float32(imin)) / np.float32(imax - imin)
+    return (image * np.float32(omax - omin) + np.float32(omin)).astype(np.float32)
+
+
+def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_type='uint16', normalize=None):
+    """cubes: iterable of (R+2b)^3 float32 arrays in index order.  Returns the cropped uint8/uint16 volume.
+    normalize = (p_lo, p_hi) percent: --normalize_intensity with --sat_level (util/assemble_dice.py:188-192)."""
     if border < 1:
         raise ValueError('border_cut must be >= 1 (reference slices [b:-b]; b=0 yields an empty cube)')
     steps = grid_steps(padded_shape, roi, overlap)
@@ -82,6 +113,9 @@ def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_typ
     assert n == steps[0] * steps[1] * steps[2]
     if overlap > 0:
         acc = (acc / cnt) * 8
+    if normalize is not None:
+        p1_, p99_ = percentile_np121(acc, normalize[0]), percentile_np121(acc, normalize[1])
+        acc = rescale_intensity_f32(acc, p1_, p99_)
     if data_type == 'uint8':
         acc *= 255
         acc = acc.astype(np.uint8)
