@@ -139,6 +139,21 @@ int nc_radix_hist(const float* x, long n, int pass, unsigned prefix, unsigned* h
 int nc_assemble_rescale_finalize(const float* merged, void* out, int out_is_u16, int L0, int L1, int L2, int roi,
                                  int overlap, float lo, float hi, float range, void* stream);
 
+/* ---- Whole-network PatchGAN (NLayerDiscriminator with InstanceNorm, networks.py:1009-1067; called from
+ *      apollo_model.py:195-283 through netD_*): forward and backward as ONE call each (the op-by-op path is
+ *      host-enqueue-bound on these ~25-kernel chains).  params = the 2 * (n_layers + 2) tensors in state-dict order,
+ *      packed; saved = activations / raw conv outputs / InstanceNorm statistics for the backward
+ *      (nc_patchgan_saved_floats); nd = 2 (x is [B,1,H,W], pass D = 1) or 3.  bwd: dx and dparams may be NULL;
+ *      dparams is overwritten (not accumulated).                                                                    */
+size_t nc_patchgan_param_floats(int n_layers, int ndf, int nd);
+size_t nc_patchgan_saved_floats(int B, int D, int H, int W, int n_layers, int ndf, int nd);
+size_t nc_patchgan_ws_bytes(int B, int D, int H, int W, int n_layers, int ndf, int nd);
+int nc_patchgan_out_shape(int B, int D, int H, int W, int n_layers, int ndf, int nd, int* oD, int* oH, int* oW);
+int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved, int B, int D, int H, int W,
+                    int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
+int nc_patchgan_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
+                    int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Whole-network forward of Unet_deconv (networks.py:512-538; called from TestModel.forward test_model.py:60-62):
  *      params = the 28 tensors in state-dict order, packed back to back (see neuroclear_amd.models.networks).       */
 size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2);

@@ -1,0 +1,198 @@
+// Whole-network entry points for the PatchGAN discriminator (reference models/networks.py:1009-1067,
+// NLayerDiscriminator with InstanceNorm: conv k4 s2 + LeakyReLU, (conv k4 s2 + IN + LeakyReLU) x (n_layers - 1),
+// conv k4 s1 + IN + LeakyReLU, conv k4 s1 -> 1 channel; every conv biased), 2-D or 3-D.
+//
+// Why: a discriminator pass on a handful of 108^2 planes is ~25 kernels of 5-40 us.  Driven op by op from Python the
+// host needs 30-80 us per launch, so the four discriminator chains of the generator loss were enqueue-bound (the GPU
+// sat idle between a chain's forward and its backward).  One C call per forward and one per backward launches the same
+// kernels back to back.  Same kernels, same order, same numbers as the op-by-op path.
+//
+// Parameter blob = the 2 * (n_layers + 2) tensors in state-dict order (model.0.weight, model.0.bias, model.2.weight,
+// ...), packed back to back.  `saved` (nc_patchgan_saved_floats) receives what the backward needs: every conv's raw
+// output, every activation, the InstanceNorm statistics.
+#include "common.hpp"
+
+using namespace nc;
+
+namespace {
+
+struct PgLayer {
+  int C, K, stride;   // channels in / out, stride
+  int iD, iH, iW;     // input spatial size (iD = 1 for 2-D)
+  int oD, oH, oW;
+  bool norm;          // InstanceNorm + LeakyReLU after the conv (else: LeakyReLU only for layer 0, nothing for the head)
+  size_t w_off, b_off;        // floats into the parameter blob
+  size_t raw_off, act_off;    // floats into `saved`: raw conv output; activation that feeds the NEXT conv
+  size_t stat_off;            // mean [B*K] then rstd [B*K]
+};
+
+struct PgPlan {
+  int nl;            // number of convs = n_layers + 2
+  PgLayer L[8];
+  size_t params, saved;       // floats
+  size_t max_act;             // largest per-layer tensor (floats), for the gradient ping-pong buffers
+  size_t conv_ws, in_ws;      // bytes
+  int oD, oH, oW;
+};
+
+bool pg_plan(PgPlan& P, int B, int D, int H, int W, int n_layers, int ndf, int nd) {
+  if (B < 1 || H < 4 || W < 4 || n_layers < 1 || n_layers > 6 || ndf < 1 || (nd != 2 && nd != 3)) return false;
+  if (nd == 2 && D != 1) return false;
+  if (nd == 3 && D < 4) return false;
+  P = PgPlan{};
+  P.nl = n_layers + 2;
+  int cin = 1, mult = 1;
+  int d = D, h = H, w = W;
+  size_t po = 0, so = 0;
+  const int k3 = nd == 3 ? 64 : 16;
+  for (int i = 0; i < P.nl; ++i) {
+    PgLayer& l = P.L[i];
+    const bool head = i == P.nl - 1;
+    if (i == 0) mult = 1;
+    else if (!head) mult = (1 << i) < 8 ? (1 << i) : 8;
+    l.C = cin;
+    l.K = head ? 1 : ndf * mult;
+    l.stride = (i < n_layers) ? 2 : 1;
+    l.norm = i > 0 && !head;
+    l.iD = d; l.iH = h; l.iW = w;
+    ConvDims cd;
+    if (!make_dims(cd, B, l.C, d, h, w, l.K, nd == 3 ? 4 : 1, 4, 4, l.stride, 1)) return false;
+    l.oD = cd.Do; l.oH = cd.Ho; l.oW = cd.Wo;
+    l.w_off = po; po += (size_t)l.K * l.C * k3;
+    l.b_off = po; po += (size_t)l.K;
+    const size_t on = (size_t)B * l.K * l.oD * l.oH * l.oW;
+    l.raw_off = so; so += on;
+    l.act_off = so;
+    if (!head) so += on;
+    l.stat_off = so;
+    if (l.norm) so += 2 * (size_t)B * l.K;
+    if (on > P.max_act) P.max_act = on;
+    const size_t in_n = (size_t)B * l.C * d * h * w;
+    if (in_n > P.max_act) P.max_act = in_n;
+    const size_t cw = nc_conv_ws_bytes(B, l.C, d, h, w, l.K, nd == 3 ? 4 : 1, 4, 4, l.stride, 1);
+    if (cw > P.conv_ws) P.conv_ws = cw;
+    if (l.norm) {
+      const size_t iw = nc_instnorm_ws_bytes(B * l.K, (long)l.oD * l.oH * l.oW);
+      if (iw > P.in_ws) P.in_ws = iw;
+    }
+    cin = l.K; d = l.oD; h = l.oH; w = l.oW;
+  }
+  P.params = po; P.saved = so;
+  P.oD = d; P.oH = h; P.oW = w;
+  return true;
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+#define NC_TRY(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
+
+extern "C" {
+
+size_t nc_patchgan_param_floats(int n_layers, int ndf, int nd) {
+  PgPlan P;
+  return pg_plan(P, 1, nd == 3 ? 64 : 1, 64, 64, n_layers, ndf, nd) ? P.params : 0;
+}
+
+size_t nc_patchgan_saved_floats(int B, int D, int H, int W, int n_layers, int ndf, int nd) {
+  PgPlan P;
+  return pg_plan(P, B, D, H, W, n_layers, ndf, nd) ? P.saved : 0;
+}
+
+// scratch for fwd and bwd: conv workspace + InstanceNorm workspace + two gradient ping-pong buffers
+size_t nc_patchgan_ws_bytes(int B, int D, int H, int W, int n_layers, int ndf, int nd) {
+  PgPlan P;
+  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) return 0;
+  return align256(P.conv_ws) + align256(P.in_ws) + 2 * align256(P.max_act * sizeof(float)) + 256;
+}
+
+int nc_patchgan_out_shape(int B, int D, int H, int W, int n_layers, int ndf, int nd, int* oD, int* oH, int* oW) {
+  PgPlan P;
+  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan: bad shape"); return NC_ERR_SHAPE; }
+  *oD = P.oD; *oH = P.oH; *oW = P.oW;
+  return NC_OK;
+}
+
+int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved, int B, int D, int H, int W,
+                    int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved) { set_error("patchgan_fwd: null pointer"); return NC_ERR_ARG; }
+  PgPlan P;
+  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_patchgan_ws_bytes(B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: workspace too small"); return NC_ERR_WS; }
+  void* cws = ws;
+  void* iws = (char*)ws + align256(P.conv_ws);
+  const int kd = nd == 3 ? 4 : 1;
+  const float* in = x;
+  for (int i = 0; i < P.nl; ++i) {
+    const PgLayer& l = P.L[i];
+    const bool head = i == P.nl - 1;
+    float* raw = head ? y : saved + l.raw_off;
+    NC_TRY(nc_conv_fwd(in, params + l.w_off, params + l.b_off, raw, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1,
+                       cws, P.conv_ws, stream));
+    if (head) {
+      // keep a copy of the head's raw output slot unused: y is the output
+      break;
+    }
+    const long S = (long)l.oD * l.oH * l.oW;
+    float* act = saved + l.act_off;
+    if (l.norm) {
+      float* mean = saved + l.stat_off;
+      float* rstd = mean + (size_t)B * l.K;
+      NC_TRY(nc_instnorm_stats(raw, B * l.K, S, 1e-5f, mean, rstd, iws, P.in_ws, stream));
+      NC_TRY(nc_instnorm_act_fwd(raw, mean, rstd, 0.2f, act, B * l.K, S, stream));
+    } else {
+      NC_TRY(nc_leaky_relu_fwd(raw, 0.2f, act, (long)B * l.K * S, stream));
+    }
+    in = act;
+  }
+  return NC_OK;
+}
+
+// dparams (nullable): packed like params, OVERWRITTEN with this call's parameter gradients.  dx (nullable): gradient
+// with respect to the input planes.
+int nc_patchgan_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
+                    int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !saved || !dy) { set_error("patchgan_bwd: null pointer"); return NC_ERR_ARG; }
+  PgPlan P;
+  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_patchgan_ws_bytes(B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: workspace too small"); return NC_ERR_WS; }
+  void* cws = ws;
+  void* iws = (char*)ws + align256(P.conv_ws);
+  float* ga = (float*)((char*)iws + align256(P.in_ws));
+  float* gb = (float*)((char*)ga + align256(P.max_act * sizeof(float)));
+  const int kd = nd == 3 ? 4 : 1;
+  const float* g = dy;  // gradient with respect to the current layer's raw conv output
+  for (int i = P.nl - 1; i >= 0; --i) {
+    const PgLayer& l = P.L[i];
+    const float* in = i == 0 ? x : saved + P.L[i - 1].act_off;
+    if (dparams)
+      NC_TRY(nc_conv_wgrad(in, g, dparams + l.w_off, dparams + l.b_off, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride,
+                           1, cws, P.conv_ws, stream));
+    if (i == 0) {
+      if (dx) NC_TRY(nc_conv_dgrad(g, params + l.w_off, dx, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1, cws,
+                                   P.conv_ws, stream));
+      break;
+    }
+    // gradient with respect to this conv's input = the previous layer's activation ...
+    float* gin = (g == ga) ? gb : ga;
+    NC_TRY(nc_conv_dgrad(g, params + l.w_off, gin, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1, cws, P.conv_ws,
+                         stream));
+    // ... pulled back through that layer's activation (and InstanceNorm) to its raw conv output
+    const PgLayer& pl = P.L[i - 1];
+    const long S = (long)pl.oD * pl.oH * pl.oW;
+    float* graw = (gin == ga) ? gb : ga;
+    const float* praw = saved + pl.raw_off;
+    if (pl.norm) {
+      const float* mean = saved + pl.stat_off;
+      const float* rstd = mean + (size_t)B * pl.K;
+      NC_TRY(nc_instnorm_act_bwd(gin, praw, mean, rstd, 0.2f, graw, B * pl.K, S, iws, P.in_ws, stream));
+    } else {
+      NC_TRY(nc_leaky_relu_bwd(gin, praw, 0.2f, graw, (long)B * pl.K * S, stream));
+    }
+    g = graw;
+  }
+  return NC_OK;
+}
+
+}  // extern "C"

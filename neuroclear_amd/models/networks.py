@@ -10,6 +10,7 @@ resnet, VGG, linear kernels, spectral-norm D, ...) raise NotImplementedError exa
 the reference (:196, :246).
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -338,8 +339,15 @@ class NLayerDiscriminator(nn.Module):
         seq += [norm_layer(ndf * nf_mult, 0.2), FusedActivation()] if norm_layer else [Identity(), LeakyReLU(0.2)]
         seq += [Conv(ndf * nf_mult, 1, kw, 1, padw, dimension=dimension)]
         self.model = nn.Sequential(*seq)
+        # one C call per direction (nc_patchgan_fwd / _bwd) instead of ~25 Python-driven launches: the discriminator
+        # chains are host-enqueue-bound otherwise.  Same kernels in the same order; NC_FUSED_PATCHGAN=0 or an
+        # architecture the entry point does not cover (no norm, other input channels) takes the op-by-op path.
+        self._cfg = (n_layers, ndf, dimension)
+        self._fusable = norm_layer is not None and input_nc == 1 and 1 <= n_layers <= 6
 
     def forward(self, input):
+        if self._fusable and input.is_cuda and os.environ.get('NC_FUSED_PATCHGAN', '1') != '0':
+            return ops.patchgan(input, list(self.parameters()), *self._cfg)
         return self.model(input)
 
 

@@ -545,3 +545,84 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
 
 def set_force_direct(on):
     lib().nc_set_force_direct(I(1 if on else 0))
+
+
+# ---- whole-network PatchGAN (nc_patchgan_fwd / nc_patchgan_bwd): one C call per direction -------------------------
+def _pack_params(params):
+    """The parameter tensors as ONE flat fp32 tensor in the given order: a zero-copy view when they already sit back
+    to back in one storage (FlatAdam's flat buffer), otherwise a concatenated copy."""
+    p0 = params[0]
+    off = p0.storage_offset()
+    same = True
+    for p in params:
+        if (not p.is_contiguous()) or p.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr() or \
+                p.storage_offset() != off:
+            same = False
+            break
+        off += p.numel()
+    total = sum(p.numel() for p in params)
+    if same:
+        return p0.detach().as_strided((total,), (1,), p0.storage_offset())
+    return torch.cat([p.detach().reshape(-1) for p in params])
+
+
+class _PatchGAN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        n_layers, ndf, nd = cfg
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        if x.shape[1] != 1:
+            raise _lib.NcError('fused PatchGAN expects one input channel')
+        B = x.shape[0]
+        D, H, W = (1, x.shape[2], x.shape[3]) if nd == 2 else tuple(x.shape[2:])
+        L = lib()
+        packed = _pack_params(params)
+        if packed.numel() != L.nc_patchgan_param_floats(I(n_layers), I(ndf), I(nd)):
+            raise _lib.NcError('fused PatchGAN: parameter count does not match (n_layers=%d, ndf=%d)' % (n_layers, ndf))
+        od, oh, ow = I(0), I(0), I(0)
+        import ctypes
+        check(L.nc_patchgan_out_shape(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd), ctypes.byref(od),
+                                      ctypes.byref(oh), ctypes.byref(ow)), 'nc_patchgan_out_shape')
+        oshape = (B, 1, oh.value, ow.value) if nd == 2 else (B, 1, od.value, oh.value, ow.value)
+        y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        saved = torch.empty(L.nc_patchgan_saved_floats(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)),
+                            dtype=torch.float32, device=x.device)
+        ws = workspace(L.nc_patchgan_ws_bytes(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
+        check(L.nc_patchgan_fwd(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), I(B), I(D), I(H), I(W), I(n_layers), I(ndf),
+                                I(nd), _ptr(ws), Z(ws.numel()), _stream()), 'nc_patchgan_fwd')
+        ctx.save_for_backward(x, saved)
+        ctx.packed = packed
+        ctx.cfg = (cfg, (B, D, H, W), [tuple(p.shape) for p in params])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved = ctx.saved_tensors
+        (n_layers, ndf, nd), (B, D, H, W), shapes = ctx.cfg
+        dy = dy.contiguous()
+        want_x = ctx.needs_input_grad[0]
+        want_p = any(ctx.needs_input_grad[2:])
+        dx = torch.empty_like(x) if want_x else None
+        dpar = torch.empty_like(ctx.packed) if want_p else None
+        L = lib()
+        ws = workspace(L.nc_patchgan_ws_bytes(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
+        check(L.nc_patchgan_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(B), I(D), I(H),
+                                I(W), I(n_layers), I(ndf), I(nd), _ptr(ws), Z(ws.numel()), _stream()), 'nc_patchgan_bwd')
+        grads = [None] * len(shapes)
+        if want_p:
+            off = 0
+            for i, shp in enumerate(shapes):
+                n = 1
+                for s in shp:
+                    n *= s
+                if ctx.needs_input_grad[2 + i]:
+                    grads[i] = dpar[off:off + n].view(shp)
+                off += n
+        return (dx, None) + tuple(grads)
+
+
+def patchgan(x, params, n_layers, ndf, dimension):
+    """NLayerDiscriminator.forward (networks.py:1063-1066) with InstanceNorm, as one C call (and one for backward)."""
+    return _PatchGAN.apply(x, (int(n_layers), int(ndf), int(dimension)), *params)

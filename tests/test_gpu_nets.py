@@ -383,3 +383,37 @@ def test_dryops_step(golden_dir, tag):
         upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(ps, before[n])])
         sel = np.array([a.dim() > 1 for a in ps])
         np.testing.assert_allclose(upd[sel], g['upd_' + n][sel], rtol=5e-2, err_msg=n)
+
+
+@pytest.mark.parametrize('dim,shape,nl', [(2, (3, 1, 36, 36), 3), (2, (1, 1, 108, 108), 3), (3, (1, 1, 36, 36, 36), 3),
+                                          (2, (2, 1, 72, 72), 4), (2, (1, 1, 20, 20), 2)])
+def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
+    """nc_patchgan_fwd / nc_patchgan_bwd (one C call per direction) against the op-by-op path of the same module:
+    same kernels in the same order, so outputs and gradients agree to rounding of the accumulation order only."""
+    net = load(networks.define_D(1, 64, 'n_layers', nl, 'instance', 'kaiming', 0.02, False, [0], dimension=dim),
+               S.patchgan_spec(dim, n_layers=nl), 31)
+    x = torch.from_numpy(rnd(41, shape)).to(DEV)
+    r = None
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('NC_FUSED_PATCHGAN', mode)
+        net.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        if r is None:
+            r = torch.from_numpy(rnd(42, y.shape)).to(DEV)
+        (y * r).mean().backward()
+        res[mode] = (y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in net.parameters()])
+    ya, xa, pa = res['1']
+    yb, xb, pb = res['0']
+    assert torch.equal(ya, yb)
+    assert torch.equal(xa, xb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    # frozen parameters (generator phase): input gradient only
+    monkeypatch.setenv('NC_FUSED_PATCHGAN', '1')
+    for p in net.parameters():
+        p.requires_grad_(False)
+    xi = x.clone().requires_grad_(True)
+    (net(xi) * r).mean().backward()
+    assert torch.equal(xi.grad, xa)
