@@ -13,13 +13,14 @@
 //     column block is 32 consecutive floats -> ds_read_b32, conflict-free for any alignment.  Output positions that
 //     fall on the 2p pad columns are computed and discarded (<= 2p/P waste) -- this is what makes 108/140/54/27-wide
 //     volumes tile without 32-alignment.
-//   * staging by ROWS: global -> registers (issued BEFORE the MFMA loop of the current unit) -> LDS (after it); a wave
-//     copies whole rows, lane = column, so the (channel, plane, row) decode and the row base are wave-uniform.
+//   * staging by LDS-DMA: the brick of the next unit goes global -> LDS directly (16 bytes per lane, per-lane source
+//     address, zero page for padding) while the current unit is multiplied; see the comment at stage_dma.
 //   * STREAM-K over (tile, channel-chunk) units: 256 persistent workgroups (one per CU) each take an equal, contiguous
 //     share of all units, so the wave of equal tiles that does not divide by the CU count (1296 tiles = 5.06 rounds at
 //     108^3) no longer costs a whole extra round.  A tile whose chunks are split between two workgroups is written
 //     as partial accumulators to a workspace slot and summed in chunk order by a fix-up kernel (deterministic, no
-//     atomics); complete tiles are stored directly.
+//     atomics); complete tiles are stored directly.  (Measured alternative: tiles / 256 whole tiles per workgroup
+//     and only the leftover tiles split -- half the partial traffic, but 0.2 % slower end to end.)
 //   * epilogue: accumulator rows are co, lanes are voxels -> each store instruction writes 2 x 128 B contiguous.
 #include "common.hpp"
 
