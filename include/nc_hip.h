@@ -51,6 +51,23 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
 int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */, int N, int C, int D, int H,
                   int W, int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- The same convolution on the 16-bit matrix cores (BASELINE.json configs[3]: "fp16 MFMA path with fp32
+ *      InstanceNorm accumulate").  Tensors and master weights stay fp32 at this boundary; inside, operands are rounded
+ *      (round-to-nearest-even) to `dtype` (NC_DT_BF16: v_mfma_f32_32x32x16_bf16, NC_DT_F16: ..._f16), products are
+ *      accumulated in fp32 and the result is written in fp32.  Covers odd cubic kernels 3^3 / 5^3, stride 1, "same"
+ *      padding with C % 16 == 0 and K % 64 == 0 (fwd), K % 16 == 0 and C % 64 == 0 (dgrad) -- every 3^3 layer of
+ *      unet_deconv except the first, G_B's feature block; nc_conv_lp_supported tells (what: 0 fwd, 1 dgrad, 2 wgrad);
+ *      unsupported shapes return NC_ERR_SHAPE (callers use nc_conv_* for those -- there is no silent fallback).       */
+#define NC_DT_F32 0
+#define NC_DT_F16 1
+#define NC_DT_BF16 2
+int nc_conv_lp_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
+size_t nc_conv_lp_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
+int nc_conv_fwd_lp(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
+                   int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_dgrad_lp(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd,
+                     int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- ConvTranspose3d(k=2, s=2) (networks.py:500,503): x[N,C,D,H,W], w[C,K,2,2,2], bias[K], y[N,K,2D,2H,2W].   */
 size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K);
 int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,

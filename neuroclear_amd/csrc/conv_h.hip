@@ -1,0 +1,426 @@
+// 16-bit (bf16 / fp16) MFMA Conv3d, odd cubic kernel, stride 1, "same" padding: forward and dgrad.
+// BASELINE.json configs[3] ("fp16 MFMA path with fp32 InstanceNorm accumulate"): the convolutions of the U-Net
+// (models/networks.py:420-425,460-469) and of G_B's feature block (:900-902) multiply 16-bit operands on
+// v_mfma_f32_32x32x16_{bf16,f16} (32 cycles per 32768 FLOP per SIMD, 16x the fp32 matrix rate) and accumulate in fp32;
+// everything between two convolutions (InstanceNorm statistics and normalisation, ReLU, pooling, losses, Adam, the
+// master weights) stays fp32.
+//
+// Layout.  The 16-bit operand tensor is "C8": [N][C/8][D][H][W][8 channels] -- one voxel's 8 channels are one 16-byte
+// unit.  k_to_c8 converts an fp32 NCDHW tensor (coalesced along W per channel, one 16-byte store per voxel).
+//   * One MFMA k-step (k = 16) is 16 input channels at ONE tap: lane (r, h) holds channels 8h..8h+7 of voxel r, i.e.
+//     one unit -> ds_read_b128, conflict-free (16 consecutive lanes read 256 contiguous bytes).
+//   * A tap (dy, dx) is a constant LDS offset (dy * P + dx) units because rows are flattened with pitch P = W + 2p
+//     (the same trick as the fp32 kernel, conv_mfma_fwd.hip): positions on the 2p pad columns are computed and
+//     discarded (1.3 % at W = 148).
+//   * LDS-DMA moves one unit per lane with a per-lane source address: x-padding, out-of-volume rows and the tail of
+//     the last piece come from a zero page -- no alignment cases, no zero-fill pass, any W.
+// Stage = (16-channel chunk, dz): the (rows + 2p) x P units of ONE input plane for both 8-channel halves, plus the
+// KS*KS x 64 x 16 packed weights of that (chunk, dz) -- weights go through LDS too, so that a wave's only vector-memory
+// traffic is DMA and its only vmcnt wait sits at the stage barrier (a weight load issued behind a DMA would have to
+// wait for the DMA: vmcnt retires in order).  Two stage buffers; the DMA of stage s+1 flies under the MFMAs of s.
+// Tile = 64 output channels x PT flattened positions of one output plane; 8 waves x (2 x VB) accumulator tiles.
+// Persistent workgroups walk XCD-contiguous tile ranges (neighbouring planes share input planes in that XCD's L2).
+#include "common.hpp"
+
+namespace nc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+static constexpr int kWaves = 8;
+static constexpr int kThreads = kWaves * 64;
+static constexpr int kLdsMaxH = 160 * 1024;
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
+unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(const i32x4& a, const i32x4& b, const f32x16& c) {
+  if constexpr (DT == NC_DT_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__device__ __forceinline__ unsigned short cvt16(float f) {
+  if constexpr (DT == NC_DT_F16) {
+    const _Float16 v = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  } else {
+    const __bf16 v = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 NCDHW -> 16-bit C8.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, one 16-byte store.
+template <int DT>
+__global__ void __launch_bounds__(256) k_to_c8(const float* __restrict__ x, uint4* __restrict__ out, long S, int C) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const long ncb = blockIdx.y;  // n * (C/8) + cb
+  const float* xs = x + ncb * 8 * S + v;
+  unsigned short e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = cvt16<DT>(xs[j * S]);
+  uint4 o;
+  o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+  o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+  out[ncb * S + v] = o;
+}
+
+// Packed weights: [cot = co/64][chunk = ci/16][dz][t = dy*KS+dx][a = (co/32)%2][h][r = co%32][8] 16-bit, element j =
+// input channel chunk*16 + 8h + j.  The weights of one stage (cot, chunk, dz) are KS*KS * 2 KiB contiguous; a lane's A
+// fragment is one 16-byte unit and the 32 lanes of a half read 512 contiguous bytes.
+// fwd:   wp(co, ci, tap) = w[co][ci][tap]                       (so = C*T, si = T, flip = 0)
+// dgrad: wp(ci as "co", co as "ci", tap) = w[co][ci][T-1-tap]    (so = T,   si = C*T, flip = 1)
+template <int DT>
+__global__ void __launch_bounds__(256) k_pack_w_h(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH,
+                                                  int T3, long so, long si, int flip, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int r = (int)(q & 31); q >>= 5;
+  const int h = (int)(q & 1); q >>= 1;
+  const int a = (int)(q & 1); q >>= 1;
+  const int tap = (int)(q % T3); q /= T3;  // dz * KS*KS + t
+  const int chunk = (int)(q % NCH);
+  const int cot = (int)(q / NCH);
+  const long co = cot * 64 + a * 32 + r, ci = chunk * 16 + 8 * h + j;
+  const int tp = flip ? T3 - 1 - tap : tap;
+  wp[i] = cvt16<DT>(w[co * so + ci * si + tp]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct HParams {
+  const uint4* xh;    // C8 input
+  const uint4* wp;    // packed weights
+  const float* bias;  // nullable
+  float* y;           // fp32 NCDHW output
+  const uint4* zeros; // >= 16 B of zeros in global memory
+  int N, NCH, D, H, W, K;  // NCH = C / 16
+  int P, R, RP;       // row pitch (units), brick rows, R * P
+  int PT, TPP;        // positions per tile, tiles per plane
+  int KT;             // K / 64
+  unsigned mP, mRP;
+  int npb;            // brick pieces (1 KiB) per stage
+  int npw;            // weight pieces per stage = KS*KS*2
+  int SB;             // bytes per stage buffer
+  long ntiles;
+  int tiles_per_xcd;  // ceil(ntiles / 8)
+};
+
+struct HTile {
+  int n, cot, z, q0, yf, xoff;
+};
+
+__device__ __forceinline__ HTile h_decode(const HParams& p, long t) {
+  HTile o;
+  o.cot = (int)(t % p.KT); t /= p.KT;
+  const int tp = (int)(t % p.TPP); t /= p.TPP;
+  o.z = (int)(t % p.D);
+  o.n = (int)(t / p.D);
+  o.q0 = tp * p.PT;
+  o.yf = (int)fdiv((unsigned)o.q0, p.mP);
+  o.xoff = o.q0 - o.yf * p.P;
+  return o;
+}
+
+template <int DT, int KS, int VB>
+__global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int PAD = KS / 2, T2 = KS * KS;
+  constexpr int MAXJ = 8;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+
+  // tiles of this workgroup: XCD x (= blockIdx % 8) owns tiles [x * tpx, (x+1) * tpx); its workgroups interleave
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const long t_lo = (long)xcd * p.tiles_per_xcd;
+  long t_hi = t_lo + p.tiles_per_xcd;
+  if (t_hi > p.ntiles) t_hi = p.ntiles;
+  long tcur = t_lo + slot;
+  if (tcur >= t_hi) return;
+
+  int off[MAXJ];  // per-lane source offset (units) of brick piece wave + 8j relative to the plane, or -1 = zero page
+  auto decode_pieces = [&](const HTile& t) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const unsigned u = (unsigned)((wave + kWaves * j) * 64 + lane);
+      const unsigned hh = u >= (unsigned)p.RP ? 1u : 0u;
+      const unsigned ur = u - hh * p.RP;
+      const unsigned rr = fdiv(ur, p.mP);
+      const int xx = (int)(ur - rr * p.P) - PAD;
+      const int y = t.yf - PAD + (int)rr;
+      const bool ok = ur < (unsigned)p.RP && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      off[j] = ok ? (int)(hh * S + (long)y * p.W + xx) : -1;
+    }
+  };
+  // valid dz range of a tile (planes outside the volume contribute nothing: their stages are skipped)
+  auto dz_lo = [&](const HTile& t) { return PAD - t.z > 0 ? PAD - t.z : 0; };
+  auto dz_hi = [&](const HTile& t) { return t.z + PAD > p.D - 1 ? KS - 1 - (t.z + PAD - (p.D - 1)) : KS - 1; };
+
+  auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
+    const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * 2 * p.D + (tz + dz - PAD)) * HW;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int pc = wave + kWaves * j;
+      if (pc < p.npb) {
+        const uint4* src = off[j] >= 0 ? plane + off[j] : p.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+      }
+    }
+    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KS + dz) * (T2 * 128) + lane;
+    unsigned char* wb = buf + p.npb * 1024;
+#pragma unroll 1
+    for (int pw = wave; pw < p.npw; pw += kWaves)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
+  };
+
+  unsigned char* const buf0 = lds_raw;
+  unsigned char* const buf1 = lds_raw + p.SB;
+
+  HTile cur = h_decode(p, tcur);
+  decode_pieces(cur);
+  int lo = dz_lo(cur), nv = dz_hi(cur) - lo + 1;
+  issue(cur.n, cur.z, cur.cot, 0, lo, buf0);
+  int g = 0;  // parity of the buffer being computed
+
+  const int qb = wave * VB * 32 + r;  // this lane's first position in the tile
+  while (true) {
+    const long tnext = tcur + nslot;
+    const bool more_tiles = tnext < t_hi;
+    HTile nxt = cur;
+    if (more_tiles) nxt = h_decode(p, tnext);
+    const int nstages = p.NCH * nv;
+
+    f32x16 acc[2][VB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int v = 0; v < VB; ++v)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][v][e] = 0.f;
+
+    int chunk = 0, dzi = 0;
+#pragma unroll 1
+    for (int i = 0; i < nstages; ++i) {
+      unsigned char* bc = (g & 1) ? buf1 : buf0;
+      unsigned char* bn = (g & 1) ? buf0 : buf1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage i has landed
+      __syncthreads();                                  // ... and everybody's; everybody is done reading bn
+      // next stage of this tile, or the first stage of the next tile
+      int nchunk = chunk, ndz = dzi + 1;
+      if (ndz == nv) { ndz = 0; ++nchunk; }
+      const bool within = i + 1 < nstages;
+      if (!within && more_tiles) decode_pieces(nxt);
+      if (within || more_tiles)
+        issue(within ? cur.n : nxt.n, within ? cur.z : nxt.z, within ? cur.cot : nxt.cot, within ? nchunk : 0,
+              within ? lo + ndz : dz_lo(nxt), bn);
+
+      // A fragments: unit ((t*2 + a)*2 + h)*32 + r of the stage's weights; B fragments: unit h*RP + position + tap
+      const i32x4* wrow = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
+      const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + h * p.RP + qb + cur.xoff;
+      // Software pipeline over the taps of the plane, pinned with sched_group_barrier: the 2 + VB LDS reads of tap
+      // t+1 are issued in front of the 2*VB MFMAs of tap t (the row loop is not unrolled so that the loop-carried
+      // operands keep the machine scheduler from re-merging the stages).
+      i32x4 a0 = wrow[0], a1 = wrow[64], b[VB], na0, na1, nb[VB];
+#pragma unroll
+      for (int v = 0; v < VB; ++v) b[v] = brow[v * 32];
+#pragma unroll 1
+      for (int dy = 0; dy < KS; ++dy) {
+        const bool last_row = dy == KS - 1;
+        const i32x4* wrow_n = last_row ? wrow : wrow + KS * 128;  // after the last row: any in-range address
+        const i32x4* brow_n = last_row ? brow : brow + p.P;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const i32x4* wn = dx + 1 < KS ? wrow + (dx + 1) * 128 : wrow_n;
+          const i32x4* bnp = dx + 1 < KS ? brow + dx + 1 : brow_n;
+          na0 = wn[0]; na1 = wn[64];
+#pragma unroll
+          for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
+#pragma unroll
+          for (int v = 0; v < VB; ++v) {
+            acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
+            acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);  // DS reads of the next tap ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * VB, 0);  // ... then this tap's MFMAs
+          a0 = na0; a1 = na1;
+#pragma unroll
+          for (int v = 0; v < VB; ++v) b[v] = nb[v];
+        }
+        wrow = wrow_n; brow = brow_n;
+      }
+      chunk = nchunk; dzi = ndz;
+      ++g;
+    }
+
+    // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
+    {
+      const int cob = cur.cot * 64;
+      float bv[2][16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          bv[a][e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+      float* yn = p.y + ((long)cur.n * p.K + cob + 4 * h) * S + (long)cur.z * HW;
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        const unsigned f = (unsigned)(cur.q0 + qb + v * 32);
+        const unsigned yy = fdiv(f, p.mP);
+        const unsigned xx = f - yy * p.P;
+        if ((int)yy < p.H && (int)xx < p.W) {
+          float* yv = yn + (long)yy * p.W + xx;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              yv[(long)(a * 32 + (e & 3) + 8 * (e >> 2)) * S] = acc[a][v][e] + bv[a][e];
+        }
+      }
+    }
+    if (!more_tiles) break;
+    cur = nxt;
+    tcur = tnext;
+    lo = dz_lo(cur);
+    nv = dz_hi(cur) - lo + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct HPlan {
+  int PT, VB, P, R, RP, TPP, npb, npw, SB;
+  bool ok;
+};
+
+HPlan h_plan(const ConvDims& d) {
+  HPlan pl{};
+  const int KS = d.kd, T2 = KS * KS;
+  pl.P = d.W + KS - 1;
+  pl.npw = T2 * 2;
+  const long plane = (long)d.H * pl.P;
+  double best = 0;
+  for (int VB : {4, 2, 1}) {
+    const int PT = VB * 256;
+    const int rows = (pl.P - 1 + PT - 1) / pl.P + 1;
+    const int R = rows + KS - 1;
+    const int RP = R * pl.P;
+    const int npb = (2 * RP + 4 + 63) / 64;
+    const int SB = (npb + pl.npw) * 1024;
+    if (npb > 64 || 2 * SB > kLdsMaxH) continue;
+    const int TPP = (int)((plane + PT - 1) / PT);
+    // cost ~ positions computed per useful position, with a small bonus for the larger tile (operand reuse)
+    const double eff = (double)d.H * d.W / ((double)TPP * PT) * (VB == 4 ? 1.0 : VB == 2 ? 0.93 : 0.8);
+    if (eff > best) {
+      best = eff;
+      pl.PT = PT; pl.VB = VB; pl.R = R; pl.RP = RP; pl.npb = npb; pl.SB = SB; pl.TPP = TPP;
+      pl.ok = true;
+    }
+  }
+  return pl;
+}
+
+bool h_shape_ok(const ConvDims& d, int Cin, int Kout) {
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
+  if (Cin % 16 || Kout % 64) return false;
+  if ((long)d.D * d.H * d.W * 2 >= (1l << 31)) return false;  // per-lane source offsets are 32-bit unit counts
+  return h_plan(d).ok;
+}
+
+size_t packed_bytes(int Cin, int Kout, int KS) { return (size_t)Cin * Kout * KS * KS * KS * 2; }
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <int DT, int KS, int VB>
+int launch_h(const HParams& p, int lds, hipStream_t s) {
+  auto kern = k_conv_h<DT, KS, VB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxH) !=
+        hipSuccess) {
+      set_error("conv_h: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
+  return check_launch("conv_h");
+}
+
+template <int DT, int KS>
+int launch_h_vb(int VB, const HParams& p, int lds, hipStream_t s) {
+  switch (VB) {
+    case 4: return launch_h<DT, KS, 4>(p, lds, s);
+    case 2: return launch_h<DT, KS, 2>(p, lds, s);
+    default: return launch_h<DT, KS, 1>(p, lds, s);
+  }
+}
+
+// x: fp32 [N][Cin][D][H][W]; w: fp32 master weights; y: fp32 [N][Kout][D][H][W].  so/si/flip: see k_pack_w_h.
+template <int DT>
+int run_h(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout, long so,
+          long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+  const int KS = d.kd, T3 = KS * KS * KS;
+  const HPlan pl = h_plan(d);
+  const long S = (long)d.D * d.H * d.W;
+  const size_t xb = align256((size_t)d.N * Cin * S * 2);
+  const size_t wb = align256(packed_bytes(Cin, Kout, KS));
+  if (!ws || wsb < xb + wb + 256) { set_error("conv_h: workspace too small"); return NC_ERR_WS; }
+  uint4* xh = (uint4*)ws;
+  unsigned short* wp = (unsigned short*)((char*)ws + xb);
+  uint4* zeros = (uint4*)((char*)ws + xb + wb);
+  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_h: memset failed"); return NC_ERR_HIP; }
+  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
+  if (int e = check_launch("to_c8")) return e;
+  const long total = (long)Cin * Kout * T3;
+  hipLaunchKernelGGL((k_pack_w_h<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 16, T3, so, si, flip,
+                     total);
+  if (int e = check_launch("pack_w_h")) return e;
+  HParams p{};
+  p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
+  p.N = d.N; p.NCH = Cin / 16; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
+  p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.mP = magic(pl.P); p.mRP = magic(pl.RP);
+  p.npb = pl.npb; p.npw = pl.npw; p.SB = pl.SB;
+  p.ntiles = (long)d.N * d.D * pl.TPP * p.KT;
+  p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
+  const int lds = 2 * pl.SB;
+  if (KS == 3) return launch_h_vb<DT, 3>(pl.VB, p, lds, s);
+  return launch_h_vb<DT, 5>(pl.VB, p, lds, s);
+}
+
+}  // namespace
+
+bool h_fwd_supported(const ConvDims& d) { return h_shape_ok(d, d.C, d.K); }
+bool h_dgrad_supported(const ConvDims& d) { return h_shape_ok(d, d.K, d.C); }
+size_t h_ws_bytes(const ConvDims& d) {
+  if (!h_fwd_supported(d) && !h_dgrad_supported(d)) return 0;
+  const long S = (long)d.D * d.H * d.W;
+  const int cm = d.C > d.K ? d.C : d.K;
+  return align256((size_t)d.N * cm * S * 2) + align256(packed_bytes(d.C, d.K, d.kd)) + 512;
+}
+
+int conv_fwd_h(const float* x, const float* w, const float* b, float* y, const ConvDims& d, int dt, void* ws, size_t wsb,
+               hipStream_t s) {
+  const long T3 = (long)d.kd * d.kh * d.kw;
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(x, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+  return run_h<NC_DT_BF16>(x, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+}
+
+int conv_dgrad_h(const float* dy, const float* w, float* dx, const ConvDims& d, int dt, void* ws, size_t wsb,
+                 hipStream_t s) {
+  const long T3 = (long)d.kd * d.kh * d.kw;
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(dy, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
+  return run_h<NC_DT_BF16>(dy, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
+}
+
+}  // namespace nc

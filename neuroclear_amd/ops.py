@@ -120,6 +120,36 @@ def _side_stream(device):
     return st
 
 
+# Arithmetic of the convolutions (BASELINE.json configs[3]): 'fp32' (default, the reference's arithmetic) or 'bf16' /
+# 'fp16' = operands rounded to 16 bits, fp32 accumulation, on the layers nc_conv_lp_supported covers (3^3 / 5^3, stride
+# 1, >= 16 input and >= 64 output channels); every other layer and everything between the convolutions stays fp32.
+_DT = {'fp32': 0, 'fp16': 1, 'bf16': 2}
+conv_precision = 'fp32'
+
+
+def set_conv_precision(name):
+    global conv_precision
+    if name not in _DT:
+        raise _lib.NcError('conv precision must be one of %s, got %r' % (sorted(_DT), name))
+    conv_precision = name
+
+
+def _lp(what, dims, K, k3, stride, pad):
+    """dtype code of the 16-bit kernel for this call, or 0 when the fp32 kernels serve it."""
+    if conv_precision == 'fp32':
+        return 0
+    N, C, D, H, W = dims
+    ok = lib().nc_conv_lp_supported(I(what), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride),
+                                    I(pad))
+    return _DT[conv_precision] if ok else 0
+
+
+def _lp_ws(dims, K, k3, stride, pad, device, tag='ws_lp'):
+    N, C, D, H, W = dims
+    nb = lib().nc_conv_lp_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
+    return workspace(nb, device, tag)
+
+
 def conv_fwd_raw(x, w, b, stride, pad):
     _chk(x, w, b)
     _f32(x, w, b)
@@ -130,6 +160,16 @@ def conv_fwd_raw(x, w, b, stride, pad):
     if w.shape[1] != C:
         raise _lib.NcError('conv: weight expects %d input channels, got %d' % (w.shape[1], C))
     y = torch.empty(_conv_out_shape(x.shape, w.shape, stride, pad), dtype=torch.float32, device=x.device)
+    dt = _lp(0, dims, K, k3, stride, pad)
+    if dt:
+        ws = _lp_ws(dims, K, k3, stride, pad, x.device)
+        e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (y.numel() // K))
+        check(lib().nc_conv_fwd_lp(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                                   I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_conv_fwd_lp')
+        if e0 is not None:
+            _prof_end(e0, 'fwd_lp_k%d' % k3[1], 2.0 * C * K * k3[0] * k3[1] * k3[2] * (y.numel() // K))
+        return y
     ws = _conv_ws(dims, K, k3, stride, pad, x.device)
     e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (y.numel() // K))
     check(lib().nc_conv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
@@ -147,6 +187,16 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     N, C, D, H, W = dims
     k3 = _kdims(w.shape)
     K = w.shape[0]
+    dt = _lp(1, dims, K, k3, stride, pad)
+    if dt:
+        ws = _lp_ws(dims, K, k3, stride, pad, dy.device)
+        e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
+        check(lib().nc_conv_dgrad_lp(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                                     I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_conv_dgrad_lp')
+        if e0 is not None:
+            _prof_end(e0, 'dgrad_lp_k%d' % k3[1], 2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
+        return dx
     ws = _conv_ws(dims, K, k3, stride, pad, dy.device)
     e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
     check(lib().nc_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]),
