@@ -67,6 +67,10 @@ int nc_conv_fwd_lp(const float* x, const float* w, const float* bias, float* y, 
                    int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
 int nc_conv_dgrad_lp(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd,
                      int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* weight gradient: 3^3, C % 32 == 0, K % 64 == 0; dbias (nullable) is summed in fp32 from the fp32 dy */
+int nc_conv_wgrad_lp(const float* x, const float* dy, float* dw, float* dbias /* or NULL */, int N, int C, int D, int H,
+                     int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes,
+                     void* stream);
 
 /* ---- ConvTranspose3d(k=2, s=2) (networks.py:500,503): x[N,C,D,H,W], w[C,K,2,2,2], bias[K], y[N,K,2D,2H,2W].   */
 size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K);

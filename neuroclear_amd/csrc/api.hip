@@ -96,7 +96,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
 int nc_conv_lp_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return 0;
-  return what == 0 ? h_fwd_supported(d) : what == 1 ? h_dgrad_supported(d) : 0;
+  return what == 0 ? h_fwd_supported(d) : what == 1 ? h_dgrad_supported(d) : what == 2 ? h_wgrad_supported(d) : 0;
 }
 
 size_t nc_conv_lp_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
@@ -121,6 +121,18 @@ int nc_conv_dgrad_lp(const float* dy, const float* w, float* dx, int N, int C, i
   if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("conv_dgrad_lp: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
   if (!h_dgrad_supported(d)) { set_error("conv_dgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
   return conv_dgrad_h(dy, w, dx, d, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_wgrad_lp(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W, int K,
+                     int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = conv_args("conv_wgrad_lp", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
+  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("conv_wgrad_lp: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  if (!h_wgrad_supported(d)) { set_error("conv_wgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = conv_wgrad_h(x, dy, dw, d, dtype, ws, ws_bytes, s)) return e;
+  if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);  // fp32, from the fp32 dy
+  return NC_OK;
 }
 
 int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W, int K,

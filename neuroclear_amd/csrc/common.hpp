@@ -97,6 +97,9 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
 // ---- 16-bit (bf16 / fp16) MFMA convolutions, conv_h.hip
 bool h_fwd_supported(const ConvDims& d);
 bool h_dgrad_supported(const ConvDims& d);
+bool h_wgrad_supported(const ConvDims& d);
+int conv_wgrad_h(const float* x, const float* dy, float* dw, const ConvDims& d, int dt, void* ws, size_t wsb,
+                 hipStream_t s);
 size_t h_ws_bytes(const ConvDims& d);
 int conv_fwd_h(const float* x, const float* w, const float* b, float* y, const ConvDims& d, int dt, void* ws, size_t wsb,
                hipStream_t s);

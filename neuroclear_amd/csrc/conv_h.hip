@@ -398,15 +398,322 @@ int run_h(const float* x, const float* w, const float* bias, float* y, const Con
   return launch_h_vb<DT, 5>(pl.VB, p, lds, s);
 }
 
+
+// =====================================================================================================================
+// Weight gradient on the 16-bit matrix cores.
+//   dW[k][c][tap] = sum_{n, voxel} dY[n][k][voxel] * X[n][c][voxel + tap]
+// MFMA view: M = 32 output channels k, N = 32 input channels c, K-dim = 16 VOXELS.  Both operands are read from the same
+// C8 images the forward kernel uses (rows = voxels, 8 channels = one 16-byte unit) with gfx950's transposing LDS read
+// ds_read_b64_tr_b16: per 16-lane group a 4-voxel x 16-channel block comes back channel-major, i.e. each lane receives 4
+// consecutive voxels of ITS channel -- two reads build the 8-voxel fragment of v_mfma_f32_32x32x16.  Every lane supplies
+// its own row address, so the 16 voxels of a k-step are simply 16 consecutive positions of a Ty x Tx tile in row-major
+// order, whatever Tx is (37 for W = 148, 36 for 108, ...), and a tap is a row shift of the X image: no alignment cases.
+//
+// Workgroup = 64 k x 32 c x all 27 taps, 8 waves: wave = (32-k half, group of 7 taps) -> 7 accumulator tiles.  It walks
+// a contiguous range of (sample, tile, z) steps; along z the three X planes live in a 4-slot LDS ring, so a step stages
+// ONE new X plane (4 C8 blocks x (Ty+2) x (Tx+2) units) and one dY plane (8 blocks x Ty x Tx units) by LDS-DMA while the
+// previous step is multiplied.  The 256 persistent workgroups are dealt evenly over the (k-tile, c-tile) pairs and over
+// the steps of a pair (equal contiguous shares: no tail); each writes one partial [tap][64][32] and k_wgrad_h_reduce
+// adds the partials of a pair in workgroup order (deterministic, no atomics).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* ltr_t;
+
+struct WhParams {
+  const uint4* xh;   // C8 X   [N][C/8][D][H][W]
+  const uint4* dyh;  // C8 dY  [N][K/8][D][H][W]
+  float* part;       // [pairs * nwp][T3][64][32]
+  const uint4* zeros;
+  int N, C, K, D, H, W;
+  int Ty, Tx, YB, XB;
+  int Xp, XU, XUp;   // X image: row pitch Tx + 2p, units per block, padded block stride (== 4 or 12 mod 16)
+  int PT, PTp, NK;   // dY image: positions Ty*Tx, padded block stride, k-steps = ceil(PT / 16)
+  int npx, npd;      // 1 KiB pieces per X slot / per dY buffer
+  int xslot, dybuf;  // bytes
+  int nct;           // C / 32
+  int npairs, nwp;   // (k-tile, c-tile) pairs, workgroups per pair
+  long steps;        // N * YB * XB * D  (per pair)
+  unsigned mTx, mXp, mXUp, mPTp;
+};
+
+template <int DT, int KS>
+__global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int PAD = KS / 2, T3 = KS * KS * KS;
+  constexpr int TG = (T3 + 3) / 4;  // taps per wave group (7 for 3^3)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 1, tg = wave >> 1;
+  const int t0 = tg * TG;
+  const int ntap = T3 - t0 < TG ? T3 - t0 : TG;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+
+  const int wg = blockIdx.x;
+  const int pair = wg % p.npairs, wi = wg / p.npairs;
+  if (wi >= p.nwp) return;
+  const int kt = pair / p.nct, ct = pair % p.nct;
+  const long s_lo = p.steps * wi / p.nwp, s_hi = p.steps * (wi + 1) / p.nwp;
+
+  unsigned char* const xring = lds_raw;                    // 4 slots
+  unsigned char* const dyb = lds_raw + 4 * p.xslot;        // 2 buffers
+
+  // ---- LDS-DMA of one X plane (4 C8 blocks of this c-tile, tile + halo) / one dY plane (8 blocks of this k-tile)
+  auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
+    const bool zok = (unsigned)pz < (unsigned)p.D;
+    const uint4* base = p.xh + (((long)n * (p.C / 8) + ct * 4) * p.D + (zok ? pz : 0)) * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npx; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned cb = fdiv(u, p.mXUp);
+      const unsigned ur = u - cb * p.XUp;
+      const unsigned ty = fdiv(ur, p.mXp);
+      const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
+      const bool ok = zok && cb < 4u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const uint4* src = ok ? base + (long)cb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
+    const uint4* base = p.dyh + (((long)n * (p.K / 8) + kt * 8) * p.D + z) * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npd; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned cb = fdiv(u, p.mPTp);
+      const unsigned rho = u - cb * p.PTp;
+      const unsigned ty = fdiv(rho, p.mTx);
+      const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
+      const bool ok = cb < 8u && rho < (unsigned)p.PT && y < p.H && x < p.W;
+      const uint4* src = ok ? base + (long)cb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- transposed-read roles of this lane: group g = lane/16 -> channels 16*(g&1).. of the 32-channel tile, voxel half
+  //      h = g/2; inside the group lane 4q+p supplies the address of voxel row q, channels 4p..4p+3
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+  const int cbsel = 2 * (g & 1) + (pp >> 1);
+  const unsigned a_lane = (unsigned)(((mt * 4 + cbsel) * p.PTp) * 16 + (pp & 1) * 8);  // + rho * 16
+  const unsigned b_lane = (unsigned)((cbsel * p.XUp) * 16 + (pp & 1) * 8);             // + (ty * Xp + tx) * 16
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int j = 0; j < TG; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  // tap j of this wave: (dz, dy, dx) and its byte offset inside an X slot
+  int tdz[TG], toff[TG];
+#pragma unroll
+  for (int j = 0; j < TG; ++j) {
+    const int t = t0 + j < T3 ? t0 + j : T3 - 1;
+    const int dz = t / (KS * KS), dy = (t / KS) % KS, dx = t % KS;
+    tdz[j] = dz;
+    toff[j] = (dy * p.Xp + dx) * 16;
+  }
+
+  long step = s_lo;
+  bool fresh = true;  // the ring has to be (re)filled: first step of this workgroup or of a new (sample, tile)
+  int n = 0, y0 = 0, x0 = 0, z = 0;
+  while (step < s_hi) {
+    if (fresh) {
+      long j = step;
+      z = (int)(j % p.D); j /= p.D;
+      const int xb = (int)(j % p.XB); j /= p.XB;
+      const int yb = (int)(j % p.YB);
+      n = (int)(j / p.YB);
+      y0 = yb * p.Ty; x0 = xb * p.Tx;
+      __syncthreads();  // everybody is done with the buffers of the previous tile
+      issue_x(n, y0, x0, z - 1, xring + ((z + 0) & 3) * p.xslot);
+      issue_x(n, y0, x0, z, xring + ((z + 1) & 3) * p.xslot);
+      issue_x(n, y0, x0, z + 1, xring + ((z + 2) & 3) * p.xslot);
+      issue_dy(n, y0, x0, z, dyb + (z & 1) * p.dybuf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      fresh = false;
+    }
+    const bool cont = z + 1 < p.D && step + 1 < s_hi;  // the next step continues this tile
+    if (cont) {
+      issue_x(n, y0, x0, z + 2, xring + ((z + 3) & 3) * p.xslot);
+      issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
+    }
+    // ---- multiply: NK k-steps x ntap taps
+    const unsigned abase = (unsigned)(4 * p.xslot + (z & 1) * p.dybuf) + a_lane;
+    unsigned sb[TG];  // slot base + tap offset
+#pragma unroll
+    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(((z + tdz[j]) & 3) * p.xslot + toff[j]) + b_lane;
+#pragma unroll 1
+    for (int s = 0; s < p.NK; ++s) {
+      unsigned rho[2], bo[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        rho[s2] = (unsigned)(16 * s + 8 * h + 4 * s2 + q);
+        unsigned rc = rho[s2] < (unsigned)p.PT ? rho[s2] : (unsigned)p.PT - 1;  // padded positions: dY = 0, X any finite
+        const unsigned ty = fdiv(rc, p.mTx);
+        bo[s2] = (ty * p.Xp + (rc - ty * p.Tx)) * 16;
+      }
+      i32x4 a;
+      {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds_raw + abase + rho[0] * 16));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds_raw + abase + rho[1] * 16));
+        a = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int j = 0; j < TG; ++j) {
+        if (j < ntap) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds_raw + sb[j] + bo[0]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds_raw + sb[j] + bo[1]));
+          const i32x4 b = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[j] = mfma16<DT>(a, b, acc[j]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++step;
+    if (cont) ++z; else fresh = true;
+  }
+
+  // ---- partial: part[wg][tap][k 0..63][c 0..31]; rows of the accumulator tile are k, lanes are c
+  float* pw = p.part + (long)wg * T3 * 64 * 32;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TG; ++j)
+    if (j < ntap) {
+      float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + 4 * hh) * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pt[((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];
+    }
+}
+
+// dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32), in workgroup order
+__global__ void __launch_bounds__(256) k_wgrad_h_reduce(const float* __restrict__ part, float* __restrict__ dw, int C,
+                                                        int T3, int nct, int npairs, int nwp, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (k, tap, c): c fastest -> coalesced partial reads
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int t = (int)((i / C) % T3);
+  const int k = (int)(i / ((long)C * T3));
+  const int pair = (k / 64) * nct + c / 32;
+  const long off = ((long)t * 64 + (k & 63)) * 32 + (c & 31);
+  float sacc = 0.f;
+  for (int w = 0; w < nwp; ++w) sacc += part[((long)(w * npairs + pair) * T3) * 64 * 32 + off];
+  dw[((long)k * C + c) * T3 + t] = sacc;
+}
+
+struct WhPlan {
+  int Ty, Tx, YB, XB, Xp, XU, XUp, PT, PTp, NK, npx, npd, xslot, dybuf;
+  bool ok;
+};
+
+int pad_4mod8(int v) {  // smallest v' >= v with v' == 4 (mod 8): block stride that keeps the transposed reads conflict-free
+  int r = v + ((4 - (v & 7)) & 7);
+  return r;
+}
+
+WhPlan wh_plan(const ConvDims& d) {
+  WhPlan best{};
+  double best_cost = 1e30;
+  const int KS = d.kd;
+  for (int nx = 1; nx <= 8; ++nx) {
+    const int Tx = (d.W + nx - 1) / nx;
+    for (int Ty = 1; Ty <= 16 && Ty <= d.H; ++Ty) {
+      WhPlan pl{};
+      pl.Ty = Ty; pl.Tx = Tx;
+      pl.XB = (d.W + Tx - 1) / Tx; pl.YB = (d.H + Ty - 1) / Ty;
+      pl.Xp = Tx + KS - 1; pl.XU = (Ty + KS - 1) * pl.Xp; pl.XUp = pad_4mod8(pl.XU + KS);  // + KS: tap reads of the clamped tail
+      pl.PT = Ty * Tx; pl.NK = (pl.PT + 15) / 16; pl.PTp = pad_4mod8(pl.NK * 16);
+      pl.npx = (4 * pl.XUp + 63) / 64; pl.npd = (8 * pl.PTp + 63) / 64;
+      pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
+      if (4 * pl.xslot + 2 * pl.dybuf > kLdsMaxH) continue;
+      if (pl.NK < 4) continue;
+      // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
+      const double useful = (double)d.H * d.W;
+      const double mfma = (double)pl.YB * pl.XB * pl.NK * 16;
+      const double stage = (double)pl.YB * pl.XB * (4.0 * pl.XUp + 8.0 * pl.PTp) / 12.0;
+      const double cost = (mfma + 0.15 * stage) / useful;
+      if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
+    }
+  }
+  return best;
+}
+
+bool wh_shape_ok(const ConvDims& d) {
+  if (d.kd != 3 || d.kh != 3 || d.kw != 3) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 1 || d.ph != 1 || d.pw != 1) return false;
+  if (d.C % 32 || d.K % 64) return false;
+  if ((d.K / 64) * (d.C / 32) > 256) return false;
+  if ((long)d.D * d.H * d.W * 8 >= (1l << 31)) return false;
+  return wh_plan(d).ok;
+}
+
+template <int DT>
+int run_wh(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  const int T3 = 27;
+  const WhPlan pl = wh_plan(d);
+  const long S = (long)d.D * d.H * d.W;
+  const size_t xb = align256((size_t)d.N * d.C * S * 2);
+  const size_t yb = align256((size_t)d.N * d.K * S * 2);
+  const int npairs = (d.K / 64) * (d.C / 32);
+  int nwp = 256 / npairs;
+  const long steps = (long)d.N * pl.YB * pl.XB * d.D;
+  if (nwp > steps) nwp = (int)steps;
+  const size_t pb = align256((size_t)npairs * nwp * T3 * 64 * 32 * 4);
+  if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_h: workspace too small"); return NC_ERR_WS; }
+  uint4* xh = (uint4*)ws;
+  uint4* dyh = (uint4*)((char*)ws + xb);
+  float* part = (float*)((char*)ws + xb + yb);
+  uint4* zeros = (uint4*)((char*)ws + xb + yb + pb);
+  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("wgrad_h: memset failed"); return NC_ERR_HIP; }
+  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xh, S, d.C);
+  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dyh, S, d.K);
+  if (int e = check_launch("to_c8")) return e;
+  WhParams p{};
+  p.xh = xh; p.dyh = dyh; p.part = part; p.zeros = zeros;
+  p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
+  p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
+  p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
+  p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  auto kern = k_wgrad_h<DT, 3>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxH) !=
+        hipSuccess) {
+      set_error("wgrad_h: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(npairs * nwp), dim3(kThreads), 4 * pl.xslot + 2 * pl.dybuf, s, p);
+  if (int e = check_launch("wgrad_h")) return e;
+  const long total = (long)d.K * d.C * T3;
+  hipLaunchKernelGGL(k_wgrad_h_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, part, dw, d.C, T3, d.C / 32, npairs,
+                     nwp, total);
+  return check_launch("wgrad_h_reduce");
+}
+
 }  // namespace
 
 bool h_fwd_supported(const ConvDims& d) { return h_shape_ok(d, d.C, d.K); }
 bool h_dgrad_supported(const ConvDims& d) { return h_shape_ok(d, d.K, d.C); }
+bool h_wgrad_supported(const ConvDims& d) { return wh_shape_ok(d); }
 size_t h_ws_bytes(const ConvDims& d) {
-  if (!h_fwd_supported(d) && !h_dgrad_supported(d)) return 0;
+  const bool fd = h_fwd_supported(d) || h_dgrad_supported(d), wg = h_wgrad_supported(d);
+  if (!fd && !wg) return 0;
   const long S = (long)d.D * d.H * d.W;
   const int cm = d.C > d.K ? d.C : d.K;
-  return align256((size_t)d.N * cm * S * 2) + align256(packed_bytes(d.C, d.K, d.kd)) + 512;
+  size_t b = align256((size_t)d.N * cm * S * 2) + align256(packed_bytes(d.C, d.K, d.kd)) + 512;
+  if (wg) {
+    const size_t w = align256((size_t)d.N * d.C * S * 2) + align256((size_t)d.N * d.K * S * 2) +
+                     align256((size_t)256 * 27 * 64 * 32 * 4) + 512;
+    if (w > b) b = w;
+  }
+  return b;
+}
+
+int conv_wgrad_h(const float* x, const float* dy, float* dw, const ConvDims& d, int dt, void* ws, size_t wsb,
+                 hipStream_t s) {
+  if (dt == NC_DT_F16) return run_wh<NC_DT_F16>(x, dy, dw, d, ws, wsb, s);
+  return run_wh<NC_DT_BF16>(x, dy, dw, d, ws, wsb, s);
 }
 
 int conv_fwd_h(const float* x, const float* w, const float* b, float* y, const ConvDims& d, int dt, void* ws, size_t wsb,

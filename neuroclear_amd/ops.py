@@ -215,6 +215,16 @@ def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws'):
     k3 = _kdims(w_shape)
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
+    dt = _lp(2, dims, K, k3, stride, pad)
+    if dt:
+        ws = _lp_ws(dims, K, k3, stride, pad, x.device, ws_tag + '_lp')
+        e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
+        check(lib().nc_conv_wgrad_lp(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                                     I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_conv_wgrad_lp')
+        if e0 is not None:
+            _prof_end(e0, 'wgrad_lp_k%d' % k3[1], 2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
+        return dw, db
     ws = _conv_ws(dims, K, k3, stride, pad, x.device, ws_tag)
     e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
     check(lib().nc_conv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
