@@ -31,10 +31,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
+    'fwd_lp_k3': 'k_conv_h<*,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,*>',
+    'dgrad_lp_k5': 'k_conv_h<*,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
 }
 
 
@@ -106,7 +109,9 @@ def run_train(args, rank, world, dev):
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = create_model(apollo_opt(dev.index, args.model))
+        o = apollo_opt(dev.index, args.model)
+        o.precision = args.precision
+        model = create_model(o)
     if world > 1:  # identical replicas: broadcast rank 0's parameters (one flat buffer per optimizer)
         for opt in model.optimizers:
             dist.broadcast(opt.flat, 0)
@@ -147,13 +152,14 @@ def run_train(args, rank, world, dev):
         s[1] += ms
         s[2] += flop
     conv_ms = sum(s[1] for s in stats.values())
-    top = max((t for t in stats if 'mfma' in t), key=lambda t: stats[t][1], default=None)
+    top = max((t for t in stats if 'mfma' in t or '_lp_' in t), key=lambda t: stats[t][1], default=None)
     roof = None
     if top:
         n, ms, flop = stats[top]
         ach = flop / ms / 1e9
+        peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_F32_PEAK_TFLOPS
         roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
-                    peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=pmc_traffic(top), launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
@@ -209,6 +215,8 @@ def main():
     ap.add_argument('--crop', type=int, default=108)
     ap.add_argument('--batch', type=int, default=1, help='crops per step and GPU (headline: 1; configs[3] shape: --crop 148 --batch 4)')
     ap.add_argument('--model', default='apollo', choices=['apollo', 'athena'], help='athena = configs[4]')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16'],
+                    help='arithmetic of the 3^3/5^3 convolutions; the headline is fp32 (the reference), bf16/fp16 = configs[3]')
     ap.add_argument('--volume', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP events (A/B runs)')
@@ -242,7 +250,9 @@ def main():
     out = dict(metric='voxels/sec', value=units / dt, unit='voxels/s', n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling='weak' if args.workload == 'train' else 'strong',
-               vs_baseline=None, dtype='f32', data='synthetic', config=cfg)
+               vs_baseline=None, dtype='f32' if args.precision == 'fp32' or args.workload != 'train' else
+               '%s (3^3/5^3 conv operands; fp32 accumulate, fp32 everywhere else)' % args.precision,
+               data='synthetic', config=cfg)
     if roof:
         out['roofline'] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train':

@@ -98,6 +98,33 @@ __global__ void __launch_bounds__(256) k_pack_w_h(const float* __restrict__ w, u
   wp[i] = cvt16<DT>(w[co * so + ci * si + tp]);
 }
 
+// 5^3 (PAIR) packing: [cot][chunk = ci/8][dz][i = tap pair][a][h][r][8], element j = input channel chunk*8 + j at tap
+// (dy, dx) = 2i + h of plane dz; zero for the 26th tap.
+template <int DT>
+__global__ void __launch_bounds__(256) k_pack_w_h8(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH,
+                                                   int KS, long so, long si, int flip, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int T2 = KS * KS, NP = (T2 + 1) / 2, T3 = T2 * KS;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int r = (int)(q & 31); q >>= 5;
+  const int h = (int)(q & 1); q >>= 1;
+  const int a = (int)(q & 1); q >>= 1;
+  const int pr = (int)(q % NP); q /= NP;
+  const int dz = (int)(q % KS); q /= KS;
+  const int chunk = (int)(q % NCH);
+  const int cot = (int)(q / NCH);
+  const int t2 = 2 * pr + h;
+  float v = 0.f;
+  if (t2 < T2) {
+    const long co = cot * 64 + a * 32 + r, ci = chunk * 8 + j;
+    const int tap = dz * T2 + t2;
+    v = w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)];
+  }
+  wp[i] = cvt16<DT>(v);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 struct HParams {
   const uint4* xh;    // C8 input
@@ -137,6 +164,12 @@ template <int DT, int KS, int VB>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS;
+  // 3^3: a k-step = 16 channels (two C8 blocks) at one tap.  5^3 ("PAIR"): a k-step = 8 channels (one C8 block) at TWO
+  // taps, lane half h taking tap 2i + h (the 26th tap has zero weights): half the brick and half the weights per
+  // stage, which is what lets two stage buffers of a 5^3 layer fit in 160 KB (13 k-steps for 25 taps: 4 % padding).
+  constexpr bool PAIR = KS == 5;
+  constexpr int NB = PAIR ? 1 : 2;                    // C8 blocks per chunk
+  constexpr int KSTEPS = PAIR ? (T2 + 1) / 2 : T2;    // k-steps per stage
   constexpr int MAXJ = 8;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
@@ -154,7 +187,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const unsigned u = (unsigned)((wave + kWaves * j) * 64 + lane);
-      const unsigned hh = u >= (unsigned)p.RP ? 1u : 0u;
+      const unsigned hh = (!PAIR && u >= (unsigned)p.RP) ? 1u : 0u;
       const unsigned ur = u - hh * p.RP;
       const unsigned rr = fdiv(ur, p.mP);
       const int xx = (int)(ur - rr * p.P) - PAD;
@@ -168,7 +201,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   auto dz_hi = [&](const HTile& t) { return t.z + PAD > p.D - 1 ? KS - 1 - (t.z + PAD - (p.D - 1)) : KS - 1; };
 
   auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
-    const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * 2 * p.D + (tz + dz - PAD)) * HW;
+    const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * NB * p.D + (tz + dz - PAD)) * HW;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int pc = wave + kWaves * j;
@@ -177,7 +210,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
       }
     }
-    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KS + dz) * (T2 * 128) + lane;
+    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KS + dz) * (KSTEPS * 128) + lane;
     unsigned char* wb = buf + p.npb * 1024;
 #pragma unroll 1
     for (int pw = wave; pw < p.npw; pw += kWaves)
@@ -225,6 +258,40 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         issue(within ? cur.n : nxt.n, within ? cur.z : nxt.z, within ? cur.cot : nxt.cot, within ? nchunk : 0,
               within ? lo + ndz : dz_lo(nxt), bn);
 
+      if constexpr (PAIR) {
+        const i32x4* wrow = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
+        const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
+        auto boff = [&](int i) {  // this lane's tap of k-step i, as a unit offset
+          const int t0 = 2 * i, t1 = 2 * i + 1 < T2 ? 2 * i + 1 : T2 - 1;
+          const int o0 = (t0 / KS) * p.P + t0 % KS, o1 = (t1 / KS) * p.P + t1 % KS;
+          return h ? o1 : o0;
+        };
+        i32x4 a0 = wrow[0], a1 = wrow[64], b[VB], na0, na1, nb[VB];
+        {
+          const i32x4* bp = brow + boff(0);
+#pragma unroll
+          for (int v = 0; v < VB; ++v) b[v] = bp[v * 32];
+        }
+#pragma unroll 1
+        for (int i = 0; i < KSTEPS; ++i) {
+          const int in = i + 1 < KSTEPS ? i + 1 : i;  // after the last k-step: a harmless re-read
+          const i32x4* wn = wrow + in * 128;
+          const i32x4* bnp = brow + boff(in);
+          na0 = wn[0]; na1 = wn[64];
+#pragma unroll
+          for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
+#pragma unroll
+          for (int v = 0; v < VB; ++v) {
+            acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
+            acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * VB, 0);
+          a0 = na0; a1 = na1;
+#pragma unroll
+          for (int v = 0; v < VB; ++v) b[v] = nb[v];
+        }
+      } else {
       // A fragments: unit ((t*2 + a)*2 + h)*32 + r of the stage's weights; B fragments: unit h*RP + position + tap
       const i32x4* wrow = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
       const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + h * p.RP + qb + cur.xoff;
@@ -258,6 +325,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
           for (int v = 0; v < VB; ++v) b[v] = nb[v];
         }
         wrow = wrow_n; brow = brow_n;
+      }
       }
       chunk = nchunk; dzi = ndz;
       ++g;
@@ -305,8 +373,9 @@ struct HPlan {
 HPlan h_plan(const ConvDims& d) {
   HPlan pl{};
   const int KS = d.kd, T2 = KS * KS;
+  const bool pair = KS == 5;
   pl.P = d.W + KS - 1;
-  pl.npw = T2 * 2;
+  pl.npw = (pair ? (T2 + 1) / 2 : T2) * 2;
   const long plane = (long)d.H * pl.P;
   double best = 0;
   for (int VB : {4, 2, 1}) {
@@ -314,7 +383,7 @@ HPlan h_plan(const ConvDims& d) {
     const int rows = (pl.P - 1 + PT - 1) / pl.P + 1;
     const int R = rows + KS - 1;
     const int RP = R * pl.P;
-    const int npb = (2 * RP + 4 + 63) / 64;
+    const int npb = ((pair ? 1 : 2) * RP + 4 + 63) / 64;
     const int SB = (npb + pl.npw) * 1024;
     if (npb > 64 || 2 * SB > kLdsMaxH) continue;
     const int TPP = (int)((plane + PT - 1) / PT);
@@ -332,12 +401,15 @@ HPlan h_plan(const ConvDims& d) {
 bool h_shape_ok(const ConvDims& d, int Cin, int Kout) {
   if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
-  if (Cin % 16 || Kout % 64) return false;
+  if (Cin % (d.kd == 5 ? 8 : 16) || Kout % 64) return false;
   if ((long)d.D * d.H * d.W * 2 >= (1l << 31)) return false;  // per-lane source offsets are 32-bit unit counts
   return h_plan(d).ok;
 }
 
-size_t packed_bytes(int Cin, int Kout, int KS) { return (size_t)Cin * Kout * KS * KS * KS * 2; }
+size_t packed_bytes(int Cin, int Kout, int KS) {
+  const int ksteps = KS == 5 ? (KS * KS + 1) / 2 * 2 : KS * KS;  // taps per plane incl. the zero tap of the 5^3 pairing
+  return (size_t)Cin * Kout * KS * ksteps * 2;
+}
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 template <int DT, int KS, int VB>
@@ -381,13 +453,17 @@ int run_h(const float* x, const float* w, const float* bias, float* y, const Con
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_h: memset failed"); return NC_ERR_HIP; }
   hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
   if (int e = check_launch("to_c8")) return e;
-  const long total = (long)Cin * Kout * T3;
-  hipLaunchKernelGGL((k_pack_w_h<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 16, T3, so, si, flip,
-                     total);
+  const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
+  if (KS == 5)
+    hipLaunchKernelGGL((k_pack_w_h8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip,
+                       total);
+  else
+    hipLaunchKernelGGL((k_pack_w_h<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 16, T3, so, si,
+                       flip, total);
   if (int e = check_launch("pack_w_h")) return e;
   HParams p{};
   p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
-  p.N = d.N; p.NCH = Cin / 16; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
+  p.N = d.N; p.NCH = KS == 5 ? Cin / 8 : Cin / 16; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
   p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.mP = magic(pl.P); p.mRP = magic(pl.RP);
   p.npb = pl.npb; p.npw = pl.npw; p.SB = pl.SB;
@@ -438,23 +514,30 @@ struct WhParams {
 template <int DT, int KS>
 __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-  constexpr int PAD = KS / 2, T3 = KS * KS * KS;
-  constexpr int TG = (T3 + 3) / 4;  // taps per wave group (7 for 3^3)
+  // 3^3: one workgroup owns all 27 taps (ZR = 3 kernel planes, 4-slot X ring).  5^3: the 125 taps do not fit one
+  // workgroup's accumulators, so a workgroup owns the 25 taps of ONE kernel plane dz (ZR = 1, 2-slot ring) and dz
+  // joins (k-tile, c-tile) in the "pair" index.
+  constexpr int PAD = KS / 2, T2 = KS * KS;
+  constexpr int ZR = KS == 3 ? 3 : 1, NS = ZR + 1, NDG = KS / ZR, TW = ZR * T2;
+  constexpr int TG = (TW + 3) / 4;  // taps per wave group: 7,7,7,6 of 27; 7,6,6,6 of 25
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mt = wave & 1, tg = wave >> 1;
-  const int t0 = tg * TG;
-  const int ntap = T3 - t0 < TG ? T3 - t0 : TG;
+  const int t0 = tg * (TW / 4) + (tg < TW % 4 ? tg : TW % 4);
+  const int ntap = TW / 4 + (tg < TW % 4 ? 1 : 0);
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
   const int wg = blockIdx.x;
   const int pair = wg % p.npairs, wi = wg / p.npairs;
   if (wi >= p.nwp) return;
-  const int kt = pair / p.nct, ct = pair % p.nct;
+  const int dzg = pair % NDG, kc = pair / NDG;
+  const int kt = kc / p.nct, ct = kc % p.nct;
+  const int zsh = dzg * ZR - PAD;  // X plane of local kernel plane l at step z: z + zsh + l
   const long s_lo = p.steps * wi / p.nwp, s_hi = p.steps * (wi + 1) / p.nwp;
 
-  unsigned char* const xring = lds_raw;                    // 4 slots
-  unsigned char* const dyb = lds_raw + 4 * p.xslot;        // 2 buffers
+  unsigned char* const xring = lds_raw;                    // NS slots; plane pz lives in slot (pz + 16) % NS
+  unsigned char* const dyb = lds_raw + NS * p.xslot;       // 2 buffers
+  auto slot_of = [&](int pz) { return ((pz + 16) & (NS - 1)) * p.xslot; };
 
   // ---- LDS-DMA of one X plane (4 C8 blocks of this c-tile, tile + halo) / one dY plane (8 blocks of this k-tile)
   auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
@@ -504,8 +587,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
   int tdz[TG], toff[TG];
 #pragma unroll
   for (int j = 0; j < TG; ++j) {
-    const int t = t0 + j < T3 ? t0 + j : T3 - 1;
-    const int dz = t / (KS * KS), dy = (t / KS) % KS, dx = t % KS;
+    const int t = t0 + j < TW ? t0 + j : TW - 1;
+    const int dz = t / T2, dy = (t / KS) % KS, dx = t % KS;
     tdz[j] = dz;
     toff[j] = (dy * p.Xp + dx) * 16;
   }
@@ -522,9 +605,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
       n = (int)(j / p.YB);
       y0 = yb * p.Ty; x0 = xb * p.Tx;
       __syncthreads();  // everybody is done with the buffers of the previous tile
-      issue_x(n, y0, x0, z - 1, xring + ((z + 0) & 3) * p.xslot);
-      issue_x(n, y0, x0, z, xring + ((z + 1) & 3) * p.xslot);
-      issue_x(n, y0, x0, z + 1, xring + ((z + 2) & 3) * p.xslot);
+#pragma unroll
+      for (int l = 0; l < ZR; ++l) issue_x(n, y0, x0, z + zsh + l, xring + slot_of(z + zsh + l));
       issue_dy(n, y0, x0, z, dyb + (z & 1) * p.dybuf);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -532,14 +614,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
     }
     const bool cont = z + 1 < p.D && step + 1 < s_hi;  // the next step continues this tile
     if (cont) {
-      issue_x(n, y0, x0, z + 2, xring + ((z + 3) & 3) * p.xslot);
+      issue_x(n, y0, x0, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
       issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
     }
     // ---- multiply: NK k-steps x ntap taps
-    const unsigned abase = (unsigned)(4 * p.xslot + (z & 1) * p.dybuf) + a_lane;
+    const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf) + a_lane;
     unsigned sb[TG];  // slot base + tap offset
 #pragma unroll
-    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(((z + tdz[j]) & 3) * p.xslot + toff[j]) + b_lane;
+    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(slot_of(z + zsh + tdz[j]) + toff[j]) + b_lane;
 #pragma unroll 1
     for (int s = 0; s < p.NK; ++s) {
       unsigned rho[2], bo[2];
@@ -573,7 +655,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
   }
 
   // ---- partial: part[wg][tap][k 0..63][c 0..31]; rows of the accumulator tile are k, lanes are c
-  float* pw = p.part + (long)wg * T3 * 64 * 32;
+  float* pw = p.part + (long)wg * TW * 64 * 32;
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int j = 0; j < TG; ++j)
@@ -584,18 +666,19 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
     }
 }
 
-// dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32), in workgroup order
+// dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32, tap / TW), in workgroup order
 __global__ void __launch_bounds__(256) k_wgrad_h_reduce(const float* __restrict__ part, float* __restrict__ dw, int C,
-                                                        int T3, int nct, int npairs, int nwp, long total) {
+                                                        int T3, int TW, int nct, int npairs, int nwp, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (k, tap, c): c fastest -> coalesced partial reads
   if (i >= total) return;
   const int c = (int)(i % C);
   const int t = (int)((i / C) % T3);
   const int k = (int)(i / ((long)C * T3));
-  const int pair = (k / 64) * nct + c / 32;
-  const long off = ((long)t * 64 + (k & 63)) * 32 + (c & 31);
+  const int ndg = T3 / TW;
+  const int pair = ((k / 64) * nct + c / 32) * ndg + t / TW;
+  const long off = ((long)(t % TW) * 64 + (k & 63)) * 32 + (c & 31);
   float sacc = 0.f;
-  for (int w = 0; w < nwp; ++w) sacc += part[((long)(w * npairs + pair) * T3) * 64 * 32 + off];
+  for (int w = 0; w < nwp; ++w) sacc += part[((long)(w * npairs + pair) * TW) * 64 * 32 + off];
   dw[((long)k * C + c) * T3 + t] = sacc;
 }
 
@@ -623,12 +706,12 @@ WhPlan wh_plan(const ConvDims& d) {
       pl.PT = Ty * Tx; pl.NK = (pl.PT + 15) / 16; pl.PTp = pad_4mod8(pl.NK * 16);
       pl.npx = (4 * pl.XUp + 63) / 64; pl.npd = (8 * pl.PTp + 63) / 64;
       pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
-      if (4 * pl.xslot + 2 * pl.dybuf > kLdsMaxH) continue;
+      if ((KS == 3 ? 4 : 2) * pl.xslot + 2 * pl.dybuf > kLdsMaxH) continue;
       if (pl.NK < 4) continue;
       // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
       const double useful = (double)d.H * d.W;
       const double mfma = (double)pl.YB * pl.XB * pl.NK * 16;
-      const double stage = (double)pl.YB * pl.XB * (4.0 * pl.XUp + 8.0 * pl.PTp) / 12.0;
+      const double stage = (double)pl.YB * pl.XB * (4.0 * pl.XUp + 8.0 * pl.PTp) / 12.0;  // units per 12 MFMA columns
       const double cost = (mfma + 0.15 * stage) / useful;
       if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
     }
@@ -637,26 +720,26 @@ WhPlan wh_plan(const ConvDims& d) {
 }
 
 bool wh_shape_ok(const ConvDims& d) {
-  if (d.kd != 3 || d.kh != 3 || d.kw != 3) return false;
-  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 1 || d.ph != 1 || d.pw != 1) return false;
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
   if (d.C % 32 || d.K % 64) return false;
-  if ((d.K / 64) * (d.C / 32) > 256) return false;
+  if ((d.K / 64) * (d.C / 32) * (d.kd == 5 ? 5 : 1) > 256) return false;
   if ((long)d.D * d.H * d.W * 8 >= (1l << 31)) return false;
   return wh_plan(d).ok;
 }
 
 template <int DT>
 int run_wh(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
-  const int T3 = 27;
+  const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
   const WhPlan pl = wh_plan(d);
   const long S = (long)d.D * d.H * d.W;
   const size_t xb = align256((size_t)d.N * d.C * S * 2);
   const size_t yb = align256((size_t)d.N * d.K * S * 2);
-  const int npairs = (d.K / 64) * (d.C / 32);
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
   int nwp = 256 / npairs;
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
   if (nwp > steps) nwp = (int)steps;
-  const size_t pb = align256((size_t)npairs * nwp * T3 * 64 * 32 * 4);
+  const size_t pb = align256((size_t)npairs * nwp * TW * 64 * 32 * 4);
   if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_h: workspace too small"); return NC_ERR_WS; }
   uint4* xh = (uint4*)ws;
   uint4* dyh = (uint4*)((char*)ws + xb);
@@ -673,21 +756,24 @@ int run_wh(const float* x, const float* dy, float* dw, const ConvDims& d, void* 
   p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
-  auto kern = k_wgrad_h<DT, 3>;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxH) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h<DT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsMaxH) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h<DT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsMaxH) != hipSuccess) {
       set_error("wgrad_h: cannot raise dynamic LDS limit");
       return NC_ERR_HIP;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(npairs * nwp), dim3(kThreads), 4 * pl.xslot + 2 * pl.dybuf, s, p);
+  const int lds = NS * pl.xslot + 2 * pl.dybuf;
+  if (KS == 3) hipLaunchKernelGGL((k_wgrad_h<DT, 3>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  else hipLaunchKernelGGL((k_wgrad_h<DT, 5>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   if (int e = check_launch("wgrad_h")) return e;
   const long total = (long)d.K * d.C * T3;
-  hipLaunchKernelGGL(k_wgrad_h_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, part, dw, d.C, T3, d.C / 32, npairs,
-                     nwp, total);
+  hipLaunchKernelGGL(k_wgrad_h_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, part, dw, d.C, T3, TW, d.C / 32,
+                     npairs, nwp, total);
   return check_launch("wgrad_h_reduce");
 }
 
@@ -704,7 +790,7 @@ size_t h_ws_bytes(const ConvDims& d) {
   size_t b = align256((size_t)d.N * cm * S * 2) + align256(packed_bytes(d.C, d.K, d.kd)) + 512;
   if (wg) {
     const size_t w = align256((size_t)d.N * d.C * S * 2) + align256((size_t)d.N * d.K * S * 2) +
-                     align256((size_t)256 * 27 * 64 * 32 * 4) + 512;
+                     align256((size_t)256 * 27 * 64 * 32 * 4) + 512;  // partials: <= 256 workgroups x <= 27 taps
     if (w > b) b = w;
   }
   return b;

@@ -21,6 +21,8 @@ class BaseModel(ABC):
             raise RuntimeError('neuroclear_amd runs the hot path on MI355X only: pass --gpu_ids 0 (there is no CPU '
                                'fallback; the CPU restatement lives in oracle/ and is test infrastructure)')
         self.device = torch.device('cuda:{}'.format(self.gpu_ids[0]))
+        from .. import ops
+        ops.set_conv_precision(getattr(opt, 'precision', 'fp32'))
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
         self.loss_names = []
         self.model_names = []

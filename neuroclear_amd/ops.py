@@ -141,7 +141,14 @@ def _lp(what, dims, K, k3, stride, pad):
     N, C, D, H, W = dims
     ok = lib().nc_conv_lp_supported(I(what), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride),
                                     I(pad))
-    return _DT[conv_precision] if ok else 0
+    if not ok:
+        return 0
+    # 'fp16': forward operands in fp16 (11-bit significand); backward operands (dy, and w / x next to it) in bf16 --
+    # gradients of a mean loss over 1e6..1e7 voxels sit below fp16's normal range (6e-5) and there is no loss scaling
+    # in the reference's step to lean on; bf16 has fp32's exponent range (measured: tools/lp_err.py).
+    if conv_precision == 'fp16' and what != 0:
+        return _DT['bf16']
+    return _DT[conv_precision]
 
 
 def _lp_ws(dims, K, k3, stride, pad, device, tag='ws_lp'):

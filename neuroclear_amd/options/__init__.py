@@ -41,6 +41,9 @@ def _base(parser):
     a('--verbose', action='store_true')
     a('--overlap', type=int, default=0)      # added by the dice dataset in the reference (diceImage_dataset.py:16-21)
     a('--border_cut', type=int, default=0)
+    # not in the reference (fp32 only): arithmetic of the 3^3 / 5^3 convolutions, BASELINE.json configs[3].  bf16 / fp16 =
+    # 16-bit MFMA operands with fp32 accumulation; InstanceNorm, losses, Adam and the master weights stay fp32.
+    a('--precision', type=str, default='fp32', choices=['fp32', 'bf16', 'fp16'])
     return parser
 
 

@@ -61,7 +61,8 @@ if __name__ == '__main__':
     for what in whats:
         for prec in ('bf16', 'fp16'):
             for (N, C, K, S, ks) in [(1, 32, 64, 8, 3), (2, 32, 64, (5, 9, 13), 3), (1, 64, 128, 20, 3),
-                                     (1, 128, 64, (7, 30, 37), 3), (1, 64, 64, 36, 3)]:
+                                     (1, 128, 64, (7, 30, 37), 3), (1, 64, 64, 36, 3), (1, 64, 64, 20, 5),
+                                     (2, 32, 64, (6, 11, 23), 5), (1, 64, 64, (9, 40, 52), 5)]:
                 if what == 'dgrad':
                     C, K = K, C
                 bad += one(N, C, K, S, ks, prec, what) > 2e-4
@@ -70,4 +71,6 @@ if __name__ == '__main__':
         one(1, 64, 64, 148, 3, 'bf16', what, True)
         one(1, 128, 128, 74, 3, 'bf16', what, True)
         one(1, 256, 256, 37, 3, 'bf16', what, True)
+        one(1, 64, 64, 108, 5, 'bf16', what, True)
+        one(1, 64, 64, 148, 5, 'bf16', what, True)
     print('BAD' if bad else 'OK', bad)
