@@ -20,6 +20,8 @@
 // wait for the DMA: vmcnt retires in order).  Two stage buffers; the DMA of stage s+1 flies under the MFMAs of s.
 // Tile = 64 output channels x PT flattened positions of one output plane; 8 waves x (2 x VB) accumulator tiles.
 // Persistent workgroups walk XCD-contiguous tile ranges (neighbouring planes share input planes in that XCD's L2).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -142,6 +144,7 @@ struct HParams {
   int SB;             // bytes per stage buffer
   long ntiles;
   int tiles_per_xcd;  // ceil(ntiles / 8)
+  int ablate;         // timing experiments only (env NC_H_ABLATE): 1 no stores, 2 no MFMA loop, 4 no DMA, 8 no LDS reads, 16 no barrier
 };
 
 struct HTile {
@@ -150,10 +153,13 @@ struct HTile {
 
 __device__ __forceinline__ HTile h_decode(const HParams& p, long t) {
   HTile o;
+  // order: output-channel tile fastest, then z, then the position tile, then the sample -- the 32 workgroups of an XCD
+  // work on ~32 consecutive planes of ONE position tile at a time, so the input plane a workgroup stages for dz is the
+  // plane its two z-neighbours stage for dz -+ 1 at about the same moment: two of three fetches hit that XCD's L2
   o.cot = (int)(t % p.KT); t /= p.KT;
-  const int tp = (int)(t % p.TPP); t /= p.TPP;
-  o.z = (int)(t % p.D);
-  o.n = (int)(t / p.D);
+  o.z = (int)(t % p.D); t /= p.D;
+  const int tp = (int)(t % p.TPP);
+  o.n = (int)(t / p.TPP);
   o.q0 = tp * p.PT;
   o.yf = (int)fdiv((unsigned)o.q0, p.mP);
   o.xoff = o.q0 - o.yf * p.P;
@@ -202,6 +208,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
 
   auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
     const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * NB * p.D + (tz + dz - PAD)) * HW;
+    if (p.ablate & 4) return;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int pc = wave + kWaves * j;
@@ -247,8 +254,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
     for (int i = 0; i < nstages; ++i) {
       unsigned char* bc = (g & 1) ? buf1 : buf0;
       unsigned char* bn = (g & 1) ? buf0 : buf1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage i has landed
-      __syncthreads();                                  // ... and everybody's; everybody is done reading bn
+      if (!(p.ablate & 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage i has landed
+        __syncthreads();                                  // ... and everybody's; everybody is done reading bn
+      }
       // next stage of this tile, or the first stage of the next tile
       int nchunk = chunk, ndz = dzi + 1;
       if (ndz == nv) { ndz = 0; ++nchunk; }
@@ -258,7 +267,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         issue(within ? cur.n : nxt.n, within ? cur.z : nxt.z, within ? cur.cot : nxt.cot, within ? nchunk : 0,
               within ? lo + ndz : dz_lo(nxt), bn);
 
-      if constexpr (PAIR) {
+      if (p.ablate & 2) {
+      } else if constexpr (PAIR) {
         const i32x4* wrow = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
         const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
         auto boff = [&](int i) {  // this lane's tap of k-step i, as a unit offset
@@ -310,9 +320,15 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         for (int dx = 0; dx < KS; ++dx) {
           const i32x4* wn = dx + 1 < KS ? wrow + (dx + 1) * 128 : wrow_n;
           const i32x4* bnp = dx + 1 < KS ? brow + dx + 1 : brow_n;
-          na0 = wn[0]; na1 = wn[64];
+          if (p.ablate & 8) {
+            na0 = a0; na1 = a1;
 #pragma unroll
-          for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
+            for (int v = 0; v < VB; ++v) nb[v] = b[v];
+          } else {
+            na0 = wn[0]; na1 = wn[64];
+#pragma unroll
+            for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
+          }
 #pragma unroll
           for (int v = 0; v < VB; ++v) {
             acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
@@ -332,7 +348,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
     }
 
     // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
-    {
+    if (!(p.ablate & 1)) {
       const int cob = cur.cot * 64;
       float bv[2][16];
 #pragma unroll
@@ -469,6 +485,8 @@ int run_h(const float* x, const float* w, const float* bias, float* y, const Con
   p.npb = pl.npb; p.npw = pl.npw; p.SB = pl.SB;
   p.ntiles = (long)d.N * d.D * pl.TPP * p.KT;
   p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
+  static const int ablate = getenv("NC_H_ABLATE") ? atoi(getenv("NC_H_ABLATE")) : 0;
+  p.ablate = ablate;
   const int lds = 2 * pl.SB;
   if (KS == 3) return launch_h_vb<DT, 3>(pl.VB, p, lds, s);
   return launch_h_vb<DT, 5>(pl.VB, p, lds, s);
@@ -509,6 +527,7 @@ struct WhParams {
   int npairs, nwp;   // (k-tile, c-tile) pairs, workgroups per pair
   long steps;        // N * YB * XB * D  (per pair)
   unsigned mTx, mXp, mXUp, mPTp;
+  int ablate;        // timing experiments only (env NC_H_ABLATE): 2 = no MFMA loop, 4 = no DMA
 };
 
 template <int DT, int KS>
@@ -541,6 +560,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
 
   // ---- LDS-DMA of one X plane (4 C8 blocks of this c-tile, tile + halo) / one dY plane (8 blocks of this k-tile)
   auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
+    if (p.ablate & 4) return;
     const bool zok = (unsigned)pz < (unsigned)p.D;
     const uint4* base = p.xh + (((long)n * (p.C / 8) + ct * 4) * p.D + (zok ? pz : 0)) * HW;
 #pragma unroll 1
@@ -557,6 +577,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
   };
   auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
     const uint4* base = p.dyh + (((long)n * (p.K / 8) + kt * 8) * p.D + z) * HW;
+    if (p.ablate & 4) return;
 #pragma unroll 1
     for (int pc = wave; pc < p.npd; pc += kWaves) {
       const unsigned u = (unsigned)(pc * 64 + lane);
@@ -623,7 +644,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
 #pragma unroll
     for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(slot_of(z + zsh + tdz[j]) + toff[j]) + b_lane;
 #pragma unroll 1
-    for (int s = 0; s < p.NK; ++s) {
+    for (int s = 0; s < ((p.ablate & 2) ? 0 : p.NK); ++s) {
       unsigned rho[2], bo[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -756,6 +777,8 @@ int run_wh(const float* x, const float* dy, float* dw, const ConvDims& d, void* 
   p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  static const int ablate = getenv("NC_H_ABLATE") ? atoi(getenv("NC_H_ABLATE")) : 0;
+  p.ablate = ablate;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h<DT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
