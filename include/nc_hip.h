@@ -63,14 +63,21 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or
 #define NC_DT_BF16 2
 int nc_conv_lp_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
 size_t nc_conv_lp_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
-int nc_conv_fwd_lp(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
-                   int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
-int nc_conv_dgrad_lp(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd,
-                     int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
-/* weight gradient: 3^3, C % 32 == 0, K % 64 == 0; dbias (nullable) is summed in fp32 from the fp32 dy */
-int nc_conv_wgrad_lp(const float* x, const float* dy, float* dw, float* dbias /* or NULL */, int N, int C, int D, int H,
-                     int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes,
-                     void* stream);
+/* Operand layout of the 16-bit kernels, "C8": [N][C/8][S voxels][8 channels] 16-bit (S = D*H*W), C % 8 == 0.  Each
+ * operand of the *_lp calls is given EITHER as the fp32 NCDHW tensor (x / dy; converted into the workspace on every
+ * call) OR already converted (xh / dyh non-NULL, then the fp32 pointer may be NULL) -- a caller that needs the same
+ * tensor twice (x: forward and weight gradient; dy: data and weight gradient) converts it once with nc_to_c8.        */
+size_t nc_c8_bytes(int N, int C, long S);
+int nc_to_c8(const float* x, void* xh, int N, int C, long S, int dtype, void* stream);
+int nc_conv_fwd_lp(const float* x, const void* xh, const float* w, const float* bias, float* y, int N, int C, int D, int H,
+                   int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes,
+                   void* stream);
+int nc_conv_dgrad_lp(const float* dy, const void* dyh, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
+                     int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* weight gradient: 3^3 / 5^3, C % 32 == 0, K % 64 == 0; dbias (nullable) is summed in fp32 from the fp32 dy */
+int nc_conv_wgrad_lp(const float* x, const void* xh, const float* dy, const void* dyh, float* dw,
+                     float* dbias /* or NULL */, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw,
+                     int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- ConvTranspose3d(k=2, s=2) (networks.py:500,503): x[N,C,D,H,W], w[C,K,2,2,2], bias[K], y[N,K,2D,2H,2W].   */
 size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K);

@@ -32,7 +32,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         for name in header_symbols():
             fn = getattr(L, name)
-            if name.endswith('_ws_bytes') or name.endswith('_floats'):
+            if name.endswith('_bytes') or name.endswith('_floats'):
                 fn.restype = ctypes.c_size_t
             elif name == 'nc_last_error':
                 fn.restype = ctypes.c_char_p

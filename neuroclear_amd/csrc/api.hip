@@ -105,32 +105,50 @@ size_t nc_conv_lp_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int
   return h_ws_bytes(d);
 }
 
-int nc_conv_fwd_lp(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K,
-                   int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
+static int lp_args(const char* what, ConvDims& d, const void* a, const void* ah, const void* b, const void* o, int N, int C,
+                   int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype) {
+  if ((!a && !ah) || !b || !o) { set_error("%s: null pointer", what); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) { set_error("%s: bad shape", what); return NC_ERR_SHAPE; }
+  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("%s: dtype must be NC_DT_F16 or NC_DT_BF16", what); return NC_ERR_ARG; }
+  return NC_OK;
+}
+
+size_t nc_c8_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : (size_t)N * C * S * 2; }
+
+int nc_to_c8(const float* x, void* xh, int N, int C, long S, int dtype, void* stream) {
+  if (!x || !xh) { set_error("to_c8: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 8 || C % 8 || S < 1) { set_error("to_c8: channels must be a multiple of 8"); return NC_ERR_SHAPE; }
+  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("to_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  return to_c8(x, xh, N, C, S, dtype, (hipStream_t)stream);
+}
+
+int nc_conv_fwd_lp(const float* x, const void* xh, const float* w, const float* bias, float* y, int N, int C, int D, int H,
+                   int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes,
+                   void* stream) {
   ConvDims d;
-  if (int e = conv_args("conv_fwd_lp", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
-  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("conv_fwd_lp: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  if (int e = lp_args("conv_fwd_lp", d, x, xh, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad, dtype)) return e;
   if (!h_fwd_supported(d)) { set_error("conv_fwd_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
-  return conv_fwd_h(x, w, bias, y, d, dtype, ws, ws_bytes, (hipStream_t)stream);
+  return conv_fwd_h(x, xh, w, bias, y, d, dtype, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int nc_conv_dgrad_lp(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int kd, int kh,
-                     int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
-  ConvDims d;
-  if (int e = conv_args("conv_dgrad_lp", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
-  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("conv_dgrad_lp: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
-  if (!h_dgrad_supported(d)) { set_error("conv_dgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
-  return conv_dgrad_h(dy, w, dx, d, dtype, ws, ws_bytes, (hipStream_t)stream);
-}
-
-int nc_conv_wgrad_lp(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W, int K,
+int nc_conv_dgrad_lp(const float* dy, const void* dyh, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
                      int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
   ConvDims d;
-  if (int e = conv_args("conv_wgrad_lp", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
-  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("conv_wgrad_lp: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  if (int e = lp_args("conv_dgrad_lp", d, dy, dyh, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad, dtype)) return e;
+  if (!h_dgrad_supported(d)) { set_error("conv_dgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  return conv_dgrad_h(dy, dyh, w, dx, d, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_wgrad_lp(const float* x, const void* xh, const float* dy, const void* dyh, float* dw, float* dbias, int N, int C,
+                     int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws,
+                     size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = lp_args("conv_wgrad_lp", d, x, xh, dw, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad, dtype)) return e;
+  if (!dy && !dyh) { set_error("conv_wgrad_lp: null pointer"); return NC_ERR_ARG; }
+  if (dbias && !dy) { set_error("conv_wgrad_lp: the bias gradient needs the fp32 dy"); return NC_ERR_ARG; }
   if (!h_wgrad_supported(d)) { set_error("conv_wgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
   hipStream_t s = (hipStream_t)stream;
-  if (int e = conv_wgrad_h(x, dy, dw, d, dtype, ws, ws_bytes, s)) return e;
+  if (int e = conv_wgrad_h(x, xh, dy, dyh, dw, d, dtype, ws, ws_bytes, s)) return e;
   if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);  // fp32, from the fp32 dy
   return NC_OK;
 }

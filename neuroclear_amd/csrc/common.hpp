@@ -94,17 +94,19 @@ bool c1_wgrad_supported(const ConvDims& d);
 size_t c1_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 
-// ---- 16-bit (bf16 / fp16) MFMA convolutions, conv_h.hip
+// ---- 16-bit (bf16 / fp16) MFMA convolutions, conv_h.hip.  Each operand comes either as the fp32 tensor (converted
+//      into the workspace) or already converted to the C8 layout (xh / dyh non-null, nc_to_c8)
 bool h_fwd_supported(const ConvDims& d);
 bool h_dgrad_supported(const ConvDims& d);
 bool h_wgrad_supported(const ConvDims& d);
-int conv_wgrad_h(const float* x, const float* dy, float* dw, const ConvDims& d, int dt, void* ws, size_t wsb,
-                 hipStream_t s);
 size_t h_ws_bytes(const ConvDims& d);
-int conv_fwd_h(const float* x, const float* w, const float* b, float* y, const ConvDims& d, int dt, void* ws, size_t wsb,
-               hipStream_t s);
-int conv_dgrad_h(const float* dy, const float* w, float* dx, const ConvDims& d, int dt, void* ws, size_t wsb,
-                 hipStream_t s);
+int to_c8(const float* x, void* xh, int N, int C, long S, int dt, hipStream_t s);
+int conv_fwd_h(const float* x, const void* xh, const float* w, const float* b, float* y, const ConvDims& d, int dt,
+               void* ws, size_t wsb, hipStream_t s);
+int conv_dgrad_h(const float* dy, const void* dyh, const float* w, float* dx, const ConvDims& d, int dt, void* ws,
+                 size_t wsb, hipStream_t s);
+int conv_wgrad_h(const float* x, const void* xh, const float* dy, const void* dyh, float* dw, const ConvDims& d, int dt,
+                 void* ws, size_t wsb, hipStream_t s);
 
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;

@@ -455,20 +455,22 @@ int launch_h_vb(int VB, const HParams& p, int lds, hipStream_t s) {
 
 // x: fp32 [N][Cin][D][H][W]; w: fp32 master weights; y: fp32 [N][Kout][D][H][W].  so/si/flip: see k_pack_w_h.
 template <int DT>
-int run_h(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout, long so,
-          long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+int run_h(const float* x, const void* xh_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin,
+          int Kout, long so, long si, int flip, void* ws, size_t wsb, hipStream_t s) {
   const int KS = d.kd, T3 = KS * KS * KS;
   const HPlan pl = h_plan(d);
   const long S = (long)d.D * d.H * d.W;
-  const size_t xb = align256((size_t)d.N * Cin * S * 2);
+  const size_t xb = xh_pre ? 0 : align256((size_t)d.N * Cin * S * 2);
   const size_t wb = align256(packed_bytes(Cin, Kout, KS));
   if (!ws || wsb < xb + wb + 256) { set_error("conv_h: workspace too small"); return NC_ERR_WS; }
-  uint4* xh = (uint4*)ws;
+  uint4* xh = xh_pre ? (uint4*)xh_pre : (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
   uint4* zeros = (uint4*)((char*)ws + xb + wb);
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_h: memset failed"); return NC_ERR_HIP; }
-  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
-  if (int e = check_launch("to_c8")) return e;
+  if (!xh_pre) {
+    hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
+    if (int e = check_launch("to_c8")) return e;
+  }
   const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
   if (KS == 5)
     hipLaunchKernelGGL((k_pack_w_h8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip,
@@ -750,25 +752,28 @@ bool wh_shape_ok(const ConvDims& d) {
 }
 
 template <int DT>
-int run_wh(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+int run_wh(const float* x, const void* xh_pre, const float* dy, const void* dyh_pre, float* dw, const ConvDims& d, void* ws,
+           size_t wsb, hipStream_t s) {
   const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
   const WhPlan pl = wh_plan(d);
   const long S = (long)d.D * d.H * d.W;
-  const size_t xb = align256((size_t)d.N * d.C * S * 2);
-  const size_t yb = align256((size_t)d.N * d.K * S * 2);
+  const size_t xb = xh_pre ? 0 : align256((size_t)d.N * d.C * S * 2);
+  const size_t yb = dyh_pre ? 0 : align256((size_t)d.N * d.K * S * 2);
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
   int nwp = 256 / npairs;
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
   if (nwp > steps) nwp = (int)steps;
   const size_t pb = align256((size_t)npairs * nwp * TW * 64 * 32 * 4);
   if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_h: workspace too small"); return NC_ERR_WS; }
-  uint4* xh = (uint4*)ws;
-  uint4* dyh = (uint4*)((char*)ws + xb);
+  uint4* xh = xh_pre ? (uint4*)xh_pre : (uint4*)ws;
+  uint4* dyh = dyh_pre ? (uint4*)dyh_pre : (uint4*)((char*)ws + xb);
   float* part = (float*)((char*)ws + xb + yb);
   uint4* zeros = (uint4*)((char*)ws + xb + yb + pb);
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("wgrad_h: memset failed"); return NC_ERR_HIP; }
-  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xh, S, d.C);
-  hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dyh, S, d.K);
+  if (!xh_pre)
+    hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xh, S, d.C);
+  if (!dyh_pre)
+    hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dyh, S, d.K);
   if (int e = check_launch("to_c8")) return e;
   WhParams p{};
   p.xh = xh; p.dyh = dyh; p.part = part; p.zeros = zeros;
@@ -819,24 +824,32 @@ size_t h_ws_bytes(const ConvDims& d) {
   return b;
 }
 
-int conv_wgrad_h(const float* x, const float* dy, float* dw, const ConvDims& d, int dt, void* ws, size_t wsb,
-                 hipStream_t s) {
-  if (dt == NC_DT_F16) return run_wh<NC_DT_F16>(x, dy, dw, d, ws, wsb, s);
-  return run_wh<NC_DT_BF16>(x, dy, dw, d, ws, wsb, s);
+int conv_wgrad_h(const float* x, const void* xh, const float* dy, const void* dyh, float* dw, const ConvDims& d, int dt,
+                 void* ws, size_t wsb, hipStream_t s) {
+  if (dt == NC_DT_F16) return run_wh<NC_DT_F16>(x, xh, dy, dyh, dw, d, ws, wsb, s);
+  return run_wh<NC_DT_BF16>(x, xh, dy, dyh, dw, d, ws, wsb, s);
 }
 
-int conv_fwd_h(const float* x, const float* w, const float* b, float* y, const ConvDims& d, int dt, void* ws, size_t wsb,
-               hipStream_t s) {
-  const long T3 = (long)d.kd * d.kh * d.kw;
-  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(x, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
-  return run_h<NC_DT_BF16>(x, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+int to_c8(const float* x, void* xh, int N, int C, long S, int dt, hipStream_t s) {
+  if (dt == NC_DT_F16)
+    hipLaunchKernelGGL((k_to_c8<NC_DT_F16>), dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xh, S, C);
+  else
+    hipLaunchKernelGGL((k_to_c8<NC_DT_BF16>), dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xh, S, C);
+  return check_launch("to_c8");
 }
 
-int conv_dgrad_h(const float* dy, const float* w, float* dx, const ConvDims& d, int dt, void* ws, size_t wsb,
-                 hipStream_t s) {
+int conv_fwd_h(const float* x, const void* xh, const float* w, const float* b, float* y, const ConvDims& d, int dt,
+               void* ws, size_t wsb, hipStream_t s) {
   const long T3 = (long)d.kd * d.kh * d.kw;
-  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(dy, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
-  return run_h<NC_DT_BF16>(dy, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(x, xh, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+  return run_h<NC_DT_BF16>(x, xh, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+}
+
+int conv_dgrad_h(const float* dy, const void* dyh, const float* w, float* dx, const ConvDims& d, int dt, void* ws,
+                 size_t wsb, hipStream_t s) {
+  const long T3 = (long)d.kd * d.kh * d.kw;
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(dy, dyh, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
+  return run_h<NC_DT_BF16>(dy, dyh, w, nullptr, dx, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s);
 }
 
 }  // namespace nc

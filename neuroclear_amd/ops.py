@@ -151,13 +151,28 @@ def _lp(what, dims, K, k3, stride, pad):
     return _DT[conv_precision]
 
 
+def to_c8(x, dt):
+    """fp32 NCDHW -> the 16-bit C8 operand layout of the *_lp kernels (include/nc_hip.h); returns a byte tensor."""
+    _chk(x)
+    _f32(x)
+    N, C = x.shape[0], x.shape[1]
+    S = x.numel() // (N * C)
+    out = torch.empty(N * C * S * 2, dtype=torch.uint8, device=x.device)
+    e0 = _prof_begin()
+    check(lib().nc_to_c8(_ptr(x), _ptr(out), I(N), I(C), L_(S), I(dt), _stream()), 'nc_to_c8')
+    if e0 is not None:
+        _prof_end(e0, 'to_c8', 0.0)
+    return out
+
+
 def _lp_ws(dims, K, k3, stride, pad, device, tag='ws_lp'):
     N, C, D, H, W = dims
     nb = lib().nc_conv_lp_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
     return workspace(nb, device, tag)
 
 
-def conv_fwd_raw(x, w, b, stride, pad):
+def conv_fwd_raw(x, w, b, stride, pad, xh=None):
+    """xh: x already in the C8 layout (to_c8) for the 16-bit kernel of this call -- saves the conversion."""
     _chk(x, w, b)
     _f32(x, w, b)
     dims = _dims5(x.shape)
@@ -171,7 +186,7 @@ def conv_fwd_raw(x, w, b, stride, pad):
     if dt:
         ws = _lp_ws(dims, K, k3, stride, pad, x.device)
         e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (y.numel() // K))
-        check(lib().nc_conv_fwd_lp(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+        check(lib().nc_conv_fwd_lp(_ptr(x), _ptr(xh), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                                    I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
               'nc_conv_fwd_lp')
         if e0 is not None:
@@ -186,7 +201,7 @@ def conv_fwd_raw(x, w, b, stride, pad):
     return y
 
 
-def conv_dgrad_raw(dy, w, x_shape, stride, pad):
+def conv_dgrad_raw(dy, w, x_shape, stride, pad, dyh=None):
     _chk(dy, w)
     _f32(dy, w)
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
@@ -198,7 +213,7 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     if dt:
         ws = _lp_ws(dims, K, k3, stride, pad, dy.device)
         e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
-        check(lib().nc_conv_dgrad_lp(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+        check(lib().nc_conv_dgrad_lp(_ptr(dy), _ptr(dyh), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                                      I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
               'nc_conv_dgrad_lp')
         if e0 is not None:
@@ -213,20 +228,23 @@ def conv_dgrad_raw(dy, w, x_shape, stride, pad):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws'):
+def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws', xh=None, dyh=None, x_shape=None):
+    """x may be None when xh (its C8 copy) and x_shape are given: the 16-bit weight gradient never reads the fp32 x."""
     _chk(x, dy)
     _f32(x, dy)
-    dims = _dims5(x.shape)
+    dims = _dims5(x.shape if x is not None else x_shape)
     N, C, D, H, W = dims
     K = w_shape[0]
     k3 = _kdims(w_shape)
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-    db = torch.empty(K, dtype=torch.float32, device=x.device) if want_bias else None
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dy.device)
+    db = torch.empty(K, dtype=torch.float32, device=dy.device) if want_bias else None
     dt = _lp(2, dims, K, k3, stride, pad)
+    if x is None and not dt:
+        raise _lib.NcError('conv_wgrad: the fp32 x is needed for the fp32 kernels')
     if dt:
-        ws = _lp_ws(dims, K, k3, stride, pad, x.device, ws_tag + '_lp')
+        ws = _lp_ws(dims, K, k3, stride, pad, dy.device, ws_tag + '_lp')
         e0 = _prof_begin(2.0 * C * K * k3[0] * k3[1] * k3[2] * (dy.numel() // K))
-        check(lib().nc_conv_wgrad_lp(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+        check(lib().nc_conv_wgrad_lp(_ptr(x), _ptr(xh), _ptr(dy), _ptr(dyh), _ptr(dw), _ptr(db), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
                                      I(k3[1]), I(k3[2]), I(stride), I(pad), I(dt), _ptr(ws), Z(ws.numel()), _stream()),
               'nc_conv_wgrad_lp')
         if e0 is not None:
@@ -246,8 +264,21 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
         x = x.contiguous()
-        ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, b is not None)
+        ctx.x_shape = tuple(x.shape)
+        dims, K, k3 = _dims5(x.shape), w.shape[0], _kdims(w.shape)
+        dt = _lp(0, dims, K, k3, stride, pad) if w.shape[1] == x.shape[1] else 0
+        if dt:
+            # 16-bit path: x is converted ONCE; if the weight gradient runs in the same type it reuses that copy, and the
+            # copy (half the bytes) is what is kept for backward instead of the fp32 activation
+            xh = to_c8(x, dt)
+            y = conv_fwd_raw(x, w, b, stride, pad, xh=xh)
+            keep = _lp(2, dims, K, k3, stride, pad) == dt
+            ctx.x_is_c8 = keep
+            ctx.save_for_backward(xh if keep else x, w)
+            return y
+        ctx.x_is_c8 = False
+        ctx.save_for_backward(x, w)
         return conv_fwd_raw(x, w, b, stride, pad)
 
     @staticmethod
@@ -258,6 +289,21 @@ class _Conv(torch.autograd.Function):
         dx = dw = db = None
         want_b = has_b and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
+        dims, K, k3 = _dims5(ctx.x_shape), w.shape[0], _kdims(w.shape)
+        dt_d = _lp(1, dims, K, k3, stride, pad) if ctx.needs_input_grad[0] else 0
+        dt_w = _lp(2, dims, K, k3, stride, pad) if want_w else 0
+        if dt_d or dt_w:  # 16-bit backward: dy is converted once for the data and the weight gradient
+            dyh = to_c8(dy, dt_d or dt_w)
+            if ctx.needs_input_grad[0]:
+                dx = conv_dgrad_raw(dy, w, ctx.x_shape, stride, pad, dyh=dyh if dt_d else None)
+            if want_w:
+                same = dt_w and (not dt_d or dt_d == dt_w)
+                if ctx.x_is_c8:
+                    dw, db = conv_wgrad_raw(None, dy, w.shape, stride, pad, want_b, xh=x, dyh=dyh if same else None,
+                                            x_shape=ctx.x_shape)
+                else:
+                    dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b, dyh=dyh if same else None)
+            return dx, dw, db, None, None
         big = x.numel() >= (1 << 20)  # small layers gain nothing from a second stream
         if want_w and ctx.needs_input_grad[0] and overlap_wgrad and big and prof is None:
             main = torch.cuda.current_stream()

@@ -77,6 +77,27 @@ def test_lp_conv_matches_rounded_operands(case, prec):
     close(db, dy.sum((0, 2, 3, 4)), 1e-5)  # bias gradient: fp32 sum of the fp32 dy
 
 
+def test_lp_preconverted_operands_give_identical_results():
+    """xh / dyh (nc_to_c8 once, reused by forward + weight gradient / data + weight gradient) vs per-call conversion."""
+    from neuroclear_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn(2, 64, 6, 20, 28, device='cuda', generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, device='cuda', generator=g) * 0.02
+    dy = torch.randn(2, 64, 6, 20, 28, device='cuda', generator=g)
+    ops.set_conv_precision('bf16')
+    xh, dyh = ops.to_c8(x, 2), ops.to_c8(dy, 2)
+    assert xh.numel() == x.numel() * 2
+    assert torch.equal(ops.conv_fwd_raw(x, w, None, 1, 1), ops.conv_fwd_raw(x, w, None, 1, 1, xh=xh))
+    assert torch.equal(ops.conv_dgrad_raw(dy, w, x.shape, 1, 1), ops.conv_dgrad_raw(dy, w, x.shape, 1, 1, dyh=dyh))
+    a, _ = ops.conv_wgrad_raw(x, dy, w.shape, 1, 1, False)
+    b, _ = ops.conv_wgrad_raw(None, dy, w.shape, 1, 1, False, xh=xh, dyh=dyh, x_shape=x.shape)
+    assert torch.equal(a, b)
+    # and through autograd (which keeps the C8 copy of x instead of x)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ops.conv(xr, wr, None, 1, 1).backward(dy)
+    assert torch.equal(wr.grad, a) and torch.equal(xr.grad, ops.conv_dgrad_raw(dy, w, x.shape, 1, 1))
+
+
 def test_lp_unsupported_shape_is_refused():
     """The 16-bit entry points never fall back: a shape they do not cover is an error at the C ABI."""
     from neuroclear_amd import _lib, ops
@@ -85,10 +106,10 @@ def test_lp_unsupported_shape_is_refused():
     y = torch.empty(1, 64, 8, 8, 8, device='cuda')
     ws = torch.empty(1 << 20, dtype=torch.uint8, device='cuda')
     L = _lib.lib()
-    rc = L.nc_conv_fwd_lp(ops._ptr(x), ops._ptr(w), None, ops._ptr(y), 1, 1, 8, 8, 8, 64, 3, 3, 3, 1, 1, 2, ops._ptr(ws),
+    rc = L.nc_conv_fwd_lp(ops._ptr(x), None, ops._ptr(w), None, ops._ptr(y), 1, 1, 8, 8, 8, 64, 3, 3, 3, 1, 1, 2, ops._ptr(ws),
                           _lib.Z(ws.numel()), None)
     assert rc == -1 and b'not covered' in L.nc_last_error()
-    rc = L.nc_conv_fwd_lp(ops._ptr(x), ops._ptr(w), None, ops._ptr(y), 1, 1, 8, 8, 8, 64, 3, 3, 3, 1, 1, 7, ops._ptr(ws),
+    rc = L.nc_conv_fwd_lp(ops._ptr(x), None, ops._ptr(w), None, ops._ptr(y), 1, 1, 8, 8, 8, 64, 3, 3, 3, 1, 1, 7, ops._ptr(ws),
                           _lib.Z(ws.numel()), None)
     assert rc == -4
 
