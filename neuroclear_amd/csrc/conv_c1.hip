@@ -404,7 +404,9 @@ struct T1Params {
   const float* w;
   float* slab;         // [7 dz][N][D][H][W]
   const float* zeros;
-  int N, D, H, W;
+  int N, D, H, W;      // W = width of the column segment this launch works on
+  int Wf, x0;          // row pitch of the tensors, first column of the segment (x0 % 4 == 0)
+  int kx0, kx1;        // segment columns [kx0, kx1) are written (the rest is the 3-column overlap with the neighbour)
   int PAr, SD;         // dY LDS pitch per channel (= 16 mod 32), floats per dY buffer (whole pieces)
   int W16;
   int parts;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(512) void k_dgrad_to1(T1Params p) {
   const int dz = 2 * blockIdx.y + dzi;  // kernel plane of this half of the workgroup (7 = none)
   const bool wave_on = dz < KS;
   const int part = blockIdx.x;
-  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const long HW = (long)p.H * p.Wf, S = (long)p.D * HW;
   const long nrows = (long)p.N * p.D * p.H;  // rows (n, z', y') of dY
   const long r0 = nrows * part / p.parts, r1 = nrows * (part + 1) / p.parts;
 
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(512) void k_dgrad_to1(T1Params p) {
     gd[i] = (c < 64 && col < p.W) ? (int)(c * S + col) : -1;
   }
   auto issue = [&](int n, int z, int y, int buf) {
-    const float* dbse = p.dy + (long)n * 64 * S + (long)z * HW + (long)y * p.W;
+    const float* dbse = p.dy + (long)n * 64 * S + (long)z * HW + (long)y * p.Wf + p.x0;
     float* ds = dyT + buf * p.SD;
 #pragma unroll
     for (int i = 0; i < MAXPD; ++i) {
@@ -524,7 +526,8 @@ __global__ __launch_bounds__(512) void k_dgrad_to1(T1Params p) {
             for (int dx = 0; dx < KS; ++dx) c += zs[(8 * e + dx) * kZsPitch + 4 + x + PAD - dx];
             const float tot = rrow[x] + c;
             if (dyy == 0 || cy == p.H - 1) {  // last addend of this output row (input row oy + 3, or the plane's last)
-              p.slab[(((long)dz * p.N + cn) * p.D + oz) * HW + (long)oy * p.W + x] = tot;
+              if (x >= p.kx0 && x < p.kx1)
+                p.slab[(((long)dz * p.N + cn) * p.D + oz) * HW + (long)oy * p.Wf + p.x0 + x] = tot;
               rrow[x] = 0.f;
             } else {
               rrow[x] = tot;
@@ -553,7 +556,7 @@ __global__ void k_dgrad_to1_reduce(const float* __restrict__ slab, float* __rest
 
 bool to1_mfma_supported(const ConvDims& d) {
   return d.C == 1 && d.K == 64 && d.kd == 7 && d.kh == 7 && d.kw == 7 && d.sd == 1 && d.sh == 1 && d.sw == 1 &&
-         d.pd == 3 && d.ph == 3 && d.pw == 3 && d.W % 4 == 0 && d.W >= 16 && d.W <= 112 &&
+         d.pd == 3 && d.ph == 3 && d.pw == 3 && d.W % 4 == 0 && d.W >= 16 && d.W <= 208 &&
          (long)d.D * d.H * d.W * 64 < (1L << 31);
 }
 
@@ -579,8 +582,16 @@ int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDi
   }
   T1Params p{};
   p.dy = dy; p.w = w; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
-  p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
-  p.W16 = (d.W + 15) & ~15;
+  p.N = d.N; p.D = d.D; p.H = d.H; p.Wf = d.W;
+  // rows wider than 112 columns (the Z strips and the ring are sized for 112) are done as two column segments that
+  // overlap by the 3-column reach of the kernel on either side of the cut; each writes its own half of the row
+  const int nseg = d.W <= 112 ? 1 : 2;
+  const int cut = nseg == 1 ? d.W : ((d.W / 2 + 3) & ~3);  // first column of the second half, a multiple of 4
+  for (int seg = 0; seg < nseg; ++seg) {
+  if (nseg == 1) { p.x0 = 0; p.W = d.W; p.kx0 = 0; p.kx1 = d.W; }
+  else if (seg == 0) { p.x0 = 0; p.W = cut + 4; p.kx0 = 0; p.kx1 = cut; }
+  else { p.x0 = cut - 4; p.W = d.W - p.x0; p.kx0 = 4; p.kx1 = p.W; }
+  p.W16 = (p.W + 15) & ~15;
   int pa = (p.W16 + 15) & ~15;
   if (pa % 32 != 16) pa += 16;  // = 16 (mod 32): the two k rows of a half-wave read disjoint banks
   p.PAr = pa;
@@ -599,6 +610,7 @@ int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDi
   }
   hipLaunchKernelGGL(k_dgrad_to1, dim3(p.parts, 4), dim3(512), lds_bytes, s, p);
   if (int e = check_launch("dgrad_to1")) return e;
+  }
   hipLaunchKernelGGL(k_dgrad_to1_reduce, dim3(2048), dim3(256), 0, s, (const float*)ws, dx, d.N, d.D,
                      (long)d.H * d.W);
   return check_launch("dgrad_to1_reduce");

@@ -48,6 +48,8 @@ CONV_CASES = [
     (2, 1, 64, (7, 11, 36), 3, 1, 1),        # same, 3^3, batch 2
     (2, 1, 64, (5, 30, 24), 7, 1, 3),        # MFMA 64 -> 1 data gradient: row ranges that split planes (halo rows)
     (2, 1, 64, (9, 10, 70), 7, 1, 3),        # 7^3, ragged: exercises tile edges of the many->one dgrad kernel
+    (1, 1, 64, (8, 9, 148), 7, 1, 3),        # W > 112: the 64 -> 1 data gradient runs as two column segments
+    (1, 1, 64, (7, 8, 116), 7, 1, 3),        # same, narrowest two-segment case
     (1, 64, 1, (10, 10, 10), 1, 1, 0),
     (1, 1, 1, (8, 8, 8), 1, 1, 0),
     (1, 64, 32, (6, 6, 6), 1, 1, 0),
