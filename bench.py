@@ -42,13 +42,20 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 
 
 PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
-             'dgrad_mfma_k5': 'conv_mfma_k5', 'wgrad_mfma_k3': 'wgrad_mfma_k3', 'wgrad_mfma_k5': 'wgrad_mfma_k5'}
+             'dgrad_mfma_k5': 'conv_mfma_k5', 'wgrad_mfma_k3': 'wgrad_mfma_k3', 'wgrad_mfma_k5': 'wgrad_mfma_k5',
+             # 16-bit classes: measured on ONE shape (64 -> 64, 4 x 148^3), so only reported for that workload
+             'fwd_lp_k3': 'conv_h_k3', 'dgrad_lp_k3': 'conv_h_k3', 'fwd_lp_k5': 'conv_h_k5', 'dgrad_lp_k5': 'conv_h_k5',
+             'wgrad_lp_k3': 'wgrad_h_k3', 'wgrad_lp_k5': 'wgrad_h_k5'}
 
 
-def pmc_traffic(tag):
+def pmc_traffic(tag, crop=108, batch=1):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
     (profiles/r01_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
+    if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
+        return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
+    if '_lp_' not in tag and (crop != 108 or batch != 1):
+        return None
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
             return round(json.load(f)['classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
@@ -160,7 +167,7 @@ def run_train(args, rank, world, dev):
         peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_F32_PEAK_TFLOPS
         roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
                     peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=pmc_traffic(top), launches=n, avg_launch_ms=round(ms / n, 4),
+                    traffic=pmc_traffic(top, crop, args.batch), launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
