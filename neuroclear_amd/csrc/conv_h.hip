@@ -548,7 +548,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
   const int ntap = TW / 4 + (tg < TW % 4 ? 1 : 0);
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
-  const int wg = blockIdx.x;
+  // Workgroups that share operands -- the pairs of one step range: same dY, and the kernel planes of a 5^3 layer the
+  // same X -- should sit on ONE XCD (one L2).  Hardware deals blockIdx round-robin over the 8 XCDs, so the logical id
+  // counts the workgroups of XCD 0 first, then XCD 1, ...: consecutive logical ids are neighbours on an XCD.
+  const int G = gridDim.x, xcd = blockIdx.x & 7;
+  const int wg = (G >> 3) * xcd + ((G & 7) < xcd ? (G & 7) : xcd) + (blockIdx.x >> 3);
   const int pair = wg % p.npairs, wi = wg / p.npairs;
   if (wi >= p.nwp) return;
   const int dzg = pair % NDG, kc = pair / NDG;
