@@ -167,6 +167,13 @@ int nc_radix_hist(const float* x, long n, int pass, unsigned prefix, unsigned* h
 int nc_assemble_rescale_finalize(const float* merged, void* out, int out_is_u16, int L0, int L1, int L2, int roi,
                                  int overlap, float lo, float hi, float range, void* stream);
 
+/* ---- --histogram_match (util/assemble_dice.py:149-151): skimage.exposure.match_histograms(fake_cube, real_cube) on
+ *      the border-cropped cubes, restated from scikit-image 0.18.3 (_match_cumulative_cdf: np.unique + np.cumsum +
+ *      np.interp, float64).  source / tmpl / out: n floats each (out = the float64 result rounded to float32).      */
+size_t nc_match_histograms_ws_bytes(long n);
+int nc_match_histograms(const float* source, const float* tmpl, float* out, long n, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* ---- Whole-network PatchGAN (NLayerDiscriminator with InstanceNorm, networks.py:1009-1067; called from
  *      apollo_model.py:195-283 through netD_*): forward and backward as ONE call each (the op-by-op path is
  *      host-enqueue-bound on these ~25-kernel chains).  params = the 2 * (n_layers + 2) tensors in state-dict order,

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .data.diceImage_dataset import DiceImageDataSet
-from .util.assemble_dice import Assemble_Dice
+from .util.assemble_dice import Assemble_Dice, match_cube
 
 
 def sharded_cube_loop(n, rank, world, produce, consume, empty_like):
@@ -41,10 +41,17 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None):
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
     asm = Assemble_Dice(opt, ds.size_original()) if rank == 0 else None
     E = opt.dice_size[0] + 2 * opt.border_cut
+    hm = bool(getattr(opt, 'histogram_match', False))  # the producing rank matches its own cube (it holds the input)
+
+    def produce(i):
+        x = ds[i]['A'].unsqueeze(0)
+        y = netG(x).reshape(E, E, E)
+        return match_cube(y, x, opt.dice_size[0], opt.border_cut, ds.device) if hm else y
+
     with torch.no_grad():
         sharded_cube_loop(
             n, rank, world,
-            produce=lambda i: netG(ds[i]['A'].unsqueeze(0)).reshape(E, E, E),
+            produce=produce,
             consume=lambda j, tile: asm.add_cube('fake', tile, j),
             empty_like=lambda: torch.zeros((E, E, E), dtype=torch.float32, device=ds.device))
     if rank != 0:

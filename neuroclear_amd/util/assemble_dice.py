@@ -7,7 +7,9 @@ in arrival = index order, exactly the reference's summation order), assemble_all
 `--normalize_intensity` (:188-192) runs on the device too: exact percentiles of the merged, still padded volume by radix
 select (util/percentile.py restates np.percentile of the reference's numpy 1.21.2), then the arithmetic of
 skimage.exposure.rescale_intensity (0.18.3) on a float32 image -- third-party arithmetic restated from its source,
-parity unpinned (scikit-image is not installed here).  `--histogram_match` (skimage match_histograms per cube) raises."""
+parity unpinned (scikit-image is not installed here).  `--histogram_match` (:149-151, skimage match_histograms of every
+border-cropped output cube against its input cube) is nc_match_histograms: radix sort of both cubes + np.interp's
+arithmetic in float64 on the device, restated from scikit-image 0.18.3, parity unpinned for the same reason."""
 from collections import OrderedDict
 
 import numpy as np
@@ -15,6 +17,33 @@ import torch
 
 from .._lib import I, P, check, lib
 from . import util
+
+
+def match_histograms(source, template):
+    """skimage.exposure.match_histograms(source, template) on the device (float32 tensors of equal size)."""
+    from .._lib import L_, Z
+    src = source.contiguous().float()
+    tm = template.contiguous().float()
+    if src.numel() != tm.numel() or not src.is_cuda or not tm.is_cuda:
+        raise ValueError('match_histograms: two CUDA tensors of equal size expected')
+    n = src.numel()
+    out = torch.empty_like(src)
+    nb = lib().nc_match_histograms_ws_bytes(L_(n))
+    ws = torch.empty(nb, dtype=torch.uint8, device=src.device)
+    check(lib().nc_match_histograms(P(src.data_ptr()), P(tm.data_ptr()), P(out.data_ptr()), L_(n), P(ws.data_ptr()), Z(nb),
+                                    P(torch.cuda.current_stream().cuda_stream)), 'nc_match_histograms')
+    return out
+
+
+def match_cube(fake, real, roi_size, border_cut, device):
+    """util/assemble_dice.py:149-151: the border-cropped fake cube matched to the border-cropped real cube; returns the
+    (R+2b)^3 fake cube with its interior replaced (the border is dropped by add_cube anyway)."""
+    E, b = roi_size + 2 * border_cut, border_cut
+    fake = fake.reshape(E, E, E).to(device, torch.float32)
+    real = real.reshape(E, E, E).to(device, torch.float32)
+    out = fake.clone()
+    out[b:-b, b:-b, b:-b] = match_histograms(fake[b:-b, b:-b, b:-b], real[b:-b, b:-b, b:-b])
+    return out
 
 
 class Assemble_Dice:
@@ -31,9 +60,7 @@ class Assemble_Dice:
         if self.overlap < 1:
             raise ValueError('overlap must be >= 1: the reference assembler adds nothing for overlap 0 '
                              '(util/assemble_dice.py:170) and returns an all-zero volume')
-        if getattr(opt, 'histogram_match', False):
-            raise NotImplementedError('--histogram_match is third-party (scikit-image match_histograms) '
-                                      'post-processing outside the pinned hot path (SURVEY.md 8c/8f)')
+        self.histogram_match = bool(getattr(opt, 'histogram_match', False))
         self.normalize_intensity = bool(getattr(opt, 'normalize_intensity', False))
         self.p1, self.p99 = getattr(opt, 'sat_level', [0.25, 99.75])  # options/test_options.py:25
         self.step = self.roi_size - self.overlap
@@ -77,8 +104,14 @@ class Assemble_Dice:
                                             I(self.roi_size), I(self.overlap), I(self.border_cut), I(int(index)),
                                             P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_scatter_add')
 
+    def match_cube(self, fake, real):
+        return match_cube(fake, real, self.roi_size, self.border_cut, self.device)
+
     def addToStack(self, cube):
         """cube: OrderedDict {'real': [1,1,E,E,E], 'fake': ...} as returned by model.get_current_visuals()."""
+        if self.histogram_match:
+            cube = OrderedDict(cube)
+            cube['fake'] = self.match_cube(cube['fake'], cube['real'])
         for name in self.visual_names:
             if self.skip_real and name == 'real':
                 continue

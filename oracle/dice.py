@@ -124,3 +124,16 @@ def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_typ
         acc = acc.astype(np.uint16)
     pads = [padded_shape[i] - original_shape[i] for i in range(3)]
     return acc[:-pads[0], :-pads[1], :-pads[2]]
+
+
+def match_histograms_np(source, template):
+    """skimage.exposure.match_histograms(image, reference) for single-channel arrays, restated from scikit-image 0.18.3
+    (exposure/histogram_matching.py::_match_cumulative_cdf) -- the reference calls it per cube at
+    util/assemble_dice.py:150-151.  PARITY UNPINNED against scikit-image itself (not installed here); the two numpy
+    functions it is made of (np.unique, np.interp) are the real ones.  Returns float64, like scikit-image."""
+    src_values, src_unique_indices, src_counts = np.unique(source.ravel(), return_inverse=True, return_counts=True)
+    tmpl_values, tmpl_counts = np.unique(template.ravel(), return_counts=True)
+    src_quantiles = np.cumsum(src_counts) / source.size
+    tmpl_quantiles = np.cumsum(tmpl_counts) / template.size
+    interp_a_values = np.interp(src_quantiles, tmpl_quantiles, tmpl_values)
+    return interp_a_values[src_unique_indices.ravel()].reshape(source.shape)
