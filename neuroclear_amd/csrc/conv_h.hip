@@ -144,7 +144,7 @@ struct HParams {
   int SB;             // bytes per stage buffer
   long ntiles;
   int tiles_per_xcd;  // ceil(ntiles / 8)
-  int ablate;         // timing experiments only (env NC_H_ABLATE): 1 no stores, 2 no MFMA loop, 4 no DMA, 8 no LDS reads, 16 no barrier
+  int ablate;         // timing experiments only (env NC_H_ABLATE): 1 no stores, 2 no MFMA loop, 4 no DMA, 8 no LDS reads, 16 no barrier, 32 every tile stages the same plane (all L2 hits)
 };
 
 struct HTile {
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
     const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * NB * p.D + (tz + dz - PAD)) * HW;
     if (p.ablate & 4) return;
+    if (p.ablate & 32) plane = p.xh + ((long)chunk * NB * p.D + 1) * HW;  // every tile stages the same plane: all L2 hits
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int pc = wave + kWaves * j;
