@@ -134,13 +134,19 @@ def set_conv_precision(name):
     conv_precision = name
 
 
+_lp_cache = {}
+
+
 def _lp(what, dims, K, k3, stride, pad):
     """dtype code of the 16-bit kernel for this call, or 0 when the fp32 kernels serve it."""
     if conv_precision == 'fp32':
         return 0
-    N, C, D, H, W = dims
-    ok = lib().nc_conv_lp_supported(I(what), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride),
-                                    I(pad))
+    key = (what, dims, K, k3, stride, pad)
+    ok = _lp_cache.get(key)
+    if ok is None:
+        N, C, D, H, W = dims
+        ok = _lp_cache[key] = bool(lib().nc_conv_lp_supported(I(what), I(N), I(C), I(D), I(H), I(W), I(K), I(k3[0]),
+                                                              I(k3[1]), I(k3[2]), I(stride), I(pad)))
     if not ok:
         return 0
     # 'fp16': forward operands in fp16 (11-bit significand); backward operands (dy, and w / x next to it) in bf16 --

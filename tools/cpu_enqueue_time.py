@@ -15,7 +15,9 @@ from neuroclear_amd.util import seed as S  # noqa: E402
 torch.manual_seed(0)
 np.random.seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
-    model = create_model(bench.apollo_opt(0))
+    o = bench.apollo_opt(0)
+    o.precision = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
+    model = create_model(o)
 vol = S.random_volume(100, 108)
 real = torch.from_numpy((vol.astype(np.float64) / 65535.0).astype(np.float32))[None, None].cuda()
 data = {'A': real, 'A_paths': 'x'}
