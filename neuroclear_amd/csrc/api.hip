@@ -31,7 +31,8 @@ int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) 
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
-  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : gemm_fwd_supported(d) ? 2 : 0;
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : gemm_fwd_supported(d) ? 2 : 0;  // (the K = 1 reduction
+  // kernel of the PatchGAN head depends on the batch, which this query does not take: reported as 2)
 }
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
@@ -76,6 +77,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   hipStream_t s = (hipStream_t)stream;
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
+  if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);
   if (!g_force_direct && gemm_fwd_supported(d)) return conv_fwd_gemm(x, w, bias, y, d, ws, ws_bytes, s);
   return conv_fwd_direct(x, w, bias, y, d, s);
 }
@@ -162,6 +164,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
+  else if (!g_force_direct && k1_wgrad_supported(d)) e = conv_wgrad_k1(x, dy, dw, d, s);
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
   if (e) return e;

@@ -89,6 +89,11 @@ bool to1_mfma_supported(const ConvDims& d);
 size_t to1_mfma_ws_bytes(const ConvDims& d);
 int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb,
                         hipStream_t s);
+// many channels -> one channel as a plain reduction (PatchGAN head), conv_c1.hip
+bool k1_fwd_supported(const ConvDims& d);
+bool k1_wgrad_supported(const ConvDims& d);
+int conv_fwd_k1(const float* x, const float* w, const float* b, float* y, const ConvDims& d, hipStream_t s);
+int conv_wgrad_k1(const float* x, const float* dy, float* dw, const ConvDims& d, hipStream_t s);
 // one channel -> 64 channels weight gradient (MFMA over the tap axis), conv_c1.hip
 bool c1_wgrad_supported(const ConvDims& d);
 size_t c1_wgrad_ws_bytes(const ConvDims& d);

@@ -616,4 +616,153 @@ int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDi
   return check_launch("dgrad_to1_reduce");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Many channels -> ONE channel, any kernel / stride (the PatchGAN head, Conv(512, 1, k4, s1, p1), networks.py:1057):
+// forward and weight gradient.  As a GEMM this layer has one row; on the 64-row MFMA tiles it ran at 0.6 TFLOP/s
+// (0.37 ms per call at Athena's batch for 32 MB of input).  These are reductions, so they are written as reductions:
+//   forward : workgroup = 64 output positions x 16 channel groups (one wave each: the weight of a (channel, tap) is
+//             wave-uniform -> scalar loads; lanes read consecutive positions); taps outside, channels inside, 8 loads
+//             in flight; the 16 partial sums are added in group order through LDS (deterministic).
+//   wgrad   : workgroup = one input channel; threads stride over (sample, output position), one partial sum per tap
+//             (4 x 4 or 4 x 4 x 4 kernels) per thread, block tree reduce in a fixed order.
+struct K1Params {
+  const float* x;
+  const float* w;     // fwd: [1][C][taps]
+  const float* bias;  // fwd, nullable
+  float* y;           // fwd: [N][1][So];  wgrad: dw [1][C][taps]
+  const float* dy;    // wgrad: [N][1][So]
+  ConvDims d;
+  long S, So;
+  int taps;
+};
+
+static constexpr int kK1Groups = 16;  // channel groups = waves per workgroup (latency hiding: the layer is tiny)
+
+__global__ __launch_bounds__(64 * kK1Groups) void k_conv_k1_fwd(K1Params p) {
+  __shared__ float part[kK1Groups][64];
+  const ConvDims& d = p.d;
+  const int lane = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.y;
+  const long pos = (long)blockIdx.x * 64 + lane;
+  const bool valid = pos < p.So;
+  const long q = valid ? pos : 0;
+  const int HoWo = d.Ho * d.Wo;
+  const int od = (int)(q / HoWo), oh = (int)((q - (long)od * HoWo) / d.Wo), ow = (int)(q - (long)od * HoWo - (long)oh * d.Wo);
+  const int cper = (d.C + kK1Groups - 1) / kK1Groups, cb = min(d.C, grp * cper), ce = min(d.C, cb + cper);
+  const long HW = (long)d.H * d.W;
+  const float* xn = p.x + (long)n * d.C * p.S;
+  float acc = 0.f;
+  for (int kz = 0; kz < d.kd; ++kz) {
+    const int iz = od * d.sd - d.pd + kz;
+    for (int ky = 0; ky < d.kh; ++ky) {
+      const int iy = oh * d.sh - d.ph + ky;
+      for (int kx = 0; kx < d.kw; ++kx) {
+        const int ix = ow * d.sw - d.pw + kx;
+        const bool ok = valid && (unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+        const float* xp = xn + (ok ? (long)iz * HW + (long)iy * d.W + ix : 0);
+        const float* wp = p.w + (kz * d.kh + ky) * d.kw + kx;
+        int c = cb;
+        for (; c + 8 <= ce; c += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = ok ? xp[(long)(c + u) * p.S] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = fmaf(v[u], wp[(long)(c + u) * p.taps], acc);
+        }
+        for (; c < ce; ++c) acc = fmaf(ok ? xp[(long)c * p.S] : 0.f, wp[(long)c * p.taps], acc);
+      }
+    }
+  }
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && valid) {
+    float v = part[0][lane];
+#pragma unroll
+    for (int g2 = 1; g2 < kK1Groups; ++g2) v += part[g2][lane];  // group order: deterministic
+    if (p.bias) v += p.bias[0];
+    p.y[(long)n * p.So + pos] = v;
+  }
+}
+
+template <int KD>  // kernel KD x 4 x 4 (the PatchGAN head: KD = 1 in 2-D, 4 in 3-D)
+__global__ __launch_bounds__(256) void k_conv_k1_wgrad(K1Params p) {
+  constexpr int T = KD * 16;
+  __shared__ float red[256];
+  const ConvDims& d = p.d;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int HoWo = d.Ho * d.Wo;
+  const long HW = (long)d.H * d.W;
+  const long total = (long)d.N * p.So;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  for (long i = tid; i < total; i += 256) {
+    const int n = (int)(i / p.So);
+    const long q = i - (long)n * p.So;
+    const int od = (int)(q / HoWo), oh = (int)((q - (long)od * HoWo) / d.Wo), ow = (int)(q - (long)od * HoWo - (long)oh * d.Wo);
+    const float g = p.dy[i];
+    const float* xc = p.x + ((long)n * d.C + c) * p.S;
+#pragma unroll
+    for (int kz = 0; kz < KD; ++kz) {
+      const int iz = od * d.sd - d.pd + kz;
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const int iy = oh * d.sh - d.ph + ky;
+        const bool oky = (unsigned)iz < (unsigned)d.D && (unsigned)iy < (unsigned)d.H;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const int ix = ow * d.sw - d.pw + kx;
+          const bool ok = oky && (unsigned)ix < (unsigned)d.W;
+          const float v = ok ? xc[(long)iz * HW + (long)iy * d.W + ix] : 0.f;
+          acc[(kz * 4 + ky) * 4 + kx] = fmaf(g, v, acc[(kz * 4 + ky) * 4 + kx]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    red[tid] = acc[t];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) p.y[(long)c * T + t] = red[0];
+    __syncthreads();
+  }
+}
+
+bool k1_fwd_supported(const ConvDims& d) {
+  return d.K == 1 && (long)d.C * d.kd * d.kh * d.kw >= 256 && (long)d.Do * d.Ho * d.Wo * d.N >= 1024;
+}
+bool k1_wgrad_supported(const ConvDims& d) {
+  return k1_fwd_supported(d) && d.kh == 4 && d.kw == 4 && (d.kd == 1 || d.kd == 4);
+}
+
+static void k1_params(K1Params& p, const ConvDims& d) {
+  p.d = d;
+  p.S = (long)d.D * d.H * d.W;
+  p.So = (long)d.Do * d.Ho * d.Wo;
+  p.taps = d.kd * d.kh * d.kw;
+}
+
+int conv_fwd_k1(const float* x, const float* w, const float* b, float* y, const ConvDims& d, hipStream_t s) {
+  K1Params p{};
+  k1_params(p, d);
+  p.x = x; p.w = w; p.bias = b; p.y = y;
+  hipLaunchKernelGGL(k_conv_k1_fwd, dim3((unsigned)cdiv(p.So, 64), d.N), dim3(64 * kK1Groups), 0, s, p);
+  return check_launch("conv_fwd_k1");
+}
+
+int conv_wgrad_k1(const float* x, const float* dy, float* dw, const ConvDims& d, hipStream_t s) {
+  K1Params p{};
+  k1_params(p, d);
+  p.x = x; p.dy = dy; p.y = dw;
+  if (d.kd == 1) hipLaunchKernelGGL(k_conv_k1_wgrad<1>, dim3(d.C), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_conv_k1_wgrad<4>, dim3(d.C), dim3(256), 0, s, p);
+  return check_launch("conv_wgrad_k1");
+}
+
 }  // namespace nc

@@ -11,6 +11,8 @@
 // conflict-free).  The B image is gathered (im2col on the fly): the reduction index of a gathered element is
 // wave-uniform, so its (channel, tap) decode lives on the scalar unit; the per-lane output position is decoded once.
 // Register-staged double buffering (global loads of chunk i+1 are issued before the MFMAs of chunk i).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -55,20 +57,27 @@ struct GemmParams {
   // G_DGRAD_P: class grid (ceil(D/sd), ceil(H/sh), ceil(W/sw)), sub-taps per dimension (k / s), their product
   int cd, ch, cw, td, th, tw, ptaps;
   Div dtaps, dkhw, dkw, dSo, dHoWo, dWo, dptaps, dthtw, dtw;  // divisors of the per-chunk index decodes
+  Div dsd, dsh, dsw;                                          // strides (data gradient: output index = u / stride)
 };
 
-static constexpr int kAP = 65;  // pitch of the A image (floats)
-
-template <int MODE>
+// TM = rows of the output tile: 64 (4 waves as 2 x 2, one 32 x 32 accumulator each) or 128 (4 waves stacked along M, two
+// accumulators each).  The gathered B image -- the expensive part: ~12 vector instructions of index arithmetic and
+// bounds checks per element -- is shared by twice as many rows in the 128-row tile, which is what the long batched
+// GEMMs of the Athena discriminators (M = 128..512, N = 10^4..10^5 columns) are bound by.
+template <int MODE, int TM>
 __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
+  constexpr int kAP = TM + 1;               // pitch of the A image (floats)
+  constexpr int WN = TM == 64 ? 2 : 1;      // waves along N
+  constexpr int NBLK = 2 / WN;              // 32-column accumulator blocks per wave
+  constexpr int AJ = TM / 16;               // A elements per thread and chunk
   __shared__ float As[2][16 * kAP];
   __shared__ float Bs[2][16 * 64];
   const ConvDims& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
   // the reduction may be split over grid.z (small outputs with a long reduction: PatchGAN tail layers, wgrad)
   const int zsplit = MODE == G_DGRAD_P ? blockIdx.z % p.splits : blockIdx.z;
   const int cls = MODE == G_DGRAD_P ? blockIdx.z / p.splits : 0;
@@ -108,11 +117,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   // ---- A image assignment: r_l = tid & 15 (fast, contiguous in memory), m_l = (tid >> 4) + 16 j
   const int ar = tid & 15, am = tid >> 4;
 
-  float ra[4], rb[4];
+  float ra[AJ], rb[4];
   auto load_chunk = [&](int r0) {
     // A
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AJ; ++j) {
       const int m = m0 + am + 16 * j, r = r0 + ar;
       float v = 0.f;
       if (m < p.M && r < r_end) {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
           const int ty = qdiv(t2, p.dkw), tx = t2 - ty * d.kw;
           const int uz = c0 + d.pd - tz, uy = c1 + d.ph - ty, ux = c2 + d.pw - tx;
           if (uz >= 0 && uy >= 0 && ux >= 0) {
-            const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
+            const int od = qdiv(uz, p.dsd), oh = qdiv(uy, p.dsh), ow = qdiv(ux, p.dsw);
             if (od * d.sd == uz && oh * d.sh == uy && ow * d.sw == ux && od < d.Do && oh < d.Ho && ow < d.Wo)
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
           const int jy = qdiv(s2, p.dtw), jx = s2 - jy * p.tw;
           const int uz = c0 + d.pd - t0z - d.sd * jz, uy = c1 + d.ph - t0y - d.sh * jy, ux = c2 + d.pw - t0x - d.sw * jx;
           if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the stride by construction
-            const int od = uz / d.sd, oh = uy / d.sh, ow = ux / d.sw;
+            const int od = qdiv(uz, p.dsd), oh = qdiv(uy, p.dsh), ow = qdiv(ux, p.dsw);
             if (od < d.Do && oh < d.Ho && ow < d.Wo)
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
@@ -183,14 +192,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) As[buf][ar * kAP + am + 16 * j] = ra[j];
+    for (int j = 0; j < AJ; ++j) As[buf][ar * kAP + am + 16 * j] = ra[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) Bs[buf][(wave + 4 * j) * 64 + (tid & 63)] = rb[j];
   };
 
-  f32x16 acc;
+  f32x16 acc[NBLK];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int nb2 = 0; nb2 < NBLK; ++nb2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb2][r] = 0.f;
 
   int buf = 0;
   if (r_begin < r_end) {
@@ -202,17 +213,23 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     const bool more = r0 + 16 < r_end;
     if (more) load_chunk(r0 + 16);
     const float* A = As[buf] + wm * 32 + li + h * kAP;
-    const float* B = Bs[buf] + wn * 32 + li + h * 64;
+    const float* B = Bs[buf] + wn * 32 * NBLK + li + h * 64;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2 * kk * kAP], B[2 * kk * 64], acc, 0, 0, 0);
+    for (int kk = 0; kk < 8; ++kk) {
+      const float av = A[2 * kk * kAP];
+#pragma unroll
+      for (int nb2 = 0; nb2 < NBLK; ++nb2)
+        acc[nb2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[2 * kk * 64 + nb2 * 32], acc[nb2], 0, 0, 0);
+    }
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
 
   // ---- epilogue: row (m) = (r&3) + 8*(r>>2) + 4*h, column (n) = li
-  const int n = n0 + wn * 32 + li;
+#pragma unroll
+  for (int nb2 = 0; nb2 < NBLK; ++nb2) {
+  const int n = n0 + (wn * NBLK + nb2) * 32 + li;
   if (n < p.N) {
     long base;
     long mstride;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
       const int pos = n - b * cs;
       const int z1 = pos / (p.ch * p.cw), y1 = (pos - z1 * p.ch * p.cw) / p.cw, x1 = pos - z1 * p.ch * p.cw - y1 * p.cw;
       const int iz = z1 * d.sd + pz, iy = y1 * d.sh + py, ix = x1 * d.sw + px;
-      if (iz >= d.D || iy >= d.H || ix >= d.W) return;
+      if (iz >= d.D || iy >= d.H || ix >= d.W) continue;
       base = (long)zsplit * d.N * d.C * p.S + (long)b * d.C * p.S + (long)iz * HW + iy * d.W + ix;
       mstride = p.S;
     } else {
@@ -241,11 +258,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m < p.M) {
-        float v = acc[r];
+        float v = acc[nb2][r];
         if (MODE == G_FWD && p.bias && p.splits == 1) v += p.bias[m];
         p.out[base + (long)m * mstride] = v;
       }
     }
+  }
   }
 }
 
@@ -259,6 +277,33 @@ __global__ void k_gemm_split_reduce(const float* __restrict__ slab, float* __res
   }
 }
 
+// Stride-1 data gradient = forward convolution of dy with the flipped, channel-transposed kernel and padding k - 1 - p:
+// wt[c][k][t] = w[k][c][T - 1 - t].  The forward gather has no stride divisions and its lanes read consecutive
+// positions (27 -> 67 TFLOP/s on the 256 -> 512 PatchGAN layer at Athena's batch).
+__global__ void k_flip_transpose_w(const float* __restrict__ w, float* __restrict__ wt, int K, int C, int T) {
+  const long total = (long)K * C * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int k = (int)((i / T) % K);
+    const int c = (int)(i / ((long)T * K));
+    wt[i] = w[((long)k * C + c) * T + (T - 1 - t)];
+  }
+}
+
+static bool dgrad_as_fwd(const ConvDims& d) {
+  return d.sd == 1 && d.sh == 1 && d.sw == 1 && d.kd - 1 - d.pd >= 0 && d.kh - 1 - d.ph >= 0 && d.kw - 1 - d.pw >= 0 &&
+         d.ph == d.pw && (d.kd == 1 || d.pd == d.ph) && d.C >= 16;
+}
+static ConvDims flipped_dims(const ConvDims& d) {  // the forward problem whose output is dx
+  ConvDims f = d;
+  f.C = d.K; f.K = d.C;
+  f.D = d.Do; f.H = d.Ho; f.W = d.Wo;
+  f.pd = d.kd - 1 - d.pd; f.ph = d.kh - 1 - d.ph; f.pw = d.kw - 1 - d.pw;
+  f.Do = d.D; f.Ho = d.H; f.Wo = d.W;
+  return f;
+}
+static size_t wt_bytes(const ConvDims& d) { return (((size_t)d.K * d.C * d.kd * d.kh * d.kw * sizeof(float)) + 255) & ~(size_t)255; }
+
 static void gemm_common(GemmParams& p, const ConvDims& d) {
   p.d = d;
   p.taps = d.kd * d.kh * d.kw;
@@ -270,6 +315,7 @@ static void gemm_common(GemmParams& p, const ConvDims& d) {
   p.dtaps = mkdiv(p.taps); p.dkhw = mkdiv(p.khw); p.dkw = mkdiv(d.kw);
   p.dSo = mkdiv(p.So); p.dHoWo = mkdiv((long)d.Ho * d.Wo); p.dWo = mkdiv(d.Wo);
   p.dptaps = mkdiv(1); p.dthtw = mkdiv(1); p.dtw = mkdiv(1);
+  p.dsd = mkdiv(d.sd); p.dsh = mkdiv(d.sh); p.dsw = mkdiv(d.sw);
 }
 
 static bool gemm_range_ok(const ConvDims& d) {
@@ -308,6 +354,7 @@ static bool dgrad_parity_ok(const ConvDims& d) {
   return (d.sd > 1 || d.sh > 1 || d.sw > 1) && d.kd % d.sd == 0 && d.kh % d.sh == 0 && d.kw % d.sw == 0;
 }
 static int dgrad_splits(const ConvDims& d) {
+  if (dgrad_as_fwd(d)) return pick_splits(d.C, Pi(d), Rd(d));
   if (dgrad_parity_ok(d)) {
     const long ncls = (long)d.sd * d.sh * d.sw;
     const long npar = (long)d.N * cdiv(d.D, d.sd) * cdiv(d.H, d.sh) * cdiv(d.W, d.sw);
@@ -324,8 +371,16 @@ size_t gemm_ws_bytes(const ConvDims& d) {
   };
   upd(gemm_fwd_supported(d), fwd_splits(d), (size_t)d.K * Po(d));
   upd(gemm_dgrad_supported(d), dgrad_splits(d), (size_t)d.C * Pi(d));
+  if (gemm_dgrad_supported(d) && dgrad_as_fwd(d)) need += wt_bytes(d);
   upd(gemm_wgrad_supported(d), wgrad_splits(d), (size_t)d.K * Rf(d));
   return need;
+}
+
+// 128-row tiles when the GEMM is large enough to fill the chip with them (>= 2 workgroups per CU) and has >= 128 rows
+static bool big_tile(const GemmParams& p) {
+  if (getenv("NC_GEMM_TM64")) return false;  // A/B switch for timing experiments
+  const int ncls = p.ptaps ? p.d.sd * p.d.sh * p.d.sw : 1;
+  return p.M >= 128 && cdiv(p.M, 128) * cdiv(p.N, 64) * p.splits * ncls >= 512;
 }
 
 static int split_setup(GemmParams& p, int splits, float* out, void* ws, size_t wsb, size_t out_elems,
@@ -360,8 +415,13 @@ int conv_fwd_gemm(const float* x, const float* w, const float* b, float* y, cons
   p.M = d.K; p.N = (int)Po(d); p.R = (int)Rf(d);
   const long n = (long)d.K * Po(d);
   if (int e = split_setup(p, fwd_splits(d), y, ws, wsb, n, "conv_fwd_gemm")) return e;
-  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-  hipLaunchKernelGGL(k_conv_gemm<G_FWD>, grid, dim3(256), 0, s, p);
+  if (big_tile(p)) {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_FWD, 128>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_FWD, 64>), grid, dim3(256), 0, s, p);
+  }
   if (int e = check_launch("conv_fwd_gemm")) return e;
   return split_reduce(p, y, n, b, p.So, d.K, s);
 }
@@ -370,6 +430,30 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
                     hipStream_t s) {
   GemmParams p{};
   gemm_common(p, d);
+  if (dgrad_as_fwd(d)) {
+    const size_t wb = wt_bytes(d);
+    if (!ws || wsb < wb) { set_error("conv_dgrad_gemm: workspace too small"); return NC_ERR_WS; }
+    float* wt = (float*)ws;
+    const int T = d.kd * d.kh * d.kw;
+    const long tot = (long)d.K * d.C * T;
+    hipLaunchKernelGGL(k_flip_transpose_w, dim3((unsigned)(cdiv(tot, 256) > 1024 ? 1024 : cdiv(tot, 256))), dim3(256), 0, s, w,
+                       wt, d.K, d.C, T);
+    const ConvDims f = flipped_dims(d);
+    gemm_common(p, f);
+    p.a = wt; p.b = dy; p.bias = nullptr;
+    p.M = f.K; p.N = (int)Po(f); p.R = (int)Rf(f);
+    const long n = (long)f.K * Po(f);
+    if (int e = split_setup(p, dgrad_splits(d), dx, (char*)ws + wb, wsb - wb, n, "conv_dgrad_gemm")) return e;
+    if (big_tile(p)) {
+      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
+      hipLaunchKernelGGL((k_conv_gemm<G_FWD, 128>), grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+      hipLaunchKernelGGL((k_conv_gemm<G_FWD, 64>), grid, dim3(256), 0, s, p);
+    }
+    if (int e = check_launch("conv_dgrad_gemm_flipped")) return e;
+    return split_reduce(p, dx, n, nullptr, p.So, f.K, s);
+  }
   p.a = w; p.b = dy; p.bias = nullptr;
   if (dgrad_parity_ok(d)) {
     p.cd = (int)cdiv(d.D, d.sd); p.ch = (int)cdiv(d.H, d.sh); p.cw = (int)cdiv(d.W, d.sw);
@@ -380,16 +464,26 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
     p.M = d.C; p.N = d.N * p.cd * p.ch * p.cw; p.R = d.K * p.ptaps;
     const long n = (long)d.C * Pi(d);
     if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), (unsigned)(p.splits * ncls));
-    hipLaunchKernelGGL(k_conv_gemm<G_DGRAD_P>, grid, dim3(256), 0, s, p);
+    if (big_tile(p)) {
+      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), (unsigned)(p.splits * ncls));
+      hipLaunchKernelGGL((k_conv_gemm<G_DGRAD_P, 128>), grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), (unsigned)(p.splits * ncls));
+      hipLaunchKernelGGL((k_conv_gemm<G_DGRAD_P, 64>), grid, dim3(256), 0, s, p);
+    }
     if (int e = check_launch("conv_dgrad_gemm_parity")) return e;
     return split_reduce(p, dx, n, nullptr, 1, 1, s);
   }
   p.M = d.C; p.N = (int)Pi(d); p.R = (int)Rd(d);
   const long n = (long)d.C * Pi(d);
   if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
-  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-  hipLaunchKernelGGL(k_conv_gemm<G_DGRAD>, grid, dim3(256), 0, s, p);
+  if (big_tile(p)) {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_DGRAD, 128>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_DGRAD, 64>), grid, dim3(256), 0, s, p);
+  }
   if (int e = check_launch("conv_dgrad_gemm")) return e;
   return split_reduce(p, dx, n, nullptr, 1, 1, s);
 }
@@ -402,8 +496,13 @@ int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& 
   p.M = d.K; p.N = (int)Rf(d); p.R = (int)Po(d);
   const long n = (long)p.M * p.N;
   if (int e = split_setup(p, wgrad_splits(d), dw, ws, wsb, n, "conv_wgrad_gemm")) return e;
-  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-  hipLaunchKernelGGL(k_conv_gemm<G_WGRAD>, grid, dim3(256), 0, s, p);
+  if (big_tile(p)) {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_WGRAD, 128>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
+    hipLaunchKernelGGL((k_conv_gemm<G_WGRAD, 64>), grid, dim3(256), 0, s, p);
+  }
   if (int e = check_launch("conv_wgrad_gemm")) return e;
   return split_reduce(p, dw, n, nullptr, 1, 1, s);
 }

@@ -60,6 +60,12 @@ CONV_CASES = [
     (1, 64, 128, (18, 18), 4, 2, 1),
     (1, 256, 512, (4, 4), 4, 1, 1),
     (1, 512, 1, (3, 3), 4, 1, 1),
+    (32, 128, 256, (40, 40), 4, 1, 1),       # Athena-sized batch: 128-row gather-GEMM tiles (fwd, dgrad)
+    (32, 128, 256, (40, 40), 4, 2, 1),       # same, strided: parity-class dgrad on 128-row tiles
+    (24, 160, 192, (33, 35), 4, 1, 1),
+    (20, 512, 1, (12, 12), 4, 1, 1),         # PatchGAN head at a large batch: K = 1 reduction kernels (fwd, wgrad)
+    (3, 100, 1, (9, 10, 11), 4, 1, 1),       # same in 3-D, ragged channel groups
+       # 128-row tiles with a ragged last row tile (M = 192 / 160) and ragged N
     (1, 1, 64, (12, 12, 12), 4, 2, 1),       # PatchGAN 3-D
 ]
 
