@@ -58,6 +58,7 @@ struct GemmParams {
   int cd, ch, cw, td, th, tw, ptaps;
   Div dtaps, dkhw, dkw, dSo, dHoWo, dWo, dptaps, dthtw, dtw;  // divisors of the per-chunk index decodes
   Div dsd, dsh, dsw;                                          // strides (data gradient: output index = u / stride)
+  int shd, shh, shw;                                          // G_DGRAD_P: log2 of the (power-of-two) strides
 };
 
 // TM = rows of the output tile: 64 (4 waves as 2 x 2, one 32 x 32 accumulator each) or 128 (4 waves stacked along M, two
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   constexpr int kAP = TM + 1;               // pitch of the A image (floats)
   constexpr int WN = TM == 64 ? 2 : 1;      // waves along N
   constexpr int NBLK = 2 / WN;              // 32-column accumulator blocks per wave
+  constexpr int MBLK = TM == 256 ? 2 : 1;   // 32-row accumulator blocks per wave
   constexpr int AJ = TM / 16;               // A elements per thread and chunk
   __shared__ float As[2][16 * kAP];
   __shared__ float Bs[2][16 * 64];
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
           const int jz = qdiv(sub, p.dthtw), s2 = sub - jz * p.th * p.tw;
           const int jy = qdiv(s2, p.dtw), jx = s2 - jy * p.tw;
           const int uz = c0 + d.pd - t0z - d.sd * jz, uy = c1 + d.ph - t0y - d.sh * jy, ux = c2 + d.pw - t0x - d.sw * jx;
-          if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the stride by construction
-            const int od = qdiv(uz, p.dsd), oh = qdiv(uy, p.dsh), ow = qdiv(ux, p.dsw);
+          if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the (power-of-two) stride by construction
+            const int od = uz >> p.shd, oh = uy >> p.shh, ow = ux >> p.shw;
             if (od < d.Do && oh < d.Ho && ow < d.Wo)
               v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
           }
@@ -197,11 +199,13 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     for (int j = 0; j < 4; ++j) Bs[buf][(wave + 4 * j) * 64 + (tid & 63)] = rb[j];
   };
 
-  f32x16 acc[NBLK];
+  f32x16 acc[MBLK][NBLK];
 #pragma unroll
-  for (int nb2 = 0; nb2 < NBLK; ++nb2)
+  for (int mb = 0; mb < MBLK; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb2][r] = 0.f;
+    for (int nb2 = 0; nb2 < NBLK; ++nb2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb2][r] = 0.f;
 
   int buf = 0;
   if (r_begin < r_end) {
@@ -212,14 +216,20 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   for (int r0 = r_begin; r0 < r_end; r0 += 16) {
     const bool more = r0 + 16 < r_end;
     if (more) load_chunk(r0 + 16);
-    const float* A = As[buf] + wm * 32 + li + h * kAP;
+    const float* A = As[buf] + wm * 32 * MBLK + li + h * kAP;
     const float* B = Bs[buf] + wn * 32 * NBLK + li + h * 64;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const float av = A[2 * kk * kAP];
+      float av[MBLK], bv[NBLK];
 #pragma unroll
-      for (int nb2 = 0; nb2 < NBLK; ++nb2)
-        acc[nb2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[2 * kk * 64 + nb2 * 32], acc[nb2], 0, 0, 0);
+      for (int mb = 0; mb < MBLK; ++mb) av[mb] = A[2 * kk * kAP + mb * 32];
+#pragma unroll
+      for (int nb2 = 0; nb2 < NBLK; ++nb2) bv[nb2] = B[2 * kk * 64 + nb2 * 32];
+#pragma unroll
+      for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+        for (int nb2 = 0; nb2 < NBLK; ++nb2)
+          acc[mb][nb2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb2], acc[mb][nb2], 0, 0, 0);
     }
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
@@ -255,10 +265,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
       mstride = p.N;
     }
 #pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int m = m0 + (wm * MBLK + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m < p.M) {
-        float v = acc[nb2][r];
+        float v = acc[mb][nb2][r];
         if (MODE == G_FWD && p.bias && p.splits == 1) v += p.bias[m];
         p.out[base + (long)m * mstride] = v;
       }
@@ -349,20 +361,35 @@ static int pick_splits(long M, long N, long R) {
   if (s > 256) s = 256;
   return (int)(s < 1 ? 1 : s);
 }
-static int fwd_splits(const ConvDims& d) { return pick_splits(d.K, Po(d), Rf(d)); }
+// with >= 128 rows the kernel uses 128-/256-row tiles (tile_rows): split the reduction further until those fill the chip
+static int fill_splits(long M, long cols64, long R, long s) {
+  if (M >= 128) {
+    const long t128 = cdiv(M, 128) * cols64;
+    while (t128 * s < 768 && s * 2 <= cdiv(R, 128) && s * 2 <= 256) s *= 2;
+  }
+  return (int)s;
+}
+static int fwd_splits(const ConvDims& d) {
+  return fill_splits(d.K, cdiv(Po(d), 64), Rf(d), pick_splits(d.K, Po(d), Rf(d)));
+}
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static bool dgrad_parity_ok(const ConvDims& d) {
-  return (d.sd > 1 || d.sh > 1 || d.sw > 1) && d.kd % d.sd == 0 && d.kh % d.sh == 0 && d.kw % d.sw == 0;
+  return (d.sd > 1 || d.sh > 1 || d.sw > 1) && d.kd % d.sd == 0 && d.kh % d.sh == 0 && d.kw % d.sw == 0 &&
+         pow2(d.sd) && pow2(d.sh) && pow2(d.sw);
 }
 static int dgrad_splits(const ConvDims& d) {
-  if (dgrad_as_fwd(d)) return pick_splits(d.C, Pi(d), Rd(d));
+  if (dgrad_as_fwd(d)) return fill_splits(d.C, cdiv(Pi(d), 64), Rd(d), pick_splits(d.C, Pi(d), Rd(d)));
   if (dgrad_parity_ok(d)) {
     const long ncls = (long)d.sd * d.sh * d.sw;
     const long npar = (long)d.N * cdiv(d.D, d.sd) * cdiv(d.H, d.sh) * cdiv(d.W, d.sw);
-    return pick_splits(d.C, npar * ncls, Rd(d) / ncls);
+    return fill_splits(d.C, cdiv(npar, 64) * ncls, Rd(d) / ncls, pick_splits(d.C, npar * ncls, Rd(d) / ncls));
   }
   return pick_splits(d.C, Pi(d), Rd(d));
 }
-static int wgrad_splits(const ConvDims& d) { return pick_splits(d.K, Rf(d), Po(d)); }
+static int wgrad_splits(const ConvDims& d) {
+  return fill_splits(d.K, cdiv(Rf(d), 64), Po(d), pick_splits(d.K, Rf(d), Po(d)));
+}
 
 size_t gemm_ws_bytes(const ConvDims& d) {
   size_t need = 0;
@@ -376,11 +403,24 @@ size_t gemm_ws_bytes(const ConvDims& d) {
   return need;
 }
 
-// 128-row tiles when the GEMM is large enough to fill the chip with them (>= 2 workgroups per CU) and has >= 128 rows
-static bool big_tile(const GemmParams& p) {
-  if (getenv("NC_GEMM_TM64")) return false;  // A/B switch for timing experiments
+// rows of the output tile: 256 / 128 when the GEMM has that many rows and is large enough to fill the chip with such
+// tiles (>= 1.5 / 2 workgroups per CU), else 64
+static int tile_rows(const GemmParams& p) {
+  const char* e = getenv("NC_GEMM_TM");  // A/B switch for timing experiments: cap on the tile rows
+  const int cap = e ? atoi(e) : 256;
   const int ncls = p.ptaps ? p.d.sd * p.d.sh * p.d.sw : 1;
-  return p.M >= 128 && cdiv(p.M, 128) * cdiv(p.N, 64) * p.splits * ncls >= 512;
+  const long cols = cdiv(p.N, 64) * p.splits * ncls;
+  if (cap >= 256 && p.M >= 256 && cdiv(p.M, 256) * cols >= 384) return 256;
+  if (cap >= 128 && p.M >= 128 && cdiv(p.M, 128) * cols >= 512) return 128;
+  return 64;
+}
+template <int MODE>
+static void launch_gemm(const GemmParams& p, unsigned gz, hipStream_t s) {
+  const int tm = tile_rows(p);
+  dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, tm), gz);
+  if (tm == 256) hipLaunchKernelGGL((k_conv_gemm<MODE, 256>), grid, dim3(256), 0, s, p);
+  else if (tm == 128) hipLaunchKernelGGL((k_conv_gemm<MODE, 128>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_gemm<MODE, 64>), grid, dim3(256), 0, s, p);
 }
 
 static int split_setup(GemmParams& p, int splits, float* out, void* ws, size_t wsb, size_t out_elems,
@@ -415,13 +455,7 @@ int conv_fwd_gemm(const float* x, const float* w, const float* b, float* y, cons
   p.M = d.K; p.N = (int)Po(d); p.R = (int)Rf(d);
   const long n = (long)d.K * Po(d);
   if (int e = split_setup(p, fwd_splits(d), y, ws, wsb, n, "conv_fwd_gemm")) return e;
-  if (big_tile(p)) {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_FWD, 128>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_FWD, 64>), grid, dim3(256), 0, s, p);
-  }
+  launch_gemm<G_FWD>(p, (unsigned)p.splits, s);
   if (int e = check_launch("conv_fwd_gemm")) return e;
   return split_reduce(p, y, n, b, p.So, d.K, s);
 }
@@ -444,13 +478,7 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
     p.M = f.K; p.N = (int)Po(f); p.R = (int)Rf(f);
     const long n = (long)f.K * Po(f);
     if (int e = split_setup(p, dgrad_splits(d), dx, (char*)ws + wb, wsb - wb, n, "conv_dgrad_gemm")) return e;
-    if (big_tile(p)) {
-      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
-      hipLaunchKernelGGL((k_conv_gemm<G_FWD, 128>), grid, dim3(256), 0, s, p);
-    } else {
-      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-      hipLaunchKernelGGL((k_conv_gemm<G_FWD, 64>), grid, dim3(256), 0, s, p);
-    }
+    launch_gemm<G_FWD>(p, (unsigned)p.splits, s);
     if (int e = check_launch("conv_dgrad_gemm_flipped")) return e;
     return split_reduce(p, dx, n, nullptr, p.So, f.K, s);
   }
@@ -460,30 +488,19 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
     p.td = d.kd / d.sd; p.th = d.kh / d.sh; p.tw = d.kw / d.sw;
     p.ptaps = p.td * p.th * p.tw;
     p.dptaps = mkdiv(p.ptaps); p.dthtw = mkdiv((long)p.th * p.tw); p.dtw = mkdiv(p.tw);
+    p.shd = ilog2(d.sd); p.shh = ilog2(d.sh); p.shw = ilog2(d.sw);
     const int ncls = d.sd * d.sh * d.sw;
     p.M = d.C; p.N = d.N * p.cd * p.ch * p.cw; p.R = d.K * p.ptaps;
     const long n = (long)d.C * Pi(d);
     if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
-    if (big_tile(p)) {
-      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), (unsigned)(p.splits * ncls));
-      hipLaunchKernelGGL((k_conv_gemm<G_DGRAD_P, 128>), grid, dim3(256), 0, s, p);
-    } else {
-      dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), (unsigned)(p.splits * ncls));
-      hipLaunchKernelGGL((k_conv_gemm<G_DGRAD_P, 64>), grid, dim3(256), 0, s, p);
-    }
+    launch_gemm<G_DGRAD_P>(p, (unsigned)(p.splits * ncls), s);
     if (int e = check_launch("conv_dgrad_gemm_parity")) return e;
     return split_reduce(p, dx, n, nullptr, 1, 1, s);
   }
   p.M = d.C; p.N = (int)Pi(d); p.R = (int)Rd(d);
   const long n = (long)d.C * Pi(d);
   if (int e = split_setup(p, dgrad_splits(d), dx, ws, wsb, n, "conv_dgrad_gemm")) return e;
-  if (big_tile(p)) {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_DGRAD, 128>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_DGRAD, 64>), grid, dim3(256), 0, s, p);
-  }
+  launch_gemm<G_DGRAD>(p, (unsigned)p.splits, s);
   if (int e = check_launch("conv_dgrad_gemm")) return e;
   return split_reduce(p, dx, n, nullptr, 1, 1, s);
 }
@@ -496,13 +513,7 @@ int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& 
   p.M = d.K; p.N = (int)Rf(d); p.R = (int)Po(d);
   const long n = (long)p.M * p.N;
   if (int e = split_setup(p, wgrad_splits(d), dw, ws, wsb, n, "conv_wgrad_gemm")) return e;
-  if (big_tile(p)) {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 128), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_WGRAD, 128>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, 64), p.splits);
-    hipLaunchKernelGGL((k_conv_gemm<G_WGRAD, 64>), grid, dim3(256), 0, s, p);
-  }
+  launch_gemm<G_WGRAD>(p, (unsigned)p.splits, s);
   if (int e = check_launch("conv_wgrad_gemm")) return e;
   return split_reduce(p, dw, n, nullptr, 1, 1, s);
 }

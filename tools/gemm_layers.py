@@ -1,5 +1,5 @@
 """Timing experiment: the PatchGAN layers at Athena's batch (108 slices of 108^2) on the gather GEMM, fwd / dgrad / wgrad,
-with 128-row tiles (default) and 64-row tiles (NC_GEMM_TM64=1)."""
+with the output-tile rows capped at 256 (default), 128 and 64 (NC_GEMM_TM)."""
 import os
 import sys
 import torch
@@ -29,14 +29,11 @@ for C, K, H, s in LAYERS:
     dy = torch.randn_like(y)
     fl = 2.0 * C * K * 16 * y.numel() / K
     row = '%3d->%3d %3d^2 s%d  %6.1f GF ' % (C, K, H, s, fl / 1e9)
-    for tm in ('', '1'):
-        if tm:
-            os.environ['NC_GEMM_TM64'] = '1'
-        else:
-            os.environ.pop('NC_GEMM_TM64', None)
+    for tm in ('256', '128', '64'):
+        os.environ['NC_GEMM_TM'] = tm
         tf = timeit(lambda: ops.conv_fwd_raw(x, w, None, s, 1))
         td = timeit(lambda: ops.conv_dgrad_raw(dy, w, x.shape, s, 1))
         tw = timeit(lambda: ops.conv_wgrad_raw(x, dy, w.shape, s, 1, False))
         row += ' | %s fwd %.3f ms %5.1f TF  dgrad %.3f %5.1f  wgrad %.3f %5.1f' % (
-            'TM64 ' if tm else 'TM128', tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9)
+            'TM<=' + tm, tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9)
     print(row, flush=True)
