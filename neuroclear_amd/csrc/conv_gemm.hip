@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
       c0 = tap / p.khw; c1 = (tap - c0 * p.khw) / d.kw; c2 = tap - c0 * p.khw - c1 * d.kw;
     }
   }
+  // G_DGRAD_P: u = c + pad - t0 - s * j is a multiple of the stride, so the output index is (c + pad - t0) / s - j: the
+  // quotient is a per-lane constant, a gathered element costs three subtractions and three unsigned compares
+  int boz = 0, boy = 0, box = 0;
+  long bo_off = 0;
+  if (MODE == G_DGRAD_P) {
+    boz = (c0 + d.pd - t0z) >> p.shd; boy = (c1 + d.ph - t0y) >> p.shh; box = (c2 + d.pw - t0x) >> p.shw;
+    bo_off = (long)nb * d.K * p.So + (long)boz * HoWo + boy * d.Wo + box;
+  }
   // ---- A image assignment: r_l = tid & 15 (fast, contiguous in memory), m_l = (tid >> 4) + 16 j
   const int ar = tid & 15, am = tid >> 4;
 
@@ -173,12 +181,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
           const int k = qdiv(r, p.dptaps), sub = r - k * p.ptaps;
           const int jz = qdiv(sub, p.dthtw), s2 = sub - jz * p.th * p.tw;
           const int jy = qdiv(s2, p.dtw), jx = s2 - jy * p.tw;
-          const int uz = c0 + d.pd - t0z - d.sd * jz, uy = c1 + d.ph - t0y - d.sh * jy, ux = c2 + d.pw - t0x - d.sw * jx;
-          if (uz >= 0 && uy >= 0 && ux >= 0) {  // multiples of the (power-of-two) stride by construction
-            const int od = uz >> p.shd, oh = uy >> p.shh, ow = ux >> p.shw;
-            if (od < d.Do && oh < d.Ho && ow < d.Wo)
-              v = p.b[((long)nb * d.K + k) * p.So + (long)od * HoWo + oh * d.Wo + ow];
-          }
+          const int od = boz - jz, oh = boy - jy, ow = box - jx;
+          if ((unsigned)od < (unsigned)d.Do && (unsigned)oh < (unsigned)d.Ho && (unsigned)ow < (unsigned)d.Wo)
+            v = p.b[bo_off + ((long)k * p.So - ((long)jz * HoWo + jy * d.Wo + jx))];
         } else {
           const int b = d.N > 1 ? qdiv(r, p.dSo) : 0;
           const int pos = r - b * (int)p.So;
