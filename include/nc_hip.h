@@ -84,7 +84,7 @@ size_t nc_convT_ws_bytes(int N, int C, int D, int H, int W, int K);
 int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
                       int K, void* stream);
 int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
-                        void* stream);
+                        void* ws, size_t ws_bytes, void* stream);
 int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int D, int H, int W,
                         int K, void* ws, size_t ws_bytes, void* stream);
 

@@ -189,9 +189,17 @@ int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* 
 }
 
 int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
-                        void* stream) {
+                        void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !w || !dx) { set_error("convT_dgrad: null pointer"); return NC_ERR_ARG; }
   if (int e = convT_check("convT_dgrad", N, C, D, H, W, K)) return e;
+  ConvDims cd;
+  if (!g_force_direct && C >= 64 && convT_as_conv(cd, N, C, D, H, W, K) && gemm_fwd_supported(cd) &&
+      (gemm_ws_bytes(cd) == 0 || (ws && ws_bytes >= gemm_ws_bytes(cd)))) {
+    // dx[ci][pos] = sum_(co, t) w[ci][co][t] * dy[co][2 pos + t]  ==  the FORWARD pass of Conv3d(K -> C, k 2, s 2, p 0) on dy
+    // with the transposed-conv weight read as [C][K][2][2][2]: MFMA gather GEMM (60-70 TFLOP/s) instead of the VALU
+    // kernel (33 TFLOP/s at 128 -> 64 channels)
+    return conv_fwd_gemm(dy, w, nullptr, dx, cd, ws, ws_bytes, (hipStream_t)stream);
+  }
   const long S = (long)D * H * W;
   const int ct = pick(C, 8, 4, 1);
   dim3 grid((unsigned)cdiv(S, 256), C / ct, N);

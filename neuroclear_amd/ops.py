@@ -360,8 +360,10 @@ class _ConvT(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib().nc_convT_k2s2_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K),
-                                            _stream()), 'nc_convT_k2s2_dgrad')
+            nb = lib().nc_convT_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K))
+            ws = workspace(nb, x.device, 'ws_convT')
+            check(lib().nc_convT_k2s2_dgrad(_ptr(dy), _ptr(w), _ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K), _ptr(ws),
+                                            Z(ws.numel()), _stream()), 'nc_convT_k2s2_dgrad')
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             db = torch.empty(K, dtype=torch.float32, device=x.device) if ctx.has_b else None

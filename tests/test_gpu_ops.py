@@ -108,8 +108,8 @@ def test_conv_paths_reported():
     assert L.nc_conv_fwd_path(I(64), I(1), I(1), I(1), I(1), I(1), I(0)) == 3  # flat-voxel pointwise kernel
 
 
-@pytest.mark.parametrize('shape', [(1, 256, 4, 5, 6), (2, 128, 3, 4, 4)])
-def test_convT(shape):
+@pytest.mark.parametrize('shape', [(1, 256, 4, 5, 6), (2, 128, 3, 4, 4), (1, 16, 3, 4, 5), (2, 128, 9, 20, 21)])
+def test_convT(shape):  # C >= 64: data gradient on the MFMA gather GEMM; C = 16: VALU kernel
     N, C = shape[:2]
     K = C // 2
     x = T(5, shape).requires_grad_(True)
