@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   constexpr bool PAIR = KS == 5;
   constexpr int NB = PAIR ? 1 : 2;                    // C8 blocks per chunk
   constexpr int KSTEPS = PAIR ? (T2 + 1) / 2 : T2;    // k-steps per stage
-  constexpr int MAXJ = 8;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
+  constexpr int MAXJ = 6;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
@@ -351,26 +351,27 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
     // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
     if (!(p.ablate & 1)) {
       const int cob = cur.cot * 64;
-      float bv[2][16];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          bv[a][e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
       float* yn = p.y + ((long)cur.n * p.K + cob + 4 * h) * S + (long)cur.z * HW;
+      long yo[VB];  // offset of this lane's position in block v, or -1
 #pragma unroll
       for (int v = 0; v < VB; ++v) {
         const unsigned f = (unsigned)(cur.q0 + qb + v * 32);
         const unsigned yy = fdiv(f, p.mP);
         const unsigned xx = f - yy * p.P;
-        if ((int)yy < p.H && (int)xx < p.W) {
-          float* yv = yn + (long)yy * p.W + xx;
+        yo[v] = ((int)yy < p.H && (int)xx < p.W) ? (long)yy * p.W + xx : -1;
+      }
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a) {  // one 32-channel half at a time: 16 bias registers live, not 32
+        float bv[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-              yv[(long)(a * 32 + (e & 3) + 8 * (e >> 2)) * S] = acc[a][v][e] + bv[a][e];
-        }
+        for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VB; ++v)
+          if (yo[v] >= 0) {
+            float* yv = yn + yo[v];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yv[(long)(a * 32 + (e & 3) + 8 * (e >> 2)) * S] = acc[a][v][e] + bv[e];
+          }
       }
     }
     if (!more_tiles) break;
@@ -402,7 +403,7 @@ HPlan h_plan(const ConvDims& d) {
     const int RP = R * pl.P;
     const int npb = ((pair ? 1 : 2) * RP + 4 + 63) / 64;
     const int SB = (npb + pl.npw) * 1024;
-    if (npb > 64 || 2 * SB > kLdsMaxH) continue;
+    if (npb > 48 || 2 * SB > kLdsMaxH) continue;
     const int TPP = (int)((plane + PT - 1) / PT);
     // cost ~ positions computed per useful position, with a small bonus for the larger tile (operand reuse)
     const double eff = (double)d.H * d.W / ((double)TPP * PT) * (VB == 4 ? 1.0 : VB == 2 ? 0.93 : 0.8);
