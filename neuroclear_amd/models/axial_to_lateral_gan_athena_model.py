@@ -7,6 +7,9 @@ come out of ONE batched pass over all S slices (`ops.volume_all_slices` -> [S, C
 stacked volume equals the mean over the batch.
 """
 import itertools
+import os
+
+import torch
 
 from .. import ops
 from . import networks
@@ -75,6 +78,34 @@ class AxialToLateralGANAthenaModel(BaseModel):
         self.fake = self.netG_A(self.real)
         self.rec = self.netG_B(self.fake)
 
+    # The six discriminators are independent networks: their passes run on six HIP streams (autograd replays every op on
+    # the stream of its forward, so the backward chains overlap too).  One batched PatchGAN pass keeps the matrix pipe
+    # ~45 % busy (profiles/README.md); two or three side by side fill the gaps.  NC_D_STREAMS=0: one stream.
+    _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+
+    def _on_streams(self, fns, after=None):
+        """fns[i]() on stream i, after everything queued on the calling stream so far (or after the event `after`); the
+        calling stream waits for all of them.  Same numbers as running them in sequence: the jobs touch disjoint
+        parameter / gradient sets."""
+        if not self._d_streams_on or not self.real.is_cuda:
+            return [f() for f in fns]
+        if not hasattr(self, '_d_streams'):
+            self._d_streams = []
+        while len(self._d_streams) < len(fns):
+            self._d_streams.append(torch.cuda.Stream(device=self.device))
+        main = torch.cuda.current_stream()
+        out = []
+        for st, f in zip(self._d_streams, fns):
+            if after is not None:
+                st.wait_event(after)
+            else:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out.append(f())
+        for st in self._d_streams[:len(fns)]:
+            main.wait_stream(st)
+        return out
+
     def iter_f(self, input, function, slice_axis):
         """athena:286-296, batched.  The reference iterates range(self.num_slice) = shape[-3] slices for every axis
         (cubes are cubic); a non-cubic crop is refused rather than silently sliced differently."""
@@ -92,13 +123,16 @@ class AxialToLateralGANAthenaModel(BaseModel):
     def backward_G(self):
         """athena:240-260"""
         g, f, r = self.criterionGAN, self.fake, self.rec
-        self.loss_G_A_xy = g(self.iter_f(f, self.netD_A_xy, self.target_sl_axis), True) * self.lambda_plane_target
-        self.loss_G_A_yz = g(self.iter_f(f, self.netD_A_yz, self.source_sl_axis), True) * self.lambda_plane_source
-        self.loss_G_A_xz = g(self.iter_f(f, self.netD_A_xz, self.remain_sl_axis), True) * self.lambda_plane_ref
+        jobs = [(f, self.netD_A_xy, self.target_sl_axis, self.lambda_plane_target),
+                (f, self.netD_A_yz, self.source_sl_axis, self.lambda_plane_source),
+                (f, self.netD_A_xz, self.remain_sl_axis, self.lambda_plane_ref),
+                (r, self.netD_B_xy, self.target_sl_axis, 1 / 3),
+                (r, self.netD_B_yz, self.source_sl_axis, 1 / 3),
+                (r, self.netD_B_xz, self.remain_sl_axis, 1 / 3)]
+        (self.loss_G_A_xy, self.loss_G_A_yz, self.loss_G_A_xz, self.loss_G_B_xy, self.loss_G_B_yz,
+         self.loss_G_B_xz) = self._on_streams([lambda x=x, n=n, a=a, w=w: g(self.iter_f(x, n, a), True) * w
+                                               for x, n, a, w in jobs])
         self.loss_G_A = self.loss_G_A_xy + self.loss_G_A_yz + self.loss_G_A_xz
-        self.loss_G_B_xy = g(self.iter_f(r, self.netD_B_xy, self.target_sl_axis), True) * (1 / 3)
-        self.loss_G_B_yz = g(self.iter_f(r, self.netD_B_yz, self.source_sl_axis), True) * (1 / 3)
-        self.loss_G_B_xz = g(self.iter_f(r, self.netD_B_xz, self.remain_sl_axis), True) * (1 / 3)
         self.loss_G_B = self.loss_G_B_xy + self.loss_G_B_yz + self.loss_G_B_xz
         self.loss_cycle_A = self.criterionCycle(self.rec, self.real) * self.opt.lambda_A
         self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle_A
@@ -115,12 +149,14 @@ class AxialToLateralGANAthenaModel(BaseModel):
         self.optimizer_G.all_reduce_mean()
         self.optimizer_G.step()
         self.set_requires_grad(Ds, True)
+        # (measured: starting these six jobs right after forward(), underneath the generators' backward pass as the Apollo
+        # model does, gains nothing here -- 167.3 vs 167.8 ms: the batched discriminator GEMMs need the whole chip)
         self.optimizer_D.zero_grad()
-        self.loss_D_A_xy = self.backward_D_basic(self.netD_A_xy, self.real, self.fake, t, t)
-        self.loss_D_A_yz = self.backward_D_basic(self.netD_A_yz, self.real, self.fake, t, s)
-        self.loss_D_A_xz = self.backward_D_basic(self.netD_A_xz, self.real, self.fake, t, r)
-        self.loss_D_B_xy = self.backward_D_basic(self.netD_B_xy, self.real, self.rec, t, t)
-        self.loss_D_B_yz = self.backward_D_basic(self.netD_B_yz, self.real, self.rec, s, s)
-        self.loss_D_B_xz = self.backward_D_basic(self.netD_B_xz, self.real, self.rec, r, r)
+        bd = self.backward_D_basic
+        (self.loss_D_A_xy, self.loss_D_A_yz, self.loss_D_A_xz, self.loss_D_B_xy, self.loss_D_B_yz,
+         self.loss_D_B_xz) = self._on_streams([
+             lambda: bd(self.netD_A_xy, self.real, self.fake, t, t), lambda: bd(self.netD_A_yz, self.real, self.fake, t, s),
+             lambda: bd(self.netD_A_xz, self.real, self.fake, t, r), lambda: bd(self.netD_B_xy, self.real, self.rec, t, t),
+             lambda: bd(self.netD_B_yz, self.real, self.rec, s, s), lambda: bd(self.netD_B_xz, self.real, self.rec, r, r)])
         self.optimizer_D.all_reduce_mean()
         self.optimizer_D.step()
