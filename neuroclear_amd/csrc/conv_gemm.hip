@@ -65,20 +65,27 @@ struct GemmParams {
 // accumulators each).  The gathered B image -- the expensive part: ~12 vector instructions of index arithmetic and
 // bounds checks per element -- is shared by twice as many rows in the 128-row tile, which is what the long batched
 // GEMMs of the Athena discriminators (M = 128..512, N = 10^4..10^5 columns) are bound by.
-template <int MODE, int TM>
-__global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
+// KG = wave groups per workgroup: with KG = 2 a second set of four waves takes the other half of every reduction chunk
+// (its own accumulators, added through LDS at the end).  Twice the waves on the same tile and LDS: a single 4-wave
+// workgroup per ~2 tiles per CU leaves the matrix pipe 35-47 % busy (profiles/README.md), the staging work per thread
+// halves as well.
+template <int MODE, int TM, int KG>
+__global__ __launch_bounds__(256 * KG) void k_conv_gemm(GemmParams p) {
   constexpr int kAP = TM + 1;               // pitch of the A image (floats)
   constexpr int WN = TM == 64 ? 2 : 1;      // waves along N
   constexpr int NBLK = 2 / WN;              // 32-column accumulator blocks per wave
   constexpr int MBLK = TM == 256 ? 2 : 1;   // 32-row accumulator blocks per wave
-  constexpr int AJ = TM / 16;               // A elements per thread and chunk
+  constexpr int AJ = TM / (16 * KG);        // A elements per thread and chunk
+  constexpr int BJ = 4 / KG;                // gathered B elements per thread and chunk
+  constexpr int NW = 4 * KG;                // waves
   __shared__ float As[2][16 * kAP];
   __shared__ float Bs[2][16 * 64];
   const ConvDims& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
+  const int kg = wave >> 2, w4 = wave & 3;  // reduction half, position of the wave in the tile
+  const int wm = w4 / WN, wn = w4 % WN;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
   // the reduction may be split over grid.z (small outputs with a long reduction: PatchGAN tail layers, wgrad)
   const int zsplit = MODE == G_DGRAD_P ? blockIdx.z % p.splits : blockIdx.z;
@@ -127,12 +134,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   // ---- A image assignment: r_l = tid & 15 (fast, contiguous in memory), m_l = (tid >> 4) + 16 j
   const int ar = tid & 15, am = tid >> 4;
 
-  float ra[AJ], rb[4];
+  float ra[AJ], rb[BJ];
   auto load_chunk = [&](int r0) {
     // A
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int m = m0 + am + 16 * j, r = r0 + ar;
+      const int m = m0 + am + 16 * KG * j, r = r0 + ar;
       float v = 0.f;
       if (m < p.M && r < r_end) {
         if (MODE == G_FWD) {
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     }
     // B (gathered): reduction index is wave-uniform
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = r0 + wave + 4 * j;
+    for (int j = 0; j < BJ; ++j) {
+      const int r = r0 + wave + NW * j;
       float v = 0.f;
       if (r < r_end && ncol_ok) {
         if (MODE == G_FWD) {
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) As[buf][ar * kAP + am + 16 * j] = ra[j];
+    for (int j = 0; j < AJ; ++j) As[buf][ar * kAP + am + 16 * KG * j] = ra[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Bs[buf][(wave + 4 * j) * 64 + (tid & 63)] = rb[j];
+    for (int j = 0; j < BJ; ++j) Bs[buf][(wave + NW * j) * 64 + (tid & 63)] = rb[j];
   };
 
   f32x16 acc[MBLK][NBLK];
@@ -224,7 +231,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     const float* A = As[buf] + wm * 32 * MBLK + li + h * kAP;
     const float* B = Bs[buf] + wn * 32 * NBLK + li + h * 64;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kq = 0; kq < 8 / KG; ++kq) {
+      const int kk = kg * (8 / KG) + kq;
       float av[MBLK], bv[NBLK];
 #pragma unroll
       for (int mb = 0; mb < MBLK; ++mb) av[mb] = A[2 * kk * kAP + mb * 32];
@@ -241,6 +249,28 @@ __global__ __launch_bounds__(256) void k_conv_gemm(GemmParams p) {
     buf ^= 1;
   }
 
+  // ---- KG = 2: the second wave group hands its accumulators over through LDS (the A image is free now), one 32-row
+  //      block at a time: [w4][nb2][r][lane]
+  if constexpr (KG == 2) {
+    float* X = &As[0][0];
+    static_assert(KG == 1 || 2 * 16 * (TM + 1) >= 4 * 16 * 64, "LDS scratch of the accumulator hand-over");
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+      for (int nb2 = 0; nb2 < NBLK; ++nb2) {  // one 32 x 32 block per wave and round: [w4][r][lane]
+        __syncthreads();
+        if (kg == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) X[(w4 * 16 + r) * 64 + lane] = acc[mb][nb2][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][nb2][r] += X[(w4 * 16 + r) * 64 + lane];
+        }
+      }
+    if (kg == 1) return;
+  }
   // ---- epilogue: row (m) = (r&3) + 8*(r>>2) + 4*h, column (n) = li
 #pragma unroll
   for (int nb2 = 0; nb2 < NBLK; ++nb2) {
@@ -423,9 +453,12 @@ template <int MODE>
 static void launch_gemm(const GemmParams& p, unsigned gz, hipStream_t s) {
   const int tm = tile_rows(p);
   dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, tm), gz);
-  if (tm == 256) hipLaunchKernelGGL((k_conv_gemm<MODE, 256>), grid, dim3(256), 0, s, p);
-  else if (tm == 128) hipLaunchKernelGGL((k_conv_gemm<MODE, 128>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((k_conv_gemm<MODE, 64>), grid, dim3(256), 0, s, p);
+  static const bool kg1 = getenv("NC_GEMM_KG1") != nullptr;  // A/B switch for timing experiments
+  if (tm == 256 && !kg1) hipLaunchKernelGGL((k_conv_gemm<MODE, 256, 2>), grid, dim3(512), 0, s, p);
+  else if (tm == 256) hipLaunchKernelGGL((k_conv_gemm<MODE, 256, 1>), grid, dim3(256), 0, s, p);
+  else if (tm == 128 && !kg1) hipLaunchKernelGGL((k_conv_gemm<MODE, 128, 2>), grid, dim3(512), 0, s, p);
+  else if (tm == 128) hipLaunchKernelGGL((k_conv_gemm<MODE, 128, 1>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_gemm<MODE, 64, 1>), grid, dim3(256), 0, s, p);
 }
 
 static int split_setup(GemmParams& p, int splits, float* out, void* ws, size_t wsb, size_t out_elems,

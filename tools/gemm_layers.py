@@ -29,7 +29,7 @@ for C, K, H, s in LAYERS:
     dy = torch.randn_like(y)
     fl = 2.0 * C * K * 16 * y.numel() / K
     row = '%3d->%3d %3d^2 s%d  %6.1f GF ' % (C, K, H, s, fl / 1e9)
-    for tm in ('256', '128', '64'):
+    for tm in ('256', '128'):
         os.environ['NC_GEMM_TM'] = tm
         tf = timeit(lambda: ops.conv_fwd_raw(x, w, None, s, 1))
         td = timeit(lambda: ops.conv_dgrad_raw(dy, w, x.shape, s, 1))
