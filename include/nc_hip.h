@@ -99,6 +99,12 @@ int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, fl
                         void* stream);
 int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                         int NC, long S, void* ws, size_t ws_bytes, void* stream);
+/* Same backward, and dbias[C] = the per-channel sum of dx over samples and voxels: dx is the gradient at the output of
+ * the convolution in front of the norm (networks.py:420-423), so this IS that convolution's bias gradient -- taken
+ * while dx is in registers instead of by a second pass over dx (nc_conv_wgrad with dbias = NULL then). */
+size_t nc_instnorm_bwd_dbias_ws_bytes(int NC, long S);
+int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 /* LeakyReLU alone (PatchGAN first block, networks.py:1030) */
 int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream);
 int nc_leaky_relu_bwd(const float* dy, const float* x, float slope, float* dx, long n, void* stream);

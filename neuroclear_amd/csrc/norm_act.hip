@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_in_bwd_sums(const float* __restrict__ d
 __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       float slope, long S, int splits,
-                                                      const double* __restrict__ part, float* __restrict__ dx) {
+                                                      const double* __restrict__ part, float* __restrict__ dx,
+                                                      double* __restrict__ rowpart) {
   const int inst = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < splits; ++k) {
@@ -144,11 +145,38 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ 
   const float* px = x + (long)inst * S;
   const float* pg = dy + (long)inst * S;
   float* o = dx + (long)inst * S;
+  double rs = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
     const float xh = (px[i] - m) * r;
     const float g = xh > 0.f ? pg[i] : pg[i] * slope;
-    o[i] = r * (g - m1 - xh * m2);
+    const float v = r * (g - m1 - xh * m2);
+    o[i] = v;
+    rs += (double)v;
   }
+  // rowpart (nullable): sum of this block's share of dx -- dx is the gradient with respect to the output of the
+  // convolution in front of the norm, so its per-channel sum is that convolution's bias gradient, and taking it here
+  // saves the separate pass over dx (nc_conv_wgrad with dbias) that would otherwise compute it
+  if (rowpart) {
+    double zero = 0.0, out2[2];
+    block_reduce2(rs, zero, out2);
+    if (threadIdx.x == 0) rowpart[(long)inst * gridDim.x + blockIdx.x] = out2[0];
+  }
+}
+
+// dbias[c] = sum over samples n and blocks b of rowpart[(n * C + c) * nb + b]: one workgroup per channel, fixed
+// assignment and tree order (deterministic)
+__global__ __launch_bounds__(256) void k_in_dbias_final(const double* __restrict__ rowpart, int N, int C, int nb,
+                                                        float* __restrict__ dbias) {
+  const int c = blockIdx.x;
+  double s = 0.0, zero = 0.0;
+  const int total = N * nb;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int n = i / nb, b = i - n * nb;
+    s += rowpart[((long)n * C + c) * nb + b];
+  }
+  __shared__ double out2[2];
+  block_reduce2(s, zero, out2);
+  if (threadIdx.x == 0) dbias[c] = (float)out2[0];
 }
 
 __global__ void k_lrelu_fwd(const float* __restrict__ x, float slope, float* __restrict__ y, long n) {
@@ -273,8 +301,33 @@ int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, cons
   long bx = cdiv(S, 1024);
   if (bx > 1024) bx = 1024;
   hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)bx, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
-                     (const double*)ws, dx);
+                     (const double*)ws, dx, (double*)nullptr);
   return check_launch("instnorm_act_bwd");
+}
+
+size_t nc_instnorm_bwd_dbias_ws_bytes(int NC, long S) {
+  long bx = cdiv(S, 1024);
+  if (bx > 1024) bx = 1024;
+  return nc_instnorm_ws_bytes(NC, S) + (size_t)NC * bx * sizeof(double);
+}
+
+int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !dx || !dbias) { set_error("instnorm_act_bwd_dbias: null pointer"); return NC_ERR_ARG; }
+  const long NCl = (long)N * C;
+  if (N < 1 || C < 1 || S < 1 || NCl > 65535) { set_error("instnorm_act_bwd_dbias: bad shape"); return NC_ERR_SHAPE; }
+  const int NC = (int)NCl;
+  if (!ws || ws_bytes < nc_instnorm_bwd_dbias_ws_bytes(NC, S)) { set_error("instnorm_act_bwd_dbias: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(NC, S);
+  double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
+  hipLaunchKernelGGL(k_in_bwd_sums, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws);
+  long bx = cdiv(S, 1024);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_in_bwd_apply, dim3((unsigned)bx, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                     (const double*)ws, dx, rowpart);
+  hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
+  return check_launch("instnorm_act_bwd_dbias");
 }
 
 int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream) {

@@ -35,8 +35,8 @@ class InstanceNormAct(nn.Module):
         super().__init__()
         self.num_features, self.slope, self.eps = num_features, slope, eps
 
-    def forward(self, x):
-        return ops.instance_norm_act(x, self.slope, self.eps)
+    def forward(self, x, link=None):
+        return ops.instance_norm_act(x, self.slope, self.eps, link)
 
     def extra_repr(self):
         return '%d, slope=%g (HIP fused IN+act)' % (self.num_features, self.slope)
@@ -130,8 +130,8 @@ class Conv(nn.Module):
         if bias:
             init.zeros_(self.bias)
 
-    def forward(self, x):
-        return ops.conv(x, self.weight, self.bias, self.stride, self.padding)
+    def forward(self, x, link=None):
+        return ops.conv(x, self.weight, self.bias, self.stride, self.padding, link)
 
     def extra_repr(self):
         return '%s, stride=%d, padding=%d' % (tuple(self.weight.shape), self.stride, self.padding)
@@ -158,6 +158,27 @@ def conv(dimension):
     return functools.partial(Conv, dimension=dimension)
 
 
+_BIAS_LINK = os.environ.get('NC_BIAS_LINK', '1') != '0'  # A/B switch (timing experiments)
+
+
+def _run_linked(seq, x):
+    """nn.Sequential.forward, with every (Conv, InstanceNormAct) pair sharing an ops.BiasLink: the norm's backward hands
+    the convolution its bias gradient (see ops.BiasLink)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if _BIAS_LINK and isinstance(m, Conv) and i + 1 < len(mods) and isinstance(mods[i + 1], InstanceNormAct) \
+                and torch.is_grad_enabled():
+            link = ops.BiasLink()
+            x = mods[i + 1](m(x, link), link)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 def _conv_norm_relu(cin, cout, k, s, p, norm_layer, dimension):
     mods = [Conv(cin, cout, k, s, p, dimension=dimension)]
     if norm_layer is not None:
@@ -177,7 +198,7 @@ class double_conv(nn.Module):
               _conv_norm_relu(out_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension)))
 
     def forward(self, x):
-        return self.convolution(x)
+        return _run_linked(self.convolution, x)
 
 
 class last_conv(nn.Module):
@@ -189,7 +210,7 @@ class last_conv(nn.Module):
             *_conv_norm_relu(in_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension))
 
     def forward(self, x):
-        return self.convolution(x)
+        return _run_linked(self.convolution, x)
 
 
 class triple_conv(nn.Module):
@@ -203,7 +224,7 @@ class triple_conv(nn.Module):
               _conv_norm_relu(out_channels, out_channels, kernel_size, stride, padding, norm_layer, dimension)))
 
     def forward(self, x):
-        return self.convolution(x)
+        return _run_linked(self.convolution, x)
 
 
 class Unet_deconv(nn.Module):

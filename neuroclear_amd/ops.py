@@ -266,10 +266,25 @@ def conv_wgrad_raw(x, dy, w_shape, stride, pad, want_bias, ws_tag='ws', xh=None,
     return dw, db
 
 
+class BiasLink:
+    """Shared by a convolution and the InstanceNorm+activation right behind it (networks.py:420-423) for one forward pass.
+    The gradient at the convolution's output is the dx of the norm's backward, so the convolution's bias gradient -- the
+    per-channel sum of that dx -- is taken inside the norm's backward kernel while dx is in registers
+    (nc_instnorm_act_bwd_dbias) and handed over here; the convolution's backward then skips its own pass over dy."""
+    __slots__ = ('want', 'dbias')
+
+    def __init__(self):
+        self.want = False
+        self.dbias = None
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad):
+    def forward(ctx, x, w, b, stride, pad, link=None):
         x = x.contiguous()
+        ctx.link = link
+        if link is not None:
+            link.want = b is not None and ctx.needs_input_grad[2]
         ctx.cfg = (stride, pad, b is not None)
         ctx.x_shape = tuple(x.shape)
         dims, K, k3 = _dims5(x.shape), w.shape[0], _kdims(w.shape)
@@ -295,6 +310,11 @@ class _Conv(torch.autograd.Function):
         dx = dw = db = None
         want_b = has_b and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
+        db_link = None
+        if want_b and ctx.link is not None and ctx.link.dbias is not None:
+            db_link, ctx.link.dbias = ctx.link.dbias, None  # taken by the norm's backward: no pass over dy for it here
+            want_b = False
+            want_w = ctx.needs_input_grad[1]
         dims, K, k3 = _dims5(ctx.x_shape), w.shape[0], _kdims(w.shape)
         dt_d = _lp(1, dims, K, k3, stride, pad) if ctx.needs_input_grad[0] else 0
         dt_w = _lp(2, dims, K, k3, stride, pad) if want_w else 0
@@ -309,7 +329,7 @@ class _Conv(torch.autograd.Function):
                                             x_shape=ctx.x_shape)
                 else:
                     dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b, dyh=dyh if same else None)
-            return dx, dw, db, None, None
+            return dx, dw, db if db_link is None else db_link, None, None, None
         big = x.numel() >= (1 << 20)  # small layers gain nothing from a second stream
         if want_w and ctx.needs_input_grad[0] and overlap_wgrad and big and prof is None:
             main = torch.cuda.current_stream()
@@ -321,17 +341,17 @@ class _Conv(torch.autograd.Function):
             x.record_stream(side)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
             main.wait_stream(side)  # dw / db are consumed (accumulated into .grad) on the main stream
-            return dx, dw, db, None, None
+            return dx, dw, db if db_link is None else db_link, None, None, None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
         if want_w:
             dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b)
-        return dx, dw, db, None, None
+        return dx, dw, db if db_link is None else db_link, None, None, None
 
 
-def conv(x, w, b=None, stride=1, padding=0):
-    """nn.Conv3d / nn.Conv2d (models/networks.py:361-369)."""
-    return _Conv.apply(x, w, b, int(stride), int(padding))
+def conv(x, w, b=None, stride=1, padding=0, link=None):
+    """nn.Conv3d / nn.Conv2d (models/networks.py:361-369).  link: see BiasLink."""
+    return _Conv.apply(x, w, b, int(stride), int(padding), link)
 
 
 class _ConvT(torch.autograd.Function):
@@ -393,8 +413,9 @@ def instnorm_stats(x, eps=1e-5):
 
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, slope, eps):
+    def forward(ctx, x, slope, eps, link=None):
         x = x.contiguous()
+        ctx.link = link
         mean, rstd = instnorm_stats(x, eps)
         NC = mean.numel()
         S = x.numel() // NC
@@ -412,15 +433,25 @@ class _InstNormAct(torch.autograd.Function):
         NC = mean.numel()
         S = x.numel() // NC
         dx = torch.empty_like(x)
+        link = ctx.link
+        if link is not None and link.want:
+            N, C = x.shape[0], x.shape[1]
+            db = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws = workspace(lib().nc_instnorm_bwd_dbias_ws_bytes(I(NC), L_(S)), x.device, 'in')
+            check(lib().nc_instnorm_act_bwd_dbias(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), F(ctx.slope), _ptr(dx), _ptr(db),
+                                                  I(N), I(C), L_(S), _ptr(ws), Z(ws.numel()), _stream()),
+                  'nc_instnorm_act_bwd_dbias')
+            link.dbias = db
+            return dx, None, None, None
         ws = workspace(lib().nc_instnorm_ws_bytes(I(NC), L_(S)), x.device, 'in')
         check(lib().nc_instnorm_act_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), F(ctx.slope), _ptr(dx), I(NC),
                                         L_(S), _ptr(ws), Z(ws.numel()), _stream()), 'nc_instnorm_act_bwd')
-        return dx, None, None
+        return dx, None, None, None
 
 
-def instance_norm_act(x, slope=0.0, eps=1e-5):
+def instance_norm_act(x, slope=0.0, eps=1e-5, link=None):
     """InstanceNorm{2,3}d(affine=False) followed by ReLU (slope 0) / LeakyReLU(slope) -- networks.py:33-34,422-423."""
-    return _InstNormAct.apply(x, float(slope), float(eps))
+    return _InstNormAct.apply(x, float(slope), float(eps), link)
 
 
 class _LeakyReLU(torch.autograd.Function):

@@ -246,3 +246,48 @@ def _sweep_cases():
 @pytest.mark.parametrize('case', _sweep_cases(), ids=lambda c: 'N%dC%dK%d_%s_k%ds%dp%d' % (c[0], c[1], c[2], 'x'.join(map(str, c[3])), c[4], c[5], c[6]))
 def test_conv_shape_sweep(case):
     test_conv(case, False)
+
+
+def test_instnorm_bwd_dbias_is_the_channel_sum_of_dx():
+    """nc_instnorm_act_bwd_dbias: dbias[c] = sum over samples and voxels of dx.  With the true statistics that sum is
+    rounding noise (InstanceNorm's backward has zero mean per instance), so the plumbing is checked with deliberately
+    wrong statistics, where the sums are O(1)."""
+    from neuroclear_amd import _lib
+    from neuroclear_amd._lib import F as CF, I, L_, Z
+    L = _lib.lib()
+    N, C, S = 3, 10, 5000
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(N, C, S, device='cuda', generator=g)
+    dy = torch.randn(N, C, S, device='cuda', generator=g)
+    mean = x.mean(2).reshape(-1) + 0.3 * torch.randn(N * C, device='cuda', generator=g)
+    rstd = 1.0 / (x.var(2, unbiased=False).reshape(-1) + 1e-5).sqrt() * 1.2
+    dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
+    db = torch.empty(C, device='cuda')
+    nb = L.nc_instnorm_bwd_dbias_ws_bytes(I(N * C), L_(S))
+    ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    P = ops._ptr
+    assert L.nc_instnorm_act_bwd(P(dy), P(x), P(mean), P(rstd), CF(0.2), P(dx1), I(N * C), L_(S), P(ws), Z(nb), None) == 0
+    assert L.nc_instnorm_act_bwd_dbias(P(dy), P(x), P(mean), P(rstd), CF(0.2), P(dx2), P(db), I(N), I(C), L_(S), P(ws), Z(nb),
+                                       None) == 0
+    assert torch.equal(dx1, dx2)
+    want = dx1.double().sum((0, 2))
+    assert want.abs().min().item() > 1e-2  # the sums are not noise in this set-up
+    assert (db.double() - want).abs().max().item() <= 1e-6 * dx1.abs().double().sum((0, 2)).max().item()
+
+
+def test_bias_link_gives_the_same_gradients():
+    """(Conv, InstanceNormAct) pairs of the U-Net blocks hand the bias gradient over through ops.BiasLink: same dx / dw as
+    the unlinked ops, bias gradient = the (noise-level) channel sum of the same dx."""
+    x = T(21, (2, 8, 6, 7, 9)).requires_grad_(True)
+    w = T(22, (12, 8, 3, 3, 3), scale=0.2).requires_grad_(True)
+    b = T(23, (12,), scale=0.1).requires_grad_(True)
+    r = T(24, (2, 12, 6, 7, 9))
+    y0 = ops.instance_norm_act(ops.conv(x, w, b, 1, 1), 0.0)
+    g0 = torch.autograd.grad((y0 * r).sum(), (x, w, b))
+    link = ops.BiasLink()
+    y1 = ops.instance_norm_act(ops.conv(x, w, b, 1, 1, link), 0.0, 1e-5, link)
+    g1 = torch.autograd.grad((y1 * r).sum(), (x, w, b))
+    assert torch.equal(y0, y1) and torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1])
+    scale = g0[1].abs().max().item()
+    assert g0[2].abs().max().item() <= 1e-4 * scale and g1[2].abs().max().item() <= 1e-4 * scale  # both are noise
+    assert link.dbias is None  # consumed
