@@ -209,8 +209,13 @@ def run_infer(args, rank, world, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     del out
+    from neuroclear_amd.util import util as U
+    padded = U.padded_shape((L, L, L), 120, 15)
+    ncubes = int(np.prod(U.grid_steps(padded, 120, 15)))
+    computed = ncubes * 140 ** 3  # voxels the network actually processes (overlap + border: 2.74 x the volume at 900^3)
     return dt, L ** 3 * args.steps, None, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
-                                               parallelism='cubes%%%d' % world)
+                                               parallelism='cubes%%%d' % world, cubes=ncubes,
+                                               computed_voxels_per_s=round(computed * args.steps / dt))
 
 
 def main():
