@@ -105,6 +105,15 @@ int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, cons
 size_t nc_instnorm_bwd_dbias_ws_bytes(int NC, long S);
 int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
+/* The normalise + activate pass and its backward for the 16-bit convolution path: next to the fp32 result they emit it
+ * in the C8 operand layout (nc_to_c8) of the convolution that consumes it -- yh for the next layer's forward, dxh (the
+ * gradient at the previous convolution's output) for its data / weight gradient -- which saves those conversion passes.
+ * C % 8 == 0; dbias nullable (see nc_instnorm_act_bwd_dbias); workspace: nc_instnorm_bwd_dbias_ws_bytes. */
+int nc_instnorm_act_fwd_c8(const float* x, const float* mean, const float* rstd, float slope, float* y, void* yh, int N, int C,
+                           long S, int dtype, void* stream);
+int nc_instnorm_act_bwd_c8(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                           void* dxh, float* dbias /* or NULL */, int N, int C, long S, int dtype, void* ws, size_t ws_bytes,
+                           void* stream);
 /* LeakyReLU alone (PatchGAN first block, networks.py:1030) */
 int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream);
 int nc_leaky_relu_bwd(const float* dy, const float* x, float slope, float* dx, long n, void* stream);

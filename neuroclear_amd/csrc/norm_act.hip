@@ -179,6 +179,106 @@ __global__ __launch_bounds__(256) void k_in_dbias_final(const double* __restrict
   if (threadIdx.x == 0) dbias[c] = (float)out2[0];
 }
 
+// ---- the same two kernels for the 16-bit convolution path (conv_h.hip): next to the fp32 result they emit it in the
+//      C8 operand layout of those kernels ([N][C/8][voxels][8 channels] bf16 / fp16), so the convolution that consumes it
+//      does not run a conversion pass of its own.  One thread = one voxel of 8 consecutive channels (C % 8 == 0).
+template <int DT>
+__device__ __forceinline__ unsigned short cvt16n(float f) {
+  if constexpr (DT == NC_DT_F16) {
+    const _Float16 v = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  } else {
+    const __bf16 v = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const unsigned short (&e)[8]) {
+  uint4 o;
+  o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+  o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+  return o;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_in_act_fwd_c8(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float slope, float* __restrict__ y,
+                                                       uint4* __restrict__ yh, long S) {
+  const long ncb = blockIdx.y;  // n * (C/8) + cb: instances ncb*8 .. ncb*8+7
+  float m[8], r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = mean[ncb * 8 + j]; r[j] = rstd[ncb * 8 + j]; }
+  const float* px = x + ncb * 8 * S;
+  float* py = y + ncb * 8 * S;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = (px[j * S + v] - m[j]) * r[j];
+      t = t > 0.f ? t : t * slope;
+      py[j * S + v] = t;
+      e[j] = cvt16n<DT>(t);
+    }
+    yh[ncb * S + v] = pack8(e);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_in_bwd_apply_c8(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float slope, long S, int splits, const double* __restrict__ part,
+                                                         float* __restrict__ dx, uint4* __restrict__ dxh,
+                                                         double* __restrict__ rowpart) {
+  __shared__ float sm[2][8];
+  __shared__ double red[8][4];
+  const long ncb = blockIdx.y;
+  if (threadIdx.x < 8) {
+    const long inst = ncb * 8 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < splits; ++k) {
+      s1 += part[(inst * splits + k) * 2];
+      s2 += part[(inst * splits + k) * 2 + 1];
+    }
+    sm[0][threadIdx.x] = (float)(s1 / (double)S);
+    sm[1][threadIdx.x] = (float)(s2 / (double)S);
+  }
+  __syncthreads();
+  float m[8], r[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = mean[ncb * 8 + j]; r[j] = rstd[ncb * 8 + j]; m1[j] = sm[0][j]; m2[j] = sm[1][j]; }
+  const float* px = x + ncb * 8 * S;
+  const float* pg = dy + ncb * 8 * S;
+  float* o = dx + ncb * 8 * S;
+  double rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rs[j] = 0.0;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (px[j * S + v] - m[j]) * r[j];
+      const float g = xh > 0.f ? pg[j * S + v] : pg[j * S + v] * slope;
+      const float t = r[j] * (g - m1[j] - xh * m2[j]);
+      o[j * S + v] = t;
+      rs[j] += (double)t;
+      e[j] = cvt16n<DT>(t);
+    }
+    dxh[ncb * S + v] = pack8(e);
+  }
+  if (rowpart) {  // per-channel sums of this block's share of dx (the convolution's bias gradient, see k_in_bwd_apply)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double a = rs[j];
+      for (int of = 32; of > 0; of >>= 1) a += __shfl_down(a, of);
+      if (lane == 0) red[j][wv] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      rowpart[(ncb * 8 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
 __global__ void k_lrelu_fwd(const float* __restrict__ x, float slope, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = x[i];
@@ -328,6 +428,46 @@ int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean
                      (const double*)ws, dx, rowpart);
   hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
   return check_launch("instnorm_act_bwd_dbias");
+}
+
+int nc_instnorm_act_fwd_c8(const float* x, const float* mean, const float* rstd, float slope, float* y, void* yh, int N, int C,
+                           long S, int dtype, void* stream) {
+  if (!x || !mean || !rstd || !y || !yh) { set_error("instnorm_act_fwd_c8: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 8 || C % 8 || S < 1 || (long)N * C / 8 > 65535) { set_error("instnorm_act_fwd_c8: bad shape"); return NC_ERR_SHAPE; }
+  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("instnorm_act_fwd_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  long bx = cdiv(S, 256);
+  if (bx > 2048) bx = 2048;
+  dim3 grid((unsigned)bx, (unsigned)(N * C / 8));
+  if (dtype == NC_DT_F16)
+    hipLaunchKernelGGL(k_in_act_fwd_c8<NC_DT_F16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, slope, y, (uint4*)yh, S);
+  else
+    hipLaunchKernelGGL(k_in_act_fwd_c8<NC_DT_BF16>, grid, dim3(256), 0, (hipStream_t)stream, x, mean, rstd, slope, y, (uint4*)yh, S);
+  return check_launch("instnorm_act_fwd_c8");
+}
+
+int nc_instnorm_act_bwd_c8(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
+                           void* dxh, float* dbias, int N, int C, long S, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !dx || !dxh) { set_error("instnorm_act_bwd_c8: null pointer"); return NC_ERR_ARG; }
+  const long NCl = (long)N * C;
+  if (N < 1 || C < 8 || C % 8 || S < 1 || NCl > 65535) { set_error("instnorm_act_bwd_c8: bad shape"); return NC_ERR_SHAPE; }
+  if (dtype != NC_DT_F16 && dtype != NC_DT_BF16) { set_error("instnorm_act_bwd_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  const int NC = (int)NCl;
+  if (!ws || ws_bytes < nc_instnorm_bwd_dbias_ws_bytes(NC, S)) { set_error("instnorm_act_bwd_c8: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(NC, S);
+  hipLaunchKernelGGL(k_in_bwd_sums, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws);
+  long bx = cdiv(S, 1024);  // the same block count as nc_instnorm_bwd_dbias_ws_bytes sizes the partials for
+  if (bx > 1024) bx = 1024;
+  double* rowpart = dbias ? (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S)) : nullptr;
+  dim3 grid((unsigned)bx, (unsigned)(NC / 8));
+  if (dtype == NC_DT_F16)
+    hipLaunchKernelGGL(k_in_bwd_apply_c8<NC_DT_F16>, grid, dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                       (const double*)ws, dx, (uint4*)dxh, rowpart);
+  else
+    hipLaunchKernelGGL(k_in_bwd_apply_c8<NC_DT_BF16>, grid, dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                       (const double*)ws, dx, (uint4*)dxh, rowpart);
+  if (dbias) hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
+  return check_launch("instnorm_act_bwd_c8");
 }
 
 int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream) {

@@ -35,8 +35,8 @@ class InstanceNormAct(nn.Module):
         super().__init__()
         self.num_features, self.slope, self.eps = num_features, slope, eps
 
-    def forward(self, x, link=None):
-        return ops.instance_norm_act(x, self.slope, self.eps, link)
+    def forward(self, x, link=None, nxt=None):
+        return ops.instance_norm_act(x, self.slope, self.eps, link, nxt)
 
     def extra_repr(self):
         return '%d, slope=%g (HIP fused IN+act)' % (self.num_features, self.slope)
@@ -130,8 +130,8 @@ class Conv(nn.Module):
         if bias:
             init.zeros_(self.bias)
 
-    def forward(self, x, link=None):
-        return ops.conv(x, self.weight, self.bias, self.stride, self.padding, link)
+    def forward(self, x, link=None, prev=None):
+        return ops.conv(x, self.weight, self.bias, self.stride, self.padding, link, prev)
 
     def extra_repr(self):
         return '%s, stride=%d, padding=%d' % (tuple(self.weight.shape), self.stride, self.padding)
@@ -162,19 +162,37 @@ _BIAS_LINK = os.environ.get('NC_BIAS_LINK', '1') != '0'  # A/B switch (timing ex
 
 
 def _run_linked(seq, x):
-    """nn.Sequential.forward, with every (Conv, InstanceNormAct) pair sharing an ops.BiasLink: the norm's backward hands
-    the convolution its bias gradient (see ops.BiasLink)."""
+    """nn.Sequential.forward, with every (Conv, InstanceNormAct) pair sharing an ops.BiasLink (the norm's backward hands
+    the convolution its bias gradient and, on the 16-bit path, dy in the kernels' operand layout) and every
+    (InstanceNormAct, next Conv) pair sharing one too (the norm's forward hands the next layer its input in that layout)."""
     mods = list(seq)
-    i = 0
+    i, prev = 0, None
     while i < len(mods):
         m = mods[i]
         if _BIAS_LINK and isinstance(m, Conv) and i + 1 < len(mods) and isinstance(mods[i + 1], InstanceNormAct) \
                 and torch.is_grad_enabled():
             link = ops.BiasLink()
-            x = mods[i + 1](m(x, link), link)
+            raw = m(x, link, prev)
+            j = i + 2
+            while j < len(mods) and isinstance(mods[j], FusedActivation):
+                j += 1
+            nxt = None
+            if j < len(mods) and isinstance(mods[j], Conv):
+                dt = ops.lp_fwd_dtype(raw.shape, mods[j].weight.shape, mods[j].stride, mods[j].padding)
+                if dt:
+                    nxt = ops.BiasLink()
+                    nxt.want_xh = dt
+            x = mods[i + 1](raw, link, nxt)
+            prev = nxt
             i += 2
         else:
-            x = m(x)
+            if isinstance(m, Conv):
+                x = m(x, None, prev)
+                prev = None
+            else:
+                x = m(x)
+                if not isinstance(m, FusedActivation):
+                    prev = None
             i += 1
     return x
 

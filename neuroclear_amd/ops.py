@@ -270,17 +270,35 @@ class BiasLink:
     """Shared by a convolution and the InstanceNorm+activation right behind it (networks.py:420-423) for one forward pass.
     The gradient at the convolution's output is the dx of the norm's backward, so the convolution's bias gradient -- the
     per-channel sum of that dx -- is taken inside the norm's backward kernel while dx is in registers
-    (nc_instnorm_act_bwd_dbias) and handed over here; the convolution's backward then skips its own pass over dy."""
-    __slots__ = ('want', 'dbias')
+    (nc_instnorm_act_bwd_dbias) and handed over here; the convolution's backward then skips its own pass over dy.
+    The same object also carries the 16-bit operand copies between the two (conv_h.hip's C8 layout), in both directions:
+    * forward, norm -> NEXT convolution: `want_xh` (dtype code, set by the caller that knows the next layer) makes the
+      norm's forward emit its result in C8 as well (`xh`), and that convolution skips its own conversion pass;
+    * backward, norm -> the convolution in FRONT of it: `want_dyh` (set by that convolution's forward) makes the norm's
+      backward emit dx in C8 (`dyh`) for the data / weight gradient kernels."""
+    __slots__ = ('want', 'dbias', 'want_xh', 'xh', 'xh_dt', 'want_dyh', 'dyh', 'dyh_dt')
 
     def __init__(self):
         self.want = False
         self.dbias = None
+        self.want_xh = 0
+        self.xh = None
+        self.xh_dt = 0
+        self.want_dyh = 0
+        self.dyh = None
+        self.dyh_dt = 0
+
+
+def lp_fwd_dtype(x_shape, w_shape, stride, pad):
+    """dtype code of the 16-bit forward kernel a convolution with this weight would use on an input of x_shape, or 0."""
+    if len(x_shape) != len(w_shape) or x_shape[1] != w_shape[1]:
+        return 0
+    return _lp(0, _dims5(x_shape), w_shape[0], _kdims(w_shape), int(stride), int(pad))
 
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, link=None):
+    def forward(ctx, x, w, b, stride, pad, link=None, prev=None):
         x = x.contiguous()
         ctx.link = link
         if link is not None:
@@ -292,9 +310,17 @@ class _Conv(torch.autograd.Function):
         if dt:
             # 16-bit path: x is converted ONCE; if the weight gradient runs in the same type it reuses that copy, and the
             # copy (half the bytes) is what is kept for backward instead of the fp32 activation
-            xh = to_c8(x, dt)
+            if prev is not None and prev.xh is not None and prev.xh_dt == dt:
+                xh, prev.xh = prev.xh, None  # emitted by the norm in front of this layer
+            else:
+                xh = to_c8(x, dt)
             y = conv_fwd_raw(x, w, b, stride, pad, xh=xh)
             keep = _lp(2, dims, K, k3, stride, pad) == dt
+            if link is not None:  # backward operands: ask the norm behind this layer for dy in C8
+                dd = _lp(1, dims, K, k3, stride, pad) if ctx.needs_input_grad[0] else 0
+                dw_ = _lp(2, dims, K, k3, stride, pad) if (ctx.needs_input_grad[1] or link.want) else 0
+                if (dd or dw_) and (not dd or not dw_ or dd == dw_):
+                    link.want_dyh = dd or dw_
             ctx.x_is_c8 = keep
             ctx.save_for_backward(xh if keep else x, w)
             return y
@@ -319,7 +345,11 @@ class _Conv(torch.autograd.Function):
         dt_d = _lp(1, dims, K, k3, stride, pad) if ctx.needs_input_grad[0] else 0
         dt_w = _lp(2, dims, K, k3, stride, pad) if want_w else 0
         if dt_d or dt_w:  # 16-bit backward: dy is converted once for the data and the weight gradient
-            dyh = to_c8(dy, dt_d or dt_w)
+            lk = ctx.link
+            if lk is not None and lk.dyh is not None and lk.dyh_dt == (dt_d or dt_w):
+                dyh, lk.dyh = lk.dyh, None  # emitted by the backward of the norm behind this layer
+            else:
+                dyh = to_c8(dy, dt_d or dt_w)
             if ctx.needs_input_grad[0]:
                 dx = conv_dgrad_raw(dy, w, ctx.x_shape, stride, pad, dyh=dyh if dt_d else None)
             if want_w:
@@ -329,7 +359,7 @@ class _Conv(torch.autograd.Function):
                                             x_shape=ctx.x_shape)
                 else:
                     dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b, dyh=dyh if same else None)
-            return dx, dw, db if db_link is None else db_link, None, None, None
+            return dx, dw, db if db_link is None else db_link, None, None, None, None
         big = x.numel() >= (1 << 20)  # small layers gain nothing from a second stream
         if want_w and ctx.needs_input_grad[0] and overlap_wgrad and big and prof is None:
             main = torch.cuda.current_stream()
@@ -341,17 +371,18 @@ class _Conv(torch.autograd.Function):
             x.record_stream(side)
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
             main.wait_stream(side)  # dw / db are consumed (accumulated into .grad) on the main stream
-            return dx, dw, db if db_link is None else db_link, None, None, None
+            return dx, dw, db if db_link is None else db_link, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dy, w, x.shape, stride, pad)
         if want_w:
             dw, db = conv_wgrad_raw(x, dy, w.shape, stride, pad, want_b)
-        return dx, dw, db if db_link is None else db_link, None, None, None
+        return dx, dw, db if db_link is None else db_link, None, None, None, None
 
 
-def conv(x, w, b=None, stride=1, padding=0, link=None):
-    """nn.Conv3d / nn.Conv2d (models/networks.py:361-369).  link: see BiasLink."""
-    return _Conv.apply(x, w, b, int(stride), int(padding), link)
+def conv(x, w, b=None, stride=1, padding=0, link=None, prev=None):
+    """nn.Conv3d / nn.Conv2d (models/networks.py:361-369).  link / prev: BiasLink shared with the InstanceNorm behind /
+    in front of this layer."""
+    return _Conv.apply(x, w, b, int(stride), int(padding), link, prev)
 
 
 class _ConvT(torch.autograd.Function):
@@ -413,15 +444,21 @@ def instnorm_stats(x, eps=1e-5):
 
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, slope, eps, link=None):
+    def forward(ctx, x, slope, eps, link=None, nxt=None):
         x = x.contiguous()
         ctx.link = link
         mean, rstd = instnorm_stats(x, eps)
         NC = mean.numel()
         S = x.numel() // NC
         y = torch.empty_like(x)
-        check(lib().nc_instnorm_act_fwd(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), I(NC), L_(S), _stream()),
-              'nc_instnorm_act_fwd')
+        if nxt is not None and nxt.want_xh and x.shape[1] % 8 == 0:
+            yh = torch.empty(x.numel() * 2, dtype=torch.uint8, device=x.device)
+            check(lib().nc_instnorm_act_fwd_c8(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), _ptr(yh), I(x.shape[0]),
+                                               I(x.shape[1]), L_(S), I(nxt.want_xh), _stream()), 'nc_instnorm_act_fwd_c8')
+            nxt.xh, nxt.xh_dt = yh, nxt.want_xh
+        else:
+            check(lib().nc_instnorm_act_fwd(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), I(NC), L_(S), _stream()),
+                  'nc_instnorm_act_fwd')
         ctx.save_for_backward(x, mean, rstd)
         ctx.slope = slope
         return y
@@ -434,6 +471,16 @@ class _InstNormAct(torch.autograd.Function):
         S = x.numel() // NC
         dx = torch.empty_like(x)
         link = ctx.link
+        if link is not None and link.want_dyh and x.shape[1] % 8 == 0:
+            N, C = x.shape[0], x.shape[1]
+            db = torch.empty(C, dtype=torch.float32, device=x.device) if link.want else None
+            dxh = torch.empty(x.numel() * 2, dtype=torch.uint8, device=x.device)
+            ws = workspace(lib().nc_instnorm_bwd_dbias_ws_bytes(I(NC), L_(S)), x.device, 'in')
+            check(lib().nc_instnorm_act_bwd_c8(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), F(ctx.slope), _ptr(dx), _ptr(dxh),
+                                               _ptr(db), I(N), I(C), L_(S), I(link.want_dyh), _ptr(ws), Z(ws.numel()),
+                                               _stream()), 'nc_instnorm_act_bwd_c8')
+            link.dyh, link.dyh_dt, link.dbias = dxh, link.want_dyh, db
+            return dx, None, None, None, None
         if link is not None and link.want:
             N, C = x.shape[0], x.shape[1]
             db = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -442,16 +489,17 @@ class _InstNormAct(torch.autograd.Function):
                                                   I(N), I(C), L_(S), _ptr(ws), Z(ws.numel()), _stream()),
                   'nc_instnorm_act_bwd_dbias')
             link.dbias = db
-            return dx, None, None, None
+            return dx, None, None, None, None
         ws = workspace(lib().nc_instnorm_ws_bytes(I(NC), L_(S)), x.device, 'in')
         check(lib().nc_instnorm_act_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), F(ctx.slope), _ptr(dx), I(NC),
                                         L_(S), _ptr(ws), Z(ws.numel()), _stream()), 'nc_instnorm_act_bwd')
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def instance_norm_act(x, slope=0.0, eps=1e-5, link=None):
-    """InstanceNorm{2,3}d(affine=False) followed by ReLU (slope 0) / LeakyReLU(slope) -- networks.py:33-34,422-423."""
-    return _InstNormAct.apply(x, float(slope), float(eps), link)
+def instance_norm_act(x, slope=0.0, eps=1e-5, link=None, nxt=None):
+    """InstanceNorm{2,3}d(affine=False) followed by ReLU (slope 0) / LeakyReLU(slope) -- networks.py:33-34,422-423.
+    link / nxt: BiasLink shared with the convolution in front of / behind this layer."""
+    return _InstNormAct.apply(x, float(slope), float(eps), link, nxt)
 
 
 class _LeakyReLU(torch.autograd.Function):

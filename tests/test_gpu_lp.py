@@ -180,3 +180,44 @@ def test_lp_apollo_step_close_to_fp32():
     assert set(l32) == set(l16) and len(l32) == 11
     for k in l32:
         assert abs(l16[k] - l32[k]) <= 2e-2 * max(abs(l32[k]), 1e-3), (k, l32[k], l16[k])
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_lp_links_hand_over_identical_operands(prec):
+    """The InstanceNorm kernels that emit the C8 copy of their result (forward: input of the next convolution; backward:
+    dy of the previous one) round the same fp32 values the separate conversion pass would: a block run with the links
+    gives bit-identical activations and weight / data gradients to the same block with per-call conversions."""
+    from neuroclear_amd import ops
+    from neuroclear_amd.models import networks
+    blk = networks.triple_conv(64, 64, 3, 1, 1, networks.get_norm_layer('instance'), 3).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(12)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, device='cuda', generator=gen) * (0.05 if p_.dim() > 1 else 0.1))
+    x = torch.randn(2, 64, 9, 20, 22, device='cuda', generator=gen)
+    r = torch.randn(2, 64, 9, 20, 22, device='cuda', generator=gen)
+
+    def run(linked):
+        old = networks._BIAS_LINK
+        networks._BIAS_LINK = linked
+        try:
+            ops.set_conv_precision(prec)
+            for p_ in blk.parameters():
+                p_.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = blk(xi)
+            (y * r).sum().backward()
+            return y.detach().clone(), xi.grad.clone(), {n: p_.grad.clone() for n, p_ in blk.named_parameters()}
+        finally:
+            networks._BIAS_LINK = old
+            ops.set_conv_precision('fp32')
+
+    y0, gx0, g0 = run(False)
+    y1, gx1, g1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    for n in g0:
+        if g0[n].dim() > 1:
+            assert torch.equal(g0[n], g1[n]), n
+        else:  # bias gradients in front of InstanceNorm: rounding noise on both sides
+            scale = max(v.abs().max().item() for k, v in g0.items() if v.dim() > 1)
+            assert g0[n].abs().max().item() <= 1e-4 * scale and g1[n].abs().max().item() <= 1e-4 * scale
