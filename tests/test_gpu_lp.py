@@ -221,3 +221,47 @@ def test_lp_links_hand_over_identical_operands(prec):
         else:  # bias gradients in front of InstanceNorm: rounding noise on both sides
             scale = max(v.abs().max().item() for k, v in g0.items() if v.dim() > 1)
             assert g0[n].abs().max().item() <= 1e-4 * scale and g1[n].abs().max().item() <= 1e-4 * scale
+
+
+def test_lp_shape_sweep():
+    """36 random small shapes (odd sizes, single rows / planes, batches, both kernel sizes, every supported channel
+    multiple): forward, data and weight gradient of the 16-bit kernels against torch on the same rounded operands."""
+    from neuroclear_amd import ops
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 36:
+        ks = int(rng.choice([3, 3, 5]))
+        C = int(rng.choice([16, 32, 48, 64, 96])) if ks == 3 else int(rng.choice([8, 32, 64]))
+        K = int(rng.choice([64, 128]))
+        N = int(rng.integers(1, 4))
+        D, H, W = (int(rng.integers(1, 12)), int(rng.integers(1, 24)), int(rng.integers(1, 40)))
+        dims = (N, C, D, H, W)
+        k3, pad = (ks, ks, ks), ks // 2
+        ops.set_conv_precision('bf16')
+        sup = [ops._lp(w_, dims, K, k3, 1, pad) for w_ in (0, 1, 2)]
+        ops.set_conv_precision('fp32')
+        if not sup[0]:
+            continue
+        g = torch.Generator(device='cuda').manual_seed(done)
+        x = torch.randn(dims, device='cuda', generator=g)
+        w = torch.randn(K, C, ks, ks, ks, device='cuda', generator=g) / (C * ks ** 3) ** 0.5
+        dy = torch.randn(N, K, D, H, W, device='cuda', generator=g)
+        xr, wr, dyr = _rnd(x, 'bf16'), _rnd(w, 'bf16'), _rnd(dy, 'bf16')
+        ops.set_conv_precision('bf16')
+        y = ops.conv_fwd_raw(x, w, None, 1, pad)
+        dx = ops.conv_dgrad_raw(dy, w, x.shape, 1, pad) if sup[1] else None
+        dw = ops.conv_wgrad_raw(x, dy, w.shape, 1, pad, False)[0] if sup[2] else None
+        ops.set_conv_precision('fp32')
+
+        def close(a, ref, tol, what):
+            err = (a - ref).abs().max().item()
+            assert err <= tol * max(ref.abs().max().item(), 1e-6), (what, dims, K, ks, err)
+
+        close(y, F.conv3d(xr, wr, None, padding=pad), 5e-5, 'fwd')
+        if dx is not None:
+            close(dx, F.conv_transpose3d(dyr, wr, padding=pad), 5e-5, 'dgrad')
+        if dw is not None:
+            wz = torch.zeros_like(w, requires_grad=True)
+            F.conv3d(xr, wz, None, padding=pad).backward(dyr)
+            close(dw, wz.grad, 1e-4, 'wgrad')
+        done += 1
