@@ -81,6 +81,9 @@ class SingleVolumeDataset:
             z = random.randint(0, v.shape[0] - cz)
             y = random.randint(0, v.shape[1] - cy)
             x = random.randint(0, v.shape[2] - cx)
+            # crop size 0 on an axis = keep the full axis: the draw still happens (RNG order), the origin is 0
+            # (data/base_dataset.py:199-214)
+            z, y, x = (z if cz else 0), (y if cy else 0), (x if cx else 0)
             v = v[z:z + cz if cz else None, y:y + cy if cy else None, x:x + cx if cx else None]
         if not (self.rot3d or self.rot90):
             a = (v.to(torch.float64) / self.den).to(torch.float32)  # __normalize: float64 division, then .float()

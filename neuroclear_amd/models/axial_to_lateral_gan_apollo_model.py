@@ -67,6 +67,7 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],
                       g['eps'], self.state_step)
+        ops.bump_param_generation(self.flat)
 
 
 class AxialToLateralGANApolloModel(BaseModel):
@@ -162,8 +163,11 @@ class AxialToLateralGANApolloModel(BaseModel):
 
     @staticmethod
     def _D(netD, planes):
+        # every plane is [N, C, A, B] (N = batch): plane i owns rows i*N .. (i+1)*N of the batched prediction, and the
+        # LSGAN mean of a plane runs over its whole batch, as the reference's per-plane netD call does (apollo:169-193)
         pred = netD(planes[0] if len(planes) == 1 else torch.cat(planes, 0))
-        return [pred[i:i + 1] for i in range(len(planes))]
+        n = planes[0].shape[0]
+        return [pred[i * n:(i + 1) * n] for i in range(len(planes))]
 
     def _D_many(self, jobs, loss_fn, after=None, backward=False):
         """Evaluate independent discriminators concurrently: jobs = [(netD, planes_fn)], loss_fn(i, preds) -> tensor or

@@ -121,6 +121,9 @@ class BaseModel(ABC):
                     if key.split('.')[-1] in ('running_mean', 'running_var', 'num_batches_tracked'):
                         state_dict.pop(key)
                 net.load_state_dict(state_dict)
+                for prm in net.parameters():  # in-place copies into (possibly flat, aliased) parameter storage
+                    ops.bump_param_generation(prm)
+                    break
 
     def print_networks(self, verbose):
         print('---------- Networks initialized -------------')

@@ -747,6 +747,21 @@ def set_force_direct(on):
     lib().nc_set_force_direct(I(1 if on else 0))
 
 
+# Generation counter per parameter storage: nc_adam_step (and checkpoint loads) write parameters through raw pointers,
+# which autograd's version counters never see.  FlatAdam.step / BaseModel.load_networks bump it; the whole-network
+# Functions, which keep a zero-copy alias of the live parameters for backward, refuse a backward across a bump.
+_param_gen = {}
+
+
+def bump_param_generation(t):
+    k = t.untyped_storage().data_ptr()
+    _param_gen[k] = _param_gen.get(k, 0) + 1
+
+
+def _param_generation(t):
+    return _param_gen.get(t.untyped_storage().data_ptr(), 0)
+
+
 # ---- whole-network PatchGAN (nc_patchgan_fwd / nc_patchgan_bwd): one C call per direction -------------------------
 def _pack_params(params):
     """The parameter tensors as ONE flat fp32 tensor in the given order: a zero-copy view when they already sit back
@@ -794,6 +809,7 @@ class _PatchGAN(torch.autograd.Function):
                                 I(nd), _ptr(ws), Z(ws.numel()), _stream()), 'nc_patchgan_fwd')
         ctx.save_for_backward(x, saved)
         ctx.packed = packed
+        ctx.packed_gen = _param_generation(packed)
         ctx.cfg = (cfg, (B, D, H, W), [tuple(p.shape) for p in params])
         return y
 
@@ -801,6 +817,9 @@ class _PatchGAN(torch.autograd.Function):
     def backward(ctx, dy):
         x, saved = ctx.saved_tensors
         (n_layers, ndf, nd), (B, D, H, W), shapes = ctx.cfg
+        if _param_generation(ctx.packed) != ctx.packed_gen:
+            raise _lib.NcError('fused PatchGAN: the parameters were updated (optimizer step / checkpoint load) between '
+                               'this forward and its backward; the saved activations no longer match them')
         dy = dy.contiguous()
         want_x = ctx.needs_input_grad[0]
         want_p = any(ctx.needs_input_grad[2:])

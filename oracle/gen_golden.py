@@ -215,16 +215,17 @@ def apollo_specs():
                        [(n, S.patchgan_spec(2)) for n in APOLLO_NETS[2:]])
 
 
-def gen_apollo():
+def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_step_36.npz'):
+    """batch > 1 pins the per-plane batch semantics of the LSGAN means (every netD call of the reference sees the whole
+    batch of ONE plane, apollo:169-193)."""
     import contextlib
     import io
     from models.axial_to_lateral_gan_apollo_model import AxialToLateralGANApolloModel
-    size, step_seed = 36, 1234
     with contextlib.redirect_stdout(io.StringIO()):
         model = AxialToLateralGANApolloModel(_opt_train('axial_to_lateral_gan_apollo'))
     for i, (name, spec) in enumerate(apollo_specs().items()):
         load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 40 + i))
-    real = torch.from_numpy(rand_input(321, (1, 1, size, size, size)))
+    real = torch.from_numpy(rand_input(real_seed, (batch, 1, size, size, size)))
     losses_per_step, upd = [], {}
     before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in APOLLO_NETS}
     np.random.seed(step_seed)
@@ -249,7 +250,7 @@ def gen_apollo():
     for n in APOLLO_NETS:
         after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
         upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
-    np.savez_compressed(os.path.join(OUT, 'apollo_step_36.npz'), size=size, step_seed=step_seed, real_seed=321,
+    np.savez_compressed(os.path.join(OUT, fname), size=size, step_seed=step_seed, real_seed=real_seed, batch=batch,
                         net_seed0=40, loss_names=np.array(model.loss_names), losses=np.array(losses_per_step),
                         draws=np.array(draws), fake0=fake0, rec0=rec0,
                         **{'upd_' + n: v for n, v in upd.items()})
@@ -343,17 +344,20 @@ def dryops_specs(netG, netD):
     return OrderedDict([('G_A', g), ('D_A_axial', d), ('D_A_lateral', d)])
 
 
-def gen_dryops():
+def gen_dryops(only=None):
     import contextlib
     import io
     from models.axial_to_lateral_gan_dryops_model import AxialToLateralGANDryopsModel
-    for tag, netG, netD, size, step_seed in (('deconv_basic_36', 'unet_deconv', 'basic', 36, 4321),
-                                             ('vanilla_pixel_32', 'unet_vanilla', 'pixel', 32, 977)):
+    cases = (('deconv_basic_36', 'unet_deconv', 'basic', 36, 4321, 1), ('vanilla_pixel_32', 'unet_vanilla', 'pixel', 32, 977, 1),
+             ('deconv_basic_24_b2', 'unet_deconv', 'basic', 24, 555, 2))
+    for tag, netG, netD, size, step_seed, batch in cases:
+        if only and tag not in only:
+            continue
         with contextlib.redirect_stdout(io.StringIO()):
             model = AxialToLateralGANDryopsModel(_opt_train('axial_to_lateral_gan_dryops', dict(netG=netG, netD=netD)))
         for i, (name, spec) in enumerate(dryops_specs(netG, netD).items()):
             load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 80 + i))
-        real = torch.from_numpy(rand_input(987, (1, 1, size, size, size)))
+        real = torch.from_numpy(rand_input(987, (batch, 1, size, size, size)))
         before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in DRYOPS_NETS}
         np.random.seed(step_seed)
         losses = []
@@ -368,7 +372,7 @@ def gen_dryops():
             after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
             upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
         np.savez_compressed(os.path.join(OUT, 'dryops_step_%s.npz' % tag), size=size, step_seed=step_seed,
-                            real_seed=987, net_seed0=80, netG=netG, netD=netD, loss_names=np.array(model.loss_names),
+                            real_seed=987, batch=batch, net_seed0=80, netG=netG, netD=netD, loss_names=np.array(model.loss_names),
                             losses=np.array(losses), fake0=fake0, **{'upd_' + n: v for n, v in upd.items()})
         print('dryops', tag, dict(zip(model.loss_names, losses[0])))
 
@@ -425,19 +429,53 @@ def gen_dice():
     print('geometry', rows)
 
 
+def gen_rotation():
+    """The two cv2-free geometry functions of the rotation augmentation (data/base_dataset.py:375-432), run as they
+    stand in the reference: inscribed-rectangle size for every whole degree, and the centre-crop rectangle recovered from
+    a coordinate-coded canvas.  (rotate_image itself calls cv2 and cannot run here: parity unpinned for the warp.)"""
+    ref_modules()
+    import math
+    from data import base_dataset as bd
+    sizes = [(60, 40), (108, 108), (17, 33), (900, 900), (148, 148), (56, 48)]
+    angles = list(range(0, 360)) + [-90, -180, -270, -37]
+    rows = []
+    for w, h in sizes:
+        for a in angles:
+            rw, rh = bd.largest_rotated_rect(w, h, math.radians(a))
+            rows.append((w, h, a, rw, rh))
+    crops = []
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        cw, ch = int(rng.integers(8, 300)), int(rng.integers(8, 300))
+        width, height = float(rng.uniform(1, cw * 1.2)), float(rng.uniform(1, ch * 1.2))
+        canvas = np.arange(ch * cw, dtype=np.int64).reshape(ch, cw)
+        sub = bd.crop_around_center(canvas, width, height)
+        y1, x1 = divmod(int(sub[0, 0]), cw)
+        crops.append((cw, ch, width, height, x1, y1, x1 + sub.shape[1], y1 + sub.shape[0]))
+    np.savez_compressed(os.path.join(OUT, 'rotation_geometry.npz'), rects=np.array(rows, dtype=np.float64),
+                        crops=np.array(crops, dtype=np.float64))
+    print('rotation', len(rows), len(crops))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     networks = ref_modules()
-    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice']
+    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice', 'rotation']
     if 'nets' in which:
         gen_nets(networks)
     if 'nets_wide' in which:
         gen_nets_wide(networks)
     if 'apollo' in which:
         gen_apollo()
+    if 'apollo_b2' in which or not sys.argv[1:]:
+        gen_apollo(size=24, step_seed=4242, batch=2, real_seed=322, fname='apollo_step_24_b2.npz')
     if 'dryops' in which:
         gen_dryops()
+    if 'dryops_b2' in which:
+        gen_dryops(only=['deconv_basic_24_b2'])
     if 'athena' in which:
         gen_athena()
     if 'dice' in which:
         gen_dice()
+    if 'rotation' in which:
+        gen_rotation()

@@ -134,6 +134,54 @@ def test_blocks(golden_dir):
     assert float(np.abs(y.detach().cpu().numpy() - g['y']).max()) < 5e-3
 
 
+def test_convT_block_golden(golden_dir):
+    """ConvTranspose3d(128, 64, 2, 2) as built at networks.py:500,503, against the reference's own forward / input
+    gradient / weight + bias gradients (block_convT_128_64.npz)."""
+    g = G(golden_dir, 'block_convT_128_64.npz')
+    ct = networks.ConvTranspose(128, 64, 2, 2, 3).to(DEV)
+    load(ct, [('weight', (128, 64, 2, 2, 2)), ('bias', (64,))], int(g['seed']))
+    x = torch.from_numpy(rnd(113, (1, 128, 6, 6, 6))).to(DEV).requires_grad_(True)
+    y = ct(x)
+    assert y.shape == (1, 64, 12, 12, 12)
+    assert relmax(y.detach().cpu().numpy(), g['y']) < 2e-5
+    r = torch.from_numpy(rnd(213, y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert relmax(x.grad.cpu().numpy(), g['dx']) < 2e-5
+    assert relmax(ct.bias.grad.cpu().numpy(), g['db']) < 2e-5
+    a = ct.weight.grad.cpu().numpy().ravel()
+    idx = np.random.default_rng(55).integers(0, a.size, size=min(4096, a.size))
+    got = np.concatenate([[np.sqrt((a.astype(np.float64) ** 2).sum()), a.astype(np.float64).sum()], a[idx]])
+    assert abs(got[0] - g['dw'][0]) < 1e-4 * g['dw'][0]
+    assert relmax(got[2:], g['dw'][2:]) < 1e-4
+
+
+def test_init_net_kaiming():
+    """init_net / init_weights('kaiming') (networks.py:88-137): every module whose class name contains 'Conv' --
+    ConvTranspose included -- gets kaiming_normal_(a=0, fan_in) weights (std = sqrt(2 / fan_in), fan_in = the torch rule
+    size(1) * receptive field) and a zero bias; the net lands on gpu_ids[0]; unknown init types raise."""
+    torch.manual_seed(3)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    seen = 0
+    for name, m in net.named_modules():
+        if not hasattr(m, 'weight') or 'Conv' not in m.__class__.__name__:
+            continue
+        w = m.weight.detach()
+        assert w.is_cuda and w.device.index == 0
+        fan_in = w.shape[1] * w[0, 0].numel()
+        if w.numel() >= 4096:
+            std = float(w.double().std())
+            assert abs(std / (2.0 / fan_in) ** 0.5 - 1.0) < 0.05, (name, std, fan_in)
+            assert abs(float(w.double().mean())) < 0.1 * (2.0 / fan_in) ** 0.5
+        assert m.bias is None or float(m.bias.abs().max()) == 0.0, name
+        seen += 1
+    assert seen == 14  # 10 3^3 convs + 2 transposed + 2 pointwise
+    d = networks.define_D(1, 64, 'basic', 3, 'instance', 'normal', 0.02, False, [0], dimension=2)
+    w = d.model[2].weight.detach()
+    assert abs(float(w.double().std()) / 0.02 - 1.0) < 0.05
+    with pytest.raises(NotImplementedError):
+        networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'no_such_init', 0.02, [0])
+
+
 def _apollo_opt():
     return Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t',
                      preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
@@ -146,16 +194,22 @@ def _apollo_opt():
 APOLLO_NETS = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
 
 
-def test_apollo_step(golden_dir):
+@pytest.mark.parametrize('fname,d_streams', [('apollo_step_36.npz', True), ('apollo_step_24_b2.npz', True),
+                                             ('apollo_step_24_b2.npz', False)])
+def test_apollo_step(golden_dir, fname, d_streams, monkeypatch):
+    """One + one optimize_parameters() against the reference's own losses; the batch-2 fixture pins the per-plane batch
+    split of the batched discriminator passes (each LSGAN mean runs over the whole batch of ONE plane)."""
     from neuroclear_amd.models import create_model
-    g = G(golden_dir, 'apollo_step_36.npz')
-    size = int(g['size'])
+    from neuroclear_amd.models.axial_to_lateral_gan_apollo_model import AxialToLateralGANApolloModel
+    monkeypatch.setattr(AxialToLateralGANApolloModel, '_d_streams_on', d_streams)
+    g = G(golden_dir, fname)
+    size, batch = int(g['size']), int(g['batch']) if 'batch' in g else 1
     model = create_model(_apollo_opt())
     specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 4
     for i, (n, sp) in enumerate(zip(APOLLO_NETS, specs)):
         load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
     before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in APOLLO_NETS}
-    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    real = torch.from_numpy(rnd(g['real_seed'], (batch, 1, size, size, size)))
     np.random.seed(int(g['step_seed']))
     names = [str(s) for s in g['loss_names']]
     for it in range(2):
@@ -351,11 +405,12 @@ def test_discriminators_wide(golden_dir, name, kind):
     check_grads(g, net, 2e-2)
 
 
-@pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32'])
+@pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32', 'deconv_basic_24_b2'])
 def test_dryops_step(golden_dir, tag):
     from neuroclear_amd.models import create_model
     g = G(golden_dir, 'dryops_step_%s.npz' % tag)
     size, netG, netD = int(g['size']), str(g['netG']), str(g['netD'])
+    batch = int(g['batch']) if 'batch' in g else 1
     opt = _apollo_opt()
     opt.model, opt.netG, opt.netD = 'axial_to_lateral_gan_dryops', netG, netD
     model = create_model(opt)
@@ -366,7 +421,7 @@ def test_dryops_step(golden_dir, tag):
     for i, (n, sp) in enumerate(zip(nets_, [gs, ds, ds])):
         load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
     before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in nets_}
-    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    real = torch.from_numpy(rnd(g['real_seed'], (batch, 1, size, size, size)))
     np.random.seed(int(g['step_seed']))
     names = [str(s) for s in g['loss_names']]
     for it in range(2):

@@ -74,15 +74,16 @@ def test_patchgan(golden_dir, tag):
     _check_grads(g, sd, tol=1e-3)
 
 
-def test_apollo_step(golden_dir):
-    g = G(golden_dir, 'apollo_step_36.npz')
-    size = int(g['size'])
+@pytest.mark.parametrize('fname', ['apollo_step_36.npz', 'apollo_step_24_b2.npz'])
+def test_apollo_step(golden_dir, fname):
+    g = G(golden_dir, fname)
+    size, batch = int(g['size']), int(g['batch']) if 'batch' in g else 1
     specs = [('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] + \
         [(n, S.patchgan_spec(2)) for n in apollo.APOLLO_D]
     sds = {n: S.weights_from_seed(sp, int(g['net_seed0']) + i) for i, (n, sp) in enumerate(specs)}
     model = apollo.ApolloOracle(sds)
     before = {n: [p.detach().clone() for p in model.n.sd[n].values()] for n in sds}
-    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    real = torch.from_numpy(rnd(g['real_seed'], (batch, 1, size, size, size)))
     np.random.seed(int(g['step_seed']))
     names = [str(s) for s in g['loss_names']]
     for it in range(2):
@@ -198,14 +199,15 @@ def dryops_specs(netG, netD):
     return [('G_A', gs), ('D_A_axial', ds), ('D_A_lateral', ds)]
 
 
-@pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32'])
+@pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32', 'deconv_basic_24_b2'])
 def test_dryops_step(golden_dir, tag):
     g = G(golden_dir, 'dryops_step_%s.npz' % tag)
     size, netG, netD = int(g['size']), str(g['netG']), str(g['netD'])
+    batch = int(g['batch']) if 'batch' in g else 1
     sds = {n: S.weights_from_seed(sp, int(g['net_seed0']) + i) for i, (n, sp) in enumerate(dryops_specs(netG, netD))}
     model = apollo.DryopsOracle(sds, netG=netG, netD=netD)
     before = {n: [p.detach().clone() for p in model.n.sd[n].values()] for n in sds}
-    real = torch.from_numpy(rnd(g['real_seed'], (1, 1, size, size, size)))
+    real = torch.from_numpy(rnd(g['real_seed'], (batch, 1, size, size, size)))
     np.random.seed(int(g['step_seed']))
     names = [str(s) for s in g['loss_names']]
     for it in range(2):

@@ -23,6 +23,27 @@ def test_geometry_matches_oracle(h, w, angle):
     assert 0 <= x1 < x2 <= plan['new_w'] and 0 <= y1 < y2 <= plan['new_h']
 
 
+def test_geometry_matches_reference_fixture(golden_dir):
+    """Inscribed-rectangle sizes and centre-crop rectangles produced by RUNNING the reference's own
+    largest_rotated_rect / crop_around_center (oracle/gen_golden.py::gen_rotation): the product's closed form must land
+    on the same integer rectangle for every whole degree, and within 1e-9 of the float size."""
+    import math
+    import os
+    g = np.load(os.path.join(golden_dir, 'rotation_geometry.npz'))
+    for w, h, a, rw, rh in g['rects']:
+        w, h, a = int(w), int(h), int(a)
+        got = rotation.inscribed_rect_size(w, h, math.radians(a))
+        assert abs(got[0] - rw) < 1e-9 and abs(got[1] - rh) < 1e-9, (w, h, a)
+        assert orot.largest_rotated_rect(w, h, math.radians(a)) == (rw, rh)  # the oracle restatement is bit-exact
+        nw, nh, _ = rotation.canvas_and_affine(h, w, a)
+        assert rotation.centered_rect(nw, nh, *got) == rotation.centered_rect(nw, nh, rw, rh), (w, h, a)
+    for cw, ch, wd, ht, x1, y1, x2, y2 in g['crops']:
+        want = (int(x1), int(y1), int(x2), int(y2))
+        assert rotation.centered_rect(int(cw), int(ch), wd, ht) == want
+        ox1, oy1, ox2, oy2 = orot.crop_rect(int(cw), int(ch), wd, ht)
+        assert (max(ox1, 0), max(oy1, 0), min(ox2, int(cw)), min(oy2, int(ch))) == want
+
+
 def test_geometry_closed_form():
     inv, rect = rotation.rotate_clean_plan(40, 60, 0)
     np.testing.assert_allclose(inv, [[1, 0, 0], [0, 1, 0]], atol=1e-12)
