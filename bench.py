@@ -2,7 +2,12 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload at every N (BASELINE.json configs[1]): one *step* = one `optimize_parameters()` of the Apollo model
+BASELINE.json's metric has two halves -- "voxels/sec: unet_deconv 108^3 train step + 900^3 diced inference" -- and the
+default run (`--workload headline`) measures both in one process: the train step is the top-level `value` (it is the
+half BASELINE.json quotes on configs[1]), the 900^3 diced inference (configs[2]) is the nested `inference` object with
+its own `roofline` and `cpu_baseline`.
+
+Train leg at every N (BASELINE.json configs[1]): one *step* = one `optimize_parameters()` of the Apollo model
 (axial_to_lateral_gan_apollo: unet_deconv G_A + deep_linear_gen G_B + four 2-D PatchGANs, LSGAN + InstanceNorm,
 fp32) on one 108^3 crop, batch 1, per GPU.  Inputs are synthetic random uint16 crops already resident in HBM; weights
 are random-init (kaiming), as the reference would start.  Scaling is WEAK: every rank trains on its own crop and the
@@ -12,9 +17,11 @@ Extra objects on the JSON line:
   roofline     -- for the kernel class that took most of the timed region: algorithmic FLOP / launch, measured with HIP
                   events on the launch stream inside the timed steps (neuroclear_amd.ops.prof), against the dense fp32
                   MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s).
-  cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32, all host cores) on a
-                  bounded sample (one step on a smaller crop), rank 0 and N = 1 only.
-`--workload infer` benches BASELINE.json configs[2] instead (900^3 diced inference, cubes sharded over ranks);
+  cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32) on the host cores of
+                  the GPU box, rank 0 and N = 1 only: full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
+                  1-thread figure on a bounded 36^3 sample; inference: 140^3 cubes through
+                  oracle/nets.py + oracle/dice.py for a bounded time, extrapolated to 729 cubes (stated).
+`--workload train` / `--workload infer` run one leg only (infer = BASELINE.json configs[2], cubes sharded over ranks);
 `--crop 148 --batch 4` is the shape of configs[3] (in fp32), `--model athena` the step of configs[4].
 """
 import argparse
@@ -83,24 +90,84 @@ def _apollo_opt(gpu):
                      direction='AtoB', model='axial_to_lateral_gan_apollo')
 
 
-def cpu_baseline_train(crop=96):
-    """Oracle Apollo step on the host cores, one step on a crop^3 volume (bounded: ~10-30 s)."""
+def _oracle_apollo(crop, threads):
     import torch
     from neuroclear_amd.util import seed as S
     from oracle import apollo as oapollo
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(threads)
     specs = [('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] + \
         [(n, S.patchgan_spec(2)) for n in oapollo.APOLLO_D]
     sds = {n: S.weights_from_seed(sp, 7 + i, bias_scale=0.0) for i, (n, sp) in enumerate(specs)}
     model = oapollo.ApolloOracle(sds)
     real = torch.from_numpy((S.random_volume(11, crop).astype(np.float64) / 65535.0).astype(np.float32))[None, None]
     np.random.seed(0)
+    return model, real
+
+
+def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
+    """Oracle Apollo step on the host cores (SURVEY.md 8d / BASELINE.md 3): full crop^3 step, 1 warm-up + median of
+    `reps` on all cores (thread count reported); plus one 1-thread step on a 36^3 crop (a full-size 1-thread step takes
+    minutes).  Bounded: if the warm-up step shows that `reps` more would pass budget_s, fewer are timed (stated)."""
+    import torch
+    ncores = min(os.cpu_count() or 1, 64)
+    model, real = _oracle_apollo(crop, ncores)
     t0 = time.time()
     model.step(real)
-    dt = time.time() - t0
-    return dict(value=crop ** 3 / dt, unit='voxels/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 Apollo optimize_parameters() step on a %d^3 crop (oracle/apollo.py, torch-CPU fp32), '
-                       '%.1f s' % (crop, dt))
+    warm = time.time() - t0
+    reps = max(1, min(reps, int((budget_s - warm) / max(warm, 1e-3))))
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        model.step(real)
+        ts.append(time.time() - t0)
+    med = float(np.median(ts))
+    del model, real
+    m1, r1 = _oracle_apollo(36, 1)
+    t0 = time.time()
+    m1.step(r1)
+    t1 = time.time() - t0
+    torch.set_num_threads(ncores)
+    return dict(value=crop ** 3 / med, unit='voxels/s', cores=ncores, kind='port',
+                sample='Apollo optimize_parameters() on a %d^3 crop (oracle/apollo.py, torch-CPU fp32): 1 warm-up (%.1f s) + '
+                       'median of %d steps = %.2f s/step on %d threads' % (crop, warm, reps, med, ncores),
+                one_thread=dict(value=36 ** 3 / t1, unit='voxels/s', cores=1,
+                                sample='1 step on a 36^3 crop, 1 thread, %.1f s (no warm-up)' % t1))
+
+
+def cpu_baseline_infer(budget_s=25.0, max_cubes=8):
+    """configs[2] on the host cores: 140^3 cubes of the 900^3 / dice 120 / overlap 15 / border 10 geometry through the
+    oracle's unet_deconv (oracle/nets.py) and overlap-add (oracle/dice.py) until max_cubes or budget_s, then scaled
+    linearly to the 729 cubes of the volume (EXTRAPOLATED -- stated in `sample`)."""
+    import torch
+    from neuroclear_amd.util import seed as S
+    from oracle import nets as onets
+    ncores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(ncores)
+    sd = onets.to_torch(S.weights_from_seed(S.unet_deconv_spec(), 3))
+    E, R, b, n_total = 140, 120, 10, 729
+    acc = np.zeros((R + 105, R, R), np.float32)
+    rng = np.random.default_rng(0)
+    done, t_net, t_asm = 0, 0.0, 0.0
+    with torch.no_grad():
+        onets.unet_deconv(sd, torch.zeros(1, 1, 32, 32, 32))  # thread-pool warm-up
+        t_start = time.time()
+        while done < max_cubes and (done == 0 or (time.time() - t_start) * (done + 1) / done < budget_s):
+            cube = (rng.integers(0, 65536, (E, E, E), dtype=np.uint16).astype(np.float64) / 65535.0).astype(np.float32)
+            t0 = time.time()
+            y = onets.unet_deconv(sd, torch.from_numpy(cube)[None, None]).numpy()[0, 0]
+            t_net += time.time() - t0
+            t0 = time.time()
+            z0 = 105 * (done % 2)
+            acc[z0:z0 + R] += y[b:-b, b:-b, b:-b] / 8  # the assembler's per-cube work (util/assemble_dice.py:167-173)
+            t_asm += time.time() - t0
+            done += 1
+    per_cube = (t_net + t_asm) / done
+    total = per_cube * n_total
+    return dict(value=900 ** 3 / total, unit='useful voxels/s', computed_voxels_per_s=n_total * E ** 3 / total,
+                cores=ncores, kind='port',
+                sample='%d cubes of 140^3 through oracle/nets.py::unet_deconv + overlap-add on %d threads: %.2f s/cube '
+                       '(network %.2f, assemble %.3f), EXTRAPOLATED linearly to 729 cubes = %.0f s per 900^3 volume'
+                       % (done, ncores, per_cube, t_net / done, t_asm / done, total))
 
 
 def run_train(args, rank, world, dev):
@@ -179,27 +246,43 @@ def run_train(args, rank, world, dev):
         parallelism='dp%d' % world, gan_mode='lsgan', norm='instance', losses=losses)
 
 
-def run_infer(args, rank, world, dev):
+GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
+
+
+def run_infer(args, rank, world, dev, steps=None, warmup=None):
     """configs[2]: 900^3 synthetic volume, dice 120 / overlap 15 / border_cut 10 -> 729 cubes of 140^3, cube i on rank
-    i % world; every rank scatter-adds its own cubes, partial accumulators are summed on rank 0 (one reduce)."""
+    i % world; rank 0's weights are broadcast (RCCL), every rank overlap-adds its own cubes into its own accumulator and
+    ONE reduce(sum) lands the volume on rank 0 (neuroclear_amd/test_dice.py)."""
     import torch
     import torch.distributed as dist
     from neuroclear_amd.test_dice import diced_inference
     from neuroclear_amd.models import networks
     from neuroclear_amd.util import seed as S
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     L = args.volume
+    torch.manual_seed(4321)  # same init on every rank; rank 0's copy is broadcast inside diced_inference anyway
     net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [dev.index])
     vol = S.random_volume(5, L)
     opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[dev.index], skip_real=True,
                     data_type='uint16', histogram_match=False, normalize_intensity=False)
-    for _ in range(args.warmup):
-        diced_inference(net, vol, opt, rank, world, max_cubes=world)
+    for _ in range(max(warmup, 1)):
+        diced_inference(net, vol, opt, rank, world, max_cubes=2 * world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev = []
+
+    def on_cube(fn):  # HIP events on the launch stream around every whole-network call
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = fn()
+        e1.record()
+        ev.append((e0, e1))
+        return y
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = diced_inference(net, vol, opt, rank, world)
+    for _ in range(steps):
+        out = diced_inference(net, vol, opt, rank, world, on_cube=None if args.no_prof else on_cube)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -213,9 +296,22 @@ def run_infer(args, rank, world, dev):
     padded = U.padded_shape((L, L, L), 120, 15)
     ncubes = int(np.prod(U.grid_steps(padded, 120, 15)))
     computed = ncubes * 140 ** 3  # voxels the network actually processes (overlap + border: 2.74 x the volume at 900^3)
-    return dt, L ** 3 * args.steps, None, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
-                                               parallelism='cubes%%%d' % world, cubes=ncubes,
-                                               computed_voxels_per_s=round(computed * args.steps / dt))
+    roof = None
+    if ev:
+        ms = sum(a.elapsed_time(b) for a, b in ev)
+        flop = GA_FWD_FLOP_PER_VOXEL * 140 ** 3
+        ach = flop * len(ev) / ms / 1e9
+        roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: '
+                                        'k_conv_mfma<3,*>, profiles/r02_infer_kernel_stats.csv)',
+                    achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=len(ev),
+                    avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
+                    share_of_run=round(ms / (dt * 1e3), 4),
+                    whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
+    return dt, L ** 3 * steps, roof, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
+                                          parallelism='cubes%%%d' % world, cubes=ncubes,
+                                          assemble='reduce' if world > 1 else 'in-order',
+                                          computed_voxels_per_s=round(computed * steps / dt))
 
 
 def main():
@@ -223,7 +319,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--workload', default='headline', choices=['headline', 'train', 'infer'],
+                    help='headline = the 108^3 train step (top-level value) + one 900^3 diced inference (nested)')
     ap.add_argument('--crop', type=int, default=108)
     ap.add_argument('--batch', type=int, default=1, help='crops per step and GPU (headline: 1; configs[3] shape: --crop 148 --batch 4)')
     ap.add_argument('--model', default='apollo', choices=['apollo', 'athena'], help='athena = configs[4]')
@@ -257,21 +354,47 @@ def main():
         if rank == 0:
             print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
-    run = run_train if args.workload == 'train' else run_infer
+    headline = args.workload == 'headline' and args.model == 'apollo' and args.crop == 108 and args.batch == 1 \
+        and args.precision == 'fp32'
+    train_like = args.workload in ('headline', 'train')
+    run = run_train if train_like else run_infer
     dt, units, roof, cfg = run(args, rank, world, dev)
     out = dict(metric='voxels/sec', value=units / dt, unit='voxels/s', n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling='weak' if args.workload == 'train' else 'strong',
-               vs_baseline=None, dtype='f32' if args.precision == 'fp32' or args.workload != 'train' else
+               scaling='weak' if train_like else 'strong',
+               vs_baseline=None, dtype='f32' if args.precision == 'fp32' or not train_like else
                '%s (3^3/5^3 conv operands; fp32 accumulate, fp32 everywhere else)' % args.precision,
                data='synthetic', config=cfg)
     if roof:
         out['roofline'] = roof
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train':
+    cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if cpu and train_like:
         try:
             out['cpu_baseline'] = cpu_baseline_train()
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out['cpu_baseline'] = dict(error=str(e))
+    if cpu and args.workload == 'infer':
+        try:
+            out['cpu_baseline'] = cpu_baseline_infer()
+        except Exception as e:
+            out['cpu_baseline'] = dict(error=str(e))
+    if headline:
+        # second half of BASELINE.json's metric: one 900^3 diced inference (configs[2]), strong scaling over ranks
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=1, warmup=1)
+        inf = dict(metric='voxels/sec (useful output voxels of the 900^3 volume, assemble included)',
+                   value=iunits / idt, unit='voxels/s', seconds_per_volume=idt, n_gpus=world, scaling='strong',
+                   dtype='f32', config=icfg)
+        if iroof:
+            inf['roofline'] = iroof
+        if cpu:
+            try:
+                inf['cpu_baseline'] = cpu_baseline_infer()
+            except Exception as e:
+                inf['cpu_baseline'] = dict(error=str(e))
+        out['inference'] = inf
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -8,6 +8,7 @@ from collections import OrderedDict
 
 import torch
 
+from .. import ops
 from . import networks
 
 

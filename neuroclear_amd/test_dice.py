@@ -2,9 +2,15 @@
 addToStack` followed by `assemble_all`).
 
 `diced_inference` is the loop itself, sharded over ranks the way SURVEY.md 8(e) describes: cube i belongs to rank
-i % world (cubes are independent units; no data-path collective is needed to COMPUTE them).  To keep the assembled
-volume bit-identical to the single-GPU / reference summation order, the cube outputs of each round are gathered to
-rank 0 over RCCL (one 11 MB tile per rank per round -- xGMI point-to-point) and overlap-added there in index order.
+i % world (cubes are independent units; no data-path collective is needed to COMPUTE them).  Around the loop:
+  * the weights are replicated by ONE RCCL broadcast of rank 0's packed parameter blob (28.3 MB for unet_deconv) --
+    the reference's replication point is nn.DataParallel at models/networks.py:132-136;
+  * assemble='reduce' (default for world > 1): every rank overlap-adds its own cubes into its own padded fp32
+    accumulator on its own GPU, then one RCCL reduce(sum) to rank 0 -- no per-round synchronisation, no tile traffic.
+    fp32 addition order then differs from the reference's sequential index order (util/assemble_dice.py:167-173) by
+    <= 1 ulp per voxel, which can flip the truncating integer cast by 1 LSB (tolerance +-1 LSB, SURVEY.md 8e);
+  * assemble='gather': lock-step rounds, each round's tiles gathered to rank 0 and overlap-added there in index order
+    -- bit-identical to the single-GPU / reference result; the verification mode.
 `main()` keeps the reference's command line for the flags that matter on this path."""
 import numpy as np
 import torch
@@ -14,7 +20,7 @@ from .util.assemble_dice import Assemble_Dice, match_cube
 
 
 def sharded_cube_loop(n, rank, world, produce, consume, empty_like):
-    """The N > 1 schedule of the diced loop, free of device code so that it can be exercised with gloo on CPU:
+    """assemble='gather' schedule, free of device code so that it can be exercised with gloo on CPU:
     round t hands cube t*world + r to rank r; `produce(i)` returns that cube's network output (a tensor), tiles of a
     round are gathered to rank 0, which calls `consume(j, tile)` in increasing j -- the reference's summation order
     (util/assemble_dice.py:167-173).  `empty_like()` makes the placeholder a rank sends when it has no cube left."""
@@ -35,25 +41,65 @@ def sharded_cube_loop(n, rank, world, produce, consume, empty_like):
                     consume(j, tiles[r])
 
 
-def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None):
-    """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0."""
+def sharded_cube_loop_reduce(n, rank, world, produce, add_local, accumulator):
+    """assemble='reduce' schedule (device-free, gloo-testable): rank r runs cubes r, r + world, ... back to back with no
+    synchronisation, `add_local(i, tile)` overlap-adds into the rank's own accumulator, and ONE reduce(sum) of
+    `accumulator()` lands the volume on rank 0."""
+    import torch.distributed as dist
+    for i in range(rank, n, world):
+        add_local(i, produce(i))
+    if world > 1:
+        dist.reduce(accumulator(), dst=0, op=dist.ReduceOp.SUM)
+
+
+def broadcast_parameters(net, src=0):
+    """One broadcast of the packed parameter blob (state-dict order) from rank `src`; every rank then holds identical
+    weights.  A no-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = list(net.parameters())
+    blob = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(blob, src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            k = p.numel()
+            p.copy_(blob[off:off + k].view_as(p))
+            off += k
+
+
+def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble=None, broadcast=True, on_cube=None):
+    """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0.
+    on_cube(fn) -> result: optional wrapper around each cube's network call (bench.py brackets it with HIP events)."""
+    if assemble is None:
+        assemble = 'reduce' if world > 1 else 'gather'
+    if assemble not in ('reduce', 'gather'):
+        raise ValueError("assemble must be 'reduce' or 'gather'")
+    if broadcast and world > 1:
+        broadcast_parameters(netG, 0)
     ds = DiceImageDataSet(opt, volume=volume)
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
-    asm = Assemble_Dice(opt, ds.size_original()) if rank == 0 else None
+    local_acc = assemble == 'reduce' or rank == 0
+    asm = Assemble_Dice(opt, ds.size_original()) if local_acc else None
     E = opt.dice_size[0] + 2 * opt.border_cut
     hm = bool(getattr(opt, 'histogram_match', False))  # the producing rank matches its own cube (it holds the input)
 
     def produce(i):
         x = ds[i]['A'].unsqueeze(0)
-        y = netG(x).reshape(E, E, E)
+        y = (netG(x) if on_cube is None else on_cube(lambda: netG(x))).reshape(E, E, E)
         return match_cube(y, x, opt.dice_size[0], opt.border_cut, ds.device) if hm else y
 
     with torch.no_grad():
-        sharded_cube_loop(
-            n, rank, world,
-            produce=produce,
-            consume=lambda j, tile: asm.add_cube('fake', tile, j),
-            empty_like=lambda: torch.zeros((E, E, E), dtype=torch.float32, device=ds.device))
+        if assemble == 'reduce':
+            sharded_cube_loop_reduce(n, rank, world, produce, add_local=lambda j, tile: asm.add_cube('fake', tile, j),
+                                     accumulator=lambda: asm.acc['fake'])
+        else:
+            sharded_cube_loop(
+                n, rank, world,
+                produce=produce,
+                consume=lambda j, tile: asm.add_cube('fake', tile, j),
+                empty_like=lambda: torch.zeros((E, E, E), dtype=torch.float32, device=ds.device))
     if rank != 0:
         return None
     asm.count['fake'] = asm.len_cube_queue  # warm-up runs (max_cubes) assemble a partial volume on purpose

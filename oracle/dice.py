@@ -111,6 +111,23 @@ def assemble(cubes, padded_shape, original_shape, roi, overlap, border, data_typ
             cnt[z0:z0 + roi, y0:y0 + roi, x0:x0 + roi] += np.ones((roi, roi, roi), dtype=np.float32)
         n += 1
     assert n == steps[0] * steps[1] * steps[2]
+    return _finish(acc, cnt, padded_shape, original_shape, overlap, data_type, normalize)
+
+
+def finalize(acc, padded_shape, original_shape, roi, overlap, data_type='uint16', normalize=None):
+    """The tail of assemble_all (util/assemble_dice.py:176-213) on an accumulator that already holds the sum of cube / 8
+    over all cubes (e.g. the reduce(sum) of per-rank accumulators): count volume, (acc / count) * 8, scale, truncating
+    cast, crop of the dicing pad."""
+    steps = grid_steps(padded_shape, roi, overlap)
+    step = roi - overlap
+    cnt = np.zeros(padded_shape, dtype=np.float32)
+    for index in range(steps[0] * steps[1] * steps[2]):
+        zi, yi, xi = index_to_zyx(index, steps)
+        cnt[zi * step:zi * step + roi, yi * step:yi * step + roi, xi * step:xi * step + roi] += 1.0
+    return _finish(np.array(acc, dtype=np.float32), cnt, padded_shape, original_shape, overlap, data_type, normalize)
+
+
+def _finish(acc, cnt, padded_shape, original_shape, overlap, data_type, normalize):
     if overlap > 0:
         acc = (acc / cnt) * 8
     if normalize is not None:

@@ -1,7 +1,9 @@
-"""CPU, world_size 2, gloo: the N > 1 paths that need no GPU code --
- * the cube sharding + gather-to-rank-0 schedule of diced inference (neuroclear_amd.test_dice.sharded_cube_loop),
-   checked against the oracle's single-process assemble;
- * the gradient exchange of the flat optimizer buffers (FlatAdam.all_reduce_mean)."""
+"""CPU, world_size 2 and 3, gloo: the N > 1 paths that need no GPU code --
+ * the cube sharding schedules of diced inference (neuroclear_amd.test_dice): 'gather' (lock-step rounds, tiles to rank 0,
+   bit-identical to the single-process order) and 'reduce' (each rank overlap-adds its own cubes, one reduce(sum);
+   +-1 LSB), both checked against the oracle's single-process assemble; 125 cubes = an odd count, like 729;
+ * the weight broadcast in front of the loop (broadcast_parameters);
+ * the gradient exchange of the flat optimizer buffers (FlatAdam.all_reduce_mean, bucketed / asynchronous form too)."""
 import os
 import socket
 
@@ -60,12 +62,70 @@ def _dice_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_sharded_dice_loop_two_ranks(tmp_path):
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_dice_loop_gather(tmp_path, world):
     port = _free_port()
     out = str(tmp_path / 'r.npy')
-    mp.spawn(_dice_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_dice_worker, args=(world, port, out), nprocs=world, join=True)
     eq, n = np.load(out)
     assert eq == 1 and n == 125
+
+
+def _dice_reduce_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    from neuroclear_amd.test_dice import broadcast_parameters, sharded_cube_loop_reduce
+    from neuroclear_amd.util import seed as S
+    from oracle import dice as odice
+    vol = S.random_volume(3, (50, 50, 50))
+    R, ov, b = 16, 4, 2
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    n = steps[0] * steps[1] * steps[2]
+    refl = odice.reflect_pad(padded, b)
+    step = R - ov
+    # "weights" of the stand-in network differ per rank until rank 0's are broadcast
+    lin = torch.nn.Linear(1, 1)
+    with torch.no_grad():
+        lin.weight.fill_(0.75 + rank)
+        lin.bias.fill_(0.01 + rank)
+    broadcast_parameters(lin, 0)
+    w, c = float(lin.weight), float(lin.bias)
+
+    def net(x):
+        return x * w + c
+
+    acc = torch.zeros(padded.shape, dtype=torch.float32)
+    mine = []
+
+    def add_local(i, tile):  # the assembler's per-cube work on this rank's own accumulator (assemble_dice.py:167-173)
+        mine.append(i)
+        zi, yi, xi = i // (steps[1] * steps[2]), (i % (steps[1] * steps[2])) // steps[2], i % steps[2]
+        z, y, x = zi * step, yi * step, xi * step
+        acc[z:z + R, y:y + R, x:x + R] += tile[b:-b, b:-b, b:-b] / 8
+
+    sharded_cube_loop_reduce(n, rank, world,
+                             produce=lambda i: net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b)))),
+                             add_local=add_local, accumulator=lambda: acc)
+    assert mine == list(range(rank, n, world))
+    if rank == 0:
+        ref = odice.assemble([(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b))) * 0.75 + 0.01).numpy()
+                              for i in range(n)], padded.shape, vol.shape, R, ov, b, 'uint16')
+        got = odice.finalize(acc.numpy(), padded.shape, vol.shape, R, ov, 'uint16')
+        d = int(np.abs(got.astype(np.int64) - ref.astype(np.int64)).max())
+        np.save(out_path, np.array([d, n, int(w == 0.75 and abs(c - 0.01) < 1e-9)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_dice_loop_reduce(tmp_path, world):
+    """One reduce(sum) of per-rank accumulators: summation order differs from the index order by <= 1 ulp per voxel, the
+    truncating uint16 cast may flip by 1 LSB -- and rank 0's weights must have reached every rank."""
+    port = _free_port()
+    out = str(tmp_path / 'r.npy')
+    mp.spawn(_dice_reduce_worker, args=(world, port, out), nprocs=world, join=True)
+    d, n, bc = np.load(out)
+    assert d <= 1 and n == 125 and bc == 1
 
 
 def _adam_worker(rank, world, port, out_path):

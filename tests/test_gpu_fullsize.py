@@ -157,3 +157,30 @@ def test_config0_diced_inference_256():
     # (ii) the oracle's assembler on the same cube values
     ref_vol = odice.assemble(outs, padded.shape, vol.shape, R, ov, b, 'uint16')
     assert np.array_equal(got, ref_vol)
+
+
+def test_diced_inference_reduce_mode_matches_in_order():
+    """assemble='reduce' (each rank overlap-adds its own cubes, one reduce(sum)) on the device: at world 1 it is the
+    in-order path bit for bit; two emulated ranks (cubes i % 2, accumulators summed as RCCL's reduce would) stay within
+    1 LSB of it."""
+    from neuroclear_amd.data.diceImage_dataset import DiceImageDataSet
+    from neuroclear_amd.test_dice import diced_inference
+    from neuroclear_amd.util.assemble_dice import Assemble_Dice
+    vol = S.random_volume(17, (100, 90, 80))
+    opt = Namespace(dice_size=[32] * 3, overlap=4, border_cut=4, gpu_ids=[0], skip_real=True, data_type='uint16',
+                    histogram_match=False, normalize_intensity=False)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 4, DEV))
+    a = diced_inference(net, vol, opt, assemble='gather')
+    b = diced_inference(net, vol, opt, assemble='reduce')
+    assert np.array_equal(a, b)
+    ds = DiceImageDataSet(opt, volume=vol)
+    asms = [Assemble_Dice(opt, vol.shape) for _ in range(2)]
+    with torch.no_grad():
+        for i in range(len(ds)):
+            asms[i % 2].add_cube('fake', net(ds[i]['A'].unsqueeze(0)).reshape(40, 40, 40), i)
+    asms[0].acc['fake'] += asms[1].acc['fake']
+    asms[0].count['fake'] = asms[0].len_cube_queue
+    asms[0].assemble_all()
+    c = asms[0].getDict()['fake']
+    assert int(np.abs(c.astype(np.int64) - a.astype(np.int64)).max()) <= 1
