@@ -24,7 +24,7 @@ class FlatAdam(torch.optim.Optimizer):
     all-reduce.  A real torch Optimizer subclass, so torch's lr schedulers (networks.get_scheduler) drive
     param_groups[0]['lr'] as usual."""
 
-    def __init__(self, params, lr, betas, eps=1e-8):
+    def __init__(self, params, lr, betas, eps=1e-8, overlap_all_reduce=False):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.params = params
@@ -42,8 +42,15 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = self.grad[off:off + k].view_as(p.data)
             off += k
         self.state_step = 0
+        self._buckets = []
+        self._overlap_armed = True
+        self._overlap = overlap_all_reduce  # only for parameter sets whose gradients are all produced on ONE stream
 
     def zero_grad(self, set_to_none=False, fill=True):
+        if self._overlap:
+            self.enable_overlapped_all_reduce()
+            for b in self._buckets:
+                b['seen'] = 0
         if fill:
             self.grad.zero_()
         off = 0
@@ -54,12 +61,58 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = g
             off += k
 
+    # -- data-parallel gradient exchange ---------------------------------------------------------------------------
+    # Backward produces the gradients of the LAST parameters first, so the flat gradient buffer fills from its end:
+    # it is cut into `n_buckets` contiguous ranges of about equal size and the all-reduce of a range is issued (async,
+    # on the collective's own stream) the moment the last of its parameters has received its gradient -- the exchange of
+    # G_B's and the U-Net decoder's gradients runs underneath the encoder's backward kernels, and only the last small
+    # bucket is exposed.  xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce is per-link bound: a few
+    # buckets of >= 8 MB keep every link busy without paying the ~50 us launch latency too often.
+    def enable_overlapped_all_reduce(self, n_buckets=3):
+        """Arm the hooks (idempotent).  Without an initialised process group of size > 1 this does nothing."""
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or self._buckets:
+            return
+        total = self.flat.numel()
+        target = (total + n_buckets - 1) // n_buckets
+        bounds, off, start = [], 0, 0
+        members = []
+        for p in self.params:
+            members.append(p)
+            off += p.numel()
+            if off - start >= target or off == total:
+                bounds.append((start, off, members))
+                start, members = off, []
+        self._buckets = [dict(lo=lo, hi=hi, n=len(m), seen=0, work=None) for lo, hi, m in bounds]
+        for bi, (_, _, m) in enumerate(bounds):
+            for p in m:
+                p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._grad_ready(bi))
+
+    def _grad_ready(self, bi):
+        b = self._buckets[bi]
+        b['seen'] += 1
+        if b['seen'] == b['n'] and self._overlap_armed:
+            # the collective is ordered behind everything queued on the current stream (autograd runs this hook on the
+            # stream that produced the gradient)
+            b['work'] = torch.distributed.all_reduce(self.grad[b['lo']:b['hi']], async_op=True)
+
     def all_reduce_mean(self):
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            ws = torch.distributed.get_world_size()
-            if ws > 1:
-                torch.distributed.all_reduce(self.grad)
-                self.grad.div_(ws)
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        ws = dist.get_world_size()
+        if ws == 1:
+            return
+        if self._buckets:
+            for b in self._buckets:
+                if b['work'] is not None:
+                    b['work'].wait()  # the current stream waits for the collective's stream
+                else:  # a bucket with a parameter that got no gradient this step (e.g. requires_grad off): do it now
+                    dist.all_reduce(self.grad[b['lo']:b['hi']])
+                b['work'], b['seen'] = None, 0
+        else:
+            dist.all_reduce(self.grad)
+        self.grad.div_(ws)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -126,8 +179,10 @@ class AxialToLateralGANApolloModel(BaseModel):
     def _make_optimizers(self, opt):
         """apollo:131-138.  Call again after loading new parameter tensors (load_state_dict copies in place, so the
         flat views stay valid)."""
+        # the generators' backward runs on one stream: their gradient exchange is bucketed and overlapped with it; the
+        # discriminators' backward passes run on four streams, their (smaller) exchange is one call after the join
         self.optimizer_G = FlatAdam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
-                                    lr=opt.lr, betas=(opt.beta1, 0.999))
+                                    lr=opt.lr, betas=(opt.beta1, 0.999), overlap_all_reduce=True)
         self.optimizer_D = FlatAdam(
             itertools.chain(self.netD_A_axial.parameters(), self.netD_A_lateral.parameters(),
                             self.netD_B_axial.parameters(), self.netD_B_lateral.parameters()),

@@ -60,7 +60,7 @@ class AxialToLateralGANAthenaModel(BaseModel):
             self.criterionGAN = networks.GANLoss(opt.gan_mode).to(self.device)
             self.criterionCycle = ops.l1_loss
             self.optimizer_G = FlatAdam(itertools.chain(self.netG_A.parameters(), self.netG_B.parameters()),
-                                        lr=opt.lr, betas=(opt.beta1, 0.999))
+                                        lr=opt.lr, betas=(opt.beta1, 0.999), overlap_all_reduce=True)
             self.optimizer_D = FlatAdam(  # chain order of athena:163-164
                 itertools.chain(self.netD_A_yz.parameters(), self.netD_A_xy.parameters(), self.netD_A_xz.parameters(),
                                 self.netD_B_yz.parameters(), self.netD_B_xy.parameters(), self.netD_B_xz.parameters()),

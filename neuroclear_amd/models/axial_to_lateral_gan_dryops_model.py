@@ -51,7 +51,8 @@ class AxialToLateralGANDryopsModel(AxialToLateralGANApolloModel):
 
     def _make_optimizers(self, opt):
         """dryops:101-106"""
-        self.optimizer_G = FlatAdam(self.netG_A.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+        self.optimizer_G = FlatAdam(self.netG_A.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999),
+                                    overlap_all_reduce=True)
         self.optimizer_D = FlatAdam(itertools.chain(self.netD_A_axial.parameters(), self.netD_A_lateral.parameters()),
                                     lr=opt.lr, betas=(opt.beta1, 0.999))
         self.optimizers = [self.optimizer_G, self.optimizer_D]
