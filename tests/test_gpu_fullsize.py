@@ -184,3 +184,52 @@ def test_diced_inference_reduce_mode_matches_in_order():
     asms[0].assemble_all()
     c = asms[0].getDict()['fake']
     assert int(np.abs(c.astype(np.int64) - a.astype(np.int64)).max()) <= 1
+
+
+def _apollo_108(monkeypatch, d_streams, fused_patchgan, seed=31):
+    import contextlib
+    import io
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.models.axial_to_lateral_gan_apollo_model import AxialToLateralGANApolloModel
+    monkeypatch.setattr(AxialToLateralGANApolloModel, '_d_streams_on', d_streams)
+    monkeypatch.setenv('NC_FUSED_PATCHGAN', '1' if fused_patchgan else '0')
+    opt = Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t108',
+                    preprocess='none', gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10,
+                    min_projection_depth=2, lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64,
+                    ndf=64, netG='unet_deconv', netG_B='deep_linear_gen', netD='basic', n_layers_D=3,
+                    norm='instance', no_dropout=True, init_type='kaiming', init_gain=0.02, lr=1e-4, beta1=0.1,
+                    direction='AtoB', model='axial_to_lateral_gan_apollo')
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    v = S.random_volume(77, 108)
+    real = torch.from_numpy((v.astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(DEV)
+    out = []
+    for it in range(2):  # the second step runs on updated weights and with the early-start discriminator phase primed
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+        out.append(dict(model.get_current_losses()))
+    with torch.no_grad():
+        fused_fake = model.netG_A(real)  # whole-network C entry point (nc_unet_deconv_fwd) on the updated weights
+        with torch.enable_grad():
+            layer_fake = model.netG_A(real)  # layer-by-layer path
+    params = torch.cat([p.detach().reshape(-1) for p in model.optimizer_G.params + model.optimizer_D.params]).clone()
+    return out, params, float((fused_fake - layer_fake.detach()).abs().max())
+
+
+def test_apollo_step_108_streams_and_fused_paths_agree(monkeypatch):
+    """BASELINE configs[1] at its size: two full optimisation steps at 108^3 with (a) the four discriminator chains on four
+    HIP streams, started under the generators' backward pass, vs everything in sequence on one stream, and (b) the
+    whole-network PatchGAN entry points vs the op-by-op path.  The kernels and their order per network are the same, and
+    no kernel uses atomics, so every loss and every updated parameter must be BIT-equal -- a missing event or a scratch
+    buffer shared between streams shows up here, where the kernels actually overlap; plus `fake` from the fused
+    whole-network forward vs the layer-wise path <= 1e-5."""
+    base, p0, dfake = _apollo_108(monkeypatch, True, True)
+    assert dfake <= 1e-5, dfake
+    for ds, fp in ((False, True), (True, False)):
+        other, p1, _ = _apollo_108(monkeypatch, ds, fp)
+        for it in range(2):
+            for k in base[it]:
+                assert base[it][k] == other[it][k], (ds, fp, it, k, base[it][k], other[it][k])
+        assert torch.equal(p0, p1), (ds, fp)
