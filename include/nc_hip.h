@@ -121,6 +121,10 @@ int nc_leaky_relu_bwd(const float* dy, const float* x, float slope, float* dx, l
 /* ---- MaxPool3d(2) (networks.py:491,494): floor mode; first maximum wins on ties (scan order d,h,w).             */
 int nc_maxpool2_fwd(const float* x, float* y, int NC, int D, int H, int W, void* stream);
 int nc_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int D, int H, int W, void* stream);
+/* dx = skip + pool-backward(dy): the pooled tensor of Unet_deconv also feeds the skip concat (networks.py:526,531), so its
+ * gradient is the sum of both paths (autograd adds them in a separate pass); even D (or D == 1), H, W only.        */
+int nc_maxpool2_bwd_add(const float* dy, const float* x, const float* skip, float* dx, int NC, int D, int H, int W,
+                        void* stream);
 
 /* ---- Sigmoid (networks.py:510,536) */
 int nc_sigmoid_fwd(const float* x, float* y, long n, void* stream);
@@ -209,6 +213,30 @@ int nc_patchgan_bwd(const float* params, const float* x, const float* saved, con
 size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2);
 int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int S0, int S1, int S2, void* ws,
                        size_t ws_bytes, void* stream);
+
+
+/* ---- Whole-network TRAINING entry points of the generators (one C call per direction, like nc_patchgan_*):
+ *      Unet_deconv.forward (networks.py:512-538) with everything its backward needs kept in `saved`, and the autograd
+ *      backward of it (driven by loss_G.backward(), apollo_model.py:283); DeepLinearGenerator.forward (networks.py:
+ *      913-917) and its backward.  params / dparams: the tensors in state-dict order, packed (28 for unet_deconv, 6 for
+ *      deep_linear_gen); dparams is OVERWRITTEN.  dx may be NULL (the data gradient of the first layer is then skipped).
+ *      Same kernels in the same order as the layer-by-layer path: bit-identical results.  The skip concats cost no copy
+ *      (producers write into halves of the concat buffers) and the two gradients of a skip tensor are merged inside the
+ *      max-pool backward (nc_maxpool2_bwd_add).  nc_deep_linear_fwd with saved == NULL is the inference form.          */
+size_t nc_unet_deconv_param_floats(void);
+size_t nc_unet_deconv_saved_floats(int N, int S0, int S1, int S2);
+size_t nc_unet_deconv_train_ws_bytes(int N, int S0, int S1, int S2);
+int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2,
+                             void* ws, size_t ws_bytes, void* stream);
+int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, const float* saved, const float* dy, float* dx,
+                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream);
+size_t nc_deep_linear_param_floats(void);
+size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2);
+size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2);
+int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved /* or NULL */, int N, int S0, int S1,
+                       int S2, void* ws, size_t ws_bytes, void* stream);
+int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
+                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,364 @@
+// Whole-network TRAINING entry points of the two generators: one C call per direction, as nets.hip does for the PatchGAN.
+//   Unet_deconv          reference models/networks.py:478-538   (forward at :512-538; backward = autograd of it, driven
+//                        by loss_G.backward() at models/axial_to_lateral_gan_apollo_model.py:283)
+//   DeepLinearGenerator  reference models/networks.py:893-917   (bias-free linear chain 7^3 / 5^3 / 3^3 / 1 / 1 / 1)
+// Same kernels in the same order as the layer-by-layer Python path (neuroclear_amd/models/networks.py), so outputs and
+// gradients are bit-identical to it; what the single call removes is ~60 autograd nodes per direction on the host, the
+// torch.cat copies of the two skip connections (the producers write straight into halves of the concat buffers) and the
+// at::native adds that merge the two gradients of a skip tensor (the max-pool backward adds the skip gradient itself).
+//
+// Parameter blob = the tensors in state-dict order, packed back to back.  `saved` receives what the
+// backward needs (raw conv outputs, activations, InstanceNorm statistics); sizes from the *_saved_floats queries.
+#include "common.hpp"
+
+using namespace nc;
+
+#define NC_TRY(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
+
+namespace {
+
+size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// ---- Unet_deconv ---------------------------------------------------------------------------------------------------
+struct UBlock { int C, K, lvl; };  // 3^3 conv + InstanceNorm + ReLU; lvl 0 = full resolution, 1 = half, 2 = quarter
+const UBlock kUB[10] = {{1, 64, 0},    {64, 64, 0},    {64, 128, 1},  {128, 128, 1}, {128, 256, 2},
+                        {256, 256, 2}, {256, 256, 2}, {256, 128, 1}, {128, 128, 1}, {128, 64, 0}};
+
+struct UPlan {
+  int N, d[3][3];      // spatial size per level
+  long S[3];           // voxels per level
+  // saved (floats): activations, raw conv outputs, statistics
+  size_t a1, cat1, p1, a2, cat2, p2, b1, b2, b3, e2a, e2b, e1, t1, raw[10], mean[10], rstd[10], saved;
+  // backward scratch (floats)
+  size_t G1, G2, G3, H1, H2, H3, Q1, Q2, s1, s2, T, grads;
+  size_t conv_ws, in_ws, convT_ws;  // bytes
+};
+
+bool u_plan(UPlan& p, int N, int S0, int S1, int S2) {
+  if (N < 1 || S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return false;
+  p = UPlan{};
+  p.N = N;
+  for (int l = 0; l < 3; ++l) {
+    p.d[l][0] = S0 >> l; p.d[l][1] = S1 >> l; p.d[l][2] = S2 >> l;
+    p.S[l] = (long)p.d[l][0] * p.d[l][1] * p.d[l][2];
+  }
+  const size_t n = (size_t)N, S = (size_t)p.S[0], Sh = (size_t)p.S[1], Sq = (size_t)p.S[2];
+  size_t off = 0;
+  auto take = [&](size_t k) { size_t r = off; off += up64(k); return r; };
+  p.a1 = take(n * 64 * S); p.cat1 = take(n * 128 * S); p.p1 = take(n * 64 * Sh); p.a2 = take(n * 128 * Sh);
+  p.cat2 = take(n * 256 * Sh); p.p2 = take(n * 128 * Sq); p.b1 = take(n * 256 * Sq); p.b2 = take(n * 256 * Sq);
+  p.b3 = take(n * 256 * Sq); p.e2a = take(n * 128 * Sh); p.e2b = take(n * 128 * Sh); p.e1 = take(n * 64 * S);
+  p.t1 = take(n * S);
+  for (int i = 0; i < 10; ++i) {
+    p.raw[i] = take(n * kUB[i].K * (size_t)p.S[kUB[i].lvl]);
+    p.mean[i] = take(n * kUB[i].K);
+    p.rstd[i] = take(n * kUB[i].K);
+  }
+  p.saved = off;
+  off = 0;
+  p.G1 = take(n * 64 * S); p.G2 = take(n * 64 * S); p.G3 = take(n * 128 * S);
+  p.H1 = take(n * 128 * Sh); p.H2 = take(n * 128 * Sh); p.H3 = take(n * 256 * Sh);
+  p.Q1 = take(n * 256 * Sq); p.Q2 = take(n * 256 * Sq); p.s1 = take(n * S); p.s2 = take(n * S);
+  p.T = take(n * 64 * S);  // dense copy of a concat half's gradient when N > 1
+  p.grads = off;
+  auto upd = [&](int C, int K, int l, int k) {
+    const size_t b = nc_conv_ws_bytes(N, C, p.d[l][0], p.d[l][1], p.d[l][2], K, k, k, k, 1, k / 2);
+    if (b > p.conv_ws) p.conv_ws = b;
+  };
+  for (int i = 0; i < 10; ++i) upd(kUB[i].C, kUB[i].K, kUB[i].lvl, 3);
+  upd(64, 1, 0, 1); upd(1, 1, 0, 1);
+  p.in_ws = nc_instnorm_bwd_dbias_ws_bytes(N * 256, (long)S);
+  p.convT_ws = nc_convT_ws_bytes(N, 256, p.d[2][0], p.d[2][1], p.d[2][2], 128);
+  const size_t c2 = nc_convT_ws_bytes(N, 128, p.d[1][0], p.d[1][1], p.d[1][2], 64);
+  if (c2 > p.convT_ws) p.convT_ws = c2;
+  return true;
+}
+
+// offsets (floats) of the 28 tensors inside the packed blob, state-dict order:
+// dc1.0 dc1.3 dc2.0 dc2.3 bot.0 bot.3 bot.6 t_conv2 ex2.0 ex2.3 t_conv1 ex1.0 1x1 1x1_2
+struct UOff { size_t w[14], b[14], total; };  // ids 0..9 = blocks, 10 = t_conv2, 11 = t_conv1, 12 = one_by_one, 13 = one_by_one_2
+UOff u_offsets() {
+  struct L { int id; size_t wn, bn; };
+  const L order[14] = {{0, 64 * 1 * 27, 64},     {1, 64 * 64 * 27, 64},    {2, 128 * 64 * 27, 128},  {3, 128 * 128 * 27, 128},
+                       {4, 256 * 128 * 27, 256}, {5, 256 * 256 * 27, 256}, {6, 256 * 256 * 27, 256}, {10, 256 * 128 * 8, 128},
+                       {7, 128 * 256 * 27, 128}, {8, 128 * 128 * 27, 128}, {11, 128 * 64 * 8, 64},   {9, 64 * 128 * 27, 64},
+                       {12, 64, 1},              {13, 1, 1}};
+  UOff o{};
+  size_t off = 0;
+  for (const L& l : order) {
+    o.w[l.id] = off; off += l.wn;
+    o.b[l.id] = off; off += l.bn;
+  }
+  o.total = off;
+  return o;
+}
+
+// dst[n][0..C) <- src[n][c0..c0+C) of a [N][Ctot][S] tensor (dense result); N == 1 needs no copy
+int gather_half(const float* src, float* dst, int N, int Ctot, int c0, int C, long S, hipStream_t s) {
+  if (hipMemcpy2DAsync(dst, (size_t)C * S * 4, src + (size_t)c0 * S, (size_t)Ctot * S * 4, (size_t)C * S * 4, N,
+                       hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    set_error("gather_half: hipMemcpy2DAsync failed");
+    return NC_ERR_HIP;
+  }
+  return NC_OK;
+}
+
+size_t u_ws_bytes(const UPlan& p, bool bwd) {
+  return align256(p.conv_ws) + align256(p.in_ws) + align256(p.convT_ws) + (bwd ? p.grads * sizeof(float) : 0) + 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nc_unet_deconv_param_floats(void) { return u_offsets().total; }
+
+size_t nc_unet_deconv_saved_floats(int N, int S0, int S1, int S2) {
+  UPlan p;
+  return u_plan(p, N, S0, S1, S2) ? p.saved : 0;
+}
+
+size_t nc_unet_deconv_train_ws_bytes(int N, int S0, int S1, int S2) {
+  UPlan p;
+  return u_plan(p, N, S0, S1, S2) ? u_ws_bytes(p, true) : 0;
+}
+
+int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2,
+                             void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved) { set_error("unet_deconv_train_fwd: null pointer"); return NC_ERR_ARG; }
+  UPlan p;
+  if (!u_plan(p, N, S0, S1, S2)) {
+    set_error("unet_deconv_train_fwd: every edge must be a positive multiple of 4 (got %d,%d,%d)", S0, S1, S2);
+    return NC_ERR_SHAPE;
+  }
+  if (!ws || ws_bytes < u_ws_bytes(p, false)) { set_error("unet_deconv_train_fwd: workspace too small"); return NC_ERR_WS; }
+  const UOff o = u_offsets();
+  void* cws = ws;
+  void* iws = (char*)ws + align256(p.conv_ws);
+  float* V = saved;
+  const float* P = params;
+  // conv (3^3, pad 1) -> raw; statistics; normalise + ReLU into `out`, where sample n's K planes start at
+  // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer)
+  auto block = [&](int i, const float* in, float* out, size_t out_stride) -> int {
+    const UBlock& b = kUB[i];
+    const int* d = p.d[b.lvl];
+    const long S = p.S[b.lvl];
+    NC_TRY(nc_conv_fwd(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws,
+                       p.conv_ws, stream));
+    NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
+    if (out_stride == (size_t)b.K * S || N == 1)
+      return nc_instnorm_act_fwd(V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, N * b.K, S, stream);
+    for (int n = 0; n < N; ++n)
+      NC_TRY(nc_instnorm_act_fwd(V + p.raw[i] + (size_t)n * b.K * S, V + p.mean[i] + n * b.K, V + p.rstd[i] + n * b.K, 0.f,
+                                 out + n * out_stride, b.K, S, stream));
+    return NC_OK;
+  };
+  const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
+  const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
+  NC_TRY(block(0, x, V + p.a1, (size_t)64 * S));
+  NC_TRY(block(1, V + p.a1, V + p.cat1, (size_t)128 * S));
+  for (int n = 0; n < N; ++n)
+    NC_TRY(nc_maxpool2_fwd(V + p.cat1 + (size_t)n * 128 * S, V + p.p1 + (size_t)n * 64 * Sh, 64, d0[0], d0[1], d0[2], stream));
+  NC_TRY(block(2, V + p.p1, V + p.a2, (size_t)128 * Sh));
+  NC_TRY(block(3, V + p.a2, V + p.cat2, (size_t)256 * Sh));
+  for (int n = 0; n < N; ++n)
+    NC_TRY(nc_maxpool2_fwd(V + p.cat2 + (size_t)n * 256 * Sh, V + p.p2 + (size_t)n * 128 * Sq, 128, d1[0], d1[1], d1[2], stream));
+  NC_TRY(block(4, V + p.p2, V + p.b1, (size_t)256 * Sq));
+  NC_TRY(block(5, V + p.b1, V + p.b2, (size_t)256 * Sq));
+  NC_TRY(block(6, V + p.b2, V + p.b3, (size_t)256 * Sq));
+  for (int n = 0; n < N; ++n)  // t_conv2 writes the second half of cat2
+    NC_TRY(nc_convT_k2s2_fwd(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
+                             1, 256, d2[0], d2[1], d2[2], 128, stream));
+  NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh));
+  NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh));
+  for (int n = 0; n < N; ++n)  // t_conv1 writes the second half of cat1
+    NC_TRY(nc_convT_k2s2_fwd(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
+                             1, 128, d1[0], d1[1], d1[2], 64, stream));
+  NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S));
+  // the 1x1 tail
+  NC_TRY(nc_conv_fwd(V + p.e1, P + o.w[12], P + o.b[12], V + p.t1, N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  // one_by_one_2 + sigmoid: y doubles as the buffer of the pre-sigmoid value (the sigmoid kernel is elementwise in place)
+  NC_TRY(nc_conv_fwd(V + p.t1, P + o.w[13], P + o.b[13], y, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  return nc_sigmoid_fwd(y, y, (long)N * S, stream);
+}
+
+// dparams: packed like params, OVERWRITTEN with this call's parameter gradients.  dx nullable (the U-Net's input is the
+// real volume in the Apollo / Athena steps: its gradient -- the data gradient of the first convolution -- is skipped).
+int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, const float* saved, const float* dy, float* dx,
+                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved || !dy || !dparams) { set_error("unet_deconv_bwd: null pointer"); return NC_ERR_ARG; }
+  UPlan p;
+  if (!u_plan(p, N, S0, S1, S2)) { set_error("unet_deconv_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < u_ws_bytes(p, true)) { set_error("unet_deconv_bwd: workspace too small"); return NC_ERR_WS; }
+  const UOff o = u_offsets();
+  hipStream_t hs = (hipStream_t)stream;
+  void* cws = ws;
+  void* iws = (char*)ws + align256(p.conv_ws);
+  void* tws = (char*)iws + align256(p.in_ws);
+  float* G = (float*)((char*)tws + align256(p.convT_ws));
+  const float* V = saved;
+  const float* P = params;
+  float* DP = dparams;
+  const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
+  const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
+  // backward of block i: g = gradient at the block's (post-ReLU) output, dense [N][K][S]; `in` = the block's input.
+  // draw <- InstanceNorm/ReLU backward (+ the conv's bias gradient); dW <- wgrad; gin (nullable) <- dgrad
+  auto block_bwd = [&](int i, const float* g, const float* in, float* draw, float* gin) -> int {
+    const UBlock& b = kUB[i];
+    const int* d = p.d[b.lvl];
+    const long Sl = p.S[b.lvl];
+    NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
+                                     p.in_ws, stream));
+    if (gin)
+      NC_TRY(nc_conv_dgrad(draw, P + o.w[i], gin, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    return nc_conv_wgrad(in, draw, DP + o.w[i], nullptr, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream);
+  };
+  // gradient of the second half of a concat buffer as a dense tensor
+  auto upper_half = [&](const float* dcat, int Ctot, long Sl, const float** out) -> int {
+    const int C = Ctot / 2;
+    if (N == 1) { *out = dcat + (size_t)C * Sl; return NC_OK; }
+    NC_TRY(gather_half(dcat, G + p.T, N, Ctot, C, C, Sl, hs));
+    *out = G + p.T;
+    return NC_OK;
+  };
+  // 1x1 tail
+  NC_TRY(nc_sigmoid_bwd(dy, y, G + p.s1, (long)N * S, stream));
+  NC_TRY(nc_conv_wgrad(V + p.t1, G + p.s1, DP + o.w[13], DP + o.b[13], N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  NC_TRY(nc_conv_dgrad(G + p.s1, P + o.w[13], G + p.s2, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  NC_TRY(nc_conv_wgrad(V + p.e1, G + p.s2, DP + o.w[12], DP + o.b[12], N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  NC_TRY(nc_conv_dgrad(G + p.s2, P + o.w[12], G + p.G1, N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  // ex_conv1_1 (cat1 -> e1)
+  NC_TRY(block_bwd(9, G + p.G1, V + p.cat1, G + p.G2, G + p.G3));
+  // t_conv1 (e2b -> cat1[:, 64:])
+  const float* g;
+  NC_TRY(upper_half(G + p.G3, 128, S, &g));
+  NC_TRY(nc_convT_k2s2_dgrad(g, P + o.w[11], G + p.H1, N, 128, d1[0], d1[1], d1[2], 64, tws, p.convT_ws, stream));
+  NC_TRY(nc_convT_k2s2_wgrad(V + p.e2b, g, DP + o.w[11], DP + o.b[11], N, 128, d1[0], d1[1], d1[2], 64, tws, p.convT_ws, stream));
+  // ex_double_conv2 (cat2 -> e2a -> e2b)
+  NC_TRY(block_bwd(8, G + p.H1, V + p.e2a, G + p.H2, G + p.H1));
+  NC_TRY(block_bwd(7, G + p.H1, V + p.cat2, G + p.H2, G + p.H3));
+  // t_conv2 (b3 -> cat2[:, 128:])
+  NC_TRY(upper_half(G + p.H3, 256, Sh, &g));
+  NC_TRY(nc_convT_k2s2_dgrad(g, P + o.w[10], G + p.Q1, N, 256, d2[0], d2[1], d2[2], 128, tws, p.convT_ws, stream));
+  NC_TRY(nc_convT_k2s2_wgrad(V + p.b3, g, DP + o.w[10], DP + o.b[10], N, 256, d2[0], d2[1], d2[2], 128, tws, p.convT_ws, stream));
+  // bottom_layer (p2 -> b1 -> b2 -> b3)
+  NC_TRY(block_bwd(6, G + p.Q1, V + p.b2, G + p.Q2, G + p.Q1));
+  NC_TRY(block_bwd(5, G + p.Q1, V + p.b1, G + p.Q2, G + p.Q1));
+  NC_TRY(block_bwd(4, G + p.Q1, V + p.p2, G + p.Q2, G + p.Q1));
+  // conv2 = cat2[:, :128] feeds the pool AND the skip: gradient = pool backward + the first half of dcat2
+  for (int n = 0; n < N; ++n)
+    NC_TRY(nc_maxpool2_bwd_add(G + p.Q1 + (size_t)n * 128 * Sq, V + p.cat2 + (size_t)n * 256 * Sh, G + p.H3 + (size_t)n * 256 * Sh,
+                               G + p.H1 + (size_t)n * 128 * Sh, 128, d1[0], d1[1], d1[2], stream));
+  // double_conv2 (p1 -> a2 -> conv2)
+  NC_TRY(block_bwd(3, G + p.H1, V + p.a2, G + p.H2, G + p.H1));
+  NC_TRY(block_bwd(2, G + p.H1, V + p.p1, G + p.H2, G + p.H1));
+  for (int n = 0; n < N; ++n)
+    NC_TRY(nc_maxpool2_bwd_add(G + p.H1 + (size_t)n * 64 * Sh, V + p.cat1 + (size_t)n * 128 * S, G + p.G3 + (size_t)n * 128 * S,
+                               G + p.G1 + (size_t)n * 64 * S, 64, d0[0], d0[1], d0[2], stream));
+  // double_conv1 (x -> a1 -> conv1)
+  NC_TRY(block_bwd(1, G + p.G1, V + p.a1, G + p.G2, G + p.G1));
+  return block_bwd(0, G + p.G1, x, G + p.G2, dx);
+}
+
+}  // extern "C"
+
+// ---- DeepLinearGenerator ------------------------------------------------------------------------------------------
+namespace {
+
+struct LLayer { int C, K, k; };
+const LLayer kLL[6] = {{1, 64, 7}, {64, 64, 5}, {64, 64, 3}, {64, 32, 1}, {32, 16, 1}, {16, 1, 1}};
+
+struct LPlan {
+  int N, d[3];
+  long S;
+  size_t w[6], params;        // floats into the packed blob
+  size_t act[5], saved;       // outputs of layers 0..4 (inputs of layers 1..5)
+  size_t g[2], grads;         // gradient ping-pong
+  size_t conv_ws;
+};
+
+bool l_plan(LPlan& p, int N, int S0, int S1, int S2) {
+  if (N < 1 || S0 < 1 || S1 < 1 || S2 < 1) return false;
+  p = LPlan{};
+  p.N = N; p.d[0] = S0; p.d[1] = S1; p.d[2] = S2;
+  p.S = (long)S0 * S1 * S2;
+  size_t off = 0;
+  for (int i = 0; i < 6; ++i) { p.w[i] = off; off += (size_t)kLL[i].K * kLL[i].C * kLL[i].k * kLL[i].k * kLL[i].k; }
+  p.params = off;
+  off = 0;
+  for (int i = 0; i < 5; ++i) { p.act[i] = off; off += up64((size_t)N * kLL[i].K * p.S); }
+  p.saved = off;
+  p.g[0] = 0; p.g[1] = up64((size_t)N * 64 * p.S);
+  p.grads = 2 * up64((size_t)N * 64 * p.S);
+  for (int i = 0; i < 6; ++i) {
+    const size_t b = nc_conv_ws_bytes(N, kLL[i].C, S0, S1, S2, kLL[i].K, kLL[i].k, kLL[i].k, kLL[i].k, 1, kLL[i].k / 2);
+    if (b > p.conv_ws) p.conv_ws = b;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nc_deep_linear_param_floats(void) {
+  LPlan p;
+  l_plan(p, 1, 8, 8, 8);
+  return p.params;
+}
+
+size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2) {
+  LPlan p;
+  return l_plan(p, N, S0, S1, S2) ? p.saved : 0;
+}
+
+size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2) {
+  LPlan p;
+  return l_plan(p, N, S0, S1, S2) ? align256(p.conv_ws) + p.grads * sizeof(float) + 256 : 0;
+}
+
+// saved == NULL: inference -- the intermediate activations ping-pong through the workspace instead
+int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!params || !x || !y) { set_error("deep_linear_fwd: null pointer"); return NC_ERR_ARG; }
+  LPlan p;
+  if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_fwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_deep_linear_ws_bytes(N, S0, S1, S2)) { set_error("deep_linear_fwd: workspace too small"); return NC_ERR_WS; }
+  void* cws = ws;
+  float* G = (float*)((char*)ws + align256(p.conv_ws));
+  const float* in = x;
+  for (int i = 0; i < 6; ++i) {
+    const LLayer& l = kLL[i];
+    float* out = i == 5 ? y : (saved ? saved + p.act[i] : G + p.g[i & 1]);
+    NC_TRY(nc_conv_fwd(in, params + p.w[i], nullptr, out, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws,
+                       stream));
+    in = out;
+  }
+  return NC_OK;
+}
+
+// dx nullable; dparams overwritten
+int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
+                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !saved || !dy || !dparams) { set_error("deep_linear_bwd: null pointer"); return NC_ERR_ARG; }
+  LPlan p;
+  if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_deep_linear_ws_bytes(N, S0, S1, S2)) { set_error("deep_linear_bwd: workspace too small"); return NC_ERR_WS; }
+  void* cws = ws;
+  float* G = (float*)((char*)ws + align256(p.conv_ws));
+  const float* g = dy;
+  for (int i = 5; i >= 0; --i) {
+    const LLayer& l = kLL[i];
+    const float* in = i == 0 ? x : saved + p.act[i - 1];
+    float* gin = i == 0 ? dx : G + p.g[i & 1];
+    if (gin)
+      NC_TRY(nc_conv_dgrad(g, params + p.w[i], gin, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
+    NC_TRY(nc_conv_wgrad(in, g, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws,
+                         stream));
+    g = gin;
+  }
+  return NC_OK;
+}
+
+}  // extern "C"

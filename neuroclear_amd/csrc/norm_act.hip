@@ -322,8 +322,11 @@ __global__ void k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
-__global__ void k_maxpool2_bwd(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                               int NC, int D, int H, int W, int Do, int Ho, int Wo, int wd) {
+// SKIP: dx = skip + (the pool's gradient): the pooled tensor also feeds a skip connection (networks.py:526,531), whose
+// gradient autograd would add in a separate pass
+template <bool SKIP>
+__global__ void k_maxpool2_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ skip,
+                               float* __restrict__ dx, int NC, int D, int H, int W, int Do, int Ho, int Wo, int wd) {
   const long total = (long)NC * Do * Ho * Wo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ow = (int)(i % Wo), oh = (int)((i / Wo) % Ho), od = (int)((i / ((long)Wo * Ho)) % Do);
@@ -344,8 +347,11 @@ __global__ void k_maxpool2_bwd(const float* __restrict__ dy, const float* __rest
     const float g = dy[i];
     for (int a = 0; a < wd; ++a)
       for (int b = 0; b < 2; ++b)
-        for (int c = 0; c < 2; ++c)
-          q[((long)(od * wd + a) * H + (oh * 2 + b)) * W + ow * 2 + c] = ((a * 2 + b) * 2 + c) == arg ? g : 0.f;
+        for (int c = 0; c < 2; ++c) {
+          const long o = ((long)(od * wd + a) * H + (oh * 2 + b)) * W + ow * 2 + c;
+          const float v = ((a * 2 + b) * 2 + c) == arg ? g : 0.f;
+          q[o] = SKIP ? skip[nc * D * H * W + o] + v : v;
+        }
   }
 }
 
@@ -514,8 +520,23 @@ int nc_maxpool2_bwd(const float* dy, const float* x, float* dx, int NC, int D, i
     }
   }
   const long total = (long)NC * Do * Ho * Wo;
-  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(flat_grid(total)), dim3(256), 0, s, dy, x, dx, NC, D, H, W, Do, Ho, Wo, wd);
+  hipLaunchKernelGGL(k_maxpool2_bwd<false>, dim3(flat_grid(total)), dim3(256), 0, s, dy, x, nullptr, dx, NC, D, H, W, Do, Ho, Wo, wd);
   return check_launch("maxpool2_bwd");
+}
+
+int nc_maxpool2_bwd_add(const float* dy, const float* x, const float* skip, float* dx, int NC, int D, int H, int W,
+                        void* stream) {
+  if (!dy || !x || !skip || !dx) { set_error("maxpool2_bwd_add: null pointer"); return NC_ERR_ARG; }
+  const int wd = D > 1 ? 2 : 1;
+  const int Do = D / wd, Ho = H / 2, Wo = W / 2;
+  if (NC < 1 || Do < 1 || Ho < 1 || Wo < 1 || (D % wd) || (H & 1) || (W & 1)) {
+    set_error("maxpool2_bwd_add: even sizes expected (the skip tensor and the pooled tensor are the same tensor)");
+    return NC_ERR_SHAPE;
+  }
+  const long total = (long)NC * Do * Ho * Wo;
+  hipLaunchKernelGGL(k_maxpool2_bwd<true>, dim3(flat_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, x, skip, dx, NC, D, H, W,
+                     Do, Ho, Wo, wd);
+  return check_launch("maxpool2_bwd_add");
 }
 
 }  // extern "C"

@@ -159,6 +159,8 @@ def conv(dimension):
 
 
 _BIAS_LINK = os.environ.get('NC_BIAS_LINK', '1') != '0'  # A/B switch (timing experiments)
+# whole-network C entry points for the generators' training passes (NC_FUSED_GEN=0: layer by layer through autograd)
+_FUSED_GEN = os.environ.get('NC_FUSED_GEN', '1') != '0'
 
 
 def _run_linked(seq, x):
@@ -292,6 +294,9 @@ class Unet_deconv(nn.Module):
             raise ValueError('Unet_deconv: every edge must be a multiple of 4, got %s' % (tuple(inputs.shape[2:]),))
         if self._fusable and not torch.is_grad_enabled() and inputs.is_cuda:
             return self._forward_fused(inputs)
+        if self._fusable and inputs.is_cuda and ops.conv_precision == 'fp32' and _FUSED_GEN:
+            # training: the whole forward (and, through autograd, the whole backward) as one C call
+            return ops.unet_deconv_train(inputs, list(self.parameters()))
         conv1 = self.double_conv1(inputs)
         conv2 = self.double_conv2(ops.maxpool2(conv1))
         conv_bottom = self.bottom_layer(ops.maxpool2(conv2))
@@ -351,6 +356,9 @@ class DeepLinearGenerator(nn.Module):
         self.final_layer = Conv(c // 4, output_nc, 1, 1, 0, bias=False)
 
     def forward(self, input):
+        if input.is_cuda and input.dim() == 5 and input.shape[1] == 1 and self.final_layer.weight.shape[0] == 1 and \
+                self.first_layer.weight.shape[0] == 64 and ops.conv_precision == 'fp32' and _FUSED_GEN:
+            return ops.deep_linear(input, list(self.parameters()))
         return self.final_layer(self.feature_block(self.first_layer(input)))
 
 

@@ -845,3 +845,121 @@ class _PatchGAN(torch.autograd.Function):
 def patchgan(x, params, n_layers, ndf, dimension):
     """NLayerDiscriminator.forward (networks.py:1063-1066) with InstanceNorm, as one C call (and one for backward)."""
     return _PatchGAN.apply(x, (int(n_layers), int(ndf), int(dimension)), *params)
+
+
+# ---- whole-network generators (nc_unet_deconv_train_fwd / _bwd, nc_deep_linear_fwd / _bwd): one C call per direction --
+def _param_grads(ctx, dpar, shapes, first):
+    grads = [None] * len(shapes)
+    off = 0
+    for i, shp in enumerate(shapes):
+        n = 1
+        for s in shp:
+            n *= s
+        if ctx.needs_input_grad[first + i]:
+            grads[i] = dpar[off:off + n].view(shp)
+        off += n
+    return grads
+
+
+class _UnetDeconvTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        packed = _pack_params(params)
+        if packed.numel() != L.nc_unet_deconv_param_floats():
+            raise _lib.NcError('fused Unet_deconv: parameter count does not match')
+        nsv = L.nc_unet_deconv_saved_floats(I(N), I(S0), I(S1), I(S2))
+        if nsv == 0:
+            raise _lib.NcError('fused Unet_deconv: every edge must be a positive multiple of 4, got %s' % ((S0, S1, S2),))
+        saved = torch.empty(nsv, dtype=torch.float32, device=x.device)
+        ws = workspace(L.nc_unet_deconv_train_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'unet_train')
+        y = torch.empty_like(x)
+        e0 = _prof_begin()
+        check(L.nc_unet_deconv_train_fwd(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), I(N), I(S0), I(S1), I(S2), _ptr(ws),
+                                         Z(ws.numel()), _stream()), 'nc_unet_deconv_train_fwd')
+        if e0 is not None:
+            _prof_end(e0, 'unet_fwd', 2.0 * 663809 * x.numel())
+        ctx.save_for_backward(x, y, saved)
+        ctx.packed = packed
+        ctx.packed_gen = _param_generation(packed)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, saved = ctx.saved_tensors
+        if _param_generation(ctx.packed) != ctx.packed_gen:
+            raise _lib.NcError('fused Unet_deconv: the parameters were updated between this forward and its backward')
+        dy = dy.contiguous()
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dpar = torch.empty_like(ctx.packed)
+        ws = workspace(L.nc_unet_deconv_train_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'unet_train')
+        e0 = _prof_begin()
+        check(L.nc_unet_deconv_bwd(_ptr(ctx.packed), _ptr(x), _ptr(y), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N),
+                                   I(S0), I(S1), I(S2), _ptr(ws), Z(ws.numel()), _stream()), 'nc_unet_deconv_bwd')
+        if e0 is not None:  # dgrad + wgrad of every layer but the first one's data gradient
+            _prof_end(e0, 'unet_bwd', 2.0 * (2 * 663809 - 1728) * x.numel())
+        return (dx,) + tuple(_param_grads(ctx, dpar, ctx.shapes, 1))
+
+
+def unet_deconv_train(x, params):
+    """Unet_deconv.forward (networks.py:512-538) with autograd, as one C call per direction."""
+    return _UnetDeconvTrain.apply(x, *params)
+
+
+class _DeepLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        packed = _pack_params(params)
+        if packed.numel() != L.nc_deep_linear_param_floats():
+            raise _lib.NcError('fused DeepLinearGenerator: parameter count does not match')
+        need = any(ctx.needs_input_grad)
+        saved = torch.empty(L.nc_deep_linear_saved_floats(I(N), I(S0), I(S1), I(S2)), dtype=torch.float32,
+                            device=x.device) if need else None
+        ws = workspace(L.nc_deep_linear_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'deep_linear')
+        y = torch.empty_like(x)
+        e0 = _prof_begin()
+        check(L.nc_deep_linear_fwd(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), I(N), I(S0), I(S1), I(S2), _ptr(ws),
+                                   Z(ws.numel()), _stream()), 'nc_deep_linear_fwd')
+        if e0 is not None:
+            _prof_end(e0, 'deep_linear_fwd', 2.0 * 647120 * x.numel())
+        if need:
+            ctx.save_for_backward(x, saved)
+            ctx.packed = packed
+            ctx.packed_gen = _param_generation(packed)
+            ctx.shapes = [tuple(p.shape) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved = ctx.saved_tensors
+        if _param_generation(ctx.packed) != ctx.packed_gen:
+            raise _lib.NcError('fused DeepLinearGenerator: the parameters were updated between this forward and its backward')
+        dy = dy.contiguous()
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dpar = torch.empty_like(ctx.packed)
+        ws = workspace(L.nc_deep_linear_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'deep_linear')
+        e0 = _prof_begin()
+        check(L.nc_deep_linear_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N), I(S0), I(S1),
+                                   I(S2), _ptr(ws), Z(ws.numel()), _stream()), 'nc_deep_linear_bwd')
+        if e0 is not None:
+            _prof_end(e0, 'deep_linear_bwd', 2.0 * (2 * 647120 - (0 if dx is not None else 21952)) * x.numel())
+        return (dx,) + tuple(_param_grads(ctx, dpar, ctx.shapes, 1))
+
+
+def deep_linear(x, params):
+    """DeepLinearGenerator.forward (networks.py:913-917), with autograd, as one C call per direction."""
+    return _DeepLinear.apply(x, *params)

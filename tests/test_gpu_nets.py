@@ -472,3 +472,41 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
     xi = x.clone().requires_grad_(True)
     (net(xi) * r).mean().backward()
     assert torch.equal(xi.grad, xa)
+
+
+@pytest.mark.parametrize('kind,shape', [('unet', (1, 1, 16, 16, 16)), ('unet', (2, 1, 12, 20, 24)), ('unet', (3, 1, 8, 8, 36)),
+                                        ('linear', (1, 1, 16, 16, 16)), ('linear', (2, 1, 9, 14, 21))])
+@pytest.mark.parametrize('want_dx', [False, True])
+def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, monkeypatch):
+    """nc_unet_deconv_train_fwd / nc_unet_deconv_bwd and nc_deep_linear_fwd / _bwd (one C call per direction, concat
+    halves written in place, skip gradients merged inside the max-pool backward) against the layer-by-layer autograd path
+    of the same module: same kernels in the same order, so output, input gradient and all parameter gradients are
+    BIT-identical -- batches included (per-sample sub-ranges of the concat buffers)."""
+    if kind == 'unet':
+        net = load(networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0]),
+                   S.unet_deconv_spec(), 31)
+    else:
+        net = load(networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0]),
+                   S.deep_linear_spec(), 32)
+    x0 = torch.from_numpy(rnd(41, shape)).to(DEV)
+    r = torch.from_numpy(rnd(42, shape)).to(DEV)
+
+    def run(fused):
+        monkeypatch.setattr(networks, '_FUSED_GEN', fused)
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(want_dx)
+        y = net(x)
+        (y * r).sum().backward()
+        return y.detach().clone(), (x.grad.clone() if want_dx else None), [p.grad.clone() for p in net.parameters()]
+
+    ya, xa, ga = run(False)
+    yb, xb, gb = run(True)
+    assert torch.equal(ya, yb)
+    if want_dx:
+        assert torch.equal(xa, xb)
+    for (n, _), a, b in zip(net.named_parameters(), ga, gb):
+        assert torch.equal(a, b), n
+    if kind == 'linear':  # inference form (saved == NULL: activations ping-pong through the workspace)
+        with torch.no_grad():
+            assert torch.equal(net(x0), ya)
