@@ -203,8 +203,8 @@ def run_train(args, rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.prof = None if args.no_prof else []
-    ops.prof_min_flop = 0.0 if args.prof_all else 1e9
+    if not args.no_prof:
+        ops.prof_start(0.0 if args.prof_all else 1e9)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -212,20 +212,20 @@ def run_train(args, rank, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, ops.prof = (ops.prof or []), None
+    stats, whole = ({}, []) if args.no_prof else ops.prof_stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # ---- per-kernel-class event statistics of the timed region (rank-local)
-    stats = {}
-    for tag, flop, e0, e1 in prof:
-        ms = e0.elapsed_time(e1)
-        s = stats.setdefault(tag, [0, 0.0, 0.0])
-        s[0] += 1
-        s[1] += ms
-        s[2] += flop
+    # ---- per-kernel-class event statistics of the timed region (rank-local): HIP events recorded inside the library
+    #      around every convolution launch of >= 1 GFLOP, on the stream it was launched on
     conv_ms = sum(s[1] for s in stats.values())
+    calls = {}
+    for tag, fl, ms in whole:
+        c = calls.setdefault(tag, [0, 0.0, 0.0])
+        c[0] += 1
+        c[1] += ms
+        c[2] += fl
     top = max((t for t in stats if 'mfma' in t or '_lp_' in t), key=lambda t: stats[t][1], default=None)
     roof = None
     if top:
@@ -239,7 +239,9 @@ def run_train(args, rank, world, dev):
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
                                      tflops=round(s[2] / s[1] / 1e9, 2)) for t, s in sorted(stats.items())},
-                    conv_ms_per_step=round(conv_ms / args.steps, 2))
+                    conv_ms_per_step=round(conv_ms / args.steps, 2),
+                    whole_network_calls={t: dict(n=c[0], ms_per_step=round(c[1] / args.steps, 3),
+                                                 tflops=round(c[2] / c[1] / 1e9, 2)) for t, c in sorted(calls.items())})
     losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
     return dt, crop ** 3 * args.batch * args.steps * world, roof, dict(
         workload='%s_train_step_%dcube_bs%d' % (args.model, crop, args.batch), crop=crop, batch_size=args.batch,

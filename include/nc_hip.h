@@ -36,6 +36,12 @@ int nc_version(void);
  * gradient (3^3 / 7^3, W % 4 == 0).  The query assumes a 256^2 plane for pointwise kernels, a 32^3 volume otherwise. */
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad);
+/* Live launch profiler (bench.py's `roofline`): between nc_prof_begin and nc_prof_end every convolution entry point of
+ * >= min_flop algorithmic FLOP is bracketed by HIP events on the stream it is launched on.  nc_prof_end returns the number
+ * of recorded calls and fills the first `max`: cls = op (0 fwd, 1 dgrad, 2 wgrad) | path << 4 | kernel edge << 8 |
+ * (16-bit kernel ? 1 << 16 : 0), flop = 2 C K kd kh kw x output voxels, ms = event-to-event duration.  Synchronise first. */
+void nc_prof_begin(double min_flop);
+int nc_prof_end(int max, int* cls, double* flop, float* ms);
 /* Force the direct path everywhere (tests cross-check MFMA vs direct on the GPU). 0 = auto (default), 1 = force. */
 void nc_set_force_direct(int on);
 

@@ -1,6 +1,7 @@
 // C-ABI glue: error reporting, convolution dispatch (MFMA implicit GEMM vs direct), and the whole-network forward of
 // Unet_deconv used by diced inference (reference models/networks.py:512-538 via models/test_model.py:60-62).
 #include <cstring>
+#include <vector>
 
 #include "common.hpp"
 
@@ -16,11 +17,79 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- live launch profiler (bench.py): HIP events on the launch stream around every convolution entry point --------
+struct ProfRec { int cls; double flop; hipEvent_t e0, e1; };
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+static bool g_prof_on = false;
+static double g_prof_min_flop = 0.0;
+
+struct ProfScope {
+  int idx = -1;
+  hipStream_t s;
+  // cls = op (0 fwd, 1 dgrad, 2 wgrad) | path << 4 | kernel edge << 8 | (16-bit ? 1 << 16 : 0)
+  ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t stream) : s(stream) {
+    if (!g_prof_on) return;
+    const double flop = 2.0 * d.C * d.K * d.kd * d.kh * d.kw * ((double)d.N * d.Do * d.Ho * d.Wo);
+    if (flop < g_prof_min_flop) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+      if (hipEventCreate(&e) != hipSuccess) return (hipEvent_t) nullptr;
+      return e;
+    };
+    ProfRec r{op | (path << 4) | (d.kh << 8) | (lp ? 1 << 16 : 0), flop, get(), get()};
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, s);
+    g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, s);
+  }
+};
+
+static int fwd_path(const ConvDims& d) {
+  if (g_force_direct) return 0;
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : gemm_fwd_supported(d) ? 2 : 0;
+}
+static int dgrad_path(const ConvDims& d) {
+  if (g_force_direct) return 0;
+  return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
+                                                                                              : gemm_dgrad_supported(d) ? 2 : 0;
+}
+static int wgrad_path(const ConvDims& d) {
+  if (g_force_direct) return 0;
+  return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4 : k1_wgrad_supported(d) ? 5
+                                                                                            : gemm_wgrad_supported(d) ? 2 : 0;
+}
+
 }  // namespace nc
 
 using namespace nc;
 
 extern "C" {
+
+void nc_prof_begin(double min_flop) {
+  for (ProfRec& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof.clear();
+  g_prof_min_flop = min_flop;
+  g_prof_on = true;
+}
+
+// Stops recording, waits for the recorded launches and returns how many there were; the first `max` are written to
+// cls / flop / ms (cls encoding: see ProfScope).  The caller synchronises the device first.
+int nc_prof_end(int max, int* cls, double* flop, float* ms) {
+  g_prof_on = false;
+  const int n = (int)g_prof.size();
+  for (int i = 0; i < n && i < max; ++i) {
+    float t = 0.f;
+    (void)hipEventSynchronize(g_prof[i].e1);
+    (void)hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
+    cls[i] = g_prof[i].cls; flop[i] = g_prof[i].flop; ms[i] = t;
+  }
+  return n;
+}
 
 const char* nc_last_error(void) { return g_err; }
 int nc_version(void) { return 100; }
@@ -75,6 +144,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   ConvDims d;
   if (int e = conv_args("conv_fwd", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(0, fwd_path(d), d, 0, s);
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);
@@ -87,6 +157,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   ConvDims d;
   if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(1, dgrad_path(d), d, 0, s);
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);
@@ -130,6 +201,7 @@ int nc_conv_fwd_lp(const float* x, const void* xh, const float* w, const float* 
   ConvDims d;
   if (int e = lp_args("conv_fwd_lp", d, x, xh, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad, dtype)) return e;
   if (!h_fwd_supported(d)) { set_error("conv_fwd_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  ProfScope ps(0, 1, d, 1, (hipStream_t)stream);
   return conv_fwd_h(x, xh, w, bias, y, d, dtype, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -138,6 +210,7 @@ int nc_conv_dgrad_lp(const float* dy, const void* dyh, const float* w, float* dx
   ConvDims d;
   if (int e = lp_args("conv_dgrad_lp", d, dy, dyh, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad, dtype)) return e;
   if (!h_dgrad_supported(d)) { set_error("conv_dgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  ProfScope ps(1, 1, d, 1, (hipStream_t)stream);
   return conv_dgrad_h(dy, dyh, w, dx, d, dtype, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -150,7 +223,10 @@ int nc_conv_wgrad_lp(const float* x, const void* xh, const float* dy, const void
   if (dbias && !dy) { set_error("conv_wgrad_lp: the bias gradient needs the fp32 dy"); return NC_ERR_ARG; }
   if (!h_wgrad_supported(d)) { set_error("conv_wgrad_lp: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
   hipStream_t s = (hipStream_t)stream;
-  if (int e = conv_wgrad_h(x, xh, dy, dyh, dw, d, dtype, ws, ws_bytes, s)) return e;
+  {
+    ProfScope ps(2, 1, d, 1, s);
+    if (int e = conv_wgrad_h(x, xh, dy, dyh, dw, d, dtype, ws, ws_bytes, s)) return e;
+  }
   if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);  // fp32, from the fp32 dy
   return NC_OK;
 }
@@ -161,12 +237,15 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   if (int e = conv_args("conv_wgrad", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
   int e;
+  {
+  ProfScope ps(2, wgrad_path(d), d, 0, s);
   if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && k1_wgrad_supported(d)) e = conv_wgrad_k1(x, dy, dw, d, s);
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
+  }
   if (e) return e;
   if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);
   return NC_OK;

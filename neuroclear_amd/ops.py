@@ -3,6 +3,7 @@ the autograd tape only -- every forward/backward below is one or more HIP kernel
 
 Each op mirrors the torch.nn call the reference makes on its hot path (models/networks.py, apollo_model.py); see the
 header for the file:line of every call site."""
+import ctypes
 import os
 
 import torch
@@ -12,14 +13,45 @@ from ._lib import F, I, L_, P, Z, check, lib
 
 _ws_cache = {}
 
-# Optional live profiler (bench.py): when `prof` is a list, every convolution C call is bracketed by HIP events on the
-# stream it is launched on and (tag, algorithmic FLOP, start, end) is appended.
+# Live profiler (bench.py).  Convolution launches are bracketed INSIDE the library (nc_prof_begin / nc_prof_end: HIP
+# events on the launch stream around every convolution entry point, also those issued by the whole-network calls);
+# `prof` additionally collects (tag, algorithmic FLOP, start, end) around the whole-network C calls themselves.
 prof = None
-prof_min_flop = 0.0  # launches below this many algorithmic FLOP are not bracketed (event cost ~ a small kernel's time)
+
+
+def prof_start(min_flop=0.0):
+    global prof
+    prof = []
+    lib().nc_prof_begin(ctypes.c_double(min_flop))
+
+
+_PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 'to1'}
+
+
+def prof_stop():
+    """-> ({tag: [launches, ms, flop]} of the convolution launches, [(tag, flop, ms)] of the whole-network calls).  The
+    caller has synchronised the device."""
+    global prof
+    L = lib()
+    cap = 1 << 16
+    cls, flop, ms = (ctypes.c_int * cap)(), (ctypes.c_double * cap)(), (ctypes.c_float * cap)()
+    n = min(L.nc_prof_end(I(cap), cls, flop, ms), cap)
+    stats = {}
+    for i in range(n):
+        c = cls[i]
+        op, path, k, lp = ('fwd', 'dgrad', 'wgrad')[c & 15], (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1
+        tag = '%s_lp_k%d' % (op, k) if lp else '%s_%s_k%d' % (op, _PATH.get(path, '?'), k)
+        s = stats.setdefault(tag, [0, 0.0, 0.0])
+        s[0] += 1
+        s[1] += ms[i]
+        s[2] += flop[i]
+    whole = [(tag, fl, e0.elapsed_time(e1)) for tag, fl, e0, e1 in (prof or [])]
+    prof = None
+    return stats, whole
 
 
 def _prof_begin(flop=None):
-    if prof is None or (flop is not None and flop < prof_min_flop):
+    if prof is None or flop is not None:  # per-convolution brackets live in the library
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record()
