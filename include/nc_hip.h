@@ -115,8 +115,8 @@ int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean
  * in the C8 operand layout (nc_to_c8) of the convolution that consumes it -- yh for the next layer's forward, dxh (the
  * gradient at the previous convolution's output) for its data / weight gradient -- which saves those conversion passes.
  * C % 8 == 0; dbias nullable (see nc_instnorm_act_bwd_dbias); workspace: nc_instnorm_bwd_dbias_ws_bytes. */
-int nc_instnorm_act_fwd_c8(const float* x, const float* mean, const float* rstd, float slope, float* y, void* yh, int N, int C,
-                           long S, int dtype, void* stream);
+int nc_instnorm_act_fwd_c8(const float* x, const float* mean, const float* rstd, float slope, float* y /* or NULL */, void* yh,
+                           int N, int C, long S, int dtype, void* stream);
 int nc_instnorm_act_bwd_c8(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                            void* dxh, float* dbias /* or NULL */, int N, int C, long S, int dtype, void* ws, size_t ws_bytes,
                            void* stream);
@@ -243,6 +243,61 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
                        int S2, void* ws, size_t ws_bytes, void* stream);
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
                        int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- The 16-bit END-TO-END path (BASELINE.json configs[3]): operators between which activations and gradients exist in
+ *      HBM only as 16-bit "C8" tensors [N][C/8][S][8] (nc_to_c8's layout).  A tensor argument (ptr, ctot, c0) means
+ *      channels [c0, c0 + C) of a ctot-channel C8 buffer -- halves of the skip concat buffers (networks.py:526,531) are
+ *      read / written in place.  Gradient tensors are bf16.  Statistics: fp32 per-thread partials, fp64 reduction.
+ *      nc_conv_fwd_c8 / nc_conv_dgrad_c8: nc_conv_fwd_lp / nc_conv_dgrad_lp with a C8 result (rounded to dtype);
+ *      nc_c8_instnorm_*: InstanceNorm3d(affine=False) + ReLU / LeakyReLU (networks.py:33-34,422-423) and its backward
+ *      (g = gradient at the activation output, xh = raw convolution output; dbias nullable = sum of dx per channel);
+ *      nc_c8_maxpool2_*: MaxPool3d(2) (networks.py:491,494), backward fused with the add of the skip gradient;
+ *      nc_convT_k2s2_*_c8: ConvTranspose3d(k 2, s 2) (networks.py:500,503) on the 16-bit matrix cores (C, K % 32 == 0);
+ *      nc_from_c8: C8 -> fp32 NCDHW.                                                                                   */
+int nc_conv_fwd_c8(const void* xh, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int C, int D, int H,
+                   int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_dgrad_c8(const void* dyh, const float* w, void* dxh, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw,
+                     int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+size_t nc_c8_instnorm_ws_bytes(int N, int C, long S);
+int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,
+                         size_t ws_bytes, void* stream);
+int nc_c8_instnorm_act_fwd(const void* xh, const float* mean, const float* rstd, float slope, void* yh, int out_ctot, int out_c0,
+                           int N, int C, long S, int dtype, void* stream);
+int nc_c8_instnorm_act_bwd(const void* gh, int g_ctot, int g_c0, const void* xh, const float* mean, const float* rstd, float slope,
+                           void* dxh, float* dbias /* or NULL */, int N, int C, long S, int dtype, void* ws, size_t ws_bytes,
+                           void* stream);
+int nc_c8_maxpool2_fwd(const void* xh, int x_ctot, int x_c0, void* yh, int N, int C, int D, int H, int W, int dtype, void* stream);
+int nc_c8_maxpool2_bwd_add(const void* dph, const void* xh, int x_ctot, int x_c0, const void* skiph, int s_ctot, int s_c0, void* dxh,
+                           int N, int C, int D, int H, int W, int dtype, void* stream);
+int nc_from_c8(const void* xh, int x_ctot, int x_c0, float* y, int N, int C, long S, int dtype, void* stream);
+size_t nc_convT_c8_ws_bytes(int N, int C, int D, int H, int W, int K);
+int nc_convT_k2s2_fwd_c8(const void* xh, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int C, int D,
+                         int H, int W, int K, int dtype, void* ws, size_t ws_bytes, void* stream);
+int nc_convT_k2s2_dgrad_c8(const void* dyh, int dy_ctot, int dy_c0, const float* w, void* dxh, int N, int C, int D, int H, int W, int K,
+                           void* ws, size_t ws_bytes, void* stream);
+int nc_convT_k2s2_wgrad_c8(const void* xh, const void* dyh, int dy_ctot, int dy_c0, float* dw, float* dbias /* or NULL */, int N,
+                           int C, int D, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Whole-network training passes of the generators on that path (dtype = NC_DT_BF16): same contract as
+ *      nc_unet_deconv_train_fwd / _bwd and nc_deep_linear_fwd / _bwd, `saved` in bytes.  The one-channel first layers
+ *      (3^3 of the U-Net, 7^3 of deep_linear_gen), statistics, weight gradients and the pointwise heads' sums stay fp32;
+ *      deep_linear_gen's bias-free linear tail 64 -> 32 -> 16 -> 1 (networks.py:903-911) is evaluated as the single
+ *      64-vector W6 W5 W4 and its weight gradients as the rank-1 products they are.  *_supported: every layer's shape is
+ *      covered by the 16-bit kernels (otherwise callers use the layer-by-layer 16-bit path).                         */
+int nc_unet_deconv_lp_supported(int N, int S0, int S1, int S2, int dtype);
+size_t nc_unet_deconv_lp_saved_bytes(int N, int S0, int S1, int S2);
+size_t nc_unet_deconv_lp_ws_bytes(int N, int S0, int S1, int S2);
+int nc_unet_deconv_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
+                          void* ws, size_t ws_bytes, void* stream);
+int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, const void* saved, const float* dy, float* dx,
+                          float* dparams, int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream);
+int nc_deep_linear_lp_supported(int N, int S0, int S1, int S2, int dtype);
+size_t nc_deep_linear_lp_saved_bytes(int N, int S0, int S1, int S2);
+size_t nc_deep_linear_lp_ws_bytes(int N, int S0, int S1, int S2);
+int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
+                          void* ws, size_t ws_bytes, void* stream);
+int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved, const float* dy, float* dx, float* dparams,
+                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

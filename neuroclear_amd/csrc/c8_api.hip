@@ -1,0 +1,108 @@
+// extern "C" surface of the 16-bit end-to-end ("C8") operators: thin argument checks over c8_ops.hip / convt_h.hip /
+// conv_h.hip.  The whole-network entry points (gen_nets_lp.hip) call the same internals directly.
+#include "common.hpp"
+
+namespace nc {
+size_t c8_stats_ws_bytes(int N, int C, long S);
+int c8_instnorm_stats(const void* x, int N, int C, long S, float eps, float* mean, float* rstd, int dt, void* ws, size_t wsb, hipStream_t s);
+int c8_instnorm_apply(const void* x, const float* mean, const float* rstd, float slope, void* y, int ctot, int c0, int N, int C, long S, int dt, hipStream_t s);
+int c8_instnorm_bwd(const void* g, int gctot, int gc0, const void* x, const float* mean, const float* rstd, float slope, void* dx, float* dbias, int N, int C, long S, int dt, void* ws, size_t wsb, hipStream_t s);
+int c8_maxpool_fwd(const void* x, int ctot, int c0, void* y, int N, int C, int D, int H, int W, int dt, hipStream_t s);
+int c8_maxpool_bwd_add(const void* dp, const void* x, int ctot, int c0, const void* skip, int sctot, int sc0, void* dx, int N, int C, int D, int H, int W, int dt, hipStream_t s);
+int c8_to_f32(const void* x, int ctot, int c0, float* y, int N, int C, long S, int dt, hipStream_t s);
+bool convT_h_supported(int C, int K);
+size_t convT_h_ws_bytes(int N, int C, int D, int H, int W, int K);
+int convT_fwd_h(const void* x, const float* w, const float* bias, void* out, int octot, int oc0, int N, int C, int D, int H, int W, int K, int dt, void* ws, size_t wsb, hipStream_t s);
+int convT_dgrad_h(const void* dy, int dctot, int dc0, const float* w, void* dx, int N, int C, int D, int H, int W, int K, void* ws, size_t wsb, hipStream_t s);
+int convT_wgrad_h(const void* x, const void* dy, int dctot, int dc0, float* dw, float* dbias, int N, int C, int D, int H, int W, int K, void* ws, size_t wsb, hipStream_t s);
+}  // namespace nc
+
+using namespace nc;
+
+static bool dt_ok(int dt) { return dt == NC_DT_F16 || dt == NC_DT_BF16; }
+
+extern "C" {
+
+int nc_conv_fwd_c8(const void* xh, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int C, int D, int H,
+                   int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!xh || !w || !yh) { set_error("conv_fwd_c8: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("conv_fwd_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  ConvDims d;
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad) || !h_fwd_supported(d)) { set_error("conv_fwd_c8: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  if (out_ctot % 8 || out_c0 % 8 || out_c0 + K > out_ctot) { set_error("conv_fwd_c8: bad output channel range"); return NC_ERR_SHAPE; }
+  return conv_fwd_h_c8(xh, w, bias, yh, out_ctot, out_c0, d, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_dgrad_c8(const void* dyh, const float* w, void* dxh, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw,
+                     int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!dyh || !w || !dxh) { set_error("conv_dgrad_c8: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("conv_dgrad_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  ConvDims d;
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad) || !h_dgrad_supported(d)) { set_error("conv_dgrad_c8: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  return conv_dgrad_h_c8(dyh, w, dxh, C, 0, d, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t nc_c8_instnorm_ws_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : c8_stats_ws_bytes(N, C, S); }
+
+int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!xh || !mean || !rstd) { set_error("c8_instnorm_stats: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("c8_instnorm_stats: bad dtype"); return NC_ERR_ARG; }
+  return c8_instnorm_stats(xh, N, C, S, eps, mean, rstd, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_c8_instnorm_act_fwd(const void* xh, const float* mean, const float* rstd, float slope, void* yh, int out_ctot, int out_c0,
+                           int N, int C, long S, int dtype, void* stream) {
+  if (!xh || !mean || !rstd || !yh) { set_error("c8_instnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype) || N < 1 || S < 1) { set_error("c8_instnorm_act_fwd: bad dtype / shape"); return NC_ERR_ARG; }
+  return c8_instnorm_apply(xh, mean, rstd, slope, yh, out_ctot, out_c0, N, C, S, dtype, (hipStream_t)stream);
+}
+
+int nc_c8_instnorm_act_bwd(const void* gh, int g_ctot, int g_c0, const void* xh, const float* mean, const float* rstd, float slope,
+                           void* dxh, float* dbias, int N, int C, long S, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!gh || !xh || !mean || !rstd || !dxh) { set_error("c8_instnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype) || N < 1 || S < 1) { set_error("c8_instnorm_act_bwd: bad dtype / shape"); return NC_ERR_ARG; }
+  return c8_instnorm_bwd(gh, g_ctot, g_c0, xh, mean, rstd, slope, dxh, dbias, N, C, S, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_c8_maxpool2_fwd(const void* xh, int x_ctot, int x_c0, void* yh, int N, int C, int D, int H, int W, int dtype, void* stream) {
+  if (!xh || !yh) { set_error("c8_maxpool2_fwd: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("c8_maxpool2_fwd: bad dtype"); return NC_ERR_ARG; }
+  return c8_maxpool_fwd(xh, x_ctot, x_c0, yh, N, C, D, H, W, dtype, (hipStream_t)stream);
+}
+
+int nc_c8_maxpool2_bwd_add(const void* dph, const void* xh, int x_ctot, int x_c0, const void* skiph, int s_ctot, int s_c0, void* dxh,
+                           int N, int C, int D, int H, int W, int dtype, void* stream) {
+  if (!dph || !xh || !skiph || !dxh) { set_error("c8_maxpool2_bwd_add: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("c8_maxpool2_bwd_add: bad dtype"); return NC_ERR_ARG; }
+  return c8_maxpool_bwd_add(dph, xh, x_ctot, x_c0, skiph, s_ctot, s_c0, dxh, N, C, D, H, W, dtype, (hipStream_t)stream);
+}
+
+int nc_from_c8(const void* xh, int x_ctot, int x_c0, float* y, int N, int C, long S, int dtype, void* stream) {
+  if (!xh || !y) { set_error("from_c8: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype) || N < 1 || S < 1) { set_error("from_c8: bad dtype / shape"); return NC_ERR_ARG; }
+  return c8_to_f32(xh, x_ctot, x_c0, y, N, C, S, dtype, (hipStream_t)stream);
+}
+
+size_t nc_convT_c8_ws_bytes(int N, int C, int D, int H, int W, int K) { return convT_h_supported(C, K) ? convT_h_ws_bytes(N, C, D, H, W, K) : 0; }
+
+int nc_convT_k2s2_fwd_c8(const void* xh, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int C, int D,
+                         int H, int W, int K, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!xh || !w || !yh) { set_error("convT_k2s2_fwd_c8: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("convT_k2s2_fwd_c8: bad dtype"); return NC_ERR_ARG; }
+  return convT_fwd_h(xh, w, bias, yh, out_ctot, out_c0, N, C, D, H, W, K, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_convT_k2s2_dgrad_c8(const void* dyh, int dy_ctot, int dy_c0, const float* w, void* dxh, int N, int C, int D, int H, int W, int K,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (!dyh || !w || !dxh) { set_error("convT_k2s2_dgrad_c8: null pointer"); return NC_ERR_ARG; }
+  return convT_dgrad_h(dyh, dy_ctot, dy_c0, w, dxh, N, C, D, H, W, K, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_convT_k2s2_wgrad_c8(const void* xh, const void* dyh, int dy_ctot, int dy_c0, float* dw, float* dbias, int N, int C, int D, int H,
+                           int W, int K, void* ws, size_t ws_bytes, void* stream) {
+  if (!xh || !dyh || !dw) { set_error("convT_k2s2_wgrad_c8: null pointer"); return NC_ERR_ARG; }
+  return convT_wgrad_h(xh, dyh, dy_ctot, dy_c0, dw, dbias, N, C, D, H, W, K, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

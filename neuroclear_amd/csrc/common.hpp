@@ -112,6 +112,10 @@ int conv_dgrad_h(const float* dy, const void* dyh, const float* w, float* dx, co
                  size_t wsb, hipStream_t s);
 int conv_wgrad_h(const float* x, const void* xh, const float* dy, const void* dyh, float* dw, const ConvDims& d, int dt,
                  void* ws, size_t wsb, hipStream_t s);
+int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int ctot, int c0, const ConvDims& d, int dt,
+                  void* ws, size_t wsb, hipStream_t s);
+int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
+                    size_t wsb, hipStream_t s);
 
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;

@@ -132,7 +132,9 @@ struct HParams {
   const uint4* xh;    // C8 input
   const uint4* wp;    // packed weights
   const float* bias;  // nullable
-  float* y;           // fp32 NCDHW output
+  float* y;           // fp32 NCDHW output, or
+  uint2* yh;          // (non-null) 16-bit C8 output [N][ctot/8][S][8], this call's K channels starting at channel c0
+  int ctot, c0;
   const uint4* zeros; // >= 16 B of zeros in global memory
   int N, NCH, D, H, W, K;  // NCH = C / 16
   int P, R, RP;       // row pitch (units), brick rows, R * P
@@ -348,6 +350,38 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
       ++g;
     }
 
+    // ---- epilogue, C8 form: a lane holds channels 4h..4h+3 of four 8-channel blocks per 32-channel half, i.e. one
+    //      8-byte half of a 16-byte unit; lanes (r, 0) and (r, 1) complete the unit of position r, consecutive r are
+    //      consecutive units: a store instruction covers 512 contiguous bytes
+    if (p.yh) {
+      const int cob = cur.cot * 64;
+      uint2* yb = p.yh + (((long)cur.n * (p.ctot >> 3) + ((p.c0 + cob) >> 3)) * S + (long)cur.z * HW) * 2 + h;
+      long yo[VB];
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        const unsigned f = (unsigned)(cur.q0 + qb + v * 32);
+        const unsigned yy = fdiv(f, p.mP);
+        const unsigned xx = f - yy * p.P;
+        yo[v] = ((int)yy < p.H && (int)xx < p.W) ? (long)yy * p.W + xx : -1;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VB; ++v)
+          if (yo[v] >= 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              uint2 o;
+              o.x = cvt16<DT>(acc[a][v][4 * g4] + bv[4 * g4]) | ((unsigned)cvt16<DT>(acc[a][v][4 * g4 + 1] + bv[4 * g4 + 1]) << 16);
+              o.y = cvt16<DT>(acc[a][v][4 * g4 + 2] + bv[4 * g4 + 2]) | ((unsigned)cvt16<DT>(acc[a][v][4 * g4 + 3] + bv[4 * g4 + 3]) << 16);
+              yb[((long)(a * 4 + g4) * S + yo[v]) * 2] = o;
+            }
+          }
+      }
+    } else
     // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
     if (!(p.ablate & 1)) {
       const int cob = cur.cot * 64;
@@ -458,7 +492,8 @@ int launch_h_vb(int VB, const HParams& p, int lds, hipStream_t s) {
 // x: fp32 [N][Cin][D][H][W]; w: fp32 master weights; y: fp32 [N][Kout][D][H][W].  so/si/flip: see k_pack_w_h.
 template <int DT>
 int run_h(const float* x, const void* xh_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin,
-          int Kout, long so, long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+          int Kout, long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* yh = nullptr, int ctot = 0,
+          int c0 = 0) {
   const int KS = d.kd, T3 = KS * KS * KS;
   const HPlan pl = h_plan(d);
   const long S = (long)d.D * d.H * d.W;
@@ -483,6 +518,7 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   if (int e = check_launch("pack_w_h")) return e;
   HParams p{};
   p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
+  p.yh = (uint2*)yh; p.ctot = yh ? ctot : Kout; p.c0 = c0;
   p.N = d.N; p.NCH = KS == 5 ? Cin / 8 : Cin / 16; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
   p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.mP = magic(pl.P); p.mRP = magic(pl.RP);
@@ -849,6 +885,22 @@ int conv_fwd_h(const float* x, const void* xh, const float* w, const float* b, f
   const long T3 = (long)d.kd * d.kh * d.kw;
   if (dt == NC_DT_F16) return run_h<NC_DT_F16>(x, xh, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
   return run_h<NC_DT_BF16>(x, xh, w, b, y, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s);
+}
+
+// C8 in -> C8 out (the 16-bit end-to-end path): yh / dxh receive the result rounded to `dt`, as channels
+// [c0, c0 + K) of a [N][ctot/8][S][8] tensor (a half of a concat buffer, or ctot = K, c0 = 0 for a dense one)
+int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int ctot, int c0, const ConvDims& d, int dt,
+                  void* ws, size_t wsb, hipStream_t s) {
+  const long T3 = (long)d.kd * d.kh * d.kw;
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
+  return run_h<NC_DT_BF16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
+}
+
+int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
+                    size_t wsb, hipStream_t s) {
+  const long T3 = (long)d.kd * d.kh * d.kw;
+  if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
+  return run_h<NC_DT_BF16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
 }
 
 int conv_dgrad_h(const float* dy, const void* dyh, const float* w, float* dx, const ConvDims& d, int dt, void* ws,

@@ -1,0 +1,373 @@
+// ConvTranspose3d(kernel 2, stride 2) on the 16-bit matrix cores, C8 in -> C8 out (reference models/networks.py:500,503:
+// t_conv2 256 -> 128 at the quarter level, t_conv1 128 -> 64 at the half level; backward = autograd of the same call).
+// A k2 / s2 transposed convolution has no overlapping taps: every fine voxel (2z+a, 2y+b, 2x+c) receives exactly one
+// product per input channel, so each of the 8 sub-positions t = (a, b, c) is a plain [K x C] x [C x voxels] GEMM.
+//   forward : out[k][fine(v, t)] = bias[k] + sum_ci w[ci][k][t] x[ci][v]        M = k,  N = coarse voxels, K-dim = ci
+//   dgrad   : dx[ci][v]          = sum_(k, t) w[ci][k][t] dy[k][fine(v, t)]     M = ci, N = coarse voxels, K-dim = (t, k)
+//   wgrad   : dw[ci][k][t]       = sum_(n, v) x[ci][v] dy[k][fine(v, t)]        M = ci, N = k,             K-dim = voxels
+// In the C8 layout a voxel's 8 channels are one 16-byte unit, which IS the B fragment of v_mfma_f32_32x32x16 when the
+// K-dim is channels (lane (r, h) = voxel r, channels 8h..8h+7): forward and dgrad load their B operand straight from
+// global memory, one unit per lane, no LDS; the packed weights (<= 1 MiB) come from L1 / L2.  The weight gradient
+// reduces over voxels, i.e. needs both operands voxel-major: its fragments are gathered with 2-byte loads (FLOP are
+// ~0.3 % of the step; the gather keeps the matrix pipe ~half busy, which is plenty).  All three are HBM-bound or small.
+#include "common.hpp"
+
+namespace nc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(const i32x4& a, const i32x4& b, const f32x16& c) {
+  if constexpr (DT == NC_DT_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ unsigned short cvt16(float f) {
+  if constexpr (DT == NC_DT_F16) {
+    const _Float16 v = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  } else {
+    const __bf16 v = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, v);
+  }
+}
+
+// packed forward weights:  wp[t][kt = k/32][chunk = ci/16][h][r = k%32][8]  element j = input channel chunk*16 + 8h + j
+// packed dgrad weights:    wp[t][ct = ci/32][chunk = k/16][h][r = ci%32][8] element j = output channel chunk*16 + 8h + j
+template <int DT>
+__global__ void __launch_bounds__(256) k_pack_wT(const float* __restrict__ w, unsigned short* __restrict__ wp, int C, int K, int dgrad,
+                                                 long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int r = (int)(q & 31); q >>= 5;
+  const int h = (int)(q & 1); q >>= 1;
+  const int RT = dgrad ? C / 32 : K / 32, NCH = dgrad ? K / 16 : C / 16;
+  const int chunk = (int)(q % NCH); q /= NCH;
+  const int rt = (int)(q % RT);
+  const int t = (int)(q / RT);
+  const int row = rt * 32 + r, red = chunk * 16 + 8 * h + j;
+  const int ci = dgrad ? row : red, k = dgrad ? red : row;
+  wp[i] = cvt16<DT>(w[((long)ci * K + k) * 8 + t]);
+}
+
+struct TParams {
+  const uint4* x;      // C8 operand with channels on the K-dim (fwd: x dense; dgrad: dy view)
+  const uint4* wp;
+  const float* bias;
+  uint2* out;          // C8 output (fwd: view; dgrad: dense)
+  int N, C, K;
+  int Dc, Hc, Wc;      // coarse spatial size
+  int xctot8, xc08;    // view of the K-dim operand
+  int octot8, oc08;    // view of the output
+  long Sc;
+};
+
+// forward: block = 4 waves = 4 tiles of 32 coarse voxels; blockIdx.y = 32-channel output tile
+template <int DT>
+__global__ void __launch_bounds__(256) k_convT_fwd_h(const TParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int kt = blockIdx.y, NCH = p.C / 16, KT = p.K / 32;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const long tiles_per_n = (p.Sc + 31) / 32;
+  if (tile >= tiles_per_n * p.N) return;
+  const int n = (int)(tile / tiles_per_n);
+  const long v0 = (tile - (long)n * tiles_per_n) * 32;
+  const long v = v0 + r;
+  const bool ok = v < p.Sc;
+  const long vc = ok ? v : p.Sc - 1;
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const uint4* xb = p.x + ((long)n * p.xctot8 + p.xc08) * p.Sc + vc;
+  const uint4* wb = p.wp + ((long)kt * NCH * 2 + h) * 32 + r;
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    const i32x4 b = __builtin_bit_cast(i32x4, xb[(long)(chunk * 2 + h) * p.Sc]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const i32x4 a = __builtin_bit_cast(i32x4, wb[((long)t * KT * NCH + chunk) * 64]);
+      acc[t] = mfma16<DT>(a, b, acc[t]);
+    }
+  }
+  if (!ok) return;
+  const int xw = (int)(v % p.Wc), yh = (int)((v / p.Wc) % p.Hc), zd = (int)(v / ((long)p.Wc * p.Hc));
+  const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+  const long Sf = 8 * p.Sc;
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+  uint2* ob = p.out + (((long)n * p.octot8 + p.oc08 + kt * 4) * Sf) * 2 + h;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const long vf = ((long)(2 * zd + (t >> 2)) * Hf + (2 * yh + ((t >> 1) & 1))) * Wf + 2 * xw + (t & 1);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 o;
+      o.x = cvt16<DT>(acc[t][4 * g4] + bv[4 * g4]) | ((unsigned)cvt16<DT>(acc[t][4 * g4 + 1] + bv[4 * g4 + 1]) << 16);
+      o.y = cvt16<DT>(acc[t][4 * g4 + 2] + bv[4 * g4 + 2]) | ((unsigned)cvt16<DT>(acc[t][4 * g4 + 3] + bv[4 * g4 + 3]) << 16);
+      ob[((long)g4 * Sf + vf) * 2] = o;
+    }
+  }
+}
+
+// dgrad: wave = 32 coarse voxels x CTW 32-channel tiles of ci; K-dim = (t, k)
+template <int DT, int CTW>
+__global__ void __launch_bounds__(256) k_convT_dgrad_h(const TParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int ct0 = blockIdx.y * CTW, NCH = p.K / 16, CT = p.C / 32;
+  const long tile = (long)blockIdx.x * 4 + wave;
+  const long tiles_per_n = (p.Sc + 31) / 32;
+  if (tile >= tiles_per_n * p.N) return;
+  const int n = (int)(tile / tiles_per_n);
+  const long v = (tile - (long)n * tiles_per_n) * 32 + r;
+  const bool ok = v < p.Sc;
+  const long vc = ok ? v : p.Sc - 1;
+  const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
+  const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+  const long Sf = 8 * p.Sc;
+  f32x16 acc[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+  const uint4* yb = p.x + ((long)n * p.xctot8 + p.xc08) * Sf;
+#pragma unroll 1
+  for (int t = 0; t < 8; ++t) {
+    const long vf = ((long)(2 * zd + (t >> 2)) * Hf + (2 * yh + ((t >> 1) & 1))) * Wf + 2 * xw + (t & 1);
+    const uint4* wb = p.wp + (((long)t * CT + ct0) * NCH * 2 + h) * 32 + r;
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      const i32x4 b = __builtin_bit_cast(i32x4, yb[(long)(chunk * 2 + h) * Sf + vf]);
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const i32x4 a = __builtin_bit_cast(i32x4, wb[((long)c * NCH + chunk) * 64]);
+        acc[c] = mfma16<DT>(a, b, acc[c]);
+      }
+    }
+  }
+  if (!ok) return;
+  uint2* ob = p.out + (((long)n * p.octot8 + p.oc08 + ct0 * 4) * p.Sc + v) * 2 + h;
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 o;
+      o.x = cvt16<DT>(acc[c][4 * g4]) | ((unsigned)cvt16<DT>(acc[c][4 * g4 + 1]) << 16);
+      o.y = cvt16<DT>(acc[c][4 * g4 + 2]) | ((unsigned)cvt16<DT>(acc[c][4 * g4 + 3]) << 16);
+      ob[(long)(c * 4 + g4) * p.Sc * 2] = o;
+    }
+}
+
+struct TWParams {
+  const unsigned short* x;   // dense C8 [N][C/8][Sc][8]
+  const unsigned short* dy;  // view of a C8 buffer at the fine size: channels [c0, c0 + K) of ctot
+  float* part;               // [splits][C][K][8]
+  int N, C, K, Dc, Hc, Wc, dctot8, dc08, splits;
+  long Sc;
+};
+
+// wgrad: wave = (ct, kt) tile of 32 x 32 for all 8 sub-positions, over a contiguous share of the 16-voxel steps
+template <int DT>
+__global__ void __launch_bounds__(64) k_convT_wgrad_h(const TWParams p) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int KT = p.K / 32;
+  const int kt = blockIdx.x % KT, ct = blockIdx.x / KT, split = blockIdx.y;
+  const long steps_per_n = (p.Sc + 15) / 16, steps = steps_per_n * p.N;
+  const long s_lo = steps * split / p.splits, s_hi = steps * (split + 1) / p.splits;
+  const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+  const long Sf = 8 * p.Sc;
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const int ci = ct * 32 + r, k = kt * 32 + r;
+  for (long st = s_lo; st < s_hi; ++st) {
+    const int n = (int)(st / steps_per_n);
+    const long v0 = (st - (long)n * steps_per_n) * 16 + 8 * h;
+    const unsigned short* xs = p.x + (((long)n * (p.C >> 3) + (ci >> 3)) * p.Sc) * 8 + (ci & 7);
+    const unsigned short* ys = p.dy + (((long)n * p.dctot8 + p.dc08 + (k >> 3)) * Sf) * 8 + (k & 7);
+    unsigned short av[8];
+    long vf[8];
+    bool okv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long v = v0 + j;
+      okv[j] = v < p.Sc;
+      const long vc = okv[j] ? v : p.Sc - 1;
+      av[j] = okv[j] ? xs[vc * 8] : (unsigned short)0;
+      const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
+      vf[j] = ((long)(2 * zd) * Hf + 2 * yh) * Wf + 2 * xw;
+    }
+    i32x4 a;
+    a[0] = av[0] | ((unsigned)av[1] << 16); a[1] = av[2] | ((unsigned)av[3] << 16);
+    a[2] = av[4] | ((unsigned)av[5] << 16); a[3] = av[6] | ((unsigned)av[7] << 16);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long to = ((long)(t >> 2) * Hf + ((t >> 1) & 1)) * Wf + (t & 1);
+      unsigned short bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = okv[j] ? ys[(vf[j] + to) * 8] : (unsigned short)0;
+      i32x4 b;
+      b[0] = bv[0] | ((unsigned)bv[1] << 16); b[1] = bv[2] | ((unsigned)bv[3] << 16);
+      b[2] = bv[4] | ((unsigned)bv[5] << 16); b[3] = bv[6] | ((unsigned)bv[7] << 16);
+      acc[t] = mfma16<DT>(a, b, acc[t]);
+    }
+  }
+  // rows = ci, lanes = k: part[split][ci][k][t]
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      p.part[(((long)split * p.C + row) * p.K + kt * 32 + r) * 8 + t] = acc[t][e];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_convT_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < splits; ++s) a += part[(long)s * n + i];
+  dw[i] = a;
+}
+
+// per-channel sum of a C8 view over samples and voxels (the transposed convolution's bias gradient)
+template <int DT>
+__global__ void __launch_bounds__(256) k_chan_sum_c8(const uint4* __restrict__ x, int ctot8, int c08, int CB, long S, int splits,
+                                                     double* __restrict__ part) {
+  __shared__ double lds[4 * 8];
+  const int ncb = blockIdx.y, n = ncb / CB, cb = ncb - n * CB, split = blockIdx.x;
+  const long lo = S * split / splits, hi = S * (split + 1) / splits;
+  const uint4* xs = x + ((long)n * ctot8 + c08 + cb) * S;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long v = lo + threadIdx.x; v < hi; v += 256) {
+    const uint4 u = xs[v];
+    const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned short hv = (unsigned short)((uu[j >> 1] >> ((j & 1) * 16)) & 0xffff);
+      s[j] += DT == NC_DT_F16 ? (float)__builtin_bit_cast(_Float16, hv) : __builtin_bit_cast(float, (unsigned)hv << 16);
+    }
+  }
+  double d[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double a = s[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    d[j] = a;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[wave * 8 + j] = d[j];
+  __syncthreads();
+  if (threadIdx.x < 8)
+    part[((long)ncb * splits + split) * 8 + threadIdx.x] = lds[threadIdx.x] + lds[8 + threadIdx.x] + lds[16 + threadIdx.x] + lds[24 + threadIdx.x];
+}
+
+__global__ void k_chan_sum_final(const double* __restrict__ part, int N, int C, int splits, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int CB = C >> 3, cb = c >> 3, j = c & 7;
+  double a = 0;
+  for (int n = 0; n < N; ++n)
+    for (int s = 0; s < splits; ++s) a += part[(((long)n * CB + cb) * splits + s) * 8 + j];
+  out[c] = (float)a;
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+int wgrad_splits(int C, int K) {
+  int s = 2048 / ((C / 32) * (K / 32));
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+bool convT_h_supported(int C, int K) { return C % 32 == 0 && K % 32 == 0 && C >= 32 && K >= 32; }
+
+size_t convT_h_ws_bytes(int N, int C, int D, int H, int W, int K) {
+  (void)D; (void)H; (void)W;
+  const size_t wpack = align256((size_t)C * K * 8 * 2);
+  const size_t part = align256((size_t)wgrad_splits(C, K) * C * K * 8 * sizeof(float));
+  const size_t bsum = align256((size_t)N * (K / 8) * 64 * 8 * sizeof(double));
+  return wpack + part + bsum + 256;
+}
+
+template <int DT>
+static int pack_T(const float* w, void* wp, int C, int K, int dgrad, hipStream_t s) {
+  const long total = (long)C * K * 8;
+  hipLaunchKernelGGL((k_pack_wT<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp, C, K, dgrad, total);
+  return check_launch("pack_wT");
+}
+
+// x: dense C8 [N][C/8][D*H*W][8]; out: channels [oc0, oc0 + K) of an octot-channel C8 buffer at (2D, 2H, 2W)
+int convT_fwd_h(const void* x, const float* w, const float* bias, void* out, int octot, int oc0, int N, int C, int D, int H, int W,
+                int K, int dt, void* ws, size_t wsb, hipStream_t s) {
+  if (!convT_h_supported(C, K) || octot % 8 || oc0 % 32 || oc0 + K > octot) { set_error("convT_fwd_h: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < convT_h_ws_bytes(N, C, D, H, W, K)) { set_error("convT_fwd_h: workspace too small"); return NC_ERR_WS; }
+  TParams p{};
+  p.x = (const uint4*)x; p.wp = (const uint4*)ws; p.bias = bias; p.out = (uint2*)out;
+  p.N = N; p.C = C; p.K = K; p.Dc = D; p.Hc = H; p.Wc = W; p.Sc = (long)D * H * W;
+  p.xctot8 = C / 8; p.xc08 = 0; p.octot8 = octot / 8; p.oc08 = oc0 / 8;
+  const unsigned gx = (unsigned)cdiv(cdiv(p.Sc, 32) * N, 4);
+  if (dt == NC_DT_F16) {
+    if (int e = pack_T<NC_DT_F16>(w, ws, C, K, 0, s)) return e;
+    hipLaunchKernelGGL((k_convT_fwd_h<NC_DT_F16>), dim3(gx, K / 32), dim3(256), 0, s, p);
+  } else {
+    if (int e = pack_T<NC_DT_BF16>(w, ws, C, K, 0, s)) return e;
+    hipLaunchKernelGGL((k_convT_fwd_h<NC_DT_BF16>), dim3(gx, K / 32), dim3(256), 0, s, p);
+  }
+  return check_launch("convT_fwd_h");
+}
+
+// dy: channels [dc0, dc0 + K) of a dctot-channel C8 buffer at (2D, 2H, 2W) (bf16); dx: dense C8 [N][C/8][D*H*W][8] (bf16)
+int convT_dgrad_h(const void* dy, int dctot, int dc0, const float* w, void* dx, int N, int C, int D, int H, int W, int K, void* ws,
+                  size_t wsb, hipStream_t s) {
+  if (!convT_h_supported(C, K) || dctot % 8 || dc0 % 8 || dc0 + K > dctot) { set_error("convT_dgrad_h: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < convT_h_ws_bytes(N, C, D, H, W, K)) { set_error("convT_dgrad_h: workspace too small"); return NC_ERR_WS; }
+  if (int e = pack_T<NC_DT_BF16>(w, ws, C, K, 1, s)) return e;
+  TParams p{};
+  p.x = (const uint4*)dy; p.wp = (const uint4*)ws; p.out = (uint2*)dx;
+  p.N = N; p.C = C; p.K = K; p.Dc = D; p.Hc = H; p.Wc = W; p.Sc = (long)D * H * W;
+  p.xctot8 = dctot / 8; p.xc08 = dc0 / 8; p.octot8 = C / 8; p.oc08 = 0;
+  const unsigned gx = (unsigned)cdiv(cdiv(p.Sc, 32) * N, 4);
+  if ((C / 32) % 4 == 0) hipLaunchKernelGGL((k_convT_dgrad_h<NC_DT_BF16, 4>), dim3(gx, C / 128), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((k_convT_dgrad_h<NC_DT_BF16, 1>), dim3(gx, C / 32), dim3(256), 0, s, p);
+  return check_launch("convT_dgrad_h");
+}
+
+// x: dense C8 (bf16); dy: view (bf16); dw fp32 [C][K][2][2][2]; dbias fp32 [K] (nullable)
+int convT_wgrad_h(const void* x, const void* dy, int dctot, int dc0, float* dw, float* dbias, int N, int C, int D, int H, int W,
+                  int K, void* ws, size_t wsb, hipStream_t s) {
+  if (!convT_h_supported(C, K) || dctot % 8 || dc0 % 8 || dc0 + K > dctot) { set_error("convT_wgrad_h: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < convT_h_ws_bytes(N, C, D, H, W, K)) { set_error("convT_wgrad_h: workspace too small"); return NC_ERR_WS; }
+  const int splits = wgrad_splits(C, K);
+  float* part = (float*)((char*)ws + align256((size_t)C * K * 8 * 2));
+  TWParams p{};
+  p.x = (const unsigned short*)x; p.dy = (const unsigned short*)dy; p.part = part;
+  p.N = N; p.C = C; p.K = K; p.Dc = D; p.Hc = H; p.Wc = W; p.dctot8 = dctot / 8; p.dc08 = dc0 / 8; p.splits = splits;
+  p.Sc = (long)D * H * W;
+  hipLaunchKernelGGL((k_convT_wgrad_h<NC_DT_BF16>), dim3((C / 32) * (K / 32), splits), dim3(64), 0, s, p);
+  const long n = (long)C * K * 8;
+  hipLaunchKernelGGL(k_convT_wgrad_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, part, dw, n, splits);
+  if (dbias) {
+    double* bp = (double*)((char*)part + align256((size_t)splits * C * K * 8 * sizeof(float)));
+    const long Sf = 8 * p.Sc;
+    hipLaunchKernelGGL((k_chan_sum_c8<NC_DT_BF16>), dim3(64, N * K / 8), dim3(256), 0, s, (const uint4*)dy, dctot / 8, dc0 / 8, K / 8, Sf,
+                       64, bp);
+    hipLaunchKernelGGL(k_chan_sum_final, dim3((unsigned)cdiv(K, 64)), dim3(64), 0, s, bp, N, K, 64, dbias);
+  }
+  return check_launch("convT_wgrad_h");
+}
+
+}  // namespace nc

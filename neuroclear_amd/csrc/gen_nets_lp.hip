@@ -1,0 +1,441 @@
+// 16-bit END-TO-END training passes of the two generators (BASELINE.json configs[3]: "fp16 MFMA path with fp32
+// InstanceNorm accumulate"), one C call per direction:
+//   Unet_deconv          reference models/networks.py:478-538
+//   DeepLinearGenerator  reference models/networks.py:893-917
+// Activations and their gradients live in HBM ONLY as 16-bit C8 tensors (conv_h.hip's operand layout): the convolution
+// epilogue writes C8, InstanceNorm statistics (fp32 / fp64 accumulation) and normalise + ReLU read and write C8
+// (c8_ops.hip), max-pool, the skip concats (written in place, no copy), the transposed convolutions (convt_h.hip) and
+// the 64 -> 1 head work on C8 -- the fp32 NCDHW store + conversion passes of the layer-by-layer 16-bit path are gone
+// (~8 GB instead of ~18 GB of HBM traffic per 64-channel full-resolution layer at 4 x 148^3).  Master weights, weight
+// gradients, statistics, the one-channel first layers (1 -> 64: 3^3 of the U-Net, 7^3 of deep_linear_gen), losses and
+// Adam stay fp32.  dtype: NC_DT_BF16 (operands and stored tensors bf16; gradients bf16).
+//
+// deep_linear_gen's pointwise tail 64 -> 32 -> 16 -> 1 has no bias and no activation: it IS a single 64-vector
+// w_eff = W6 W5 W4, and every weight gradient of the three layers is an outer product with q = sum_v dy[v] f3[:, v]
+// (one output channel => rank 1).  The tail is evaluated in that form (k_lin_tail_*): no 32- / 16-channel tensors exist.
+#include "common.hpp"
+
+namespace nc {
+// c8_ops.hip
+size_t c8_stats_ws_bytes(int N, int C, long S);
+int c8_instnorm_stats(const void* x, int N, int C, long S, float eps, float* mean, float* rstd, int dt, void* ws, size_t wsb, hipStream_t s);
+int c8_instnorm_apply(const void* x, const float* mean, const float* rstd, float slope, void* y, int ctot, int c0, int N, int C, long S, int dt, hipStream_t s);
+int c8_instnorm_bwd(const void* g, int gctot, int gc0, const void* x, const float* mean, const float* rstd, float slope, void* dx, float* dbias, int N, int C, long S, int dt, void* ws, size_t wsb, hipStream_t s);
+int c8_maxpool_fwd(const void* x, int ctot, int c0, void* y, int N, int C, int D, int H, int W, int dt, hipStream_t s);
+int c8_maxpool_bwd_add(const void* dp, const void* x, int ctot, int c0, const void* skip, int sctot, int sc0, void* dx, int N, int C, int D, int H, int W, int dt, hipStream_t s);
+int c8_to_f32(const void* x, int ctot, int c0, float* y, int N, int C, long S, int dt, hipStream_t s);
+int c8_dot64(const void* x, const float* w, const float* bias, float* out, int N, long S, int dt, hipStream_t s);
+size_t c8_outer64_ws_bytes(int N, long S);
+int c8_outer64(const float* g, const void* x, const float* w, void* dx, float* dw, float* db, int N, long S, int dt, void* ws, size_t wsb, hipStream_t s);
+// convt_h.hip
+bool convT_h_supported(int C, int K);
+size_t convT_h_ws_bytes(int N, int C, int D, int H, int W, int K);
+int convT_fwd_h(const void* x, const float* w, const float* bias, void* out, int octot, int oc0, int N, int C, int D, int H, int W, int K, int dt, void* ws, size_t wsb, hipStream_t s);
+int convT_dgrad_h(const void* dy, int dctot, int dc0, const float* w, void* dx, int N, int C, int D, int H, int W, int K, void* ws, size_t wsb, hipStream_t s);
+int convT_wgrad_h(const void* x, const void* dy, int dctot, int dc0, float* dw, float* dbias, int N, int C, int D, int H, int W, int K, void* ws, size_t wsb, hipStream_t s);
+}  // namespace nc
+
+using namespace nc;
+
+#define NC_TRY(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
+
+namespace {
+
+size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct UBlock { int C, K, lvl; };
+const UBlock kUB[10] = {{1, 64, 0},    {64, 64, 0},    {64, 128, 1},  {128, 128, 1}, {128, 256, 2},
+                        {256, 256, 2}, {256, 256, 2}, {256, 128, 1}, {128, 128, 1}, {128, 64, 0}};
+
+struct UOff { size_t w[14], b[14], total; };
+UOff u_offsets() {
+  struct L { int id; size_t wn, bn; };
+  const L order[14] = {{0, 64 * 1 * 27, 64},     {1, 64 * 64 * 27, 64},    {2, 128 * 64 * 27, 128},  {3, 128 * 128 * 27, 128},
+                       {4, 256 * 128 * 27, 256}, {5, 256 * 256 * 27, 256}, {6, 256 * 256 * 27, 256}, {10, 256 * 128 * 8, 128},
+                       {7, 128 * 256 * 27, 128}, {8, 128 * 128 * 27, 128}, {11, 128 * 64 * 8, 64},   {9, 64 * 128 * 27, 64},
+                       {12, 64, 1},              {13, 1, 1}};
+  UOff o{};
+  size_t off = 0;
+  for (const L& l : order) {
+    o.w[l.id] = off; off += l.wn;
+    o.b[l.id] = off; off += l.bn;
+  }
+  o.total = off;
+  return o;
+}
+
+// byte offsets into `saved` / the backward scratch
+struct ULp {
+  int N, d[3][3];
+  long S[3];
+  size_t raw0, a1, cat1, p1, a2, cat2, p2, b1, b2, b3, e2a, e2b, e1, t1, raw[10], mean[10], rstd[10], saved;
+  size_t G1, G2, G3, H1, H2, H3, Q1, Q2, s1, s2, F1, F2, grads;
+  size_t conv_ws, in_ws, c8_ws, convT_ws, o64_ws, f32conv_ws;
+  bool ok;
+};
+
+bool ulp_plan(ULp& p, int N, int S0, int S1, int S2) {
+  p = ULp{};
+  if (N < 1 || S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return false;
+  p.N = N;
+  for (int l = 0; l < 3; ++l) {
+    p.d[l][0] = S0 >> l; p.d[l][1] = S1 >> l; p.d[l][2] = S2 >> l;
+    p.S[l] = (long)p.d[l][0] * p.d[l][1] * p.d[l][2];
+  }
+  const size_t n = (size_t)N, S = (size_t)p.S[0], Sh = (size_t)p.S[1], Sq = (size_t)p.S[2];
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes); return r; };
+  p.raw0 = take(n * 64 * S * 4);
+  p.a1 = take(n * 64 * S * 2); p.cat1 = take(n * 128 * S * 2); p.p1 = take(n * 64 * Sh * 2); p.a2 = take(n * 128 * Sh * 2);
+  p.cat2 = take(n * 256 * Sh * 2); p.p2 = take(n * 128 * Sq * 2); p.b1 = take(n * 256 * Sq * 2); p.b2 = take(n * 256 * Sq * 2);
+  p.b3 = take(n * 256 * Sq * 2); p.e2a = take(n * 128 * Sh * 2); p.e2b = take(n * 128 * Sh * 2); p.e1 = take(n * 64 * S * 2);
+  p.t1 = take(n * S * 4);
+  for (int i = 0; i < 10; ++i) {
+    p.raw[i] = i == 0 ? p.raw0 : take(n * kUB[i].K * (size_t)p.S[kUB[i].lvl] * 2);
+    p.mean[i] = take(n * kUB[i].K * 4);
+    p.rstd[i] = take(n * kUB[i].K * 4);
+  }
+  p.saved = off;
+  off = 0;
+  p.G1 = take(n * 64 * S * 2); p.G2 = take(n * 64 * S * 2); p.G3 = take(n * 128 * S * 2);
+  p.H1 = take(n * 128 * Sh * 2); p.H2 = take(n * 128 * Sh * 2); p.H3 = take(n * 256 * Sh * 2);
+  p.Q1 = take(n * 256 * Sq * 2); p.Q2 = take(n * 256 * Sq * 2); p.s1 = take(n * S * 4); p.s2 = take(n * S * 4);
+  p.F1 = take(n * 64 * S * 4); p.F2 = take(n * 64 * S * 4);
+  p.grads = off;
+  p.ok = true;
+  for (int i = 1; i < 10; ++i) {
+    const int* d = p.d[kUB[i].lvl];
+    ConvDims cd;
+    if (!make_dims(cd, N, kUB[i].C, d[0], d[1], d[2], kUB[i].K, 3, 3, 3, 1, 1) || !h_fwd_supported(cd) || !h_dgrad_supported(cd) ||
+        !h_wgrad_supported(cd)) { p.ok = false; return true; }
+    const size_t b = h_ws_bytes(cd);
+    if (b > p.conv_ws) p.conv_ws = b;
+  }
+  p.f32conv_ws = nc_conv_ws_bytes(N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  const size_t t = nc_conv_ws_bytes(N, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0);
+  if (t > p.f32conv_ws) p.f32conv_ws = t;
+  p.in_ws = nc_instnorm_bwd_dbias_ws_bytes(N * 64, (long)S);
+  p.c8_ws = c8_stats_ws_bytes(N, 256, (long)S);
+  p.convT_ws = convT_h_ws_bytes(N, 256, p.d[2][0], p.d[2][1], p.d[2][2], 128);
+  const size_t c2 = convT_h_ws_bytes(N, 128, p.d[1][0], p.d[1][1], p.d[1][2], 64);
+  if (c2 > p.convT_ws) p.convT_ws = c2;
+  p.o64_ws = c8_outer64_ws_bytes(N, (long)S);
+  return true;
+}
+
+size_t ulp_ws_bytes(const ULp& p, bool bwd) {
+  return al(p.conv_ws) + al(p.f32conv_ws) + al(p.in_ws) + al(p.c8_ws) + al(p.convT_ws) + al(p.o64_ws) + (bwd ? p.grads : 0) + 256;
+}
+
+struct UWs { void *cws, *fws, *iws, *c8ws, *tws, *ows; char* G; };
+UWs ulp_ws(const ULp& p, void* ws) {
+  UWs u;
+  char* b = (char*)ws;
+  u.cws = b; b += al(p.conv_ws);
+  u.fws = b; b += al(p.f32conv_ws);
+  u.iws = b; b += al(p.in_ws);
+  u.c8ws = b; b += al(p.c8_ws);
+  u.tws = b; b += al(p.convT_ws);
+  u.ows = b; b += al(p.o64_ws);
+  u.G = b;
+  return u;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nc_unet_deconv_lp_supported(int N, int S0, int S1, int S2, int dtype) {
+  ULp p;
+  return dtype == NC_DT_BF16 && ulp_plan(p, N, S0, S1, S2) && p.ok;
+}
+
+size_t nc_unet_deconv_lp_saved_bytes(int N, int S0, int S1, int S2) {
+  ULp p;
+  return ulp_plan(p, N, S0, S1, S2) && p.ok ? p.saved : 0;
+}
+
+size_t nc_unet_deconv_lp_ws_bytes(int N, int S0, int S1, int S2) {
+  ULp p;
+  return ulp_plan(p, N, S0, S1, S2) && p.ok ? ulp_ws_bytes(p, true) : 0;
+}
+
+int nc_unet_deconv_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved) { set_error("unet_deconv_lp_fwd: null pointer"); return NC_ERR_ARG; }
+  if (dtype != NC_DT_BF16) { set_error("unet_deconv_lp_fwd: the 16-bit end-to-end path stores bf16 (dtype NC_DT_BF16)"); return NC_ERR_ARG; }
+  ULp p;
+  if (!ulp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("unet_deconv_lp_fwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < ulp_ws_bytes(p, false)) { set_error("unet_deconv_lp_fwd: workspace too small"); return NC_ERR_WS; }
+  const UOff o = u_offsets();
+  const UWs u = ulp_ws(p, ws);
+  hipStream_t hs = (hipStream_t)stream;
+  char* V = (char*)saved;
+  const float* P = params;
+  const int dt = dtype;
+  auto F = [&](size_t off) { return (float*)(V + off); };
+  // block i >= 1: conv (C8 -> C8 raw), statistics, normalise + ReLU into channels [c0, c0 + K) of an out buffer of ctot
+  auto block = [&](int i, const void* in, void* out, int ctot, int c0) -> int {
+    const UBlock& b = kUB[i];
+    const int* d = p.d[b.lvl];
+    const long S = p.S[b.lvl];
+    ConvDims cd;
+    make_dims(cd, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1);
+    NC_TRY(conv_fwd_h_c8(in, P + o.w[i], P + o.b[i], V + p.raw[i], b.K, 0, cd, dt, u.cws, p.conv_ws, hs));
+    NC_TRY(c8_instnorm_stats(V + p.raw[i], N, b.K, S, 1e-5f, F(p.mean[i]), F(p.rstd[i]), dt, u.c8ws, p.c8_ws, hs));
+    return c8_instnorm_apply(V + p.raw[i], F(p.mean[i]), F(p.rstd[i]), 0.f, out, ctot, c0, N, b.K, S, dt, hs);
+  };
+  const long S = p.S[0];
+  const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
+  // block 0 (1 -> 64 channels): the fp32 one-channel kernel, statistics in fp32, the activation leaves as C8
+  NC_TRY(nc_conv_fwd(x, P + o.w[0], P + o.b[0], F(p.raw0), N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream));
+  NC_TRY(nc_instnorm_stats(F(p.raw0), N * 64, S, 1e-5f, F(p.mean[0]), F(p.rstd[0]), u.iws, p.in_ws, stream));
+  NC_TRY(nc_instnorm_act_fwd_c8(F(p.raw0), F(p.mean[0]), F(p.rstd[0]), 0.f, nullptr, V + p.a1, N, 64, S, dt, stream));
+  NC_TRY(block(1, V + p.a1, V + p.cat1, 128, 0));
+  NC_TRY(c8_maxpool_fwd(V + p.cat1, 128, 0, V + p.p1, N, 64, d0[0], d0[1], d0[2], dt, hs));
+  NC_TRY(block(2, V + p.p1, V + p.a2, 128, 0));
+  NC_TRY(block(3, V + p.a2, V + p.cat2, 256, 0));
+  NC_TRY(c8_maxpool_fwd(V + p.cat2, 256, 0, V + p.p2, N, 128, d1[0], d1[1], d1[2], dt, hs));
+  NC_TRY(block(4, V + p.p2, V + p.b1, 256, 0));
+  NC_TRY(block(5, V + p.b1, V + p.b2, 256, 0));
+  NC_TRY(block(6, V + p.b2, V + p.b3, 256, 0));
+  NC_TRY(convT_fwd_h(V + p.b3, P + o.w[10], P + o.b[10], V + p.cat2, 256, 128, N, 256, d2[0], d2[1], d2[2], 128, dt, u.tws, p.convT_ws, hs));
+  NC_TRY(block(7, V + p.cat2, V + p.e2a, 128, 0));
+  NC_TRY(block(8, V + p.e2a, V + p.e2b, 128, 0));
+  NC_TRY(convT_fwd_h(V + p.e2b, P + o.w[11], P + o.b[11], V + p.cat1, 128, 64, N, 128, d1[0], d1[1], d1[2], 64, dt, u.tws, p.convT_ws, hs));
+  NC_TRY(block(9, V + p.cat1, V + p.e1, 64, 0));
+  // head: one_by_one (64 -> 1) on C8, one_by_one_2 (1 -> 1) + sigmoid in fp32
+  NC_TRY(c8_dot64(V + p.e1, P + o.w[12], P + o.b[12], F(p.t1), N, S, dt, hs));
+  NC_TRY(nc_conv_fwd(F(p.t1), P + o.w[13], P + o.b[13], y, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, u.fws, p.f32conv_ws, stream));
+  return nc_sigmoid_fwd(y, y, (long)N * S, stream);
+}
+
+int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, const void* saved, const float* dy, float* dx,
+                          float* dparams, int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved || !dy || !dparams) { set_error("unet_deconv_lp_bwd: null pointer"); return NC_ERR_ARG; }
+  if (dtype != NC_DT_BF16) { set_error("unet_deconv_lp_bwd: dtype must be NC_DT_BF16"); return NC_ERR_ARG; }
+  ULp p;
+  if (!ulp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("unet_deconv_lp_bwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < ulp_ws_bytes(p, true)) { set_error("unet_deconv_lp_bwd: workspace too small"); return NC_ERR_WS; }
+  const UOff o = u_offsets();
+  const UWs u = ulp_ws(p, ws);
+  hipStream_t hs = (hipStream_t)stream;
+  const char* V = (const char*)saved;
+  char* G = u.G;
+  const float* P = params;
+  float* DP = dparams;
+  const int dt = dtype;
+  auto F = [&](size_t off) { return (const float*)(V + off); };
+  const long S = p.S[0];
+  const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
+  // block i >= 1 backward: g = gradient at the block's output = channels [gc0, ..) of a gctot buffer; `in` = the block's
+  // (dense C8) input; draw <- InstanceNorm / ReLU backward (+ bias gradient); gin (nullable, dense C channels) <- dgrad
+  auto block_bwd = [&](int i, const void* g, int gctot, int gc0, const void* in, void* draw, void* gin) -> int {
+    const UBlock& b = kUB[i];
+    const int* d = p.d[b.lvl];
+    const long Sl = p.S[b.lvl];
+    ConvDims cd;
+    make_dims(cd, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1);
+    NC_TRY(c8_instnorm_bwd(g, gctot, gc0, V + p.raw[i], F(p.mean[i]), F(p.rstd[i]), 0.f, draw, DP + o.b[i], N, b.K, Sl, dt, u.c8ws,
+                           p.c8_ws, hs));
+    if (gin) NC_TRY(conv_dgrad_h_c8(draw, P + o.w[i], gin, b.C, 0, cd, NC_DT_BF16, u.cws, p.conv_ws, hs));
+    return conv_wgrad_h(nullptr, in, nullptr, draw, DP + o.w[i], cd, NC_DT_BF16, u.cws, p.conv_ws, hs);
+  };
+  // head
+  float* s1 = (float*)(G + p.s1);
+  float* s2 = (float*)(G + p.s2);
+  NC_TRY(nc_sigmoid_bwd(dy, y, s1, (long)N * S, stream));
+  NC_TRY(nc_conv_wgrad(F(p.t1), s1, DP + o.w[13], DP + o.b[13], N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, u.fws, p.f32conv_ws, stream));
+  NC_TRY(nc_conv_dgrad(s1, P + o.w[13], s2, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, u.fws, p.f32conv_ws, stream));
+  NC_TRY(c8_outer64(s2, V + p.e1, P + o.w[12], G + p.G1, DP + o.w[12], DP + o.b[12], N, S, dt, u.ows, p.o64_ws, hs));
+  // ex_conv1_1
+  NC_TRY(block_bwd(9, G + p.G1, 64, 0, V + p.cat1, G + p.G2, G + p.G3));
+  // t_conv1: its output is the second half of cat1, so its dy is channels [64, 128) of dcat1 (read in place)
+  NC_TRY(convT_dgrad_h(G + p.G3, 128, 64, P + o.w[11], G + p.H1, N, 128, d1[0], d1[1], d1[2], 64, u.tws, p.convT_ws, hs));
+  NC_TRY(convT_wgrad_h(V + p.e2b, G + p.G3, 128, 64, DP + o.w[11], DP + o.b[11], N, 128, d1[0], d1[1], d1[2], 64, u.tws, p.convT_ws, hs));
+  NC_TRY(block_bwd(8, G + p.H1, 128, 0, V + p.e2a, G + p.H2, G + p.H1));
+  NC_TRY(block_bwd(7, G + p.H1, 128, 0, V + p.cat2, G + p.H2, G + p.H3));
+  NC_TRY(convT_dgrad_h(G + p.H3, 256, 128, P + o.w[10], G + p.Q1, N, 256, d2[0], d2[1], d2[2], 128, u.tws, p.convT_ws, hs));
+  NC_TRY(convT_wgrad_h(V + p.b3, G + p.H3, 256, 128, DP + o.w[10], DP + o.b[10], N, 256, d2[0], d2[1], d2[2], 128, u.tws, p.convT_ws, hs));
+  NC_TRY(block_bwd(6, G + p.Q1, 256, 0, V + p.b2, G + p.Q2, G + p.Q1));
+  NC_TRY(block_bwd(5, G + p.Q1, 256, 0, V + p.b1, G + p.Q2, G + p.Q1));
+  NC_TRY(block_bwd(4, G + p.Q1, 256, 0, V + p.p2, G + p.Q2, G + p.Q1));
+  // conv2 = cat2[:, :128] feeds the pool AND the skip: pool backward + first half of dcat2, in one pass
+  NC_TRY(c8_maxpool_bwd_add(G + p.Q1, V + p.cat2, 256, 0, G + p.H3, 256, 0, G + p.H1, N, 128, d1[0], d1[1], d1[2], dt, hs));
+  NC_TRY(block_bwd(3, G + p.H1, 128, 0, V + p.a2, G + p.H2, G + p.H1));
+  NC_TRY(block_bwd(2, G + p.H1, 128, 0, V + p.p1, G + p.H2, G + p.H1));
+  NC_TRY(c8_maxpool_bwd_add(G + p.H1, V + p.cat1, 128, 0, G + p.G3, 128, 0, G + p.G1, N, 64, d0[0], d0[1], d0[2], dt, hs));
+  NC_TRY(block_bwd(1, G + p.G1, 64, 0, V + p.a1, G + p.G2, G + p.G1));
+  // block 0 in fp32 (one input channel): gradient C8 -> fp32, then the fp32 kernels
+  float* f1 = (float*)(G + p.F1);
+  float* f2 = (float*)(G + p.F2);
+  NC_TRY(c8_to_f32(G + p.G1, 64, 0, f1, N, 64, S, NC_DT_BF16, hs));
+  NC_TRY(nc_instnorm_act_bwd_dbias(f1, F(p.raw0), F(p.mean[0]), F(p.rstd[0]), 0.f, f2, DP + o.b[0], N, 64, S, u.iws, p.in_ws, stream));
+  if (dx) NC_TRY(nc_conv_dgrad(f2, P + o.w[0], dx, N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream));
+  return nc_conv_wgrad(x, f2, DP + o.w[0], nullptr, N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream);
+}
+
+}  // extern "C"
+
+// ---- deep_linear_gen ---------------------------------------------------------------------------------------------------
+namespace {
+
+// w_eff = W6 W5 W4 (64), u1 = W6 W5 (32): one block of 64 threads
+__global__ void k_lin_tail_prep(const float* __restrict__ W4, const float* __restrict__ W5, const float* __restrict__ W6,
+                                float* __restrict__ weff, float* __restrict__ u1) {
+  __shared__ float su[32];
+  const int t = threadIdx.x;
+  if (t < 32) {
+    float a = 0.f;
+    for (int i = 0; i < 16; ++i) a = fmaf(W6[i], W5[i * 32 + t], a);
+    su[t] = a;
+    u1[t] = a;
+  }
+  __syncthreads();
+  float a = 0.f;
+  for (int j = 0; j < 32; ++j) a = fmaf(su[j], W4[j * 64 + t], a);
+  weff[t] = a;
+}
+
+// weight gradients of the three pointwise layers from q[c] = sum_v dy[v] f3[c][v]:
+//   dW4[j][c] = u1[j] q[c];  p1 = W4 q;  dW5[i][j] = W6[i] p1[j];  dW6[i] = (W5 p1)[i]
+__global__ void k_lin_tail_wgrad(const float* __restrict__ W4, const float* __restrict__ W5, const float* __restrict__ W6,
+                                 const float* __restrict__ u1, const float* __restrict__ q, float* __restrict__ dW4,
+                                 float* __restrict__ dW5, float* __restrict__ dW6) {
+  __shared__ float p1[32];
+  const int t = threadIdx.x;  // 256 threads
+  if (t < 32) {
+    float a = 0.f;
+    for (int c = 0; c < 64; ++c) a = fmaf(W4[t * 64 + c], q[c], a);
+    p1[t] = a;
+  }
+  __syncthreads();
+  for (int i = t; i < 32 * 64; i += 256) dW4[i] = u1[i >> 6] * q[i & 63];
+  for (int i = t; i < 16 * 32; i += 256) dW5[i] = W6[i >> 5] * p1[i & 31];
+  if (t < 16) {
+    float a = 0.f;
+    for (int j = 0; j < 32; ++j) a = fmaf(W5[t * 32 + j], p1[j], a);
+    dW6[t] = a;
+  }
+}
+
+struct LLp {
+  int N, d[3];
+  long S;
+  size_t w[6];
+  size_t f1h, f2h, f3h, weff, u1, saved;        // bytes into saved
+  size_t F, A, B, q, grads;                      // bytes into the scratch
+  size_t conv_ws, f32conv_ws, o64_ws;
+  bool ok;
+};
+
+bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
+  p = LLp{};
+  if (N < 1 || S0 < 1 || S1 < 1 || S2 < 1) return false;
+  p.N = N; p.d[0] = S0; p.d[1] = S1; p.d[2] = S2;
+  p.S = (long)S0 * S1 * S2;
+  const int ks[6] = {7, 5, 3, 1, 1, 1}, C[6] = {1, 64, 64, 64, 32, 16}, K[6] = {64, 64, 64, 32, 16, 1};
+  size_t off = 0;
+  for (int i = 0; i < 6; ++i) { p.w[i] = off; off += (size_t)K[i] * C[i] * ks[i] * ks[i] * ks[i]; }
+  const size_t n = (size_t)N, S = (size_t)p.S;
+  off = 0;
+  auto take = [&](size_t bytes) { size_t r = off; off += al(bytes); return r; };
+  p.f1h = take(n * 64 * S * 2); p.f2h = take(n * 64 * S * 2); p.f3h = take(n * 64 * S * 2); p.weff = take(64 * 4); p.u1 = take(32 * 4);
+  p.saved = off;
+  off = 0;
+  p.F = take(n * 64 * S * 4); p.A = take(n * 64 * S * 2); p.B = take(n * 64 * S * 2); p.q = take(65 * 4);
+  p.grads = off;
+  p.ok = true;
+  for (int i = 1; i <= 2; ++i) {
+    ConvDims cd;
+    if (!make_dims(cd, N, 64, S0, S1, S2, 64, ks[i], ks[i], ks[i], 1, ks[i] / 2) || !h_fwd_supported(cd) || !h_dgrad_supported(cd) ||
+        !h_wgrad_supported(cd)) { p.ok = false; return true; }
+    const size_t b = h_ws_bytes(cd);
+    if (b > p.conv_ws) p.conv_ws = b;
+  }
+  p.f32conv_ws = nc_conv_ws_bytes(N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3);
+  p.o64_ws = c8_outer64_ws_bytes(N, p.S);
+  return true;
+}
+
+size_t llp_ws_bytes(const LLp& p) { return al(p.conv_ws) + al(p.f32conv_ws) + al(p.o64_ws) + p.grads + 256; }
+
+}  // namespace
+
+extern "C" {
+
+int nc_deep_linear_lp_supported(int N, int S0, int S1, int S2, int dtype) {
+  LLp p;
+  return dtype == NC_DT_BF16 && llp_plan(p, N, S0, S1, S2) && p.ok;
+}
+size_t nc_deep_linear_lp_saved_bytes(int N, int S0, int S1, int S2) {
+  LLp p;
+  return llp_plan(p, N, S0, S1, S2) && p.ok ? p.saved : 0;
+}
+size_t nc_deep_linear_lp_ws_bytes(int N, int S0, int S1, int S2) {
+  LLp p;
+  return llp_plan(p, N, S0, S1, S2) && p.ok ? llp_ws_bytes(p) : 0;
+}
+
+int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved) { set_error("deep_linear_lp_fwd: null pointer"); return NC_ERR_ARG; }
+  if (dtype != NC_DT_BF16) { set_error("deep_linear_lp_fwd: dtype must be NC_DT_BF16"); return NC_ERR_ARG; }
+  LLp p;
+  if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_fwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < llp_ws_bytes(p)) { set_error("deep_linear_lp_fwd: workspace too small"); return NC_ERR_WS; }
+  hipStream_t hs = (hipStream_t)stream;
+  char* cws = (char*)ws;
+  char* fws = cws + al(p.conv_ws);
+  char* G = fws + al(p.f32conv_ws) + al(p.o64_ws);
+  char* V = (char*)saved;
+  float* Ff = (float*)(G + p.F);
+  // 7^3, one input channel: fp32 kernel, then the 64-channel result becomes C8
+  NC_TRY(nc_conv_fwd(x, params + p.w[0], nullptr, Ff, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream));
+  NC_TRY(to_c8(Ff, V + p.f1h, N, 64, p.S, dtype, hs));
+  ConvDims c5, c3;
+  make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
+  make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  NC_TRY(conv_fwd_h_c8(V + p.f1h, params + p.w[1], nullptr, V + p.f2h, 64, 0, c5, dtype, cws, p.conv_ws, hs));
+  NC_TRY(conv_fwd_h_c8(V + p.f2h, params + p.w[2], nullptr, V + p.f3h, 64, 0, c3, dtype, cws, p.conv_ws, hs));
+  hipLaunchKernelGGL(k_lin_tail_prep, dim3(1), dim3(64), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (float*)(V + p.weff),
+                     (float*)(V + p.u1));
+  NC_TRY(check_launch("lin_tail_prep"));
+  return c8_dot64(V + p.f3h, (const float*)(V + p.weff), nullptr, y, N, p.S, dtype, hs);
+}
+
+int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved, const float* dy, float* dx, float* dparams,
+                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !saved || !dy || !dparams) { set_error("deep_linear_lp_bwd: null pointer"); return NC_ERR_ARG; }
+  if (dtype != NC_DT_BF16) { set_error("deep_linear_lp_bwd: dtype must be NC_DT_BF16"); return NC_ERR_ARG; }
+  LLp p;
+  if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_bwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < llp_ws_bytes(p)) { set_error("deep_linear_lp_bwd: workspace too small"); return NC_ERR_WS; }
+  hipStream_t hs = (hipStream_t)stream;
+  char* cws = (char*)ws;
+  char* fws = cws + al(p.conv_ws);
+  char* ows = fws + al(p.f32conv_ws);
+  char* G = ows + al(p.o64_ws);
+  const char* V = (const char*)saved;
+  float* q = (float*)(G + p.q);
+  // tail: df3 = w_eff (x) dy (C8), q = sum dy f3
+  NC_TRY(c8_outer64(dy, V + p.f3h, (const float*)(V + p.weff), G + p.A, q, nullptr, N, p.S, dtype, ows, p.o64_ws, hs));
+  hipLaunchKernelGGL(k_lin_tail_wgrad, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5],
+                     (const float*)(V + p.u1), q, dparams + p.w[3], dparams + p.w[4], dparams + p.w[5]);
+  NC_TRY(check_launch("lin_tail_wgrad"));
+  ConvDims c5, c3;
+  make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
+  make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  // 3^3 layer
+  NC_TRY(conv_wgrad_h(nullptr, V + p.f2h, nullptr, G + p.A, dparams + p.w[2], c3, NC_DT_BF16, cws, p.conv_ws, hs));
+  NC_TRY(conv_dgrad_h_c8(G + p.A, params + p.w[2], G + p.B, 64, 0, c3, NC_DT_BF16, cws, p.conv_ws, hs));
+  // 5^3 layer: its data gradient feeds the fp32 one-channel 7^3 kernels, so it leaves as fp32 NCDHW
+  NC_TRY(conv_wgrad_h(nullptr, V + p.f1h, nullptr, G + p.B, dparams + p.w[1], c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  float* Ff = (float*)(G + p.F);
+  NC_TRY(conv_dgrad_h(nullptr, G + p.B, params + p.w[1], Ff, c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  // 7^3 layer (fp32)
+  if (dx) NC_TRY(nc_conv_dgrad(Ff, params + p.w[0], dx, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream));
+  return nc_conv_wgrad(x, Ff, dparams + p.w[0], nullptr, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream);
+}
+
+}  // extern "C"

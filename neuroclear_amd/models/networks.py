@@ -297,6 +297,9 @@ class Unet_deconv(nn.Module):
         if self._fusable and inputs.is_cuda and ops.conv_precision == 'fp32' and _FUSED_GEN:
             # training: the whole forward (and, through autograd, the whole backward) as one C call
             return ops.unet_deconv_train(inputs, list(self.parameters()))
+        if self._fusable and inputs.is_cuda and _FUSED_GEN and ops.gen_lp_supported('unet', inputs.shape):
+            # --precision bf16: the 16-bit end-to-end whole-network call (bf16 activations in HBM, fp32 statistics)
+            return ops.unet_deconv_lp(inputs, list(self.parameters()))
         conv1 = self.double_conv1(inputs)
         conv2 = self.double_conv2(ops.maxpool2(conv1))
         conv_bottom = self.bottom_layer(ops.maxpool2(conv2))
@@ -359,6 +362,10 @@ class DeepLinearGenerator(nn.Module):
         if input.is_cuda and input.dim() == 5 and input.shape[1] == 1 and self.final_layer.weight.shape[0] == 1 and \
                 self.first_layer.weight.shape[0] == 64 and ops.conv_precision == 'fp32' and _FUSED_GEN:
             return ops.deep_linear(input, list(self.parameters()))
+        if input.is_cuda and input.dim() == 5 and self.final_layer.weight.shape[0] == 1 and \
+                self.first_layer.weight.shape[0] == 64 and _FUSED_GEN and torch.is_grad_enabled() and \
+                ops.gen_lp_supported('linear', input.shape):
+            return ops.deep_linear_lp(input, list(self.parameters()))
         return self.final_layer(self.feature_block(self.first_layer(input)))
 
 

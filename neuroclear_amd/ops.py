@@ -995,3 +995,83 @@ class _DeepLinear(torch.autograd.Function):
 def deep_linear(x, params):
     """DeepLinearGenerator.forward (networks.py:913-917), with autograd, as one C call per direction."""
     return _DeepLinear.apply(x, *params)
+
+
+# ---- the same two generators on the 16-bit end-to-end path (nc_unet_deconv_lp_* / nc_deep_linear_lp_*) ---------------
+def gen_lp_supported(kind, shape):
+    """True when --precision bf16 can run this generator as the whole-network 16-bit call (every layer covered)."""
+    if conv_precision != 'bf16' or len(shape) != 5 or shape[1] != 1:
+        return False
+    N, _, S0, S1, S2 = shape
+    fn = lib().nc_unet_deconv_lp_supported if kind == 'unet' else lib().nc_deep_linear_lp_supported
+    return bool(fn(I(N), I(S0), I(S1), I(S2), I(_DT['bf16'])))
+
+
+class _GenLp(torch.autograd.Function):
+    """kind 'unet': Unet_deconv, 'linear': DeepLinearGenerator; bf16 activations end to end, fp32 master weights."""
+
+    @staticmethod
+    def forward(ctx, x, kind, *params):
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        pre = 'nc_unet_deconv_lp' if kind == 'unet' else 'nc_deep_linear_lp'
+        packed = _pack_params(params)
+        want = L.nc_unet_deconv_param_floats() if kind == 'unet' else L.nc_deep_linear_param_floats()
+        if packed.numel() != want:
+            raise _lib.NcError('%s: parameter count does not match' % pre)
+        dims = (I(N), I(S0), I(S1), I(S2))
+        nsv = getattr(L, pre + '_saved_bytes')(*dims)
+        if nsv == 0:
+            raise _lib.NcError('%s: shape %s is not covered by the 16-bit kernels' % (pre, (S0, S1, S2)))
+        saved = torch.empty(nsv, dtype=torch.uint8, device=x.device)
+        ws = workspace(getattr(L, pre + '_ws_bytes')(*dims), x.device, pre)
+        y = torch.empty_like(x)
+        dt = _DT['bf16']
+        flop = 2.0 * (663809 if kind == 'unet' else 647120) * x.numel()
+        e0 = _prof_begin()
+        check(getattr(L, pre + '_fwd')(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), *dims, I(dt), _ptr(ws), Z(ws.numel()),
+                                       _stream()), pre + '_fwd')
+        if e0 is not None:
+            _prof_end(e0, ('unet' if kind == 'unet' else 'deep_linear') + '_lp_fwd', flop)
+        ctx.save_for_backward(x, y, saved)
+        ctx.packed, ctx.packed_gen, ctx.kind = packed, _param_generation(packed), kind
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, saved = ctx.saved_tensors
+        if _param_generation(ctx.packed) != ctx.packed_gen:
+            raise _lib.NcError('16-bit generator: the parameters were updated between this forward and its backward')
+        dy = dy.contiguous()
+        N, _, S0, S1, S2 = x.shape
+        L = lib()
+        kind = ctx.kind
+        pre = 'nc_unet_deconv_lp' if kind == 'unet' else 'nc_deep_linear_lp'
+        dims = (I(N), I(S0), I(S1), I(S2))
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dpar = torch.empty_like(ctx.packed)
+        ws = workspace(getattr(L, pre + '_ws_bytes')(*dims), x.device, pre)
+        dt = _DT['bf16']
+        e0 = _prof_begin()
+        if kind == 'unet':
+            check(L.nc_unet_deconv_lp_bwd(_ptr(ctx.packed), _ptr(x), _ptr(y), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), *dims,
+                                          I(dt), _ptr(ws), Z(ws.numel()), _stream()), pre + '_bwd')
+        else:
+            check(L.nc_deep_linear_lp_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), *dims, I(dt),
+                                          _ptr(ws), Z(ws.numel()), _stream()), pre + '_bwd')
+        if e0 is not None:
+            mac = (2 * 663809 - 1728) if kind == 'unet' else 2 * 647120
+            _prof_end(e0, ('unet' if kind == 'unet' else 'deep_linear') + '_lp_bwd', 2.0 * mac * x.numel())
+        return (dx, None) + tuple(_param_grads(ctx, dpar, ctx.shapes, 2))
+
+
+def unet_deconv_lp(x, params):
+    return _GenLp.apply(x, 'unet', *params)
+
+
+def deep_linear_lp(x, params):
+    return _GenLp.apply(x, 'linear', *params)

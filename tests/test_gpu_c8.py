@@ -1,0 +1,281 @@
+"""GPU parity of the 16-bit END-TO-END ("C8") operators through the C ABI (include/nc_hip.h, BASELINE.json configs[3]).
+
+Every operator is compared with the same operation done by torch in fp32 on the SAME 16-bit values (so only summation
+order and the final rounding to 16 bits differ):
+  * nc_conv_fwd_c8 / nc_conv_dgrad_c8: bit-identical to nc_to_c8 of the fp32-output kernels' result (same accumulators,
+    one rounding), also when written into a channel range of a wider buffer;
+  * nc_c8_instnorm_*: statistics vs fp64 (1e-5), normalise + ReLU bit-identical to torch's bf16 rounding of the same
+    fp32 expression, backward vs autograd within the bf16 rounding of the result (2^-8 relative to the largest value);
+  * nc_c8_maxpool2_*: forward bit-identical; backward = skip + gradient routed to the FIRST maximum of each window;
+  * nc_convT_k2s2_*_c8 vs torch conv_transpose3d / its gradients on the rounded operands;
+  * whole-network nc_unet_deconv_lp_* / nc_deep_linear_lp_* against the layer-by-layer 16-bit path and fp32.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BF, FP = 2, 1
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    from neuroclear_amd import ops
+    yield
+    ops.set_conv_precision('fp32')
+
+
+def L():
+    from neuroclear_amd import _lib
+    return _lib.lib()
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def ok(rc, what=''):
+    assert rc == 0, (what, rc, L().nc_last_error())
+
+
+def tdt(dt):
+    return torch.bfloat16 if dt == BF else torch.float16
+
+
+def to_c8(x, dt):
+    """torch restatement of the layout: [N,C,...] fp32 -> [N, C/8, S, 8] 16-bit."""
+    N, C = x.shape[:2]
+    return x.reshape(N, C // 8, 8, -1).permute(0, 1, 3, 2).contiguous().to(tdt(dt))
+
+
+def from_c8(xh, shape):
+    N, C = shape[:2]
+    return xh.float().permute(0, 1, 3, 2).reshape(shape).contiguous()
+
+
+def ws(nbytes):
+    return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=DEV)
+
+
+def test_layout_roundtrip_and_from_c8():
+    from neuroclear_amd import ops
+    x = torch.randn(2, 24, 3, 5, 7, device=DEV)
+    for dt in (BF, FP):
+        xh = ops.to_c8(x, dt)
+        ref = to_c8(x, dt)
+        assert torch.equal(xh.view(tdt(dt)).reshape(ref.shape), ref)
+        y = torch.empty(2, 16, 3, 5, 7, device=DEV)
+        ok(L().nc_from_c8(P(xh), 24, 8, P(y), 2, 16, ctypes.c_long(105), dt, None))
+        assert torch.equal(y, ref.float().permute(0, 1, 3, 2).reshape(2, 24, 3, 5, 7)[:, 8:24])
+
+
+@pytest.mark.parametrize('dt', [BF, FP])
+@pytest.mark.parametrize('N,C,K,dims,ks', [(2, 32, 64, (5, 9, 13), 3), (1, 64, 128, (12, 12, 12), 3), (2, 64, 64, (6, 11, 23), 5)])
+def test_conv_c8_bit_identical_to_fp32_output_kernels(N, C, K, dims, ks, dt):
+    from neuroclear_amd import ops
+    D, H, W = dims
+    S = D * H * W
+    pad = ks // 2
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, C, D, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV, generator=g) / (C * ks ** 3) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g)
+    dy = torch.randn(N, K, D, H, W, device=DEV, generator=g)
+    ops.set_conv_precision('bf16' if dt == BF else 'fp16')
+    xh = ops.to_c8(x, dt)
+    y32 = ops.conv_fwd_raw(x, w, b, 1, pad, xh=xh)
+    nb = L().nc_conv_lp_ws_bytes(N, C, D, H, W, K, ks, ks, ks, 1, pad)
+    wsb = ws(nb)
+    # dense output
+    yh = torch.empty(N * K * S * 2, dtype=torch.uint8, device=DEV)
+    ok(L().nc_conv_fwd_c8(P(xh), P(w), P(b), P(yh), K, 0, N, C, D, H, W, K, ks, ks, ks, 1, pad, dt, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    assert torch.equal(yh, ops.to_c8(y32, dt))
+    # into channels [K, 2K) of a 2K + 8 channel buffer; the rest must stay untouched
+    ctot = 2 * K + 8
+    buf = torch.full((N * ctot * S * 2,), 0x5a, dtype=torch.uint8, device=DEV)
+    ok(L().nc_conv_fwd_c8(P(xh), P(w), P(b), P(buf), ctot, K, N, C, D, H, W, K, ks, ks, ks, 1, pad, dt, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    v = buf.view(N, ctot // 8, S * 16)
+    assert torch.equal(v[:, K // 8:2 * K // 8].reshape(-1), yh)
+    assert bool((v[:, :K // 8] == 0x5a).all()) and bool((v[:, 2 * K // 8:] == 0x5a).all())
+    # data gradient (bf16 operands in both modes)
+    ops.set_conv_precision('bf16')
+    dyh = ops.to_c8(dy, BF)
+    dx32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, pad, dyh=dyh)
+    dxh = torch.empty(N * C * S * 2, dtype=torch.uint8, device=DEV)
+    ok(L().nc_conv_dgrad_c8(P(dyh), P(w), P(dxh), N, C, D, H, W, K, ks, ks, ks, 1, pad, BF, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    assert torch.equal(dxh, ops.to_c8(dx32, BF))
+
+
+@pytest.mark.parametrize('dt', [BF, FP])
+@pytest.mark.parametrize('N,C,dims,slope', [(2, 16, (6, 10, 14), 0.0), (1, 64, (20, 20, 20), 0.0), (3, 8, (1, 33, 17), 0.2)])
+def test_c8_instnorm_forward_and_backward(N, C, dims, slope, dt):
+    from neuroclear_amd import ops
+    D, H, W = dims
+    S = D * H * W
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(N, C, D, H, W, device=DEV, generator=g) * 1.7 + 0.6
+    xh = ops.to_c8(x, dt)
+    xr = x.to(tdt(dt)).float()
+    mean = torch.empty(N * C, device=DEV)
+    rstd = torch.empty(N * C, device=DEV)
+    wsb = ws(L().nc_c8_instnorm_ws_bytes(N, C, ctypes.c_long(S)))
+    ok(L().nc_c8_instnorm_stats(P(xh), N, C, ctypes.c_long(S), ctypes.c_float(1e-5), P(mean), P(rstd), dt, P(wsb),
+                                ctypes.c_size_t(wsb.numel()), None))
+    m64 = xr.double().mean((2, 3, 4)).reshape(-1)
+    v64 = xr.double().var((2, 3, 4), unbiased=False).reshape(-1)
+    assert float((mean.double() - m64).abs().max()) < 1e-5
+    assert float((rstd.double() * torch.sqrt(v64 + 1e-5) - 1).abs().max()) < 1e-5
+    # normalise + activation into channels [8, 8 + C) of a wider buffer: bit-identical to torch's rounding of the same fp32 expression
+    ctot = C + 16
+    buf = torch.zeros(N * ctot * S * 2, dtype=torch.uint8, device=DEV)
+    ok(L().nc_c8_instnorm_act_fwd(P(xh), P(mean), P(rstd), ctypes.c_float(slope), P(buf), ctot, 8, N, C, ctypes.c_long(S), dt, None))
+    t = (xr - mean.view(N, C, 1, 1, 1)) * rstd.view(N, C, 1, 1, 1)
+    yref = torch.where(t > 0, t, t * slope)
+    got = buf.view(tdt(dt)).reshape(N, ctot // 8, S, 8)[:, 1:1 + C // 8]
+    assert torch.equal(got, to_c8(yref, dt))
+    # backward vs autograd of the fp32 expression on the rounded tensors (gradient operands are bf16)
+    gy = torch.randn(N, C, D, H, W, device=DEV, generator=g)
+    gbuf = torch.zeros(N * ctot * S * 2, dtype=torch.uint8, device=DEV)
+    gbuf.view(torch.bfloat16).reshape(N, ctot // 8, S, 8)[:, 1:1 + C // 8] = to_c8(gy, BF)
+    dxh = torch.empty(N * C * S * 2, dtype=torch.uint8, device=DEV)
+    db = torch.empty(C, device=DEV)
+    ok(L().nc_c8_instnorm_act_bwd(P(gbuf), ctot, 8, P(xh), P(mean), P(rstd), ctypes.c_float(slope), P(dxh), P(db), N, C, ctypes.c_long(S),
+                                  dt, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    xa = xr.clone().requires_grad_(True)
+    ya = F.instance_norm(xa, eps=1e-5)
+    ya = torch.where(ya > 0, ya, ya * slope)
+    ya.backward(gy.to(torch.bfloat16).float())
+    got = from_c8(dxh.view(torch.bfloat16).reshape(N, C // 8, S, 8), x.shape)
+    scale = float(xa.grad.abs().max())
+    assert float((got - xa.grad).abs().max()) <= 2 ** -7 * scale
+    assert float((got - xa.grad).abs().mean()) <= 2 ** -9 * scale
+    assert float(db.abs().max()) <= 1e-3 * scale * S ** 0.5  # sum of dx per channel: zero up to rounding
+
+
+@pytest.mark.parametrize('dt', [BF, FP])
+def test_c8_maxpool_forward_and_backward_add(dt):
+    from neuroclear_amd import ops
+    N, C, D, H, W = 2, 16, 6, 8, 10
+    S, So = D * H * W, D * H * W // 8
+    g = torch.Generator(device=DEV).manual_seed(3)
+    # coarse values so that ties inside a window DO occur: the first maximum must win
+    x = (torch.randint(-3, 4, (N, C, D, H, W), device=DEV, generator=g)).float() * 0.5
+    ctot = C + 8
+    xb = torch.zeros(N, ctot // 8, S, 8, dtype=tdt(dt), device=DEV)
+    xb[:, 1:] = to_c8(x, dt)
+    yh = torch.empty(N * C * So * 2, dtype=torch.uint8, device=DEV)
+    ok(L().nc_c8_maxpool2_fwd(P(xb), ctot, 8, P(yh), N, C, D, H, W, dt, None))
+    ref = F.max_pool3d(x, 2)
+    assert torch.equal(yh.view(tdt(dt)).reshape(N, C // 8, So, 8), to_c8(ref, dt))
+    dp = torch.randn(N, C, D // 2, H // 2, W // 2, device=DEV, generator=g)
+    skip = torch.randn(N, C, D, H, W, device=DEV, generator=g)
+    sb = torch.zeros(N, ctot // 8, S, 8, dtype=torch.bfloat16, device=DEV)
+    sb[:, :C // 8] = to_c8(skip, BF)
+    dxh = torch.empty(N * C * S * 2, dtype=torch.uint8, device=DEV)
+    ok(L().nc_c8_maxpool2_bwd_add(P(to_c8(dp, BF)), P(xb), ctot, 8, P(sb), ctot, 0, P(dxh), N, C, D, H, W, dt, None))
+    # reference: windows as a trailing axis of 8 in scan order (a, b, c); torch.argmax returns the FIRST maximum
+    xw = x.reshape(N, C, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(N, C, D // 2, H // 2, W // 2, 8)
+    arg = xw.argmax(-1)
+    gw = torch.zeros_like(xw)
+    gw.scatter_(-1, arg.unsqueeze(-1), dp.to(torch.bfloat16).float().unsqueeze(-1))
+    gfull = gw.reshape(N, C, D // 2, H // 2, W // 2, 2, 2, 2).permute(0, 1, 2, 5, 3, 6, 4, 7).reshape(N, C, D, H, W)
+    want = (skip.to(torch.bfloat16).float() + gfull).to(torch.bfloat16)
+    got = dxh.view(torch.bfloat16).reshape(N, C // 8, S, 8)
+    assert torch.equal(got, to_c8(want.float(), BF))
+
+
+@pytest.mark.parametrize('N,C,K,dims', [(2, 64, 32, (3, 5, 7)), (1, 256, 128, (6, 6, 6)), (3, 128, 64, (4, 9, 10))])
+def test_convT_c8(N, C, K, dims):
+    D, H, W = dims
+    Sc, Sf = D * H * W, 8 * D * H * W
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(N, C, D, H, W, device=DEV, generator=g)
+    w = torch.randn(C, K, 2, 2, 2, device=DEV, generator=g) / C ** 0.5
+    b = torch.randn(K, device=DEV, generator=g)
+    dy = torch.randn(N, K, 2 * D, 2 * H, 2 * W, device=DEV, generator=g)
+    xr, wr, dyr = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    wsb = ws(L().nc_convT_c8_ws_bytes(N, C, D, H, W, K))
+    nb = ctypes.c_size_t(wsb.numel())
+    ctot = 2 * K
+    out = torch.zeros(N, ctot // 8, Sf, 8, dtype=torch.bfloat16, device=DEV)
+    ok(L().nc_convT_k2s2_fwd_c8(P(to_c8(x, BF)), P(w), P(b), P(out), ctot, K, N, C, D, H, W, K, BF, P(wsb), nb, None))
+    ref = F.conv_transpose3d(xr, wr, b, stride=2)
+    got = from_c8(out[:, K // 8:], ref.shape)
+    assert float((got - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert float(out[:, :K // 8].float().abs().max()) == 0.0
+    # dgrad: dy lives in channels [K, 2K) of the wide buffer
+    dyb = torch.zeros(N, ctot // 8, Sf, 8, dtype=torch.bfloat16, device=DEV)
+    dyb[:, K // 8:] = to_c8(dy, BF)
+    dxh = torch.empty(N, C // 8, Sc, 8, dtype=torch.bfloat16, device=DEV)
+    ok(L().nc_convT_k2s2_dgrad_c8(P(dyb), ctot, K, P(w), P(dxh), N, C, D, H, W, K, P(wsb), nb, None))
+    ref = F.conv3d(dyr, wr, None, stride=2)
+    got = from_c8(dxh, ref.shape)
+    assert float((got - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    # wgrad + bias gradient (fp32 results)
+    dw = torch.empty_like(w)
+    db = torch.empty(K, device=DEV)
+    ok(L().nc_convT_k2s2_wgrad_c8(P(to_c8(x, BF)), P(dyb), ctot, K, P(dw), P(db), N, C, D, H, W, K, P(wsb), nb, None))
+    wz = torch.zeros_like(w, requires_grad=True)
+    F.conv_transpose3d(xr, wz, None, stride=2).backward(dyr)
+    assert float((dw - wz.grad).abs().max()) <= 1e-4 * float(wz.grad.abs().max())
+    assert float((db - dyr.sum((0, 2, 3, 4))).abs().max()) <= 1e-4 * float(dyr.sum((0, 2, 3, 4)).abs().max()) + 1e-3
+
+
+def _nets():
+    from neuroclear_amd.models import networks
+    from neuroclear_amd.util import seed as S
+    ga = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    ga.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 11, device=DEV))
+    gb = networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0])
+    gb.load_state_dict(S.state_dict_from_seed(S.deep_linear_spec(), 12, device=DEV))
+    return ga, gb
+
+
+@pytest.mark.parametrize('kind,shape', [('unet', (1, 1, 32, 32, 32)), ('unet', (2, 1, 24, 32, 40)), ('linear', (1, 1, 24, 24, 24)),
+                                        ('linear', (2, 1, 16, 20, 28))])
+def test_whole_network_16bit_paths(kind, shape, monkeypatch):
+    """nc_unet_deconv_lp_* / nc_deep_linear_lp_* (bf16 activations end to end) against (a) the layer-by-layer 16-bit path
+    (fp32 tensors between the layers) and (b) fp32: outputs within the 16-bit tolerance of DESIGN.md 2 (after the sigmoid
+    |err| <= 1.5e-2, mean <= 3e-3; deep_linear 2e-2 of the largest value), weight gradients of the big layers within
+    2.5 x the change a 1e-3 relative input perturbation causes in pure fp32, + 3 % (ReLU / max-pool flips dominate)."""
+    from neuroclear_amd import ops
+    from neuroclear_amd.models import networks
+    ga, gb = _nets()
+    net = ga if kind == 'unet' else gb
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(shape, device=DEV, generator=gen)
+    r = torch.randn(shape, device=DEV, generator=gen)
+    noise = 1 + 1e-3 * torch.randn(shape, device=DEV, generator=gen)
+
+    def run(prec, fused, xi):
+        ops.set_conv_precision(prec)
+        monkeypatch.setattr(networks, '_FUSED_GEN', fused)
+        assert (not fused) or prec == 'fp32' or ops.gen_lp_supported(kind, xi.shape)
+        for q in net.parameters():
+            q.grad = None
+        xi = xi.clone().requires_grad_(True)
+        y = net(xi)
+        (y * r).mean().backward()
+        ops.set_conv_precision('fp32')
+        return y.detach().clone(), xi.grad.clone(), {n: q.grad.clone() for n, q in net.named_parameters()}
+
+    y32, dx32, g32 = run('fp32', True, x)
+    _, _, gp = run('fp32', True, x * noise)
+    yl, dxl, gl = run('bf16', False, x)   # layer by layer
+    yw, dxw, gw = run('bf16', True, x)    # whole-network, C8 end to end
+    scale = 1.0 if kind == 'unet' else float(y32.abs().max())
+    for y16 in (yl, yw):
+        assert float((y16 - y32).abs().max()) <= (1.5e-2 if kind == 'unet' else 2e-2) * scale
+        assert float((y16 - y32).abs().mean()) <= 3e-3 * scale
+    assert float((yw - yl).abs().max()) <= 1.5e-2 * scale
+    assert float((dxw - dx32).norm() / dx32.norm()) <= 2.5 * float((run('fp32', True, x * noise)[1] - dx32).norm() / dx32.norm()) + 0.05
+    for n, g in g32.items():
+        if g.dim() == 5 and g.numel() >= 4096:
+            floor = float((gp[n] - g).norm() / g.norm())
+            rel = float((gw[n] - g).norm() / g.norm())
+            assert rel <= 2.5 * floor + 0.03, (n, rel, floor)
+            assert torch.isfinite(gw[n]).all()
