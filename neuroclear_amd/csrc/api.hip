@@ -24,30 +24,25 @@ static std::vector<hipEvent_t> g_prof_pool;
 static bool g_prof_on = false;
 static double g_prof_min_flop = 0.0;
 
-struct ProfScope {
-  int idx = -1;
-  hipStream_t s;
-  // cls = op (0 fwd, 1 dgrad, 2 wgrad) | path << 4 | kernel edge << 8 | (16-bit ? 1 << 16 : 0)
-  ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t stream) : s(stream) {
-    if (!g_prof_on) return;
-    const double flop = 2.0 * d.C * d.K * d.kd * d.kh * d.kw * ((double)d.N * d.Do * d.Ho * d.Wo);
-    if (flop < g_prof_min_flop) return;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
-      if (hipEventCreate(&e) != hipSuccess) return (hipEvent_t) nullptr;
-      return e;
-    };
-    ProfRec r{op | (path << 4) | (d.kh << 8) | (lp ? 1 << 16 : 0), flop, get(), get()};
-    if (!r.e0 || !r.e1) return;
-    (void)hipEventRecord(r.e0, s);
-    g_prof.push_back(r);
-    idx = (int)g_prof.size() - 1;
-  }
-  ~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, s);
-  }
-};
+ProfScope::ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t stream) : idx(-1), s(stream) {
+  if (!g_prof_on) return;
+  const double flop = 2.0 * d.C * d.K * d.kd * d.kh * d.kw * ((double)d.N * d.Do * d.Ho * d.Wo);
+  if (flop < g_prof_min_flop) return;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return (hipEvent_t) nullptr;
+    return e;
+  };
+  ProfRec r{op | (path << 4) | (d.kh << 8) | (lp ? 1 << 16 : 0), flop, get(), get()};
+  if (!r.e0 || !r.e1) return;
+  (void)hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+  idx = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, s);
+}
 
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;

@@ -215,15 +215,22 @@ __global__ void __launch_bounds__(256) k_bwd_apply_c8(const uint4* __restrict__ 
   }
 }
 
-// dbias[c] = sum over samples and blocks of the partial sums, fixed order
-__global__ void k_dbias_final_c8(const double* __restrict__ dbp, int N, int C, int nbx, float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dbias[c] = sum over samples and blocks of the partial sums: one block per channel, fixed-shape tree (deterministic)
+__global__ void __launch_bounds__(256) k_dbias_final_c8(const double* __restrict__ dbp, int N, int C, int nbx, float* __restrict__ dbias) {
+  __shared__ double lds[4];
+  const int c = blockIdx.x;
   const int CB = C >> 3, cb = c >> 3, j = c & 7;
   double a = 0;
-  for (int n = 0; n < N; ++n)
-    for (int b = 0; b < nbx; ++b) a += dbp[(((long)n * CB + cb) * nbx + b) * 8 + j];
-  dbias[c] = (float)a;
+  const int total = N * nbx;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int n = i / nbx, b = i - n * nbx;
+    a += dbp[(((long)n * CB + cb) * nbx + b) * 8 + j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) dbias[c] = (float)(lds[0] + lds[1] + lds[2] + lds[3]);
 }
 
 // ---- MaxPool3d(2): x = channels [c0, ..) of a ctot buffer at (D, H, W); y dense at (D/2, H/2, W/2) -----------------------
@@ -372,13 +379,21 @@ __global__ void __launch_bounds__(256) k_outer64_c8(const float* __restrict__ g,
   block_reduce<65>(d, lds, part + ((long)n * gridDim.x + blockIdx.x) * 65);
 }
 
-__global__ void k_outer64_final(const double* __restrict__ part, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
-  const int j = threadIdx.x;
-  if (j >= 65) return;
+// one block per output (64 weight sums + the plain sum), fixed-shape tree
+__global__ void __launch_bounds__(256) k_outer64_final(const double* __restrict__ part, int nblocks, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double lds[4];
+  const int j = blockIdx.x;
   double a = 0;
-  for (int b = 0; b < nblocks; ++b) a += part[(long)b * 65 + j];
-  if (j < 64) dw[j] = (float)a;
-  else if (db) db[0] = (float)a;
+  for (int b = threadIdx.x; b < nblocks; b += 256) a += part[(long)b * 65 + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = lds[0] + lds[1] + lds[2] + lds[3];
+    if (j < 64) dw[j] = (float)t;
+    else if (db) db[0] = (float)t;
+  }
 }
 
 #define DISPATCH_DT(dt, CALL)            \
@@ -438,7 +453,7 @@ int c8_instnorm_bwd(const void* g, int gctot, int gc0, const void* x, const floa
   DISPATCH_DT(dt, CALL);
 #undef CALL
   if (dbias)
-    hipLaunchKernelGGL(k_dbias_final_c8, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, s, dbp, N, C, (int)nbx, dbias);
+    hipLaunchKernelGGL(k_dbias_final_c8, dim3(C), dim3(256), 0, s, dbp, N, C, (int)nbx, dbias);
   return check_launch("c8_instnorm_bwd");
 }
 
@@ -490,7 +505,7 @@ int c8_outer64(const float* g, const void* x, const float* w, void* dx, float* d
 #define CALL(T) hipLaunchKernelGGL((k_outer64_c8<T, NC_DT_BF16>), dim3((unsigned)nbx, N), dim3(256), 0, s, g, (const uint4*)x, w, (uint4*)dx, S, 16, part)
   DISPATCH_DT(dt, CALL);
 #undef CALL
-  hipLaunchKernelGGL(k_outer64_final, dim3(1), dim3(128), 0, s, part, (int)(N * nbx), dw, db);
+  hipLaunchKernelGGL(k_outer64_final, dim3(65), dim3(256), 0, s, part, (int)(N * nbx), dw, db);
   return check_launch("c8_outer64");
 }
 

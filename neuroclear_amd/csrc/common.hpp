@@ -122,4 +122,13 @@ static constexpr size_t kPackSlackBytes = 128 * 1024;
 
 extern int g_force_direct;
 
+// Live launch profiler (nc_prof_begin / nc_prof_end, api.hip): brackets one convolution launch with HIP events on its
+// stream when profiling is on.  cls = op (0 fwd, 1 dgrad, 2 wgrad) | path << 4 | kernel edge << 8 | (16-bit ? 1 << 16 : 0)
+struct ProfScope {
+  int idx;
+  hipStream_t s;
+  ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t stream);
+  ~ProfScope();
+};
+
 }  // namespace nc

@@ -892,6 +892,7 @@ int conv_fwd_h(const float* x, const void* xh, const float* w, const float* b, f
 int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int ctot, int c0, const ConvDims& d, int dt,
                   void* ws, size_t wsb, hipStream_t s) {
   const long T3 = (long)d.kd * d.kh * d.kw;
+  ProfScope ps(0, 1, d, 1, s);
   if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
   return run_h<NC_DT_BF16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
 }
@@ -899,6 +900,7 @@ int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int 
 int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
                     size_t wsb, hipStream_t s) {
   const long T3 = (long)d.kd * d.kh * d.kw;
+  ProfScope ps(1, 1, d, 1, s);
   if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
   return run_h<NC_DT_BF16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
 }

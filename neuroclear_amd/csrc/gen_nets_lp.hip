@@ -239,6 +239,7 @@ int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, c
     NC_TRY(c8_instnorm_bwd(g, gctot, gc0, V + p.raw[i], F(p.mean[i]), F(p.rstd[i]), 0.f, draw, DP + o.b[i], N, b.K, Sl, dt, u.c8ws,
                            p.c8_ws, hs));
     if (gin) NC_TRY(conv_dgrad_h_c8(draw, P + o.w[i], gin, b.C, 0, cd, NC_DT_BF16, u.cws, p.conv_ws, hs));
+    ProfScope ps(2, 1, cd, 1, hs);
     return conv_wgrad_h(nullptr, in, nullptr, draw, DP + o.w[i], cd, NC_DT_BF16, u.cws, p.conv_ws, hs);
   };
   // head
@@ -427,12 +428,21 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
   // 3^3 layer
-  NC_TRY(conv_wgrad_h(nullptr, V + p.f2h, nullptr, G + p.A, dparams + p.w[2], c3, NC_DT_BF16, cws, p.conv_ws, hs));
+  {
+    ProfScope ps(2, 1, c3, 1, hs);
+    NC_TRY(conv_wgrad_h(nullptr, V + p.f2h, nullptr, G + p.A, dparams + p.w[2], c3, NC_DT_BF16, cws, p.conv_ws, hs));
+  }
   NC_TRY(conv_dgrad_h_c8(G + p.A, params + p.w[2], G + p.B, 64, 0, c3, NC_DT_BF16, cws, p.conv_ws, hs));
   // 5^3 layer: its data gradient feeds the fp32 one-channel 7^3 kernels, so it leaves as fp32 NCDHW
-  NC_TRY(conv_wgrad_h(nullptr, V + p.f1h, nullptr, G + p.B, dparams + p.w[1], c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  {
+    ProfScope ps(2, 1, c5, 1, hs);
+    NC_TRY(conv_wgrad_h(nullptr, V + p.f1h, nullptr, G + p.B, dparams + p.w[1], c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  }
   float* Ff = (float*)(G + p.F);
-  NC_TRY(conv_dgrad_h(nullptr, G + p.B, params + p.w[1], Ff, c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  {
+    ProfScope ps(1, 1, c5, 1, hs);
+    NC_TRY(conv_dgrad_h(nullptr, G + p.B, params + p.w[1], Ff, c5, NC_DT_BF16, cws, p.conv_ws, hs));
+  }
   // 7^3 layer (fp32)
   if (dx) NC_TRY(nc_conv_dgrad(Ff, params + p.w[0], dx, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream));
   return nc_conv_wgrad(x, Ff, dparams + p.w[0], nullptr, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream);
