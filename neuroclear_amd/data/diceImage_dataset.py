@@ -17,11 +17,8 @@ from ..util import util
 def _load_volume(path):
     if path.endswith('.npy'):
         return np.load(path)
-    try:
-        import tifffile
-        return tifffile.imread(path)
-    except ImportError:
-        raise RuntimeError('reading %s needs tifffile (not installed); .npy volumes are read natively' % path)
+    from ..util import tiff
+    return tiff.imread(path)  # uncompressed grayscale TIFF stacks (what the reference's skimage.io.imsave writes)
 
 
 class DiceImageDataSet:

@@ -12,6 +12,8 @@ i % world (cubes are independent units; no data-path collective is needed to COM
   * assemble='gather': lock-step rounds, each round's tiles gathered to rank 0 and overlap-added there in index order
     -- bit-identical to the single-GPU / reference result; the verification mode.
 `main()` keeps the reference's command line for the flags that matter on this path."""
+import os
+
 import numpy as np
 import torch
 
@@ -69,9 +71,12 @@ def broadcast_parameters(net, src=0):
             off += k
 
 
-def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble=None, broadcast=True, on_cube=None):
+def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble=None, broadcast=True, on_cube=None,
+                    with_real=False):
     """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0.
-    on_cube(fn) -> result: optional wrapper around each cube's network call (bench.py brackets it with HIP events)."""
+    on_cube(fn) -> result: optional wrapper around each cube's network call (bench.py brackets it with HIP events).
+    with_real: also assemble the input cubes (the reference's 'real' visual, test_dice.py without --skip_real) and return
+    (fake, real); the dice -> assemble round trip of the input is the input up to 1 LSB of the truncating cast."""
     if assemble is None:
         assemble = 'reduce' if world > 1 else 'gather'
     if assemble not in ('reduce', 'gather'):
@@ -81,6 +86,12 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     ds = DiceImageDataSet(opt, volume=volume)
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
     local_acc = assemble == 'reduce' or rank == 0
+    if with_real and assemble == 'gather' and world > 1:
+        raise NotImplementedError("with_real needs assemble='reduce' when sharded")
+    if with_real:
+        import copy
+        opt = copy.copy(opt)
+        opt.skip_real = False
     asm = Assemble_Dice(opt, ds.size_original()) if local_acc else None
     E = opt.dice_size[0] + 2 * opt.border_cut
     hm = bool(getattr(opt, 'histogram_match', False))  # the producing rank matches its own cube (it holds the input)
@@ -88,12 +99,16 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     def produce(i):
         x = ds[i]['A'].unsqueeze(0)
         y = (netG(x) if on_cube is None else on_cube(lambda: netG(x))).reshape(E, E, E)
+        if with_real:
+            asm.add_cube('real', x.reshape(E, E, E), i)
         return match_cube(y, x, opt.dice_size[0], opt.border_cut, ds.device) if hm else y
 
     with torch.no_grad():
         if assemble == 'reduce':
             sharded_cube_loop_reduce(n, rank, world, produce, add_local=lambda j, tile: asm.add_cube('fake', tile, j),
                                      accumulator=lambda: asm.acc['fake'])
+            if with_real and world > 1:
+                torch.distributed.reduce(asm.acc['real'], dst=0, op=torch.distributed.ReduceOp.SUM)
         else:
             sharded_cube_loop(
                 n, rank, world,
@@ -102,9 +117,75 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
                 empty_like=lambda: torch.zeros((E, E, E), dtype=torch.float32, device=ds.device))
     if rank != 0:
         return None
-    asm.count['fake'] = asm.len_cube_queue  # warm-up runs (max_cubes) assemble a partial volume on purpose
+    for k in asm.count:
+        asm.count[k] = asm.len_cube_queue  # warm-up runs (max_cubes) assemble a partial volume on purpose
     asm.assemble_all()
-    return asm.getDict()['fake']
+    return (asm.getDict()['fake'], asm.getDict()['real']) if with_real else asm.getDict()['fake']
+
+
+def write_outputs(opt, web_dir, fake_volume, real_volume=None, gt_volume=None):
+    """The tail of the reference's test script (test_dice.py:126-270): the assembled volume as a multi-page TIFF, maximum
+    intensity projections, per-slice TIFFs along the three axes, and the PSNR report against a ground-truth volume --
+    same directory layout and file names.  Returns the metrics dict (empty without ground truth)."""
+    from .util import tiff
+    from .util import util as U
+    skip_real = real_volume is None
+    if getattr(opt, 'save_volume', False):
+        U.mkdir(web_dir + '/volumes')
+        tag = 'iter-' + str(opt.load_iter) if getattr(opt, 'load_iter', 0) > 0 else 'epoch-' + str(opt.epoch)
+        tiff.imsave(web_dir + '/volumes/output_volume_xy-view_' + tag + '.tif', fake_volume)
+        print('Output volume is saved as a tiff file. ')
+        if not skip_real:
+            tiff.imsave(web_dir + '/volumes/input_volume_xy-view.tif', real_volume)
+            print('Input volume is saved as a tiff file. ')
+    if getattr(opt, 'save_projections', False):
+        U.mkdir(web_dir + '/projections')
+        ep = str(opt.epoch)
+        # (the reference projects fixed sub-ranges of the output volume along y and x, test_dice.py:163-164)
+        U.save_image(np.amax(fake_volume, axis=0), web_dir + '/projections/fake_xy_proj_epoch-' + ep + '.tif')
+        U.save_image(np.amax(fake_volume[:, 800:1100, :], axis=1, initial=0), web_dir + '/projections/fake_xz_proj_epoch-' + ep + '.tif')
+        U.save_image(np.amax(fake_volume[:, :, 200:500], axis=2, initial=0), web_dir + '/projections/fake_yz_proj_epoch-' + ep + '.tif')
+        if not skip_real:
+            for ax, nm in ((0, 'xy'), (1, 'xz'), (2, 'yz')):
+                U.save_image(np.amax(real_volume, axis=ax), web_dir + '/projections/real_%s_proj.tif' % nm)
+    if getattr(opt, 'save_slices', False):
+        for nm in ('xy', 'yz', 'xz'):
+            U.mkdir(web_dir + '/images/output_' + nm)
+            if not skip_real:
+                U.mkdir(web_dir + '/images/input_' + nm)
+        for i in range(fake_volume.shape[2]):
+            U.save_image(fake_volume[:, :, i], web_dir + '/images/output_yz/output_yz_%d.tif' % i)
+            if not skip_real:
+                U.save_image(real_volume[:, :, i], web_dir + '/images/input_yz/input_yz_%d.tif' % i)
+        for i in range(fake_volume.shape[1]):
+            U.save_image(fake_volume[:, i, :], web_dir + '/images/output_xz/output_xz_%d.tif' % i)
+            if not skip_real:
+                U.save_image(real_volume[:, i, :], web_dir + '/images/input_xz/input_xz_%d.tif' % i)
+        for i in range(fake_volume.shape[0]):
+            U.save_image(fake_volume[i], web_dir + '/images/output_xy/output_xy_%d.tif' % i)
+            if not skip_real:
+                U.save_image(real_volume[i], web_dir + '/images/input_xy/input_xy_%d.tif' % i)
+    metrics = {}
+    if gt_volume is not None:
+        if skip_real:
+            raise ValueError('the PSNR report compares input and output with the ground truth: do not pass --skip_real')
+        print('Calculating PSNR for the whole image volume...')
+        vols = {}
+        for k, v in (('real', real_volume), ('fake', fake_volume), ('gt', gt_volume)):
+            for _ in range(2):  # standardize + 8-bit normalize, applied twice as at test_dice.py:244-251
+                v = U.normalize(U.standardize(v), data_type=np.uint8)
+            vols[k] = v
+        metrics['psnr_input_gt'] = U.get_psnr(vols['real'], vols['gt'], 2 ** 8 - 1)
+        metrics['psnr_output_gt'] = U.get_psnr(vols['fake'], vols['gt'], 2 ** 8 - 1)
+        bar = '---------------------------------------------------------'
+        message = '\n'.join(['Experiment Name: ' + opt.name, bar, '', 'Whole_volume', bar, 'Network Input vs. Groundtruth',
+                             '(psnr: %.4f) ' % metrics['psnr_input_gt'], bar, 'Network Output vs. Groundtruth',
+                             '(psnr: %.4f) ' % metrics['psnr_output_gt'], bar])
+        print(message)
+        U.mkdir(web_dir)
+        with open(os.path.join(web_dir, 'metrics.txt'), 'a') as f:
+            f.write('%s\n' % message)
+    return metrics
 
 
 def main(argv=None):
@@ -139,6 +220,12 @@ def main(argv=None):
     p.add_argument('--normalize_intensity', action='store_true')
     p.add_argument('--sat_level', type=float, nargs='+', default=[0.25, 99.75])
     p.add_argument('--verbose', action='store_true')
+    p.add_argument('--phase', default='test')
+    p.add_argument('--data_name', default=None)
+    p.add_argument('--dataroot_gt', default=None, help='directory with the ground-truth volume: enables the PSNR report')
+    p.add_argument('--save_volume', action='store_true')
+    p.add_argument('--save_projections', action='store_true')
+    p.add_argument('--save_slices', action='store_true')
     opt = p.parse_args(argv)
     opt.gpu_ids = [int(g) for g in opt.gpu_ids.split(',') if int(g) >= 0]
     opt.isTrain, opt.continue_train, opt.preprocess = False, False, 'addColorChannel'
@@ -154,13 +241,27 @@ def main(argv=None):
     from .data.diceImage_dataset import _load_volume
     names = sorted(f for f in os.listdir(opt.dataroot) if f.endswith(('.npy', '.tif', '.tiff')))
     vol = _load_volume(os.path.join(opt.dataroot, names[0]))
-    opt.skip_real = True
-    out = diced_inference(model.netG, vol, opt, rank, world)
+    gt = None
+    if opt.dataroot_gt is not None:
+        gnames = sorted(f for f in os.listdir(opt.dataroot_gt) if f.endswith(('.npy', '.tif', '.tiff')))
+        gt = _load_volume(os.path.join(opt.dataroot_gt, gnames[0]))
+    want_real = not opt.skip_real
+    res = diced_inference(model.netG, vol, opt, rank, world, with_real=want_real)
+    metrics = {}
     if rank == 0:
-        d = os.path.join(opt.results_dir, opt.name, 'volumes')
-        os.makedirs(d, exist_ok=True)
-        np.save(os.path.join(d, 'output_volume.npy'), out)
+        out, real = res if want_real else (res, None)
+        print('Image volume re-assembled.')
         print('re-merged image shape: {}'.format(out.shape))
+        # web_dir as at test_dice.py:80-88
+        base = opt.name if opt.data_name is None else opt.data_name + '_by_' + opt.name
+        web_dir = os.path.join(opt.results_dir, base, '{}_{}'.format(opt.phase, opt.epoch))
+        if opt.load_iter > 0:
+            web_dir = '{:s}_iter{:d}'.format(web_dir, opt.load_iter)
+        os.makedirs(os.path.join(web_dir, 'volumes'), exist_ok=True)
+        np.save(os.path.join(web_dir, 'volumes', 'output_volume.npy'), out)
+        metrics = write_outputs(opt, web_dir, out, real, gt)
+        print('----Test done----')
+    return metrics
 
 
 if __name__ == '__main__':

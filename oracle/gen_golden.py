@@ -457,10 +457,34 @@ def gen_rotation():
     print('rotation', len(rows), len(crops))
 
 
+def gen_postproc():
+    """The numpy metrics of the test script's report, produced by the reference's own util/util.py functions
+    (normalize :56-71, standardize :111-112, get_psnr :114-119) in the order test_dice.py:244-253 applies them."""
+    ref_modules()
+    from util import util as rutil
+    rng = np.random.default_rng(91)
+    real = rng.integers(0, 65536, (24, 30, 36), dtype=np.uint16)
+    fake = np.clip(real.astype(np.float64) * 0.8 + rng.normal(0, 900, real.shape), 0, 65535).astype(np.uint16)
+    gt = np.clip(real.astype(np.float64) * 0.9 + rng.normal(0, 300, real.shape) + 500, 0, 65535).astype(np.uint16)
+    out = {}
+    vols = dict(real=real, fake=fake, gt=gt)
+    for k, v in vols.items():
+        for _ in range(2):  # the reference applies the pair twice
+            v = rutil.normalize(rutil.standardize(v), data_type=np.uint8)
+        out['n_' + k] = v
+    out['std_real'] = rutil.standardize(real)
+    out['norm16_fake'] = rutil.normalize(fake.astype(np.float64), data_type=np.uint16)
+    out['psnr_in'] = np.float64(rutil.get_psnr(out['n_real'], out['n_gt'], 255))
+    out['psnr_out'] = np.float64(rutil.get_psnr(out['n_fake'], out['n_gt'], 255))
+    out['mse'] = np.float64(rutil.get_mse(out['n_fake'].astype(float), out['n_gt'].astype(float)))
+    np.savez_compressed(os.path.join(OUT, 'postproc_metrics.npz'), seed=91, **out)
+    print('postproc', float(out['psnr_in']), float(out['psnr_out']))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     networks = ref_modules()
-    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice', 'rotation']
+    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice', 'rotation', 'postproc']
     if 'nets' in which:
         gen_nets(networks)
     if 'nets_wide' in which:
@@ -479,3 +503,5 @@ if __name__ == '__main__':
         gen_dice()
     if 'rotation' in which:
         gen_rotation()
+    if 'postproc' in which:
+        gen_postproc()
