@@ -42,6 +42,7 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = self.grad[off:off + k].view_as(p.data)
             off += k
         self.state_step = 0
+        ops.register_flat_grad(self.flat, self.grad)
         self._buckets = []
         self._overlap_armed = True
         self._overlap = overlap_all_reduce  # only for parameter sets whose gradients are all produced on ONE stream
@@ -53,12 +54,24 @@ class FlatAdam(torch.optim.Optimizer):
                 b['seen'] = 0
         if fill:
             self.grad.zero_()
+        ops.flat_grad_step_begin(self.flat)
+        # .grad = None: the whole-network backward calls write into slices of self.grad and hand autograd views of them,
+        # which AccumulateGrad adopts as they are; gradients that arrive any other way are collected by _collect()
+        for p in self.params:
+            p.grad = None
+
+    def _collect(self):
+        """Make self.grad hold every parameter's gradient and p.grad a view of it (gradients produced outside the direct
+        path -- layer-by-layer modules, clones made by autograd -- are copied in; a parameter without a gradient keeps
+        the zeros of zero_grad)."""
         off = 0
-        for p in self.params:  # re-attach the views if autograd replaced / dropped .grad
+        for p in self.params:
             k = p.numel()
-            g = self.grad[off:off + k].view_as(p.data)
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
-                p.grad = g
+            g = p.grad
+            if g is not None and g.data_ptr() != self.grad.data_ptr() + 4 * off:
+                view = self.grad[off:off + k].view_as(p.data)
+                view.copy_(g)
+                p.grad = view
             off += k
 
     # -- data-parallel gradient exchange ---------------------------------------------------------------------------
@@ -83,7 +96,7 @@ class FlatAdam(torch.optim.Optimizer):
             if off - start >= target or off == total:
                 bounds.append((start, off, members))
                 start, members = off, []
-        self._buckets = [dict(lo=lo, hi=hi, n=len(m), seen=0, work=None) for lo, hi, m in bounds]
+        self._buckets = [dict(lo=lo, hi=hi, n=len(m), seen=0, work=None, members=m) for lo, hi, m in bounds]
         for bi, (_, _, m) in enumerate(bounds):
             for p in m:
                 p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._grad_ready(bi))
@@ -92,6 +105,13 @@ class FlatAdam(torch.optim.Optimizer):
         b = self._buckets[bi]
         b['seen'] += 1
         if b['seen'] == b['n'] and self._overlap_armed:
+            # only when every gradient of the range already sits in the flat buffer (written there by the whole-network
+            # backward calls); otherwise all_reduce_mean() collects them first and exchanges the range synchronously
+            off = b['lo']
+            for p in b['members']:
+                if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                    return
+                off += p.numel()
             # the collective is ordered behind everything queued on the current stream (autograd runs this hook on the
             # stream that produced the gradient)
             b['work'] = torch.distributed.all_reduce(self.grad[b['lo']:b['hi']], async_op=True)
@@ -103,6 +123,7 @@ class FlatAdam(torch.optim.Optimizer):
         ws = dist.get_world_size()
         if ws == 1:
             return
+        self._collect()
         if self._buckets:
             for b in self._buckets:
                 if b['work'] is not None:
@@ -116,6 +137,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._collect()
         self.state_step += 1
         g = self.param_groups[0]
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1],

@@ -794,6 +794,36 @@ def _param_generation(t):
     return _param_gen.get(t.untyped_storage().data_ptr(), 0)
 
 
+# Direct gradient destination of the whole-network calls.  FlatAdam registers its flat gradient buffer under its flat
+# parameter buffer's storage; when a whole-network backward finds that its packed parameters ARE a slice of such a
+# buffer, it lets the kernels write the parameter gradients straight into the matching slice of the gradient buffer
+# (they overwrite, so only the first backward of a slice per optimizer step may do that) and returns views of it: with
+# p.grad = None autograd's AccumulateGrad adopts them -- no per-parameter add kernels, no extra copy.
+_flat_grads = {}   # storage ptr of the flat parameter buffer -> [grad buffer, set of slices written this step]
+
+
+def register_flat_grad(flat, grad):
+    _flat_grads[flat.untyped_storage().data_ptr()] = [grad, set()]
+
+
+def flat_grad_step_begin(flat):
+    ent = _flat_grads.get(flat.untyped_storage().data_ptr())
+    if ent is not None:
+        ent[1].clear()
+
+
+def _grad_destination(packed):
+    """A slice of the registered flat gradient buffer for these packed parameters, or a fresh tensor."""
+    ent = _flat_grads.get(packed.untyped_storage().data_ptr())
+    if ent is not None and os.environ.get('NC_DIRECT_GRADS', '1') != '0':
+        grad, written = ent
+        off, n = packed.storage_offset(), packed.numel()
+        if off + n <= grad.numel() and not any(a < off + n and off < b for a, b in written):
+            written.add((off, off + n))
+            return grad[off:off + n]
+    return torch.empty_like(packed)
+
+
 # ---- whole-network PatchGAN (nc_patchgan_fwd / nc_patchgan_bwd): one C call per direction -------------------------
 def _pack_params(params):
     """The parameter tensors as ONE flat fp32 tensor in the given order: a zero-copy view when they already sit back
@@ -856,7 +886,7 @@ class _PatchGAN(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         want_p = any(ctx.needs_input_grad[2:])
         dx = torch.empty_like(x) if want_x else None
-        dpar = torch.empty_like(ctx.packed) if want_p else None
+        dpar = _grad_destination(ctx.packed) if want_p else None
         L = lib()
         ws = workspace(L.nc_patchgan_ws_bytes(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
         check(L.nc_patchgan_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(B), I(D), I(H),
@@ -930,7 +960,7 @@ class _UnetDeconvTrain(torch.autograd.Function):
         N, _, S0, S1, S2 = x.shape
         L = lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = torch.empty_like(ctx.packed)
+        dpar = _grad_destination(ctx.packed)
         ws = workspace(L.nc_unet_deconv_train_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'unet_train')
         e0 = _prof_begin()
         check(L.nc_unet_deconv_bwd(_ptr(ctx.packed), _ptr(x), _ptr(y), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N),
@@ -982,7 +1012,7 @@ class _DeepLinear(torch.autograd.Function):
         N, _, S0, S1, S2 = x.shape
         L = lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = torch.empty_like(ctx.packed)
+        dpar = _grad_destination(ctx.packed)
         ws = workspace(L.nc_deep_linear_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'deep_linear')
         e0 = _prof_begin()
         check(L.nc_deep_linear_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N), I(S0), I(S1),
@@ -1053,7 +1083,7 @@ class _GenLp(torch.autograd.Function):
         pre = 'nc_unet_deconv_lp' if kind == 'unet' else 'nc_deep_linear_lp'
         dims = (I(N), I(S0), I(S1), I(S2))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = torch.empty_like(ctx.packed)
+        dpar = _grad_destination(ctx.packed)
         ws = workspace(getattr(L, pre + '_ws_bytes')(*dims), x.device, pre)
         dt = _DT['bf16']
         e0 = _prof_begin()

@@ -138,6 +138,7 @@ def _adam_worker(rank, world, port, out_path):
     opt.zero_grad()
     loss = (params[0] * (rank + 1)).sum() + (params[1] ** 2).sum() * (rank + 1)
     loss.backward()
+    opt._collect()  # gradients that autograd produced outside the flat buffer are copied into it
     g_local = opt.grad.clone()
     opt.all_reduce_mean()
     gathered = [torch.empty_like(g_local) for _ in range(world)]

@@ -510,3 +510,35 @@ def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, 
     if kind == 'linear':  # inference form (saved == NULL: activations ping-pong through the workspace)
         with torch.no_grad():
             assert torch.equal(net(x0), ya)
+
+
+def test_whole_network_backward_writes_gradients_in_place():
+    """The whole-network backward calls write parameter gradients straight into the optimizer's flat gradient buffer and
+    autograd adopts those views (no per-parameter add kernels): after an Apollo step's backward every generator / PatchGAN
+    parameter's .grad aliases its slice of FlatAdam.grad, and NC_DIRECT_GRADS=0 (separate tensors + accumulate) gives
+    bit-identical updates."""
+    from neuroclear_amd.models import create_model
+
+    def run(direct):
+        os.environ['NC_DIRECT_GRADS'] = '1' if direct else '0'
+        try:
+            torch.manual_seed(5)
+            np.random.seed(5)
+            model = create_model(_apollo_opt())
+            real = torch.from_numpy(rnd(77, (1, 1, 36, 36, 36))).to(DEV)
+            model.set_input({'A': real, 'A_paths': 'x'})
+            model.optimize_parameters()
+            alias = []
+            for opt in (model.optimizer_G, model.optimizer_D):
+                off = 0
+                for p in opt.params:
+                    alias.append(p.grad is not None and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * off)
+                    off += p.numel()
+            return model.optimizer_G.flat.clone(), model.optimizer_D.flat.clone(), alias, dict(model.get_current_losses())
+        finally:
+            os.environ.pop('NC_DIRECT_GRADS', None)
+
+    g1, d1, alias, l1 = run(True)
+    g0, d0, _, l0 = run(False)
+    assert all(alias)
+    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(d1, d0)
