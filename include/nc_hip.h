@@ -258,6 +258,15 @@ int nc_conv_fwd_c8(const void* xh, const float* w, const float* bias, void* yh, 
                    int W, int K, int kd, int kh, int kw, int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
 int nc_conv_dgrad_c8(const void* dyh, const float* w, void* dxh, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw,
                      int stride, int pad, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* One-channel layers (Conv3d(1, 64, ks, padding ks/2), ks = 3: networks.py:420 first U-Net layer; ks = 7: :899 first
+ * deep_linear layer) on the 16-bit cores in "pseudo-channel" form: the ks taps along x become 8 input channels
+ * X8[v][j] = x[v + j - ks/2], the layer a ks x ks x 1 convolution of that C8 tensor.  fwd: x fp32 [N,1,D,H,W] -> C8 result
+ * in channels [out_c0, out_c0 + 64); dgrad: dyh C8 [N][8][S][8] (bf16) -> dx fp32 [N,1,D,H,W].                        */
+size_t nc_conv_c1_c8_ws_bytes(int N, int D, int H, int W, int ks);
+int nc_conv_c1_fwd_c8(const float* x, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int D, int H, int W,
+                      int ks, int dtype, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_c1_dgrad_c8(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int ks, void* ws, size_t ws_bytes,
+                        void* stream);
 size_t nc_c8_instnorm_ws_bytes(int N, int C, long S);
 int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,
                          size_t ws_bytes, void* stream);

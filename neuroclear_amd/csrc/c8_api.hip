@@ -42,6 +42,26 @@ int nc_conv_dgrad_c8(const void* dyh, const float* w, void* dxh, int N, int C, i
   return conv_dgrad_h_c8(dyh, w, dxh, C, 0, d, dtype, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t nc_conv_c1_c8_ws_bytes(int N, int D, int H, int W, int ks) { return c1_h_supported(D, H, W, ks) ? c1_h_ws_bytes(N, D, H, W, ks) : 0; }
+
+int nc_conv_c1_fwd_c8(const float* x, const float* w, const float* bias, void* yh, int out_ctot, int out_c0, int N, int D, int H, int W,
+                      int ks, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w || !yh) { set_error("conv_c1_fwd_c8: null pointer"); return NC_ERR_ARG; }
+  if (!dt_ok(dtype)) { set_error("conv_c1_fwd_c8: dtype must be NC_DT_F16 or NC_DT_BF16"); return NC_ERR_ARG; }
+  if (N < 1 || !c1_h_supported(D, H, W, ks) || out_ctot % 8 || out_c0 % 8 || out_c0 + 64 > out_ctot) {
+    set_error("conv_c1_fwd_c8: shape not covered (kernel 3 or 7, 64 output channels)");
+    return NC_ERR_SHAPE;
+  }
+  return conv_c1_fwd_h(x, w, bias, yh, out_ctot, out_c0, N, D, H, W, ks, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_c1_dgrad_c8(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int ks, void* ws, size_t ws_bytes,
+                        void* stream) {
+  if (!dyh || !w || !dx) { set_error("conv_c1_dgrad_c8: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || !c1_h_supported(D, H, W, ks)) { set_error("conv_c1_dgrad_c8: shape not covered"); return NC_ERR_SHAPE; }
+  return conv_c1_dgrad_h(dyh, w, dx, N, D, H, W, ks, ws, ws_bytes, (hipStream_t)stream);
+}
+
 size_t nc_c8_instnorm_ws_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : c8_stats_ws_bytes(N, C, S); }
 
 int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,

@@ -116,6 +116,13 @@ int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int 
                   void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
                     size_t wsb, hipStream_t s);
+// one-channel KS^3 layers (KS = 3, 7) in "pseudo-channel" form on the 16-bit cores (conv_h.hip)
+bool c1_h_supported(int D, int H, int W, int KS);
+size_t c1_h_ws_bytes(int N, int D, int H, int W, int KS);
+int conv_c1_fwd_h(const float* x, const float* w, const float* bias, void* yh, int ctot, int c0, int N, int D, int H, int W, int KS,
+                  int dt, void* ws, size_t wsb, hipStream_t s);
+int conv_c1_dgrad_h(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int KS, void* ws, size_t wsb,
+                    hipStream_t s);
 
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;

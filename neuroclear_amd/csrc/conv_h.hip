@@ -135,6 +135,7 @@ struct HParams {
   float* y;           // fp32 NCDHW output, or
   uint2* yh;          // (non-null) 16-bit C8 output [N][ctot/8][S][8], this call's K channels starting at channel c0
   int ctot, c0;
+  int nblk_out;      // C8 epilogue: 8-channel blocks of the 64-channel tile that exist in the output (8 = all)
   const uint4* zeros; // >= 16 B of zeros in global memory
   int N, NCH, D, H, W, K;  // NCH = C / 16
   int P, R, RP;       // row pitch (units), brick rows, R * P
@@ -168,14 +169,16 @@ __device__ __forceinline__ HTile h_decode(const HParams& p, long t) {
   return o;
 }
 
-template <int DT, int KS, int VB>
+// Kernel box KZ x KY x KX ("same" padding KZ/2, KY/2, KX/2).  NA = 32-channel halves of the 64-channel tile that are
+// computed (1: only output channels 0..31 -- layers with <= 32 real output channels).
+template <int DT, int KZ, int KY, int KX, bool PAIR, int VB, int NA>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-  constexpr int PAD = KS / 2, T2 = KS * KS;
-  // 3^3: a k-step = 16 channels (two C8 blocks) at one tap.  5^3 ("PAIR"): a k-step = 8 channels (one C8 block) at TWO
-  // taps, lane half h taking tap 2i + h (the 26th tap has zero weights): half the brick and half the weights per
-  // stage, which is what lets two stage buffers of a 5^3 layer fit in 160 KB (13 k-steps for 25 taps: 4 % padding).
-  constexpr bool PAIR = KS == 5;
+  constexpr int PADZ = KZ / 2, PADY = KY / 2, PADX = KX / 2, T2 = KY * KX;
+  // !PAIR (3^3): a k-step = 16 channels (two C8 blocks) at one tap.  PAIR (5^3, and the 8-pseudo-channel layers): a k-step
+  // = 8 channels (one C8 block) at TWO taps, lane half h taking tap 2i + h (an odd tap count ends in a zero-weight tap):
+  // half the brick and half the weights per stage, which is what lets two stage buffers of a 5^3 layer fit in 160 KB
+  // (13 k-steps for 25 taps: 4 % padding).
   constexpr int NB = PAIR ? 1 : 2;                    // C8 blocks per chunk
   constexpr int KSTEPS = PAIR ? (T2 + 1) / 2 : T2;    // k-steps per stage
   constexpr int MAXJ = 6;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
@@ -198,18 +201,18 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
       const unsigned hh = (!PAIR && u >= (unsigned)p.RP) ? 1u : 0u;
       const unsigned ur = u - hh * p.RP;
       const unsigned rr = fdiv(ur, p.mP);
-      const int xx = (int)(ur - rr * p.P) - PAD;
-      const int y = t.yf - PAD + (int)rr;
+      const int xx = (int)(ur - rr * p.P) - PADX;
+      const int y = t.yf - PADY + (int)rr;
       const bool ok = ur < (unsigned)p.RP && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       off[j] = ok ? (int)(hh * S + (long)y * p.W + xx) : -1;
     }
   };
   // valid dz range of a tile (planes outside the volume contribute nothing: their stages are skipped)
-  auto dz_lo = [&](const HTile& t) { return PAD - t.z > 0 ? PAD - t.z : 0; };
-  auto dz_hi = [&](const HTile& t) { return t.z + PAD > p.D - 1 ? KS - 1 - (t.z + PAD - (p.D - 1)) : KS - 1; };
+  auto dz_lo = [&](const HTile& t) { return PADZ - t.z > 0 ? PADZ - t.z : 0; };
+  auto dz_hi = [&](const HTile& t) { return t.z + PADZ > p.D - 1 ? KZ - 1 - (t.z + PADZ - (p.D - 1)) : KZ - 1; };
 
   auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
-    const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * NB * p.D + (tz + dz - PAD)) * HW;
+    const uint4* plane = p.xh + (((long)tn * p.NCH + chunk) * NB * p.D + (tz + dz - PADZ)) * HW;
     if (p.ablate & 4) return;
     if (p.ablate & 32) plane = p.xh + ((long)chunk * NB * p.D + 1) * HW;  // every tile stages the same plane: all L2 hits
 #pragma unroll
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
       }
     }
-    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KS + dz) * (KSTEPS * 128) + lane;
+    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KZ + dz) * (KSTEPS * 128) + lane;
     unsigned char* wb = buf + p.npb * 1024;
 #pragma unroll 1
     for (int pw = wave; pw < p.npw; pw += kWaves)
@@ -244,9 +247,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
     if (more_tiles) nxt = h_decode(p, tnext);
     const int nstages = p.NCH * nv;
 
-    f32x16 acc[2][VB];
+    f32x16 acc[NA][VB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int v = 0; v < VB; ++v)
 #pragma unroll
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
         auto boff = [&](int i) {  // this lane's tap of k-step i, as a unit offset
           const int t0 = 2 * i, t1 = 2 * i + 1 < T2 ? 2 * i + 1 : T2 - 1;
-          const int o0 = (t0 / KS) * p.P + t0 % KS, o1 = (t1 / KS) * p.P + t1 % KS;
+          const int o0 = (t0 / KX) * p.P + t0 % KX, o1 = (t1 / KX) * p.P + t1 % KX;
           return h ? o1 : o0;
         };
         i32x4 a0 = wrow[0], a1 = wrow[64], b[VB], na0, na1, nb[VB];
@@ -296,10 +299,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
 #pragma unroll
           for (int v = 0; v < VB; ++v) {
             acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
-            acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
+            if constexpr (NA == 2) acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
           }
           __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * VB, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NA * VB, 0);
           a0 = na0; a1 = na1;
 #pragma unroll
           for (int v = 0; v < VB; ++v) b[v] = nb[v];
@@ -315,14 +318,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
 #pragma unroll
       for (int v = 0; v < VB; ++v) b[v] = brow[v * 32];
 #pragma unroll 1
-      for (int dy = 0; dy < KS; ++dy) {
-        const bool last_row = dy == KS - 1;
-        const i32x4* wrow_n = last_row ? wrow : wrow + KS * 128;  // after the last row: any in-range address
+      for (int dy = 0; dy < KY; ++dy) {
+        const bool last_row = dy == KY - 1;
+        const i32x4* wrow_n = last_row ? wrow : wrow + KX * 128;  // after the last row: any in-range address
         const i32x4* brow_n = last_row ? brow : brow + p.P;
 #pragma unroll
-        for (int dx = 0; dx < KS; ++dx) {
-          const i32x4* wn = dx + 1 < KS ? wrow + (dx + 1) * 128 : wrow_n;
-          const i32x4* bnp = dx + 1 < KS ? brow + dx + 1 : brow_n;
+        for (int dx = 0; dx < KX; ++dx) {
+          const i32x4* wn = dx + 1 < KX ? wrow + (dx + 1) * 128 : wrow_n;
+          const i32x4* bnp = dx + 1 < KX ? brow + dx + 1 : brow_n;
           if (p.ablate & 8) {
             na0 = a0; na1 = a1;
 #pragma unroll
@@ -335,10 +338,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
 #pragma unroll
           for (int v = 0; v < VB; ++v) {
             acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
-            acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
+            if constexpr (NA == 2) acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
           }
           __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);  // DS reads of the next tap ...
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * VB, 0);  // ... then this tap's MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, NA * VB, 0);  // ... then this tap's MFMAs
           a0 = na0; a1 = na1;
 #pragma unroll
           for (int v = 0; v < VB; ++v) b[v] = nb[v];
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         yo[v] = ((int)yy < p.H && (int)xx < p.W) ? (long)yy * p.W + xx : -1;
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < NA; ++a) {
         float bv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
@@ -374,6 +377,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
           if (yo[v] >= 0) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+              if (a * 4 + g4 >= p.nblk_out) continue;
               uint2 o;
               o.x = cvt16<DT>(acc[a][v][4 * g4] + bv[4 * g4]) | ((unsigned)cvt16<DT>(acc[a][v][4 * g4 + 1] + bv[4 * g4 + 1]) << 16);
               o.y = cvt16<DT>(acc[a][v][4 * g4 + 2] + bv[4 * g4 + 2]) | ((unsigned)cvt16<DT>(acc[a][v][4 * g4 + 3] + bv[4 * g4 + 3]) << 16);
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
         yo[v] = ((int)yy < p.H && (int)xx < p.W) ? (long)yy * p.W + xx : -1;
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {  // one 32-channel half at a time: 16 bias registers live, not 32
+      for (int a = 0; a < NA; ++a) {  // one 32-channel half at a time: 16 bias registers live, not 32
         float bv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
@@ -422,25 +426,25 @@ struct HPlan {
   bool ok;
 };
 
-HPlan h_plan(const ConvDims& d) {
+// ky x kx: in-plane taps; pair: 8-channel chunks at two taps per k-step
+HPlan h_plan_box(int H, int W, int ky, int kx, bool pair) {
   HPlan pl{};
-  const int KS = d.kd, T2 = KS * KS;
-  const bool pair = KS == 5;
-  pl.P = d.W + KS - 1;
+  const int T2 = ky * kx;
+  pl.P = W + kx - 1;
   pl.npw = (pair ? (T2 + 1) / 2 : T2) * 2;
-  const long plane = (long)d.H * pl.P;
+  const long plane = (long)H * pl.P;
   double best = 0;
   for (int VB : {4, 2, 1}) {
     const int PT = VB * 256;
     const int rows = (pl.P - 1 + PT - 1) / pl.P + 1;
-    const int R = rows + KS - 1;
+    const int R = rows + ky - 1;
     const int RP = R * pl.P;
     const int npb = ((pair ? 1 : 2) * RP + 4 + 63) / 64;
     const int SB = (npb + pl.npw) * 1024;
     if (npb > 48 || 2 * SB > kLdsMaxH) continue;
     const int TPP = (int)((plane + PT - 1) / PT);
     // cost ~ positions computed per useful position, with a small bonus for the larger tile (operand reuse)
-    const double eff = (double)d.H * d.W / ((double)TPP * PT) * (VB == 4 ? 1.0 : VB == 2 ? 0.93 : 0.8);
+    const double eff = (double)H * W / ((double)TPP * PT) * (VB == 4 ? 1.0 : VB == 2 ? 0.93 : 0.8);
     if (eff > best) {
       best = eff;
       pl.PT = PT; pl.VB = VB; pl.R = R; pl.RP = RP; pl.npb = npb; pl.SB = SB; pl.TPP = TPP;
@@ -449,6 +453,8 @@ HPlan h_plan(const ConvDims& d) {
   }
   return pl;
 }
+
+HPlan h_plan(const ConvDims& d) { return h_plan_box(d.H, d.W, d.kh, d.kw, d.kd == 5); }
 
 bool h_shape_ok(const ConvDims& d, int Cin, int Kout) {
   if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
@@ -464,9 +470,9 @@ size_t packed_bytes(int Cin, int Kout, int KS) {
 }
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-template <int DT, int KS, int VB>
+template <int DT, int KZ, int KY, int KX, bool PAIR, int VB, int NA>
 int launch_h(const HParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_h<DT, KS, VB>;
+  auto kern = k_conv_h<DT, KZ, KY, KX, PAIR, VB, NA>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxH) !=
@@ -480,12 +486,12 @@ int launch_h(const HParams& p, int lds, hipStream_t s) {
   return check_launch("conv_h");
 }
 
-template <int DT, int KS>
+template <int DT, int KZ, int KY, int KX, bool PAIR, int NA>
 int launch_h_vb(int VB, const HParams& p, int lds, hipStream_t s) {
   switch (VB) {
-    case 4: return launch_h<DT, KS, 4>(p, lds, s);
-    case 2: return launch_h<DT, KS, 2>(p, lds, s);
-    default: return launch_h<DT, KS, 1>(p, lds, s);
+    case 4: return launch_h<DT, KZ, KY, KX, PAIR, 4, NA>(p, lds, s);
+    case 2: return launch_h<DT, KZ, KY, KX, PAIR, 2, NA>(p, lds, s);
+    default: return launch_h<DT, KZ, KY, KX, PAIR, 1, NA>(p, lds, s);
   }
 }
 
@@ -518,7 +524,7 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   if (int e = check_launch("pack_w_h")) return e;
   HParams p{};
   p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
-  p.yh = (uint2*)yh; p.ctot = yh ? ctot : Kout; p.c0 = c0;
+  p.yh = (uint2*)yh; p.ctot = yh ? ctot : Kout; p.c0 = c0; p.nblk_out = 8;
   p.N = d.N; p.NCH = KS == 5 ? Cin / 8 : Cin / 16; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
   p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.mP = magic(pl.P); p.mRP = magic(pl.RP);
@@ -528,8 +534,145 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   static const int ablate = getenv("NC_H_ABLATE") ? atoi(getenv("NC_H_ABLATE")) : 0;
   p.ablate = ablate;
   const int lds = 2 * pl.SB;
-  if (KS == 3) return launch_h_vb<DT, 3>(pl.VB, p, lds, s);
-  return launch_h_vb<DT, 5>(pl.VB, p, lds, s);
+  if (KS == 3) return launch_h_vb<DT, 3, 3, 3, false, 2>(pl.VB, p, lds, s);
+  return launch_h_vb<DT, 5, 5, 5, true, 2>(pl.VB, p, lds, s);
+}
+
+// ---- one-channel layers on the 16-bit cores: "pseudo-channel" form ------------------------------------------------------
+// A KS^3 convolution with ONE input channel (networks.py:420 first U-Net layer 3^3, :899 first deep_linear layer 7^3)
+// becomes a KS x KS x 1 convolution with 8 input channels when the KS taps along x are moved into the channel axis:
+//   X8[v][j] = x[v + (0, 0, j - KS/2)]  (j < KS; 0 beyond the row)        y[k][v] = sum_(dz,dy) sum_j w[k][dz][dy][j] X8[v + (dz,dy)][j]
+// X8 is an ordinary C8 tensor with one 8-channel block (16 B per voxel), so the layer runs on k_conv_h in PAIR mode with
+// the box KS x KS x 1.  The data gradient of the same layer (64 -> 1 channel) is the mirror image: a KS x KS x 1
+// convolution 64 -> 8 pseudo-channels with z/y-flipped taps, DX8[v][j] = sum_k sum_(dz,dy) w[k][dz][dy][j] dy[k][v - (dz,dy)],
+// followed by the fold dx[u] = sum_j DX8[u - (0, 0, j - KS/2)][j] (k_fold_x8); it computes only the first 32-channel half
+// of the tile (NA = 1: 8 real + 24 zero output channels).
+template <int DT>
+__global__ void __launch_bounds__(256) k_build_x8(const float* __restrict__ x, uint4* __restrict__ x8, int W, int KS, long total) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= total) return;
+  const int xw = (int)(v % W);
+  unsigned short e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int xx = xw + j - KS / 2;
+    e[j] = (j < KS && xx >= 0 && xx < W) ? cvt16<DT>(x[v + j - KS / 2]) : (unsigned short)0;
+  }
+  uint4 o;
+  o.x = e[0] | ((unsigned)e[1] << 16); o.y = e[2] | ((unsigned)e[3] << 16);
+  o.z = e[4] | ((unsigned)e[5] << 16); o.w = e[6] | ((unsigned)e[7] << 16);
+  x8[v] = o;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256) k_fold_x8(const uint4* __restrict__ dx8, float* __restrict__ dx, int W, int KS, long total) {
+  const long u = (long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= total) return;
+  const int xw = (int)(u % W);
+  float a = 0.f;
+  for (int j = 0; j < KS; ++j) {
+    const int xx = xw - (j - KS / 2);
+    if (xx < 0 || xx >= W) continue;
+    const uint4 q = dx8[u - (j - KS / 2)];
+    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+    const unsigned short hv = (unsigned short)((w4[j >> 1] >> ((j & 1) * 16)) & 0xffff);
+    a += DT == NC_DT_F16 ? (float)__builtin_bit_cast(_Float16, hv) : __builtin_bit_cast(float, (unsigned)hv << 16);
+  }
+  dx[u] = a;
+}
+
+// PAIR packing [cot = 0][chunk][dz][i = dy pair][a][h][r][8] of the pseudo-channel layers, from w[K][1][KS][KS][KS]:
+//   fwd  (chunk = 0, 8 pseudo-channels -> K = 64):   element (co = a*32 + r, j, tap dy = 2i + h) = w[co][dz][dy][j]
+//   dgrad (chunks = K/8 of the real channels -> 8):  element (co = a*32 + r = j', ci = chunk*8 + j, tap) = w[ci][KS-1-dz][KS-1-dy][j']
+template <int DT>
+__global__ void __launch_bounds__(256) k_pack_w_x8(const float* __restrict__ w, unsigned short* __restrict__ wp, int KS, int NCH,
+                                                   int dgrad, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int NP = (KS + 1) / 2, T3 = KS * KS * KS;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int r = (int)(q & 31); q >>= 5;
+  const int h = (int)(q & 1); q >>= 1;
+  const int a = (int)(q & 1); q >>= 1;
+  const int pr = (int)(q % NP); q /= NP;
+  const int dz = (int)(q % KS); q /= KS;
+  const int chunk = (int)q;
+  (void)NCH;
+  const int dy = 2 * pr + h, co = a * 32 + r;
+  float v = 0.f;
+  if (dy < KS) {
+    if (!dgrad) {
+      if (j < KS) v = w[(long)co * T3 + (dz * KS + dy) * KS + j];
+    } else if (co < KS) {
+      v = w[(long)(chunk * 8 + j) * T3 + ((KS - 1 - dz) * KS + (KS - 1 - dy)) * KS + co];
+    }
+  }
+  wp[i] = cvt16<DT>(v);
+}
+
+size_t x8_packed_bytes(int KS, int chunks) { return (size_t)chunks * KS * ((KS + 1) / 2) * 2 * 2 * 32 * 8 * 2; }
+
+// forward of a one-channel KS^3 layer (KS = 3 or 7): x fp32 [N][1][D][H][W] -> C8 [N][ctot/8][S][8] channels [c0, c0 + 64)
+template <int DT>
+int run_c1_fwd(const float* x, const float* w, const float* bias, void* yh, int ctot, int c0, int N, int D, int H, int W, int KS,
+               void* ws, size_t wsb, hipStream_t s) {
+  const long S = (long)D * H * W;
+  const HPlan pl = h_plan_box(H, W, KS, 1, true);
+  const size_t xb = align256((size_t)N * S * 16), wb = align256(x8_packed_bytes(KS, 1));
+  if (!pl.ok) { set_error("conv_c1_fwd_h: shape not covered"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < xb + wb + 256) { set_error("conv_c1_fwd_h: workspace too small"); return NC_ERR_WS; }
+  uint4* x8 = (uint4*)ws;
+  unsigned short* wp = (unsigned short*)((char*)ws + xb);
+  uint4* zeros = (uint4*)((char*)ws + xb + wb);
+  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_fwd_h: memset failed"); return NC_ERR_HIP; }
+  hipLaunchKernelGGL((k_build_x8<DT>), dim3((unsigned)cdiv(N * S, 256)), dim3(256), 0, s, x, x8, W, KS, N * S);
+  const long total = (long)(x8_packed_bytes(KS, 1) / 2);
+  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 1, 0, total);
+  if (int e = check_launch("c1_fwd_h prep")) return e;
+  HParams p{};
+  p.xh = x8; p.wp = (const uint4*)wp; p.bias = bias; p.y = nullptr; p.zeros = zeros;
+  p.yh = (uint2*)yh; p.ctot = ctot; p.c0 = c0; p.nblk_out = 8;
+  p.N = N; p.NCH = 1; p.D = D; p.H = H; p.W = W; p.K = 64;
+  p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = 1;
+  p.mP = magic(pl.P); p.mRP = magic(pl.RP);
+  p.npb = pl.npb; p.npw = pl.npw; p.SB = pl.SB;
+  p.ntiles = (long)N * D * pl.TPP;
+  p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
+  const int lds = 2 * pl.SB;
+  if (KS == 7) return launch_h_vb<DT, 7, 7, 1, true, 2>(pl.VB, p, lds, s);
+  return launch_h_vb<DT, 3, 3, 1, true, 2>(pl.VB, p, lds, s);
+}
+
+// data gradient of the same layer: dyh C8 [N][8][S][8] (64 channels, bf16) -> dx fp32 [N][1][D][H][W]
+template <int DT>
+int run_c1_dgrad(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int KS, void* ws, size_t wsb, hipStream_t s) {
+  const long S = (long)D * H * W;
+  const HPlan pl = h_plan_box(H, W, KS, 1, true);
+  const size_t xb = align256((size_t)N * S * 16), wb = align256(x8_packed_bytes(KS, 8));
+  if (!pl.ok) { set_error("conv_c1_dgrad_h: shape not covered"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < xb + wb + 256) { set_error("conv_c1_dgrad_h: workspace too small"); return NC_ERR_WS; }
+  uint4* dx8 = (uint4*)ws;
+  unsigned short* wp = (unsigned short*)((char*)ws + xb);
+  uint4* zeros = (uint4*)((char*)ws + xb + wb);
+  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_dgrad_h: memset failed"); return NC_ERR_HIP; }
+  const long total = (long)(x8_packed_bytes(KS, 8) / 2);
+  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 8, 1, total);
+  if (int e = check_launch("c1_dgrad_h pack")) return e;
+  HParams p{};
+  p.xh = (const uint4*)dyh; p.wp = (const uint4*)wp; p.bias = nullptr; p.y = nullptr; p.zeros = zeros;
+  p.yh = (uint2*)dx8; p.ctot = 8; p.c0 = 0; p.nblk_out = 1;
+  p.N = N; p.NCH = 8; p.D = D; p.H = H; p.W = W; p.K = 64;
+  p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = 1;
+  p.mP = magic(pl.P); p.mRP = magic(pl.RP);
+  p.npb = pl.npb; p.npw = pl.npw; p.SB = pl.SB;
+  p.ntiles = (long)N * D * pl.TPP;
+  p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
+  const int lds = 2 * pl.SB;
+  int e = KS == 7 ? launch_h_vb<DT, 7, 7, 1, true, 1>(pl.VB, p, lds, s) : launch_h_vb<DT, 3, 3, 1, true, 1>(pl.VB, p, lds, s);
+  if (e) return e;
+  hipLaunchKernelGGL((k_fold_x8<DT>), dim3((unsigned)cdiv(N * S, 256)), dim3(256), 0, s, dx8, dx, W, KS, N * S);
+  return check_launch("c1_dgrad_h fold");
 }
 
 
@@ -903,6 +1046,30 @@ int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0
   ProfScope ps(1, 1, d, 1, s);
   if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
   return run_h<NC_DT_BF16>(nullptr, dyh, w, nullptr, nullptr, d, d.K, d.C, T3, d.C * T3, 1, ws, wsb, s, dxh, ctot, c0);
+}
+
+bool c1_h_supported(int D, int H, int W, int KS) {
+  if (KS != 3 && KS != 7) return false;
+  if ((long)D * H * W * 2 >= (1l << 31)) return false;
+  return h_plan_box(H, W, KS, 1, true).ok;
+}
+size_t c1_h_ws_bytes(int N, int D, int H, int W, int KS) {
+  return align256((size_t)N * D * H * W * 16) + align256(x8_packed_bytes(KS, 8)) + 512;
+}
+int conv_c1_fwd_h(const float* x, const float* w, const float* bias, void* yh, int ctot, int c0, int N, int D, int H, int W, int KS,
+                  int dt, void* ws, size_t wsb, hipStream_t s) {
+  ConvDims d;
+  make_dims(d, N, 1, D, H, W, 64, KS, KS, KS, 1, KS / 2);
+  ProfScope ps(0, 1, d, 1, s);
+  if (dt == NC_DT_F16) return run_c1_fwd<NC_DT_F16>(x, w, bias, yh, ctot, c0, N, D, H, W, KS, ws, wsb, s);
+  return run_c1_fwd<NC_DT_BF16>(x, w, bias, yh, ctot, c0, N, D, H, W, KS, ws, wsb, s);
+}
+int conv_c1_dgrad_h(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int KS, void* ws, size_t wsb,
+                    hipStream_t s) {
+  ConvDims d;
+  make_dims(d, N, 1, D, H, W, 64, KS, KS, KS, 1, KS / 2);
+  ProfScope ps(1, 1, d, 1, s);
+  return run_c1_dgrad<NC_DT_BF16>(dyh, w, dx, N, D, H, W, KS, ws, wsb, s);
 }
 
 int conv_dgrad_h(const float* dy, const void* dyh, const float* w, float* dx, const ConvDims& d, int dt, void* ws,

@@ -70,8 +70,8 @@ struct ULp {
   long S[3];
   size_t raw0, a1, cat1, p1, a2, cat2, p2, b1, b2, b3, e2a, e2b, e1, t1, raw[10], mean[10], rstd[10], saved;
   size_t G1, G2, G3, H1, H2, H3, Q1, Q2, s1, s2, F1, F2, grads;
-  size_t conv_ws, in_ws, c8_ws, convT_ws, o64_ws, f32conv_ws;
-  bool ok;
+  size_t conv_ws, in_ws, c8_ws, convT_ws, o64_ws, f32conv_ws, c1_ws;
+  bool ok, c1;  // c1: block 0 (1 -> 64 channels) on the 16-bit cores in pseudo-channel form (conv_h.hip)
 };
 
 bool ulp_plan(ULp& p, int N, int S0, int S1, int S2) {
@@ -85,7 +85,8 @@ bool ulp_plan(ULp& p, int N, int S0, int S1, int S2) {
   const size_t n = (size_t)N, S = (size_t)p.S[0], Sh = (size_t)p.S[1], Sq = (size_t)p.S[2];
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t r = off; off += al(bytes); return r; };
-  p.raw0 = take(n * 64 * S * 4);
+  p.c1 = c1_h_supported(S0, S1, S2, 3);
+  p.raw0 = take(n * 64 * S * (p.c1 ? 2 : 4));
   p.a1 = take(n * 64 * S * 2); p.cat1 = take(n * 128 * S * 2); p.p1 = take(n * 64 * Sh * 2); p.a2 = take(n * 128 * Sh * 2);
   p.cat2 = take(n * 256 * Sh * 2); p.p2 = take(n * 128 * Sq * 2); p.b1 = take(n * 256 * Sq * 2); p.b2 = take(n * 256 * Sq * 2);
   p.b3 = take(n * 256 * Sq * 2); p.e2a = take(n * 128 * Sh * 2); p.e2b = take(n * 128 * Sh * 2); p.e1 = take(n * 64 * S * 2);
@@ -120,14 +121,16 @@ bool ulp_plan(ULp& p, int N, int S0, int S1, int S2) {
   const size_t c2 = convT_h_ws_bytes(N, 128, p.d[1][0], p.d[1][1], p.d[1][2], 64);
   if (c2 > p.convT_ws) p.convT_ws = c2;
   p.o64_ws = c8_outer64_ws_bytes(N, (long)S);
+  p.c1_ws = p.c1 ? c1_h_ws_bytes(N, S0, S1, S2, 3) : 0;
   return true;
 }
 
 size_t ulp_ws_bytes(const ULp& p, bool bwd) {
-  return al(p.conv_ws) + al(p.f32conv_ws) + al(p.in_ws) + al(p.c8_ws) + al(p.convT_ws) + al(p.o64_ws) + (bwd ? p.grads : 0) + 256;
+  return al(p.conv_ws) + al(p.f32conv_ws) + al(p.in_ws) + al(p.c8_ws) + al(p.convT_ws) + al(p.o64_ws) + al(p.c1_ws) +
+         (bwd ? p.grads : 0) + 256;
 }
 
-struct UWs { void *cws, *fws, *iws, *c8ws, *tws, *ows; char* G; };
+struct UWs { void *cws, *fws, *iws, *c8ws, *tws, *ows, *c1ws; char* G; };
 UWs ulp_ws(const ULp& p, void* ws) {
   UWs u;
   char* b = (char*)ws;
@@ -137,6 +140,7 @@ UWs ulp_ws(const ULp& p, void* ws) {
   u.c8ws = b; b += al(p.c8_ws);
   u.tws = b; b += al(p.convT_ws);
   u.ows = b; b += al(p.o64_ws);
+  u.c1ws = b; b += al(p.c1_ws);
   u.G = b;
   return u;
 }
@@ -187,10 +191,17 @@ int nc_unet_deconv_lp_fwd(const float* params, const float* x, float* y, void* s
   };
   const long S = p.S[0];
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
-  // block 0 (1 -> 64 channels): the fp32 one-channel kernel, statistics in fp32, the activation leaves as C8
-  NC_TRY(nc_conv_fwd(x, P + o.w[0], P + o.b[0], F(p.raw0), N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream));
-  NC_TRY(nc_instnorm_stats(F(p.raw0), N * 64, S, 1e-5f, F(p.mean[0]), F(p.rstd[0]), u.iws, p.in_ws, stream));
-  NC_TRY(nc_instnorm_act_fwd_c8(F(p.raw0), F(p.mean[0]), F(p.rstd[0]), 0.f, nullptr, V + p.a1, N, 64, S, dt, stream));
+  if (p.c1) {
+    // block 0 (1 -> 64 channels) in pseudo-channel form on the 16-bit cores: raw output, statistics and activation as C8
+    NC_TRY(conv_c1_fwd_h(x, P + o.w[0], P + o.b[0], V + p.raw0, 64, 0, N, d0[0], d0[1], d0[2], 3, dt, u.c1ws, p.c1_ws, hs));
+    NC_TRY(c8_instnorm_stats(V + p.raw0, N, 64, S, 1e-5f, F(p.mean[0]), F(p.rstd[0]), dt, u.c8ws, p.c8_ws, hs));
+    NC_TRY(c8_instnorm_apply(V + p.raw0, F(p.mean[0]), F(p.rstd[0]), 0.f, V + p.a1, 64, 0, N, 64, S, dt, hs));
+  } else {
+    // (shapes the 16-bit one-channel form does not cover) the fp32 one-channel kernel; the activation leaves as C8
+    NC_TRY(nc_conv_fwd(x, P + o.w[0], P + o.b[0], F(p.raw0), N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream));
+    NC_TRY(nc_instnorm_stats(F(p.raw0), N * 64, S, 1e-5f, F(p.mean[0]), F(p.rstd[0]), u.iws, p.in_ws, stream));
+    NC_TRY(nc_instnorm_act_fwd_c8(F(p.raw0), F(p.mean[0]), F(p.rstd[0]), 0.f, nullptr, V + p.a1, N, 64, S, dt, stream));
+  }
   NC_TRY(block(1, V + p.a1, V + p.cat1, 128, 0));
   NC_TRY(c8_maxpool_fwd(V + p.cat1, 128, 0, V + p.p1, N, 64, d0[0], d0[1], d0[2], dt, hs));
   NC_TRY(block(2, V + p.p1, V + p.a2, 128, 0));
@@ -267,9 +278,18 @@ int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, c
   NC_TRY(block_bwd(2, G + p.H1, 128, 0, V + p.p1, G + p.H2, G + p.H1));
   NC_TRY(c8_maxpool_bwd_add(G + p.H1, V + p.cat1, 128, 0, G + p.G3, 128, 0, G + p.G1, N, 64, d0[0], d0[1], d0[2], dt, hs));
   NC_TRY(block_bwd(1, G + p.G1, 64, 0, V + p.a1, G + p.G2, G + p.G1));
-  // block 0 in fp32 (one input channel): gradient C8 -> fp32, then the fp32 kernels
   float* f1 = (float*)(G + p.F1);
   float* f2 = (float*)(G + p.F2);
+  if (p.c1) {
+    // block 0: InstanceNorm backward on C8; the data gradient (if wanted) in pseudo-channel form; the weight gradient
+    // of the one-channel layer on the fp32 tap-axis kernel, fed with the fp32 copy of the C8 gradient
+    NC_TRY(c8_instnorm_bwd(G + p.G1, 64, 0, V + p.raw0, F(p.mean[0]), F(p.rstd[0]), 0.f, G + p.G2, DP + o.b[0], N, 64, S, dt, u.c8ws,
+                           p.c8_ws, hs));
+    if (dx) NC_TRY(conv_c1_dgrad_h(G + p.G2, P + o.w[0], dx, N, d0[0], d0[1], d0[2], 3, u.c1ws, p.c1_ws, hs));
+    NC_TRY(c8_to_f32(G + p.G2, 64, 0, f2, N, 64, S, NC_DT_BF16, hs));
+    return nc_conv_wgrad(x, f2, DP + o.w[0], nullptr, N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream);
+  }
+  // block 0 in fp32 (one input channel): gradient C8 -> fp32, then the fp32 kernels
   NC_TRY(c8_to_f32(G + p.G1, 64, 0, f1, N, 64, S, NC_DT_BF16, hs));
   NC_TRY(nc_instnorm_act_bwd_dbias(f1, F(p.raw0), F(p.mean[0]), F(p.rstd[0]), 0.f, f2, DP + o.b[0], N, 64, S, u.iws, p.in_ws, stream));
   if (dx) NC_TRY(nc_conv_dgrad(f2, P + o.w[0], dx, N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream));
@@ -326,8 +346,8 @@ struct LLp {
   size_t w[6];
   size_t f1h, f2h, f3h, weff, u1, saved;        // bytes into saved
   size_t F, A, B, q, grads;                      // bytes into the scratch
-  size_t conv_ws, f32conv_ws, o64_ws;
-  bool ok;
+  size_t conv_ws, f32conv_ws, o64_ws, c1_ws;
+  bool ok, c1;
 };
 
 bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
@@ -356,10 +376,12 @@ bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
   }
   p.f32conv_ws = nc_conv_ws_bytes(N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3);
   p.o64_ws = c8_outer64_ws_bytes(N, p.S);
+  p.c1 = c1_h_supported(S0, S1, S2, 7);
+  p.c1_ws = p.c1 ? c1_h_ws_bytes(N, S0, S1, S2, 7) : 0;
   return true;
 }
 
-size_t llp_ws_bytes(const LLp& p) { return al(p.conv_ws) + al(p.f32conv_ws) + al(p.o64_ws) + p.grads + 256; }
+size_t llp_ws_bytes(const LLp& p) { return al(p.conv_ws) + al(p.f32conv_ws) + al(p.o64_ws) + al(p.c1_ws) + p.grads + 256; }
 
 }  // namespace
 
@@ -388,12 +410,18 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
   hipStream_t hs = (hipStream_t)stream;
   char* cws = (char*)ws;
   char* fws = cws + al(p.conv_ws);
-  char* G = fws + al(p.f32conv_ws) + al(p.o64_ws);
+  char* c1ws = fws + al(p.f32conv_ws) + al(p.o64_ws);
+  char* G = c1ws + al(p.c1_ws);
   char* V = (char*)saved;
   float* Ff = (float*)(G + p.F);
-  // 7^3, one input channel: fp32 kernel, then the 64-channel result becomes C8
-  NC_TRY(nc_conv_fwd(x, params + p.w[0], nullptr, Ff, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream));
-  NC_TRY(to_c8(Ff, V + p.f1h, N, 64, p.S, dtype, hs));
+  if (p.c1) {
+    // 7^3, one input channel, in pseudo-channel form on the 16-bit cores: straight to C8
+    NC_TRY(conv_c1_fwd_h(x, params + p.w[0], nullptr, V + p.f1h, 64, 0, N, S0, S1, S2, 7, dtype, c1ws, p.c1_ws, hs));
+  } else {
+    // fp32 one-channel kernel, then the 64-channel result becomes C8
+    NC_TRY(nc_conv_fwd(x, params + p.w[0], nullptr, Ff, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream));
+    NC_TRY(to_c8(Ff, V + p.f1h, N, 64, p.S, dtype, hs));
+  }
   ConvDims c5, c3;
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
@@ -416,7 +444,8 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   char* cws = (char*)ws;
   char* fws = cws + al(p.conv_ws);
   char* ows = fws + al(p.f32conv_ws);
-  char* G = ows + al(p.o64_ws);
+  char* c1ws = ows + al(p.o64_ws);
+  char* G = c1ws + al(p.c1_ws);
   const char* V = (const char*)saved;
   float* q = (float*)(G + p.q);
   // tail: df3 = w_eff (x) dy (C8), q = sum dy f3
@@ -439,6 +468,14 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
     NC_TRY(conv_wgrad_h(nullptr, V + p.f1h, nullptr, G + p.B, dparams + p.w[1], c5, NC_DT_BF16, cws, p.conv_ws, hs));
   }
   float* Ff = (float*)(G + p.F);
+  if (p.c1) {
+    // df1 stays C8 (in A: df3 is no longer needed); data gradient of the 7^3 layer in pseudo-channel form; its weight
+    // gradient on the fp32 tap-axis kernel, fed with the fp32 copy of df1
+    NC_TRY(conv_dgrad_h_c8(G + p.B, params + p.w[1], G + p.A, 64, 0, c5, NC_DT_BF16, cws, p.conv_ws, hs));
+    if (dx) NC_TRY(conv_c1_dgrad_h(G + p.A, params + p.w[0], dx, N, S0, S1, S2, 7, c1ws, p.c1_ws, hs));
+    NC_TRY(c8_to_f32(G + p.A, 64, 0, Ff, N, 64, p.S, NC_DT_BF16, hs));
+    return nc_conv_wgrad(x, Ff, dparams + p.w[0], nullptr, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream);
+  }
   {
     ProfScope ps(1, 1, c5, 1, hs);
     NC_TRY(conv_dgrad_h(nullptr, G + p.B, params + p.w[1], Ff, c5, NC_DT_BF16, cws, p.conv_ws, hs));

@@ -227,6 +227,37 @@ def test_convT_c8(N, C, K, dims):
     assert float((db - dyr.sum((0, 2, 3, 4))).abs().max()) <= 1e-4 * float(dyr.sum((0, 2, 3, 4)).abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize('ks', [3, 7])
+@pytest.mark.parametrize('N,dims', [(1, (9, 12, 20)), (2, (8, 17, 33)), (1, (20, 40, 148))])
+def test_one_channel_layers_pseudo_channel_form(N, dims, ks):
+    """Conv3d(1, 64, ks) forward and its data gradient on the 16-bit cores (taps along x folded into 8 pseudo-channels)
+    against torch on the bf16-rounded operands; the result is rounded to bf16 once (forward) / the 8 partial sums per
+    voxel are rounded to bf16 before the fold (data gradient): 2^-7 of the largest value."""
+    D, H, W = dims
+    S = D * H * W
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(N, 1, D, H, W, device=DEV, generator=g)
+    w = torch.randn(64, 1, ks, ks, ks, device=DEV, generator=g) / ks ** 1.5
+    b = torch.randn(64, device=DEV, generator=g)
+    dy = torch.randn(N, 64, D, H, W, device=DEV, generator=g)
+    xr, wr, dyr = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    nb = L().nc_conv_c1_c8_ws_bytes(N, D, H, W, ks)
+    assert nb > 0
+    wsb = ws(nb)
+    ctot = 64 + 16
+    out = torch.zeros(N, ctot // 8, S, 8, dtype=torch.bfloat16, device=DEV)
+    ok(L().nc_conv_c1_fwd_c8(P(x), P(w), P(b), P(out), ctot, 8, N, D, H, W, ks, BF, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    ref = F.conv3d(xr, wr, b, padding=ks // 2)
+    got = from_c8(out[:, 1:9], ref.shape)
+    assert float((got - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert float(out[:, 0].float().abs().max()) == 0.0 and float(out[:, 9].float().abs().max()) == 0.0
+    dx = torch.empty(N, 1, D, H, W, device=DEV)
+    ok(L().nc_conv_c1_dgrad_c8(P(to_c8(dy, BF)), P(w), P(dx), N, D, H, W, ks, P(wsb), ctypes.c_size_t(wsb.numel()), None))
+    ref = F.conv_transpose3d(dyr, wr, padding=ks // 2)
+    assert float((dx - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert float((dx - ref).abs().mean()) <= 2 ** -9 * float(ref.abs().max())
+
+
 def _nets():
     from neuroclear_amd.models import networks
     from neuroclear_amd.util import seed as S
