@@ -174,9 +174,18 @@ struct TWParams {
   long Sc;
 };
 
-// wgrad: wave = (ct, kt) tile of 32 x 32 for all 8 sub-positions, over a contiguous share of the 16-voxel steps
+// wgrad: one wave = a (ct, kt) tile of 32 x 32 for all 8 sub-positions, over a contiguous share of the 16-voxel steps.
+// Per step the wave loads the 16 voxels x 32 channels of x and, for each sub-position, of dy as whole 16-byte units
+// (lane = (C8 block, voxel): coalesced), parks them in a private LDS image [block][voxel][8 channels] and takes the MFMA
+// fragments -- 8 consecutive VOXELS of one channel per lane -- with the transposing LDS read ds_read_b64_tr_b16 (lane
+// 4q + p of a 16-lane group supplies the address of voxel row q, channels 4p..4p+3; lane i receives channel i of the 4 rows).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* ltr_t;
+
 template <int DT>
 __global__ void __launch_bounds__(64) k_convT_wgrad_h(const TWParams p) {
+  constexpr int BS = 20;  // units between the 4 blocks of an image (16 voxels + 4: spreads the banks)
+  __shared__ __attribute__((aligned(16))) uint4 img[9 * 4 * BS];
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int KT = p.K / 32;
   const int kt = blockIdx.x % KT, ct = blockIdx.x / KT, split = blockIdx.y;
@@ -189,36 +198,48 @@ __global__ void __launch_bounds__(64) k_convT_wgrad_h(const TWParams p) {
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  const int ci = ct * 32 + r, k = kt * 32 + r;
-  for (long st = s_lo; st < s_hi; ++st) {
+  // loader role: C8 block cb of the tile, voxel j of the step
+  const int cb = lane >> 4, j = lane & 15;
+  const uint4* xg = reinterpret_cast<const uint4*>(p.x);
+  const uint4* yg = reinterpret_cast<const uint4*>(p.dy);
+  // reader role (transposed read): group g -> channels 16 (g & 1).., voxel half g >> 1
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int cbsel = 2 * (g & 1) + (pp >> 1);
+  const unsigned rd = (unsigned)((cbsel * BS + 8 * (g >> 1) + q) * 16 + (pp & 1) * 8);  // + 64 for voxels 4..7 of the half
+  unsigned char* lds = reinterpret_cast<unsigned char*>(img);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  uint4 nx = zero4, ny[8];
+  auto fetch = [&](long st) {
     const int n = (int)(st / steps_per_n);
-    const long v0 = (st - (long)n * steps_per_n) * 16 + 8 * h;
-    const unsigned short* xs = p.x + (((long)n * (p.C >> 3) + (ci >> 3)) * p.Sc) * 8 + (ci & 7);
-    const unsigned short* ys = p.dy + (((long)n * p.dctot8 + p.dc08 + (k >> 3)) * Sf) * 8 + (k & 7);
-    unsigned short av[8];
-    long vf[8];
-    bool okv[8];
+    const long v = (st - (long)n * steps_per_n) * 16 + j;
+    const bool ok = v < p.Sc;
+    const long vc = ok ? v : p.Sc - 1;
+    const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
+    const long vf = ((long)(2 * zd) * Hf + 2 * yh) * Wf + 2 * xw;
+    nx = ok ? xg[((long)n * (p.C >> 3) + ct * 4 + cb) * p.Sc + vc] : zero4;
+    const uint4* yb = yg + ((long)n * p.dctot8 + p.dc08 + kt * 4 + cb) * Sf + vf;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const long v = v0 + j;
-      okv[j] = v < p.Sc;
-      const long vc = okv[j] ? v : p.Sc - 1;
-      av[j] = okv[j] ? xs[vc * 8] : (unsigned short)0;
-      const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
-      vf[j] = ((long)(2 * zd) * Hf + 2 * yh) * Wf + 2 * xw;
-    }
+    for (int t = 0; t < 8; ++t) ny[t] = ok ? yb[((long)(t >> 2) * Hf + ((t >> 1) & 1)) * Wf + (t & 1)] : zero4;
+  };
+  if (s_lo < s_hi) fetch(s_lo);
+  for (long st = s_lo; st < s_hi; ++st) {
+    img[cb * BS + j] = nx;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) img[(1 + t) * 4 * BS + cb * BS + j] = ny[t];
+    if (st + 1 < s_hi) fetch(st + 1);  // next step's units fly under this step's MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the image is written (one wave: no barrier needed)
     i32x4 a;
-    a[0] = av[0] | ((unsigned)av[1] << 16); a[1] = av[2] | ((unsigned)av[3] << 16);
-    a[2] = av[4] | ((unsigned)av[5] << 16); a[3] = av[6] | ((unsigned)av[7] << 16);
+    {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + rd));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + rd + 64));
+      a = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const long to = ((long)(t >> 2) * Hf + ((t >> 1) & 1)) * Wf + (t & 1);
-      unsigned short bv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = okv[j] ? ys[(vf[j] + to) * 8] : (unsigned short)0;
-      i32x4 b;
-      b[0] = bv[0] | ((unsigned)bv[1] << 16); b[1] = bv[2] | ((unsigned)bv[3] << 16);
-      b[2] = bv[4] | ((unsigned)bv[5] << 16); b[3] = bv[6] | ((unsigned)bv[7] << 16);
+      const unsigned base = (unsigned)((1 + t) * 4 * BS * 16) + rd;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + base));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + base + 64));
+      const i32x4 b = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       acc[t] = mfma16<DT>(a, b, acc[t]);
     }
   }
