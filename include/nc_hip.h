@@ -199,6 +199,15 @@ size_t nc_match_histograms_ws_bytes(long n);
 int nc_match_histograms(const float* source, const float* tmpl, float* out, long n, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* ---- torch.nn.utils.spectral_norm on a convolution weight (NLayerDiscriminatorSN, networks.py:1069-1111; --netD
+ *      basic_SN / n_layers_SN).  w_orig viewed as [K][M]; power_iteration = 1 (training): v <- normalize(W^T u),
+ *      u <- normalize(W v) in place (eps 1e-12), then sigma = u . W v and w_out = W / sigma; 0 (eval): u, v as stored.
+ *      scratch_k: K floats.  bwd: dw_orig = (g - <g, w_sn> u v^T) / sigma (u, v are constants of the forward).          */
+int nc_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* w_out, float* sigma, float* scratch_k, int K, int M,
+                         int power_iteration, float eps, void* stream);
+int nc_spectral_norm_bwd(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma, float* dw_orig, int K,
+                         int M, void* stream);
+
 /* ---- Whole-network PatchGAN (NLayerDiscriminator with InstanceNorm, networks.py:1009-1067; called from
  *      apollo_model.py:195-283 through netD_*): forward and backward as ONE call each (the op-by-op path is
  *      host-enqueue-bound on these ~25-kernel chains).  params = the 2 * (n_layers + 2) tensors in state-dict order,

@@ -242,6 +242,8 @@ class AxialToLateralGANApolloModel(BaseModel):
     def _D(netD, planes):
         # every plane is [N, C, A, B] (N = batch): plane i owns rows i*N .. (i+1)*N of the batched prediction, and the
         # LSGAN mean of a plane runs over its whole batch, as the reference's per-plane netD call does (apollo:169-193)
+        if getattr(netD, 'one_plane_per_call', False):  # spectral norm: every call moves (u, v), keep the reference's calls
+            return [netD(pl) for pl in planes]
         pred = netD(planes[0] if len(planes) == 1 else torch.cat(planes, 0))
         n = planes[0].shape[0]
         return [pred[i * n:(i + 1) * n] for i in range(len(planes))]

@@ -152,6 +152,59 @@ class ConvTranspose(nn.Module):
         return ops.conv_transpose_k2s2(x, self.weight, self.bias)
 
 
+class SpectralConv(nn.Module):
+    """nn.utils.spectral_norm(nn.Conv{2,3}d(...)) (networks.py:1079-1102): parameters `weight_orig` (+ `bias`), buffers
+    `weight_u` [K] and `weight_v` [C * taps] -- the state-dict keys of torch's hook.  Every forward in training mode runs
+    one power iteration on (u, v) and convolves with weight_orig / sigma (nc_spectral_norm_fwd + the conv kernels).
+    `weight` is a plain attribute, as under torch's hook: the reference's init_weights writes into it, which the next
+    forward overwrites -- weight_orig keeps the Conv default initialisation there, and so it does here."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, dimension=3):
+        super().__init__()
+        self.stride, self.padding, self.dimension = stride, padding, dimension
+        self.weight_orig = nn.Parameter(torch.empty((out_channels, in_channels) + (kernel_size,) * dimension))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        init.kaiming_uniform_(self.weight_orig, a=5 ** 0.5)
+        m = self.weight_orig.numel() // out_channels
+        self.register_buffer('weight_u', torch.nn.functional.normalize(torch.randn(out_channels), dim=0, eps=1e-12))
+        self.register_buffer('weight_v', torch.nn.functional.normalize(torch.randn(m), dim=0, eps=1e-12))
+        self.weight = self.weight_orig.detach().clone()
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.weight = fn(self.weight)
+        return r
+
+    def forward(self, x):
+        w = ops.spectral_norm_weight(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        self.weight = w.detach()
+        return ops.conv(x, w, self.bias, self.stride, self.padding)
+
+
+class NLayerDiscriminatorSN(nn.Module):
+    """networks.py:1069-1111: the PatchGAN with every convolution spectrally normalised, no norm layers; only the first
+    and the last convolution carry a bias."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, dimension=3):
+        super().__init__()
+        if use_sigmoid:
+            raise NotImplementedError('use_sigmoid=True is never set by the hot-path models (apollo:108-123)')
+        kw, padw = 4, 1
+        seq = [SpectralConv(input_nc, ndf, kw, 2, padw, dimension=dimension), LeakyReLU(0.2)]
+        nf_mult = 1
+        for n in range(1, n_layers):
+            nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+            seq += [SpectralConv(ndf * nf_prev, ndf * nf_mult, kw, 2, padw, bias=False, dimension=dimension), LeakyReLU(0.2)]
+        nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+        seq += [SpectralConv(ndf * nf_prev, ndf * nf_mult, kw, 1, padw, bias=False, dimension=dimension), LeakyReLU(0.2)]
+        seq += [SpectralConv(ndf * nf_mult, 1, kw, 1, padw, dimension=dimension)]
+        self.model = nn.Sequential(*seq)
+        self.one_plane_per_call = True  # a forward updates (u, v): planes must go through one by one, as in the reference
+
+    def forward(self, input):
+        return self.model(input)
+
+
 def conv(dimension):
     if dimension not in (2, 3):
         raise Exception('Invalid image dimension.')
@@ -446,7 +499,11 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
         net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer, use_sigmoid, dimension)
     elif netD == 'pixel':
         net = PixelDiscriminator(input_nc, ndf, norm_layer, dimension)
-    elif netD in ('basic_SN', 'n_layers_SN', 'kernelGAN'):
+    elif netD == 'basic_SN':
+        net = NLayerDiscriminatorSN(input_nc, ndf, 3, norm_layer, use_sigmoid, dimension)
+    elif netD == 'n_layers_SN':
+        net = NLayerDiscriminatorSN(input_nc, ndf, n_layers_D, norm_layer, use_sigmoid, dimension)
+    elif netD in ('kernelGAN',):
         raise NotImplementedError('Discriminator [%s] is outside the MI355X hot path (SURVEY.md 8a)' % netD)
     else:
         raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)

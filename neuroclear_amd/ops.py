@@ -1105,3 +1105,40 @@ def unet_deconv_lp(x, params):
 
 def deep_linear_lp(x, params):
     return _GenLp.apply(x, 'linear', *params)
+
+
+# ---- torch.nn.utils.spectral_norm (NLayerDiscriminatorSN, networks.py:1069-1111) ------------------------------------
+class _SpectralNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_orig, u, v, power_iteration):
+        w_orig = w_orig.contiguous()
+        _chk(w_orig, u, v)
+        _f32(w_orig, u, v)
+        K = w_orig.shape[0]
+        M = w_orig.numel() // K
+        if u.numel() != K or v.numel() != M:
+            raise _lib.NcError('spectral_norm: u / v do not match the weight (%d x %d)' % (K, M))
+        w = torch.empty_like(w_orig)
+        sigma = torch.empty(1, dtype=torch.float32, device=w_orig.device)
+        scratch = torch.empty(K, dtype=torch.float32, device=w_orig.device)
+        check(lib().nc_spectral_norm_fwd(_ptr(w_orig), _ptr(u), _ptr(v), _ptr(w), _ptr(sigma), _ptr(scratch), I(K), I(M),
+                                         I(1 if power_iteration else 0), F(1e-12), _stream()), 'nc_spectral_norm_fwd')
+        # u, v as they stand after this forward (later forwards update the buffers in place)
+        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        w, u, v, sigma = ctx.saved_tensors
+        g = g.contiguous()
+        K = w.shape[0]
+        M = w.numel() // K
+        dw = torch.empty_like(w)
+        check(lib().nc_spectral_norm_bwd(_ptr(g), _ptr(w), _ptr(u), _ptr(v), _ptr(sigma), _ptr(dw), I(K), I(M), _stream()),
+              'nc_spectral_norm_bwd')
+        return dw, None, None, None
+
+
+def spectral_norm_weight(w_orig, u, v, power_iteration):
+    """weight = w_orig / sigma with one power iteration on (u, v) (in place) when `power_iteration`."""
+    return _SpectralNorm.apply(w_orig, u, v, bool(power_iteration))

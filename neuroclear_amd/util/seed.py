@@ -79,6 +79,29 @@ def patchgan_spec(dimension=2, input_nc=1, ndf=64, n_layers=3):
     return spec
 
 
+def patchgan_sn_spec(dimension=2, input_nc=1, ndf=64, n_layers=3):
+    """(key, shape) list of ``NLayerDiscriminatorSN`` (``models/networks.py:1069-1111``) in state-dict order: per conv
+    ``bias`` (first and last conv only), ``weight_orig``, ``weight_u`` [K], ``weight_v`` [C * taps]; Sequential indices
+    0, 2, 4, ... (conv, LeakyReLU pairs)."""
+    k = (4,) * dimension
+    taps = 4 ** dimension
+    chans = [(input_nc, ndf, True)]
+    nf = 1
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        chans.append((ndf * nf_prev, ndf * nf, False))
+    nf_prev, nf = nf, min(2 ** n_layers, 8)
+    chans.append((ndf * nf_prev, ndf * nf, False))
+    chans.append((ndf * nf, 1, True))
+    spec = []
+    for i, (c, kk, bias) in enumerate(chans):
+        pre = 'model.%d.' % (2 * i)
+        if bias:
+            spec.append((pre + 'bias', (kk,)))
+        spec += [(pre + 'weight_orig', (kk, c) + k), (pre + 'weight_u', (kk,)), (pre + 'weight_v', (c * taps,))]
+    return spec
+
+
 def unet_vanilla_spec(dimension=3):
     """(key, shape) list of ``Unet_vanilla`` (``models/networks.py:540-574``), input_nc forced to 1 (``:176``):
     three double_conv levels, a double_conv bottom at 512 channels, three transposed convs, one 1x1 head."""
@@ -132,9 +155,12 @@ def weights_from_seed(spec, seed, bias_scale=0.1):
     out = OrderedDict()
     for idx, (key, shape) in enumerate(spec):
         rng = np.random.default_rng([int(seed), idx])
-        if key.endswith('.weight'):
+        if key.endswith('.weight') or key.endswith('.weight_orig'):
             std = np.sqrt(2.0 / _fan_in(key, shape))
             out[key] = (rng.standard_normal(shape) * std).astype(np.float32)
+        elif key.endswith('.weight_u') or key.endswith('.weight_v'):  # spectral-norm power-iteration vectors: unit length
+            t = rng.standard_normal(shape)
+            out[key] = (t / np.linalg.norm(t)).astype(np.float32)
         else:
             out[key] = rng.uniform(-bias_scale, bias_scale, size=shape).astype(np.float32)
     return out

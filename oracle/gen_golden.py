@@ -457,6 +457,31 @@ def gen_rotation():
     print('rotation', len(rows), len(crops))
 
 
+def gen_sn(networks):
+    """NLayerDiscriminatorSN (--netD basic_SN): two successive training-mode forwards (the power-iteration vectors move
+    between them), backward of the second; outputs, input gradient, parameter-gradient summaries and the final u of
+    every conv.  bias / weight_orig / u / v all come from the seed (loaded through load_state_dict)."""
+    import contextlib
+    import io
+    for tag, dim, shape, seed in (('2d_36', 2, (2, 1, 36, 36), 33), ('3d_28', 3, (1, 1, 28, 28, 28), 34)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = networks.define_D(1, 64, 'basic_SN', 3, 'instance', 'kaiming', 0.02, False, [], dimension=dim)
+        load_sd(net, S.weights_from_seed(S.patchgan_sn_spec(dim), seed))
+        net.train()
+        x = torch.from_numpy(rand_input(100 + seed, shape)).requires_grad_(True)
+        y1 = net(x).detach().numpy().copy()
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        named = [(k, p.grad) for k, p in net.named_parameters()]
+        l2, sm, samp = grad_summary(named)
+        us = np.concatenate([b.detach().numpy().ravel() for k, b in net.named_buffers() if k.endswith('weight_u')])
+        np.savez_compressed(os.path.join(OUT, 'patchgan_sn_%s.npz' % tag), seed=seed, dim=dim, x_seed=100 + seed, r_seed=200 + seed,
+                            shape=np.array(shape), y1=y1, y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm, g_samp=samp,
+                            g_names=np.array([k for k, _ in named]), u_final=us)
+        print('patchgan_sn', tag, tuple(y.shape), float(np.abs(y1).max()))
+
+
 def gen_postproc():
     """The numpy metrics of the test script's report, produced by the reference's own util/util.py functions
     (normalize :56-71, standardize :111-112, get_psnr :114-119) in the order test_dice.py:244-253 applies them."""
@@ -484,7 +509,7 @@ def gen_postproc():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     networks = ref_modules()
-    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice', 'rotation', 'postproc']
+    which = sys.argv[1:] or ['nets', 'nets_wide', 'apollo', 'athena', 'dryops', 'dice', 'rotation', 'postproc', 'sn']
     if 'nets' in which:
         gen_nets(networks)
     if 'nets_wide' in which:
@@ -505,3 +530,5 @@ if __name__ == '__main__':
         gen_rotation()
     if 'postproc' in which:
         gen_postproc()
+    if 'sn' in which:
+        gen_sn(networks)

@@ -88,6 +88,34 @@ def patchgan(sd, x, n_layers=3):
     return _conv(x, sd, 'model.%d' % idx, stride=1, padding=1)
 
 
+def spectral_weight(sd, name, training=True):
+    """torch.nn.utils.spectral_norm's forward pre-hook (legacy hook, n_power_iterations = 1, eps = 1e-12, dim = 0) on the
+    conv `name`: one power iteration updating sd[name + '.weight_u'/'_v'] IN PLACE (training), then weight_orig / sigma."""
+    w = sd[name + '.weight_orig']
+    u, v = sd[name + '.weight_u'], sd[name + '.weight_v']
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=1e-12))
+    sigma = torch.dot(u.detach().clone(), torch.mv(wm, v.detach().clone()))
+    return w / sigma
+
+
+def patchgan_sn(sd, x, n_layers=3, training=True):
+    """networks.py:1069-1111 (NLayerDiscriminatorSN): spectrally normalised convs + LeakyReLU(0.2), no norm layers; bias on
+    the first and last conv only.  Each call performs one power iteration per conv, like a forward of the module."""
+    conv = F.conv3d if x.dim() == 5 else F.conv2d
+    n_conv = n_layers + 2
+    for i in range(n_conv):
+        name = 'model.%d' % (2 * i)
+        stride = 2 if i < n_layers else 1
+        x = conv(x, spectral_weight(sd, name, training), sd.get(name + '.bias'), stride=stride, padding=1)
+        if i < n_conv - 1:
+            x = F.leaky_relu(x, 0.2)
+    return x
+
+
 def unet_vanilla(sd, x):
     """networks.py:576-608: four-level U-Net, double_conv everywhere, single 1x1 head + sigmoid."""
     pool = F.max_pool3d if x.dim() == 5 else F.max_pool2d

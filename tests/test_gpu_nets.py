@@ -542,3 +542,38 @@ def test_whole_network_backward_writes_gradients_in_place():
     g0, d0, _, l0 = run(False)
     assert all(alias)
     assert l1 == l0 and torch.equal(g1, g0) and torch.equal(d1, d0)
+
+
+@pytest.mark.parametrize('tag', ['2d_36', '3d_28'])
+def test_patchgan_spectral_norm(golden_dir, tag):
+    """--netD basic_SN (NLayerDiscriminatorSN, networks.py:1069-1111) against the reference's own outputs: two training-mode
+    forwards (the power-iteration vectors move in between), backward of the second, the final u of every convolution; the
+    state dict round-trips with torch's spectral_norm key names."""
+    g = G(golden_dir, 'patchgan_sn_%s.npz' % tag)
+    dim = int(g['dim'])
+    net = networks.define_D(1, 64, 'basic_SN', 3, 'instance', 'kaiming', 0.02, False, [0], dimension=dim)
+    spec = S.patchgan_sn_spec(dim)
+    assert list(net.state_dict().keys()) == [k for k, _ in spec]
+    load(net, spec, int(g['seed']))
+    net.train()
+    x = torch.from_numpy(rnd(g['x_seed'], g['shape'])).to(DEV).requires_grad_(True)
+    y1 = net(x)
+    assert relmax(y1.detach().cpu().numpy(), g['y1']) < 5e-4
+    y = net(x)
+    assert relmax(y.detach().cpu().numpy(), g['y']) < 5e-4
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < 2e-3
+    params = dict(net.named_parameters())
+    for i, k in enumerate(str(n) for n in g['g_names']):
+        gr = params[k].grad.detach().cpu().numpy().ravel()
+        l2 = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(l2 - g['g_l2'][i]) <= 2e-3 * g['g_l2'][i] + 1e-9, (k, l2, g['g_l2'][i])
+    us = np.concatenate([b.detach().cpu().numpy().ravel() for k, b in net.named_buffers() if k.endswith('weight_u')])
+    assert float(np.abs(us - g['u_final']).max()) < 1e-4
+    # eval mode: no power iteration -- u stays put
+    net.eval()
+    with torch.no_grad():
+        net(x)
+    us2 = np.concatenate([b.detach().cpu().numpy().ravel() for k, b in net.named_buffers() if k.endswith('weight_u')])
+    assert np.array_equal(us, us2)

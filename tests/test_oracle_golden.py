@@ -221,3 +221,28 @@ def test_dryops_step(golden_dir, tag):
         w = [i for i, p in enumerate(before[n]) if p.dim() > 1]
         upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(model.n.sd[n].values(), before[n])])
         np.testing.assert_allclose(upd[w], g['upd_' + n][w], rtol=2e-3, err_msg=n)
+
+
+@pytest.mark.parametrize('tag', ['2d_36', '3d_28'])
+def test_patchgan_sn(golden_dir, tag):
+    """Spectral-norm PatchGAN (--netD basic_SN): two training-mode forwards (u, v move), backward of the second."""
+    g = G(golden_dir, 'patchgan_sn_%s.npz' % tag)
+    dim = int(g['dim'])
+    sd = nets.to_torch(S.weights_from_seed(S.patchgan_sn_spec(dim), int(g['seed'])))
+    names = [str(n) for n in g['g_names']]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = torch.from_numpy(rnd(g['x_seed'], g['shape'])).requires_grad_(True)
+    y1 = nets.patchgan_sn(sd, x)
+    np.testing.assert_allclose(y1.detach().numpy(), g['y1'], rtol=1e-4, atol=1e-6)
+    y = nets.patchgan_sn(sd, x)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], rtol=1e-4, atol=1e-6)
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape))
+    (y * r).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['dx'], atol=2e-4 * np.abs(g['dx']).max())
+    for i, k in enumerate(names):
+        gr = sd[k].grad.numpy().ravel()
+        l2 = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(l2 - g['g_l2'][i]) <= 1e-3 * max(1e-9, g['g_l2'][i]), k
+    us = np.concatenate([sd[k].detach().numpy().ravel() for k in sd if k.endswith('weight_u')])
+    np.testing.assert_allclose(us, g['u_final'], atol=1e-5)
