@@ -162,8 +162,9 @@ class SpectralConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, dimension=3):
         super().__init__()
         self.stride, self.padding, self.dimension = stride, padding, dimension
-        self.weight_orig = nn.Parameter(torch.empty((out_channels, in_channels) + (kernel_size,) * dimension))
+        # registration order = torch's state-dict order under the hook: bias, weight_orig, then the buffers u, v
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.weight_orig = nn.Parameter(torch.empty((out_channels, in_channels) + (kernel_size,) * dimension))
         init.kaiming_uniform_(self.weight_orig, a=5 ** 0.5)
         m = self.weight_orig.numel() // out_channels
         self.register_buffer('weight_u', torch.nn.functional.normalize(torch.randn(out_channels), dim=0, eps=1e-12))
