@@ -43,8 +43,9 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
-    'fwd_lp_k3': 'k_conv_h<*,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,*>',
-    'dgrad_lp_k5': 'k_conv_h<*,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
+    'fwd_lp_k3': 'k_conv_h<*,3,3,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,3,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>',
+    'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
+    'fwd_lp_k7': 'k_conv_h<*,7,7,1,*> (pseudo-channel form)', 'dgrad_lp_k7': 'k_conv_h<*,7,7,1,*,1> + k_fold_x8',
 }
 
 
@@ -57,7 +58,7 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
 
 def pmc_traffic(tag, crop=108, batch=1):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
     if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
         return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
@@ -219,7 +220,9 @@ def run_train(args, rank, world, dev):
         dt = float(t.item())
     # ---- per-kernel-class event statistics of the timed region (rank-local): HIP events recorded inside the library
     #      around every convolution launch of >= 1 GFLOP, on the stream it was launched on
-    conv_ms = sum(s[1] for s in stats.values())
+    # (the PatchGAN launches -- gather-GEMM / k1 classes -- run on side streams underneath the generators' kernels: their
+    #  event durations overlap the main stream's and are left out of the main-stream sum)
+    conv_ms = sum(s[1] for t, s in stats.items() if '_gemm_' not in t and '_k1_' not in t)
     calls = {}
     for tag, fl, ms in whole:
         c = calls.setdefault(tag, [0, 0.0, 0.0])
