@@ -376,7 +376,14 @@ size_t nc_instnorm_ws_bytes(int NC, long S) {
 int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, float* rstd, void* ws, size_t ws_bytes,
                       void* stream) {
   if (!x || !mean || !rstd) { set_error("instnorm_stats: null pointer"); return NC_ERR_ARG; }
-  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_stats: bad shape NC=%d S=%ld", NC, S); return NC_ERR_SHAPE; }
+  if (NC > 65535) {  // grid.y limit: instances in chunks (stream-ordered reuse of the workspace)
+    for (int c0 = 0; c0 < NC; c0 += 65535) {
+      const int n = NC - c0 < 65535 ? NC - c0 : 65535;
+      if (int e = nc_instnorm_stats(x + (long)c0 * S, n, S, eps, mean + c0, rstd + c0, ws, ws_bytes, stream)) return e;
+    }
+    return NC_OK;
+  }
+  if (NC < 1 || S < 1) { set_error("instnorm_stats: bad shape NC=%d S=%ld", NC, S); return NC_ERR_SHAPE; }
   if (!ws || ws_bytes < nc_instnorm_ws_bytes(NC, S)) { set_error("instnorm_stats: workspace too small"); return NC_ERR_WS; }
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(NC, S);
@@ -389,7 +396,14 @@ int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, fl
 int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, float slope, float* y, int NC, long S,
                         void* stream) {
   if (!x || !mean || !rstd || !y) { set_error("instnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
-  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
+  if (NC > 65535) {
+    for (int c0 = 0; c0 < NC; c0 += 65535) {
+      const int n = NC - c0 < 65535 ? NC - c0 : 65535;
+      if (int e = nc_instnorm_act_fwd(x + (long)c0 * S, mean + c0, rstd + c0, slope, y + (long)c0 * S, n, S, stream)) return e;
+    }
+    return NC_OK;
+  }
+  if (NC < 1 || S < 1) { set_error("instnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
   long bx = cdiv(S, 1024 * 4);
   if (bx > 1024) bx = 1024;
   hipLaunchKernelGGL(k_in_act_fwd, dim3((unsigned)bx, NC), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, slope, y, S);
@@ -399,7 +413,15 @@ int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, fl
 int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                         int NC, long S, void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !x || !mean || !rstd || !dx) { set_error("instnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
-  if (NC < 1 || S < 1 || NC > 65535) { set_error("instnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (NC > 65535) {
+    for (int c0 = 0; c0 < NC; c0 += 65535) {
+      const int n = NC - c0 < 65535 ? NC - c0 : 65535;
+      if (int e = nc_instnorm_act_bwd(dy + (long)c0 * S, x + (long)c0 * S, mean + c0, rstd + c0, slope, dx + (long)c0 * S, n, S, ws,
+                                      ws_bytes, stream)) return e;
+    }
+    return NC_OK;
+  }
+  if (NC < 1 || S < 1) { set_error("instnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
   if (!ws || ws_bytes < nc_instnorm_ws_bytes(NC, S)) { set_error("instnorm_act_bwd: workspace too small"); return NC_ERR_WS; }
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(NC, S);

@@ -114,8 +114,19 @@ class AxialToLateralGANAthenaModel(BaseModel):
         return function(ops.volume_all_slices(input, slice_axis))
 
     def backward_D_basic(self, netD, real, fake, slice_axis_real, slice_axis_fake):
-        pred_real = self.iter_f(real, netD, slice_axis_real)
-        pred_fake = self.iter_f(fake.detach(), netD, slice_axis_fake)
+        """athena:190-238.  The slices of `real` and of `fake` go through netD as ONE batch (InstanceNorm is per instance
+        and each LSGAN mean runs over its own half, so every number is what two passes give; the GEMMs are twice as long
+        and there are half as many launches).  A discriminator whose forward has side effects per call (spectral norm's
+        power iteration) keeps the reference's two calls."""
+        sr = ops.volume_all_slices(real, slice_axis_real)
+        sf = ops.volume_all_slices(fake.detach(), slice_axis_fake)
+        if not (real.shape[-1] == real.shape[-2] == real.shape[-3]):
+            raise ValueError('Athena assumes cubic crops (num_slice = shape[-3] is used for every axis)')
+        if getattr(netD, 'one_plane_per_call', False):
+            pred_real, pred_fake = netD(sr), netD(sf)
+        else:
+            pred = netD(torch.cat([sr, sf], 0))
+            pred_real, pred_fake = pred[:sr.shape[0]], pred[sr.shape[0]:]
         loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
         loss_D.backward()
         return loss_D
