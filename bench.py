@@ -389,7 +389,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=1, warmup=1)
-        inf = dict(metric='voxels/sec (useful output voxels of the 900^3 volume, assemble included)',
+        inf = dict(metric='voxels/sec (useful output voxels of the %d^3 volume, assemble included)' % args.volume,
                    value=iunits / idt, unit='voxels/s', seconds_per_volume=idt, n_gpus=world, scaling='strong',
                    dtype='f32', config=icfg)
         if iroof:
