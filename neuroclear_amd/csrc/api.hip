@@ -1,5 +1,6 @@
 // C-ABI glue: error reporting, convolution dispatch (MFMA implicit GEMM vs direct), and the whole-network forward of
 // Unet_deconv used by diced inference (reference models/networks.py:512-538 via models/test_model.py:60-62).
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -44,13 +45,19 @@ ProfScope::~ProfScope() {
   if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, s);
 }
 
+// NC_SCONV=0 switches the image-staged kernels of the PatchGAN layers off (A/B runs against the gather GEMM)
+static bool sconv_on(const ConvDims& d, int dgrad) {
+  static const bool on = !(getenv("NC_SCONV") && atoi(getenv("NC_SCONV")) == 0);
+  return on && (dgrad ? sconv_dgrad_supported(d) : sconv_fwd_supported(d));
+}
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
-  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : gemm_fwd_supported(d) ? 2 : 0;
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
+                                                                                              : sconv_on(d, 1)        ? 7
                                                                                               : gemm_dgrad_supported(d) ? 2 : 0;
 }
 static int wgrad_path(const ConvDims& d) {
@@ -119,6 +126,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   if (c1 > b) b = c1;
   const size_t t1 = to1_mfma_ws_bytes(d);
   if (t1 > b) b = t1;
+  if (sconv_fwd_supported(d) || sconv_dgrad_supported(d)) {
+    const size_t sc = sconv_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
@@ -143,6 +154,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);
+  if (!g_force_direct && sconv_on(d, 0)) return conv_fwd_sconv(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && gemm_fwd_supported(d)) return conv_fwd_gemm(x, w, bias, y, d, ws, ws_bytes, s);
   return conv_fwd_direct(x, w, bias, y, d, s);
 }
@@ -157,6 +169,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_dgrad_supported(d)) return conv_dgrad_to1(dy, w, dx, d, s);
+  if (!g_force_direct && sconv_on(d, 1)) return conv_dgrad_sconv(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && gemm_dgrad_supported(d)) return conv_dgrad_gemm(dy, w, dx, d, ws, ws_bytes, s);
   return conv_dgrad_direct(dy, w, dx, d, s);
 }

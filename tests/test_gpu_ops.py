@@ -291,3 +291,28 @@ def test_bias_link_gives_the_same_gradients():
     scale = g0[1].abs().max().item()
     assert g0[2].abs().max().item() <= 1e-4 * scale and g1[2].abs().max().item() <= 1e-4 * scale  # both are noise
     assert link.dbias is None  # consumed
+
+
+@pytest.mark.parametrize('B,C,K,H,W,s', [(3, 64, 128, 54, 54, 2), (5, 128, 256, 27, 27, 2), (4, 256, 512, 13, 13, 1),
+                                         (2, 32, 64, 40, 36, 2), (2, 16, 64, 21, 30, 1), (7, 64, 64, 23, 19, 2),
+                                         (1, 64, 128, 108, 108, 2), (216, 256, 512, 13, 13, 1)])
+def test_image_staged_patchgan_convs(B, C, K, H, W, s):
+    """conv2d_img.hip (k_sconv): the 4 x 4 / padding 1 PatchGAN layers, forward and data gradient (stride 2: four parity
+    classes), against torch fp32 -- odd sizes, batches that make a tile span three images, Athena's real + fake batch."""
+    import torch.nn.functional as F
+    from neuroclear_amd._lib import lib
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + H)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, 4, 4, device=DEV, generator=g) / (C * 16) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g)
+    assert lib().nc_conv_fwd_path(C, K, 1, 4, 4, s, 1) in (2, 7)  # (the path query assumes a 32^2 image)
+    y = ops.conv_fwd_raw(x, w, b, s, 1)
+    ref = F.conv2d(x, w, b, stride=s, padding=1)
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    dy = torch.randn(ref.shape, device=DEV, generator=g)
+    dx = ops.conv_dgrad_raw(dy, w, x.shape, s, 1)
+    refd = F.conv_transpose2d(dy, w, stride=s, padding=1, output_padding=(H + 2 - 4) % s if s > 1 else 0)
+    if refd.shape != x.shape:  # odd input sizes: the transposed convolution's natural size is one short
+        refd = F.pad(refd, (0, x.shape[3] - refd.shape[3], 0, x.shape[2] - refd.shape[2]))
+    assert float((dx - refd).abs().max()) <= 2e-5 * float(refd.abs().max())
