@@ -16,6 +16,8 @@
 //     kernels, one per class, walked backwards: dt = -1), of the stride-1 layer as one 4 x 4 problem with dt = -1;
 //   * weights stream through a buffer descriptor, packed [co tile][channel pair][tap][h][32][2], as in conv_mfma_fwd.hip.
 // v_mfma_f32_32x32x2_f32 (exact fp32): the two k values of an MFMA are two input channels of one tap.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -28,24 +30,44 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int kMaxSeg = 4;
 constexpr int kLds = 160 * 1024;
 
+// one problem = one output grid; the data gradient of a stride-2 layer is four of them (parity classes) in ONE launch
+// (blockIdx.z), so that the chip sees all their tiles at once
+struct SClass {
+  const float* wp;    // packed weights
+  int Hu, Wu;         // output grid: pixel (u, v) -> (oy0 + so * u, ox0 + so * v)
+  int oy0, ox0;
+  int ay, ax;         // tap (ty, tx) of pixel (u, v) reads input (u * si + ay + ty * dt, v * si + ax + tx * dt)
+  int xlo, Wp;        // staged columns [xlo, xlo + Wp)
+  int rlo_off;        // rows needed by output rows [ulo, uhi]: [ulo * si + rlo_off, uhi * si + rlo_off + rspan)
+  long ncol;          // B * Hu * Wu
+};
 struct SParams {
   const float* x;     // input  [B][C][Hi][Wi]
-  const float* wp;    // packed weights
   const float* bias;  // nullable
   float* y;           // output [B][M][Hf][Wf]
   const float* zeros; // >= 4 B of zeros in global memory
   int B, C, M, Hi, Wi, Hf, Wf;
-  int Hu, Wu;         // output grid of this launch: pixel (u, v) -> (oy0 + so * u, ox0 + so * v)
-  int oy0, ox0, so;
-  int si, ay, ax;     // tap (ty, tx) of pixel (u, v) reads input (u * si + ay + ty * dt, v * si + ax + tx * dt)
-  int xlo, Wp;        // staged columns [xlo, xlo + Wp)
-  int rlo_off, rspan; // rows needed by output rows [ulo, uhi]: [ulo * si + rlo_off, uhi * si + rlo_off + rspan)
+  int so, si, rspan;
   int CK, CS;         // channels per chunk, floats per channel image in LDS (capacity of the staged segments)
-  long ncol;          // B * Hu * Wu
+  SClass cls[4];
 };
 
 template <int TY, int TX, int DT, int WM, int WN, int VB>
-__global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams p) {
+__global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
+  // flatten (shared fields, this block's class) into the names the body uses
+  struct {
+    const float *x, *wp, *bias, *zeros;
+    float* y;
+    int B, C, M, Hi, Wi, Hf, Wf, Hu, Wu, oy0, ox0, so, si, ay, ax, xlo, Wp, rlo_off, rspan, CK, CS;
+    long ncol;
+  } p;
+  {
+    const SClass& c = P.cls[blockIdx.z];
+    p.x = P.x; p.wp = c.wp; p.bias = P.bias; p.zeros = P.zeros; p.y = P.y;
+    p.B = P.B; p.C = P.C; p.M = P.M; p.Hi = P.Hi; p.Wi = P.Wi; p.Hf = P.Hf; p.Wf = P.Wf;
+    p.Hu = c.Hu; p.Wu = c.Wu; p.oy0 = c.oy0; p.ox0 = c.ox0; p.so = P.so; p.si = P.si; p.ay = c.ay; p.ax = c.ax;
+    p.xlo = c.xlo; p.Wp = c.Wp; p.rlo_off = c.rlo_off; p.rspan = P.rspan; p.CK = P.CK; p.CS = P.CS; p.ncol = c.ncol;
+  }
   constexpr int NT = WM * WN * 64, NW = WM * WN, T = TY * TX, NCT = WM * VB * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // LDS: [segment descriptors: 64 ints][tab: CS ints][buf0: CK * CS][buf1: CK * CS]
@@ -62,6 +84,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams p) {
   const int wm = wave % WM, wn = wave / WM;
   const int li = lane & 31, h = lane >> 5;
   const long j0 = (long)blockIdx.x * NCT;
+  if (j0 >= p.ncol) return;  // (classes of different size share one grid)
   const int cot = blockIdx.y * WN + wn;
   const int HW = p.Hu * p.Wu;
   const long Sin = (long)p.Hi * p.Wi, Sf = (long)p.Hf * p.Wf;
@@ -225,15 +248,27 @@ __global__ void __launch_bounds__(256) k_pack_sconv(const float* __restrict__ w,
 struct SPlan {
   int WM, WN, VB, CK, CS, lds;
   bool ok;
+  long tiles;
 };
+// Below this many tiles the problem does not fill the chip (a workgroup walks its whole reduction alone): the gather GEMM,
+// which splits the reduction over grid.z, serves such small batches (the Apollo step's 1-4 planes per discriminator)
+constexpr long kMinTiles = 192;
+// LDS per workgroup is capped well below the CU's 160 KB so that two workgroups (of this launch, or of the launches of other
+// discriminators on other streams) can share a CU: one's barrier / staging phase hides under the other's MFMAs
+static long lds_cap() {
+  static const long v = getenv("NC_SCONV_LDS_KB") ? atol(getenv("NC_SCONV_LDS_KB")) * 1024 : 80 * 1024;
+  return v < kLds ? v : kLds;
+}
+struct SCfg { int WM, WN, VB; };
+// tiles: 64 * WN output channels x 32 * WM * VB columns.  Several shapes so that the number of tiles can be matched to
+// whole rounds of 256 workgroups (M = 64..512, 10^4..10^5 columns)
+static const SCfg kSCfgs[] = {{4, 2, 2}, {8, 1, 1}, {5, 2, 1}, {6, 2, 1}, {3, 2, 2}, {4, 2, 1}, {6, 1, 1}, {5, 1, 1}};
 
 // rows_max: the most rows of one channel image a tile of NCT columns can need
-SPlan plan_sconv(int B, int C, int M, int Hu, int Wu, int si, int rspan, int Wp) {
+SPlan plan_sconv(int B, int C, int M, int Hu, int Wu, int si, int rspan, int Wp, int nclass = 1) {
   SPlan best{};
   double best_eff = 0;
-  struct Cfg { int WM, WN, VB; };
-  const Cfg cfgs[2] = {{4, 2, 2}, {8, 1, 1}};
-  for (const Cfg& g : cfgs) {
+  for (const SCfg& g : kSCfgs) {
     if (M % (g.WN * 64)) continue;
     const int NCT = g.WM * g.VB * 32;
     const long HW = (long)Hu * Wu;
@@ -246,12 +281,13 @@ SPlan plan_sconv(int B, int C, int M, int Hu, int Wu, int si, int rspan, int Wp)
     for (int CK : {32, 16, 8, 4, 2}) {
       if (C % CK) continue;
       const long bytes = (64 + (long)CS + 2L * CK * CS) * 4;
-      if (bytes > kLds) continue;
+      if (bytes > lds_cap()) continue;
       // efficiency: how full the rounds of 256 workgroups (one per CU) are
-      const long tiles = cdiv((long)B * HW, NCT) * (M / (64 * g.WN));
-      const double eff = (double)tiles / (double)(cdiv(tiles, 256) * 256);
-      if (!best.ok || eff > best_eff || (eff == best_eff && g.WN > best.WN)) {
-        best = SPlan{g.WM, g.WN, g.VB, CK, CS, (int)bytes, true};
+      const long tiles = cdiv((long)B * HW, NCT) * (M / (64 * g.WN)) * nclass;
+      // how full the rounds of 256 workgroups are, times a mild preference for larger tiles (operand reuse)
+      const double eff = (double)tiles / (double)(cdiv(tiles, 256) * 256) * (0.85 + 0.15 * (g.WN * NCT) / 512.0);
+      if (!best.ok || eff > best_eff) {
+        best = SPlan{g.WM, g.WN, g.VB, CK, CS, (int)bytes, true, tiles};
         best_eff = eff;
       }
       break;
@@ -260,34 +296,37 @@ SPlan plan_sconv(int B, int C, int M, int Hu, int Wu, int si, int rspan, int Wp)
   return best;
 }
 
-template <int TY, int TX, int DT>
-int launch_sconv(const SPlan& pl, const SParams& p, int M, hipStream_t s) {
-  const int NCT = pl.WM * pl.VB * 32;
-  const dim3 grid((unsigned)cdiv(p.ncol, NCT), (unsigned)(M / (64 * pl.WN)));
-  if (pl.WM == 4) {
-    auto kern = k_sconv<TY, TX, DT, 4, 2, 2>;
-    static bool done = false;
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
-        set_error("sconv: cannot raise dynamic LDS limit");
-        return NC_ERR_HIP;
-      }
-      done = true;
+template <int TY, int TX, int DT, int WM, int WN, int VB>
+int launch_sconv_cfg(const SPlan& pl, const SParams& p, long max_ncol, int nclass, hipStream_t s) {
+  auto kern = k_sconv<TY, TX, DT, WM, WN, VB>;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
+      set_error("sconv: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), pl.lds, s, p);
-  } else {
-    auto kern = k_sconv<TY, TX, DT, 8, 1, 1>;
-    static bool done = false;
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
-        set_error("sconv: cannot raise dynamic LDS limit");
-        return NC_ERR_HIP;
-      }
-      done = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(512), pl.lds, s, p);
+    done = true;
   }
+  const dim3 grid((unsigned)cdiv(max_ncol, WM * VB * 32), (unsigned)(p.M / (64 * WN)), (unsigned)nclass);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), pl.lds, s, p);
   return check_launch("sconv");
+}
+
+template <int TY, int TX, int DT>
+int launch_sconv(const SPlan& pl, const SParams& p, long max_ncol, int nclass, hipStream_t s) {
+  const int key = pl.WM * 100 + pl.WN * 10 + pl.VB;
+  switch (key) {
+    case 422: return launch_sconv_cfg<TY, TX, DT, 4, 2, 2>(pl, p, max_ncol, nclass, s);
+    case 811: return launch_sconv_cfg<TY, TX, DT, 8, 1, 1>(pl, p, max_ncol, nclass, s);
+    case 521: return launch_sconv_cfg<TY, TX, DT, 5, 2, 1>(pl, p, max_ncol, nclass, s);
+    case 621: return launch_sconv_cfg<TY, TX, DT, 6, 2, 1>(pl, p, max_ncol, nclass, s);
+    case 322: return launch_sconv_cfg<TY, TX, DT, 3, 2, 2>(pl, p, max_ncol, nclass, s);
+    case 421: return launch_sconv_cfg<TY, TX, DT, 4, 2, 1>(pl, p, max_ncol, nclass, s);
+    case 611: return launch_sconv_cfg<TY, TX, DT, 6, 1, 1>(pl, p, max_ncol, nclass, s);
+    case 511: return launch_sconv_cfg<TY, TX, DT, 5, 1, 1>(pl, p, max_ncol, nclass, s);
+  }
+  set_error("sconv: unknown tile configuration");
+  return NC_ERR_SHAPE;
 }
 
 bool sconv_layer_ok(const ConvDims& d) {
@@ -304,18 +343,21 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 bool sconv_fwd_supported(const ConvDims& d) {
   if (!sconv_layer_ok(d) || d.C % 2 || d.C < 16 || d.K % 64) return false;
   if ((long)d.Ho * d.Wo < 96) return false;  // tiny images: too many images per tile (the gather GEMM serves them)
-  return plan_sconv(d.N, d.C, d.K, d.Ho, d.Wo, d.sh, 4, (d.Wo - 1) * d.sw + 4).ok;
+  const SPlan pl = plan_sconv(d.N, d.C, d.K, d.Ho, d.Wo, d.sh, 4, (d.Wo - 1) * d.sw + 4);
+  return pl.ok && pl.tiles >= kMinTiles;
 }
 // data gradient: M = C, reduction over K
 bool sconv_dgrad_supported(const ConvDims& d) {
   if (!sconv_layer_ok(d) || d.K % 2 || d.K < 16 || d.C % 64) return false;
   if (d.sh == 1) {
     if ((long)d.H * d.W < 96) return false;
-    return plan_sconv(d.N, d.K, d.C, d.H, d.W, 1, 4, d.W + 3).ok;
+    const SPlan pl = plan_sconv(d.N, d.K, d.C, d.H, d.W, 1, 4, d.W + 3);
+    return pl.ok && pl.tiles >= kMinTiles;
   }
   const int Hu = (d.H + 1) / 2, Wu = (d.W + 1) / 2;
   if ((long)(d.H / 2) * (d.W / 2) < 96) return false;
-  return plan_sconv(d.N, d.K, d.C, Hu, Wu, 1, 2, Wu + 1).ok;
+  const SPlan pl = plan_sconv(d.N, d.K, d.C, Hu, Wu, 1, 2, Wu + 1, 4);
+  return pl.ok && pl.tiles >= kMinTiles;
 }
 size_t sconv_ws_bytes(const ConvDims& d) {
   return align256((size_t)d.C * d.K * 16 * sizeof(float)) + 512;
@@ -331,16 +373,16 @@ int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, 
                      1, 4, total);
   if (int e = check_launch("pack_sconv")) return e;
   SParams p{};
-  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.zeros = zeros;
+  p.x = x; p.bias = bias; p.y = y; p.zeros = zeros;
   p.B = d.N; p.C = d.C; p.M = d.K; p.Hi = d.H; p.Wi = d.W; p.Hf = d.Ho; p.Wf = d.Wo;
-  p.Hu = d.Ho; p.Wu = d.Wo; p.oy0 = 0; p.ox0 = 0; p.so = 1;
-  p.si = d.sh; p.ay = -1; p.ax = -1;
-  p.xlo = -1; p.Wp = (d.Wo - 1) * d.sw + 4;
-  p.rlo_off = -1; p.rspan = 4;
-  const SPlan pl = plan_sconv(d.N, d.C, d.K, d.Ho, d.Wo, d.sh, 4, p.Wp);
+  p.so = 1; p.si = d.sh; p.rspan = 4;
+  SClass& c = p.cls[0];
+  c.wp = wp; c.Hu = d.Ho; c.Wu = d.Wo; c.oy0 = 0; c.ox0 = 0; c.ay = -1; c.ax = -1;
+  c.xlo = -1; c.Wp = (d.Wo - 1) * d.sw + 4; c.rlo_off = -1; c.ncol = (long)d.N * d.Ho * d.Wo;
+  const SPlan pl = plan_sconv(d.N, d.C, d.K, d.Ho, d.Wo, d.sh, 4, c.Wp);
   if (!pl.ok) { set_error("sconv_fwd: no plan"); return NC_ERR_SHAPE; }
-  p.CK = pl.CK; p.CS = pl.CS; p.ncol = (long)d.N * d.Ho * d.Wo;
-  return launch_sconv<4, 4, 1>(pl, p, d.K, s);
+  p.CK = pl.CK; p.CS = pl.CS;
+  return launch_sconv<4, 4, 1>(pl, p, c.ncol, 1, s);
 }
 
 int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
@@ -349,7 +391,7 @@ int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims&
   float* zeros = (float*)((char*)ws + align256((size_t)d.C * d.K * 16 * sizeof(float)));
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("sconv_dgrad: memset failed"); return NC_ERR_HIP; }
   SParams p{};
-  p.x = dy; p.wp = wp; p.bias = nullptr; p.y = dx; p.zeros = zeros;
+  p.x = dy; p.bias = nullptr; p.y = dx; p.zeros = zeros;
   p.B = d.N; p.C = d.K; p.M = d.C; p.Hi = d.Ho; p.Wi = d.Wo; p.Hf = d.H; p.Wf = d.W;
   if (d.sh == 1) {
     // dx[iy][ix] = sum_(k, ky, kx) w[k][c][ky][kx] dy[iy + 1 - ky][ix + 1 - kx]: one 4 x 4 problem walked backwards
@@ -357,39 +399,39 @@ int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims&
     hipLaunchKernelGGL(k_pack_sconv, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, d.K, d.C, 4, 4, 16L, (long)d.C * 16, 0, 1,
                        0, 1, 4, total);
     if (int e = check_launch("pack_sconv")) return e;
-    p.Hu = d.H; p.Wu = d.W; p.oy0 = 0; p.ox0 = 0; p.so = 1;
-    p.si = 1; p.ay = 1; p.ax = 1;
-    p.xlo = 1 - 3; p.Wp = d.W + 3;
-    p.rlo_off = 1 - 3; p.rspan = 4;
-    const SPlan pl = plan_sconv(d.N, d.K, d.C, d.H, d.W, 1, 4, p.Wp);
+    p.so = 1; p.si = 1; p.rspan = 4;
+    SClass& c = p.cls[0];
+    c.wp = wp; c.Hu = d.H; c.Wu = d.W; c.oy0 = 0; c.ox0 = 0; c.ay = 1; c.ax = 1;
+    c.xlo = -2; c.Wp = d.W + 3; c.rlo_off = -2; c.ncol = (long)d.N * d.H * d.W;
+    const SPlan pl = plan_sconv(d.N, d.K, d.C, d.H, d.W, 1, 4, c.Wp);
     if (!pl.ok) { set_error("sconv_dgrad: no plan"); return NC_ERR_SHAPE; }
-    p.CK = pl.CK; p.CS = pl.CS; p.ncol = (long)d.N * d.H * d.W;
-    return launch_sconv<4, 4, -1>(pl, p, d.C, s);
+    p.CK = pl.CK; p.CS = pl.CS;
+    return launch_sconv<4, 4, -1>(pl, p, c.ncol, 1, s);
   }
   // stride 2: input pixel iy = 2u + py receives the taps ky = t0y + 2 jy (t0y = (py + 1) & 1) from dy[(iy + 1 - ky) / 2]
-  // = dy[u + ay - jy], ay = (py + 1 - t0y) / 2: per parity class a 2 x 2 problem walked backwards
+  // = dy[u + ay - jy], ay = (py + 1 - t0y) / 2: per parity class a 2 x 2 problem walked backwards; all four in one launch
+  p.so = 2; p.si = 1; p.rspan = 2;
+  const int HuM = (d.H + 1) / 2, WuM = (d.W + 1) / 2;
+  const SPlan pl = plan_sconv(d.N, d.K, d.C, HuM, WuM, 1, 2, WuM + 1, 4);
+  if (!pl.ok) { set_error("sconv_dgrad: no plan"); return NC_ERR_SHAPE; }
+  p.CK = pl.CK; p.CS = pl.CS;
+  long max_ncol = 0;
   for (int cls = 0; cls < 4; ++cls) {
     const int py = cls >> 1, px = cls & 1;
     const int t0y = (py + 1) & 1, t0x = (px + 1) & 1;
     const int Hu = (d.H - py + 1) / 2, Wu = (d.W - px + 1) / 2;
-    if (Hu < 1 || Wu < 1) continue;
     const long total = (long)d.C * d.K * 4;
     float* wpc = wp + (size_t)cls * d.C * d.K * 4;
     hipLaunchKernelGGL(k_pack_sconv, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wpc, d.K, d.C, 2, 2, 16L, (long)d.C * 16, t0y,
                        2, t0x, 2, 4, total);
     if (int e = check_launch("pack_sconv")) return e;
-    SParams q = p;
-    q.wp = wpc;
-    q.Hu = Hu; q.Wu = Wu; q.oy0 = py; q.ox0 = px; q.so = 2;
-    q.si = 1; q.ay = (py + 1 - t0y) / 2; q.ax = (px + 1 - t0x) / 2;
-    q.xlo = q.ax - 1; q.Wp = Wu + 1;
-    q.rlo_off = q.ay - 1; q.rspan = 2;
-    const SPlan pl = plan_sconv(d.N, d.K, d.C, Hu, Wu, 1, 2, q.Wp);
-    if (!pl.ok) { set_error("sconv_dgrad: no plan"); return NC_ERR_SHAPE; }
-    q.CK = pl.CK; q.CS = pl.CS; q.ncol = (long)d.N * Hu * Wu;
-    if (int e = launch_sconv<2, 2, -1>(pl, q, d.C, s)) return e;
+    SClass& c = p.cls[cls];
+    c.wp = wpc; c.Hu = Hu; c.Wu = Wu; c.oy0 = py; c.ox0 = px;
+    c.ay = (py + 1 - t0y) / 2; c.ax = (px + 1 - t0x) / 2;
+    c.xlo = c.ax - 1; c.Wp = Wu + 1; c.rlo_off = c.ay - 1; c.ncol = (long)d.N * Hu * Wu;
+    if (c.ncol > max_ncol) max_ncol = c.ncol;
   }
-  return NC_OK;
+  return launch_sconv<2, 2, -1>(pl, p, max_ncol, 4, s);
 }
 
 }  // namespace nc
