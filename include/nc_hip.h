@@ -101,6 +101,10 @@ int nc_convT_k2s2_wgrad(const float* x, const float* dy, float* dw, float* dbias
 size_t nc_instnorm_ws_bytes(int NC, long S);
 int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, float* rstd, void* ws, size_t ws_bytes,
                       void* stream);
+/* stats + fwd in one call (mean / rstd are outputs).  Instances of S <= 2048 elements -- the 2-D PatchGAN layers --
+ * run as ONE kernel with a group of 16 or 64 lanes per instance; the three entry points agree bit for bit. */
+int nc_instnorm_fwd(const float* x, float eps, float slope, float* mean, float* rstd, float* y, int NC, long S, void* ws,
+                    size_t ws_bytes, void* stream);
 int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, float slope, float* y, int NC, long S,
                         void* stream);
 int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
@@ -222,6 +226,15 @@ int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved,
                     int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
 int nc_patchgan_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
                     int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
+/* Planes b0 .. b0 + B - 1 of a batch of Btot (x / y / dy / dx hold the B planes; saved and the workspace are the whole
+ * batch's).  Athena sends the slices of `fake` through every discriminator twice with the same weights -- in the
+ * generator loss (athena_model.py:240-260) and, detached, next to the slices of `real` in the discriminator loss
+ * (:190-238, before optimizer_D.step()): the first pass is run as the second half of that batch (fwd_part + bwd_part, input
+ * gradient only), the discriminator loss then only runs the `real` half and nc_patchgan_bwd over the whole batch. */
+int nc_patchgan_fwd_part(const float* params, const float* x, float* y, float* saved, int Btot, int b0, int B, int D, int H,
+                         int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
+int nc_patchgan_bwd_part(const float* params, const float* x, const float* saved, const float* dy, float* dx, int Btot, int b0,
+                         int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Whole-network forward of Unet_deconv (networks.py:512-538; called from TestModel.forward test_model.py:60-62):
  *      params = the 28 tensors in state-dict order, packed back to back (see neuroclear_amd.models.networks).       */

@@ -159,16 +159,18 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ x,
   }
 }
 
-// db[k] = sum over n and positions of dy[n][k][:]  -- two-stage, fixed order (deterministic): grid (splits, K)
-// partial sums in fp64, then one lane per k adds the partials.
+// db[k] = sum over n and positions of dy[n][k][:]  -- two-stage, fixed order (deterministic): grid (splits * nsplit, K)
+// partial sums in fp64 (a block = one range of positions x one range of samples), then one lane per k adds the partials.
 __global__ __launch_bounds__(256) void k_bias_grad_part(const float* __restrict__ dy, double* __restrict__ part, int N,
-                                                        int K, long S, int splits) {
-  const int k = blockIdx.y, sp = blockIdx.x;
+                                                        int K, long S, int splits, int nsplit) {
+  const int k = blockIdx.y, sp = blockIdx.x % splits, ns = blockIdx.x / splits;
   long chunk = (S + splits - 1) / splits;
   chunk = (chunk + 3) & ~3L;
   const long b = (long)sp * chunk, e = b + chunk < S ? b + chunk : S;
+  const int nper = (N + nsplit - 1) / nsplit;
+  const int n0 = ns * nper, n1 = n0 + nper < N ? n0 + nper : N;
   double acc = 0.0;
-  for (int n = 0; n < N; ++n) {
+  for (int n = n0; n < n1; ++n) {
     const float* p = dy + ((long)n * K + k) * S;
     if ((S & 3) == 0 && ((uintptr_t)dy & 15) == 0) {
       const float4* p4 = reinterpret_cast<const float4*>(p);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_bias_grad_part(const float* __restrict_
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part[(long)k * splits + sp] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) part[(long)k * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void k_bias_grad_final(const double* __restrict__ part, float* __restrict__ db, int K, int splits) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,14 +246,20 @@ int bias_grad(const float* dy, float* db, int N, int K, long S, void* ws, size_t
   if (splits > cap) splits = cap;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
-  if (!ws || wsb < (size_t)K * splits * sizeof(double)) {
+  // batches of short planes (the 2-D PatchGAN layers: hundreds of samples): split the sample axis too
+  long nsplit = cdiv(2048, (long)K * splits);
+  if (nsplit > N) nsplit = N;
+  while (nsplit > 1 && (long)K * splits * nsplit > 65536) --nsplit;
+  if (nsplit < 1) nsplit = 1;
+  const long parts = splits * nsplit;
+  if (!ws || wsb < (size_t)K * parts * sizeof(double)) {
     set_error("bias_grad: workspace too small");
     return NC_ERR_WS;
   }
-  hipLaunchKernelGGL(k_bias_grad_part, dim3((unsigned)splits, K), dim3(256), 0, s, dy, (double*)ws, N, K, S,
-                     (int)splits);
+  hipLaunchKernelGGL(k_bias_grad_part, dim3((unsigned)parts, K), dim3(256), 0, s, dy, (double*)ws, N, K, S,
+                     (int)splits, (int)nsplit);
   hipLaunchKernelGGL(k_bias_grad_final, dim3((unsigned)cdiv(K, 128)), dim3(128), 0, s, (const double*)ws, db, K,
-                     (int)splits);
+                     (int)parts);
   return check_launch("bias_grad");
 }
 

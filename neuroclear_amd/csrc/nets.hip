@@ -72,7 +72,7 @@ bool pg_plan(PgPlan& P, int B, int D, int H, int W, int n_layers, int ndf, int n
     const size_t cw = nc_conv_ws_bytes(B, l.C, d, h, w, l.K, nd == 3 ? 4 : 1, 4, 4, l.stride, 1);
     if (cw > P.conv_ws) P.conv_ws = cw;
     if (l.norm) {
-      const size_t iw = nc_instnorm_ws_bytes(B * l.K, (long)l.oD * l.oH * l.oW);
+      const size_t iw = nc_instnorm_bwd_dbias_ws_bytes(B * l.K, (long)l.oD * l.oH * l.oW);
       if (iw > P.in_ws) P.in_ws = iw;
     }
     cin = l.K; d = l.oD; h = l.oH; w = l.oW;
@@ -114,12 +114,11 @@ int nc_patchgan_out_shape(int B, int D, int H, int W, int n_layers, int ndf, int
   return NC_OK;
 }
 
-int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved, int B, int D, int H, int W,
-                    int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
-  if (!params || !x || !y || !saved) { set_error("patchgan_fwd: null pointer"); return NC_ERR_ARG; }
-  PgPlan P;
-  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: bad shape"); return NC_ERR_SHAPE; }
-  if (!ws || ws_bytes < nc_patchgan_ws_bytes(B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: workspace too small"); return NC_ERR_WS; }
+// forward of planes b0 .. b0 + B - 1 of a batch of Btot: `saved` has the layout of the whole batch (P is its plan), x / y
+// are the B planes themselves.  Convolutions, InstanceNorm and LeakyReLU are per sample, so a part of the batch is the
+// same kernels on offset pointers.
+static int pg_fwd(const PgPlan& P, const float* params, const float* x, float* y, float* saved, int Btot, int b0, int B,
+                  int nd, void* ws, void* stream) {
   void* cws = ws;
   void* iws = (char*)ws + align256(P.conv_ws);
   const int kd = nd == 3 ? 4 : 1;
@@ -127,20 +126,17 @@ int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved,
   for (int i = 0; i < P.nl; ++i) {
     const PgLayer& l = P.L[i];
     const bool head = i == P.nl - 1;
-    float* raw = head ? y : saved + l.raw_off;
+    const long S = (long)l.oD * l.oH * l.oW;
+    const size_t boff = (size_t)b0 * l.K * S;
+    float* raw = head ? y : saved + l.raw_off + boff;
     NC_TRY(nc_conv_fwd(in, params + l.w_off, params + l.b_off, raw, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1,
                        cws, P.conv_ws, stream));
-    if (head) {
-      // keep a copy of the head's raw output slot unused: y is the output
-      break;
-    }
-    const long S = (long)l.oD * l.oH * l.oW;
-    float* act = saved + l.act_off;
+    if (head) break;  // y is the output; the head's slot in `saved` stays unused
+    float* act = saved + l.act_off + boff;
     if (l.norm) {
-      float* mean = saved + l.stat_off;
-      float* rstd = mean + (size_t)B * l.K;
-      NC_TRY(nc_instnorm_stats(raw, B * l.K, S, 1e-5f, mean, rstd, iws, P.in_ws, stream));
-      NC_TRY(nc_instnorm_act_fwd(raw, mean, rstd, 0.2f, act, B * l.K, S, stream));
+      float* mean = saved + l.stat_off + (size_t)b0 * l.K;
+      float* rstd = saved + l.stat_off + (size_t)Btot * l.K + (size_t)b0 * l.K;
+      NC_TRY(nc_instnorm_fwd(raw, 1e-5f, 0.2f, mean, rstd, act, B * l.K, S, iws, P.in_ws, stream));
     } else {
       NC_TRY(nc_leaky_relu_fwd(raw, 0.2f, act, (long)B * l.K * S, stream));
     }
@@ -149,26 +145,41 @@ int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved,
   return NC_OK;
 }
 
+int nc_patchgan_fwd(const float* params, const float* x, float* y, float* saved, int B, int D, int H, int W,
+                    int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  return nc_patchgan_fwd_part(params, x, y, saved, B, 0, B, D, H, W, n_layers, ndf, nd, ws, ws_bytes, stream);
+}
+
+int nc_patchgan_fwd_part(const float* params, const float* x, float* y, float* saved, int Btot, int b0, int B, int D, int H,
+                         int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !y || !saved) { set_error("patchgan_fwd: null pointer"); return NC_ERR_ARG; }
+  PgPlan P;
+  if (B < 1 || b0 < 0 || b0 + B > Btot || !pg_plan(P, Btot, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_patchgan_ws_bytes(Btot, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_fwd: workspace too small"); return NC_ERR_WS; }
+  return pg_fwd(P, params, x, y, saved, Btot, b0, B, nd, ws, stream);
+}
+
 // dparams (nullable): packed like params, OVERWRITTEN with this call's parameter gradients.  dx (nullable): gradient
 // with respect to the input planes.
-int nc_patchgan_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
-                    int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
-  if (!params || !x || !saved || !dy) { set_error("patchgan_bwd: null pointer"); return NC_ERR_ARG; }
-  PgPlan P;
-  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: bad shape"); return NC_ERR_SHAPE; }
-  if (!ws || ws_bytes < nc_patchgan_ws_bytes(B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: workspace too small"); return NC_ERR_WS; }
+static int pg_bwd(const PgPlan& P, const float* params, const float* x, const float* saved, const float* dy, float* dx,
+                  float* dparams, int Btot, int b0, int B, int nd, void* ws, void* stream) {
   void* cws = ws;
   void* iws = (char*)ws + align256(P.conv_ws);
   float* ga = (float*)((char*)iws + align256(P.in_ws));
   float* gb = (float*)((char*)ga + align256(P.max_act * sizeof(float)));
   const int kd = nd == 3 ? 4 : 1;
   const float* g = dy;  // gradient with respect to the current layer's raw conv output
+  bool have_db = false;  // this layer's bias gradient was already taken by the backward of the norm behind it
   for (int i = P.nl - 1; i >= 0; --i) {
     const PgLayer& l = P.L[i];
-    const float* in = i == 0 ? x : saved + P.L[i - 1].act_off;
+    const float* in = x;
+    if (i > 0) {
+      const PgLayer& q = P.L[i - 1];
+      in = saved + q.act_off + (size_t)b0 * q.K * ((long)q.oD * q.oH * q.oW);
+    }
     if (dparams)
-      NC_TRY(nc_conv_wgrad(in, g, dparams + l.w_off, dparams + l.b_off, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride,
-                           1, cws, P.conv_ws, stream));
+      NC_TRY(nc_conv_wgrad(in, g, dparams + l.w_off, have_db ? nullptr : dparams + l.b_off, B, l.C, l.iD, l.iH, l.iW, l.K, kd,
+                           4, 4, l.stride, 1, cws, P.conv_ws, stream));
     if (i == 0) {
       if (dx) NC_TRY(nc_conv_dgrad(g, params + l.w_off, dx, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1, cws,
                                    P.conv_ws, stream));
@@ -182,11 +193,20 @@ int nc_patchgan_bwd(const float* params, const float* x, const float* saved, con
     const PgLayer& pl = P.L[i - 1];
     const long S = (long)pl.oD * pl.oH * pl.oW;
     float* graw = (gin == ga) ? gb : ga;
-    const float* praw = saved + pl.raw_off;
+    const float* praw = saved + pl.raw_off + (size_t)b0 * pl.K * S;
+    have_db = false;
     if (pl.norm) {
-      const float* mean = saved + pl.stat_off;
-      const float* rstd = mean + (size_t)B * pl.K;
-      NC_TRY(nc_instnorm_act_bwd(gin, praw, mean, rstd, 0.2f, graw, B * pl.K, S, iws, P.in_ws, stream));
+      const float* mean = saved + pl.stat_off + (size_t)b0 * pl.K;
+      const float* rstd = saved + pl.stat_off + (size_t)Btot * pl.K + (size_t)b0 * pl.K;
+      // the norm's backward has dx -- the gradient at the previous conv's output -- in registers: its per-channel sum is
+      // that conv's bias gradient (same hand-over as ops.BiasLink on the op-by-op path)
+      if (dparams && ((long)B * pl.K <= 65535 || S <= 2048)) {
+        NC_TRY(nc_instnorm_act_bwd_dbias(gin, praw, mean, rstd, 0.2f, graw, dparams + pl.b_off, B, pl.K, S, iws, P.in_ws,
+                                         stream));
+        have_db = true;
+      } else {
+        NC_TRY(nc_instnorm_act_bwd(gin, praw, mean, rstd, 0.2f, graw, B * pl.K, S, iws, P.in_ws, stream));
+      }
     } else {
       NC_TRY(nc_leaky_relu_bwd(gin, praw, 0.2f, graw, (long)B * pl.K * S, stream));
     }
@@ -195,4 +215,21 @@ int nc_patchgan_bwd(const float* params, const float* x, const float* saved, con
   return NC_OK;
 }
 
+int nc_patchgan_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
+                    int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !saved || !dy) { set_error("patchgan_bwd: null pointer"); return NC_ERR_ARG; }
+  PgPlan P;
+  if (!pg_plan(P, B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_patchgan_ws_bytes(B, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd: workspace too small"); return NC_ERR_WS; }
+  return pg_bwd(P, params, x, saved, dy, dx, dparams, B, 0, B, nd, ws, stream);
+}
+
+int nc_patchgan_bwd_part(const float* params, const float* x, const float* saved, const float* dy, float* dx, int Btot, int b0,
+                         int B, int D, int H, int W, int n_layers, int ndf, int nd, void* ws, size_t ws_bytes, void* stream) {
+  if (!params || !x || !saved || !dy || !dx) { set_error("patchgan_bwd_part: null pointer"); return NC_ERR_ARG; }
+  PgPlan P;
+  if (B < 1 || b0 < 0 || b0 + B > Btot || !pg_plan(P, Btot, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd_part: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_patchgan_ws_bytes(Btot, D, H, W, n_layers, ndf, nd)) { set_error("patchgan_bwd_part: workspace too small"); return NC_ERR_WS; }
+  return pg_bwd(P, params, x, saved, dy, dx, nullptr, Btot, b0, B, nd, ws, stream);
+}
 }  // extern "C"

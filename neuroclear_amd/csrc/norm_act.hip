@@ -179,6 +179,125 @@ __global__ __launch_bounds__(256) void k_in_dbias_final(const double* __restrict
   if (threadIdx.x == 0) dbias[c] = (float)out2[0];
 }
 
+// ---- short instances (S <= kRowsMaxS: the 2-D PatchGAN layers, 12^2 .. 27^2 positions x tens of thousands of
+//      instances, and the deepest U-Net levels): a group of G lanes owns one instance, so a workgroup covers 256 / G of
+//      them, the reductions are shuffles inside the group (no LDS, no barrier, no partial-sum pass) and statistics,
+//      normalisation and activation are ONE kernel -- the second sweep over the instance hits L2.
+static constexpr long kRowsMaxS = 2048;
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);  // butterfly: every lane of the group ends with the same bits
+  return v;
+}
+
+// MODE 0: statistics only; 1: normalise + activation with the statistics given; 2: both
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void k_in_fwd_rows(const float* __restrict__ x, long NC, int S, float eps, float slope,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     float* __restrict__ y) {
+  const int sub = threadIdx.x % G;
+  const long inst = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  if (inst >= NC) return;
+  const float* p = x + inst * S;
+  float m, r;
+  if constexpr (MODE != 1) {
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (int i = sub; i < S; i += G) {
+      const double a = p[i];
+      s += a;
+      q = fma(a, a, q);
+    }
+    s = group_sum<G>(s);
+    q = group_sum<G>(q);
+    const double mm = s / (double)S;
+    double var = q / (double)S - mm * mm;
+    if (var < 0.0) var = 0.0;
+    m = (float)mm;
+    r = (float)(1.0 / sqrt(var + (double)eps));
+    if (sub == 0) {
+      mean[inst] = m;
+      rstd[inst] = r;
+    }
+  } else {
+    m = mean[inst];
+    r = rstd[inst];
+  }
+  if constexpr (MODE != 0) {
+    float* o = y + inst * S;
+#pragma unroll 4
+    for (int i = sub; i < S; i += G) {
+      const float v = (p[i] - m) * r;
+      o[i] = v > 0.f ? v : v * slope;
+    }
+  }
+}
+
+// backward of the same: both sums, then dx, in one kernel; rowsum (nullable) [inst] = sum of dx over the instance (the
+// bias gradient of the convolution in front of the norm, see k_in_bwd_apply)
+template <int G>
+__global__ __launch_bounds__(256) void k_in_bwd_rows(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float slope, long NC, int S, float* __restrict__ dx,
+                                                     double* __restrict__ rowsum) {
+  const int sub = threadIdx.x % G;
+  const long inst = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  if (inst >= NC) return;
+  const float m = mean[inst], r = rstd[inst];
+  const float* px = x + inst * S;
+  const float* pg = dy + inst * S;
+  float* o = dx + inst * S;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int i = sub; i < S; i += G) {
+    const float xh = (px[i] - m) * r;
+    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
+    s1 += (double)g;
+    s2 = fma((double)g, (double)xh, s2);
+  }
+  s1 = group_sum<G>(s1);
+  s2 = group_sum<G>(s2);
+  const float m1 = (float)(s1 / (double)S), m2 = (float)(s2 / (double)S);
+  double rs = 0.0;
+#pragma unroll 4
+  for (int i = sub; i < S; i += G) {
+    const float xh = (px[i] - m) * r;
+    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
+    const float v = r * (g - m1 - xh * m2);
+    o[i] = v;
+    rs += (double)v;
+  }
+  if (rowsum) {
+    rs = group_sum<G>(rs);
+    if (sub == 0) rowsum[inst] = rs;
+  }
+}
+
+static inline bool rows_path(long S) { return S <= kRowsMaxS; }
+
+template <int MODE>
+static void launch_fwd_rows(const float* x, long NC, long S, float eps, float slope, float* mean, float* rstd, float* y,
+                            hipStream_t s) {
+  if (S <= 256)
+    hipLaunchKernelGGL((k_in_fwd_rows<16, MODE>), dim3((unsigned)cdiv(NC, 16)), dim3(256), 0, s, x, NC, (int)S, eps, slope, mean,
+                       rstd, y);
+  else
+    hipLaunchKernelGGL((k_in_fwd_rows<64, MODE>), dim3((unsigned)cdiv(NC, 4)), dim3(256), 0, s, x, NC, (int)S, eps, slope, mean,
+                       rstd, y);
+}
+
+static void launch_bwd_rows(const float* dy, const float* x, const float* mean, const float* rstd, float slope, long NC, long S,
+                            float* dx, double* rowsum, hipStream_t s) {
+  if (S <= 256)
+    hipLaunchKernelGGL((k_in_bwd_rows<16>), dim3((unsigned)cdiv(NC, 16)), dim3(256), 0, s, dy, x, mean, rstd, slope, NC, (int)S, dx,
+                       rowsum);
+  else
+    hipLaunchKernelGGL((k_in_bwd_rows<64>), dim3((unsigned)cdiv(NC, 4)), dim3(256), 0, s, dy, x, mean, rstd, slope, NC, (int)S, dx,
+                       rowsum);
+}
+
 // ---- the same two kernels for the 16-bit convolution path (conv_h.hip): next to the fp32 result they emit it in the
 //      C8 operand layout of those kernels ([N][C/8][voxels][8 channels] bf16 / fp16), so the convolution that consumes it
 //      does not run a conversion pass of its own.  One thread = one voxel of 8 consecutive channels (C % 8 == 0).
@@ -369,13 +488,17 @@ using namespace nc;
 extern "C" {
 
 size_t nc_instnorm_ws_bytes(int NC, long S) {
-  (void)S;
+  if (S >= 1 && rows_path(S)) return (size_t)NC * 2 * sizeof(double);  // short instances: one split at most
   return (size_t)NC * kMaxSplits * 2 * sizeof(double);
 }
 
 int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, float* rstd, void* ws, size_t ws_bytes,
                       void* stream) {
   if (!x || !mean || !rstd) { set_error("instnorm_stats: null pointer"); return NC_ERR_ARG; }
+  if (NC >= 1 && S >= 1 && rows_path(S)) {
+    launch_fwd_rows<0>(x, NC, S, eps, 0.f, mean, rstd, nullptr, (hipStream_t)stream);
+    return check_launch("instnorm_stats");
+  }
   if (NC > 65535) {  // grid.y limit: instances in chunks (stream-ordered reuse of the workspace)
     for (int c0 = 0; c0 < NC; c0 += 65535) {
       const int n = NC - c0 < 65535 ? NC - c0 : 65535;
@@ -396,6 +519,10 @@ int nc_instnorm_stats(const float* x, int NC, long S, float eps, float* mean, fl
 int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, float slope, float* y, int NC, long S,
                         void* stream) {
   if (!x || !mean || !rstd || !y) { set_error("instnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
+  if (NC >= 1 && S >= 1 && rows_path(S)) {
+    launch_fwd_rows<1>(x, NC, S, 0.f, slope, const_cast<float*>(mean), const_cast<float*>(rstd), y, (hipStream_t)stream);
+    return check_launch("instnorm_act_fwd");
+  }
   if (NC > 65535) {
     for (int c0 = 0; c0 < NC; c0 += 65535) {
       const int n = NC - c0 < 65535 ? NC - c0 : 65535;
@@ -410,9 +537,25 @@ int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, fl
   return check_launch("instnorm_act_fwd");
 }
 
+int nc_instnorm_fwd(const float* x, float eps, float slope, float* mean, float* rstd, float* y, int NC, long S, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!x || !mean || !rstd || !y) { set_error("instnorm_fwd: null pointer"); return NC_ERR_ARG; }
+  if (NC < 1 || S < 1) { set_error("instnorm_fwd: bad shape NC=%d S=%ld", NC, S); return NC_ERR_SHAPE; }
+  if (rows_path(S)) {
+    launch_fwd_rows<2>(x, NC, S, eps, slope, mean, rstd, y, (hipStream_t)stream);
+    return check_launch("instnorm_fwd");
+  }
+  if (int e = nc_instnorm_stats(x, NC, S, eps, mean, rstd, ws, ws_bytes, stream)) return e;
+  return nc_instnorm_act_fwd(x, mean, rstd, slope, y, NC, S, stream);
+}
+
 int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                         int NC, long S, void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !x || !mean || !rstd || !dx) { set_error("instnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
+  if (NC >= 1 && S >= 1 && rows_path(S)) {
+    launch_bwd_rows(dy, x, mean, rstd, slope, NC, S, dx, nullptr, (hipStream_t)stream);
+    return check_launch("instnorm_act_bwd");
+  }
   if (NC > 65535) {
     for (int c0 = 0; c0 < NC; c0 += 65535) {
       const int n = NC - c0 < 65535 ? NC - c0 : 65535;
@@ -443,10 +586,17 @@ int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
   if (!dy || !x || !mean || !rstd || !dx || !dbias) { set_error("instnorm_act_bwd_dbias: null pointer"); return NC_ERR_ARG; }
   const long NCl = (long)N * C;
-  if (N < 1 || C < 1 || S < 1 || NCl > 65535) { set_error("instnorm_act_bwd_dbias: bad shape"); return NC_ERR_SHAPE; }
+  if (N < 1 || C < 1 || S < 1 || NCl > 0x7fffffffL) { set_error("instnorm_act_bwd_dbias: bad shape"); return NC_ERR_SHAPE; }
+  hipStream_t s = (hipStream_t)stream;
+  if (rows_path(S)) {  // one sum per instance, then one workgroup per channel over the samples
+    if (!ws || ws_bytes < (size_t)NCl * sizeof(double)) { set_error("instnorm_act_bwd_dbias: workspace too small"); return NC_ERR_WS; }
+    launch_bwd_rows(dy, x, mean, rstd, slope, NCl, S, dx, (double*)ws, s);
+    hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)ws, N, C, 1, dbias);
+    return check_launch("instnorm_act_bwd_dbias");
+  }
+  if (NCl > 65535) { set_error("instnorm_act_bwd_dbias: more than 65535 long instances"); return NC_ERR_SHAPE; }
   const int NC = (int)NCl;
   if (!ws || ws_bytes < nc_instnorm_bwd_dbias_ws_bytes(NC, S)) { set_error("instnorm_act_bwd_dbias: workspace too small"); return NC_ERR_WS; }
-  hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(NC, S);
   double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
   hipLaunchKernelGGL(k_in_bwd_sums, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws);

@@ -82,6 +82,10 @@ class AxialToLateralGANAthenaModel(BaseModel):
     # the stream of its forward, so the backward chains overlap too).  One batched PatchGAN pass keeps the matrix pipe
     # ~45 % busy (profiles/README.md); two or three side by side fill the gaps.  NC_D_STREAMS=0: one stream.
     _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+    # backward_G's discriminator passes over the slices of fake / rec are kept and reused by backward_D_basic, which runs
+    # the same planes through the same (not yet updated) weights (ops.PatchGANShare).  NC_D_REUSE=0: both passes are run.
+    _reuse_on = os.environ.get('NC_D_REUSE', '1') != '0'
+    _shares = {}
 
     def _on_streams(self, fns, after=None):
         """fns[i]() on stream i, after everything queued on the calling stream so far (or after the event `after`); the
@@ -119,12 +123,17 @@ class AxialToLateralGANAthenaModel(BaseModel):
         and there are half as many launches).  A discriminator whose forward has side effects per call (spectral norm's
         power iteration) keeps the reference's two calls."""
         sr = ops.volume_all_slices(real, slice_axis_real)
-        sf = ops.volume_all_slices(fake.detach(), slice_axis_fake)
         if not (real.shape[-1] == real.shape[-2] == real.shape[-3]):
             raise ValueError('Athena assumes cubic crops (num_slice = shape[-3] is used for every axis)')
-        if getattr(netD, 'one_plane_per_call', False):
-            pred_real, pred_fake = netD(sr), netD(sf)
+        share = self._shares.pop(id(netD), None)
+        if share is not None and netD.share_matches(share, fake, slice_axis_fake):
+            # netD already saw exactly these fake planes with these weights in backward_G: only the real half runs
+            pred = netD.forward_join_real(sr, share)
+            pred_real, pred_fake = pred[:sr.shape[0]], pred[sr.shape[0]:]
+        elif getattr(netD, 'one_plane_per_call', False):
+            pred_real, pred_fake = netD(sr), netD(ops.volume_all_slices(fake.detach(), slice_axis_fake))
         else:
+            sf = ops.volume_all_slices(fake.detach(), slice_axis_fake)
             pred = netD(torch.cat([sr, sf], 0))
             pred_real, pred_fake = pred[:sr.shape[0]], pred[sr.shape[0]:]
         loss_D = (self.criterionGAN(pred_real, True) + self.criterionGAN(pred_fake, False)) * 0.5
@@ -140,9 +149,17 @@ class AxialToLateralGANAthenaModel(BaseModel):
                 (r, self.netD_B_xy, self.target_sl_axis, 1 / 3),
                 (r, self.netD_B_yz, self.source_sl_axis, 1 / 3),
                 (r, self.netD_B_xz, self.remain_sl_axis, 1 / 3)]
+        self._shares = {}
+
+        def job(x, n, a, w):
+            def fn(planes):
+                if self._reuse_on and hasattr(n, 'can_share') and n.can_share(planes):
+                    share = self._shares[id(n)] = ops.PatchGANShare()
+                    return n.forward_fake_half(planes, share, x, a)
+                return n(planes)
+            return g(self.iter_f(x, fn, a), True) * w
         (self.loss_G_A_xy, self.loss_G_A_yz, self.loss_G_A_xz, self.loss_G_B_xy, self.loss_G_B_yz,
-         self.loss_G_B_xz) = self._on_streams([lambda x=x, n=n, a=a, w=w: g(self.iter_f(x, n, a), True) * w
-                                               for x, n, a, w in jobs])
+         self.loss_G_B_xz) = self._on_streams([lambda x=x, n=n, a=a, w=w: job(x, n, a, w) for x, n, a, w in jobs])
         self.loss_G_A = self.loss_G_A_xy + self.loss_G_A_yz + self.loss_G_A_xz
         self.loss_G_B = self.loss_G_B_xy + self.loss_G_B_yz + self.loss_G_B_xz
         self.loss_cycle_A = self.criterionCycle(self.rec, self.real) * self.opt.lambda_A
@@ -169,5 +186,8 @@ class AxialToLateralGANAthenaModel(BaseModel):
              lambda: bd(self.netD_A_xy, self.real, self.fake, t, t), lambda: bd(self.netD_A_yz, self.real, self.fake, t, s),
              lambda: bd(self.netD_A_xz, self.real, self.fake, t, r), lambda: bd(self.netD_B_xy, self.real, self.rec, t, t),
              lambda: bd(self.netD_B_yz, self.real, self.rec, s, s), lambda: bd(self.netD_B_xz, self.real, self.rec, r, r)])
+        for sh in self._shares.values():
+            sh.release()
+        self._shares = {}
         self.optimizer_D.all_reduce_mean()
         self.optimizer_D.step()

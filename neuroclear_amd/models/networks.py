@@ -449,10 +449,28 @@ class NLayerDiscriminator(nn.Module):
         self._cfg = (n_layers, ndf, dimension)
         self._fusable = norm_layer is not None and input_nc == 1 and 1 <= n_layers <= 6
 
+    def _fused_on(self, input):
+        return self._fusable and input.is_cuda and os.environ.get('NC_FUSED_PATCHGAN', '1') != '0'
+
     def forward(self, input):
-        if self._fusable and input.is_cuda and os.environ.get('NC_FUSED_PATCHGAN', '1') != '0':
+        if self._fused_on(input):
             return ops.patchgan(input, list(self.parameters()), *self._cfg)
-        return self.model(input)
+        return _run_linked(self.model, input)
+
+    # Athena evaluates every discriminator on the slices of `fake` twice with the same weights (generator loss, then --
+    # detached, next to the slices of `real` -- discriminator loss, athena_model.py:240-260 / :190-238).  forward_fake_half
+    # is the first of the two and keeps its activations in `share`; forward_join_real then runs only the real planes.
+    def can_share(self, input):
+        return self._fused_on(input) and not any(p.requires_grad for p in self.parameters())
+
+    def forward_fake_half(self, input, share, src, axis):
+        return ops.patchgan_fake_half(input, list(self.parameters()), *self._cfg, share, src=src, axis=axis)
+
+    def share_matches(self, share, fake, axis):
+        return share is not None and share.matches(list(self.parameters()), self._cfg, fake, axis)
+
+    def forward_join_real(self, input, share):
+        return ops.patchgan_join_real(input, list(self.parameters()), *self._cfg, share)
 
 
 class PixelDiscriminator(nn.Module):

@@ -479,18 +479,25 @@ class _InstNormAct(torch.autograd.Function):
     def forward(ctx, x, slope, eps, link=None, nxt=None):
         x = x.contiguous()
         ctx.link = link
-        mean, rstd = instnorm_stats(x, eps)
-        NC = mean.numel()
-        S = x.numel() // NC
         y = torch.empty_like(x)
         if nxt is not None and nxt.want_xh and x.shape[1] % 8 == 0:
+            mean, rstd = instnorm_stats(x, eps)
+            NC = mean.numel()
+            S = x.numel() // NC
             yh = torch.empty(x.numel() * 2, dtype=torch.uint8, device=x.device)
             check(lib().nc_instnorm_act_fwd_c8(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), _ptr(yh), I(x.shape[0]),
                                                I(x.shape[1]), L_(S), I(nxt.want_xh), _stream()), 'nc_instnorm_act_fwd_c8')
             nxt.xh, nxt.xh_dt = yh, nxt.want_xh
         else:
-            check(lib().nc_instnorm_act_fwd(_ptr(x), _ptr(mean), _ptr(rstd), F(slope), _ptr(y), I(NC), L_(S), _stream()),
-                  'nc_instnorm_act_fwd')
+            _chk(x)
+            _f32(x)
+            NC = x.shape[0] * x.shape[1]
+            S = x.numel() // NC
+            mean = torch.empty(NC, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(NC, dtype=torch.float32, device=x.device)
+            ws = workspace(lib().nc_instnorm_ws_bytes(I(NC), L_(S)), x.device, 'in')
+            check(lib().nc_instnorm_fwd(_ptr(x), F(eps), F(slope), _ptr(mean), _ptr(rstd), _ptr(y), I(NC), L_(S), _ptr(ws),
+                                        Z(ws.numel()), _stream()), 'nc_instnorm_fwd')
         ctx.save_for_backward(x, mean, rstd)
         ctx.slope = slope
         return y
@@ -902,6 +909,159 @@ class _PatchGAN(torch.autograd.Function):
                     grads[i] = dpar[off:off + n].view(shp)
                 off += n
         return (dx, None) + tuple(grads)
+
+
+class PatchGANShare:
+    """One discriminator, one optimisation step: the activations of the pass over the slices of `fake` in the generator
+    loss, laid out as the SECOND half of the (real, fake) batch of the discriminator loss that follows with the same
+    weights (athena_model.py:240-260 then :190-238: optimizer_D.step() comes after both).  patchgan_fake_half fills it,
+    patchgan_join_real runs only the `real` half and back-propagates through the whole batch."""
+    __slots__ = ('saved', 'x', 'y', 'gen', 'packed_ptr', 'cfg', 'dims', 'src', 'src_version', 'axis')
+
+    def __init__(self):
+        self.saved = None
+
+    def matches(self, params, cfg, fake, axis):
+        if self.saved is None or self.cfg != tuple(cfg) or self.src is not fake or self.src_version != fake._version \
+                or self.axis != axis:
+            return False
+        packed = _pack_params(params)
+        return packed.data_ptr() == self.packed_ptr and _param_generation(packed) == self.gen
+
+    def release(self):
+        self.saved = self.x = self.y = self.src = None
+
+
+def _pg_dims(x, nd):
+    return (1, x.shape[2], x.shape[3]) if nd == 2 else tuple(x.shape[2:])
+
+
+class _PatchGANFakeHalf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, share, *params):
+        n_layers, ndf, nd = cfg
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        if x.shape[1] != 1:
+            raise _lib.NcError('fused PatchGAN expects one input channel')
+        B = x.shape[0]
+        D, H, W = _pg_dims(x, nd)
+        L = lib()
+        packed = _pack_params(params)
+        if packed.numel() != L.nc_patchgan_param_floats(I(n_layers), I(ndf), I(nd)):
+            raise _lib.NcError('fused PatchGAN: parameter count does not match (n_layers=%d, ndf=%d)' % (n_layers, ndf))
+        import ctypes
+        od, oh, ow = I(0), I(0), I(0)
+        check(L.nc_patchgan_out_shape(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd), ctypes.byref(od),
+                                      ctypes.byref(oh), ctypes.byref(ow)), 'nc_patchgan_out_shape')
+        oshape = (2 * B, 1, oh.value, ow.value) if nd == 2 else (2 * B, 1, od.value, oh.value, ow.value)
+        share.saved = torch.empty(L.nc_patchgan_saved_floats(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)),
+                                  dtype=torch.float32, device=x.device)
+        share.x = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        share.x[B:].copy_(x)
+        share.y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        ws = workspace(L.nc_patchgan_ws_bytes(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
+        check(L.nc_patchgan_fwd_part(_ptr(packed), _ptr(share.x[B:]), _ptr(share.y[B:]), _ptr(share.saved), I(2 * B), I(B), I(B),
+                                     I(D), I(H), I(W), I(n_layers), I(ndf), I(nd), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_patchgan_fwd_part')
+        share.gen, share.packed_ptr, share.cfg, share.dims = _param_generation(packed), packed.data_ptr(), tuple(cfg), (B, D, H, W)
+        ctx.share, ctx.packed, ctx.cfg = share, packed, cfg
+        ctx.saved_ref = share.saved  # keeps the buffers alive for this backward even if the share is released first
+        ctx.x_ref = share.x
+        return share.y[B:].clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        n_layers, ndf, nd = ctx.cfg
+        share = ctx.share
+        B, D, H, W = share.dims
+        if _param_generation(ctx.packed) != share.gen:
+            raise _lib.NcError('fused PatchGAN: the parameters were updated between this forward and its backward')
+        if any(ctx.needs_input_grad[3:]):
+            raise _lib.NcError('patchgan_fake_half: the discriminator must be frozen (generator loss)')
+        if not ctx.needs_input_grad[0]:
+            return (None,) * (3 + len(ctx.needs_input_grad[3:]))
+        dy = dy.contiguous()
+        xs = ctx.x_ref[B:]
+        dx = torch.empty_like(xs)
+        L = lib()
+        ws = workspace(L.nc_patchgan_ws_bytes(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), dy.device, 'patchgan')
+        check(L.nc_patchgan_bwd_part(_ptr(ctx.packed), _ptr(xs), _ptr(ctx.saved_ref), _ptr(dy), _ptr(dx), I(2 * B), I(B), I(B),
+                                     I(D), I(H), I(W), I(n_layers), I(ndf), I(nd), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_patchgan_bwd_part')
+        return (dx, None, None) + (None,) * len(ctx.needs_input_grad[3:])
+
+
+class _PatchGANJoinReal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg, share, *params):
+        n_layers, ndf, nd = cfg
+        x = x.contiguous()
+        _chk(x, *params)
+        _f32(x, *params)
+        B, D, H, W = share.dims
+        if tuple(x.shape) != tuple(share.x.shape[1:]) and tuple(x.shape) != (B,) + tuple(share.x.shape[1:]):
+            raise _lib.NcError('patchgan_join_real: the real planes do not have the shape of the cached fake planes')
+        packed = _pack_params(params)
+        if packed.data_ptr() != share.packed_ptr or _param_generation(packed) != share.gen:
+            raise _lib.NcError('patchgan_join_real: the parameters changed since the pass over the fake planes')
+        cur = torch.cuda.current_stream()
+        for t in (share.saved, share.x, share.y):
+            t.record_stream(cur)
+        share.x[:B].copy_(x)
+        L = lib()
+        ws = workspace(L.nc_patchgan_ws_bytes(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
+        check(L.nc_patchgan_fwd_part(_ptr(packed), _ptr(share.x), _ptr(share.y), _ptr(share.saved), I(2 * B), I(0), I(B), I(D),
+                                     I(H), I(W), I(n_layers), I(ndf), I(nd), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_patchgan_fwd_part')
+        ctx.save_for_backward(share.x, share.saved)
+        ctx.packed, ctx.gen, ctx.cfg, ctx.dims = packed, share.gen, cfg, share.dims
+        ctx.shapes = [tuple(p.shape) for p in params]
+        y = share.y
+        share.release()  # the autograd graph owns the buffers from here
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved = ctx.saved_tensors
+        n_layers, ndf, nd = ctx.cfg
+        B, D, H, W = ctx.dims
+        if _param_generation(ctx.packed) != ctx.gen:
+            raise _lib.NcError('fused PatchGAN: the parameters were updated between this forward and its backward')
+        dy = dy.contiguous()
+        want_p = any(ctx.needs_input_grad[3:])
+        dpar = _grad_destination(ctx.packed) if want_p else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        L = lib()
+        ws = workspace(L.nc_patchgan_ws_bytes(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
+        check(L.nc_patchgan_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(2 * B), I(D), I(H),
+                                I(W), I(n_layers), I(ndf), I(nd), _ptr(ws), Z(ws.numel()), _stream()), 'nc_patchgan_bwd')
+        grads = [None] * len(ctx.shapes)
+        if want_p:
+            off = 0
+            for i, shp in enumerate(ctx.shapes):
+                n = 1
+                for s_ in shp:
+                    n *= s_
+                if ctx.needs_input_grad[3 + i]:
+                    grads[i] = dpar[off:off + n].view(shp)
+                off += n
+        return (dx[:B] if dx is not None else None, None, None) + tuple(grads)
+
+
+def patchgan_fake_half(x, params, n_layers, ndf, dimension, share, src=None, axis=None):
+    """The frozen discriminator on the slices of `fake` (generator loss), kept in `share` as the second half of the batch
+    the discriminator loss runs next (see PatchGANShare).  src / axis: the volume the planes were cut from and the axis,
+    which PatchGANShare.matches compares before the cached half is used."""
+    y = _PatchGANFakeHalf.apply(x, (int(n_layers), int(ndf), int(dimension)), share, *params)
+    share.src, share.src_version, share.axis = src, (src._version if src is not None else None), axis
+    return y
+
+
+def patchgan_join_real(x, params, n_layers, ndf, dimension, share):
+    """Predictions for the batch (x, cached fake planes): forward of the `real` half only; backward over the whole batch."""
+    return _PatchGANJoinReal.apply(x, (int(n_layers), int(ndf), int(dimension)), share, *params)
 
 
 def patchgan(x, params, n_layers, ndf, dimension):

@@ -329,6 +329,49 @@ def test_athena_step(golden_dir):
         np.testing.assert_allclose(upd[sel], g['upd_' + n][sel], rtol=5e-2, err_msg=n)
 
 
+@pytest.mark.parametrize('size,batch', [(36, 1), (24, 2)])
+def test_athena_shared_fake_pass_matches_two_passes(size, batch, monkeypatch):
+    """Athena's discriminator loss re-evaluates every discriminator on the planes of `fake` / `rec` that the generator loss
+    just sent through the same weights (athena:240-260, :190-238).  The product path keeps that pass (ops.PatchGANShare) and
+    runs only the real planes the second time; with NC_D_REUSE=0 both passes run.  Same arithmetic per plane either way:
+    the losses of the first step must agree to fp32 rounding, and the share must actually be used."""
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.models.axial_to_lateral_gan_athena_model import AxialToLateralGANAthenaModel as M
+    used = []
+    orig = ops.patchgan_join_real
+    monkeypatch.setattr(ops, 'patchgan_join_real', lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+    res = {}
+    for reuse in (True, False):
+        monkeypatch.setattr(M, '_reuse_on', reuse)
+        opt = _apollo_opt()
+        opt.model = 'axial_to_lateral_gan_athena'
+        opt.conversion_plane = ['yz', 'xy']
+        opt.pool_size = 50
+        model = create_model(opt)
+        specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 6
+        for i, (n, sp) in enumerate(zip(ATHENA_NETS, specs)):
+            load(getattr(model, 'net' + n), sp, 500 + i)
+        real = torch.from_numpy(rnd(77, (batch, 1, size, size, size)))
+        losses = []
+        for it in range(2):
+            model.set_input({'A': real, 'A_paths': 'x'})
+            model.optimize_parameters()
+            losses.append(dict(model.get_current_losses()))
+        params = torch.cat([p.detach().reshape(-1) for n in ATHENA_NETS for p in getattr(model, 'net' + n).parameters()])
+        res[reuse] = (losses, params.clone())
+        if reuse:
+            assert len(used) == 12, len(used)  # six discriminators x two steps
+    assert len(used) == 12
+    for it in range(2):
+        for k in res[True][0][it]:
+            # step 2 runs on Adam-updated weights: Adam turns rounding-level differences of near-zero gradients into
+            # lr-sized steps (the same allowance as the golden test of the step, test_athena_step)
+            np.testing.assert_allclose(res[True][0][it][k], res[False][0][it][k], rtol=1e-5 if it == 0 else 2e-3,
+                                       err_msg='%d %s' % (it, k))
+    a, b = res[True][1].double(), res[False][1].double()
+    assert float((a - b).norm() / b.norm()) < 1e-3
+
+
 def test_train_onecube_and_checkpoint_roundtrip(tmp_path):
     """Entry-script level: two iterations of train_onecube on a synthetic volume (option parsing, on-device crops,
     schedulers, checkpoint files with the reference's names), then the generator is reloaded through TestModel /

@@ -275,6 +275,53 @@ def test_instnorm_bwd_dbias_is_the_channel_sum_of_dx():
     assert (db.double() - want).abs().max().item() <= 1e-6 * dx1.abs().double().sum((0, 2)).max().item()
 
 
+@pytest.mark.parametrize('N,C,S', [(5, 24, 144), (3, 16, 169), (2, 32, 729), (2, 8, 2048), (7, 3, 7), (1, 2, 1),
+                                   (300, 256, 16)])
+def test_instnorm_short_instances(N, C, S):
+    """Instances of S <= 2048 elements (the 2-D PatchGAN layers) run in the one-kernel group-per-instance form: statistics
+    against fp64, stats / stats + fwd / fwd-with-given-stats bit-equal, backward against autograd, the instance sums of dx
+    (bias gradient hand-over) with deliberately wrong statistics; N * C = 76800 > the 65535 grid.y limit of the long path."""
+    from neuroclear_amd import _lib
+    from neuroclear_amd._lib import F as CF, I, L_, Z
+    L = _lib.lib()
+    P = ops._ptr
+    g = torch.Generator(device='cuda').manual_seed(N * 1000 + S)
+    x = torch.randn(N, C, S, device='cuda', generator=g) * 2 + 0.5
+    dy = torch.randn(N, C, S, device='cuda', generator=g)
+    NC = N * C
+    nb = L.nc_instnorm_bwd_dbias_ws_bytes(I(NC), L_(S))
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device='cuda')
+    m0, r0, m1, r1 = (torch.empty(NC, device='cuda') for _ in range(4))
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    assert L.nc_instnorm_stats(P(x), I(NC), L_(S), CF(1e-5), P(m0), P(r0), P(ws), Z(nb), None) == 0
+    assert L.nc_instnorm_fwd(P(x), CF(1e-5), CF(0.2), P(m1), P(r1), P(y1), I(NC), L_(S), P(ws), Z(nb), None) == 0
+    assert L.nc_instnorm_act_fwd(P(x), P(m0), P(r0), CF(0.2), P(y2), I(NC), L_(S), None) == 0
+    assert torch.equal(m0, m1) and torch.equal(r0, r1) and torch.equal(y1, y2)
+    xd = x.double().requires_grad_(True)
+    mean = xd.mean(2)
+    var = xd.var(2, unbiased=False)
+    assert (m0.double() - mean.reshape(-1)).abs().max().item() <= 1e-6
+    assert rel(r0, (1.0 / (var + 1e-5).sqrt()).reshape(-1).detach()) <= 1e-6
+    yr = F.leaky_relu((xd - mean[..., None]) / (var[..., None] + 1e-5).sqrt(), 0.2)
+    assert rel(y1, yr.detach()) <= 2e-6
+    (gx,) = torch.autograd.grad((yr * dy.double()).sum(), xd)
+    dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
+    db = torch.empty(C, device='cuda')
+    assert L.nc_instnorm_act_bwd(P(dy), P(x), P(m0), P(r0), CF(0.2), P(dx1), I(NC), L_(S), P(ws), Z(nb), None) == 0
+    assert L.nc_instnorm_act_bwd_dbias(P(dy), P(x), P(m0), P(r0), CF(0.2), P(dx2), P(db), I(N), I(C), L_(S), P(ws), Z(nb),
+                                       None) == 0
+    assert torch.equal(dx1, dx2)
+    if S > 1:
+        assert rel(dx1, gx) <= 2e-5, rel(dx1, gx)
+    # wrong statistics: the channel sums of dx are O(1) and must come out of the hand-over
+    mw = m0 + 0.3 * torch.randn(NC, device='cuda', generator=g)
+    rw = r0 * 1.2
+    assert L.nc_instnorm_act_bwd_dbias(P(dy), P(x), P(mw), P(rw), CF(0.2), P(dx2), P(db), I(N), I(C), L_(S), P(ws), Z(nb),
+                                       None) == 0
+    want = dx2.double().sum((0, 2))
+    assert (db.double() - want).abs().max().item() <= 1e-6 * dx2.abs().double().sum((0, 2)).max().item()
+
+
 def test_bias_link_gives_the_same_gradients():
     """(Conv, InstanceNormAct) pairs of the U-Net blocks hand the bias gradient over through ops.BiasLink: same dx / dw as
     the unlinked ops, bias gradient = the (noise-level) channel sum of the same dx."""
