@@ -44,6 +44,10 @@ void nc_prof_begin(double min_flop);
 int nc_prof_end(int max, int* cls, double* flop, float* ms);
 /* Force the direct path everywhere (tests cross-check MFMA vs direct on the GPU). 0 = auto (default), 1 = force. */
 void nc_set_force_direct(int on);
+/* The image-staged PatchGAN kernels (conv2d_img.hip) pick their tile shape per problem by timing the candidates on the
+ * first call (NC_SCONV_TUNE=0: a fixed heuristic).  Every shape gives the same bits; this pins shape `cfg` (0-based, -1 =
+ * back to automatic) so that a test can check exactly that. */
+void nc_sconv_set_cfg(int cfg);
 
 /* ---- Convolution: nn.Conv3d / nn.Conv2d (models/networks.py:361-369; used at :420-425,:442,:460-469 (U-Net 3^3),
  *      :899-911 (deep_linear 7^3/5^3/3^3/1^3), :507-508 (1x1 tail), :1030-1057 (PatchGAN 4x4 s2/s1)).

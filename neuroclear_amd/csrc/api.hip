@@ -60,9 +60,15 @@ static int dgrad_path(const ConvDims& d) {
                                                                                               : sconv_on(d, 1)        ? 7
                                                                                               : gemm_dgrad_supported(d) ? 2 : 0;
 }
+static bool sconv_wgrad_on(const ConvDims& d) {
+  static const bool on = !(getenv("NC_SCONV") && atoi(getenv("NC_SCONV")) == 0) &&
+                         !(getenv("NC_SCONV_WGRAD") && atoi(getenv("NC_SCONV_WGRAD")) == 0);
+  return on && sconv_wgrad_supported(d);
+}
 static int wgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4 : k1_wgrad_supported(d) ? 5
+                                                                                            : sconv_wgrad_on(d)      ? 7
                                                                                             : gemm_wgrad_supported(d) ? 2 : 0;
 }
 
@@ -96,6 +102,7 @@ int nc_prof_end(int max, int* cls, double* flop, float* ms) {
 const char* nc_last_error(void) { return g_err; }
 int nc_version(void) { return 100; }
 void nc_set_force_direct(int on) { g_force_direct = on; }
+void nc_sconv_set_cfg(int cfg) { sconv_set_cfg(cfg); }
 
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
@@ -128,6 +135,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   if (t1 > b) b = t1;
   if (sconv_fwd_supported(d) || sconv_dgrad_supported(d)) {
     const size_t sc = sconv_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
+  if (sconv_wgrad_supported(d)) {
+    const size_t sc = sconv_wgrad_ws_bytes(d);
     if (sc > b) b = sc;
   }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
@@ -251,6 +262,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && k1_wgrad_supported(d)) e = conv_wgrad_k1(x, dy, dw, d, s);
+  else if (!g_force_direct && sconv_wgrad_on(d)) e = conv_wgrad_sconv(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);
   }

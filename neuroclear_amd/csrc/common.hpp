@@ -72,12 +72,16 @@ int conv_dgrad_gemm(const float* dy, const float* w, float* dx, const ConvDims& 
 int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb,
                     hipStream_t s);
 
-// ---- image-staged implicit GEMM for the 2-D 4 x 4 PatchGAN layers (fwd + dgrad), conv2d_img.hip
+// ---- image-staged implicit GEMM for the 2-D 4 x 4 PatchGAN layers (fwd, dgrad, wgrad), conv2d_img.hip
 bool sconv_fwd_supported(const ConvDims& d);
 bool sconv_dgrad_supported(const ConvDims& d);
 size_t sconv_ws_bytes(const ConvDims& d);
 int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+void sconv_set_cfg(int cfg);
+bool sconv_wgrad_supported(const ConvDims& d);
+size_t sconv_wgrad_ws_bytes(const ConvDims& d);
+int conv_wgrad_sconv(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 
 // ---- 1x1 convolutions on the flat voxel axis (MFMA, HBM-bound), conv_1x1.hip
 bool wgrad_1x1_supported(const ConvDims& d);

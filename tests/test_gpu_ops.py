@@ -364,3 +364,45 @@ def test_image_staged_patchgan_convs(B, C, K, H, W, s):
     if refd.shape != x.shape:  # odd input sizes: the transposed convolution's natural size is one short
         refd = F.pad(refd, (0, x.shape[3] - refd.shape[3], 0, x.shape[2] - refd.shape[2]))
     assert float((dx - refd).abs().max()) <= 2e-5 * float(refd.abs().max())
+    # weight gradient (k_swgrad: the reduction runs over the flat (image, u, v) axis in chunks, summed in a fixed order)
+    dw, db = ops.conv_wgrad_raw(x, dy, w.shape, s, 1, True)
+    refw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=s, padding=1)
+    assert float((dw.double() - refw).abs().max()) <= 2e-5 * float(refw.abs().max())
+    assert float((db.double() - dy.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(dy.double().sum((0, 2, 3)).abs().max() + 1)
+    dw2, _ = ops.conv_wgrad_raw(x, dy, w.shape, s, 1, False)
+    assert torch.equal(dw, dw2)  # deterministic
+
+
+@pytest.mark.parametrize('B,C,K,H,W,s', [(108, 128, 256, 27, 27, 2), (60, 256, 128, 13, 13, 1), (40, 64, 128, 31, 22, 2)])
+def test_image_staged_configs_agree(B, C, K, H, W, s):
+    """The tile shape of k_sconv is picked per problem by timing (conv2d_img.hip, run_tuned).  That is only admissible because
+    every shape accumulates an output element in the same order: forward and data gradient of every applicable shape must be
+    BIT-equal to the automatically chosen one."""
+    from neuroclear_amd._lib import lib, I
+    L = lib()
+    g = torch.Generator(device=DEV).manual_seed(B + H)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, 4, 4, device=DEV, generator=g) / (C * 16) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g)
+    y0 = ops.conv_fwd_raw(x, w, b, s, 1)
+    dy = torch.randn(y0.shape, device=DEV, generator=g)
+    dx0 = ops.conv_dgrad_raw(dy, w, x.shape, s, 1)
+    n = [0, 0]
+    try:
+        for cfg in range(14):
+            L.nc_sconv_set_cfg(I(cfg))
+            try:
+                y = ops.conv_fwd_raw(x, w, b, s, 1)
+                assert torch.equal(y, y0), cfg
+                n[0] += 1
+            except Exception as e:
+                assert 'does not apply' in str(e), e
+            try:
+                dx = ops.conv_dgrad_raw(dy, w, x.shape, s, 1)
+                assert torch.equal(dx, dx0), cfg
+                n[1] += 1
+            except Exception as e:
+                assert 'does not apply' in str(e), e
+    finally:
+        L.nc_sconv_set_cfg(I(-1))
+    assert n[0] >= 4 and n[1] >= 4, n
