@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.f;
 
+  for (int i = tid; i < NCW * p.CS; i += 256) Xs[i] = 0.f;  // padding columns stay zero for the whole kernel
   // this lane's (channel, tap) inside n-tile 0 of its wave; n-tile t adds 2 * CS
   const int tap = li & 15;
   const int laneoff = ((wn * NTW * 2) + (li >> 4)) * p.CS + (tap >> 2) * p.pitch + (tap & 3);
@@ -530,27 +531,31 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
       for (int ch = wave * 32; ch < wave * 32 + 32; ++ch)
         __builtin_amdgcn_global_load_lds((gptr_t)(src0 + ch * cstride), (lptr_t)(As + ch * kWAP), 4, 0, 0);
     }
-    // ---- stage the input rows: channels wave, wave + 4, ...; one row (<= 64 dwords) per instruction
+    // ---- stage the input rows: channels wave, wave + 4, ...; one row (<= 64 dwords) per instruction.  The padding
+    //      columns (ix = -1, ix >= Wi) are never written (lanes masked off; zeroed once above); a padding ROW is written as
+    //      zeros by the wave.  Sources are 32-bit element offsets from p.x (uniform base + lane offset)
     {
       const int rows = rows0 + rows1;
 #pragma unroll 1
       for (int ci = wave; ci < NCW; ci += 4) {
-        const float* xc0 = p.x + ((long)b0 * p.C + c0 + ci) * Sin;
-        const float* xc1 = p.x + ((long)b1 * p.C + c0 + ci) * Sin;
+        const int xo0 = (b0 * p.C + c0 + ci) * (int)Sin - 1;
+        const int xo1 = (b1 * p.C + c0 + ci) * (int)Sin - 1;
+        float* const xd = Xs + ci * p.CS;
 #pragma unroll 1
         for (int r = 0; r < rows; ++r) {
           const bool s1 = r >= rows0;
           const int iy = s1 ? r - rows0 - 1 : u0 * p.s - 1 + r;
-          const float* xr = (s1 ? xc1 : xc0) + (long)iy * p.Wi - 1;
-          const bool rowok = (unsigned)iy < (unsigned)p.Hi;
+          const int ro = (s1 ? xo1 : xo0) + iy * p.Wi;
+          if ((unsigned)iy < (unsigned)p.Hi) {
 #pragma unroll 1
-          for (int cc = 0; cc < p.pitch; cc += 64) {
-            const int col = cc + lane;
-            if (col < p.pitch) {
-              const bool ok = rowok && (unsigned)(col - 1) < (unsigned)p.Wi;
-              const float* src = ok ? xr + col : p.zeros;
-              __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (long)ci * p.CS + r * p.pitch + cc), 4, 0, 0);
+            for (int cc = 0; cc < p.pitch; cc += 64) {
+              const int col = cc + lane;
+              if ((unsigned)(col - 1) < (unsigned)p.Wi)
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)((ro + col) * 4)), (lptr_t)(xd + r * p.pitch + cc),
+                                                 4, 0, 0);
             }
+          } else {
+            for (int col = lane; col < p.pitch; col += 64) xd[r * p.pitch + col] = 0.f;
           }
         }
       }
@@ -614,7 +619,9 @@ WPlan plan_swgrad(const ConvDims& d) {
   const int urows = (kWNJ + d.Wo - 1) / d.Wo + 1;
   const int rows = (urows - 1) * s + 2 * 4 + s;
   const int CS = rows * pitch + 16;  // (+16: two channels of an n-tile on different bank groups when rows * pitch is a multiple of 32)
+  static const int only = getenv("NC_SWGRAD_NTW") ? atoi(getenv("NC_SWGRAD_NTW")) : 0;
   for (int NTW : {4, 2}) {
+    if (only && NTW != only) continue;
     const int NCW = 4 * NTW;
     if (d.C % NCW) continue;
     const long bytes = (128 + 128L * kWAP + (long)NCW * CS) * 4;
@@ -623,7 +630,8 @@ WPlan plan_swgrad(const ConvDims& d) {
     w.ngroups = d.C / NCW; w.mtiles = d.K / 128;
     const long nst = cdiv((long)d.N * HW, kWNJ);
     const long tiles = (long)w.ngroups * w.mtiles;
-    long splits = cdiv(1024, tiles);  // ~2 workgroups per CU and two rounds
+    static const long target = getenv("NC_SWGRAD_TARGET") ? atol(getenv("NC_SWGRAD_TARGET")) : 512;
+    long splits = cdiv(target, tiles);  // 2 resident workgroups per CU, one round (measured: 512 beats 256 / 1024)
     if (splits > nst) splits = nst;
     if (splits > 256) splits = 256;
     w.stages_per_split = (int)cdiv(nst, splits);
