@@ -647,7 +647,8 @@ bool sconv_wgrad_supported(const ConvDims& d) {
   if (!sconv_layer_ok(d) || d.K % 128 || d.C % 8) return false;
   const WPlan w = plan_swgrad(d);
   // worth it once the reduction is long (batched planes); a few planes stay on the gather GEMM
-  return w.ok && (long)d.N * d.Ho * d.Wo >= 4096;
+  static const long mincol = getenv("NC_SWGRAD_MINCOL") ? atol(getenv("NC_SWGRAD_MINCOL")) : 4096;
+  return w.ok && (long)d.N * d.Ho * d.Wo >= mincol;
 }
 size_t sconv_wgrad_ws_bytes(const ConvDims& d) {
   const WPlan w = plan_swgrad(d);
