@@ -135,6 +135,9 @@ int conv_c1_fwd_h(const float* x, const float* w, const float* bias, void* yh, i
 int conv_c1_dgrad_h(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int KS, void* ws, size_t wsb,
                     hipStream_t s);
 
+// 16-bit weight rounding for the calls that follow on this host thread: 0 round-to-nearest, 1 tap-diffused (conv_h.hip)
+void h_set_weight_diffusion(int on);
+
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;
 

@@ -82,9 +82,37 @@ __global__ void __launch_bounds__(256) k_to_c8(const float* __restrict__ x, uint
 // fragment is one 16-byte unit and the 32 lanes of a half read 512 contiguous bytes.
 // fwd:   wp(co, ci, tap) = w[co][ci][tap]                       (so = C*T, si = T, flip = 0)
 // dgrad: wp(ci as "co", co as "ci", tap) = w[co][ci][T-1-tap]    (so = T,   si = C*T, flip = 1)
+// Weight rounding of a bias-free, norm-free stack (deep_linear_gen, networks.py:899-917): tap-diffused.  Rounding each
+// weight to nearest leaves every (co, ci) pair's tap SUM -- the layer's response to a constant input -- with an error of
+// ~sqrt(taps) half-ulps, and G_B's output for the nearly constant `fake` of the first iterations is a heavily cancelling sum
+// of such responses: at configs[3]'s seed the bf16 cycle loss came out 2.2 % low (tools/glin_round_exp.py: weight rounding
+// +0.0155 on a mean of 0.245, activation rounding -0.0001).  Here weight t of a pair is rounded after adding the residual
+// carried from weights 0..t-1 (master order), so the running sums of the rounded weights follow the exact ones to one ulp
+// -- noise shaping: the rounding error moves to the spatial frequencies where images have no energy (5 x less output bias).
+// A layer in front of an InstanceNorm gains nothing (the norm removes the constant) and keeps round-to-nearest.
+static thread_local int g_wdiffuse = 0;
+
+template <int DT>
+__device__ __forceinline__ float round16f(float v) {
+  if constexpr (DT == NC_DT_F16) return (float)(_Float16)v;
+  else return (float)(__bf16)v;
+}
+// value of weight `tp` of the pair whose taps start at w[0] (stride 1): round-to-nearest, or tap-diffused
+template <int DT>
+__device__ __forceinline__ float wvalue(const float* __restrict__ w, int tp, int diffuse) {
+  if (!diffuse) return w[tp];
+  float r = 0.f, q = 0.f;
+  for (int t = 0; t <= tp; ++t) {
+    const float v = w[t] + r;
+    q = round16f<DT>(v);
+    r = v - q;
+  }
+  return q;
+}
+
 template <int DT>
 __global__ void __launch_bounds__(256) k_pack_w_h(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH,
-                                                  int T3, long so, long si, int flip, long total) {
+                                                  int T3, long so, long si, int flip, int diffuse, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7);
@@ -97,14 +125,14 @@ __global__ void __launch_bounds__(256) k_pack_w_h(const float* __restrict__ w, u
   const int cot = (int)(q / NCH);
   const long co = cot * 64 + a * 32 + r, ci = chunk * 16 + 8 * h + j;
   const int tp = flip ? T3 - 1 - tap : tap;
-  wp[i] = cvt16<DT>(w[co * so + ci * si + tp]);
+  wp[i] = cvt16<DT>(wvalue<DT>(w + co * so + ci * si, tp, diffuse));
 }
 
 // 5^3 (PAIR) packing: [cot][chunk = ci/8][dz][i = tap pair][a][h][r][8], element j = input channel chunk*8 + j at tap
 // (dy, dx) = 2i + h of plane dz; zero for the 26th tap.
 template <int DT>
 __global__ void __launch_bounds__(256) k_pack_w_h8(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH,
-                                                   int KS, long so, long si, int flip, long total) {
+                                                   int KS, long so, long si, int flip, int diffuse, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int T2 = KS * KS, NP = (T2 + 1) / 2, T3 = T2 * KS;
@@ -122,7 +150,7 @@ __global__ void __launch_bounds__(256) k_pack_w_h8(const float* __restrict__ w, 
   if (t2 < T2) {
     const long co = cot * 64 + a * 32 + r, ci = chunk * 8 + j;
     const int tap = dz * T2 + t2;
-    v = w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)];
+    v = wvalue<DT>(w + co * so + ci * si, flip ? T3 - 1 - tap : tap, diffuse);
   }
   wp[i] = cvt16<DT>(v);
 }
@@ -517,10 +545,10 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
   if (KS == 5)
     hipLaunchKernelGGL((k_pack_w_h8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip,
-                       total);
+                       g_wdiffuse, total);
   else
     hipLaunchKernelGGL((k_pack_w_h<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 16, T3, so, si,
-                       flip, total);
+                       flip, g_wdiffuse, total);
   if (int e = check_launch("pack_w_h")) return e;
   HParams p{};
   p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
@@ -586,7 +614,7 @@ __global__ void __launch_bounds__(256) k_fold_x8(const uint4* __restrict__ dx8, 
 //   dgrad (chunks = K/8 of the real channels -> 8):  element (co = a*32 + r = j', ci = chunk*8 + j, tap) = w[ci][KS-1-dz][KS-1-dy][j']
 template <int DT>
 __global__ void __launch_bounds__(256) k_pack_w_x8(const float* __restrict__ w, unsigned short* __restrict__ wp, int KS, int NCH,
-                                                   int dgrad, long total) {
+                                                   int dgrad, int diffuse, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int NP = (KS + 1) / 2, T3 = KS * KS * KS;
@@ -603,9 +631,9 @@ __global__ void __launch_bounds__(256) k_pack_w_x8(const float* __restrict__ w, 
   float v = 0.f;
   if (dy < KS) {
     if (!dgrad) {
-      if (j < KS) v = w[(long)co * T3 + (dz * KS + dy) * KS + j];
+      if (j < KS) v = wvalue<DT>(w + (long)co * T3, (dz * KS + dy) * KS + j, diffuse);
     } else if (co < KS) {
-      v = w[(long)(chunk * 8 + j) * T3 + ((KS - 1 - dz) * KS + (KS - 1 - dy)) * KS + co];
+      v = wvalue<DT>(w + (long)(chunk * 8 + j) * T3, ((KS - 1 - dz) * KS + (KS - 1 - dy)) * KS + co, diffuse);
     }
   }
   wp[i] = cvt16<DT>(v);
@@ -628,7 +656,7 @@ int run_c1_fwd(const float* x, const float* w, const float* bias, void* yh, int 
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_fwd_h: memset failed"); return NC_ERR_HIP; }
   hipLaunchKernelGGL((k_build_x8<DT>), dim3((unsigned)cdiv(N * S, 256)), dim3(256), 0, s, x, x8, W, KS, N * S);
   const long total = (long)(x8_packed_bytes(KS, 1) / 2);
-  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 1, 0, total);
+  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 1, 0, g_wdiffuse, total);
   if (int e = check_launch("c1_fwd_h prep")) return e;
   HParams p{};
   p.xh = x8; p.wp = (const uint4*)wp; p.bias = bias; p.y = nullptr; p.zeros = zeros;
@@ -657,7 +685,7 @@ int run_c1_dgrad(const void* dyh, const float* w, float* dx, int N, int D, int H
   uint4* zeros = (uint4*)((char*)ws + xb + wb);
   if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_dgrad_h: memset failed"); return NC_ERR_HIP; }
   const long total = (long)(x8_packed_bytes(KS, 8) / 2);
-  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 8, 1, total);
+  hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 8, 1, g_wdiffuse, total);
   if (int e = check_launch("c1_dgrad_h pack")) return e;
   HParams p{};
   p.xh = (const uint4*)dyh; p.wp = (const uint4*)wp; p.bias = nullptr; p.y = nullptr; p.zeros = zeros;
@@ -991,6 +1019,11 @@ int run_wh(const float* x, const void* xh_pre, const float* dy, const void* dyh_
 }
 
 }  // namespace
+
+void h_set_weight_diffusion(int on) {
+  static const bool allowed = !(getenv("NC_W_DIFFUSE") && atoi(getenv("NC_W_DIFFUSE")) == 0);  // A/B switch
+  g_wdiffuse = on && allowed;
+}
 
 bool h_fwd_supported(const ConvDims& d) { return h_shape_ok(d, d.C, d.K); }
 bool h_dgrad_supported(const ConvDims& d) { return h_shape_ok(d, d.K, d.C); }

@@ -147,6 +147,13 @@ UWs ulp_ws(const ULp& p, void* ws) {
 
 }  // namespace
 
+namespace {
+struct WeightDiffusion {
+  WeightDiffusion() { nc::h_set_weight_diffusion(1); }
+  ~WeightDiffusion() { nc::h_set_weight_diffusion(0); }
+};
+}  // namespace
+
 extern "C" {
 
 int nc_unet_deconv_lp_supported(int N, int S0, int S1, int S2, int dtype) {
@@ -407,6 +414,7 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
   LLp p;
   if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_fwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
   if (!ws || ws_bytes < llp_ws_bytes(p)) { set_error("deep_linear_lp_fwd: workspace too small"); return NC_ERR_WS; }
+  const WeightDiffusion wd_;  // the bias-free, norm-free stack rounds its weights tap-diffused (conv_h.hip)
   hipStream_t hs = (hipStream_t)stream;
   char* cws = (char*)ws;
   char* fws = cws + al(p.conv_ws);
@@ -440,6 +448,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   LLp p;
   if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_bwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
   if (!ws || ws_bytes < llp_ws_bytes(p)) { set_error("deep_linear_lp_bwd: workspace too small"); return NC_ERR_WS; }
+  const WeightDiffusion wd_;  // the bias-free, norm-free stack rounds its weights tap-diffused (conv_h.hip)
   hipStream_t hs = (hipStream_t)stream;
   char* cws = (char*)ws;
   char* fws = cws + al(p.conv_ws);

@@ -2,6 +2,8 @@
 // elementwise / reduction part of the hot path (reference models/networks.py:33-34,:422-423,:1042-1046,:491,:510).
 // All of these are pure streams: 16-byte loads where the instance length allows it, fp64 accumulation for every
 // statistic (1.26 M elements per instance at 108^3 -- fp32 sums would not hold the stated tolerance).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -275,7 +277,10 @@ __global__ __launch_bounds__(256) void k_in_bwd_rows(const float* __restrict__ d
   }
 }
 
-static inline bool rows_path(long S) { return S <= kRowsMaxS; }
+static inline bool rows_path(long S) {
+  static const bool on = !(getenv("NC_IN_ROWS") && atoi(getenv("NC_IN_ROWS")) == 0);  // A/B switch (timing experiments)
+  return on && S <= kRowsMaxS;
+}
 
 template <int MODE>
 static void launch_fwd_rows(const float* x, long NC, long S, float eps, float slope, float* mean, float* rstd, float* y,
