@@ -255,7 +255,10 @@ struct SPlan {
 };
 // Below this many tiles the problem does not fill the chip (a workgroup walks its whole reduction alone): the gather GEMM,
 // which splits the reduction over grid.z, serves such small batches (the Apollo step's 1-4 planes per discriminator)
-constexpr long kMinTiles = 192;
+static long min_tiles() {
+  static const long v = getenv("NC_SCONV_MINTILES") ? atol(getenv("NC_SCONV_MINTILES")) : 192;
+  return v;
+}
 // LDS per workgroup is capped well below the CU's 160 KB so that two workgroups (of this launch, or of the launches of other
 // discriminators on other streams) can share a CU: one's barrier / staging phase hides under the other's MFMAs
 static long lds_cap() {
@@ -696,7 +699,7 @@ bool sconv_fwd_supported(const ConvDims& d) {
   if (!sconv_layer_ok(d) || d.C % 2 || d.C < 16 || d.K % 64) return false;
   if ((long)d.Ho * d.Wo < 96) return false;  // tiny images: too many images per tile (the gather GEMM serves them)
   const SPlan pl = plan_sconv(d.N, d.C, d.K, d.Ho, d.Wo, d.sh, 4, (d.Wo - 1) * d.sw + 4);
-  return pl.ok && pl.tiles >= kMinTiles;
+  return pl.ok && pl.tiles >= min_tiles();
 }
 // data gradient: M = C, reduction over K
 bool sconv_dgrad_supported(const ConvDims& d) {
@@ -704,12 +707,12 @@ bool sconv_dgrad_supported(const ConvDims& d) {
   if (d.sh == 1) {
     if ((long)d.H * d.W < 96) return false;
     const SPlan pl = plan_sconv(d.N, d.K, d.C, d.H, d.W, 1, 4, d.W + 3);
-    return pl.ok && pl.tiles >= kMinTiles;
+    return pl.ok && pl.tiles >= min_tiles();
   }
   const int Hu = (d.H + 1) / 2, Wu = (d.W + 1) / 2;
   if ((long)(d.H / 2) * (d.W / 2) < 96) return false;
   const SPlan pl = plan_sconv(d.N, d.K, d.C, Hu, Wu, 1, 2, Wu + 1, 4);
-  return pl.ok && pl.tiles >= kMinTiles;
+  return pl.ok && pl.tiles >= min_tiles();
 }
 size_t sconv_ws_bytes(const ConvDims& d) {
   return align256((size_t)d.C * d.K * 16 * sizeof(float)) + 512;
