@@ -342,11 +342,14 @@ def test_bias_link_gives_the_same_gradients():
 
 @pytest.mark.parametrize('B,C,K,H,W,s', [(54, 64, 128, 54, 54, 2), (108, 128, 256, 27, 27, 2), (108, 256, 512, 13, 13, 1),
                                          (70, 32, 64, 40, 36, 2), (90, 16, 64, 21, 30, 1), (130, 64, 64, 23, 19, 2),
-                                         (9, 64, 128, 108, 108, 2), (216, 256, 512, 13, 13, 1), (3, 64, 128, 54, 54, 2)])
+                                         (9, 64, 128, 108, 108, 2), (216, 256, 512, 13, 13, 1), (3, 64, 128, 54, 54, 2),
+                                         (24, 64, 128, 74, 74, 2), (40, 32, 128, 31, 45, 2), (30, 64, 128, 20, 70, 1),
+                                         (50, 8, 256, 17, 33, 1)])
 def test_image_staged_patchgan_convs(B, C, K, H, W, s):
     """conv2d_img.hip (k_sconv): the 4 x 4 / padding 1 PatchGAN layers at batches that fill the chip (smaller ones stay on
     the gather GEMM: last case), forward and data gradient (stride 2: four parity classes in one launch), against torch
-    fp32 -- odd sizes, tiles that span three images, Athena's real + fake batch."""
+    fp32 -- odd sizes, tiles that span three images, Athena's real + fake batch; the last four: weight-gradient stages whose
+    input rows are wider than one 64-lane copy (W = 74 / 70), odd non-square planes, 8 input channels."""
     import torch.nn.functional as F
     from neuroclear_amd._lib import lib
     g = torch.Generator(device=DEV).manual_seed(B * 1000 + H)
