@@ -50,13 +50,19 @@ static bool sconv_on(const ConvDims& d, int dgrad) {
   static const bool on = !(getenv("NC_SCONV") && atoi(getenv("NC_SCONV")) == 0);
   return on && (dgrad ? sconv_dgrad_supported(d) : sconv_fwd_supported(d));
 }
+// NC_PG1=0: the PatchGAN's first layer back on the generic kernels (A/B runs)
+static bool pg1_on(const ConvDims& d) {
+  static const bool on = !(getenv("NC_PG1") && atoi(getenv("NC_PG1")) == 0);
+  return on && pg1_supported(d);
+}
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
-  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
+                                                                                              : pg1_on(d)             ? 8
                                                                                               : sconv_on(d, 1)        ? 7
                                                                                               : gemm_dgrad_supported(d) ? 2 : 0;
 }
@@ -68,6 +74,7 @@ static bool sconv_wgrad_on(const ConvDims& d) {
 static int wgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4 : k1_wgrad_supported(d) ? 5
+                                                                                            : pg1_on(d)              ? 8
                                                                                             : sconv_wgrad_on(d)      ? 7
                                                                                             : gemm_wgrad_supported(d) ? 2 : 0;
 }
@@ -109,8 +116,9 @@ int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) 
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
-  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : gemm_fwd_supported(d) ? 2 : 0;  // (the K = 1 reduction
-  // kernel of the PatchGAN head depends on the batch, which this query does not take: reported as 2)
+  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : pg1_on(d) ? 8 : gemm_fwd_supported(d) ? 2 : 0;  // (the K = 1
+  // reduction kernel of the PatchGAN head and the image-staged kernels depend on the batch, which this query does not take:
+  // reported as 2)
 }
 int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
@@ -141,6 +149,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     const size_t sc = sconv_wgrad_ws_bytes(d);
     if (sc > b) b = sc;
   }
+  if (pg1_supported(d)) {
+    const size_t sc = pg1_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
@@ -165,6 +177,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);
+  if (!g_force_direct && fwd_path(d) == 8) return conv_fwd_pg1(x, w, bias, y, d, 1.f, s);
   if (!g_force_direct && sconv_on(d, 0)) return conv_fwd_sconv(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && gemm_fwd_supported(d)) return conv_fwd_gemm(x, w, bias, y, d, ws, ws_bytes, s);
   return conv_fwd_direct(x, w, bias, y, d, s);
@@ -180,6 +193,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_dgrad_supported(d)) return conv_dgrad_to1(dy, w, dx, d, s);
+  if (!g_force_direct && dgrad_path(d) == 8) return conv_dgrad_pg1(dy, nullptr, 1.f, w, dx, d, s);
   if (!g_force_direct && sconv_on(d, 1)) return conv_dgrad_sconv(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && gemm_dgrad_supported(d)) return conv_dgrad_gemm(dy, w, dx, d, ws, ws_bytes, s);
   return conv_dgrad_direct(dy, w, dx, d, s);
@@ -262,6 +276,10 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && k1_wgrad_supported(d)) e = conv_wgrad_k1(x, dy, dw, d, s);
+  else if (!g_force_direct && wgrad_path(d) == 8) {  // the bias gradient is a column of the same product
+    e = conv_wgrad_pg1(x, dy, nullptr, 1.f, dw, dbias, d, ws, ws_bytes, s);
+    dbias = nullptr;
+  }
   else if (!g_force_direct && sconv_wgrad_on(d)) e = conv_wgrad_sconv(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && gemm_wgrad_supported(d)) e = conv_wgrad_gemm(x, dy, dw, d, ws, ws_bytes, s);
   else e = conv_wgrad_direct(x, dy, dw, d, s);

@@ -83,6 +83,15 @@ bool sconv_wgrad_supported(const ConvDims& d);
 size_t sconv_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_sconv(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 
+// ---- the PatchGAN's first layer, Conv2d(1 -> K <= 64, k 4, s 2, p 1) [+ LeakyReLU], as HBM streams (patchgan_edge.hip).
+//      slope 1 = plain convolution; act != NULL in the gradients = g is the gradient BEHIND the LeakyReLU whose output is act
+bool pg1_supported(const ConvDims& d);
+size_t pg1_ws_bytes(const ConvDims& d);
+int conv_fwd_pg1(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, float slope, hipStream_t s);
+int conv_wgrad_pg1(const float* x, const float* g, const float* act, float slope, float* dw, float* db, const ConvDims& d,
+                   void* ws, size_t wsb, hipStream_t s);
+int conv_dgrad_pg1(const float* g, const float* act, float slope, const float* w, float* dx, const ConvDims& d, hipStream_t s);
+
 // ---- 1x1 convolutions on the flat voxel axis (MFMA, HBM-bound), conv_1x1.hip
 bool wgrad_1x1_supported(const ConvDims& d);
 size_t wgrad_1x1_ws_bytes(const ConvDims& d);

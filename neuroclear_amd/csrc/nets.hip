@@ -10,6 +10,8 @@
 // Parameter blob = the 2 * (n_layers + 2) tensors in state-dict order (model.0.weight, model.0.bias, model.2.weight,
 // ...), packed back to back.  `saved` (nc_patchgan_saved_floats) receives what the backward needs: every conv's raw
 // output, every activation, the InstanceNorm statistics.
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace nc;
@@ -30,6 +32,7 @@ struct PgPlan {
   int nl;            // number of convs = n_layers + 2
   PgLayer L[8];
   size_t params, saved;       // floats
+  bool fused0;                // first layer = conv + LeakyReLU in one kernel (patchgan_edge.hip): only its activation is stored
   size_t max_act;             // largest per-layer tensor (floats), for the gradient ping-pong buffers
   size_t conv_ws, in_ws;      // bytes
   int oD, oH, oW;
@@ -48,7 +51,12 @@ bool pg_plan(PgPlan& P, int B, int D, int H, int W, int n_layers, int ndf, int n
   for (int i = 0; i < P.nl; ++i) {
     PgLayer& l = P.L[i];
     const bool head = i == P.nl - 1;
-    if (i == 0) mult = 1;
+    if (i == 0) {
+      mult = 1;
+      static const bool pg1 = !(getenv("NC_PG1") && atoi(getenv("NC_PG1")) == 0);
+      ConvDims c0;
+      P.fused0 = pg1 && nd == 2 && make_dims(c0, B, 1, 1, h, w, ndf, 1, 4, 4, 2, 1) && pg1_supported(c0);
+    }
     else if (!head) mult = (1 << i) < 8 ? (1 << i) : 8;
     l.C = cin;
     l.K = head ? 1 : ndf * mult;
@@ -129,10 +137,17 @@ static int pg_fwd(const PgPlan& P, const float* params, const float* x, float* y
     const long S = (long)l.oD * l.oH * l.oW;
     const size_t boff = (size_t)b0 * l.K * S;
     float* raw = head ? y : saved + l.raw_off + boff;
+    float* act = saved + l.act_off + boff;
+    if (i == 0 && P.fused0) {  // conv + bias + LeakyReLU as one HBM stream; the raw slot stays unwritten
+      ConvDims c0;
+      make_dims(c0, B, 1, 1, l.iH, l.iW, l.K, 1, 4, 4, 2, 1);
+      NC_TRY(conv_fwd_pg1(in, params + l.w_off, params + l.b_off, act, c0, 0.2f, (hipStream_t)stream));
+      in = act;
+      continue;
+    }
     NC_TRY(nc_conv_fwd(in, params + l.w_off, params + l.b_off, raw, B, l.C, l.iD, l.iH, l.iW, l.K, kd, 4, 4, l.stride, 1,
                        cws, P.conv_ws, stream));
     if (head) break;  // y is the output; the head's slot in `saved` stays unused
-    float* act = saved + l.act_off + boff;
     if (l.norm) {
       float* mean = saved + l.stat_off + (size_t)b0 * l.K;
       float* rstd = saved + l.stat_off + (size_t)Btot * l.K + (size_t)b0 * l.K;
@@ -177,6 +192,17 @@ static int pg_bwd(const PgPlan& P, const float* params, const float* x, const fl
       const PgLayer& q = P.L[i - 1];
       in = saved + q.act_off + (size_t)b0 * q.K * ((long)q.oD * q.oH * q.oW);
     }
+    if (i == 0 && P.fused0) {
+      // g is still the gradient BEHIND the first layer's LeakyReLU (no pass was spent on it below): both gradients of the
+      // layer pull it through the mask of the stored activation on the fly
+      ConvDims c0;
+      make_dims(c0, B, 1, 1, l.iH, l.iW, l.K, 1, 4, 4, 2, 1);
+      const float* act0 = saved + l.act_off + (size_t)b0 * l.K * ((long)l.oD * l.oH * l.oW);
+      if (dparams)
+        NC_TRY(conv_wgrad_pg1(in, g, act0, 0.2f, dparams + l.w_off, dparams + l.b_off, c0, cws, P.conv_ws, (hipStream_t)stream));
+      if (dx) NC_TRY(conv_dgrad_pg1(g, act0, 0.2f, params + l.w_off, dx, c0, (hipStream_t)stream));
+      break;
+    }
     if (dparams)
       NC_TRY(nc_conv_wgrad(in, g, dparams + l.w_off, have_db ? nullptr : dparams + l.b_off, B, l.C, l.iD, l.iH, l.iW, l.K, kd,
                            4, 4, l.stride, 1, cws, P.conv_ws, stream));
@@ -207,6 +233,8 @@ static int pg_bwd(const PgPlan& P, const float* params, const float* x, const fl
       } else {
         NC_TRY(nc_instnorm_act_bwd(gin, praw, mean, rstd, 0.2f, graw, B * pl.K, S, iws, P.in_ws, stream));
       }
+    } else if (i == 1 && P.fused0) {
+      graw = gin;  // the first layer's gradients apply the mask themselves
     } else {
       NC_TRY(nc_leaky_relu_bwd(gin, praw, 0.2f, graw, (long)B * pl.K * S, stream));
     }

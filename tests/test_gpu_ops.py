@@ -409,3 +409,31 @@ def test_image_staged_configs_agree(B, C, K, H, W, s):
     finally:
         L.nc_sconv_set_cfg(I(-1))
     assert n[0] >= 4 and n[1] >= 4, n
+
+
+@pytest.mark.parametrize('B,K,H,W', [(108, 64, 108, 108), (7, 64, 37, 53), (3, 48, 20, 21), (216, 64, 36, 36), (1, 8, 5, 4)])
+def test_patchgan_first_layer_kernels(B, K, H, W):
+    """patchgan_edge.hip: Conv2d(1 -> K, k 4, s 2, p 1) forward, weight + bias gradient (MFMA over the pixel axis, the bias as
+    a column of ones) and data gradient (2 x 2 input blocks), against torch fp32 -- Athena's batch, odd planes, K < 64."""
+    import torch.nn.functional as F
+    from neuroclear_amd._lib import lib
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + H)
+    x = torch.randn(B, 1, H, W, device=DEV, generator=g)
+    w = torch.randn(K, 1, 4, 4, device=DEV, generator=g) * 0.25
+    b = torch.randn(K, device=DEV, generator=g)
+    assert lib().nc_conv_fwd_path(1, K, 1, 4, 4, 2, 1) == 8
+    y = ops.conv_fwd_raw(x, w, b, 2, 1)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    assert y.shape == ref.shape
+    assert float((y - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    dy = torch.randn(ref.shape, device=DEV, generator=g)
+    dx = ops.conv_dgrad_raw(dy, w, x.shape, 2, 1)
+    refd = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=2, padding=1)
+    assert float((dx - refd).abs().max()) <= 1e-5 * float(refd.abs().max())
+    dw, db = ops.conv_wgrad_raw(x, dy, w.shape, 2, 1, True)
+    refw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=2, padding=1)
+    assert float((dw.double() - refw).abs().max()) <= 2e-5 * float(refw.abs().max())
+    refb = dy.double().sum((0, 2, 3))
+    assert float((db.double() - refb).abs().max()) <= 2e-5 * float(refb.abs().max() + 1)
+    dw2, _ = ops.conv_wgrad_raw(x, dy, w.shape, 2, 1, False)
+    assert torch.equal(dw, dw2)
