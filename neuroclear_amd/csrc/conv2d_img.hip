@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// source of every padding / out-of-range lane of an LDS-DMA copy: 256 B of zeros in the code object (no memset per launch)
+__device__ const float g_zero_page[64] = {};
+
 constexpr int kMaxSeg = 4;
 constexpr int kLds = 160 * 1024;
 
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
       for (int s0 = wave * 64; s0 < used; s0 += NW * 64) {
         const int s = s0 + lane;
         const int o = s < used ? tab[s] : -1;
-        const float* src = o >= 0 ? xc + (long)ci * Sin + o : p.zeros;
+        const float* src = o >= 0 ? xc + (long)ci * Sin + o : g_zero_page;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bd + (long)ci * p.CS + s0), 4, 0, 0);
       }
     }
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
     if (wave == 0) cbtab[lane] = valid ? cb : 0;
     // ---- stage dy: 32 channels per wave, lanes = columns
     {
-      const float* src0 = dyoff >= 0 ? p.dy + dyoff : p.zeros;
+      const float* src0 = dyoff >= 0 ? p.dy + dyoff : g_zero_page;
       const long cstride = dyoff >= 0 ? (long)HW : 0;
 #pragma unroll 4
       for (int ch = wave * 32; ch < wave * 32 + 32; ++ch)
@@ -666,7 +669,6 @@ int conv_wgrad_sconv(const float* x, const float* dy, float* dw, const ConvDims&
   const size_t pbytes = align256((size_t)w.splits * d.K * d.C * 16 * sizeof(float));
   float* part = (float*)ws;
   float* zeros = (float*)((char*)ws + pbytes);
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("sconv_wgrad: memset failed"); return NC_ERR_HIP; }
   WParams p{};
   p.x = x; p.dy = dy; p.out = w.splits == 1 ? dw : part; p.zeros = zeros;
   p.B = d.N; p.C = d.C; p.K = d.K; p.Hi = d.H; p.Wi = d.W; p.Hu = d.Ho; p.Wu = d.Wo; p.s = d.sh;
@@ -722,7 +724,6 @@ int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, 
   if (!ws || wsb < sconv_ws_bytes(d)) { set_error("sconv_fwd: workspace too small"); return NC_ERR_WS; }
   float* wp = (float*)ws;
   float* zeros = (float*)((char*)ws + align256((size_t)d.C * d.K * 16 * sizeof(float)));
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("sconv_fwd: memset failed"); return NC_ERR_HIP; }
   const long total = (long)d.C * d.K * 16;
   hipLaunchKernelGGL(k_pack_sconv, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, d.C, d.K, 4, 4, (long)d.C * 16, 16L, 0, 1, 0,
                      1, 4, total);
@@ -745,7 +746,6 @@ int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims&
   if (!ws || wsb < sconv_ws_bytes(d)) { set_error("sconv_dgrad: workspace too small"); return NC_ERR_WS; }
   float* wp = (float*)ws;
   float* zeros = (float*)((char*)ws + align256((size_t)d.C * d.K * 16 * sizeof(float)));
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("sconv_dgrad: memset failed"); return NC_ERR_HIP; }
   SParams p{};
   p.x = dy; p.bias = nullptr; p.y = dx; p.zeros = zeros;
   p.B = d.N; p.C = d.K; p.M = d.C; p.Hi = d.Ho; p.Wi = d.Wo; p.Hf = d.H; p.Wf = d.W;

@@ -14,6 +14,8 @@
 #include "common.hpp"
 
 namespace nc {
+NC_ZERO_PAGE()
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -165,11 +167,8 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
   }
   W1Params p{};
   p.x = x; p.dy = dy; p.slab = (float*)ws;
-  p.zeros = (const float*)((const char*)ws + need - 256);
-  if (hipMemsetAsync((char*)ws + need - 256, 0, 256, s) != hipSuccess) {
-    set_error("wgrad_1x1: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
+  p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("wgrad_1x1: no zero page"); return NC_ERR_HIP; }
   p.C = d.C; p.K = d.K; p.N = d.N;
   p.S = (long)d.D * d.H * d.W;
   p.Kp = (d.K + 15) & ~15; p.Cp = (d.C + 15) & ~15;
@@ -314,12 +313,9 @@ static int launch_flat(const float* in, const float* w, const float* bias, float
     set_error("flat_1x1: workspace too small");
     return NC_ERR_WS;
   }
-  if (hipMemsetAsync(ws, 0, 256, s) != hipSuccess) {
-    set_error("flat_1x1: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
   F1Params p{};
-  p.in = in; p.w = w; p.bias = bias; p.out = out; p.zeros = (const float*)ws;
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("flat_1x1: no zero page"); return NC_ERR_HIP; }
   p.M = M; p.R = R; p.N = d.N; p.sm = sm; p.sr = sr;
   p.S = (long)d.D * d.H * d.W;
   p.Rp = (R + 3) & ~3;

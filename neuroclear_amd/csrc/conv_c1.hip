@@ -7,6 +7,8 @@
 #include "common.hpp"
 
 namespace nc {
+NC_ZERO_PAGE()
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -364,17 +366,14 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
     set_error("wgrad_c1: workspace too small (%zu < %zu)", wsb, need);
     return NC_ERR_WS;
   }
-  if (hipMemsetAsync((char*)ws + need - 256, 0, 256, s) != hipSuccess) {
-    set_error("wgrad_c1: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
   C1wParams p{};
   int lds_bytes = 0;
   if (!c1w_plan(d, p, lds_bytes)) {
     set_error("wgrad_c1: unsupported shape");
     return NC_ERR_SHAPE;
   }
-  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("wgrad_c1: no zero page"); return NC_ERR_HIP; }
   p.parts = c1w_parts(d);
   const int e = d.kd == 7 ? launch_c1w<7>(p, lds_bytes, s) : launch_c1w<3>(p, lds_bytes, s);
   if (e) return e;
@@ -576,12 +575,9 @@ int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDi
     set_error("dgrad_to1: workspace too small (%zu < %zu)", wsb, need);
     return NC_ERR_WS;
   }
-  if (hipMemsetAsync((char*)ws + need - 256, 0, 256, s) != hipSuccess) {
-    set_error("dgrad_to1: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
   T1Params p{};
-  p.dy = dy; p.w = w; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + need - 256);
+  p.dy = dy; p.w = w; p.slab = (float*)ws; p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("dgrad_to1: no zero page"); return NC_ERR_HIP; }
   p.N = d.N; p.D = d.D; p.H = d.H; p.Wf = d.W;
   // rows wider than 112 columns (the Z strips and the ring are sized for 112) are done as two column segments that
   // overlap by the 3-column reach of the kernel on either side of the cut; each writes its own half of the row

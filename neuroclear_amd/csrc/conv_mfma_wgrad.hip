@@ -17,6 +17,8 @@
 #include "common.hpp"
 
 namespace nc {
+NC_ZERO_PAGE()
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -815,12 +817,9 @@ static int conv_wgrad_dma(const float* x, const float* dy, float* dw, const Conv
     set_error("wgrad_dma: workspace too small (%zu < %zu)", wsb, slab + 256);
     return NC_ERR_WS;
   }
-  if (hipMemsetAsync((char*)ws + slab, 0, 256, s) != hipSuccess) {
-    set_error("wgrad_dma: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
   WdParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + slab);
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("wgrad: no zero page"); return NC_ERR_HIP; }
   p.C = d.C; p.K = d.K; p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
   p.PR = pl.PR; p.PAr = pl.PAr; p.SX = pl.SX; p.SD = pl.SD; p.NXB = pl.NXB; p.XW = pl.XW;
   p.CB = d.C / CIW; p.KBK = d.K / 64; p.parts = pl.parts;
@@ -843,12 +842,9 @@ static int conv_wgrad_rows(const float* x, const float* dy, float* dw, const Con
     set_error("wgrad_rows: workspace too small (%zu < %zu)", wsb, slab + 256);
     return NC_ERR_WS;
   }
-  if (hipMemsetAsync((char*)ws + slab, 0, 256, s) != hipSuccess) {
-    set_error("wgrad_rows: memset of the zero page failed");
-    return NC_ERR_HIP;
-  }
   WrParams p{};
-  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = (const float*)((const char*)ws + slab);
+  p.x = x; p.dy = dy; p.slab = (float*)ws; p.zeros = nc_zero_page();
+  if (!p.zeros) { set_error("wgrad: no zero page"); return NC_ERR_HIP; }
   p.C = d.C; p.K = d.K; p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W;
   p.R = pl.R; p.Wg = pl.Wg; p.PRc = pl.PRc; p.PAc = pl.PAc; p.SX = pl.SX; p.SD = pl.SD;
   p.CB = d.C / 32; p.KBK = d.K / 64; p.parts = pl.parts;
