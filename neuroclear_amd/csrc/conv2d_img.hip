@@ -529,36 +529,50 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
 
     __syncthreads();  // the previous stage's operand reads are done
     if (wave == 0) cbtab[lane] = valid ? cb : 0;
-    // ---- stage dy: 32 channels per wave, lanes = columns
+    // ---- stage dy: 32 channels per wave, lanes = columns; 32-bit offsets from the uniform base p.dy; a column past the end
+    //      of the chunk (last stage only) is written as zero by its lane
     {
-      const float* src0 = dyoff >= 0 ? p.dy + dyoff : g_zero_page;
-      const long cstride = dyoff >= 0 ? (long)HW : 0;
-#pragma unroll 4
-      for (int ch = wave * 32; ch < wave * 32 + 32; ++ch)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src0 + ch * cstride), (lptr_t)(As + ch * kWAP), 4, 0, 0);
+      const unsigned dyo = (unsigned)(valid ? dyoff : 0);
+      if (valid) {
+#pragma unroll 8
+        for (int ch = wave * 32; ch < wave * 32 + 32; ++ch)
+          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.dy + (dyo + (unsigned)(ch * HW)) * 4u), (lptr_t)(As + ch * kWAP), 4, 0,
+                                           0);
+      } else {
+        for (int ch = wave * 32; ch < wave * 32 + 32; ++ch) As[ch * kWAP + lane] = 0.f;
+      }
     }
     // ---- stage the input rows: channels wave, wave + 4, ...; one row (<= 64 dwords) per instruction.  The padding
     //      columns (ix = -1, ix >= Wi) are never written (lanes masked off; zeroed once above); a padding ROW is written as
-    //      zeros by the wave.  Sources are 32-bit element offsets from p.x (uniform base + lane offset)
+    //      zeros by the wave.  Lane r decodes row r once per stage (element offset of its column 0 inside channel 0 of its
+    //      image, or -1 for a padding row); a copy is then that offset + the channel + the lane - 1, off the uniform base p.x
     {
       const int rows = rows0 + rows1;
+      int rowoff;
+      {
+        const int r = lane;
+        const bool s1 = r >= rows0;
+        const int iy = s1 ? r - rows0 - 1 : u0 * p.s - 1 + r;
+        rowoff = (r < rows && (unsigned)iy < (unsigned)p.Hi) ? (s1 ? b1 : b0) * p.C * (int)Sin + iy * p.Wi : -1;
+      }
+      const bool colok = (unsigned)(lane - 1) < (unsigned)p.Wi;
 #pragma unroll 1
       for (int ci = wave; ci < NCW; ci += 4) {
-        const int xo0 = (b0 * p.C + c0 + ci) * (int)Sin - 1;
-        const int xo1 = (b1 * p.C + c0 + ci) * (int)Sin - 1;
+        const int co = (c0 + ci) * (int)Sin;
         float* const xd = Xs + ci * p.CS;
 #pragma unroll 1
         for (int r = 0; r < rows; ++r) {
-          const bool s1 = r >= rows0;
-          const int iy = s1 ? r - rows0 - 1 : u0 * p.s - 1 + r;
-          const int ro = (s1 ? xo1 : xo0) + iy * p.Wi;
-          if ((unsigned)iy < (unsigned)p.Hi) {
+          const int ro = __builtin_amdgcn_readlane(rowoff, r);
+          if (ro >= 0) {
+            if (colok && lane < p.pitch)
+              __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)(ro + co + lane - 1) * 4u), (lptr_t)(xd + r * p.pitch), 4,
+                                               0, 0);
 #pragma unroll 1
-            for (int cc = 0; cc < p.pitch; cc += 64) {
+            for (int cc = 64; cc < p.pitch; cc += 64) {
               const int col = cc + lane;
               if ((unsigned)(col - 1) < (unsigned)p.Wi)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)((ro + col) * 4)), (lptr_t)(xd + r * p.pitch + cc),
-                                                 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)(ro + co + col - 1) * 4u),
+                                                 (lptr_t)(xd + r * p.pitch + cc), 4, 0, 0);
             }
           } else {
             for (int col = lane; col < p.pitch; col += 64) xd[r * p.pitch + col] = 0.f;
@@ -651,6 +665,8 @@ WPlan plan_swgrad(const ConvDims& d) {
 
 bool sconv_wgrad_supported(const ConvDims& d) {
   if (!sconv_layer_ok(d) || d.K % 128 || d.C % 8) return false;
+  // the staging copies address x and dy by 32-bit BYTE offsets from their base pointers
+  if ((long)d.N * d.C * d.H * d.W >= (1L << 30) || (long)d.N * d.K * d.Ho * d.Wo >= (1L << 30)) return false;
   const WPlan w = plan_swgrad(d);
   // worth it once the reduction is long (batched planes); a few planes stay on the gather GEMM
   static const long mincol = getenv("NC_SWGRAD_MINCOL") ? atol(getenv("NC_SWGRAD_MINCOL")) : 4096;
