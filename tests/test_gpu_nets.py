@@ -372,6 +372,36 @@ def test_athena_shared_fake_pass_matches_two_passes(size, batch, monkeypatch):
     assert float((a - b).norm() / b.norm()) < 1e-3
 
 
+def test_patchgan_share_guards():
+    """ops.PatchGANShare is only honoured for exactly the planes it holds and the weights that produced them: another source
+    tensor, another slicing axis, an in-place change of the source or a parameter update (generation bump) make
+    share_matches false (the model then runs the ordinary two-half batch), and a discriminator whose parameters require
+    grad is never shared."""
+    net = load(networks.define_D(1, 64, 'n_layers', 3, 'instance', 'kaiming', 0.02, False, [0], dimension=2),
+               S.patchgan_spec(2), 5)
+    from neuroclear_amd.models.axial_to_lateral_gan_apollo_model import FlatAdam
+    FlatAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.999))  # the parameters become views of one flat buffer, as in the models
+    vol = torch.from_numpy(rnd(3, (1, 1, 24, 24, 24))).to(DEV).requires_grad_(True)
+    fake = vol * 1.0
+    planes = ops.volume_all_slices(fake, 1)
+    assert not net.can_share(planes)  # parameters still require grad
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert net.can_share(planes)
+    share = ops.PatchGANShare()
+    y = net.forward_fake_half(planes, share, fake, 1)
+    assert y.shape[0] == planes.shape[0]
+    assert net.share_matches(share, fake, 1)
+    assert not net.share_matches(share, fake, 2)          # other axis
+    assert not net.share_matches(share, fake.clone(), 1)  # other tensor
+    ref = net(planes)                                     # the ordinary pass gives the same predictions
+    assert torch.equal(ref, y)
+    ops.bump_param_generation(ops._pack_params(list(net.parameters())))
+    assert not net.share_matches(share, fake, 1)          # "optimizer step" since the pass
+    share.release()
+    assert not net.share_matches(share, fake, 1)
+
+
 def test_train_onecube_and_checkpoint_roundtrip(tmp_path):
     """Entry-script level: two iterations of train_onecube on a synthetic volume (option parsing, on-device crops,
     schedulers, checkpoint files with the reference's names), then the generator is reloaded through TestModel /
