@@ -25,7 +25,7 @@ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 // 256 B of zeros in the code object of a translation unit: the source of padding / out-of-range lanes of LDS-DMA copies
 // (no memset launch per convolution).  NC_ZERO_PAGE() once at namespace scope, nc_zero_page() = its device address.
 #define NC_ZERO_PAGE()                                                                          \
-  static __device__ __attribute__((used)) float g_nc_zero_page[64];                             \
+  static __device__ __attribute__((used, aligned(256))) float g_nc_zero_page[64];               \
   static const float* nc_zero_page() {                                                          \
     static const float* p = nullptr;                                                            \
     if (!p) {                                                                                   \

@@ -31,7 +31,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // source of every padding / out-of-range lane of an LDS-DMA copy: 256 B of zeros in the code object (no memset per launch)
-__device__ const float g_zero_page[64] = {};
+__device__ __attribute__((aligned(256))) const float g_zero_page[64] = {};
 
 constexpr int kMaxSeg = 4;
 constexpr int kLds = 160 * 1024;

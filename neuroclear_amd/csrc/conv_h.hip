@@ -25,6 +25,7 @@
 #include "common.hpp"
 
 namespace nc {
+NC_ZERO_PAGE()
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -536,8 +537,8 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   if (!ws || wsb < xb + wb + 256) { set_error("conv_h: workspace too small"); return NC_ERR_WS; }
   uint4* xh = xh_pre ? (uint4*)xh_pre : (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
-  uint4* zeros = (uint4*)((char*)ws + xb + wb);
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_h: memset failed"); return NC_ERR_HIP; }
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("conv_h: no zero page"); return NC_ERR_HIP; }
   if (!xh_pre) {
     hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
     if (int e = check_launch("to_c8")) return e;
@@ -652,8 +653,8 @@ int run_c1_fwd(const float* x, const float* w, const float* bias, void* yh, int 
   if (!ws || wsb < xb + wb + 256) { set_error("conv_c1_fwd_h: workspace too small"); return NC_ERR_WS; }
   uint4* x8 = (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
-  uint4* zeros = (uint4*)((char*)ws + xb + wb);
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_fwd_h: memset failed"); return NC_ERR_HIP; }
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("conv_c1_fwd_h: no zero page"); return NC_ERR_HIP; }
   hipLaunchKernelGGL((k_build_x8<DT>), dim3((unsigned)cdiv(N * S, 256)), dim3(256), 0, s, x, x8, W, KS, N * S);
   const long total = (long)(x8_packed_bytes(KS, 1) / 2);
   hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 1, 0, g_wdiffuse, total);
@@ -682,8 +683,8 @@ int run_c1_dgrad(const void* dyh, const float* w, float* dx, int N, int D, int H
   if (!ws || wsb < xb + wb + 256) { set_error("conv_c1_dgrad_h: workspace too small"); return NC_ERR_WS; }
   uint4* dx8 = (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
-  uint4* zeros = (uint4*)((char*)ws + xb + wb);
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("conv_c1_dgrad_h: memset failed"); return NC_ERR_HIP; }
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("conv_c1_dgrad_h: no zero page"); return NC_ERR_HIP; }
   const long total = (long)(x8_packed_bytes(KS, 8) / 2);
   hipLaunchKernelGGL((k_pack_w_x8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, KS, 8, 1, g_wdiffuse, total);
   if (int e = check_launch("c1_dgrad_h pack")) return e;
@@ -981,8 +982,8 @@ int run_wh(const float* x, const void* xh_pre, const float* dy, const void* dyh_
   uint4* xh = xh_pre ? (uint4*)xh_pre : (uint4*)ws;
   uint4* dyh = dyh_pre ? (uint4*)dyh_pre : (uint4*)((char*)ws + xb);
   float* part = (float*)((char*)ws + xb + yb);
-  uint4* zeros = (uint4*)((char*)ws + xb + yb + pb);
-  if (hipMemsetAsync(zeros, 0, 256, s) != hipSuccess) { set_error("wgrad_h: memset failed"); return NC_ERR_HIP; }
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("wgrad_h: no zero page"); return NC_ERR_HIP; }
   if (!xh_pre)
     hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xh, S, d.C);
   if (!dyh_pre)
