@@ -65,7 +65,7 @@ def pmc_traffic(tag, crop=108, batch=1):
     if '_lp_' not in tag and (crop != 108 or batch != 1):
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
             return round(json.load(f)['classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
     except Exception:
         return None
@@ -254,6 +254,15 @@ def run_train(args, rank, world, dev):
 GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
 
 
+def pmc_traffic_cube():
+    """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+            return round(json.load(f)['inference_cube_140']['hbm_bytes_per_cube'])
+    except Exception:
+        return None
+
+
 def run_infer(args, rank, world, dev, steps=None, warmup=None):
     """configs[2]: 900^3 synthetic volume, dice 120 / overlap 15 / border_cut 10 -> 729 cubes of 140^3, cube i on rank
     i % world; rank 0's weights are broadcast (RCCL), every rank overlap-adds its own cubes into its own accumulator and
@@ -309,7 +318,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: '
                                         'k_conv_mfma<3,*>, profiles/r02_infer_kernel_stats.csv)',
                     achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, launches=len(ev),
+                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic_cube(), launches=len(ev),
                     avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     share_of_run=round(ms / (dt * 1e3), 4),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
