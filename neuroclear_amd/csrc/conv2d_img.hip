@@ -1,5 +1,8 @@
 // "Image-staged" implicit-GEMM convolution for the 2-D PatchGAN layers (reference models/networks.py:1030-1057: Conv2d
-// k 4, stride 2 / 1, padding 1) on the fp32 matrix cores: forward, and the data gradient as forward-shaped problems.
+// k 4, stride 2 / 1, padding 1) on the fp32 matrix cores: forward, the data gradient as forward-shaped problems (k_sconv),
+// and the weight gradient as a GEMM over the flat (image, u, v) axis (k_swgrad, further down).  The tile shape of k_sconv is
+// chosen per problem by timing on first use (run_tuned): every shape accumulates in the same order, so the bits do not depend
+// on the choice.
 //
 // Why: batched over Athena's slices (108-216 images of 108^2 per discriminator pass, axial_to_lateral_gan_athena_model.py:
 // 286-296) these layers are long GEMMs -- M = 128..512 output channels, N = 10^4..10^5 output pixels, K = 1024..4096 -- and
