@@ -372,6 +372,35 @@ def test_athena_shared_fake_pass_matches_two_passes(size, batch, monkeypatch):
     assert float((a - b).norm() / b.norm()) < 1e-3
 
 
+@pytest.mark.parametrize('model_name', ['axial_to_lateral_gan_apollo', 'axial_to_lateral_gan_athena'])
+def test_step_with_spectral_norm_discriminators(model_name):
+    """--netD basic_SN through a whole optimisation step of both models: every plane goes through such a discriminator in its
+    own call (each call moves the power-iteration vectors, as in the reference), so neither the batched pass nor Athena's shared
+    fake pass applies -- two steps must run, with finite losses and moving discriminator weights."""
+    from neuroclear_amd.models import create_model
+    opt = _apollo_opt()
+    opt.model = model_name
+    opt.netD = 'basic_SN'
+    if 'athena' in model_name:
+        opt.conversion_plane = ['yz', 'xy']
+        opt.pool_size = 50
+    torch.manual_seed(3)
+    np.random.seed(3)
+    model = create_model(opt)
+    dname = [n for n in model.model_names if n.startswith('D_')][0]
+    before = [p.detach().clone() for p in getattr(model, 'net' + dname).parameters()]
+    real = torch.from_numpy(rnd(5, (1, 1, 24, 24, 24)))
+    for _ in range(2):
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+    L = model.get_current_losses()
+    assert all(np.isfinite(v) for v in L.values()), L
+    after = list(getattr(model, 'net' + dname).parameters())
+    assert any(float((a.detach() - b).abs().max()) > 0 for a, b in zip(after, before))
+    if 'athena' in model_name:
+        assert model._shares == {}
+
+
 def test_patchgan_share_guards():
     """ops.PatchGANShare is only honoured for exactly the planes it holds and the weights that produced them: another source
     tensor, another slicing axis, an in-place change of the source or a parameter update (generation bump) make
