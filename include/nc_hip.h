@@ -293,6 +293,12 @@ int nc_conv_c1_fwd_c8(const float* x, const float* w, const float* bias, void* y
                       int ks, int dtype, void* ws, size_t ws_bytes, void* stream);
 int nc_conv_c1_dgrad_c8(const void* dyh, const float* w, float* dx, int N, int D, int H, int W, int ks, void* ws, size_t ws_bytes,
                         void* stream);
+/* Weight gradient of the same layers from the C8 (bf16) gradient: dw fp32 [64,1,ks,ks,ks] = sum dyh * shifted x.  The K-dim of
+ * the 16-bit MFMA is 16 consecutive voxels of an x row (planar 16-bit copies of dy and of the 8 x-shifted copies of x are built
+ * in the workspace); W <= 192. */
+size_t nc_conv_c1_wgrad_c8_ws_bytes(int N, int D, int H, int W, int ks);
+int nc_conv_c1_wgrad_c8(const float* x, const void* dyh, float* dw, int N, int D, int H, int W, int ks, void* ws, size_t ws_bytes,
+                        void* stream);
 size_t nc_c8_instnorm_ws_bytes(int N, int C, long S);
 int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,
                          size_t ws_bytes, void* stream);

@@ -62,6 +62,15 @@ int nc_conv_c1_dgrad_c8(const void* dyh, const float* w, float* dx, int N, int D
   return conv_c1_dgrad_h(dyh, w, dx, N, D, H, W, ks, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t nc_conv_c1_wgrad_c8_ws_bytes(int N, int D, int H, int W, int ks) { return c1_wgrad_h_ws_bytes(N, D, H, W, ks); }
+
+int nc_conv_c1_wgrad_c8(const float* x, const void* dyh, float* dw, int N, int D, int H, int W, int ks, void* ws, size_t ws_bytes,
+                        void* stream) {
+  if (!x || !dyh || !dw) { set_error("conv_c1_wgrad_c8: null pointer"); return NC_ERR_ARG; }
+  if (!c1_wgrad_h_supported(N, D, H, W, ks)) { set_error("conv_c1_wgrad_c8: shape not covered (kernel 3 or 7, W <= 192)"); return NC_ERR_SHAPE; }
+  return conv_c1_wgrad_h(x, dyh, dw, N, D, H, W, ks, ws, ws_bytes, (hipStream_t)stream);
+}
+
 size_t nc_c8_instnorm_ws_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : c8_stats_ws_bytes(N, C, S); }
 
 int nc_c8_instnorm_stats(const void* xh, int N, int C, long S, float eps, float* mean, float* rstd, int dtype, void* ws,

@@ -160,6 +160,12 @@ int conv_c1_dgrad_h(const void* dyh, const float* w, float* dx, int N, int D, in
 // 16-bit weight rounding for the calls that follow on this host thread: 0 round-to-nearest, 1 tap-diffused (conv_h.hip)
 void h_set_weight_diffusion(int on);
 
+// weight gradient of the one-channel KS^3 layers (KS = 3, 7) on the 16-bit cores from the C8 gradient (c1_wgrad_h.hip)
+bool c1_wgrad_h_supported(int N, int D, int H, int W, int KS);
+size_t c1_wgrad_h_ws_bytes(int N, int D, int H, int W, int KS);
+int conv_c1_wgrad_h(const float* x, const void* dyh, float* dw, int N, int D, int H, int W, int KS, void* ws, size_t wsb,
+                    hipStream_t s);
+
 // the fwd/dgrad MFMA kernel prefetches packed weights one kernel row ahead: slack behind the packed stream
 static constexpr size_t kPackSlackBytes = 128 * 1024;
 

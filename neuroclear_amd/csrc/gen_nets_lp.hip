@@ -13,6 +13,8 @@
 // deep_linear_gen's pointwise tail 64 -> 32 -> 16 -> 1 has no bias and no activation: it IS a single 64-vector
 // w_eff = W6 W5 W4, and every weight gradient of the three layers is an outer product with q = sum_v dy[v] f3[:, v]
 // (one output channel => rank 1).  The tail is evaluated in that form (k_lin_tail_*): no 32- / 16-channel tensors exist.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -148,6 +150,11 @@ UWs ulp_ws(const ULp& p, void* ws) {
 }  // namespace
 
 namespace {
+// NC_C1_WGRAD=0: the one-channel layers' weight gradient back on the fp32 tap-axis kernel (A/B runs)
+bool c1_wgrad_on() {
+  static const bool on = !(getenv("NC_C1_WGRAD") && atoi(getenv("NC_C1_WGRAD")) == 0);
+  return on;
+}
 struct WeightDiffusion {
   WeightDiffusion() { nc::h_set_weight_diffusion(1); }
   ~WeightDiffusion() { nc::h_set_weight_diffusion(0); }
@@ -293,6 +300,13 @@ int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, c
     NC_TRY(c8_instnorm_bwd(G + p.G1, 64, 0, V + p.raw0, F(p.mean[0]), F(p.rstd[0]), 0.f, G + p.G2, DP + o.b[0], N, 64, S, dt, u.c8ws,
                            p.c8_ws, hs));
     if (dx) NC_TRY(conv_c1_dgrad_h(G + p.G2, P + o.w[0], dx, N, d0[0], d0[1], d0[2], 3, u.c1ws, p.c1_ws, hs));
+    {
+      // weight gradient on the 16-bit cores straight from the C8 gradient (c1_wgrad_h.hip); its planar copies live in the
+      // fp32 gradient buffers F1 + F2, which this path does not use
+      const size_t fbytes = (size_t)2 * N * 64 * S * 4, need = c1_wgrad_h_ws_bytes(N, d0[0], d0[1], d0[2], 3);
+      if (c1_wgrad_on() && need > 0 && need <= fbytes)
+        return conv_c1_wgrad_h(x, G + p.G2, DP + o.w[0], N, d0[0], d0[1], d0[2], 3, f1, fbytes, hs);
+    }
     NC_TRY(c8_to_f32(G + p.G2, 64, 0, f2, N, 64, S, NC_DT_BF16, hs));
     return nc_conv_wgrad(x, f2, DP + o.w[0], nullptr, N, 1, d0[0], d0[1], d0[2], 64, 3, 3, 3, 1, 1, u.fws, p.f32conv_ws, stream);
   }
@@ -482,6 +496,11 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
     // gradient on the fp32 tap-axis kernel, fed with the fp32 copy of df1
     NC_TRY(conv_dgrad_h_c8(G + p.B, params + p.w[1], G + p.A, 64, 0, c5, NC_DT_BF16, cws, p.conv_ws, hs));
     if (dx) NC_TRY(conv_c1_dgrad_h(G + p.A, params + p.w[0], dx, N, S0, S1, S2, 7, c1ws, p.c1_ws, hs));
+    {
+      const size_t fbytes = (size_t)N * 64 * p.S * 4, need = c1_wgrad_h_ws_bytes(N, S0, S1, S2, 7);
+      if (c1_wgrad_on() && need > 0 && need <= fbytes)  // 16-bit weight gradient from the C8 gradient; scratch = the unused fp32 buffer
+        return conv_c1_wgrad_h(x, G + p.A, dparams + p.w[0], N, S0, S1, S2, 7, Ff, fbytes, hs);
+    }
     NC_TRY(c8_to_f32(G + p.A, 64, 0, Ff, N, 64, p.S, NC_DT_BF16, hs));
     return nc_conv_wgrad(x, Ff, dparams + p.w[0], nullptr, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3, fws, p.f32conv_ws, stream);
   }

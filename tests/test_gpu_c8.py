@@ -256,6 +256,17 @@ def test_one_channel_layers_pseudo_channel_form(N, dims, ks):
     ref = F.conv_transpose3d(dyr, wr, padding=ks // 2)
     assert float((dx - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
     assert float((dx - ref).abs().mean()) <= 2 ** -9 * float(ref.abs().max())
+    # weight gradient on the 16-bit cores (c1_wgrad_h.hip): exact products of the bf16-rounded operands, fp32 accumulation
+    nbw = L().nc_conv_c1_wgrad_c8_ws_bytes(N, D, H, W, ks)
+    assert nbw > 0
+    wsw = ws(nbw)
+    dw = torch.empty(64, 1, ks, ks, ks, device=DEV)
+    ok(L().nc_conv_c1_wgrad_c8(P(x), P(to_c8(dy, BF)), P(dw), N, D, H, W, ks, P(wsw), ctypes.c_size_t(wsw.numel()), None))
+    refw = torch.nn.grad.conv3d_weight(xr.double(), w.shape, dyr.double(), padding=ks // 2)
+    assert float((dw.double() - refw).abs().max()) <= 1e-4 * float(refw.abs().max()), float((dw.double() - refw).abs().max() / refw.abs().max())
+    dw2 = torch.empty_like(dw)
+    ok(L().nc_conv_c1_wgrad_c8(P(x), P(to_c8(dy, BF)), P(dw2), N, D, H, W, ks, P(wsw), ctypes.c_size_t(wsw.numel()), None))
+    assert torch.equal(dw, dw2)
 
 
 def _nets():
