@@ -3,14 +3,15 @@
 //   dW[k][dz][dy][dx] = sum over (n, z, y, x) of g[n][k][z][y][x] * xin[n][z + dz - p][y + dy - p][x + dx - p].
 // The fp32 tap-axis kernel (conv_c1.hip, 95 TFLOP/s) cost 6.0 ms + 0.8 ms per configs[3] step, plus two 1 ms conversions of
 // the C8 gradient to fp32 to feed it.  Here the K-dim of v_mfma_f32_32x32x16_bf16 is 16 consecutive voxels of an x row:
-//   * operands are PLANAR 16-bit rows (pitch PX, a multiple of 16, zero beyond W): GP[n][k][row][x] from the C8 gradient
-//     (k_c8_to_planar16) and the pseudo-channel planes XP[n][j][row][x] = xin[row][x + j - p] (k_build_xp: the dx taps become 8
-//     "channels", as in conv_h.hip's forward of the same layer) -- so a lane's 8 k values are 16 contiguous, aligned bytes;
-//   * A = GP[k = lane][x0 + 8h ..], B = XP[j][row shifted by (dz, dy)][x0 + 8h ..] with the 32 columns n = (dy quad member, j):
-//     one MFMA covers 4 dy x 8 dx taps of one dz for 32 output channels;
+//   * B comes from PLANAR 16-bit rows (pitch PX, a multiple of 16, zero beyond W): the pseudo-channel planes
+//     XP[n][j][row][x] = xin[row][x + j - p] (k_build_xp: the dx taps become 8 "channels", as in conv_h.hip's forward of the same
+//     layer) -- a lane's 8 k values are 16 contiguous, aligned bytes of the row shifted by (dz, dy); the 32 columns are
+//     n = (dy quad member, j): one MFMA covers 4 dy x 8 dx taps of one dz for 32 output channels;
+//   * A comes straight from the C8 gradient row (8 blocks x W units of 16 bytes, staged as it is) through gfx950's transposing
+//     LDS read ds_read_b64_tr_b16 -- per 16-lane group a 4-voxel x 16-channel block comes back channel-major, two reads build
+//     the 8-voxel fragment (the lane roles of conv_h.hip's k_wgrad_h);
 //   * a workgroup owns one (sample, z) plane and one group of 4 dz: its 8 waves are (channel half, dz); it walks the rows y
-//     with the 2p + 1 rows of each of its dz planes in an 8-slot LDS ring and the gradient row double-buffered (LDS-DMA, one
-//     instruction per row: the LDS pitch is PX + 8 so that lanes = channels fall on distinct 16-byte slots);
+//     with the 2p + 1 rows of each of its dz planes in an 8-slot LDS ring and the gradient row double-buffered (LDS-DMA);
 //   * one partial [64][4 dz][8 dy][8 dx] per workgroup, summed over the planes in a fixed order (k_c1_wgrad_reduce).
 #include "common.hpp"
 
@@ -27,25 +28,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ unsigned short to_bf16(float f) {
   const __bf16 v = (__bf16)f;
   return __builtin_bit_cast(unsigned short, v);
-}
-
-// C8 [N][8][S][8] -> planar [N][64][R][PX], zero for x >= W.  One thread per (n, block, row, x < PX).
-__global__ void __launch_bounds__(256) k_c8_to_planar16(const uint4* __restrict__ c8, unsigned short* __restrict__ gp, int W, int PX,
-                                                        long R, long total) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int x = (int)(i % PX);
-  const long q = i / PX;
-  const long r = q % R;
-  const long nb = q / R;  // n * 8 + block
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (x < W) v = c8[(nb * R + r) * W + x];
-  unsigned short* o = gp + ((nb * 8) * R + r) * PX + x;
-  const long cs = R * PX;
-  o[0 * cs] = (unsigned short)(v.x & 0xffff); o[1 * cs] = (unsigned short)(v.x >> 16);
-  o[2 * cs] = (unsigned short)(v.y & 0xffff); o[3 * cs] = (unsigned short)(v.y >> 16);
-  o[4 * cs] = (unsigned short)(v.z & 0xffff); o[5 * cs] = (unsigned short)(v.z >> 16);
-  o[6 * cs] = (unsigned short)(v.w & 0xffff); o[7 * cs] = (unsigned short)(v.w >> 16);
 }
 
 // fp32 x [N][R][W] -> XP [N][8][R][PX]: plane j holds x shifted by j - p along the row (zero outside the row, for j >= KS and
@@ -68,8 +50,11 @@ __global__ void __launch_bounds__(256) k_build_xp(const float* __restrict__ x, u
   }
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* ltr_t;
+
 struct CwParams {
-  const unsigned short* gp;
+  const uint4* gc8;          // C8 gradient [N][8][S][8]
   const unsigned short* xp;
   const float* zeros;
   float* part;
@@ -81,8 +66,8 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
   constexpr int P = KS / 2, NTT = KS > 4 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* const zrow = lds;                                   // [PL] zeros
-  unsigned short* const Gs = lds + p.PL;                              // [2][64][PL]
-  unsigned short* const XPs = Gs + 2 * 64 * p.PL;                     // [4 dzl][8 slots][8 j][PL]
+  unsigned short* const Gs = lds + p.PL;                              // [2][8 blocks][PX units of 8 channels]
+  unsigned short* const XPs = Gs + 2 * 64 * p.PX;                     // [4 dzl][8 slots][8 j][PL]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -90,22 +75,25 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
   const int n = blockIdx.x / p.D, z = blockIdx.x - n * p.D;
   const int grp = blockIdx.y;
   const long R = (long)p.D * p.H;
-  const int nl = p.PX / 8;  // 16-byte lanes per row
+  const long S = R * p.W;
+  const int nl = p.PX / 8;  // 16-byte lanes per planar row
 
   for (int i = tid; i < p.PL; i += 512) zrow[i] = 0;
-  // the 8 pad elements behind every LDS row are never read (x groups end at PX); nothing else needs initialising: every
-  // ring slot is written before its first use
+  // units x >= W of the gradient rows are never copied: zero them once (their B operand is zero too, but 0 x garbage
+  // could be NaN)
+  for (int i = tid; i < 2 * 8 * (p.PX - p.W) * 8; i += 512) {
+    const int e = i & 7, u = i >> 3;
+    const int xr = u % (p.PX - p.W), bb = u / (p.PX - p.W);  // bb = buffer * 8 + block
+    Gs[((long)bb * p.PX + p.W + xr) * 8 + e] = 0;
+  }
 
-  // staging: wave w copies gradient rows of channels 8 w .. 8 w + 7 and pseudo-channel rows (dzl', j) = 4 w .. 4 w + 3
+  // staging: wave w copies block w of the gradient row (W units of 16 bytes, contiguous in the C8 tensor) and the
+  // pseudo-channel rows (dzl', j) = 4 w .. 4 w + 3
   auto stage_g = [&](int y, int buf) {
-    if (lane < nl) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int ch = wave * 8 + c;
-        const unsigned short* src = p.gp + (((long)n * 64 + ch) * R + (long)z * p.H + y) * p.PX + lane * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Gs + ((long)buf * 64 + ch) * p.PL), 16, 0, 0);
-      }
-    }
+    const uint4* src = p.gc8 + ((long)n * 8 + wave) * S + ((long)z * p.H + y) * p.W;
+    unsigned short* dst = Gs + ((long)buf * 8 + wave) * p.PX * 8;
+    for (int u0 = 0; u0 < p.W; u0 += 64)
+      if (u0 + lane < p.W) __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)(dst + (long)u0 * 8), 16, 0, 0);
   };
   auto stage_x = [&](int yy) {  // input row yy (may be outside the plane) of this group's 4 dz planes -> ring slot (yy + P) & 7
     const int slot = (yy + P) & 7;
@@ -142,7 +130,12 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
       stage_g(y + 1, (y + 1) & 1);
     }
     if (dzok) {
-      const unsigned short* arow = Gs + ((long)(y & 1) * 64 + mt * 32 + li) * p.PL + 8 * h;
+      // transposed-read roles (k_wgrad_h): group g = lane / 16 -> channels 16 (g & 1) .. of this wave's 32, voxel half g / 2;
+      // inside the group lane 4 q + pp supplies the address of voxel row q, channels 4 pp .. 4 pp + 3
+      const int g16 = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+      const int cbsel = 2 * (g16 & 1) + (pp >> 1);
+      const char* abase = reinterpret_cast<const char*>(Gs) + (((long)(y & 1) * 8 + mt * 4 + cbsel) * p.PX) * 16 + (pp & 1) * 8 +
+                          (8 * (g16 >> 1) + q4) * 16;
       const unsigned short* brow[NTT];
       int bstep[NTT];
 #pragma unroll
@@ -153,7 +146,9 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
       }
 #pragma unroll 2
       for (int xg = 0; xg < p.nxg; ++xg) {
-        const i32x4 a = *reinterpret_cast<const i32x4*>(arow + xg * 16);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(abase + xg * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(abase + xg * 256 + 64));
+        const i32x4 a = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
           const i32x4 b = *reinterpret_cast<const i32x4*>(brow[t] + xg * bstep[t]);
@@ -212,11 +207,10 @@ CwPlan cw_plan(int N, int D, int H, int W, int KS) {
   c.PL = c.PX + 8;
   c.nxg = c.PX / 16;
   c.ngrp = KS > 4 ? 2 : 1;
-  c.lds = (c.PL + 2 * 64 * c.PL + 4 * 8 * 8 * c.PL) * 2;
+  c.lds = (c.PL + 2 * 64 * c.PX + 4 * 8 * 8 * c.PL) * 2;
   if (c.lds > 160 * 1024) return c;
   const size_t R = (size_t)D * H;
-  if ((size_t)N * 64 * R * c.PX >= (1ull << 40)) return c;
-  c.gp_bytes = ((size_t)N * 64 * R * c.PX * 2 + 255) & ~(size_t)255;
+  c.gp_bytes = 0;  // (the gradient is read as C8: no planar copy)
   c.xp_bytes = ((size_t)N * 8 * R * c.PX * 2 + 255) & ~(size_t)255;
   c.part_bytes = ((size_t)c.ngrp * N * D * 64 * 256 * 4 + 255) & ~(size_t)255;
   c.ok = true;
@@ -239,21 +233,16 @@ int conv_c1_wgrad_h(const float* x, const void* dyh, float* dw, int N, int D, in
   if (!ws || wsb < c.gp_bytes + c.xp_bytes + c.part_bytes) { set_error("conv_c1_wgrad_h: workspace too small"); return NC_ERR_WS; }
   const float* zeros = nc_zero_page();
   if (!zeros) { set_error("conv_c1_wgrad_h: no zero page"); return NC_ERR_HIP; }
-  unsigned short* gp = (unsigned short*)ws;
   unsigned short* xp = (unsigned short*)((char*)ws + c.gp_bytes);
   float* part = (float*)((char*)ws + c.gp_bytes + c.xp_bytes);
   const long R = (long)D * H;
-  {
-    const long total = (long)N * 8 * R * c.PX;
-    hipLaunchKernelGGL(k_c8_to_planar16, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const uint4*)dyh, gp, W, c.PX, R, total);
-  }
   {
     const long total = (long)N * R * c.PX;
     hipLaunchKernelGGL(k_build_xp, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, xp, W, c.PX, KS, R, total);
   }
   if (int e = check_launch("c1_wgrad_h prep")) return e;
   CwParams p{};
-  p.gp = gp; p.xp = xp; p.zeros = zeros; p.part = part;
+  p.gc8 = (const uint4*)dyh; p.xp = xp; p.zeros = zeros; p.part = part;
   p.N = N; p.D = D; p.H = H; p.W = W; p.PX = c.PX; p.PL = c.PL; p.nxg = c.nxg;
   const dim3 grid((unsigned)(N * D), (unsigned)c.ngrp);
   auto launch = [&](auto kern) -> int {
