@@ -88,21 +88,36 @@ __global__ void __launch_bounds__(256) k_stats_c8(const uint4* __restrict__ x, l
   block_reduce<16>(d, lds, part + (ncb * splits + split) * 16);
 }
 
-__global__ void k_stats_final_c8(const double* __restrict__ part, int NC, int splits, long S, float eps, float* __restrict__ mean,
-                                 float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // n * C + c
-  if (i >= NC) return;
-  const int ncb = i >> 3, j = i & 7;
-  double s = 0, q = 0;
-  for (int k = 0; k < splits; ++k) {
+// one wave per 8-channel block: lane = (split lane kl = lane / 8, channel j = lane % 8) walks the partials kl, kl + 8, ...;
+// the eight split lanes of a channel are then added in a fixed (butterfly) order
+__device__ __forceinline__ void c8_final_sums(const double* __restrict__ part, int ncb, int splits, int lane, double& s, double& q) {
+  const int j = lane & 7, kl = lane >> 3;
+  s = 0;
+  q = 0;
+  for (int k = kl; k < splits; k += 8) {
     s += part[((long)ncb * splits + k) * 16 + j];
     q += part[((long)ncb * splits + k) * 16 + 8 + j];
   }
-  const double m = s / (double)S;
-  double var = q / (double)S - m * m;
-  if (var < 0) var = 0;
-  mean[i] = (float)m;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o >= 8; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_stats_final_c8(const double* __restrict__ part, int NC, int splits, long S, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  const int ncb = blockIdx.x, lane = threadIdx.x;
+  double s, q;
+  c8_final_sums(part, ncb, splits, lane, s, q);
+  const int i = ncb * 8 + lane;  // n * C + c
+  if (lane < 8 && i < NC) {
+    const double m = s / (double)S;
+    double var = q / (double)S - m * m;
+    if (var < 0) var = 0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // ---- normalise + ReLU / LeakyReLU, C8 -> C8 (out: channels [c0, c0 + C) of a ctot-channel buffer) --------------------
@@ -159,17 +174,16 @@ __global__ void __launch_bounds__(256) k_bwd_sums_c8(const uint4* __restrict__ g
   block_reduce<16>(d, lds, part + ((long)ncb * splits + split) * 16);
 }
 
-__global__ void k_bwd_final_c8(const double* __restrict__ part, int NC, int splits, long S, float* __restrict__ m1, float* __restrict__ m2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NC) return;
-  const int ncb = i >> 3, j = i & 7;
-  double a = 0, b = 0;
-  for (int k = 0; k < splits; ++k) {
-    a += part[((long)ncb * splits + k) * 16 + j];
-    b += part[((long)ncb * splits + k) * 16 + 8 + j];
+__global__ void __launch_bounds__(64) k_bwd_final_c8(const double* __restrict__ part, int NC, int splits, long S, float* __restrict__ m1,
+                                                     float* __restrict__ m2) {
+  const int ncb = blockIdx.x, lane = threadIdx.x;
+  double a, b;
+  c8_final_sums(part, ncb, splits, lane, a, b);
+  const int i = ncb * 8 + lane;
+  if (lane < 8 && i < NC) {
+    m1[i] = (float)(a / (double)S);
+    m2[i] = (float)(b / (double)S);
   }
-  m1[i] = (float)(a / (double)S);
-  m2[i] = (float)(b / (double)S);
 }
 
 // dx = rstd * (g' - mean(g') - xhat * mean(g' xhat)) -> C8 (DG); dbp[(ncb * nbx + blockIdx.x)][8] = this block's sums of dx
@@ -421,7 +435,7 @@ int c8_instnorm_stats(const void* x, int N, int C, long S, float eps, float* mea
 #define CALL(D) hipLaunchKernelGGL((k_stats_c8<D>), dim3(sp, N * C / 8), dim3(256), 0, s, (const uint4*)x, S, sp, part)
   DISPATCH_DT(dt, CALL);
 #undef CALL
-  hipLaunchKernelGGL(k_stats_final_c8, dim3((unsigned)cdiv((long)N * C, 256)), dim3(256), 0, s, part, N * C, sp, S, eps, mean, rstd);
+  hipLaunchKernelGGL(k_stats_final_c8, dim3((unsigned)(N * C / 8)), dim3(64), 0, s, part, N * C, sp, S, eps, mean, rstd);
   return check_launch("c8_instnorm_stats");
 }
 
@@ -448,7 +462,7 @@ int c8_instnorm_bwd(const void* g, int gctot, int gc0, const void* x, const floa
 #define CALL(D) hipLaunchKernelGGL((k_bwd_sums_c8<D, NC_DT_BF16>), dim3(sp, N * C / 8), dim3(256), 0, s, (const uint4*)g, gctot / 8, gc0 / 8, (const uint4*)x, mean, rstd, slope, C / 8, S, sp, part)
   DISPATCH_DT(dt, CALL);
 #undef CALL
-  hipLaunchKernelGGL(k_bwd_final_c8, dim3((unsigned)cdiv((long)N * C, 256)), dim3(256), 0, s, part, N * C, sp, S, m1, m2);
+  hipLaunchKernelGGL(k_bwd_final_c8, dim3((unsigned)(N * C / 8)), dim3(64), 0, s, part, N * C, sp, S, m1, m2);
 #define CALL(D) hipLaunchKernelGGL((k_bwd_apply_c8<D, NC_DT_BF16>), dim3((unsigned)nbx, N * C / 8), dim3(256), 0, s, (const uint4*)g, gctot / 8, gc0 / 8, (const uint4*)x, mean, rstd, m1, m2, slope, C / 8, S, 8, (uint4*)dx, dbias ? dbp : nullptr)
   DISPATCH_DT(dt, CALL);
 #undef CALL

@@ -156,6 +156,42 @@ __global__ void __launch_bounds__(256) k_pack_w_h8(const float* __restrict__ w, 
   wp[i] = cvt16<DT>(v);
 }
 
+// Tap-diffused packing (wvalue above costs O(taps) per element when every element walks the residual chain on its own: 0.18 ms
+// for a 5^3 layer): one thread per (co, ci) pair walks its taps ONCE in master order and scatters the rounded values to their
+// packed places -- the inverse of the index maps of k_pack_w_h / k_pack_w_h8.
+template <int DT>
+__global__ void __launch_bounds__(256) k_pack_w_h_diff(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout,
+                                                       int KS, long so, long si, int flip, int pair8) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cin * Cout) return;
+  const int ci = idx % Cin, co = idx / Cin;
+  const int T2 = KS * KS, T3 = T2 * KS, NP = (T2 + 1) / 2;
+  const int cot = co >> 6, a = (co >> 5) & 1, r = co & 31;
+  const float* wpair = w + co * so + ci * si;
+  float res = 0.f;
+  for (int t = 0; t < T3; ++t) {
+    const float v = wpair[t] + res;
+    const float q = round16f<DT>(v);
+    res = v - q;
+    const int tp = flip ? T3 - 1 - t : t;  // packed tap
+    long i;
+    if (pair8) {
+      const int NCH = Cin / 8, chunk = ci >> 3, j = ci & 7;
+      const int dz = tp / T2, t2 = tp - dz * T2, pr = t2 >> 1, h = t2 & 1;
+      i = ((((((long)(cot * NCH + chunk) * KS + dz) * NP + pr) * 2 + a) * 2 + h) * 32 + r) * 8 + j;
+    } else {
+      const int NCH = Cin / 16, chunk = ci >> 4, h = (ci >> 3) & 1, j = ci & 7;
+      i = (((((long)(cot * NCH + chunk) * T3 + tp) * 2 + a) * 2 + h) * 32 + r) * 8 + j;
+    }
+    wp[i] = cvt16<DT>(q);
+  }
+  if (pair8 && (T2 & 1)) {  // the unused second half of the last tap pair of every plane
+    const int NCH = Cin / 8, chunk = ci >> 3, j = ci & 7;
+    for (int dz = 0; dz < KS; ++dz)
+      wp[((((((long)(cot * NCH + chunk) * KS + dz) * NP + NP - 1) * 2 + a) * 2 + 1) * 32 + r) * 8 + j] = 0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 struct HParams {
   const uint4* xh;    // C8 input
@@ -544,12 +580,15 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
     if (int e = check_launch("to_c8")) return e;
   }
   const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
-  if (KS == 5)
+  if (g_wdiffuse)
+    hipLaunchKernelGGL((k_pack_w_h_diff<DT>), dim3((unsigned)cdiv((long)Cin * Kout, 256)), dim3(256), 0, s, w, wp, Cin, Kout, KS, so, si,
+                       flip, KS == 5 ? 1 : 0);
+  else if (KS == 5)
     hipLaunchKernelGGL((k_pack_w_h8<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip,
-                       g_wdiffuse, total);
+                       0, total);
   else
     hipLaunchKernelGGL((k_pack_w_h<DT>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 16, T3, so, si,
-                       flip, g_wdiffuse, total);
+                       flip, 0, total);
   if (int e = check_launch("pack_w_h")) return e;
   HParams p{};
   p.xh = xh; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
