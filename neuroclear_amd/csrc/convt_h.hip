@@ -260,16 +260,17 @@ __global__ void __launch_bounds__(64) k_convT_wgrad_h(const TWParams p) {
 // for 1.66 GB of dY); here every 16-voxel step's dY units are fetched once per workgroup (wave w brings the sub-positions
 // w, w + C/32, ...) into one of two shared LDS images, the x units stay wave-private.  One barrier per step: a wave can only
 // be one step ahead of the slowest one, so the image of step s + 2 never overwrites fragments still being read.
-template <int DT>
+template <int DT, int VS>  // VS 16-voxel groups per step (one barrier per step)
 __global__ void __launch_bounds__(512) k_convT_wgrad_h2(const TWParams p) {
-  constexpr int BS = 20;
+  constexpr int BS = VS * 16 + 4;
   extern __shared__ __attribute__((aligned(16))) uint4 dimg[];  // [NW][4 * BS] x, then [2][8][4 * BS] dY
   const int NW = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kt = blockIdx.x, ct = wave, split = blockIdx.y;
   const int TPW = 8 / NW;  // dY sub-positions fetched per wave
-  const long steps_per_n = (p.Sc + 15) / 16, steps = steps_per_n * p.N;
+  const long G = VS * 16;
+  const long steps_per_n = (p.Sc + G - 1) / G, steps = steps_per_n * p.N;
   const long s_lo = steps * split / p.splits, s_hi = steps * (split + 1) / p.splits;
   const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
   const long Sf = 8 * p.Sc;
@@ -289,45 +290,54 @@ __global__ void __launch_bounds__(512) k_convT_wgrad_h2(const TWParams p) {
   const unsigned char* xl = reinterpret_cast<const unsigned char*>(ximg);
   const unsigned char* yl = reinterpret_cast<const unsigned char*>(yimg);
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  uint4 nx = zero4, ny[8];
+  uint4 nx[VS], ny[VS][8];
   auto fetch = [&](long st) {
     const int n = (int)(st / steps_per_n);
-    const long v = (st - (long)n * steps_per_n) * 16 + j;
-    const bool ok = v < p.Sc;
-    const long vc = ok ? v : p.Sc - 1;
-    const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
-    const long vf = ((long)(2 * zd) * Hf + 2 * yh) * Wf + 2 * xw;
-    nx = ok ? xg[((long)n * (p.C >> 3) + ct * 4 + cb) * p.Sc + vc] : zero4;
-    const uint4* yb = yg + ((long)n * p.dctot8 + p.dc08 + kt * 4 + cb) * Sf + vf;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < TPW) {
-        const int t = wave + i * NW;
-        ny[i] = ok ? yb[((long)(t >> 2) * Hf + ((t >> 1) & 1)) * Wf + (t & 1)] : zero4;
-      }
+    for (int ss = 0; ss < VS; ++ss) {
+      const long v = (st - (long)n * steps_per_n) * G + ss * 16 + j;
+      const bool ok = v < p.Sc;
+      const long vc = ok ? v : p.Sc - 1;
+      const int xw = (int)(vc % p.Wc), yh = (int)((vc / p.Wc) % p.Hc), zd = (int)(vc / ((long)p.Wc * p.Hc));
+      const long vf = ((long)(2 * zd) * Hf + 2 * yh) * Wf + 2 * xw;
+      nx[ss] = ok ? xg[((long)n * (p.C >> 3) + ct * 4 + cb) * p.Sc + vc] : zero4;
+      const uint4* yb = yg + ((long)n * p.dctot8 + p.dc08 + kt * 4 + cb) * Sf + vf;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < TPW) {
+          const int t = wave + i * NW;
+          ny[ss][i] = ok ? yb[((long)(t >> 2) * Hf + ((t >> 1) & 1)) * Wf + (t & 1)] : zero4;
+        }
+    }
   };
   if (s_lo < s_hi) fetch(s_lo);
   for (long st = s_lo; st < s_hi; ++st) {
     const int buf = (int)((st - s_lo) & 1);
-    ximg[cb * BS + j] = nx;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < TPW) yimg[(buf * 8 + wave + i * NW) * 4 * BS + cb * BS + j] = ny[i];
+    for (int ss = 0; ss < VS; ++ss) {
+      ximg[cb * BS + ss * 16 + j] = nx[ss];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < TPW) yimg[(buf * 8 + wave + i * NW) * 4 * BS + cb * BS + ss * 16 + j] = ny[ss][i];
+    }
     if (st + 1 < s_hi) fetch(st + 1);
     __syncthreads();
-    i32x4 a;
-    {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(xl + rd));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(xl + rd + 64));
-      a = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const unsigned base = (unsigned)((buf * 8 + t) * 4 * BS * 16) + rd;
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(yl + base));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(yl + base + 64));
-      const i32x4 b = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      acc[t] = mfma16<DT>(a, b, acc[t]);
+    for (int ss = 0; ss < VS; ++ss) {
+      i32x4 a;
+      {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(xl + rd + ss * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(xl + rd + ss * 256 + 64));
+        a = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const unsigned base = (unsigned)((buf * 8 + t) * 4 * BS * 16) + rd + ss * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(yl + base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(yl + base + 64));
+        const i32x4 b = __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        acc[t] = mfma16<DT>(a, b, acc[t]);
+      }
     }
   }
 #pragma unroll
@@ -467,8 +477,14 @@ int convT_wgrad_h(const void* x, const void* dy, int dctot, int dc0, float* dw, 
   static const bool shared_dy = !(getenv("NC_CONVT_WGRAD_SHARED") && atoi(getenv("NC_CONVT_WGRAD_SHARED")) == 0);  // A/B switch
   const int NW = C / 32;
   if (shared_dy && (NW == 1 || NW == 2 || NW == 4 || NW == 8)) {
-    const size_t lds = (size_t)(NW * 4 * 20 + 2 * 8 * 4 * 20) * 16;
-    hipLaunchKernelGGL((k_convT_wgrad_h2<NC_DT_BF16>), dim3(K / 32, splits), dim3(64 * NW), lds, s, p);
+    static const int vs = getenv("NC_CONVT_WGRAD_VS") ? atoi(getenv("NC_CONVT_WGRAD_VS")) : 1;  // (2 = 32 voxels per barrier: measured 40 % slower)
+    if (vs == 2) {
+      const size_t lds = (size_t)(NW * 4 * 36 + 2 * 8 * 4 * 36) * 16;
+      hipLaunchKernelGGL((k_convT_wgrad_h2<NC_DT_BF16, 2>), dim3(K / 32, splits), dim3(64 * NW), lds, s, p);
+    } else {
+      const size_t lds = (size_t)(NW * 4 * 20 + 2 * 8 * 4 * 20) * 16;
+      hipLaunchKernelGGL((k_convT_wgrad_h2<NC_DT_BF16, 1>), dim3(K / 32, splits), dim3(64 * NW), lds, s, p);
+    }
   } else {
     hipLaunchKernelGGL((k_convT_wgrad_h<NC_DT_BF16>), dim3((C / 32) * (K / 32), splits), dim3(64), 0, s, p);
   }
