@@ -72,14 +72,27 @@ struct TParams {
   long Sc;
 };
 
-// forward: block = 4 waves = 4 tiles of 32 coarse voxels; blockIdx.y = 32-channel output tile
+// forward: block = 4 waves, a wave = tiles of 32 coarse voxels; blockIdx.y = 32-channel output tile.  The packed weights of
+// the output tile (8 sub-positions x C / 16 chunks x 1 KiB) are copied into LDS once per workgroup and every wave walks several
+// voxel tiles with them: read from global per (sub-position, chunk) they were 64 KB per 32 voxels -- 6.5 GB of L2 traffic per
+// launch at 128 -> 64 / 4 x 74^3, which was what the kernel spent its time on.
 template <int DT>
 __global__ void __launch_bounds__(256) k_convT_fwd_h(const TParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 wl[];  // [8 t][NCH][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int kt = blockIdx.y, NCH = p.C / 16, KT = p.K / 32;
-  const long tile = (long)blockIdx.x * 4 + wave;
-  const long tiles_per_n = (p.Sc + 31) / 32;
-  if (tile >= tiles_per_n * p.N) return;
+  for (int i = threadIdx.x; i < 8 * NCH * 64; i += 256) {
+    const int t = i / (NCH * 64), rem = i - t * NCH * 64;
+    wl[i] = p.wp[((long)t * KT + kt) * NCH * 64 + rem];
+  }
+  __syncthreads();
+  const long tiles_per_n = (p.Sc + 31) / 32, ntiles = tiles_per_n * p.N;
+  const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
+  const long Sf = 8 * p.Sc;
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
   const int n = (int)(tile / tiles_per_n);
   const long v0 = (tile - (long)n * tiles_per_n) * 32;
   const long v = v0 + r;
@@ -91,34 +104,49 @@ __global__ void __launch_bounds__(256) k_convT_fwd_h(const TParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   const uint4* xb = p.x + ((long)n * p.xctot8 + p.xc08) * p.Sc + vc;
-  const uint4* wb = p.wp + ((long)kt * NCH * 2 + h) * 32 + r;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    const i32x4 b = __builtin_bit_cast(i32x4, xb[(long)(chunk * 2 + h) * p.Sc]);
+  // all the tile's input units first (8 chunks in flight: one HBM round trip per 8, not per chunk), then the products
+  for (int c0 = 0; c0 < NCH; c0 += 8) {
+    i32x4 b[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const i32x4 a = __builtin_bit_cast(i32x4, wb[((long)t * KT * NCH + chunk) * 64]);
-      acc[t] = mfma16<DT>(a, b, acc[t]);
-    }
+    for (int c = 0; c < 8; ++c)
+      if (c0 + c < NCH) b[c] = __builtin_bit_cast(i32x4, xb[(long)((c0 + c) * 2 + h) * p.Sc]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c0 + c < NCH) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const i32x4 a = __builtin_bit_cast(i32x4, wl[(t * NCH + c0 + c) * 64 + lane]);
+          acc[t] = mfma16<DT>(a, b[c], acc[t]);
+        }
+      }
   }
-  if (!ok) return;
+  if (!ok) continue;
   const int xw = (int)(v % p.Wc), yh = (int)((v / p.Wc) % p.Hc), zd = (int)(v / ((long)p.Wc * p.Hc));
-  const int Hf = 2 * p.Hc, Wf = 2 * p.Wc;
-  const long Sf = 8 * p.Sc;
-  float bv[16];
+  // A lane holds channels 4h .. 4h + 3 of the four 8-channel blocks, i.e. one 8-byte half of a unit, for both x sub-positions
+  // c = 0 / 1 of a (z, y) sub-position.  The two lanes (r, 0) / (r, 1) swap halves so that lane h writes the WHOLE unit of
+  // c = h: 64 lanes x 16 bytes = 1 KiB of contiguous output per store (consecutive r are consecutive fine x pairs).
+  uint4* ob = reinterpret_cast<uint4*>(p.out) + ((long)n * p.octot8 + p.oc08 + kt * 4) * Sf;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
-  uint2* ob = p.out + (((long)n * p.octot8 + p.oc08 + kt * 4) * Sf) * 2 + h;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const long vf = ((long)(2 * zd + (t >> 2)) * Hf + (2 * yh + ((t >> 1) & 1))) * Wf + 2 * xw + (t & 1);
+  for (int ab = 0; ab < 4; ++ab) {
+    const long vf = ((long)(2 * zd + (ab >> 1)) * Hf + (2 * yh + (ab & 1))) * Wf + 2 * xw + h;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      uint2 o;
-      o.x = cvt16<DT>(acc[t][4 * g4] + bv[4 * g4]) | ((unsigned)cvt16<DT>(acc[t][4 * g4 + 1] + bv[4 * g4 + 1]) << 16);
-      o.y = cvt16<DT>(acc[t][4 * g4 + 2] + bv[4 * g4 + 2]) | ((unsigned)cvt16<DT>(acc[t][4 * g4 + 3] + bv[4 * g4 + 3]) << 16);
-      ob[((long)g4 * Sf + vf) * 2] = o;
+      uint2 o[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x16& a = acc[2 * ab + c];
+        o[c].x = cvt16<DT>(a[4 * g4] + bv[4 * g4]) | ((unsigned)cvt16<DT>(a[4 * g4 + 1] + bv[4 * g4 + 1]) << 16);
+        o[c].y = cvt16<DT>(a[4 * g4 + 2] + bv[4 * g4 + 2]) | ((unsigned)cvt16<DT>(a[4 * g4 + 3] + bv[4 * g4 + 3]) << 16);
+      }
+      const uint2 send = h ? o[0] : o[1];  // what the partner lane needs: its c's other half
+      uint2 recv;
+      recv.x = (unsigned)__shfl_xor((int)send.x, 32);
+      recv.y = (unsigned)__shfl_xor((int)send.y, 32);
+      const uint4 u = h ? make_uint4(recv.x, recv.y, o[1].x, o[1].y) : make_uint4(o[0].x, o[0].y, recv.x, recv.y);
+      ob[(long)g4 * Sf + vf] = u;
     }
   }
+  }  // tiles
 }
 
 // dgrad: wave = 32 coarse voxels x CTW 32-channel tiles of ci; K-dim = (t, k)
@@ -436,15 +464,27 @@ int convT_fwd_h(const void* x, const float* w, const float* bias, void* out, int
   p.x = (const uint4*)x; p.wp = (const uint4*)ws; p.bias = bias; p.out = (uint2*)out;
   p.N = N; p.C = C; p.K = K; p.Dc = D; p.Hc = H; p.Wc = W; p.Sc = (long)D * H * W;
   p.xctot8 = C / 8; p.xc08 = 0; p.octot8 = octot / 8; p.oc08 = oc0 / 8;
-  const unsigned gx = (unsigned)cdiv(cdiv(p.Sc, 32) * N, 4);
+  // ~2048 workgroups in all (each keeps its output tile's weights in LDS and walks several voxel tiles)
+  long gxl = cdiv(cdiv(p.Sc, 32) * N, 4);
+  const long cap = cdiv(2048, K / 32);
+  if (gxl > cap) gxl = cap;
+  const unsigned gx = (unsigned)gxl;
+  const size_t lds = (size_t)8 * (C / 16) * 64 * 16;
+  if (lds > 160 * 1024) { set_error("convT_fwd_h: more than 320 input channels"); return NC_ERR_SHAPE; }
+  auto launch = [&](auto kern) -> int {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("convT_fwd_h: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, K / 32), dim3(256), lds, s, p);
+    return check_launch("convT_fwd_h");
+  };
   if (dt == NC_DT_F16) {
     if (int e = pack_T<NC_DT_F16>(w, ws, C, K, 0, s)) return e;
-    hipLaunchKernelGGL((k_convT_fwd_h<NC_DT_F16>), dim3(gx, K / 32), dim3(256), 0, s, p);
-  } else {
-    if (int e = pack_T<NC_DT_BF16>(w, ws, C, K, 0, s)) return e;
-    hipLaunchKernelGGL((k_convT_fwd_h<NC_DT_BF16>), dim3(gx, K / 32), dim3(256), 0, s, p);
+    return launch(k_convT_fwd_h<NC_DT_F16>);
   }
-  return check_launch("convT_fwd_h");
+  if (int e = pack_T<NC_DT_BF16>(w, ws, C, K, 0, s)) return e;
+  return launch(k_convT_fwd_h<NC_DT_BF16>);
 }
 
 // dy: channels [dc0, dc0 + K) of a dctot-channel C8 buffer at (2D, 2H, 2W) (bf16); dx: dense C8 [N][C/8][D*H*W][8] (bf16)
