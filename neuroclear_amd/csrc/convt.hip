@@ -3,6 +3,8 @@
 // input voxel, out[k, 2z+a, 2y+b, 2x+c] = bias[k] + sum_c x[c, z, y, x] * w[c, k, a, b, c'].
 // One lane owns one INPUT voxel and KT output channels x 8 taps of accumulators; weights are wave-uniform (scalar
 // cache).  1.9 % of the U-Net's FLOPs -- kept on the VALU for round 1.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nc {
@@ -44,6 +46,76 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
         float2* dst = reinterpret_cast<float2*>(yk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
         *dst = make_float2(acc[j][(a * 2 + b) * 2], acc[j][(a * 2 + b) * 2 + 1]);
       }
+  }
+}
+
+// The same forward on the fp32 matrix cores (K % 32 == 0, C even): with k == s each sub-position (a, b, c) is a plain GEMM
+// Y_abc[k][voxel] = sum_ci W[ci][k][abc] X[ci][voxel].  A workgroup owns 32 output channels and one a; its weights
+// (C x 32 x 4 floats, laid out as MFMA A operands) are gathered into LDS once, and each of its 4 waves walks tiles of 32 voxels:
+// ALL input values of a tile are requested first (C / 2 dwords per lane, one HBM round trip per tile), then C / 2 k-steps of
+// 4 MFMAs (the (b, c) sub-positions) with the A operand from LDS.  The c = 0 / 1 results of a voxel leave as one float2.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int CH>  // C / 2, compile time: the input values of a tile live in registers
+__global__ __launch_bounds__(256, 2) void k_convT_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C, int D, int H,
+                                                           int W, int K, int N) {
+  extern __shared__ float wl[];  // [CH][4][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int kt = blockIdx.y >> 1, a = blockIdx.y & 1;
+  for (int i = threadIdx.x; i < CH * 4 * 64; i += 256) {
+    const int s2 = i >> 8, q = (i >> 6) & 3, ln = i & 63;
+    wl[i] = w[((long)(2 * s2 + (ln >> 5)) * K + kt * 32 + (ln & 31)) * 8 + a * 4 + q];
+  }
+  __syncthreads();
+  const long S = (long)D * H * W;
+  const long tiles_per_n = (S + 31) / 32, ntiles = tiles_per_n * N;
+  const int H2 = 2 * H, W2 = 2 * W;
+  const long S2 = 8 * S;
+  float bb[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bb[e] = bias ? bias[kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const int n = (int)(tile / tiles_per_n);
+    const long pos = (tile - (long)n * tiles_per_n) * 32 + li;
+    const bool valid = pos < S;
+    const long p = valid ? pos : S - 1;
+    const float* xp = x + ((long)n * C + h) * S + p;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    // input values in groups of 16 k-steps, the next group requested before the current one is multiplied
+    float bc[16], bn[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bc[i] = xp[(long)(2 * i) * S];
+#pragma unroll 1
+    for (int s0 = 0; s0 < CH; s0 += 16) {
+      if (s0 + 16 < CH) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bn[i] = xp[(long)(2 * (s0 + 16 + i)) * S];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[((s0 + i) * 4 + q) * 64 + lane], bc[i], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+    }
+    if (!valid) continue;
+    const int ix = (int)(p % W), iy = (int)((p / W) % H), iz = (int)(p / ((long)W * H));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float* yk = y + ((long)n * K + k) * S2;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float2* dst = reinterpret_cast<float2*>(yk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
+        *dst = make_float2(acc[b * 2][e] + bb[e], acc[b * 2 + 1][e] + bb[e]);
+      }
+    }
   }
 }
 
@@ -179,9 +251,27 @@ int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* 
   if (!x || !w || !y) { set_error("convT_fwd: null pointer"); return NC_ERR_ARG; }
   if (int e = convT_check("convT_fwd", N, C, D, H, W, K)) return e;
   const long S = (long)D * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  static const bool mfma_on = !(getenv("NC_CONVT_MFMA") && atoi(getenv("NC_CONVT_MFMA")) == 0);  // A/B switch
+  // (measured: 128 -> 64 at 70^3 0.77 -> 0.55 ms, at 54^3 0.34 -> 0.28; 256 -> 128 at 35^3 0.30 -> 0.36: the VALU kernel keeps it)
+  if (mfma_on && !g_force_direct && K % 32 == 0 && C == 128 && (long)N * K * 8 * S < (1L << 40)) {
+    long gx = cdiv(cdiv(S, 32) * N, 4);
+    const long cap = cdiv(2048, 2 * (K / 32));
+    if (gx > cap) gx = cap;
+    const dim3 g((unsigned)gx, 2 * (K / 32));
+    const size_t lds = (size_t)(C / 2) * 4 * 64 * sizeof(float);
+    auto launch = [&](auto kern) -> int {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("convT_fwd: cannot raise dynamic LDS limit");
+        return NC_ERR_HIP;
+      }
+      hipLaunchKernelGGL(kern, g, dim3(256), lds, s, x, w, bias, y, C, D, H, W, K, N);
+      return check_launch("convT_fwd_mfma");
+    };
+    return launch(k_convT_fwd_mfma<64>);
+  }
   const int kt = pick(K, 4, 2, 1);
   dim3 grid((unsigned)cdiv(S, 256), K / kt, N);
-  hipStream_t s = (hipStream_t)stream;
   if (kt == 4) hipLaunchKernelGGL(k_convT_fwd<4>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
   else if (kt == 2) hipLaunchKernelGGL(k_convT_fwd<2>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
   else hipLaunchKernelGGL(k_convT_fwd<1>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
