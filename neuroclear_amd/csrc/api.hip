@@ -55,12 +55,17 @@ static bool pg1_on(const ConvDims& d) {
   static const bool on = !(getenv("NC_PG1") && atoi(getenv("NC_PG1")) == 0);
   return on && pg1_supported(d);
 }
+// Split-operand mode (conv_split.hip): fp32 convolutions of the covered shapes run as six bf16 MFMA products of a three-term
+// operand split.  Off by default; nc_set_conv_split(1) or NC_CONV_SPLIT=1 switch it on.
+static int g_split = getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 0;
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
+  if (g_split && s3_fwd_supported(d)) return 9;
   return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
+  if (g_split && s3_dgrad_supported(d)) return 9;
   return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
                                                                                               : pg1_on(d)             ? 8
                                                                                               : sconv_on(d, 1)        ? 7
@@ -110,6 +115,8 @@ const char* nc_last_error(void) { return g_err; }
 int nc_version(void) { return 100; }
 void nc_set_force_direct(int on) { g_force_direct = on; }
 void nc_sconv_set_cfg(int cfg) { sconv_set_cfg(cfg); }
+void nc_set_conv_split(int on) { g_split = on; }
+int nc_get_conv_split(void) { return g_split; }
 
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
@@ -153,6 +160,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     const size_t sc = pg1_ws_bytes(d);
     if (sc > b) b = sc;
   }
+  if (g_split && (s3_fwd_supported(d) || s3_dgrad_supported(d))) {
+    const size_t sc = s3_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
   return (b + 255) & ~(size_t)255;
 }
@@ -173,7 +184,9 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   ConvDims d;
   if (int e = conv_args("conv_fwd", d, x, w, y, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(0, fwd_path(d), d, 0, s);
+  const int path = fwd_path(d);
+  ProfScope ps(0, path, d, 0, s);
+  if (path == 9) return conv_fwd_s3(x, nullptr, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);
@@ -188,7 +201,9 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   ConvDims d;
   if (int e = conv_args("conv_dgrad", d, dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(1, dgrad_path(d), d, 0, s);
+  const int path = dgrad_path(d);
+  ProfScope ps(1, path, d, 0, s);
+  if (path == 9) return conv_dgrad_s3(dy, nullptr, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);

@@ -134,4 +134,43 @@ int nc_convT_k2s2_wgrad_c8(const void* xh, const void* dyh, int dy_ctot, int dy_
   return convT_wgrad_h(xh, dyh, dy_ctot, dy_c0, dw, dbias, N, C, D, H, W, K, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ---- fp32 3^3 convolutions as six bf16 MFMA products of a three-term operand split (conv_split.hip) -----------------------
+int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
+  ConvDims d;
+  if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return 0;
+  return what == 0 ? s3_fwd_supported(d) : what == 1 ? s3_dgrad_supported(d) : 0;
+}
+
+size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K) {
+  ConvDims d;
+  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1)) return 0;
+  return s3_ws_bytes(d);
+}
+
+size_t nc_s3_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : s3_tensor_bytes(N, C, S); }
+
+int nc_to_s3(const float* x, void* xs, int N, int C, long S, void* stream) {
+  if (!x || !xs) { set_error("to_s3: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 8 || C % 8 || S < 1) { set_error("to_s3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }
+  return split3_to(x, xs, N, C, S, (hipStream_t)stream);
+}
+
+int nc_conv_fwd_split(const float* x, const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
+                      int K, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if ((!x && !xs) || !w || !y) { set_error("conv_fwd_split: null pointer"); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1) || !s3_fwd_supported(d)) { set_error("conv_fwd_split: shape not covered"); return NC_ERR_SHAPE; }
+  ProfScope ps(0, 1, d, 1, (hipStream_t)stream);
+  return conv_fwd_s3(x, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, void* ws,
+                        size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if ((!dy && !dys) || !w || !dx) { set_error("conv_dgrad_split: null pointer"); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1) || !s3_dgrad_supported(d)) { set_error("conv_dgrad_split: shape not covered"); return NC_ERR_SHAPE; }
+  ProfScope ps(1, 1, d, 1, (hipStream_t)stream);
+  return conv_dgrad_s3(dy, dys, w, dx, d, ws, ws_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

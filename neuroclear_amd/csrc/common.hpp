@@ -134,6 +134,15 @@ int conv_wgrad_c1(const float* x, const float* dy, float* dw, const ConvDims& d,
 
 // ---- 16-bit (bf16 / fp16) MFMA convolutions, conv_h.hip.  Each operand comes either as the fp32 tensor (converted
 //      into the workspace) or already converted to the C8 layout (xh / dyh non-null, nc_to_c8)
+// conv_split.hip: fp32 3^3 convolutions as six bf16 MFMA products of a three-term split
+bool s3_fwd_supported(const ConvDims& d);
+bool s3_dgrad_supported(const ConvDims& d);
+size_t s3_ws_bytes(const ConvDims& d);
+size_t s3_tensor_bytes(int N, int C, long S);
+int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
+int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                hipStream_t s);
+int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 bool h_fwd_supported(const ConvDims& d);
 bool h_dgrad_supported(const ConvDims& d);
 bool h_wgrad_supported(const ConvDims& d);

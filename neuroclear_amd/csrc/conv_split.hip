@@ -1,0 +1,432 @@
+// fp32 Conv3d 3^3 (stride 1, "same" padding) on the 16-bit matrix cores: forward and dgrad of the U-Net's 3^3 layers
+// (models/networks.py:420-425, 460-469) with fp32 operands and fp32-grade results.
+//
+// gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32768 FLOP in 32 cycles; the fp32
+// instruction v_mfma_f32_32x32x2_f32: 4096 FLOP in 64).  An fp32 number is EXACTLY the sum of three bf16 numbers
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (8 + 8 + 8 significand bits)
+// and a bf16 x bf16 product is exact in the fp32 accumulator of the MFMA, so
+//     a * b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2]
+// where the bracket is below 2^-23 |a b| -- the size of ONE rounding of an fp32 product.  The six other products are six
+// bf16 MFMAs on the same accumulator: the arithmetic of an fp32 convolution (exact operands, fp32 accumulation) at 16 / 6
+// = 2.7 x the fp32 matrix rate.  tests/test_gpu_split.py measures the error against fp64 next to the fp32 MFMA kernel's.
+//
+// Layout "S3": [N][C/8][3 terms][D][H][W][8 channels] bf16 -- one voxel's 8 channels of one term are one 16-byte unit, the
+// MFMA B fragment of a lane.  k_split3 writes it from fp32 NCDHW.  The kernel is the PAIR form of the 16-bit kernel
+// (conv_h.hip): stage = (8-channel chunk, dz), a k-step = 8 channels at two taps (lane half h takes tap 2i + h; 5 k-steps
+// for the 9 taps of a plane, the 10th tap has zero weights), brick and weights of a stage in LDS by LDS-DMA for all three
+// terms (3 x the 16-bit bytes, 6 x the MFMAs: a third of the 16-bit kernel's staging traffic per MFMA), two stage buffers,
+// tile = 64 output channels x 512 flattened positions of one output plane on 8 waves (2 x 2 accumulator tiles each).
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace nc {
+NC_ZERO_PAGE()
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kLdsMax = 160 * 1024;
+constexpr int kPairs = 5;   // k-steps per stage: 9 taps of a plane, two per step
+constexpr int kWPieces = kPairs * 3 * 2;  // 1 KiB weight pieces per stage: [pair][term][a] x (2 halves x 32 rows x 16 B)
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
+unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+
+__device__ __forceinline__ f32x16 mfma(const i32x4& a, const i32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) {
+  const __bf16 v = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, v);
+}
+__device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
+
+// the three terms of an fp32 value (round to nearest each: the remainders are exact, the third term is exact)
+__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {
+  const float a0 = bf16_val(v);
+  const float r1 = v - a0;
+  const float a1 = bf16_val(r1);
+  const float r2 = r1 - a1;
+  t[0] = bf16_bits(a0); t[1] = bf16_bits(a1); t[2] = bf16_bits(r2);
+}
+
+// fp32 NCDHW -> S3.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, three 16-byte stores.
+__global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uint4* __restrict__ out, long S) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const long ncb = blockIdx.y;  // n * (C/8) + cb
+  const float* xs = x + ncb * 8 * S + v;
+  unsigned short e[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(xs[j * S], e[j]);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    uint4 o;
+    o.x = e[0][t] | ((unsigned)e[1][t] << 16); o.y = e[2][t] | ((unsigned)e[3][t] << 16);
+    o.z = e[4][t] | ((unsigned)e[5][t] << 16); o.w = e[6][t] | ((unsigned)e[7][t] << 16);
+    out[(ncb * 3 + t) * S + v] = o;
+  }
+}
+
+// Packed weights: [cot = co/64][chunk = ci/8][dz][pair i][term][a = (co/32)%2][h][r = co%32][8] bf16, element j = input
+// channel chunk*8 + j at in-plane tap 2i + h (zero for the 10th).  One stage (cot, chunk, dz) = 30 KiB contiguous.
+// fwd:   wp(co, ci, tap) = w[co][ci][tap]                       (so = C*27, si = 27, flip = 0)
+// dgrad: wp(ci as "co", co as "ci", tap) = w[co][ci][26 - tap]   (so = 27,   si = C*27, flip = 1)
+__global__ void __launch_bounds__(256) k_pack_w_s3(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH, long so,
+                                                   long si, int flip, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int r = (int)(q & 31); q >>= 5;
+  const int h = (int)(q & 1); q >>= 1;
+  const int a = (int)(q & 1); q >>= 1;
+  const int term = (int)(q % 3); q /= 3;
+  const int pr = (int)(q % kPairs); q /= kPairs;
+  const int dz = (int)(q % 3); q /= 3;
+  const int chunk = (int)(q % NCH);
+  const int cot = (int)(q / NCH);
+  const int t2 = 2 * pr + h;
+  unsigned short t[3] = {0, 0, 0};
+  if (t2 < 9) {
+    const long co = cot * 64 + a * 32 + r, ci = chunk * 8 + j;
+    const int tap = dz * 9 + t2;
+    split3(w[co * so + ci * si + (flip ? 26 - tap : tap)], t);
+  }
+  wp[i] = t[term];
+}
+
+struct SParams {
+  const uint4* xs;    // S3 input
+  const uint4* wp;    // packed weights
+  const float* bias;  // nullable
+  float* y;           // fp32 NCDHW output
+  const uint4* zeros; // >= 16 B of zeros in global memory
+  int N, NCH, D, H, W, K;  // NCH = C / 8
+  int P, R, RP;       // row pitch (units), brick rows, R * P
+  int PT, TPP;        // positions per tile, tiles per plane
+  int KT;             // K / 64
+  unsigned mP, mRP;
+  int npb;            // brick pieces (1 KiB) per stage, all three terms
+  int SB;             // bytes per stage buffer
+  long ntiles;
+  int tiles_per_xcd;
+};
+
+struct STile {
+  int n, cot, z, q0, yf, xoff;
+};
+
+__device__ __forceinline__ STile s_decode(const SParams& p, long t) {
+  STile o;  // order as in conv_h.hip: output-channel tile fastest, then z: neighbouring planes share input planes in L2
+  o.cot = (int)(t % p.KT); t /= p.KT;
+  o.z = (int)(t % p.D); t /= p.D;
+  const int tp = (int)(t % p.TPP);
+  o.n = (int)(t / p.TPP);
+  o.q0 = tp * p.PT;
+  o.yf = (int)fdiv((unsigned)o.q0, p.mP);
+  o.xoff = o.q0 - o.yf * p.P;
+  return o;
+}
+
+template <int VB>
+__global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int MAXJ = 7;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const long t_lo = (long)xcd * p.tiles_per_xcd;
+  long t_hi = t_lo + p.tiles_per_xcd;
+  if (t_hi > p.ntiles) t_hi = p.ntiles;
+  long tcur = t_lo + slot;
+  if (tcur >= t_hi) return;
+
+  int off[MAXJ];  // per-lane source offset (units) of brick piece wave + 8j relative to term 0 of the plane, or -1 = zero page
+  auto decode_pieces = [&](const STile& t) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const unsigned u = (unsigned)((wave + kWaves * j) * 64 + lane);
+      const unsigned term = fdiv(u, p.mRP);
+      const unsigned ur = u - term * p.RP;
+      const unsigned rr = fdiv(ur, p.mP);
+      const int xx = (int)(ur - rr * p.P) - 1;
+      const int y = t.yf - 1 + (int)rr;
+      const bool ok = term < 3u && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      off[j] = ok ? (int)(term * S + (long)y * p.W + xx) : -1;
+    }
+  };
+  auto dz_lo = [&](const STile& t) { return 1 - t.z > 0 ? 1 - t.z : 0; };
+  auto dz_hi = [&](const STile& t) { return t.z + 1 > p.D - 1 ? 2 - (t.z + 1 - (p.D - 1)) : 2; };
+
+  auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
+    const uint4* plane = p.xs + ((long)tn * p.NCH + chunk) * 3 * S + (long)(tz + dz - 1) * HW;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int pc = wave + kWaves * j;
+      if (pc < p.npb) {
+        const uint4* src = off[j] >= 0 ? plane + off[j] : p.zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+      }
+    }
+    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * 3 + dz) * (kWPieces * 64) + lane;
+    unsigned char* wb = buf + p.npb * 1024;
+#pragma unroll 1
+    for (int pw = wave; pw < kWPieces; pw += kWaves)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
+  };
+
+  unsigned char* const buf0 = lds_raw;
+  unsigned char* const buf1 = lds_raw + p.SB;
+
+  STile cur = s_decode(p, tcur);
+  decode_pieces(cur);
+  int lo = dz_lo(cur), nv = dz_hi(cur) - lo + 1;
+  issue(cur.n, cur.z, cur.cot, 0, lo, buf0);
+  int g = 0;
+
+  // this lane's tap of k-step i as a unit offset: tap 2i + h (the 10th tap reads tap 8's data against zero weights)
+  int bo[kPairs];
+#pragma unroll
+  for (int i = 0; i < kPairs; ++i) {
+    const int t0 = 2 * i, t1 = 2 * i + 1 < 9 ? 2 * i + 1 : 8;
+    bo[i] = h ? (t1 / 3) * p.P + t1 % 3 : (t0 / 3) * p.P + t0 % 3;
+  }
+
+  const int qb = wave * VB * 32 + r;  // this lane's first position in the tile
+  while (true) {
+    const long tnext = tcur + nslot;
+    const bool more_tiles = tnext < t_hi;
+    STile nxt = cur;
+    if (more_tiles) nxt = s_decode(p, tnext);
+    const int nstages = p.NCH * nv;
+
+    f32x16 acc[2][VB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int v = 0; v < VB; ++v)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][v][e] = 0.f;
+
+    int chunk = 0, dzi = 0;
+#pragma unroll 1
+    for (int i = 0; i < nstages; ++i) {
+      unsigned char* bc = (g & 1) ? buf1 : buf0;
+      unsigned char* bn = (g & 1) ? buf0 : buf1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage i has landed
+      __syncthreads();                                  // ... and everybody's; everybody is done reading bn
+      int nchunk = chunk, ndz = dzi + 1;
+      if (ndz == nv) { ndz = 0; ++nchunk; }
+      const bool within = i + 1 < nstages;
+      if (!within && more_tiles) decode_pieces(nxt);
+      if (within || more_tiles)
+        issue(within ? cur.n : nxt.n, within ? cur.z : nxt.z, within ? cur.cot : nxt.cot, within ? nchunk : 0,
+              within ? lo + ndz : dz_lo(nxt), bn);
+
+      // A fragment (pair i, term, a): unit ((i*3 + term)*2 + a)*64 + h*32 + r of the stage's weights;
+      // B fragment (pair i, term, v): unit term*RP + position + tap
+      const i32x4* wl = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
+      const i32x4* bl = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
+      i32x4 A[3][2], B[3][VB], nA[3][2], nB[3][VB];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        A[t][0] = wl[(t * 2) * 64]; A[t][1] = wl[(t * 2 + 1) * 64];
+#pragma unroll
+        for (int v = 0; v < VB; ++v) B[t][v] = bl[t * p.RP + bo[0] + v * 32];
+      }
+#pragma unroll
+      for (int s = 0; s < kPairs; ++s) {
+        if (s + 1 < kPairs) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            nA[t][0] = wl[(((s + 1) * 3 + t) * 2) * 64]; nA[t][1] = wl[(((s + 1) * 3 + t) * 2 + 1) * 64];
+#pragma unroll
+            for (int v = 0; v < VB; ++v) nB[t][v] = bl[t * p.RP + bo[s + 1] + v * 32];
+          }
+        }
+        // six products per (a, v), smallest first; consecutive MFMAs go to different accumulators
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int v = 0; v < VB; ++v) acc[a][v] = mfma(A[TA[m]][a], B[TB[m]][v], acc[a][v]);
+        if (s + 1 < kPairs) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {  // the 6 + 3 VB reads of the next k-step spread over this one's 12 VB MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * VB, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            A[t][0] = nA[t][0]; A[t][1] = nA[t][1];
+#pragma unroll
+            for (int v = 0; v < VB; ++v) B[t][v] = nB[t][v];
+          }
+        }
+      }
+      chunk = nchunk; dzi = ndz;
+      ++g;
+    }
+
+    // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
+    {
+      const int cob = cur.cot * 64;
+      float* yn = p.y + ((long)cur.n * p.K + cob + 4 * h) * S + (long)cur.z * HW;
+      long yo[VB];
+#pragma unroll
+      for (int v = 0; v < VB; ++v) {
+        const unsigned f = (unsigned)(cur.q0 + qb + v * 32);
+        const unsigned yy = fdiv(f, p.mP);
+        const unsigned xx = f - yy * p.P;
+        yo[v] = ((int)yy < p.H && (int)xx < p.W) ? (long)yy * p.W + xx : -1;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[cob + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VB; ++v)
+          if (yo[v] >= 0) {
+            float* yv = yn + yo[v];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yv[(long)(a * 32 + (e & 3) + 8 * (e >> 2)) * S] = acc[a][v][e] + bv[e];
+          }
+      }
+    }
+    if (!more_tiles) break;
+    cur = nxt;
+    tcur = tnext;
+    lo = dz_lo(cur);
+    nv = dz_hi(cur) - lo + 1;
+  }
+}
+
+struct SPlan {
+  int PT, VB, P, R, RP, TPP, npb, SB;
+  bool ok;
+};
+
+SPlan s_plan(int H, int W) {
+  SPlan pl{};
+  pl.P = W + 2;
+  const long plane = (long)H * pl.P;
+  double best = 0;
+  for (int VB : {2, 1}) {
+    const int PT = VB * 256;
+    const int rows = (pl.P - 1 + PT - 1) / pl.P + 1;
+    const int R = rows + 2;
+    const int RP = R * pl.P;
+    const int npb = (3 * RP + 4 + 63) / 64;
+    const int SB = (npb + kWPieces) * 1024;
+    if (npb > 8 * 7 || 2 * SB > kLdsMax) continue;
+    const int TPP = (int)((plane + PT - 1) / PT);
+    const double eff = (double)H * W / ((double)TPP * PT) * (VB == 2 ? 1.0 : 0.85);
+    if (eff > best) {
+      best = eff;
+      pl.PT = PT; pl.VB = VB; pl.R = R; pl.RP = RP; pl.npb = npb; pl.SB = SB; pl.TPP = TPP;
+      pl.ok = true;
+    }
+  }
+  return pl;
+}
+
+bool s_shape_ok(const ConvDims& d, int Cin, int Kout) {
+  if (d.kd != 3 || d.kh != 3 || d.kw != 3) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 1 || d.ph != 1 || d.pw != 1) return false;
+  if (Cin % 8 || Kout % 64) return false;
+  if ((long)d.D * d.H * d.W * 3 >= (1l << 31)) return false;  // per-lane source offsets are 32-bit unit counts
+  return s_plan(d.H, d.W).ok;
+}
+
+size_t s_packed_bytes(int Cin, int Kout) { return (size_t)(Kout / 64) * (Cin / 8) * 3 * kWPieces * 1024; }
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <int VB>
+int launch_s3(const SParams& p, int lds, hipStream_t s) {
+  auto kern = k_conv_s3<VB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+      set_error("conv_s3: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
+  return check_launch("conv_s3");
+}
+
+int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
+           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+  const SPlan pl = s_plan(d.H, d.W);
+  const long S = (long)d.D * d.H * d.W;
+  const size_t xb = xs_pre ? 0 : align256((size_t)d.N * Cin * S * 6);
+  const size_t wb = align256(s_packed_bytes(Cin, Kout));
+  if (!ws || wsb < xb + wb + 256) { set_error("conv_s3: workspace too small"); return NC_ERR_WS; }
+  uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
+  unsigned short* wp = (unsigned short*)((char*)ws + xb);
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("conv_s3: no zero page"); return NC_ERR_HIP; }
+  if (!xs_pre) {
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xs, S);
+    if (int e = check_launch("split3")) return e;
+  }
+  const long total = (long)(s_packed_bytes(Cin, Kout) / 2);
+  hipLaunchKernelGGL(k_pack_w_s3, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, so, si, flip, total);
+  if (int e = check_launch("pack_w_s3")) return e;
+  SParams p{};
+  p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
+  p.N = d.N; p.NCH = Cin / 8; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
+  p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.mP = magic(pl.P); p.mRP = magic(pl.RP);
+  p.npb = pl.npb; p.SB = pl.SB;
+  p.ntiles = (long)d.N * d.D * pl.TPP * p.KT;
+  p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
+  const int lds = 2 * pl.SB;
+  return pl.VB == 2 ? launch_s3<2>(p, lds, s) : launch_s3<1>(p, lds, s);
+}
+
+}  // namespace
+
+bool s3_fwd_supported(const ConvDims& d) { return s_shape_ok(d, d.C, d.K); }
+bool s3_dgrad_supported(const ConvDims& d) { return s_shape_ok(d, d.K, d.C); }
+size_t s3_ws_bytes(const ConvDims& d) {
+  const long S = (long)d.D * d.H * d.W;
+  const int cmax = d.C > d.K ? d.C : d.K;
+  return align256((size_t)d.N * cmax * S * 6) + align256(s_packed_bytes(d.C, d.K) > s_packed_bytes(d.K, d.C) ? s_packed_bytes(d.C, d.K) : s_packed_bytes(d.K, d.C)) + 512;
+}
+size_t s3_tensor_bytes(int N, int C, long S) { return (size_t)N * C * S * 6; }
+
+int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) {
+  if (C % 8) { set_error("split3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S);
+  return check_launch("split3");
+}
+
+int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
+                hipStream_t s) {
+  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * 27, 27, 0, ws, wsb, s);
+}
+
+int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  // dx = conv(dy, flipped / channel-transposed w): "input" channels K, "output" channels C
+  ConvDims t = d;
+  t.C = d.K; t.K = d.C;
+  return run_s3(dy, dys, w, nullptr, dx, t, d.K, d.C, 27, (long)d.C * 27, 1, ws, wsb, s);
+}
+
+}  // namespace nc
