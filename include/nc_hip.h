@@ -340,22 +340,23 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
 int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved, const float* dy, float* dx, float* dparams,
                           int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream);
 
-/* ---- fp32 3^3 convolutions on the 16-bit matrix cores (csrc/conv_split.hip): an fp32 value is exactly the sum of three
+/* ---- fp32 3^3 / 5^3 convolutions on the 16-bit matrix cores (csrc/conv_split.hip): an fp32 value is exactly the sum of three
  *      bf16 terms; the six products a_i b_j with i + j <= 2 are bf16 MFMAs on one fp32 accumulator (what is dropped is below
  *      2^-23 of a product).  Same operands and results as nc_conv_fwd / nc_conv_dgrad (networks.py:420-425, 460-469) to
  *      fp32 rounding.  "S3" tensor: [N][C/8][3 terms][D][H][W][8] bf16 (nc_to_s3); xs / dys: the operand already in that
  *      form, or NULL (then converted into the workspace).  what: 0 forward, 1 data gradient.                              */
-void nc_set_conv_split(int on); /* 1: nc_conv_fwd / nc_conv_dgrad (and the whole-network calls built on them) take this path
-                                  * for the shapes it covers; default 0, or the value of NC_CONV_SPLIT at load time */
+void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at load time): nc_conv_fwd / nc_conv_dgrad and the
+                                  * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
+                                  * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
 int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
-size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K);
+size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K, int ks);
 size_t nc_s3_bytes(int N, int C, long S);
 int nc_to_s3(const float* x, void* xs, int N, int C, long S, void* stream);
 int nc_conv_fwd_split(const float* x, const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
-                      int K, void* ws, size_t ws_bytes, void* stream);
-int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, void* ws,
-                        size_t ws_bytes, void* stream);
+                      int K, int ks /* 3 or 5: cubic kernel, stride 1, padding ks/2 */, void* ws, size_t ws_bytes, void* stream);
+int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int ks,
+                        void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,9 +55,10 @@ static bool pg1_on(const ConvDims& d) {
   static const bool on = !(getenv("NC_PG1") && atoi(getenv("NC_PG1")) == 0);
   return on && pg1_supported(d);
 }
-// Split-operand mode (conv_split.hip): fp32 convolutions of the covered shapes run as six bf16 MFMA products of a three-term
-// operand split.  Off by default; nc_set_conv_split(1) or NC_CONV_SPLIT=1 switch it on.
-static int g_split = getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 0;
+// Split-operand kernels (conv_split.hip): the fp32 3^3 / 5^3 convolutions they cover run as six bf16 MFMA products of an exact
+// three-term operand split (same operands, fp32 accumulation, error against fp64 not above the fp32 MFMA kernel's:
+// tests/test_gpu_split.py).  On by default; nc_set_conv_split(0) or NC_CONV_SPLIT=0 put those layers back on the fp32 MFMA kernels.
+static int g_split = getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 1;
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
@@ -123,6 +124,7 @@ int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) 
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
+  if (g_split && s3_fwd_supported(d)) return 9;
   return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : pg1_on(d) ? 8 : gemm_fwd_supported(d) ? 2 : 0;  // (the K = 1
   // reduction kernel of the PatchGAN head and the image-staged kernels depend on the batch, which this query does not take:
   // reported as 2)

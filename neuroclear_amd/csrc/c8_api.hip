@@ -141,9 +141,9 @@ int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, 
   return what == 0 ? s3_fwd_supported(d) : what == 1 ? s3_dgrad_supported(d) : 0;
 }
 
-size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K) {
+size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K, int ks) {
   ConvDims d;
-  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1)) return 0;
+  if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2)) return 0;
   return s3_ws_bytes(d);
 }
 
@@ -156,19 +156,19 @@ int nc_to_s3(const float* x, void* xs, int N, int C, long S, void* stream) {
 }
 
 int nc_conv_fwd_split(const float* x, const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
-                      int K, void* ws, size_t ws_bytes, void* stream) {
+                      int K, int ks, void* ws, size_t ws_bytes, void* stream) {
   ConvDims d;
   if ((!x && !xs) || !w || !y) { set_error("conv_fwd_split: null pointer"); return NC_ERR_ARG; }
-  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1) || !s3_fwd_supported(d)) { set_error("conv_fwd_split: shape not covered"); return NC_ERR_SHAPE; }
+  if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_fwd_supported(d)) { set_error("conv_fwd_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(0, 1, d, 1, (hipStream_t)stream);
   return conv_fwd_s3(x, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, void* ws,
-                        size_t ws_bytes, void* stream) {
+int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int ks,
+                        void* ws, size_t ws_bytes, void* stream) {
   ConvDims d;
   if ((!dy && !dys) || !w || !dx) { set_error("conv_dgrad_split: null pointer"); return NC_ERR_ARG; }
-  if (!make_dims(d, N, C, D, H, W, K, 3, 3, 3, 1, 1) || !s3_dgrad_supported(d)) { set_error("conv_dgrad_split: shape not covered"); return NC_ERR_SHAPE; }
+  if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_dgrad_supported(d)) { set_error("conv_dgrad_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(1, 1, d, 1, (hipStream_t)stream);
   return conv_dgrad_s3(dy, dys, w, dx, d, ws, ws_bytes, (hipStream_t)stream);
 }

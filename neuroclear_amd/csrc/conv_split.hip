@@ -1,5 +1,6 @@
-// fp32 Conv3d 3^3 (stride 1, "same" padding) on the 16-bit matrix cores: forward and dgrad of the U-Net's 3^3 layers
-// (models/networks.py:420-425, 460-469) with fp32 operands and fp32-grade results.
+// fp32 Conv3d 3^3 / 5^3 (stride 1, "same" padding) on the 16-bit matrix cores: forward and dgrad of the U-Net's 3^3 layers
+// (models/networks.py:420-425, 460-469) and of G_B's 5^3 / 3^3 feature layers (:900-902) with fp32 operands and fp32-grade
+// results.
 //
 // gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32768 FLOP in 32 cycles; the fp32
 // instruction v_mfma_f32_32x32x2_f32: 4096 FLOP in 64).  An fp32 number is EXACTLY the sum of three bf16 numbers
@@ -17,6 +18,7 @@
 // terms (3 x the 16-bit bytes, 6 x the MFMAs: a third of the 16-bit kernel's staging traffic per MFMA), two stage buffers,
 // tile = 64 output channels x 512 flattened positions of one output plane on 8 waves (2 x 2 accumulator tiles each).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -33,8 +35,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kLdsMax = 160 * 1024;
-constexpr int kPairs = 5;   // k-steps per stage: 9 taps of a plane, two per step
-constexpr int kWPieces = kPairs * 3 * 2;  // 1 KiB weight pieces per stage: [pair][term][a] x (2 halves x 32 rows x 16 B)
+// Taps of one kernel plane are taken two per k-step ("pair" q = taps 2q, 2q + 1 in row-major order; an odd count ends in a
+// zero-weight tap).  The pairs of a plane are split into sub-stages so that two weight buffers and two brick buffers fit 160 KB:
+// 3^3: 5 pairs, one sub-stage;  5^3: 13 pairs in sub-stages of 4 + 3 + 3 + 3 (the brick of the plane is staged once).
+template <int KS> struct Sub;
+template <> struct Sub<3> { static constexpr int NP = 5, NSUB = 1, MAXP = 5; static constexpr int q0[2] = {0, 5}; };
+template <> struct Sub<5> { static constexpr int NP = 13, NSUB = 4, MAXP = 4; static constexpr int q0[5] = {0, 4, 7, 10, 13}; };
+constexpr int kPairPieces = 3 * 2;  // 1 KiB weight pieces per pair: [term][a] x (2 halves x 32 rows x 16 B)
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
 unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
@@ -76,30 +83,31 @@ __global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uin
   }
 }
 
-// Packed weights: [cot = co/64][chunk = ci/8][dz][pair i][term][a = (co/32)%2][h][r = co%32][8] bf16, element j = input
-// channel chunk*8 + j at in-plane tap 2i + h (zero for the 10th).  One stage (cot, chunk, dz) = 30 KiB contiguous.
-// fwd:   wp(co, ci, tap) = w[co][ci][tap]                       (so = C*27, si = 27, flip = 0)
-// dgrad: wp(ci as "co", co as "ci", tap) = w[co][ci][26 - tap]   (so = 27,   si = C*27, flip = 1)
-__global__ void __launch_bounds__(256) k_pack_w_s3(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH, long so,
+// Packed weights: [cot = co/64][chunk = ci/8][dz][pair q][term][a = (co/32)%2][h][r = co%32][8] bf16, element j = input
+// channel chunk*8 + j at in-plane tap 2q + h (zero beyond the last tap).  One plane (cot, chunk, dz) = NP * 6 KiB contiguous.
+// fwd:   wp(co, ci, tap) = w[co][ci][tap]                           (so = C*T3, si = T3, flip = 0)
+// dgrad: wp(ci as "co", co as "ci", tap) = w[co][ci][T3 - 1 - tap]   (so = T3,   si = C*T3, flip = 1)
+__global__ void __launch_bounds__(256) k_pack_w_s3(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH, int KS, long so,
                                                    long si, int flip, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  const int T2 = KS * KS, NP = (T2 + 1) / 2, T3 = T2 * KS;
   const int j = (int)(i & 7);
   long q = i >> 3;
   const int r = (int)(q & 31); q >>= 5;
   const int h = (int)(q & 1); q >>= 1;
   const int a = (int)(q & 1); q >>= 1;
   const int term = (int)(q % 3); q /= 3;
-  const int pr = (int)(q % kPairs); q /= kPairs;
-  const int dz = (int)(q % 3); q /= 3;
+  const int pr = (int)(q % NP); q /= NP;
+  const int dz = (int)(q % KS); q /= KS;
   const int chunk = (int)(q % NCH);
   const int cot = (int)(q / NCH);
   const int t2 = 2 * pr + h;
   unsigned short t[3] = {0, 0, 0};
-  if (t2 < 9) {
+  if (t2 < T2) {
     const long co = cot * 64 + a * 32 + r, ci = chunk * 8 + j;
-    const int tap = dz * 9 + t2;
-    split3(w[co * so + ci * si + (flip ? 26 - tap : tap)], t);
+    const int tap = dz * T2 + t2;
+    split3(w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)], t);
   }
   wp[i] = t[term];
 }
@@ -115,10 +123,10 @@ struct SParams {
   int PT, TPP;        // positions per tile, tiles per plane
   int KT;             // K / 64
   unsigned mP, mRP;
-  int npb;            // brick pieces (1 KiB) per stage, all three terms
-  int SB;             // bytes per stage buffer
+  int npb;            // brick pieces (1 KiB) per plane, all three terms
   long ntiles;
   int tiles_per_xcd;
+  int flush;          // 1: per-group accumulator restart (see the kernel)
 };
 
 struct STile {
@@ -137,9 +145,27 @@ __device__ __forceinline__ STile s_decode(const SParams& p, long t) {
   return o;
 }
 
-template <int VB>
+__device__ __forceinline__ void wait_vm(int n) {  // s_waitcnt vmcnt(n) for a wave-uniform n <= 7
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+  }
+}
+
+// LDS: [brick 0][brick 1][weights 0][weights 1]; a brick = the (rows + KS - 1) x P units of ONE input plane for the three terms,
+// a weight buffer = the pairs of one sub-stage.  Group = (8-channel chunk, dz); per group the brick is staged once and the
+// sub-stages walk the plane's tap pairs.
+template <int KS, int VB>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  using SU = Sub<KS>;
+  constexpr int PAD = KS / 2, T2 = KS * KS, NP = SU::NP, NSUB = SU::NSUB;
   constexpr int MAXJ = 7;  // brick pieces per wave (planner: npb <= 8 * MAXJ)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
@@ -159,17 +185,17 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
       const unsigned term = fdiv(u, p.mRP);
       const unsigned ur = u - term * p.RP;
       const unsigned rr = fdiv(ur, p.mP);
-      const int xx = (int)(ur - rr * p.P) - 1;
-      const int y = t.yf - 1 + (int)rr;
+      const int xx = (int)(ur - rr * p.P) - PAD;
+      const int y = t.yf - PAD + (int)rr;
       const bool ok = term < 3u && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       off[j] = ok ? (int)(term * S + (long)y * p.W + xx) : -1;
     }
   };
-  auto dz_lo = [&](const STile& t) { return 1 - t.z > 0 ? 1 - t.z : 0; };
-  auto dz_hi = [&](const STile& t) { return t.z + 1 > p.D - 1 ? 2 - (t.z + 1 - (p.D - 1)) : 2; };
+  auto dz_lo = [&](const STile& t) { return PAD - t.z > 0 ? PAD - t.z : 0; };
+  auto dz_hi = [&](const STile& t) { return t.z + PAD > p.D - 1 ? KS - 1 - (t.z + PAD - (p.D - 1)) : KS - 1; };
 
-  auto issue = [&](int tn, int tz, int tcot, int chunk, int dz, unsigned char* buf) {
-    const uint4* plane = p.xs + ((long)tn * p.NCH + chunk) * 3 * S + (long)(tz + dz - 1) * HW;
+  auto issue_brick = [&](int tn, int tz, int chunk, int dz, unsigned char* buf) {
+    const uint4* plane = p.xs + ((long)tn * p.NCH + chunk) * 3 * S + (long)(tz + dz - PAD) * HW;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const int pc = wave + kWaves * j;
@@ -178,29 +204,33 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
       }
     }
-    const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * 3 + dz) * (kWPieces * 64) + lane;
-    unsigned char* wb = buf + p.npb * 1024;
+  };
+  auto issue_w = [&](int tcot, int chunk, int dz, int qa, int qe, unsigned char* wb) {
+    const uint4* ws = p.wp + ((((long)tcot * p.NCH + chunk) * KS + dz) * NP + qa) * (kPairPieces * 64) + lane;
+    const int npw = (qe - qa) * kPairPieces;
 #pragma unroll 1
-    for (int pw = wave; pw < kWPieces; pw += kWaves)
+    for (int pw = wave; pw < npw; pw += kWaves)
       __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
   };
 
-  unsigned char* const buf0 = lds_raw;
-  unsigned char* const buf1 = lds_raw + p.SB;
+  const int BB = p.npb * 1024;
+  unsigned char* const brick0 = lds_raw;
+  unsigned char* const wbuf0 = lds_raw + 2 * BB;
+  constexpr int WB = SU::MAXP * kPairPieces * 1024;
+  const int nbw = p.npb > wave ? (p.npb - wave + kWaves - 1) / kWaves : 0;  // brick DMAs this wave issues per plane
 
   STile cur = s_decode(p, tcur);
   decode_pieces(cur);
   int lo = dz_lo(cur), nv = dz_hi(cur) - lo + 1;
-  issue(cur.n, cur.z, cur.cot, 0, lo, buf0);
-  int g = 0;
+  issue_brick(cur.n, cur.z, 0, lo, brick0);
+  issue_w(cur.cot, 0, lo, SU::q0[0], SU::q0[1], wbuf0);
+  int gb = 0, gw = 0;  // parities of the brick / weight buffer being computed
 
-  // this lane's tap of k-step i as a unit offset: tap 2i + h (the 10th tap reads tap 8's data against zero weights)
-  int bo[kPairs];
-#pragma unroll
-  for (int i = 0; i < kPairs; ++i) {
-    const int t0 = 2 * i, t1 = 2 * i + 1 < 9 ? 2 * i + 1 : 8;
-    bo[i] = h ? (t1 / 3) * p.P + t1 % 3 : (t0 / 3) * p.P + t0 % 3;
-  }
+  // tap 2q + h of this lane as a unit offset (a tap beyond the last reads the last tap's data against zero weights)
+  auto tap_off = [&](int q) {
+    const int t0 = 2 * q, t1 = 2 * q + 1 < T2 ? 2 * q + 1 : T2 - 1;
+    return h ? (t1 / KS) * p.P + t1 % KS : (t0 / KS) * p.P + t0 % KS;
+  };
 
   const int qb = wave * VB * 32 + r;  // this lane's first position in the tile
   while (true) {
@@ -208,77 +238,126 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
     const bool more_tiles = tnext < t_hi;
     STile nxt = cur;
     if (more_tiles) nxt = s_decode(p, tnext);
-    const int nstages = p.NCH * nv;
+    const int ngroups = p.NCH * nv;
 
-    f32x16 acc[2][VB];
+    // acc: the MFMA accumulator of ONE group; tot: the sum of the groups, added with fp32 VALU adds (round to nearest).  The
+    // matrix core aligns the 16 products of a k-step to the accumulator's exponent before adding them, so its error grows with
+    // the accumulator; restarting it per group keeps it ~5 x smaller than the finished sum while most products are added.
+    f32x16 acc[2][VB], tot[2][VB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int v = 0; v < VB; ++v)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][v][e] = 0.f;
+        for (int e = 0; e < 16; ++e) { acc[a][v][e] = 0.f; tot[a][v][e] = 0.f; }
 
     int chunk = 0, dzi = 0;
 #pragma unroll 1
-    for (int i = 0; i < nstages; ++i) {
-      unsigned char* bc = (g & 1) ? buf1 : buf0;
-      unsigned char* bn = (g & 1) ? buf0 : buf1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage i has landed
-      __syncthreads();                                  // ... and everybody's; everybody is done reading bn
+    for (int g = 0; g < ngroups; ++g) {
       int nchunk = chunk, ndz = dzi + 1;
       if (ndz == nv) { ndz = 0; ++nchunk; }
-      const bool within = i + 1 < nstages;
-      if (!within && more_tiles) decode_pieces(nxt);
-      if (within || more_tiles)
-        issue(within ? cur.n : nxt.n, within ? cur.z : nxt.z, within ? cur.cot : nxt.cot, within ? nchunk : 0,
-              within ? lo + ndz : dz_lo(nxt), bn);
+      const bool within = g + 1 < ngroups;
+      const bool have_next = within || more_tiles;
+      // the group after this one: (sample, plane, channel tile, chunk, dz)
+      const int xn = within ? cur.n : nxt.n, xz = within ? cur.z : nxt.z, xcot = within ? cur.cot : nxt.cot;
+      const int xchunk = within ? nchunk : 0, xdz = within ? lo + ndz : dz_lo(nxt);
+      unsigned char* const bc = brick0 + (gb & 1) * BB;
+      unsigned char* const bnx = brick0 + ((gb & 1) ^ 1) * BB;
+      auto do_sub = [&](auto subc) {
+        constexpr int sub = decltype(subc)::value;
+        unsigned char* const wc = wbuf0 + (gw & 1) * WB;
+        unsigned char* const wn = wbuf0 + ((gw & 1) ^ 1) * WB;
+        // this sub-stage's weights (and, at sub 0, the brick) have landed; with several sub-stages the next brick, issued
+        // behind the weights of sub 1, may stay in flight over the barrier of sub 1
+        if constexpr (NSUB > 1 && sub == 1) wait_vm(have_next ? nbw : 0);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // ... everybody's share too; everybody is done with the buffers written next
+        if constexpr (sub == 0) {
+          if constexpr (NSUB > 1) issue_w(cur.cot, chunk, lo + dzi, SU::q0[1], SU::q0[NSUB > 1 ? 2 : 1], wn);
+          if (have_next) {
+            if (!within) decode_pieces(nxt);
+            issue_brick(xn, xz, xchunk, xdz, bnx);
+            if constexpr (NSUB == 1) issue_w(xcot, xchunk, xdz, SU::q0[0], SU::q0[1], wn);
+          }
+        } else if constexpr (sub + 1 < NSUB) {
+          issue_w(cur.cot, chunk, lo + dzi, SU::q0[sub + 1], SU::q0[sub + 2 <= NSUB ? sub + 2 : NSUB], wn);
+        } else {
+          if (have_next) issue_w(xcot, xchunk, xdz, SU::q0[0], SU::q0[1], wn);
+        }
 
-      // A fragment (pair i, term, a): unit ((i*3 + term)*2 + a)*64 + h*32 + r of the stage's weights;
-      // B fragment (pair i, term, v): unit term*RP + position + tap
-      const i32x4* wl = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
-      const i32x4* bl = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
-      i32x4 A[3][2], B[3][VB], nA[3][2], nB[3][VB];
+        // A fragment (pair i of the sub-stage, term, a): unit ((i*3 + term)*2 + a)*64 + h*32 + r of the weight buffer;
+        // B fragment (pair q, term, v): unit term*RP + position + tap
+        const i32x4* wl = reinterpret_cast<const i32x4*>(wc) + h * 32 + r;
+        const i32x4* bl = reinterpret_cast<const i32x4*>(bc) + qb + cur.xoff;
+        constexpr int QA = SU::q0[sub], NQ = SU::q0[sub + 1] - SU::q0[sub];
+        i32x4 A[3][2], B[3][VB], nA[3][2], nB[3][VB];
+        {
+          const int bo = tap_off(QA);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        A[t][0] = wl[(t * 2) * 64]; A[t][1] = wl[(t * 2 + 1) * 64];
+          for (int t = 0; t < 3; ++t) {
+            A[t][0] = wl[(t * 2) * 64]; A[t][1] = wl[(t * 2 + 1) * 64];
 #pragma unroll
-        for (int v = 0; v < VB; ++v) B[t][v] = bl[t * p.RP + bo[0] + v * 32];
+            for (int v = 0; v < VB; ++v) B[t][v] = bl[t * p.RP + bo + v * 32];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+          if (s + 1 < NQ) {
+            const int bo = tap_off(QA + s + 1);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              nA[t][0] = wl[(((s + 1) * 3 + t) * 2) * 64]; nA[t][1] = wl[(((s + 1) * 3 + t) * 2 + 1) * 64];
+#pragma unroll
+              for (int v = 0; v < VB; ++v) nB[t][v] = bl[t * p.RP + bo + v * 32];
+            }
+          }
+          // six products per (a, v), smallest first; consecutive MFMAs go to different accumulators
+          constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int v = 0; v < VB; ++v) acc[a][v] = mfma(A[TA[m]][a], B[TB[m]][v], acc[a][v]);
+          if (s + 1 < NQ) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // the 6 + 3 VB reads of the next k-step spread over this one's 12 VB MFMAs
+              __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 4 * VB, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              A[t][0] = nA[t][0]; A[t][1] = nA[t][1];
+#pragma unroll
+              for (int v = 0; v < VB; ++v) B[t][v] = nB[t][v];
+            }
+          }
+        }
+        ++gw;
+      };
+      do_sub(std::integral_constant<int, 0>{});
+      if constexpr (NSUB > 1) {
+        do_sub(std::integral_constant<int, 1>{});
+        do_sub(std::integral_constant<int, 2>{});
+        do_sub(std::integral_constant<int, 3>{});
       }
+      if (p.flush) {
 #pragma unroll
-      for (int s = 0; s < kPairs; ++s) {
-        if (s + 1 < kPairs) {
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            nA[t][0] = wl[(((s + 1) * 3 + t) * 2) * 64]; nA[t][1] = wl[(((s + 1) * 3 + t) * 2 + 1) * 64];
+          for (int v = 0; v < VB; ++v)
 #pragma unroll
-            for (int v = 0; v < VB; ++v) nB[t][v] = bl[t * p.RP + bo[s + 1] + v * 32];
-          }
-        }
-        // six products per (a, v), smallest first; consecutive MFMAs go to different accumulators
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int v = 0; v < VB; ++v) acc[a][v] = mfma(A[TA[m]][a], B[TB[m]][v], acc[a][v]);
-        if (s + 1 < kPairs) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {  // the 6 + 3 VB reads of the next k-step spread over this one's 12 VB MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * VB, 0);
-          }
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            A[t][0] = nA[t][0]; A[t][1] = nA[t][1];
-#pragma unroll
-            for (int v = 0; v < VB; ++v) B[t][v] = nB[t][v];
-          }
-        }
+            for (int e = 0; e < 16; ++e) { tot[a][v][e] += acc[a][v][e]; acc[a][v][e] = 0.f; }
       }
       chunk = nchunk; dzi = ndz;
-      ++g;
+      ++gb;
+    }
+    if (p.flush) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int v = 0; v < VB; ++v) acc[a][v] = tot[a][v];
     }
 
     // ---- epilogue: rows = output channels, lanes = positions; each store writes 128 contiguous bytes per half
@@ -316,28 +395,29 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
 }
 
 struct SPlan {
-  int PT, VB, P, R, RP, TPP, npb, SB;
+  int PT, VB, P, R, RP, TPP, npb, lds;
   bool ok;
 };
 
-SPlan s_plan(int H, int W) {
+SPlan s_plan(int H, int W, int KS) {
   SPlan pl{};
-  pl.P = W + 2;
+  pl.P = W + KS - 1;
   const long plane = (long)H * pl.P;
+  const int wbytes = (KS == 3 ? Sub<3>::MAXP : Sub<5>::MAXP) * kPairPieces * 1024;
   double best = 0;
   for (int VB : {2, 1}) {
     const int PT = VB * 256;
     const int rows = (pl.P - 1 + PT - 1) / pl.P + 1;
-    const int R = rows + 2;
+    const int R = rows + KS - 1;
     const int RP = R * pl.P;
     const int npb = (3 * RP + 4 + 63) / 64;
-    const int SB = (npb + kWPieces) * 1024;
-    if (npb > 8 * 7 || 2 * SB > kLdsMax) continue;
+    const int lds = 2 * npb * 1024 + 2 * wbytes;
+    if (npb > 8 * 7 || lds > kLdsMax) continue;
     const int TPP = (int)((plane + PT - 1) / PT);
     const double eff = (double)H * W / ((double)TPP * PT) * (VB == 2 ? 1.0 : 0.85);
     if (eff > best) {
       best = eff;
-      pl.PT = PT; pl.VB = VB; pl.R = R; pl.RP = RP; pl.npb = npb; pl.SB = SB; pl.TPP = TPP;
+      pl.PT = PT; pl.VB = VB; pl.R = R; pl.RP = RP; pl.npb = npb; pl.lds = lds; pl.TPP = TPP;
       pl.ok = true;
     }
   }
@@ -345,19 +425,21 @@ SPlan s_plan(int H, int W) {
 }
 
 bool s_shape_ok(const ConvDims& d, int Cin, int Kout) {
-  if (d.kd != 3 || d.kh != 3 || d.kw != 3) return false;
-  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 1 || d.ph != 1 || d.pw != 1) return false;
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
   if (Cin % 8 || Kout % 64) return false;
   if ((long)d.D * d.H * d.W * 3 >= (1l << 31)) return false;  // per-lane source offsets are 32-bit unit counts
-  return s_plan(d.H, d.W).ok;
+  return s_plan(d.H, d.W, d.kd).ok;
 }
 
-size_t s_packed_bytes(int Cin, int Kout) { return (size_t)(Kout / 64) * (Cin / 8) * 3 * kWPieces * 1024; }
+size_t s_packed_bytes(int Cin, int Kout, int KS) {
+  return (size_t)(Kout / 64) * (Cin / 8) * KS * ((KS * KS + 1) / 2) * kPairPieces * 1024;
+}
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-template <int VB>
+template <int KS, int VB>
 int launch_s3(const SParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_s3<VB>;
+  auto kern = k_conv_s3<KS, VB>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
@@ -372,10 +454,11 @@ int launch_s3(const SParams& p, int lds, hipStream_t s) {
 
 int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
            long so, long si, int flip, void* ws, size_t wsb, hipStream_t s) {
-  const SPlan pl = s_plan(d.H, d.W);
+  const int KS = d.kd;
+  const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
   const size_t xb = xs_pre ? 0 : align256((size_t)d.N * Cin * S * 6);
-  const size_t wb = align256(s_packed_bytes(Cin, Kout));
+  const size_t wb = align256(s_packed_bytes(Cin, Kout, KS));
   if (!ws || wsb < xb + wb + 256) { set_error("conv_s3: workspace too small"); return NC_ERR_WS; }
   uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
@@ -385,19 +468,21 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
     hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xs, S);
     if (int e = check_launch("split3")) return e;
   }
-  const long total = (long)(s_packed_bytes(Cin, Kout) / 2);
-  hipLaunchKernelGGL(k_pack_w_s3, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, so, si, flip, total);
+  const long total = (long)(s_packed_bytes(Cin, Kout, KS) / 2);
+  hipLaunchKernelGGL(k_pack_w_s3, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip, total);
   if (int e = check_launch("pack_w_s3")) return e;
   SParams p{};
   p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.zeros = zeros;
   p.N = d.N; p.NCH = Cin / 8; p.D = d.D; p.H = d.H; p.W = d.W; p.K = Kout;
   p.P = pl.P; p.R = pl.R; p.RP = pl.RP; p.PT = pl.PT; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.mP = magic(pl.P); p.mRP = magic(pl.RP);
-  p.npb = pl.npb; p.SB = pl.SB;
+  p.npb = pl.npb;
   p.ntiles = (long)d.N * d.D * pl.TPP * p.KT;
   p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
-  const int lds = 2 * pl.SB;
-  return pl.VB == 2 ? launch_s3<2>(p, lds, s) : launch_s3<1>(p, lds, s);
+  static const int flush = getenv("NC_SPLIT_FLUSH") ? atoi(getenv("NC_SPLIT_FLUSH")) : 1;
+  p.flush = flush;
+  if (KS == 3) return pl.VB == 2 ? launch_s3<3, 2>(p, pl.lds, s) : launch_s3<3, 1>(p, pl.lds, s);
+  return pl.VB == 2 ? launch_s3<5, 2>(p, pl.lds, s) : launch_s3<5, 1>(p, pl.lds, s);
 }
 
 }  // namespace
@@ -407,7 +492,8 @@ bool s3_dgrad_supported(const ConvDims& d) { return s_shape_ok(d, d.K, d.C); }
 size_t s3_ws_bytes(const ConvDims& d) {
   const long S = (long)d.D * d.H * d.W;
   const int cmax = d.C > d.K ? d.C : d.K;
-  return align256((size_t)d.N * cmax * S * 6) + align256(s_packed_bytes(d.C, d.K) > s_packed_bytes(d.K, d.C) ? s_packed_bytes(d.C, d.K) : s_packed_bytes(d.K, d.C)) + 512;
+  const int c64 = (d.C + 63) / 64 * 64, k64 = (d.K + 63) / 64 * 64;  // either may be the 64-multiple "output" side
+  return align256((size_t)d.N * cmax * S * 6) + align256(s_packed_bytes(c64, k64, d.kd)) + 512;
 }
 size_t s3_tensor_bytes(int N, int C, long S) { return (size_t)N * C * S * 6; }
 
@@ -419,14 +505,16 @@ int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) {
 
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s) {
-  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * 27, 27, 0, ws, wsb, s);
+  const int T3 = d.kd * d.kh * d.kw;
+  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s);
 }
 
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
   // dx = conv(dy, flipped / channel-transposed w): "input" channels K, "output" channels C
   ConvDims t = d;
   t.C = d.K; t.K = d.C;
-  return run_s3(dy, dys, w, nullptr, dx, t, d.K, d.C, 27, (long)d.C * 27, 1, ws, wsb, s);
+  const int T3 = d.kd * d.kh * d.kw;
+  return run_s3(dy, dys, w, nullptr, dx, t, d.K, d.C, T3, (long)d.C * T3, 1, ws, wsb, s);
 }
 
 }  // namespace nc

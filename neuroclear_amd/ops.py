@@ -25,7 +25,7 @@ def prof_start(min_flop=0.0):
     lib().nc_prof_begin(ctypes.c_double(min_flop))
 
 
-_PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 'to1', 7: 'img', 8: 'pg1'}
+_PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 'to1', 7: 'img', 8: 'pg1', 9: 'split'}
 
 
 def prof_stop():
@@ -71,7 +71,7 @@ def _conv_tag(op, C, K, k3, stride, pad, out_vox):
         path = lib().nc_conv_fwd_path(I(K), I(C), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
     else:
         path = mf(I(C), I(K), I(k3[0]), I(k3[1]), I(k3[2]), I(stride), I(pad))
-    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps'}.get(path, 'direct'), k3[1])
+    tag = '%s_%s_k%d' % (op, {1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 9: 'split'}.get(path, 'direct'), k3[1])
     return tag, 2.0 * C * K * k3[0] * k3[1] * k3[2] * out_vox
 
 
@@ -157,6 +157,14 @@ def _side_stream(device):
 # 1, >= 16 input and >= 64 output channels); every other layer and everything between the convolutions stays fp32.
 _DT = {'fp32': 0, 'fp16': 1, 'bf16': 2}
 conv_precision = 'fp32'
+
+
+def set_conv_split(on):
+    """fp32 3^3 / 5^3 convolutions as six bf16 MFMA products of an exact three-term operand split (csrc/conv_split.hip; the
+    library default) or, with on=False, on the fp32 MFMA kernels.  Returns the previous setting."""
+    prev = bool(lib().nc_get_conv_split())
+    lib().nc_set_conv_split(I(1 if on else 0))
+    return prev
 
 
 def set_conv_precision(name):

@@ -99,8 +99,8 @@ def test_conv(case, force_direct):
 def test_conv_paths_reported():
     from neuroclear_amd._lib import I, lib
     L = lib()
-    assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
-    assert L.nc_conv_fwd_path(I(64), I(64), I(5), I(5), I(5), I(1), I(2)) == 1
+    assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) in (1, 9)  # 9: split-operand kernel (default on)
+    assert L.nc_conv_fwd_path(I(64), I(64), I(5), I(5), I(5), I(1), I(2)) in (1, 9)
     assert L.nc_conv_wgrad_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
     assert L.nc_conv_fwd_path(I(1), I(64), I(3), I(3), I(3), I(1), I(1)) == 1  # single-channel mode of the brick kernel
     assert L.nc_conv_wgrad_path(I(1), I(64), I(7), I(7), I(7), I(1), I(3)) == 4

@@ -1,0 +1,218 @@
+"""GPU parity of the split-operand fp32 convolutions (csrc/conv_split.hip) through the C ABI.
+
+The kernels compute an fp32 convolution (models/networks.py:420-425, 460-469, 900-902) on the bf16 matrix cores: every fp32
+operand is the exact sum of three bf16 terms and six of the nine term products are accumulated in fp32.  The checks:
+* the three terms reproduce the fp32 value bit for bit;
+* forward and data gradient against an fp64 reference: the error must not exceed the fp32 MFMA kernel's own error against the
+  same reference by more than a small factor (measured: it is smaller), with an absolute bound of 4e-7 of the output rms;
+* the library switch: with the kernels off the same calls run on the fp32 MFMA kernels and agree to 2e-6 of the output rms;
+* at the 108^3 size of the headline step: the adjoint identity <conv(x), g> == <x, dgrad(g)>, agreement with the fp32 MFMA
+  kernels, and -- against fp64 on a slab -- an error not above theirs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _restore_switch():
+    from neuroclear_amd import ops
+    prev = ops.set_conv_split(True)
+    yield
+    ops.set_conv_split(prev)
+
+
+def _ws(N, C, D, H, W, K, ks):
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, lib
+    return ops.workspace(lib().nc_conv_split_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(ks)), DEV, 'ws_split_test')
+
+
+def to_s3(x):
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, L_, check, lib
+    N, C = x.shape[:2]
+    S = x.numel() // (N * C)
+    assert lib().nc_s3_bytes(I(N), I(C), L_(S)) == N * C * S * 6
+    out = torch.empty(N * C * S * 6, dtype=torch.uint8, device=x.device)
+    check(lib().nc_to_s3(ops._ptr(x), ops._ptr(out), I(N), I(C), L_(S), ops._stream()), 'nc_to_s3')
+    return out
+
+
+def fwd_split(x, w, b, xs=None):
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, Z, check, lib
+    N, C, D, H, W = x.shape
+    K, ks = w.shape[0], w.shape[2]
+    y = torch.empty(N, K, D, H, W, device=x.device)
+    ws = _ws(N, C, D, H, W, K, ks)
+    check(lib().nc_conv_fwd_split(ops._ptr(x), ops._ptr(xs), ops._ptr(w), ops._ptr(b), ops._ptr(y), I(N), I(C), I(D), I(H), I(W), I(K),
+                                  I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_fwd_split')
+    return y
+
+
+def dgrad_split(dy, w, dys=None):
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, Z, check, lib
+    N, K, D, H, W = dy.shape
+    C, ks = w.shape[1], w.shape[2]
+    dx = torch.empty(N, C, D, H, W, device=dy.device)
+    ws = _ws(N, C, D, H, W, K, ks)
+    check(lib().nc_conv_dgrad_split(ops._ptr(dy), ops._ptr(dys), ops._ptr(w), ops._ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K),
+                                    I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_dgrad_split')
+    return dx
+
+
+def test_three_terms_are_the_fp32_value():
+    torch.manual_seed(3)
+    N, C, S = 2, 16, 5000
+    x = torch.randn(N, C, S, device=DEV) * torch.pow(10.0, torch.empty(N, C, S, device=DEV).uniform_(-6, 6))
+    x[0, 0, :4] = torch.tensor([0.0, 1.0, -1.0, 3.0e-30], device=DEV)
+    raw = to_s3(x)
+    t = raw.view(torch.bfloat16).view(N, C // 8, 3, S, 8).float()  # [n][block][term][voxel][channel in block]
+    back = ((t[:, :, 0] + t[:, :, 1]) + t[:, :, 2]).permute(0, 1, 3, 2).reshape(N, C, S)
+    assert torch.equal(back, x)
+    # the terms shrink by 2^-8 each: |a1| <= 2^-8 |a0|, |a2| <= 2^-16 |a0|
+    a0, a1, a2 = t[:, :, 0].abs(), t[:, :, 1].abs(), t[:, :, 2].abs()
+    assert bool((a1 <= a0 * 2.0 ** -8).all()) and bool((a2 <= a0 * 2.0 ** -16).all())
+
+
+CASES = [  # N, C, K, (D, H, W), kernel size
+    (1, 64, 64, (20, 22, 27), 3),
+    (2, 16, 128, (9, 17, 30), 3),
+    (1, 128, 64, (12, 12, 12), 3),
+    (1, 8, 64, (1, 5, 3), 3),        # one plane, three columns
+    (1, 256, 256, (6, 27, 27), 3),
+    (2, 64, 64, (3, 54, 54), 3),
+    (1, 64, 64, (11, 14, 19), 5),    # G_B's 5^3 feature layer (networks.py:900)
+    (2, 8, 64, (3, 30, 40), 5),
+    (1, 64, 128, (7, 9, 150), 3),    # wide rows: the 256-position tile
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_split_conv_against_fp64(case):
+    from neuroclear_amd import ops
+    N, C, K, n, ks = case
+    pd = ks // 2
+    torch.manual_seed(11)
+    x = torch.randn(N, C, *n, device=DEV)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV) * 0.02
+    b = torch.randn(K, device=DEV)
+    ref = F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=pd)
+    sc = ref.pow(2).mean().sqrt().item()
+    prev = ops.set_conv_split(False)
+    y32 = ops.conv_fwd_raw(x, w, b, 1, pd)
+    ops.set_conv_split(prev)
+    ys = fwd_split(x, w, b)
+    ys_pre = fwd_split(x, w, b, to_s3(x))
+    assert torch.equal(ys, ys_pre)  # operand converted by the call or by the caller: the same kernel, the same result
+
+    def err(y, r, s):
+        e = y.double().cpu() - r
+        return e.abs().max().item() / s, e.pow(2).mean().sqrt().item() / s
+    m32, r32 = err(y32, ref, sc)
+    ms, rs = err(ys, ref, sc)
+    print(case, 'fwd fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+    assert rs <= 1.3 * r32 + 2e-8 and rs < 4e-7, (rs, r32)
+    assert ms <= 2.0 * m32 + 2e-7, (ms, m32)
+    if C % 64 == 0:  # data gradient: the "output" side is C
+        dy = torch.randn(N, K, *n, device=DEV)
+        refd = torch.nn.grad.conv3d_input(x.shape, w.double().cpu(), dy.double().cpu(), padding=pd)
+        sd = refd.pow(2).mean().sqrt().item()
+        prev = ops.set_conv_split(False)
+        d32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, pd)
+        ops.set_conv_split(prev)
+        dsp = dgrad_split(dy, w)
+        m32, r32 = err(d32, refd, sd)
+        ms, rs = err(dsp, refd, sd)
+        print(case, 'dgrad fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+        assert rs <= 1.3 * r32 + 2e-8 and rs < 4e-7, (rs, r32)
+        assert ms <= 2.0 * m32 + 2e-7, (ms, m32)
+
+
+def test_library_switch_selects_the_kernels():
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, lib
+    L = lib()
+    torch.manual_seed(5)
+    x = torch.randn(1, 64, 10, 20, 30, device=DEV)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.03
+    assert L.nc_get_conv_split() == 1
+    assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 9
+    y_on = ops.conv_fwd_raw(x, w, None, 1, 1)
+    assert torch.equal(y_on, fwd_split(x, w, None))           # nc_conv_fwd took the split kernels
+    g_on = ops.conv_dgrad_raw(y_on, w, x.shape, 1, 1)
+    assert torch.equal(g_on, dgrad_split(y_on, w))
+    ops.set_conv_split(False)
+    assert L.nc_get_conv_split() == 0
+    assert L.nc_conv_fwd_path(I(64), I(64), I(3), I(3), I(3), I(1), I(1)) == 1
+    y_off = ops.conv_fwd_raw(x, w, None, 1, 1)
+    g_off = ops.conv_dgrad_raw(y_on, w, x.shape, 1, 1)
+    ops.set_conv_split(True)
+    assert not torch.equal(y_on, y_off)                       # different kernels, different summation order ...
+    sc = y_off.pow(2).mean().sqrt().item()
+    assert (y_on - y_off).abs().max().item() < 2e-6 * sc      # ... the same fp32 result
+    sg = g_off.pow(2).mean().sqrt().item()
+    assert (g_on - g_off).abs().max().item() < 2e-6 * sg
+    # shapes the kernels do not cover are refused by the explicit entry points and stay on the other kernels in nc_conv_fwd
+    assert L.nc_conv_split_supported(I(0), I(1), I(4), I(8), I(8), I(8), I(64), I(3), I(3), I(3), I(1), I(1)) == 0   # C % 8
+    assert L.nc_conv_split_supported(I(0), I(1), I(64), I(8), I(8), I(8), I(32), I(3), I(3), I(3), I(1), I(1)) == 0  # K % 64
+    assert L.nc_conv_split_supported(I(0), I(1), I(64), I(8), I(8), I(8), I(64), I(3), I(3), I(3), I(2), I(1)) == 0  # stride
+    x4 = torch.randn(1, 4, 8, 8, 8, device=DEV)
+    w4 = torch.randn(64, 4, 3, 3, 3, device=DEV)
+    with pytest.raises(Exception):
+        fwd_split(x4, w4, None)
+
+
+@pytest.mark.parametrize('ks,C,K', [(3, 64, 64), (3, 128, 64), (5, 64, 64)])
+def test_full_size_layer_adjoint_and_fp32_agreement(ks, C, K):
+    """The layer shapes of the headline step at 108^3 (BASELINE configs[1])."""
+    from neuroclear_amd import ops
+    torch.manual_seed(2)
+    E, pd = 108, ks // 2
+    x = torch.randn(1, C, E, E, E, device=DEV)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV) * (1.0 / np.sqrt(C * ks ** 3))
+    g = torch.randn(1, K, E, E, E, device=DEV)
+    y = ops.conv_fwd_raw(x, w, None, 1, pd)
+    dx = ops.conv_dgrad_raw(g, w, x.shape, 1, pd)
+    lhs = torch.dot(y.double().flatten(), g.double().flatten()).item()
+    rhs = torch.dot(x.double().flatten(), dx.double().flatten()).item()
+    nrm = (y.double().norm() * g.double().norm()).item()
+    assert abs(lhs - rhs) < 1e-6 * nrm, (lhs, rhs, nrm)
+    ops.set_conv_split(False)
+    y32 = ops.conv_fwd_raw(x, w, None, 1, pd)
+    dx32 = ops.conv_dgrad_raw(g, w, x.shape, 1, pd)
+    ops.set_conv_split(True)
+    # the two kernel families agree to the fp32 MFMA kernel's own accuracy at this reduction length (C * ks^3 sequential
+    # fp32 roundings: ~1e-5 of the rms at the worst voxel) ...
+    assert (y - y32).abs().max().item() < 3e-5 * y32.pow(2).mean().sqrt().item()
+    assert (dx - dx32).abs().max().item() < 3e-5 * dx32.pow(2).mean().sqrt().item()
+    # ... and against fp64 on a slab of 6 planes the split kernel is the closer one
+    z0, z1 = 40, 46
+    ref = F.conv3d(x[:, :, z0 - pd:z1 + pd].double().cpu(), w.double().cpu(), padding=pd)[:, :, pd:pd + z1 - z0]
+    sc = ref.pow(2).mean().sqrt().item()
+    e_s = (y[:, :, z0:z1].double().cpu() - ref).abs().max().item() / sc
+    e_f = (y32[:, :, z0:z1].double().cpu() - ref).abs().max().item() / sc
+    print('108^3 ks=%d %d->%d: max error vs fp64  split %.2e  fp32 MFMA %.2e' % (ks, C, K, e_s, e_f))
+    assert e_s < 3e-6 and e_s <= e_f
+
+
+def test_whole_network_inference_with_and_without_the_split_kernels():
+    """unet_deconv forward of one 60^3 cube (the TestModel path): both kernel families give the same image."""
+    from neuroclear_amd import ops
+    from neuroclear_amd.models import networks
+    torch.manual_seed(7)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'normal', 0.02, [0])
+    x = torch.rand(1, 1, 60, 60, 60, device=DEV)
+    with torch.no_grad():
+        y_on = net(x).clone()
+        ops.set_conv_split(False)
+        y_off = net(x).clone()
+        ops.set_conv_split(True)
+    assert (y_on - y_off).abs().max().item() < 2e-6

@@ -24,8 +24,8 @@ def timeit(fn, iters=5, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def split_ws(N, C, D, H, W, K):
-    nb = lib().nc_conv_split_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K))
+def split_ws(N, C, D, H, W, K, ks):
+    nb = lib().nc_conv_split_ws_bytes(I(N), I(C), I(D), I(H), I(W), I(K), I(ks))
     return ops.workspace(nb, dev, 'ws_split')
 
 
@@ -41,9 +41,10 @@ def fwd_split(x, w, b, xs=None):
     N, C, D, H, W = x.shape
     K = w.shape[0]
     y = torch.empty(N, K, D, H, W, device=x.device)
-    ws = split_ws(N, C, D, H, W, K)
+    ks = w.shape[2]
+    ws = split_ws(N, C, D, H, W, K, ks)
     check(lib().nc_conv_fwd_split(ops._ptr(x), ops._ptr(xs), ops._ptr(w), ops._ptr(b), ops._ptr(y), I(N), I(C), I(D), I(H), I(W), I(K),
-                                  ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_fwd_split')
+                                  I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_fwd_split')
     return y
 
 
@@ -51,48 +52,55 @@ def dgrad_split(dy, w, dys=None):
     N, K, D, H, W = dy.shape
     C = w.shape[1]
     dx = torch.empty(N, C, D, H, W, device=dy.device)
-    ws = split_ws(N, C, D, H, W, K)
+    ks = w.shape[2]
+    ws = split_ws(N, C, D, H, W, K, ks)
     check(lib().nc_conv_dgrad_split(ops._ptr(dy), ops._ptr(dys), ops._ptr(w), ops._ptr(dx), I(N), I(C), I(D), I(H), I(W), I(K),
-                                    ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_dgrad_split')
+                                    I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_dgrad_split')
     return dx
 
 
 def main():
     torch.manual_seed(0)
-    for (N, C, K, n) in ((1, 64, 64, (20, 22, 27)), (2, 16, 128, (9, 17, 30)), (1, 128, 64, (12, 12, 12))):
+    for (N, C, K, n, ks) in ((1, 64, 64, (20, 22, 27), 3), (2, 16, 128, (9, 17, 30), 3), (1, 128, 64, (12, 12, 12), 3),
+                             (1, 64, 64, (11, 14, 19), 5), (2, 8, 64, (3, 30, 40), 5)):
+        pd = ks // 2
         x = torch.randn(N, C, *n, device=dev)
-        w = torch.randn(K, C, 3, 3, 3, device=dev) * 0.02
+        w = torch.randn(K, C, ks, ks, ks, device=dev) * 0.02
         b = torch.randn(K, device=dev)
-        ref = torch.nn.functional.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+        ref = torch.nn.functional.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=pd)
         sc = ref.pow(2).mean().sqrt().item()
-        y32 = ops.conv_fwd_raw(x, w, b, 1, 1)
+        y32 = ops.conv_fwd_raw(x, w, b, 1, pd)
         ys = fwd_split(x, w, b)
         for name, y in (('fp32', y32), ('split', ys)):
             e = y.double().cpu() - ref
-            print('fwd   %s %-5s max %.2e rms %.2e' % ((N, C, K, n), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
+            print('fwd   %s %-5s max %.2e rms %.2e' % ((N, C, K, n, ks), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
         if C % 64:
             continue
         dy = torch.randn(N, K, *n, device=dev)
-        refd = torch.nn.grad.conv3d_input(x.shape, w.double().cpu(), dy.double().cpu(), padding=1)
+        refd = torch.nn.grad.conv3d_input(x.shape, w.double().cpu(), dy.double().cpu(), padding=pd)
         sc = refd.pow(2).mean().sqrt().item()
-        d32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+        d32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, pd)
         dsp = dgrad_split(dy, w)
         for name, y in (('fp32', d32), ('split', dsp)):
             e = y.double().cpu() - refd
-            print('dgrad %s %-5s max %.2e rms %.2e' % ((N, C, K, n), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
+            print('dgrad %s %-5s max %.2e rms %.2e' % ((N, C, K, n, ks), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
     sizes = [int(a) for a in sys.argv[1:]] or [108]
     for S in sizes:
-        for name, C, K, E in [('64->64 @S', 64, 64, S), ('128->64 @S', 128, 64, S), ('64->128 @S/2', 64, 128, S // 2),
-                              ('128->128 @S/2', 128, 128, S // 2), ('256->128 @S/2', 256, 128, S // 2), ('128->256 @S/4', 128, 256, S // 4),
-                              ('256->256 @S/4', 256, 256, S // 4)]:
+        for name, C, K, E, ks in [('64->64 @S', 64, 64, S, 3), ('128->64 @S', 128, 64, S, 3), ('64->128 @S/2', 64, 128, S // 2, 3),
+                                  ('128->128 @S/2', 128, 128, S // 2, 3), ('256->128 @S/2', 256, 128, S // 2, 3),
+                                  ('128->256 @S/4', 128, 256, S // 4, 3), ('256->256 @S/4', 256, 256, S // 4, 3),
+                                  ('5^3 64->64 @S', 64, 64, S, 5)]:
+            if not lib().nc_conv_split_supported(I(0), I(1), I(C), I(E), I(E), I(E), I(K), I(ks), I(ks), I(ks), I(1), I(ks // 2)):
+                print('S=%d %s: not covered' % (S, name))
+                continue
             x = torch.randn(1, C, E, E, E, device=dev)
-            w = torch.randn(K, C, 3, 3, 3, device=dev) * 0.05
+            w = torch.randn(K, C, ks, ks, ks, device=dev) * 0.05
             xs = to_s3(x)
-            t32 = timeit(lambda: ops.conv_fwd_raw(x, w, None, 1, 1))
+            t32 = timeit(lambda: ops.conv_fwd_raw(x, w, None, 1, ks // 2))
             tsp = timeit(lambda: fwd_split(x, w, None))
             tpre = timeit(lambda: fwd_split(x, w, None, xs))
             tcv = timeit(lambda: to_s3(x))
-            gf = 2.0 * 27 * C * K * E ** 3 / 1e9
+            gf = 2.0 * ks ** 3 * C * K * E ** 3 / 1e9
             print('S=%d %-16s fp32 %.3f ms (%.0f TF)   split %.3f ms (%.0f TF; pre-split input %.3f = %.0f TF; to_s3 %.3f)' % (
                 S, name, t32, gf / t32, tsp, gf / tsp, tpre, gf / tpre, tcv))
 
