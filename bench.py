@@ -15,8 +15,12 @@ gradients are all-reduced (RCCL) once per optimizer phase.  value = voxels fed t
 
 Extra objects on the JSON line:
   roofline     -- for the kernel class that took most of the timed region: algorithmic FLOP / launch, measured with HIP
-                  events on the launch stream inside the timed steps (neuroclear_amd.ops.prof), against the dense fp32
-                  MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s).
+                  events on the launch stream inside the timed steps (neuroclear_amd.ops.prof), against the dense MFMA
+                  peak of /opt/skills/guides/MI355X_MICROARCH.md for the instruction the class runs on: 157.3 TFLOP/s
+                  (fp32 MFMA), or 2500 / 6 = 416.7 TFLOP/s of fp32 products for the split-operand kernels (six bf16 MFMA
+                  products per fp32 product, csrc/conv_split.hip).
+  arithmetic / fp32_mfma_kernels -- what "f32" is computed with, and the same step with the split-operand layers back on
+                  the fp32 MFMA kernels (3 steps, same process).
   cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32) on the host cores of
                   the GPU box, rank 0 and N = 1 only: full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
                   1-thread figure on a bounded 36^3 sample; inference: 140^3 cubes through
@@ -39,10 +43,19 @@ if ROOT not in sys.path:
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: "Peak FP32 (matrix) 157.3 TFLOPS"
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# The fp32 3^3 / 5^3 convolutions run on the bf16 matrix cores (csrc/conv_split.hip): each fp32 operand is the exact sum of three
+# bf16 terms and an fp32 product costs six bf16 MFMA products.  Roofline of those kernels: algorithmic fp32 FLOP against the
+# bf16 dense peak / 6 (what the matrix cores can deliver of THIS arithmetic); the fp32 MFMA peak is printed next to it.
+SPLIT_PRODUCTS = 6
+MFMA_SPLIT_PEAK_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
+ARITHMETIC = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 6 bf16 MFMA products of an exact 3-term operand '
+              'split (csrc/conv_split.hip; error vs fp64 <= the fp32 MFMA kernels\': tests/test_gpu_split.py); NC_CONV_SPLIT=0 = fp32 MFMA kernels')
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
+    'fwd_split_k3': 'k_conv_s3<3,*>', 'dgrad_split_k3': 'k_conv_s3<3,*>', 'fwd_split_k5': 'k_conv_s3<5,*>',
+    'dgrad_split_k5': 'k_conv_s3<5,*>',
     'fwd_lp_k3': 'k_conv_h<*,3,3,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,3,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>',
     'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
     'fwd_lp_k7': 'k_conv_h<*,7,7,1,*> (pseudo-channel form)', 'dgrad_lp_k7': 'k_conv_h<*,7,7,1,*,1> + k_fold_x8',
@@ -229,14 +242,18 @@ def run_train(args, rank, world, dev):
         c[0] += 1
         c[1] += ms
         c[2] += fl
-    top = max((t for t in stats if 'mfma' in t or '_lp_' in t), key=lambda t: stats[t][1], default=None)
+    top = max((t for t in stats if 'mfma' in t or '_lp_' in t or '_split_' in t), key=lambda t: stats[t][1], default=None)
     roof = None
     if top:
         n, ms, flop = stats[top]
         ach = flop / ms / 1e9
-        peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_SPLIT_PEAK_TFLOPS if '_split_' in top else MFMA_F32_PEAK_TFLOPS
+        extra = {}
+        if '_split_' in top:
+            extra = dict(peak_is='bf16 dense MFMA peak %.0f / %d MFMA products per fp32 product' % (MFMA_16BIT_PEAK_TFLOPS, SPLIT_PRODUCTS),
+                         bf16_tflops=round(ach * SPLIT_PRODUCTS, 1), vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
         roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
-                    peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                    peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
                     traffic=pmc_traffic(top, crop, args.batch), launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
@@ -315,10 +332,15 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         ms = sum(a.elapsed_time(b) for a, b in ev)
         flop = GA_FWD_FLOP_PER_VOXEL * 140 ** 3
         ach = flop * len(ev) / ms / 1e9
-        roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: '
-                                        'k_conv_mfma<3,*>, profiles/r02_infer_kernel_stats.csv)',
-                    achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=pmc_traffic_cube(), launches=len(ev),
+        from neuroclear_amd._lib import lib
+        split = bool(lib().nc_get_conv_split())
+        peak = MFMA_SPLIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+        extra = dict(peak_is='bf16 dense MFMA peak %.0f / %d MFMA products per fp32 product' % (MFMA_16BIT_PEAK_TFLOPS, SPLIT_PRODUCTS),
+                     vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4)) if split else {}
+        roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
+                                        'profiles/r02_infer_kernel_stats.csv)' % ('k_conv_s3<3,*>' if split else 'k_conv_mfma<3,*>'),
+                    achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
+                    frac=round(ach / peak, 4), **extra, traffic=None if split else pmc_traffic_cube(), launches=len(ev),
                     avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     share_of_run=round(ms / (dt * 1e3), 4),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
@@ -379,8 +401,25 @@ def main():
                vs_baseline=None, dtype='f32' if args.precision == 'fp32' or not train_like else
                '%s (3^3/5^3 conv operands; fp32 accumulate, fp32 everywhere else)' % args.precision,
                data='synthetic', config=cfg)
+    from neuroclear_amd import ops as _ops
+    from neuroclear_amd._lib import lib as _lib
+    split_on = bool(_lib().nc_get_conv_split()) and args.precision == 'fp32'
+    if split_on:
+        out['arithmetic'] = ARITHMETIC
     if roof:
         out['roofline'] = roof
+    if headline and split_on:
+        # the same step with those layers on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32), for comparison
+        import copy
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup, a2.no_prof = 3, 1, True
+        _ops.set_conv_split(False)
+        try:
+            dt2, units2, _, cfg2 = run_train(a2, rank, world, dev)
+            out['fp32_mfma_kernels'] = dict(ms_per_step=dt2 / a2.steps * 1e3, value=units2 / dt2, unit='voxels/s', steps=a2.steps,
+                                            losses=cfg2['losses'])
+        finally:
+            _ops.set_conv_split(True)
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if cpu and train_like:
         try:
@@ -401,6 +440,8 @@ def main():
         inf = dict(metric='voxels/sec (useful output voxels of the %d^3 volume, assemble included)' % args.volume,
                    value=iunits / idt, unit='voxels/s', seconds_per_volume=idt, n_gpus=world, scaling='strong',
                    dtype='f32', config=icfg)
+        if split_on:
+            inf['arithmetic'] = ARITHMETIC
         if iroof:
             inf['roofline'] = iroof
         if cpu:
