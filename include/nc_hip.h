@@ -344,7 +344,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
  *      bf16 terms; the six products a_i b_j with i + j <= 2 are bf16 MFMAs on one fp32 accumulator (what is dropped is below
  *      2^-23 of a product).  Same operands and results as nc_conv_fwd / nc_conv_dgrad (networks.py:420-425, 460-469) to
  *      fp32 rounding.  "S3" tensor: [N][C/8][3 terms][D][H][W][8] bf16 (nc_to_s3); xs / dys: the operand already in that
- *      form, or NULL (then converted into the workspace).  what: 0 forward, 1 data gradient.                              */
+ *      form, or NULL (then converted into the workspace).  what: 0 forward, 1 data gradient, 2 weight gradient.                             */
 void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at load time): nc_conv_fwd / nc_conv_dgrad and the
                                   * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
@@ -357,6 +357,8 @@ int nc_conv_fwd_split(const float* x, const void* xs, const float* w, const floa
                       int K, int ks /* 3 or 5: cubic kernel, stride 1, padding ks/2 */, void* ws, size_t ws_bytes, void* stream);
 int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float* dx, int N, int C, int D, int H, int W, int K, int ks,
                         void* ws, size_t ws_bytes, void* stream);
+int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const void* dys, float* dw, int N, int C, int D, int H, int W,
+                        int K, int ks, void* ws, size_t ws_bytes, void* stream); /* nc_conv_wgrad (weights only) */
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ static bool sconv_wgrad_on(const ConvDims& d) {
 }
 static int wgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
+  if (g_split && s3_wgrad_supported(d)) return 9;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4 : k1_wgrad_supported(d) ? 5
                                                                                             : pg1_on(d)              ? 8
                                                                                             : sconv_wgrad_on(d)      ? 7
@@ -134,6 +135,7 @@ int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
+  if (g_split && s3_wgrad_supported(d)) return 9;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4
                                                                          : gemm_wgrad_supported(d) ? 2 : 0;
 }
@@ -164,6 +166,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
   }
   if (g_split && (s3_fwd_supported(d) || s3_dgrad_supported(d))) {
     const size_t sc = s3_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
+  if (g_split && s3_wgrad_supported(d)) {
+    const size_t sc = s3_wgrad_ws_bytes(d);
     if (sc > b) b = sc;
   }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
@@ -288,8 +294,10 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   hipStream_t s = (hipStream_t)stream;
   int e;
   {
-  ProfScope ps(2, wgrad_path(d), d, 0, s);
-  if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
+  const int path = wgrad_path(d);
+  ProfScope ps(2, path, d, 0, s);
+  if (path == 9) e = conv_wgrad_s3(x, nullptr, dy, nullptr, dw, d, ws, ws_bytes, s);
+  else if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && k1_wgrad_supported(d)) e = conv_wgrad_k1(x, dy, dw, d, s);

@@ -138,13 +138,14 @@ int nc_convT_k2s2_wgrad_c8(const void* xh, const void* dyh, int dy_ctot, int dy_
 int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return 0;
-  return what == 0 ? s3_fwd_supported(d) : what == 1 ? s3_dgrad_supported(d) : 0;
+  return what == 0 ? s3_fwd_supported(d) : what == 1 ? s3_dgrad_supported(d) : what == 2 ? s3_wgrad_supported(d) : 0;
 }
 
 size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K, int ks) {
   ConvDims d;
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2)) return 0;
-  return s3_ws_bytes(d);
+  const size_t a = s3_ws_bytes(d), b = s3_wgrad_ws_bytes(d);
+  return a > b ? a : b;
 }
 
 size_t nc_s3_bytes(int N, int C, long S) { return (C % 8 || N < 1 || S < 1) ? 0 : s3_tensor_bytes(N, C, S); }
@@ -171,6 +172,15 @@ int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float*
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_dgrad_supported(d)) { set_error("conv_dgrad_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(1, 1, d, 1, (hipStream_t)stream);
   return conv_dgrad_s3(dy, dys, w, dx, d, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const void* dys, float* dw, int N, int C, int D, int H, int W,
+                        int K, int ks, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if ((!x && !xs) || (!dy && !dys) || !dw) { set_error("conv_wgrad_split: null pointer"); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_wgrad_supported(d)) { set_error("conv_wgrad_split: shape not covered"); return NC_ERR_SHAPE; }
+  ProfScope ps(2, 9, d, 0, (hipStream_t)stream);
+  return conv_wgrad_s3(x, xs, dy, dys, dw, d, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -143,6 +143,10 @@ int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s);
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+bool s3_wgrad_supported(const ConvDims& d);
+size_t s3_wgrad_ws_bytes(const ConvDims& d);
+int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                  hipStream_t s);
 bool h_fwd_supported(const ConvDims& d);
 bool h_dgrad_supported(const ConvDims& d);
 bool h_wgrad_supported(const ConvDims& d);

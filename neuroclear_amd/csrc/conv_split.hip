@@ -485,6 +485,310 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
   return pl.VB == 2 ? launch_s3<5, 2>(p, pl.lds, s) : launch_s3<5, 1>(p, pl.lds, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient dW[k][c][tap] = sum_v dY[k][v] X[c][v + tap] of the same layers (nn.Conv3d backward-weight at the same
+// call sites): M = 32 output channels, N = 32 input channels, K-dim = 16 voxels per MFMA, both operands from S3 images in
+// LDS through the transposing read ds_read_b64_tr_b16 (a lane receives 4 consecutive voxels of ITS channel; two reads make
+// the 8-voxel fragment).  The structure is the 16-bit kernel's (conv_h.hip k_wgrad_h): workgroup = 64 k x 32 c x all taps of
+// ZR kernel planes, 8 waves = 2 k-halves x 4 tap groups; it walks a contiguous range of (sample, tile, z) steps with the X
+// planes in an LDS ring (one new X plane + one dY plane per step by LDS-DMA); per k-step and tap the three terms of both
+// operands are read and six MFMAs issued.  One partial per workgroup, summed in workgroup order (deterministic).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* ltr_t;
+
+struct WsParams {
+  const uint4* xs;   // S3 X   [N][C/8][3][D][H][W]
+  const uint4* dys;  // S3 dY  [N][K/8][3][D][H][W]
+  float* part;       // [pairs * nwp][TW][64][32]
+  const uint4* zeros;
+  int N, C, K, D, H, W;
+  int Ty, Tx, YB, XB;
+  int Xp, XU, XUp;   // X image: row pitch Tx + 2p, units per sub-block, padded sub-block stride (== 4 mod 8)
+  int PT, PTp, NK;   // dY image: positions Ty*Tx, padded sub-block stride, k-steps = ceil(PT / 16)
+  int npx, npd;      // 1 KiB pieces per X slot / per dY buffer
+  int xslot, dybuf;  // bytes
+  int nct;           // C / 32
+  int npairs, nwp;   // (k-tile, c-tile[, kernel plane]) pairs, workgroups per pair
+  long steps;        // N * YB * XB * D  (per pair)
+  unsigned mTx, mXp, mXUp, mPTp;
+};
+
+__device__ __forceinline__ i32x4 tr_frag(const unsigned char* lds, unsigned a0, unsigned a1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(lds + a1));
+  return __builtin_bit_cast(i32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int KS>
+__global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  // 3^3: one workgroup owns all 27 taps (ZR = 3 kernel planes, 4-slot X ring).  5^3: a workgroup owns the 25 taps of ONE
+  // kernel plane (ZR = 1, 2-slot ring) and dz joins (k-tile, c-tile) in the "pair" index.
+  constexpr int PAD = KS / 2, T2 = KS * KS;
+  constexpr int ZR = KS == 3 ? 3 : 1, NS = ZR + 1, NDG = KS / ZR, TW = ZR * T2;
+  constexpr int TG = (TW + 3) / 4;  // taps per wave group: 7,7,7,6 of 27; 7,6,6,6 of 25
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 1, tg = wave >> 1;
+  const int t0 = tg * (TW / 4) + (tg < TW % 4 ? tg : TW % 4);
+  const int ntap = TW / 4 + (tg < TW % 4 ? 1 : 0);
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+
+  // logical workgroup id: neighbours on an XCD share dY (and, for 5^3, X) in that XCD's L2
+  const int G = gridDim.x, xcd = blockIdx.x & 7;
+  const int wg = (G >> 3) * xcd + ((G & 7) < xcd ? (G & 7) : xcd) + (blockIdx.x >> 3);
+  const int pair = wg % p.npairs, wi = wg / p.npairs;
+  if (wi >= p.nwp) return;
+  const int dzg = pair % NDG, kc = pair / NDG;
+  const int kt = kc / p.nct, ct = kc % p.nct;
+  const int zsh = dzg * ZR - PAD;  // X plane of local kernel plane l at step z: z + zsh + l
+  const long s_lo = p.steps * wi / p.nwp, s_hi = p.steps * (wi + 1) / p.nwp;
+
+  unsigned char* const xring = lds_raw;               // NS slots; plane pz lives in slot (pz + 16) % NS
+  unsigned char* const dyb = lds_raw + NS * p.xslot;  // 2 buffers
+  auto slot_of = [&](int pz) { return ((pz + 16) & (NS - 1)) * p.xslot; };
+
+  // LDS-DMA of one X plane (4 blocks x 3 terms of this c-tile, tile + halo) / one dY plane (8 blocks x 3 terms of this k-tile)
+  auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
+    const bool zok = (unsigned)pz < (unsigned)p.D;
+    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S + (long)(zok ? pz : 0) * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npx; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned sb = fdiv(u, p.mXUp);  // sub-block = block * 3 + term
+      const unsigned ur = u - sb * p.XUp;
+      const unsigned ty = fdiv(ur, p.mXp);
+      const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
+      const bool ok = zok && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
+    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S + (long)z * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npd; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned sb = fdiv(u, p.mPTp);
+      const unsigned rho = u - sb * p.PTp;
+      const unsigned ty = fdiv(rho, p.mTx);
+      const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
+      const bool ok = sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
+      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+    }
+  };
+
+  // transposed-read roles of this lane: group g = lane/16 -> channels 16*(g&1).. of the 32-channel tile, voxel half h = g/2;
+  // inside the group lane 4q+pp supplies the address of voxel row q, channels 4pp..4pp+3
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+  const int cbsel = 2 * (g & 1) + (pp >> 1);
+  const unsigned a_lane = (unsigned)((((mt * 4 + cbsel) * 3) * p.PTp) * 16 + (pp & 1) * 8);  // + term * PTp * 16 + rho * 16
+  const unsigned b_lane = (unsigned)(((cbsel * 3) * p.XUp) * 16 + (pp & 1) * 8);             // + term * XUp * 16 + (ty * Xp + tx) * 16
+  const unsigned a_term = (unsigned)p.PTp * 16, b_term = (unsigned)p.XUp * 16;
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int j = 0; j < TG; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  int tdz[TG], toff[TG];  // tap j of this wave: kernel plane and byte offset inside an X slot
+#pragma unroll
+  for (int j = 0; j < TG; ++j) {
+    const int t = t0 + j < TW ? t0 + j : TW - 1;
+    const int dz = t / T2, dy = (t / KS) % KS, dx = t % KS;
+    tdz[j] = dz;
+    toff[j] = (dy * p.Xp + dx) * 16;
+  }
+
+  long step = s_lo;
+  bool fresh = true;  // the ring has to be (re)filled: first step of this workgroup or of a new (sample, tile)
+  int n = 0, y0 = 0, x0 = 0, z = 0;
+  while (step < s_hi) {
+    if (fresh) {
+      long j = step;
+      z = (int)(j % p.D); j /= p.D;
+      const int xb = (int)(j % p.XB); j /= p.XB;
+      const int yb = (int)(j % p.YB);
+      n = (int)(j / p.YB);
+      y0 = yb * p.Ty; x0 = xb * p.Tx;
+      __syncthreads();  // everybody is done with the buffers of the previous tile
+#pragma unroll
+      for (int l = 0; l < ZR; ++l) issue_x(n, y0, x0, z + zsh + l, xring + slot_of(z + zsh + l));
+      issue_dy(n, y0, x0, z, dyb + (z & 1) * p.dybuf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      fresh = false;
+    }
+    const bool cont = z + 1 < p.D && step + 1 < s_hi;  // the next step continues this tile
+    if (cont) {
+      issue_x(n, y0, x0, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
+      issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
+    }
+    // ---- multiply: NK k-steps x ntap taps x 6 term products
+    const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf) + a_lane;
+    unsigned sb[TG];  // slot base + tap offset
+#pragma unroll
+    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(slot_of(z + zsh + tdz[j]) + toff[j]) + b_lane;
+#pragma unroll 1
+    for (int s = 0; s < p.NK; ++s) {
+      unsigned rho[2], bo[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        rho[s2] = (unsigned)(16 * s + 8 * h + 4 * s2 + q);
+        unsigned rc = rho[s2] < (unsigned)p.PT ? rho[s2] : (unsigned)p.PT - 1;  // padded positions: dY = 0, X any finite
+        const unsigned ty = fdiv(rc, p.mTx);
+        bo[s2] = (ty * p.Xp + (rc - ty * p.Tx)) * 16;
+      }
+      i32x4 A[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) A[t] = tr_frag(lds_raw, abase + t * a_term + rho[0] * 16, abase + t * a_term + rho[1] * 16);
+#pragma unroll
+      for (int j = 0; j < TG; ++j) {
+        if (j < ntap) {
+          i32x4 B[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) B[t] = tr_frag(lds_raw, sb[j] + t * b_term + bo[0], sb[j] + t * b_term + bo[1]);
+          acc[j] = mfma(A[2], B[0], acc[j]);
+          acc[j] = mfma(A[1], B[1], acc[j]);
+          acc[j] = mfma(A[0], B[2], acc[j]);
+          acc[j] = mfma(A[1], B[0], acc[j]);
+          acc[j] = mfma(A[0], B[1], acc[j]);
+          acc[j] = mfma(A[0], B[0], acc[j]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++step;
+    if (cont) ++z; else fresh = true;
+  }
+
+  // ---- partial: part[wg][tap][k 0..63][c 0..31]; rows of the accumulator tile are k, lanes are c
+  float* pw = p.part + (long)wg * TW * 64 * 32;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TG; ++j)
+    if (j < ntap) {
+      float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + 4 * hh) * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pt[((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];
+    }
+}
+
+// dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32, tap / TW), in workgroup order
+__global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict__ part, float* __restrict__ dw, int C, int T3, int TW,
+                                                         int nct, int npairs, int nwp, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (k, tap, c): c fastest -> coalesced partial reads
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int t = (int)((i / C) % T3);
+  const int k = (int)(i / ((long)C * T3));
+  const int ndg = T3 / TW;
+  const int pair = ((k / 64) * nct + c / 32) * ndg + t / TW;
+  const long off = ((long)(t % TW) * 64 + (k & 63)) * 32 + (c & 31);
+  float sacc = 0.f;
+  for (int w = 0; w < nwp; ++w) sacc += part[((long)(w * npairs + pair) * TW) * 64 * 32 + off];
+  dw[((long)k * C + c) * T3 + t] = sacc;
+}
+
+struct WsPlan {
+  int Ty, Tx, YB, XB, Xp, XU, XUp, PT, PTp, NK, npx, npd, xslot, dybuf;
+  bool ok;
+};
+
+int pad_4mod8(int v) { return v + ((4 - (v & 7)) & 7); }  // sub-block stride that keeps the transposed reads conflict-free
+
+WsPlan ws_plan(const ConvDims& d) {
+  WsPlan best{};
+  double best_cost = 1e30;
+  const int KS = d.kd;
+  for (int nx = 1; nx <= 12; ++nx) {
+    const int Tx = (d.W + nx - 1) / nx;
+    for (int Ty = 1; Ty <= 16 && Ty <= d.H; ++Ty) {
+      WsPlan pl{};
+      pl.Ty = Ty; pl.Tx = Tx;
+      pl.XB = (d.W + Tx - 1) / Tx; pl.YB = (d.H + Ty - 1) / Ty;
+      pl.Xp = Tx + KS - 1; pl.XU = (Ty + KS - 1) * pl.Xp; pl.XUp = pad_4mod8(pl.XU + KS);  // + KS: tap reads of the clamped tail
+      pl.PT = Ty * Tx; pl.NK = (pl.PT + 15) / 16; pl.PTp = pad_4mod8(pl.NK * 16);
+      pl.npx = (12 * pl.XUp + 63) / 64; pl.npd = (24 * pl.PTp + 63) / 64;
+      pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
+      if ((KS == 3 ? 4 : 2) * pl.xslot + 2 * pl.dybuf > kLdsMax) continue;
+      if (pl.NK < 3) continue;
+      // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
+      const double useful = (double)d.H * d.W;
+      const double mfma = (double)pl.YB * pl.XB * pl.NK * 16;
+      const double stage = (double)pl.YB * pl.XB * (12.0 * pl.XUp + 24.0 * pl.PTp) / 72.0;
+      const double cost = (mfma + 0.15 * stage) / useful;
+      if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
+    }
+  }
+  return best;
+}
+
+bool ws_shape_ok(const ConvDims& d) {
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
+  if (d.C % 32 || d.K % 64) return false;
+  if ((d.K / 64) * (d.C / 32) * (d.kd == 5 ? 5 : 1) > 256) return false;
+  if ((long)d.D * d.H * d.W * 24 >= (1l << 31)) return false;
+  return ws_plan(d).ok;
+}
+
+int ws_nwp(const ConvDims& d, const WsPlan& pl, int npairs) {
+  int nwp = 256 / npairs;
+  const long steps = (long)d.N * pl.YB * pl.XB * d.D;
+  if (nwp > steps) nwp = (int)steps;
+  return nwp;
+}
+
+int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
+           hipStream_t s) {
+  const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
+  const WsPlan pl = ws_plan(d);
+  const long S = (long)d.D * d.H * d.W;
+  const size_t xb = xs_pre ? 0 : align256((size_t)d.N * d.C * S * 6);
+  const size_t yb = dys_pre ? 0 : align256((size_t)d.N * d.K * S * 6);
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  const int nwp = ws_nwp(d, pl, npairs);
+  const long steps = (long)d.N * pl.YB * pl.XB * d.D;
+  const size_t pb = align256((size_t)npairs * nwp * TW * 64 * 32 * 4);
+  if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3: workspace too small"); return NC_ERR_WS; }
+  uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
+  uint4* dys = dys_pre ? (uint4*)dys_pre : (uint4*)((char*)ws + xb);
+  float* part = (float*)((char*)ws + xb + yb);
+  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
+  if (!zeros) { set_error("wgrad_s3: no zero page"); return NC_ERR_HIP; }
+  if (!xs_pre) hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xs, S);
+  if (!dys_pre) hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dys, S);
+  if (int e = check_launch("split3")) return e;
+  WsParams p{};
+  p.xs = xs; p.dys = dys; p.part = part; p.zeros = zeros;
+  p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
+  p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
+  p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
+  p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+      set_error("wgrad_s3: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int lds = NS * pl.xslot + 2 * pl.dybuf;
+  if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  else hipLaunchKernelGGL(k_wgrad_s3<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  if (int e = check_launch("wgrad_s3")) return e;
+  const long total = (long)d.K * d.C * T3;
+  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
+                     total);
+  return check_launch("wgrad_s3_reduce");
+}
+
 }  // namespace
 
 bool s3_fwd_supported(const ConvDims& d) { return s_shape_ok(d, d.C, d.K); }
@@ -496,6 +800,19 @@ size_t s3_ws_bytes(const ConvDims& d) {
   return align256((size_t)d.N * cmax * S * 6) + align256(s_packed_bytes(c64, k64, d.kd)) + 512;
 }
 size_t s3_tensor_bytes(int N, int C, long S) { return (size_t)N * C * S * 6; }
+bool s3_wgrad_supported(const ConvDims& d) { return ws_shape_ok(d); }
+size_t s3_wgrad_ws_bytes(const ConvDims& d) {
+  if (!ws_shape_ok(d)) return 0;
+  const long S = (long)d.D * d.H * d.W;
+  const int T3 = d.kd * d.kh * d.kw, TW = d.kd == 3 ? 27 : 25;
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  const int nwp = ws_nwp(d, ws_plan(d), npairs);
+  return align256((size_t)d.N * d.C * S * 6) + align256((size_t)d.N * d.K * S * 6) + align256((size_t)npairs * nwp * TW * 64 * 32 * 4) + 512;
+}
+int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                  hipStream_t s) {
+  return run_ws(x, xs, dy, dys, dw, d, ws, wsb, s);
+}
 
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) {
   if (C % 8) { set_error("split3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }

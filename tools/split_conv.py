@@ -59,6 +59,16 @@ def dgrad_split(dy, w, dys=None):
     return dx
 
 
+def wgrad_split(x, dy, ks, xs=None, dys=None):
+    N, C, D, H, W = x.shape
+    K = dy.shape[1]
+    dw = torch.empty(K, C, ks, ks, ks, device=x.device)
+    ws = split_ws(N, C, D, H, W, K, ks)
+    check(lib().nc_conv_wgrad_split(ops._ptr(x), ops._ptr(xs), ops._ptr(dy), ops._ptr(dys), ops._ptr(dw), I(N), I(C), I(D), I(H), I(W),
+                                    I(K), I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_wgrad_split')
+    return dw
+
+
 def main():
     torch.manual_seed(0)
     for (N, C, K, n, ks) in ((1, 64, 64, (20, 22, 27), 3), (2, 16, 128, (9, 17, 30), 3), (1, 128, 64, (12, 12, 12), 3),
@@ -74,6 +84,17 @@ def main():
         for name, y in (('fp32', y32), ('split', ys)):
             e = y.double().cpu() - ref
             print('fwd   %s %-5s max %.2e rms %.2e' % ((N, C, K, n, ks), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
+        if C % 32 == 0:
+            dy = torch.randn(N, K, *n, device=dev)
+            refw = torch.nn.grad.conv3d_weight(x.double().cpu(), w.shape, dy.double().cpu(), padding=pd)
+            sc = refw.pow(2).mean().sqrt().item()
+            ops.set_conv_split(False)
+            w32 = ops.conv_wgrad_raw(x, dy, w.shape, 1, pd, False)[0]
+            ops.set_conv_split(True)
+            wsp = wgrad_split(x, dy, ks)
+            for name, y in (('fp32', w32), ('split', wsp)):
+                e = y.double().cpu() - refw
+                print('wgrad %s %-5s max %.2e rms %.2e' % ((N, C, K, n, ks), name, e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc))
         if C % 64:
             continue
         dy = torch.randn(N, K, *n, device=dev)
@@ -100,6 +121,18 @@ def main():
             tsp = timeit(lambda: fwd_split(x, w, None))
             tpre = timeit(lambda: fwd_split(x, w, None, xs))
             tcv = timeit(lambda: to_s3(x))
+            if lib().nc_conv_split_supported(I(2), I(1), I(C), I(E), I(E), I(E), I(K), I(ks), I(ks), I(ks), I(1), I(ks // 2)):
+                dy = torch.randn(1, K, E, E, E, device=dev)
+                ops.set_conv_split(False)
+                tw32 = timeit(lambda: ops.conv_wgrad_raw(x, dy, w.shape, 1, ks // 2, False))
+                ops.set_conv_split(True)
+                tws = timeit(lambda: wgrad_split(x, dy, ks))
+                dys = to_s3(dy)
+                twp = timeit(lambda: wgrad_split(x, dy, ks, xs, dys))
+                gfw = 2.0 * ks ** 3 * C * K * E ** 3 / 1e9
+                print('S=%d %-16s wgrad fp32 %.3f ms (%.0f TF)   split %.3f ms (%.0f TF; pre-split operands %.3f = %.0f TF)' % (
+                    S, name, tw32, gfw / tw32, tws, gfw / tws, twp, gfw / twp))
+                del dy, dys
             gf = 2.0 * ks ** 3 * C * K * E ** 3 / 1e9
             print('S=%d %-16s fp32 %.3f ms (%.0f TF)   split %.3f ms (%.0f TF; pre-split input %.3f = %.0f TF; to_s3 %.3f)' % (
                 S, name, t32, gf / t32, tsp, gf / tsp, tpre, gf / tpre, tcv))
