@@ -499,10 +499,11 @@ typedef __attribute__((address_space(3))) s16x4* ltr_t;
 struct WsParams {
   const uint4* xs;   // S3 X   [N][C/8][3][D][H][W]
   const uint4* dys;  // S3 dY  [N][K/8][3][D][H][W]
-  float* part;       // [pairs * nwp][TW][64][32]
+  float* part;       // [pairs * nwp][NF][TW][64][32]
   const uint4* zeros;
   int N, C, K, D, H, W;
   int Ty, Tx, YB, XB;
+  int F, NF;         // steps between two accumulator restarts, partial slots per workgroup
   int Xp, XU, XUp;   // X image: row pitch Tx + 2p, units per sub-block, padded sub-block stride (== 4 mod 8)
   int PT, PTp, NK;   // dY image: positions Ty*Tx, padded sub-block stride, k-steps = ceil(PT / 16)
   int npx, npd;      // 1 KiB pieces per X slot / per dY buffer
@@ -602,6 +603,25 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
     toff[j] = (dy * p.Xp + dx) * 16;
   }
 
+  // partial slot f of this workgroup: part[wg][f][tap][k 0..63][c 0..31]; rows of the accumulator tile are k, lanes are c.
+  // The accumulators restart every F steps (the matrix core aligns a k-step's products to the accumulator's exponent: its
+  // rounding error grows with the running sum, see k_conv_s3); the slots are added in fp32 by k_wgrad_s3_reduce.
+  int nflush = 0, since = 0;
+  auto write_partial = [&](bool live) {
+    float* pw = p.part + ((long)wg * p.NF + nflush) * TW * 64 * 32;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TG; ++j)
+      if (j < ntap) {
+        float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + 4 * hh) * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          pt[((e & 3) + 8 * (e >> 2)) * 32] = live ? acc[j][e] : 0.f;
+          acc[j][e] = 0.f;
+        }
+      }
+  };
+
   long step = s_lo;
   bool fresh = true;  // the ring has to be (re)filled: first step of this workgroup or of a new (sample, tile)
   int n = 0, y0 = 0, x0 = 0, z = 0;
@@ -626,6 +646,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
       issue_x(n, y0, x0, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
       issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
     }
+    if (since == p.F && nflush + 1 < p.NF) {
+      write_partial(true);
+      ++nflush;
+      since = 0;
+    }
+    ++since;
     // ---- multiply: NK k-steps x ntap taps x 6 term products
     const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf) + a_lane;
     unsigned sb[TG];  // slot base + tap offset
@@ -665,21 +691,13 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
     if (cont) ++z; else fresh = true;
   }
 
-  // ---- partial: part[wg][tap][k 0..63][c 0..31]; rows of the accumulator tile are k, lanes are c
-  float* pw = p.part + (long)wg * TW * 64 * 32;
-  const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < TG; ++j)
-    if (j < ntap) {
-      float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + 4 * hh) * 32 + r;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) pt[((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];
-    }
+  write_partial(nflush < p.NF);
+  for (++nflush; nflush < p.NF; ++nflush) write_partial(false);  // slots this workgroup did not need: zeros
 }
 
 // dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32, tap / TW), in workgroup order
 __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict__ part, float* __restrict__ dw, int C, int T3, int TW,
-                                                         int nct, int npairs, int nwp, long total) {
+                                                         int nct, int npairs, int nwp, int NF, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (k, tap, c): c fastest -> coalesced partial reads
   if (i >= total) return;
   const int c = (int)(i % C);
@@ -689,7 +707,8 @@ __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict
   const int pair = ((k / 64) * nct + c / 32) * ndg + t / TW;
   const long off = ((long)(t % TW) * 64 + (k & 63)) * 32 + (c & 31);
   float sacc = 0.f;
-  for (int w = 0; w < nwp; ++w) sacc += part[((long)(w * npairs + pair) * TW) * 64 * 32 + off];
+  for (int w = 0; w < nwp; ++w)
+    for (int f = 0; f < NF; ++f) sacc += part[(((long)(w * npairs + pair) * NF + f) * TW) * 64 * 32 + off];
   dw[((long)k * C + c) * T3 + t] = sacc;
 }
 
@@ -736,6 +755,16 @@ bool ws_shape_ok(const ConvDims& d) {
   return ws_plan(d).ok;
 }
 
+int ws_flush_steps() {
+  static const int f = getenv("NC_SPLIT_WFLUSH") ? atoi(getenv("NC_SPLIT_WFLUSH")) : 64;
+  return f > 0 ? f : 1 << 30;
+}
+int ws_nf(long steps, int nwp) {  // partial slots per workgroup: ceil(most steps of a workgroup / F)
+  const long most = (steps + nwp - 1) / nwp;
+  const long nf = (most + ws_flush_steps() - 1) / ws_flush_steps();
+  return nf < 1 ? 1 : (int)nf;
+}
+
 int ws_nwp(const ConvDims& d, const WsPlan& pl, int npairs) {
   int nwp = 256 / npairs;
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
@@ -753,7 +782,8 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
   const int nwp = ws_nwp(d, pl, npairs);
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
-  const size_t pb = align256((size_t)npairs * nwp * TW * 64 * 32 * 4);
+  const int NF = ws_nf(steps, nwp);
+  const size_t pb = align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
   if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3: workspace too small"); return NC_ERR_WS; }
   uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
   uint4* dys = dys_pre ? (uint4*)dys_pre : (uint4*)((char*)ws + xb);
@@ -769,6 +799,7 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
   p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
+  p.F = ws_flush_steps(); p.NF = NF;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
   static bool attr_done = false;
   if (!attr_done) {
@@ -785,7 +816,7 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   if (int e = check_launch("wgrad_s3")) return e;
   const long total = (long)d.K * d.C * T3;
   hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
-                     total);
+                     NF, total);
   return check_launch("wgrad_s3_reduce");
 }
 
@@ -806,8 +837,10 @@ size_t s3_wgrad_ws_bytes(const ConvDims& d) {
   const long S = (long)d.D * d.H * d.W;
   const int T3 = d.kd * d.kh * d.kw, TW = d.kd == 3 ? 27 : 25;
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
-  const int nwp = ws_nwp(d, ws_plan(d), npairs);
-  return align256((size_t)d.N * d.C * S * 6) + align256((size_t)d.N * d.K * S * 6) + align256((size_t)npairs * nwp * TW * 64 * 32 * 4) + 512;
+  const WsPlan pl = ws_plan(d);
+  const int nwp = ws_nwp(d, pl, npairs);
+  const int NF = ws_nf((long)d.N * pl.YB * pl.XB * d.D, nwp);
+  return align256((size_t)d.N * d.C * S * 6) + align256((size_t)d.N * d.K * S * 6) + align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4) + 512;
 }
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s) {

@@ -3,7 +3,7 @@
 The kernels compute an fp32 convolution (models/networks.py:420-425, 460-469, 900-902) on the bf16 matrix cores: every fp32
 operand is the exact sum of three bf16 terms and six of the nine term products are accumulated in fp32.  The checks:
 * the three terms reproduce the fp32 value bit for bit;
-* forward and data gradient against an fp64 reference: the error must not exceed the fp32 MFMA kernel's own error against the
+* forward, data gradient and weight gradient against an fp64 reference: the error must not exceed the fp32 MFMA kernel's own error against the
   same reference by more than a small factor (measured: it is smaller), with an absolute bound of 4e-7 of the output rms;
 * the library switch: with the kernels off the same calls run on the fp32 MFMA kernels and agree to 2e-6 of the output rms;
 * at the 108^3 size of the headline step: the adjoint identity <conv(x), g> == <x, dgrad(g)>, agreement with the fp32 MFMA
@@ -68,6 +68,18 @@ def dgrad_split(dy, w, dys=None):
     return dx
 
 
+def wgrad_split(x, dy, ks, xs=None, dys=None):
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, Z, check, lib
+    N, C, D, H, W = x.shape
+    K = dy.shape[1]
+    dw = torch.empty(K, C, ks, ks, ks, device=x.device)
+    ws = _ws(N, C, D, H, W, K, ks)
+    check(lib().nc_conv_wgrad_split(ops._ptr(x), ops._ptr(xs), ops._ptr(dy), ops._ptr(dys), ops._ptr(dw), I(N), I(C), I(D), I(H), I(W),
+                                    I(K), I(ks), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_wgrad_split')
+    return dw
+
+
 def test_three_terms_are_the_fp32_value():
     torch.manual_seed(3)
     N, C, S = 2, 16, 5000
@@ -121,6 +133,21 @@ def test_split_conv_against_fp64(case):
     print(case, 'fwd fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
     assert rs <= 1.3 * r32 + 2e-8 and rs < 4e-7, (rs, r32)
     assert ms <= 2.0 * m32 + 2e-7, (ms, m32)
+    if C % 32 == 0:  # weight gradient
+        dy = torch.randn(N, K, *n, device=DEV)
+        refw = torch.nn.grad.conv3d_weight(x.double().cpu(), w.shape, dy.double().cpu(), padding=pd)
+        sw = refw.pow(2).mean().sqrt().item()
+        prev = ops.set_conv_split(False)
+        w32 = ops.conv_wgrad_raw(x, dy, w.shape, 1, pd, False)[0]
+        ops.set_conv_split(prev)
+        wsp = wgrad_split(x, dy, ks)
+        assert torch.equal(wsp, wgrad_split(x, dy, ks, to_s3(x), to_s3(dy)))
+        assert torch.equal(wsp, ops.conv_wgrad_raw(x, dy, w.shape, 1, pd, False)[0])  # nc_conv_wgrad takes the same kernel
+        m32, r32 = err(w32, refw, sw)
+        ms, rs = err(wsp, refw, sw)
+        print(case, 'wgrad fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+        assert rs <= 1.3 * r32 + 2e-8 and rs < 6e-7, (rs, r32)
+        assert ms <= 2.0 * m32 + 3e-7, (ms, m32)
     if C % 64 == 0:  # data gradient: the "output" side is C
         dy = torch.randn(N, K, *n, device=DEV)
         refd = torch.nn.grad.conv3d_input(x.shape, w.double().cpu(), dy.double().cpu(), padding=pd)
@@ -193,6 +220,20 @@ def test_full_size_layer_adjoint_and_fp32_agreement(ks, C, K):
     # fp32 roundings: ~1e-5 of the rms at the worst voxel) ...
     assert (y - y32).abs().max().item() < 3e-5 * y32.pow(2).mean().sqrt().item()
     assert (dx - dx32).abs().max().item() < 3e-5 * dx32.pow(2).mean().sqrt().item()
+    # weight gradient (a sum over 1.26 M voxels per weight): <dW, w> == <conv(x) , g> and agreement with the fp32 kernels
+    dw = ops.conv_wgrad_raw(x, g, w.shape, 1, pd, False)[0]
+    assert abs(torch.dot(dw.double().flatten(), w.double().flatten()).item() - lhs) < 1e-6 * nrm
+    ops.set_conv_split(False)
+    dw32 = ops.conv_wgrad_raw(x, g, w.shape, 1, pd, False)[0]
+    ops.set_conv_split(True)
+    assert (dw - dw32).abs().max().item() < 1e-4 * dw32.pow(2).mean().sqrt().item()
+    # ... and against fp64 on the first 4 x 4 channel pairs the split kernel is not the worse one
+    refw = torch.nn.grad.conv3d_weight(x[:, :4].double().cpu(), (4, 4, ks, ks, ks), g[:, :4].double().cpu(), padding=pd)
+    sw = refw.pow(2).mean().sqrt().item()
+    w_s = (dw[:4, :4].double().cpu() - refw).abs().max().item() / sw
+    w_f = (dw32[:4, :4].double().cpu() - refw).abs().max().item() / sw
+    print('108^3 ks=%d %d->%d: weight gradient max error vs fp64  split %.2e  fp32 MFMA %.2e' % (ks, C, K, w_s, w_f))
+    assert w_s < 2e-5 and w_s <= 1.5 * w_f + 1e-6
     # ... and against fp64 on a slab of 6 planes the split kernel is the closer one
     z0, z1 = 40, 46
     ref = F.conv3d(x[:, :, z0 - pd:z1 + pd].double().cpu(), w.double().cpu(), padding=pd)[:, :, pd:pd + z1 - z0]
