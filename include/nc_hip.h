@@ -60,6 +60,10 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
                   int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */, int N, int C, int D, int H,
                   int W, int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* Backward of one layer in one call: dx (or NULL) and dw (+ dbias or NULL) -- nc_conv_dgrad followed by nc_conv_wgrad with
+ * the conversions of dy shared where the kernels have one (nn.Conv3d backward, same call sites). */
+int nc_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias, int N, int C, int D, int H, int W,
+                int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- The same convolution on the 16-bit matrix cores (BASELINE.json configs[3]: "fp16 MFMA path with fp32
  *      InstanceNorm accumulate").  Tensors and master weights stay fp32 at this boundary; inside, operands are rounded

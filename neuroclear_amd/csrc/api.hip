@@ -169,7 +169,9 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     if (sc > b) b = sc;
   }
   if (g_split && s3_wgrad_supported(d)) {
-    const size_t sc = s3_wgrad_ws_bytes(d);
+    size_t sc = s3_wgrad_ws_bytes(d);
+    if (sc > b) b = sc;
+    sc = s3_bwd_ws_bytes(d);
     if (sc > b) b = sc;
   }
   if (b < kBiasGradWsBytes) b = kBiasGradWsBytes;
@@ -312,6 +314,32 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   if (e) return e;
   if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);
   return NC_OK;
+}
+
+// Backward of one convolution layer: dx (nullable) and dw (+ dbias) from x, dy, w.  The same results as nc_conv_dgrad followed
+// by nc_conv_wgrad; on the split-operand kernels dY is converted to its three-term form once for both.
+int nc_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* dbias, int N, int C, int D, int H, int W,
+                int K, int kd, int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (int e = conv_args("conv_bwd", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
+  if (!w) { set_error("conv_bwd: null pointer"); return NC_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  if (dx && dgrad_path(d) == 9 && wgrad_path(d) == 9 && ws && ws_bytes >= s3_bwd_ws_bytes(d)) {
+    {
+      ProfScope ps(1, 9, d, 0, s);
+      if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 0)) return e;
+      if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 1)) return e;
+    }
+    {
+      ProfScope ps(2, 9, d, 0, s);
+      if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 2)) return e;
+    }
+    if (dbias) return bias_grad(dy, dbias, d.N, d.K, (long)d.Do * d.Ho * d.Wo, ws, ws_bytes, s);
+    return NC_OK;
+  }
+  if (dx)
+    if (int e = nc_conv_dgrad(dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad, ws, ws_bytes, stream)) return e;
+  return nc_conv_wgrad(x, dy, dw, dbias, N, C, D, H, W, K, kd, kh, kw, stride, pad, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

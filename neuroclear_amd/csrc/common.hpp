@@ -143,6 +143,9 @@ int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s);
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+size_t s3_bwd_ws_bytes(const ConvDims& d);
+int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                hipStream_t s, int phase);
 bool s3_wgrad_supported(const ConvDims& d);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,

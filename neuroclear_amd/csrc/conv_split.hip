@@ -846,6 +846,24 @@ int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* d
                   hipStream_t s) {
   return run_ws(x, xs, dy, dys, dw, d, ws, wsb, s);
 }
+// data + weight gradient of one layer with dY converted once: [S3 of dY | scratch of whichever kernel runs]
+size_t s3_bwd_ws_bytes(const ConvDims& d) {
+  if (!s_shape_ok(d, d.K, d.C) || !ws_shape_ok(d)) return 0;
+  const long S = (long)d.D * d.H * d.W;
+  const size_t A = align256((size_t)d.N * d.K * S * 6);
+  const size_t dg = align256(s_packed_bytes(d.K, d.C, d.kd)) + 512;
+  const size_t wg = s3_wgrad_ws_bytes(d) - align256((size_t)d.N * d.K * S * 6);
+  return A + (dg > wg ? dg : wg);
+}
+int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
+                hipStream_t s, int phase) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient
+  const long S = (long)d.D * d.H * d.W;
+  const size_t A = align256((size_t)d.N * d.K * S * 6);
+  if (!ws || wsb < s3_bwd_ws_bytes(d)) { set_error("conv_bwd_s3: workspace too small"); return NC_ERR_WS; }
+  if (phase == 0) return split3_to(dy, ws, d.N, d.K, S, s);
+  if (phase == 1) return conv_dgrad_s3(dy, ws, w, dx, d, (char*)ws + A, wsb - A, s);
+  return conv_wgrad_s3(x, nullptr, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
+}
 
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) {
   if (C % 8) { set_error("split3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }

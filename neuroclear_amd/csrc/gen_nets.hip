@@ -210,9 +210,7 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
     const long Sl = p.S[b.lvl];
     NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
                                      p.in_ws, stream));
-    if (gin)
-      NC_TRY(nc_conv_dgrad(draw, P + o.w[i], gin, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
-    return nc_conv_wgrad(in, draw, DP + o.w[i], nullptr, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream);
+    return nc_conv_bwd(in, draw, P + o.w[i], gin, DP + o.w[i], nullptr, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream);
   };
   // gradient of the second half of a concat buffer as a dense tensor
   auto upper_half = [&](const float* dcat, int Ctot, long Sl, const float** out) -> int {
@@ -352,10 +350,8 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     const LLayer& l = kLL[i];
     const float* in = i == 0 ? x : saved + p.act[i - 1];
     float* gin = i == 0 ? dx : G + p.g[i & 1];
-    if (gin)
-      NC_TRY(nc_conv_dgrad(g, params + p.w[i], gin, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
-    NC_TRY(nc_conv_wgrad(in, g, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws,
-                         stream));
+    NC_TRY(nc_conv_bwd(in, g, params + p.w[i], gin, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws,
+                       p.conv_ws, stream));
     g = gin;
   }
   return NC_OK;

@@ -197,6 +197,30 @@ def test_library_switch_selects_the_kernels():
         fwd_split(x4, w4, None)
 
 
+@pytest.mark.parametrize('split', [True, False])
+def test_layer_backward_in_one_call(split):
+    """nc_conv_bwd == nc_conv_dgrad + nc_conv_wgrad, bit for bit (on the split kernels dY is converted once for both)."""
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, Z, check, lib
+    ops.set_conv_split(split)
+    torch.manual_seed(9)
+    N, C, K, n = 2, 64, 128, (6, 20, 33)
+    x = torch.randn(N, C, *n, device=DEV)
+    dy = torch.randn(N, K, *n, device=DEV)
+    w = torch.randn(K, C, 3, 3, 3, device=DEV) * 0.05
+    dx_ref = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+    dw_ref, db_ref = ops.conv_wgrad_raw(x, dy, w.shape, 1, 1, True)
+    L = lib()
+    ws = ops.workspace(L.nc_conv_ws_bytes(I(N), I(C), I(n[0]), I(n[1]), I(n[2]), I(K), I(3), I(3), I(3), I(1), I(1)), DEV, 'ws_bwd_test')
+    for with_dx in (True, False):
+        dx, dw, db = torch.full_like(x, 7.0), torch.empty_like(w), torch.empty(K, device=DEV)
+        check(L.nc_conv_bwd(ops._ptr(x), ops._ptr(dy), ops._ptr(w), ops._ptr(dx if with_dx else None), ops._ptr(dw), ops._ptr(db), I(N),
+                            I(C), I(n[0]), I(n[1]), I(n[2]), I(K), I(3), I(3), I(3), I(1), I(1), ops._ptr(ws), Z(ws.numel()),
+                            ops._stream()), 'nc_conv_bwd')
+        assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+        assert torch.equal(dx, dx_ref) if with_dx else bool((dx == 7.0).all())
+
+
 @pytest.mark.parametrize('ks,C,K', [(3, 64, 64), (3, 128, 64), (5, 64, 64)])
 def test_full_size_layer_adjoint_and_fp32_agreement(ks, C, K):
     """The layer shapes of the headline step at 108^3 (BASELINE configs[1])."""
