@@ -55,7 +55,7 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
     'fwd_split_k3': 'k_conv_s3<3,*>', 'dgrad_split_k3': 'k_conv_s3<3,*>', 'fwd_split_k5': 'k_conv_s3<5,*>',
-    'dgrad_split_k5': 'k_conv_s3<5,*>',
+    'dgrad_split_k5': 'k_conv_s3<5,*>', 'wgrad_split_k3': 'k_wgrad_s3<3>', 'wgrad_split_k5': 'k_wgrad_s3<5>',
     'fwd_lp_k3': 'k_conv_h<*,3,3,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,3,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>',
     'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
     'fwd_lp_k7': 'k_conv_h<*,7,7,1,*> (pseudo-channel form)', 'dgrad_lp_k7': 'k_conv_h<*,7,7,1,*,1> + k_fold_x8',
@@ -66,7 +66,9 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
              'dgrad_mfma_k5': 'conv_mfma_k5', 'wgrad_mfma_k3': 'wgrad_mfma_k3', 'wgrad_mfma_k5': 'wgrad_mfma_k5',
              # 16-bit classes: measured on ONE shape (64 -> 64, 4 x 148^3), so only reported for that workload
              'fwd_lp_k3': 'conv_h_k3', 'dgrad_lp_k3': 'conv_h_k3', 'fwd_lp_k5': 'conv_h_k5', 'dgrad_lp_k5': 'conv_h_k5',
-             'wgrad_lp_k3': 'wgrad_h_k3', 'wgrad_lp_k5': 'wgrad_h_k5'}
+             'wgrad_lp_k3': 'wgrad_h_k3', 'wgrad_lp_k5': 'wgrad_h_k5',
+             'fwd_split_k3': 'conv_split_k3', 'dgrad_split_k3': 'conv_split_k3', 'fwd_split_k5': 'conv_split_k5',
+             'dgrad_split_k5': 'conv_split_k5', 'wgrad_split_k3': 'wgrad_split_k3', 'wgrad_split_k5': 'wgrad_split_k5'}
 
 
 def pmc_traffic(tag, crop=108, batch=1):
@@ -79,7 +81,7 @@ def pmc_traffic(tag, crop=108, batch=1):
         return None
     try:
         with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
-            return round(json.load(f)['classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
+            return round(json.load(f)['split_classes' if '_split_' in tag else 'classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
     except Exception:
         return None
 
@@ -271,11 +273,11 @@ def run_train(args, rank, world, dev):
 GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
 
 
-def pmc_traffic_cube():
-    """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh)."""
+def pmc_traffic_cube(split=False):
+    """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh, tools/pmc_split.sh)."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
-            return round(json.load(f)['inference_cube_140']['hbm_bytes_per_cube'])
+            return round(json.load(f)['inference_cube_140_split' if split else 'inference_cube_140']['hbm_bytes_per_cube'])
     except Exception:
         return None
 
@@ -340,7 +342,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
                                         'profiles/r02_infer_kernel_stats.csv)' % ('k_conv_s3<3,*>' if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
-                    frac=round(ach / peak, 4), **extra, traffic=None if split else pmc_traffic_cube(), launches=len(ev),
+                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), launches=len(ev),
                     avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     share_of_run=round(ms / (dt * 1e3), 4),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))

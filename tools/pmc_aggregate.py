@@ -21,6 +21,10 @@ def kernel_class(name):
         return 'wgrad_mfma_k3'
     if 'k_wgrad_mfma<5' in name or 'k_wgrad_dma<5' in name:
         return 'wgrad_mfma_k5'
+    for kern, cls in (('k_conv_s3<3', 'conv_split_k3'), ('k_conv_s3<5', 'conv_split_k5'), ('k_wgrad_s3<3', 'wgrad_split_k3'),
+                      ('k_wgrad_s3<5', 'wgrad_split_k5'), ('k_split3', 'split3')):
+        if kern in name:
+            return cls
     return None
 
 
