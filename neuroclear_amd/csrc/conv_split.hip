@@ -38,6 +38,11 @@ constexpr int kLdsMax = 160 * 1024;
 // Taps of one kernel plane are taken two per k-step ("pair" q = taps 2q, 2q + 1 in row-major order; an odd count ends in a
 // zero-weight tap).  The pairs of a plane are split into sub-stages so that two weight buffers and two brick buffers fit 160 KB:
 // 3^3: 5 pairs, one sub-stage;  5^3: 13 pairs in sub-stages of 4 + 3 + 3 + 3 (the brick of the plane is staged once).
+// NC_S3_ABLATE (timing experiments only, results are garbage when set): 1 no LDS fragment reads after the first of a sub-stage,
+// 4 no brick / weight DMA after the first, 8 no flush
+#ifndef NC_S3_ABLATE
+#define NC_S3_ABLATE 0
+#endif
 template <int KS> struct Sub;
 template <> struct Sub<3> { static constexpr int NP = 5, NSUB = 1, MAXP = 5; static constexpr int q0[2] = {0, 5}; };
 template <> struct Sub<5> { static constexpr int NP = 13, NSUB = 4, MAXP = 4; static constexpr int q0[5] = {0, 4, 7, 10, 13}; };
@@ -195,6 +200,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
   auto dz_hi = [&](const STile& t) { return t.z + PAD > p.D - 1 ? KS - 1 - (t.z + PAD - (p.D - 1)) : KS - 1; };
 
   auto issue_brick = [&](int tn, int tz, int chunk, int dz, unsigned char* buf) {
+    if ((NC_S3_ABLATE & 4) && buf != lds_raw) return;
     const uint4* plane = p.xs + ((long)tn * p.NCH + chunk) * 3 * S + (long)(tz + dz - PAD) * HW;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
@@ -207,7 +213,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
   };
   auto issue_w = [&](int tcot, int chunk, int dz, int qa, int qe, unsigned char* wb) {
     const uint4* ws = p.wp + ((((long)tcot * p.NCH + chunk) * KS + dz) * NP + qa) * (kPairPieces * 64) + lane;
-    const int npw = (qe - qa) * kPairPieces;
+    const int npw = (NC_S3_ABLATE & 4) ? 0 : (qe - qa) * kPairPieces;
 #pragma unroll 1
     for (int pw = wave; pw < npw; pw += kWaves)
       __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
@@ -306,6 +312,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
             const int bo = tap_off(QA + s + 1);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
+              if (NC_S3_ABLATE & 1) {
+                nA[t][0] = A[t][1]; nA[t][1] = A[t][0];
+#pragma unroll
+                for (int v = 0; v < VB; ++v) nB[t][v] = B[t][(v + 1) % VB];
+                continue;
+              }
               nA[t][0] = wl[(((s + 1) * 3 + t) * 2) * 64]; nA[t][1] = wl[(((s + 1) * 3 + t) * 2 + 1) * 64];
 #pragma unroll
               for (int v = 0; v < VB; ++v) nB[t][v] = bl[t * p.RP + bo + v * 32];
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
         do_sub(std::integral_constant<int, 2>{});
         do_sub(std::integral_constant<int, 3>{});
       }
-      if (p.flush) {
+      if (p.flush && !(NC_S3_ABLATE & 8)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -670,18 +682,29 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
       i32x4 A[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) A[t] = tr_frag(lds_raw, abase + t * a_term + rho[0] * 16, abase + t * a_term + rho[1] * 16);
+      // taps two at a time: consecutive MFMAs go to different accumulators (six dependent MFMAs in a row leave issue gaps)
 #pragma unroll
-      for (int j = 0; j < TG; ++j) {
+      for (int j = 0; j < TG; j += 2) {
         if (j < ntap) {
-          i32x4 B[3];
+          const bool two = j + 1 < TG && j + 1 < ntap;
+          i32x4 B[3], B2[3];
 #pragma unroll
           for (int t = 0; t < 3; ++t) B[t] = tr_frag(lds_raw, sb[j] + t * b_term + bo[0], sb[j] + t * b_term + bo[1]);
-          acc[j] = mfma(A[2], B[0], acc[j]);
-          acc[j] = mfma(A[1], B[1], acc[j]);
-          acc[j] = mfma(A[0], B[2], acc[j]);
-          acc[j] = mfma(A[1], B[0], acc[j]);
-          acc[j] = mfma(A[0], B[1], acc[j]);
-          acc[j] = mfma(A[0], B[0], acc[j]);
+          if (j + 1 < TG) {
+            if (two) {
+#pragma unroll
+              for (int t = 0; t < 3; ++t) B2[t] = tr_frag(lds_raw, sb[j + 1] + t * b_term + bo[0], sb[j + 1] + t * b_term + bo[1]);
+            }
+          }
+          constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int m = 0; m < 6; ++m) {
+            acc[j] = mfma(A[TA[m]], B[TB[m]], acc[j]);
+            if (j + 1 < TG) {
+              if (two) acc[j + 1] = mfma(A[TA[m]], B2[TB[m]], acc[j + 1]);
+            }
+          }
         }
       }
     }
