@@ -353,6 +353,8 @@ void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at 
                                   * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
+void nc_set_s3_fusion(int on); /* 1 (default; NC_S3_FUSE): nc_unet_deconv_fwd has InstanceNorm + ReLU write the three-term form of a
+                                * layer that only feeds a split-operand convolution; 0: separate conversion passes (bit-identical) */
 int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);
 size_t nc_conv_split_ws_bytes(int N, int C, int D, int H, int W, int K, int ks);
 size_t nc_s3_bytes(int N, int C, long S);

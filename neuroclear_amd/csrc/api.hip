@@ -59,6 +59,8 @@ static bool pg1_on(const ConvDims& d) {
 // three-term operand split (same operands, fp32 accumulation, error against fp64 not above the fp32 MFMA kernel's:
 // tests/test_gpu_split.py).  On by default; nc_set_conv_split(0) or NC_CONV_SPLIT=0 put those layers back on the fp32 MFMA kernels.
 static int g_split = getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 1;
+// NC_S3_FUSE=0 (nc_set_s3_fusion(0)): nc_unet_deconv_fwd converts every convolution input to S3 in a separate pass (A/B, tests)
+static int g_s3_fuse = getenv("NC_S3_FUSE") ? atoi(getenv("NC_S3_FUSE")) : 1;
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
@@ -118,6 +120,7 @@ int nc_version(void) { return 100; }
 void nc_set_force_direct(int on) { g_force_direct = on; }
 void nc_sconv_set_cfg(int cfg) { sconv_set_cfg(cfg); }
 void nc_set_conv_split(int on) { g_split = on; }
+void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
 
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
@@ -368,6 +371,7 @@ UnetOff unet_offsets() {
 }
 struct UnetWs {
   size_t raw, cat1, a1, p1, cat2, a2, a2b, p2, b1, b2, t1, t2, mean, rstd, in_ws, conv_ws, total;
+  size_t s_a1, s_cat1, s_a2, s_cat2, s_b1, s_b2;  // S3 (three-term bf16) forms of the convolution inputs, conv_split.hip
   size_t in_ws_bytes, conv_ws_bytes;
 };
 UnetWs unet_ws(int S0, int S1, int S2) {
@@ -390,6 +394,9 @@ UnetWs unet_ws(int S0, int S1, int S2) {
   upd(128, S0 / 4, S1 / 4, S2 / 4, 256); upd(256, S0 / 4, S1 / 4, S2 / 4, 256);
   u.conv_ws_bytes = cw;
   u.conv_ws = take(cw / 4 + 64);
+  auto take3 = [&](size_t elems) { return take((elems * 6 + 3) / 4); };  // 6 bytes per element
+  u.s_a1 = take3(64 * S); u.s_cat1 = take3(128 * S); u.s_a2 = take3(128 * Sh); u.s_cat2 = take3(256 * Sh);
+  u.s_b1 = take3(256 * Sq); u.s_b2 = take3(256 * Sq);
   u.total = off;
   return u;
 }
@@ -421,31 +428,52 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
   void* cws = W + u.conv_ws;
   void* iws = W + u.in_ws;
   float *mean = W + u.mean, *rstd = W + u.rstd;
-  // conv (3^3, pad 1) + InstanceNorm + ReLU: in -> raw -> out
-  auto block = [&](int id, const float* in, float* out, int C, int K, int D, int H, int Wd) -> int {
+  hipStream_t hs = (hipStream_t)stream;
+  // Does the 3^3 convolution C -> K at (D, H, Wd) run on the split-operand kernels?  Then its input is wanted in S3 form, and the
+  // layer in front writes that form from its normalisation pass (k_act_split3) instead of a separate conversion pass.
+  auto split_in = [&](int C, int K, int D, int H, int Wd) {
+    ConvDims d;
+    return g_s3_fuse && make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1) && fwd_path(d) == 9;
+  };
+  // conv (3^3, pad 1) + InstanceNorm + ReLU: in (fp32) or in3 (S3, when the convolution takes it) -> raw -> out (fp32, nullable)
+  // and / or out3 (channels c0 .. of an S3 tensor with ctot channels, nullable)
+  auto block = [&](int id, const float* in, const void* in3, float* out, void* out3, int ctot, int c0, int C, int K, int D, int H,
+                   int Wd) -> int {
     const long Sl = (long)D * H * Wd;
-    NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes,
-                       stream));
+    if (in3) {
+      ConvDims d;
+      make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1);
+      ProfScope ps(0, 9, d, 0, hs);
+      NC_TRY(conv_fwd_s3(nullptr, in3, P + o.w[id], P + o.b[id], W + u.raw, d, cws, u.conv_ws_bytes, hs));
+    } else {
+      NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
+    }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
+    if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
     return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
   };
+  const bool f1 = split_in(64, 64, S0, S1, S2), f9 = split_in(128, 64, S0, S1, S2);
+  const bool f3 = split_in(128, 128, h0, h1, h2), f7 = split_in(256, 128, h0, h1, h2), f8 = f3;
+  const bool f5 = split_in(256, 256, q0, q1, q2), f6 = f5;
   for (int n = 0; n < N; ++n) {
     const float* xn = x + (long)n * S;
     float* yn = y + (long)n * S;
-    NC_TRY(block(0, xn, W + u.a1, 1, 64, S0, S1, S2));
-    NC_TRY(block(1, W + u.a1, W + u.cat1, 64, 64, S0, S1, S2));
+    NC_TRY(block(0, xn, nullptr, f1 ? nullptr : W + u.a1, f1 ? W + u.s_a1 : nullptr, 64, 0, 1, 64, S0, S1, S2));
+    NC_TRY(block(1, W + u.a1, f1 ? W + u.s_a1 : nullptr, W + u.cat1, f9 ? W + u.s_cat1 : nullptr, 128, 0, 64, 64, S0, S1, S2));
     NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
-    NC_TRY(block(2, W + u.p1, W + u.a2, 64, 128, h0, h1, h2));
-    NC_TRY(block(3, W + u.a2, W + u.cat2, 128, 128, h0, h1, h2));
+    NC_TRY(block(2, W + u.p1, nullptr, f3 ? nullptr : W + u.a2, f3 ? W + u.s_a2 : nullptr, 128, 0, 64, 128, h0, h1, h2));
+    NC_TRY(block(3, W + u.a2, f3 ? W + u.s_a2 : nullptr, W + u.cat2, f7 ? W + u.s_cat2 : nullptr, 256, 0, 128, 128, h0, h1, h2));
     NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
-    NC_TRY(block(4, W + u.p2, W + u.b1, 128, 256, q0, q1, q2));
-    NC_TRY(block(5, W + u.b1, W + u.b2, 256, 256, q0, q1, q2));
-    NC_TRY(block(6, W + u.b2, W + u.b1, 256, 256, q0, q1, q2));
+    NC_TRY(block(4, W + u.p2, nullptr, f5 ? nullptr : W + u.b1, f5 ? W + u.s_b1 : nullptr, 256, 0, 128, 256, q0, q1, q2));
+    NC_TRY(block(5, W + u.b1, f5 ? W + u.s_b1 : nullptr, f6 ? nullptr : W + u.b2, f6 ? W + u.s_b2 : nullptr, 256, 0, 256, 256, q0, q1, q2));
+    NC_TRY(block(6, W + u.b2, f6 ? W + u.s_b2 : nullptr, W + u.b1, nullptr, 0, 0, 256, 256, q0, q1, q2));
     NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
-    NC_TRY(block(7, W + u.cat2, W + u.a2, 256, 128, h0, h1, h2));
-    NC_TRY(block(8, W + u.a2, W + u.a2b, 128, 128, h0, h1, h2));
+    if (f7) NC_TRY(split3_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, hs));
+    NC_TRY(block(7, W + u.cat2, f7 ? W + u.s_cat2 : nullptr, f8 ? nullptr : W + u.a2, f8 ? W + u.s_a2 : nullptr, 128, 0, 256, 128, h0, h1, h2));
+    NC_TRY(block(8, W + u.a2, f8 ? W + u.s_a2 : nullptr, W + u.a2b, nullptr, 0, 0, 128, 128, h0, h1, h2));
     NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
-    NC_TRY(block(9, W + u.cat1, W + u.a1, 128, 64, S0, S1, S2));
+    if (f9) NC_TRY(split3_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, hs));
+    NC_TRY(block(9, W + u.cat1, f9 ? W + u.s_cat1 : nullptr, W + u.a1, nullptr, 0, 0, 128, 64, S0, S1, S2));
     NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
     NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
     NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S, stream));

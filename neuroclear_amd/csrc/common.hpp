@@ -140,6 +140,9 @@ bool s3_dgrad_supported(const ConvDims& d);
 size_t s3_ws_bytes(const ConvDims& d);
 size_t s3_tensor_bytes(int N, int C, long S);
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
+int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
+int act_split3(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S,
+               int ctot, int c0, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s);
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);

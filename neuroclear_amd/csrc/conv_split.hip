@@ -70,21 +70,54 @@ __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {
   t[0] = bf16_bits(a0); t[1] = bf16_bits(a1); t[2] = bf16_bits(r2);
 }
 
-// fp32 NCDHW -> S3.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, three 16-byte stores.
-__global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uint4* __restrict__ out, long S) {
+// fp32 NCDHW -> S3.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, three 16-byte stores.  The C
+// channels land at blocks ob0 .. ob0 + C/8 - 1 of an S3 tensor with `oblocks` blocks per sample (a half of a concat buffer).
+__global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks,
+                                                int ob0, long xstride) {
   const long v = (long)blockIdx.x * 256 + threadIdx.x;
   if (v >= S) return;
-  const long ncb = blockIdx.y;  // n * (C/8) + cb
-  const float* xs = x + ncb * 8 * S + v;
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
   unsigned short e[8][3];
 #pragma unroll
   for (int j = 0; j < 8; ++j) split3(xs[j * S], e[j]);
+  const long ob = (long)n * oblocks + ob0 + cb;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     uint4 o;
     o.x = e[0][t] | ((unsigned)e[1][t] << 16); o.y = e[2][t] | ((unsigned)e[3][t] << 16);
     o.z = e[4][t] | ((unsigned)e[5][t] << 16); o.w = e[6][t] | ((unsigned)e[7][t] << 16);
-    out[(ncb * 3 + t) * S + v] = o;
+    out[(ob * 3 + t) * S + v] = o;
+  }
+}
+
+// InstanceNorm normalisation + (Leaky)ReLU (norm_act.hip k_in_act_fwd: the same arithmetic, operation for operation) writing the
+// S3 form of the result -- and the fp32 tensor too when y != NULL: a layer whose only consumer is a split-operand convolution
+// never exists in fp32 (whole-network forward, api.hip).
+__global__ void __launch_bounds__(256) k_act_split3(const float* __restrict__ x, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, float slope, float* __restrict__ y, long ystride,
+                                                    uint4* __restrict__ out, long S, int cblocks, int oblocks, int ob0) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  const long c0 = (long)blockIdx.y * 8;  // instance index of channel 0 of this block
+  const float* xs = x + c0 * S + v;
+  float* ys = y ? y + (long)n * ystride + (long)cb * 8 * S + v : nullptr;
+  unsigned short e[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float t = (xs[j * S] - mean[c0 + j]) * rstd[c0 + j];
+    t = t > 0.f ? t : t * slope;
+    if (ys) ys[j * S] = t;
+    split3(t, e[j]);
+  }
+  const long ob = (long)n * oblocks + ob0 + cb;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    uint4 o;
+    o.x = e[0][t] | ((unsigned)e[1][t] << 16); o.y = e[2][t] | ((unsigned)e[3][t] << 16);
+    o.z = e[4][t] | ((unsigned)e[5][t] << 16); o.w = e[6][t] | ((unsigned)e[7][t] << 16);
+    out[(ob * 3 + t) * S + v] = o;
   }
 }
 
@@ -477,7 +510,8 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
   const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
   if (!zeros) { set_error("conv_s3: no zero page"); return NC_ERR_HIP; }
   if (!xs_pre) {
-    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xs, S);
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xs, S, Cin / 8, Cin / 8, 0,
+                       (long)Cin * S);
     if (int e = check_launch("split3")) return e;
   }
   const long total = (long)(s_packed_bytes(Cin, Kout, KS) / 2);
@@ -813,8 +847,12 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   float* part = (float*)((char*)ws + xb + yb);
   const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
   if (!zeros) { set_error("wgrad_s3: no zero page"); return NC_ERR_HIP; }
-  if (!xs_pre) hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xs, S);
-  if (!dys_pre) hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dys, S);
+  if (!xs_pre)
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xs, S, d.C / 8, d.C / 8, 0,
+                       (long)d.C * S);
+  if (!dys_pre)
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dys, S, d.K / 8, d.K / 8, 0,
+                       (long)d.K * S);
   if (int e = check_launch("split3")) return e;
   WsParams p{};
   p.xs = xs; p.dys = dys; p.part = part; p.zeros = zeros;
@@ -888,10 +926,23 @@ int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, floa
   return conv_wgrad_s3(x, nullptr, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
 }
 
-int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) {
-  if (C % 8) { set_error("split3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S);
+int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) { return split3_into(x, (long)C * S, xs, N, C, S, C, 0, s); }
+
+// x: N samples of C channels, `xstride` floats apart; result: channels c0 .. c0 + C - 1 of an S3 tensor with ctot channels
+int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s) {
+  if (C % 8 || ctot % 8 || c0 % 8) { set_error("split3: channels must be multiples of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8,
+                     xstride);
   return check_launch("split3");
+}
+
+// y (nullable, samples `ystride` floats apart) and the S3 tensor ys (channels c0 .. of ctot) <- act((x - mean) * rstd), x dense [N][C][S]
+int act_split3(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S,
+               int ctot, int c0, hipStream_t s) {
+  if (C % 8 || ctot % 8 || c0 % 8) { set_error("act_split3: channels must be multiples of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_act_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, mean, rstd, slope, y, ystride,
+                     (uint4*)ys, S, C / 8, ctot / 8, c0 / 8);
+  return check_launch("act_split3");
 }
 
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,

@@ -281,3 +281,12 @@ def test_whole_network_inference_with_and_without_the_split_kernels():
         y_off = net(x).clone()
         ops.set_conv_split(True)
     assert (y_on - y_off).abs().max().item() < 2e-6
+    # the normalisation pass writing the three-term form itself (default) or a separate conversion pass: the same bits
+    from neuroclear_amd._lib import I, lib
+    lib().nc_set_s3_fusion(I(0))
+    try:
+        with torch.no_grad():
+            y_sep = net(x).clone()
+    finally:
+        lib().nc_set_s3_fusion(I(1))
+    assert torch.equal(y_on, y_sep)
