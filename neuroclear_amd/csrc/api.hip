@@ -327,7 +327,7 @@ int nc_conv_bwd(const float* x, const float* dy, const float* w, float* dx, floa
   if (int e = conv_args("conv_bwd", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   if (!w) { set_error("conv_bwd: null pointer"); return NC_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  if (dx && dgrad_path(d) == 9 && wgrad_path(d) == 9 && ws && ws_bytes >= s3_bwd_ws_bytes(d)) {
+  if (dx && dgrad_path(d) == 9 && wgrad_path(d) == 9 && ws && s3_bwd_ws_bytes(d) && ws_bytes >= s3_bwd_ws_bytes(d)) {
     {
       ProfScope ps(1, 9, d, 0, s);
       if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 0)) return e;
@@ -344,6 +344,45 @@ int nc_conv_bwd(const float* x, const float* dy, const float* w, float* dx, floa
     if (int e = nc_conv_dgrad(dy, w, dx, N, C, D, H, W, K, kd, kh, kw, stride, pad, ws, ws_bytes, stream)) return e;
   return nc_conv_wgrad(x, dy, dw, dbias, N, C, D, H, W, K, kd, kh, kw, stride, pad, ws, ws_bytes, stream);
 }
+
+}  // extern "C"
+
+namespace nc {
+int conv_fwd_keep(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks,
+                  void* ws, size_t ws_bytes, void* stream, void* xs_keep, bool* kept) {
+  ConvDims d;
+  *kept = false;
+  if (xs_keep && make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) && fwd_path(d) == 9 && wgrad_path(d) == 9) {
+    if (!x || !w || !y) { set_error("conv_fwd: null pointer"); return NC_ERR_ARG; }
+    ProfScope ps(0, 9, d, 0, (hipStream_t)stream);
+    *kept = true;
+    return conv_fwd_s3(x, nullptr, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream, xs_keep);
+  }
+  return nc_conv_fwd(x, w, bias, y, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2, ws, ws_bytes, stream);
+}
+
+int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* w, float* dx, float* dw, int N, int C, int D, int H,
+                  int W, int K, int ks, void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  hipStream_t s = (hipStream_t)stream;
+  if (xs && make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) && wgrad_path(d) == 9 && ws && s3_bwd_ws_bytes(d) &&
+      ws_bytes >= s3_bwd_ws_bytes(d) &&
+      (!dx || dgrad_path(d) == 9)) {
+    if (!x || !dy || !w || !dw) { set_error("conv_bwd: null pointer"); return NC_ERR_ARG; }
+    {
+      ProfScope ps(1, 9, d, 0, s);
+      if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 0)) return e;
+      if (dx)
+        if (int e = conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 1)) return e;
+    }
+    ProfScope ps(2, 9, d, 0, s);
+    return conv_bwd_s3(x, dy, w, dx, dw, d, ws, ws_bytes, s, 2, xs);
+  }
+  return nc_conv_bwd(x, dy, w, dx, dw, nullptr, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2, ws, ws_bytes, stream);
+}
+}  // namespace nc
+
+extern "C" {
 
 // ------------------------------------------------------------------------------------------------------------------
 // Whole-network forward of Unet_deconv.  Parameter blob = state-dict order, fp32, back to back.

@@ -144,11 +144,18 @@ int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, in
 int act_split3(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S,
                int ctot, int c0, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s);
+                hipStream_t s, void* xs_keep = nullptr);
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 size_t s3_bwd_ws_bytes(const ConvDims& d);
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, int phase);
+                hipStream_t s, int phase, const void* xs = nullptr);
+// api.hip: forward / backward of one layer for the whole-network training calls.  conv_fwd_keep: nc_conv_fwd; when the layer runs
+// on the split-operand kernels its converted input is written to xs_keep and *kept set.  conv_bwd_keep: nc_conv_bwd with that
+// tensor handed back (xs NULL: converted again).
+int conv_fwd_keep(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks,
+                  void* ws, size_t ws_bytes, void* stream, void* xs_keep, bool* kept);
+int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* w, float* dx, float* dw, int N, int C, int D, int H,
+                  int W, int K, int ks, void* ws, size_t ws_bytes, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,

@@ -497,15 +497,17 @@ int launch_s3(const SParams& p, int lds, hipStream_t s) {
   return check_launch("conv_s3");
 }
 
+// xs_keep (only without xs_pre): the converted operand is written THERE instead of into the workspace -- the caller keeps it (the
+// weight gradient of the same layer wants the same S3 tensor)
 int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
-           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr) {
   const int KS = d.kd;
   const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
-  const size_t xb = xs_pre ? 0 : align256((size_t)d.N * Cin * S * 6);
+  const size_t xb = (xs_pre || xs_keep) ? 0 : align256((size_t)d.N * Cin * S * 6);
   const size_t wb = align256(s_packed_bytes(Cin, Kout, KS));
   if (!ws || wsb < xb + wb + 256) { set_error("conv_s3: workspace too small"); return NC_ERR_WS; }
-  uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
+  uint4* xs = xs_pre ? (uint4*)xs_pre : xs_keep ? (uint4*)xs_keep : (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + xb);
   const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
   if (!zeros) { set_error("conv_s3: no zero page"); return NC_ERR_HIP; }
@@ -909,21 +911,21 @@ int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* d
 }
 // data + weight gradient of one layer with dY converted once: [S3 of dY | scratch of whichever kernel runs]
 size_t s3_bwd_ws_bytes(const ConvDims& d) {
-  if (!s_shape_ok(d, d.K, d.C) || !ws_shape_ok(d)) return 0;
+  if (!ws_shape_ok(d)) return 0;
   const long S = (long)d.D * d.H * d.W;
   const size_t A = align256((size_t)d.N * d.K * S * 6);
-  const size_t dg = align256(s_packed_bytes(d.K, d.C, d.kd)) + 512;
+  const size_t dg = s_shape_ok(d, d.K, d.C) ? align256(s_packed_bytes(d.K, d.C, d.kd)) + 512 : 0;  // (the data gradient is optional)
   const size_t wg = s3_wgrad_ws_bytes(d) - align256((size_t)d.N * d.K * S * 6);
   return A + (dg > wg ? dg : wg);
 }
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, int phase) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient
+                hipStream_t s, int phase, const void* xs) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient (xs: x in S3, or NULL)
   const long S = (long)d.D * d.H * d.W;
   const size_t A = align256((size_t)d.N * d.K * S * 6);
   if (!ws || wsb < s3_bwd_ws_bytes(d)) { set_error("conv_bwd_s3: workspace too small"); return NC_ERR_WS; }
   if (phase == 0) return split3_to(dy, ws, d.N, d.K, S, s);
   if (phase == 1) return conv_dgrad_s3(dy, ws, w, dx, d, (char*)ws + A, wsb - A, s);
-  return conv_wgrad_s3(x, nullptr, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
+  return conv_wgrad_s3(x, xs, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
 }
 
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) { return split3_into(x, (long)C * S, xs, N, C, S, C, 0, s); }
@@ -946,9 +948,9 @@ int act_split3(const float* x, const float* mean, const float* rstd, float slope
 }
 
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s) {
+                hipStream_t s, void* xs_keep) {
   const int T3 = d.kd * d.kh * d.kw;
-  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s);
+  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, xs_keep);
 }
 
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {

@@ -9,6 +9,9 @@
 //
 // Parameter blob = the tensors in state-dict order, packed back to back.  `saved` receives what the
 // backward needs (raw conv outputs, activations, InstanceNorm statistics); sizes from the *_saved_floats queries.
+#include <mutex>
+#include <unordered_map>
+
 #include "common.hpp"
 
 using namespace nc;
@@ -18,6 +21,24 @@ using namespace nc;
 namespace {
 
 size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// Which S3 (three-term) copies of convolution inputs did the last forward into a `saved` buffer leave there (bit i = layer i)?
+// The forward of a layer that runs on the split-operand kernels converts its input INTO the saved buffer (conv_fwd_keep) and the
+// backward hands that tensor to the weight gradient instead of converting x again; the mask is host state because the decision
+// (library switch, shape coverage) is host state -- a backward whose `saved` has no entry, or a layer whose bit is clear, converts.
+std::mutex g_keep_mu;
+std::unordered_map<const void*, unsigned> g_keep;
+void keep_set(const void* saved, unsigned mask) {
+  std::lock_guard<std::mutex> lk(g_keep_mu);
+  if (g_keep.size() > 4096) g_keep.clear();
+  g_keep[saved] = mask;
+}
+unsigned keep_get(const void* saved) {
+  std::lock_guard<std::mutex> lk(g_keep_mu);
+  auto it = g_keep.find(saved);
+  return it == g_keep.end() ? 0u : it->second;
+}
+size_t s3_floats(size_t elems) { return up64((elems * 6 + 3) / 4); }
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- Unet_deconv ---------------------------------------------------------------------------------------------------
@@ -30,6 +51,7 @@ struct UPlan {
   long S[3];           // voxels per level
   // saved (floats): activations, raw conv outputs, statistics
   size_t a1, cat1, p1, a2, cat2, p2, b1, b2, b3, e2a, e2b, e1, t1, raw[10], mean[10], rstd[10], saved;
+  size_t xs3[10];      // S3 copy of block i's input (i >= 1), see g_keep
   // backward scratch (floats)
   size_t G1, G2, G3, H1, H2, H3, Q1, Q2, s1, s2, T, grads;
   size_t conv_ws, in_ws, convT_ws;  // bytes
@@ -55,6 +77,7 @@ bool u_plan(UPlan& p, int N, int S0, int S1, int S2) {
     p.mean[i] = take(n * kUB[i].K);
     p.rstd[i] = take(n * kUB[i].K);
   }
+  for (int i = 1; i < 10; ++i) { p.xs3[i] = off; off += s3_floats(n * kUB[i].C * (size_t)p.S[kUB[i].lvl]); }
   p.saved = off;
   off = 0;
   p.G1 = take(n * 64 * S); p.G2 = take(n * 64 * S); p.G3 = take(n * 128 * S);
@@ -138,14 +161,18 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   void* iws = (char*)ws + align256(p.conv_ws);
   float* V = saved;
   const float* P = params;
+  keep_set(saved, 0);
   // conv (3^3, pad 1) -> raw; statistics; normalise + ReLU into `out`, where sample n's K planes start at
   // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer)
+  unsigned kept_mask = 0;
   auto block = [&](int i, const float* in, float* out, size_t out_stride) -> int {
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     const long S = p.S[b.lvl];
-    NC_TRY(nc_conv_fwd(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws,
-                       p.conv_ws, stream));
+    bool kept = false;
+    NC_TRY(conv_fwd_keep(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream,
+                         i >= 1 ? (void*)(V + p.xs3[i]) : nullptr, &kept));
+    if (kept) kept_mask |= 1u << i;
     NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
     if (out_stride == (size_t)b.K * S || N == 1)
       return nc_instnorm_act_fwd(V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, N * b.K, S, stream);
@@ -180,6 +207,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   NC_TRY(nc_conv_fwd(V + p.e1, P + o.w[12], P + o.b[12], V + p.t1, N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
   // one_by_one_2 + sigmoid: y doubles as the buffer of the pre-sigmoid value (the sigmoid kernel is elementwise in place)
   NC_TRY(nc_conv_fwd(V + p.t1, P + o.w[13], P + o.b[13], y, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
+  keep_set(saved, kept_mask);
   return nc_sigmoid_fwd(y, y, (long)N * S, stream);
 }
 
@@ -202,6 +230,7 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
   float* DP = dparams;
   const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
+  const unsigned kept_mask = keep_get(saved);
   // backward of block i: g = gradient at the block's (post-ReLU) output, dense [N][K][S]; `in` = the block's input.
   // draw <- InstanceNorm/ReLU backward (+ the conv's bias gradient); dW <- wgrad; gin (nullable) <- dgrad
   auto block_bwd = [&](int i, const float* g, const float* in, float* draw, float* gin) -> int {
@@ -210,7 +239,8 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
     const long Sl = p.S[b.lvl];
     NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
                                      p.in_ws, stream));
-    return nc_conv_bwd(in, draw, P + o.w[i], gin, DP + o.w[i], nullptr, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1, cws, p.conv_ws, stream);
+    return conv_bwd_keep(in, (kept_mask >> i) & 1 ? (const void*)(V + p.xs3[i]) : nullptr, draw, P + o.w[i], gin, DP + o.w[i], N, b.C,
+                         d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
   };
   // gradient of the second half of a concat buffer as a dense tensor
   auto upper_half = [&](const float* dcat, int Ctot, long Sl, const float** out) -> int {
@@ -272,6 +302,7 @@ struct LPlan {
   long S;
   size_t w[6], params;        // floats into the packed blob
   size_t act[5], saved;       // outputs of layers 0..4 (inputs of layers 1..5)
+  size_t xs3[6];              // S3 copy of the input of layer i (the 5^3 and 3^3 layers), see g_keep
   size_t g[2], grads;         // gradient ping-pong
   size_t conv_ws;
 };
@@ -286,6 +317,10 @@ bool l_plan(LPlan& p, int N, int S0, int S1, int S2) {
   p.params = off;
   off = 0;
   for (int i = 0; i < 5; ++i) { p.act[i] = off; off += up64((size_t)N * kLL[i].K * p.S); }
+  for (int i = 0; i < 6; ++i) {
+    p.xs3[i] = off;
+    if (kLL[i].k > 1 && kLL[i].C % 8 == 0) off += s3_floats((size_t)N * kLL[i].C * p.S);
+  }
   p.saved = off;
   p.g[0] = 0; p.g[1] = up64((size_t)N * 64 * p.S);
   p.grads = 2 * up64((size_t)N * 64 * p.S);
@@ -326,13 +361,21 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
   void* cws = ws;
   float* G = (float*)((char*)ws + align256(p.conv_ws));
   const float* in = x;
+  unsigned kept_mask = 0;
+  if (saved) keep_set(saved, 0);
   for (int i = 0; i < 6; ++i) {
     const LLayer& l = kLL[i];
     float* out = i == 5 ? y : (saved ? saved + p.act[i] : G + p.g[i & 1]);
-    NC_TRY(nc_conv_fwd(in, params + p.w[i], nullptr, out, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws,
-                       stream));
+    bool kept = false;
+    void* keep = saved && l.k > 1 && l.C % 8 == 0 ? (void*)(saved + p.xs3[i]) : nullptr;
+    if (l.k > 1)
+      NC_TRY(conv_fwd_keep(in, params + p.w[i], nullptr, out, N, l.C, S0, S1, S2, l.K, l.k, cws, p.conv_ws, stream, keep, &kept));
+    else
+      NC_TRY(nc_conv_fwd(in, params + p.w[i], nullptr, out, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
+    if (kept) kept_mask |= 1u << i;
     in = out;
   }
+  if (saved) keep_set(saved, kept_mask);
   return NC_OK;
 }
 
@@ -346,12 +389,17 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
   void* cws = ws;
   float* G = (float*)((char*)ws + align256(p.conv_ws));
   const float* g = dy;
+  const unsigned kept_mask = keep_get(saved);
   for (int i = 5; i >= 0; --i) {
     const LLayer& l = kLL[i];
     const float* in = i == 0 ? x : saved + p.act[i - 1];
     float* gin = i == 0 ? dx : G + p.g[i & 1];
-    NC_TRY(nc_conv_bwd(in, g, params + p.w[i], gin, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws,
-                       p.conv_ws, stream));
+    if (l.k > 1)
+      NC_TRY(conv_bwd_keep(in, (kept_mask >> i) & 1 ? (const void*)(saved + p.xs3[i]) : nullptr, g, params + p.w[i], gin, dparams + p.w[i],
+                           N, l.C, S0, S1, S2, l.K, l.k, cws, p.conv_ws, stream));
+    else
+      NC_TRY(nc_conv_bwd(in, g, params + p.w[i], gin, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws,
+                         p.conv_ws, stream));
     g = gin;
   }
   return NC_OK;
