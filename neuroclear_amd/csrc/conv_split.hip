@@ -39,7 +39,7 @@ constexpr int kLdsMax = 160 * 1024;
 // zero-weight tap).  The pairs of a plane are split into sub-stages so that two weight buffers and two brick buffers fit 160 KB:
 // 3^3: 5 pairs, one sub-stage;  5^3: 13 pairs in sub-stages of 4 + 3 + 3 + 3 (the brick of the plane is staged once).
 // NC_S3_ABLATE (timing experiments only, results are garbage when set): 1 no LDS fragment reads after the first of a sub-stage,
-// 4 no brick / weight DMA after the first, 8 no flush
+// 4 no brick / weight DMA after the first, 8 no flush, 16 no stage barrier
 #ifndef NC_S3_ABLATE
 #define NC_S3_ABLATE 0
 #endif
@@ -308,9 +308,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
         unsigned char* const wn = wbuf0 + ((gw & 1) ^ 1) * WB;
         // this sub-stage's weights (and, at sub 0, the brick) have landed; with several sub-stages the next brick, issued
         // behind the weights of sub 1, may stay in flight over the barrier of sub 1
-        if constexpr (NSUB > 1 && sub == 1) wait_vm(have_next ? nbw : 0);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // ... everybody's share too; everybody is done with the buffers written next
+        if (!(NC_S3_ABLATE & 16)) {
+          if constexpr (NSUB > 1 && sub == 1) wait_vm(have_next ? nbw : 0);
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();  // ... everybody's share too; everybody is done with the buffers written next
+        }
         if constexpr (sub == 0) {
           if constexpr (NSUB > 1) issue_w(cur.cot, chunk, lo + dzi, SU::q0[1], SU::q0[NSUB > 1 ? 2 : 1], wn);
           if (have_next) {
