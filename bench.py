@@ -25,6 +25,9 @@ Extra objects on the JSON line:
                   the GPU box, rank 0 and N = 1 only: full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
                   1-thread figure on a bounded 36^3 sample; inference: 140^3 cubes through
                   oracle/nets.py + oracle/dice.py for a bounded time, extrapolated to 729 cubes (stated).
+The inference leg keeps NC_INFER_STREAMS (3) cubes in flight on as many HIP streams; its `roofline.achieved` is therefore all cubes'
+FLOP over the wall time of the timed region (`event_ms_per_cube` = the mean HIP-event interval of one whole-network call, which now
+overlaps its neighbours').
 `--workload train` / `--workload infer` run one leg only (infer = BASELINE.json configs[2], cubes sharded over ranks);
 `--crop 148 --batch 4` is the shape of configs[3] (in fp32), `--model athena` the step of configs[4].
 """
@@ -331,7 +334,11 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
     computed = ncubes * 140 ** 3  # voxels the network actually processes (overlap + border: 2.74 x the volume at 900^3)
     roof = None
     if ev:
-        ms = sum(a.elapsed_time(b) for a, b in ev)
+        # Cubes overlap on NC_INFER_STREAMS HIP streams (test_dice.py), so the per-call event intervals overlap too: the rate is
+        # taken over the wall time of the timed region (all cubes' FLOP / dt); avg_launch_ms = wall time per cube.
+        in_flight = int(os.environ.get('NC_INFER_STREAMS', '3'))
+        ms_events = sum(a.elapsed_time(b) for a, b in ev)
+        ms = dt * 1e3 if in_flight > 1 else ms_events
         flop = GA_FWD_FLOP_PER_VOXEL * 140 ** 3
         ach = flop * len(ev) / ms / 1e9
         from neuroclear_amd._lib import lib
@@ -343,8 +350,8 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                                         'profiles/r02_infer_kernel_stats.csv)' % ('k_conv_s3<3,*>' if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
                     frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), launches=len(ev),
-                    avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
-                    share_of_run=round(ms / (dt * 1e3), 4),
+                    cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
+                    event_ms_per_cube=round(ms_events / len(ev), 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
     return dt, L ** 3 * steps, roof, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
                                           parallelism='cubes%%%d' % world, cubes=ncubes,
