@@ -159,6 +159,24 @@ def test_config0_diced_inference_256():
     assert np.array_equal(got, ref_vol)
 
 
+def test_diced_inference_cubes_in_flight_is_bit_identical(monkeypatch):
+    """Three cubes in flight on three HIP streams (the default) against one cube at a time: the overlap-adds stay in cube
+    order, so the assembled volume is the same array; also with the input volume assembled beside it (with_real)."""
+    from neuroclear_amd.test_dice import diced_inference
+    vol = S.random_volume(23, (96, 110, 75))
+    opt = Namespace(dice_size=[32] * 3, overlap=4, border_cut=4, gpu_ids=[0], skip_real=True, data_type='uint16',
+                    histogram_match=False, normalize_intensity=False)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 5, DEV))
+    out = {}
+    for n in ('1', '3', '4'):
+        monkeypatch.setenv('NC_INFER_STREAMS', n)
+        out[n] = diced_inference(net, vol, opt, with_real=True)
+    for n in ('3', '4'):
+        assert np.array_equal(out['1'][0], out[n][0]) and np.array_equal(out['1'][1], out[n][1])
+    assert float(np.abs(out['3'][1].astype(np.int64) - vol.astype(np.int64)).max()) <= 1  # the dice -> assemble round trip of the input
+
+
 def test_diced_inference_reduce_mode_matches_in_order():
     """assemble='reduce' (each rank overlap-adds its own cubes, one reduce(sum)) on the device: at world 1 it is the
     in-order path bit for bit; two emulated ranks (cubes i % 2, accumulators summed as RCCL's reduce would) stay within
