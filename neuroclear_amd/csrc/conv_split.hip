@@ -1,6 +1,6 @@
-// fp32 Conv3d 3^3 / 5^3 (stride 1, "same" padding) on the 16-bit matrix cores: forward and dgrad of the U-Net's 3^3 layers
-// (models/networks.py:420-425, 460-469) and of G_B's 5^3 / 3^3 feature layers (:900-902) with fp32 operands and fp32-grade
-// results.
+// fp32 Conv3d 3^3 / 5^3 (stride 1, "same" padding) on the 16-bit matrix cores: forward, data gradient and weight gradient of
+// the U-Net's 3^3 layers (models/networks.py:420-425, 460-469) and of G_B's 5^3 / 3^3 feature layers (:900-902) with fp32
+// operands, fp32 accumulation and fp32 results.
 //
 // gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32768 FLOP in 32 cycles; the fp32
 // instruction v_mfma_f32_32x32x2_f32: 4096 FLOP in 64).  An fp32 number is EXACTLY the sum of three bf16 numbers
@@ -16,7 +16,11 @@
 // (conv_h.hip): stage = (8-channel chunk, dz), a k-step = 8 channels at two taps (lane half h takes tap 2i + h; 5 k-steps
 // for the 9 taps of a plane, the 10th tap has zero weights), brick and weights of a stage in LDS by LDS-DMA for all three
 // terms (3 x the 16-bit bytes, 6 x the MFMAs: a third of the 16-bit kernel's staging traffic per MFMA), two stage buffers,
-// tile = 64 output channels x 512 flattened positions of one output plane on 8 waves (2 x 2 accumulator tiles each).
+// tile = 64 output channels x 512 flattened positions of one output plane on 8 waves (2 x 2 accumulator tiles each).  5^3: the
+// 13 tap pairs of a plane come in four sub-stages of weights over one staged brick.  k_wgrad_s3 (below) is the weight gradient.
+// Accuracy: the matrix core's rounding error grows with the running sum in its accumulator, so the accumulators restart per
+// stage group (forward / dgrad) or every 64 steps (wgrad) and the pieces are added in fp32 -- with that the error against fp64
+// is below the fp32 MFMA kernels' at every shape tested ("Split-operand fp32 convolutions").
 #include <cstdlib>
 #include <type_traits>
 
