@@ -302,8 +302,9 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
     vol = S.random_volume(5, L)
     opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[dev.index], skip_real=True,
                     data_type='uint16', histogram_match=False, normalize_intensity=False)
-    for _ in range(max(warmup, 1)):
-        diced_inference(net, vol, opt, rank, world, max_cubes=2 * world)
+    in_flight = max(int(os.environ.get('NC_INFER_STREAMS', '3')), 1)
+    for _ in range(max(warmup, 1)):  # every stream of the cubes in flight gets its workspace and its first launches here
+        diced_inference(net, vol, opt, rank, world, max_cubes=max(2, in_flight) * world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

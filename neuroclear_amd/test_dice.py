@@ -21,6 +21,18 @@ from .data.diceImage_dataset import DiceImageDataSet
 from .util.assemble_dice import Assemble_Dice, match_cube
 
 
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    """The HIP streams of the cubes in flight, created once per device: scratch buffers are cached per stream
+    (ops.workspace), so fresh streams per call would mean fresh multi-GB workspaces per call."""
+    key = (device.index, n)
+    if key not in _SIDE:
+        _SIDE[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return _SIDE[key]
+
+
 def sharded_cube_loop(n, rank, world, produce, consume, empty_like):
     """assemble='gather' schedule, free of device code so that it can be exercised with gloo on CPU:
     round t hands cube t*world + r to rank r; `produce(i)` returns that cube's network output (a tensor), tiles of a
@@ -105,7 +117,7 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     nstreams = int(os.environ.get('NC_INFER_STREAMS', '3'))
     piped = ds.device.type == 'cuda' and nstreams > 1 and (world == 1 or assemble == 'reduce')
     main = torch.cuda.current_stream(ds.device) if piped else None
-    side = [torch.cuda.Stream(ds.device) for _ in range(nstreams)] if piped else []
+    side = _side_streams(ds.device, nstreams) if piped else []
     for st in side:
         st.wait_stream(main)  # the volume upload and the parameter broadcast were enqueued on the calling stream
     issued = [0]
