@@ -156,6 +156,11 @@ int conv_fwd_keep(const float* x, const float* w, const float* bias, float* y, i
                   void* ws, size_t ws_bytes, void* stream, void* xs_keep, bool* kept);
 int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* w, float* dx, float* dw, int N, int C, int D, int H,
                   int W, int K, int ks, void* ws, size_t ws_bytes, void* stream);
+// conv_s3x.hip: the tap-stream form of the split-operand forward / data-gradient kernel (S3 input, packed weights in wp_ws)
+bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS);
+size_t s3x_packed_bytes(int Cin, int Kout, int KS);
+int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
+             long si, int flip, void* wp_ws, hipStream_t s);
 bool s3_wgrad_supported(const ConvDims& d);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,

@@ -1,0 +1,485 @@
+// fp32 Conv3d 3^3 / 5^3 (stride 1, "same" padding), forward and data gradient, on the bf16 matrix cores with the exact
+// three-term operand split of conv_split.hip (same S3 input layout, same six products per fp32 product) -- the "tap stream"
+// form of that kernel (models/networks.py:420-425, 460-469, 900-902: the nn.Conv3d layers of unet_deconv / deep_linear_gen):
+//
+//  * v_mfma_f32_16x16x32_bf16 instead of 32x32x16: at equal work the chip holds a ~25 % higher clock under it (bare loops on
+//    random data: 2.01 against 1.74 PFLOP/s, tools/mfma_rate.hip) -- dense bf16 MFMA loops are power-bound on this part;
+//  * NO zero tap: the K-dim of a tile is ONE stream of taps, (8-channel chunk, dz, dy, dx) in that order, consumed four at
+//    a time (a k-step of 32 = lane group g = lane / 16 takes tap 4s + g, 8 channels each).  KS^2 taps (9 or 25) of one
+//    input plane of one chunk are a "brick"; k-steps straddle bricks, so the bricks live in an LDS RING of three
+//    (in use / arrived / loading) filled by LDS-DMA, one barrier per brick.  conv_split.hip's pairing spent 10 % of the
+//    3^3 MFMAs on a zero-weight tenth tap;
+//  * a brick is the flat range [q0, q0 + PT + (KS-1)(P+1)) of the zero-padded plane (pitch P = W + KS - 1), not whole rows:
+//    37-40 KB for 512 positions and three terms, so three of them fit and NO weights go through LDS;
+//  * weights stream from global memory (L2-resident) straight into registers as MFMA A fragments, one k-step ahead, through
+//    a buffer descriptor with scalar offsets: [cot][co half][k-step][row block][term][lane][8] bf16, 1 KiB per fragment;
+//  * 8 waves = 2 halves of the 64 output channels x 4 groups of NCB*16 positions; per k-step a wave holds its 6 A fragments
+//    and walks its NCB column blocks: 6 ds_read_b64 (3 terms) + 12 MFMAs each.  The B fragment of a lane is one 16-byte unit
+//    read as two ds_read_b64 -- lane groups 1 and 3 read the upper half first (their packed weights have the channel halves
+//    swapped to match): every read instruction touches each of the 64 banks exactly once whatever the tap offsets of the
+//    groups are (one ds_read_b128 would be 2-way conflicted for every pair of taps that is not a multiple of 16 units apart);
+//  * tile quantisation: the launch covers whole rounds of 256 tiles with NCB = 8 (512 positions) and the remainder with a
+//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,592 tiles at 108^3 cost 10.3 rounds instead of 11.
+// Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace nc {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef const volatile __attribute__((address_space(3))) unsigned long long* lds64_t;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kLdsMax = 160 * 1024;
+constexpr int kMaxJ = 7;  // brick pieces (1 KiB) per wave
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
+unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+
+__device__ __forceinline__ unsigned short bf16_bits(float f) {
+  const __bf16 v = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, v);
+}
+__device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {  // conv_split.hip split3
+  const float a0 = bf16_val(v);
+  const float r1 = v - a0;
+  const float a1 = bf16_val(r1);
+  const float r2 = r1 - a1;
+  t[0] = bf16_bits(a0); t[1] = bf16_bits(a1); t[2] = bf16_bits(r2);
+}
+
+// Packed weights: [cot = co/64][half = (co/32)%2][k-step s][f = rb*3 + term][lane][8] bf16.  Lane l = (g = l/16, m = l%16) holds
+// output channel cot*64 + half*32 + rb*16 + m at tap T = 4s + g of the tile's tap stream: brick T / KS^2 = chunk*KS + dz,
+// in-plane tap T % KS^2; element j = input channel chunk*8 + (g odd ? (j + 4) % 8 : j)  (the B fragment of an odd lane
+// group is read upper half first).
+// fwd:   w[co][ci][tap]                   (so = C*T3, si = T3, flip = 0)
+// dgrad: w[co as "ci"][ci as "co"][T3-1-tap]  (so = T3, si = C*T3, flip = 1)
+__global__ void __launch_bounds__(256) k_pack_w_s3x(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH, int KS, int NS,
+                                                    long so, long si, int flip, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int T2 = KS * KS, T3 = T2 * KS, NB = NCH * KS;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int lane = (int)(q & 63); q >>= 6;
+  const int f = (int)(q % 6); q /= 6;
+  const int s = (int)(q % NS); q /= NS;
+  const int half = (int)(q & 1);
+  const int cot = (int)(q >> 1);
+  const int rb = f / 3, term = f % 3;
+  const int g = lane >> 4, m = lane & 15;
+  const int T = 4 * s + g;
+  const int bi = T / T2, tp = T % T2;
+  unsigned short t[3] = {0, 0, 0};
+  if (bi < NB) {
+    const int chunk = bi / KS, dz = bi % KS;
+    const int jj = (g & 1) ? ((j + 4) & 7) : j;
+    const long co = cot * 64 + half * 32 + rb * 16 + m, ci = chunk * 8 + jj;
+    const int tap = dz * T2 + tp;
+    split3(w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)], t);
+  }
+  wp[i] = t[term];
+}
+
+struct XParams {
+  const uint4* xs;     // S3 input [N][C/8][3][D][H][W] units
+  const uint4* wp;     // packed weights
+  const float* bias;   // nullable
+  float* y;            // fp32 NCDHW output
+  int N, NCH, D, H, W, K;
+  int P;               // row pitch of the padded plane, W + KS - 1
+  int HP;              // H * P: flattened output positions of a plane (pad columns included)
+  int TPP, KT;         // main-tiling tiles per plane, K / 64
+  int fsub;            // this launch's tiles are 1 / fsub of a main tile (tile index = main index * fsub + sub)
+  int UB;              // units per term of a brick (multiple of 64)
+  int npb;             // 1 KiB pieces per brick (three terms)
+  int NS;              // k-steps per tile
+  unsigned mP, mUB;
+  int t_begin, t_count;  // first main tile and number of (sub-)tiles of this launch
+  int tiles_per_xcd;
+  int flush;           // k-steps between two accumulator restarts
+};
+
+struct XTile {
+  int n, cot, z, q0;
+};
+
+template <int PT>
+__device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
+  int t = p.t_begin + idx / p.fsub;
+  const int sub = idx % p.fsub;
+  XTile o;  // output-channel tile fastest, then z: neighbouring planes share input planes in L2
+  o.cot = t % p.KT; t /= p.KT;
+  o.z = t % p.D; t /= p.D;
+  const int tp = t % p.TPP;
+  o.n = t / p.TPP;
+  o.q0 = (tp * p.fsub + sub) * PT;
+  return o;
+}
+
+template <int KS, int NCB>
+__global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int PAD = KS / 2, T2 = KS * KS, PT = 64 * NCB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, g = lane >> 4;
+  const int half = wave & 1, pg = wave >> 1;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int NB = p.NCH * KS;     // bricks per tile
+  const int BB = p.npb * 1024;   // bytes per ring slot
+
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int t_lo = xcd * p.tiles_per_xcd;
+  int t_hi = t_lo + p.tiles_per_xcd;
+  if (t_hi > p.t_count) t_hi = p.t_count;
+  // the (sub-)tiles of this workgroup: t_lo + wslot, + nslot, ...; sub-tiles that start beyond the plane are empty
+  auto next_tile = [&](int t, XTile& o) {
+    for (; t < t_hi; t += nslot) {
+      o = x_decode<PT>(p, t);
+      if (o.q0 < p.HP) return t;
+    }
+    return -1;
+  };
+  XTile cur, nxt;
+  int tcur = next_tile(t_lo + wslot, cur);
+  if (tcur < 0) return;
+
+  // ---- brick staging: unit u of a term = padded flat position q0 + u -> (row, column) of the padded plane.  The DMA goes
+  // through a buffer descriptor over the three terms of ONE 8-channel block: a lane whose unit is padding asks for an offset
+  // beyond the descriptor's range and the hardware delivers zeros (no zero page, no 64-bit address arithmetic per lane)
+  constexpr unsigned kOut = 0x80000000u;
+  unsigned off[kMaxJ];  // per-lane byte offset of piece wave + 8j inside the block, relative to plane 0 -- or kOut
+  auto decode_pieces = [&](const XTile& t) {
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) {
+      const unsigned u = (unsigned)((wave + kWaves * j) * 64 + lane);
+      const unsigned term = fdiv(u, p.mUB);
+      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
+      const unsigned rr = fdiv(F, p.mP);
+      const int xx = (int)(F - rr * p.P) - PAD;
+      const int yy = (int)rr - PAD;
+      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      off[j] = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+    }
+  };
+  auto issue_brick = [&](const XTile& t, int bi, int slot) {
+    const int chunk = bi / KS, dz = bi - chunk * KS;
+    const int zz = t.z + dz - PAD;
+    const bool zok = (unsigned)zz < (unsigned)p.D;
+    const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * 3 * S;
+    // a plane outside the volume: an empty descriptor, every lane reads zeros
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(3 * S * 16) : 0u, 0x00020000);
+    const int soff = zok ? (int)(zz * HW * 16) : 0;
+    unsigned char* buf = lds_raw + slot * BB;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) {
+      const int pc = wave + kWaves * j;
+      if (pc < p.npb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, off[j], soff, 0, 0);
+    }
+  };
+
+  // ---- weights: A fragments through a buffer descriptor, scalar offset per (tile, k-step, fragment).  The loads are inline
+  // assembly on purpose: the compiler's own vmcnt bookkeeping merges the paths with and without a brick request conservatively
+  // and would wait for freshly issued LDS-DMA in front of every k-step; here every wait is placed by hand (wait_a, arrival).
+  u32x4 wrsrc;
+  {
+    const unsigned long long wa = (unsigned long long)p.wp;
+    wrsrc.x = __builtin_amdgcn_readfirstlane((unsigned)wa);
+    wrsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+    wrsrc.z = 0x7fffffffu;
+    wrsrc.w = 0x00020000u;
+  }
+  const int wvoff = lane * 16;
+  auto wtile = [&](int cot) { return ((cot * 2 + half) * p.NS) * (6 * 1024); };
+  auto load_a = [&](u32x4 (&A)[2][3], int soff) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(soff + (rb * 3 + t) * 1024) : "memory");
+  };
+  // all vector-memory operations but this wave's 6 youngest (the A fragments requested last) are complete: A is ready
+  auto wait_a = [&](u32x4 (&A)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  };
+
+  // ---- B fragments: unit (slot, term, position + tap) of the ring, read as two 8-byte halves (odd lane groups: upper first)
+  const unsigned lane_b = (unsigned)(((pg * NCB * 16 + m16) * 16) + (g & 1) * 8);
+  const unsigned term_b = (unsigned)p.UB * 16;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)lds_raw;
+  struct BAddr { unsigned lo[3], hi[3]; };  // per term: address of the half read first / second (column block 0)
+  auto b_addr = [&](unsigned vo) {
+    BAddr a;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { a.lo[t] = lds_base + vo + t * term_b; a.hi[t] = a.lo[t] ^ 8u; }
+    return a;
+  };
+  auto read_b = [&](u32x4 (&B)[3], const BAddr& a, int cb) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      u64x2 v;
+      v.x = *(lds64_t)(a.lo[t] + cb * 256);  // volatile: two ds_read_b64, never one ds_read2_b64
+      v.y = *(lds64_t)(a.hi[t] + cb * 256);
+      B[t] = __builtin_bit_cast(u32x4, v);
+    }
+  };
+
+  // ---- prologue: brick 0 of the first tile
+  decode_pieces(cur);
+  int ring = 0;  // ring slot of brick 0 of the current tile
+  issue_brick(cur, 0, 0);
+
+  while (true) {
+    XTile nx{};
+    const int tnext = next_tile(tcur + nslot, nx);
+    const bool more_tiles = tnext >= 0;
+    nxt = nx;
+
+    f32x4 acc[2][NCB], tot[2][NCB];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[rb][cb][e] = 0.f; tot[rb][cb][e] = 0.f; }
+
+    const int wt = wtile(cur.cot);
+    u32x4 A[2][3], nA[2][3];
+    load_a(A, wt);
+    int na = 0;  // next brick of this tile to arrive (brick 0 was requested during the previous tile / in the prologue)
+
+    // per-lane tap state: lane group g is at tap tpl of the brick in slot sl
+    int tpl = g, sl = ring;
+    auto b_off = [&]() {
+      const int dy = KS == 3 ? (tpl * 11) >> 5 : (tpl * 13) >> 6;
+      const int dx = tpl - dy * KS;
+      return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
+    };
+    BAddr vo = b_addr(b_off());
+    u32x4 B[2][3];
+    int since = 0;
+
+    // One k-step.  Ac = this step's A fragments (requested one step ago), An receives the next step's.  Order of the vector-memory
+    // operations of a wave: [A of step s + 1] then, when a brick arrives, [its successor's DMA pieces] -- so "all but the 6
+    // youngest complete" at the top of a step covers this step's A fragments AND every DMA piece requested before this step.
+    auto kstep = [&](int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
+      const bool last = s + 1 == p.NS;
+      load_a(An, last ? wt : wt + (s + 1) * (6 * 1024));  // (last step: a dummy request keeps the count at 6)
+      wait_a(Ac);
+      // brick `na` is first used by k-step s + 1 (brick 0: by step 0): it is complete in LDS for THIS wave's pieces; the barrier
+      // makes that true for everybody's, and says everybody is done with brick na - 2 (last tap consumed in k-step s - 1 at the
+      // latest, KS^2 > 6), whose slot the brick after `na` is requested into
+      if (na < NB && 4 * s + 7 >= T2 * na) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (na + 1 < NB) {
+          issue_brick(cur, na + 1, (ring + na + 1) % 3);
+        } else if (more_tiles) {
+          decode_pieces(nxt);
+          issue_brick(nxt, 0, (ring + NB) % 3);
+        }
+        ++na;
+      }
+      if (s == 0) read_b(B[0], vo, 0);
+      // next k-step's tap state
+      tpl += 4;
+      if (tpl >= T2) { tpl -= T2; sl = sl == 2 ? 0 : sl + 1; }
+      const BAddr nvo = b_addr(b_off());
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        u32x4(&Bc)[3] = B[cb & 1];
+        u32x4(&Bn)[3] = B[(cb + 1) & 1];
+        if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
+        else if (!last) read_b(Bn, nvo, 0);
+        // six products per (row block, column block), smallest first: (term of A, term of B)
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ac[rb][TA[m]]), __builtin_bit_cast(bf16x8, Bc[TB[m]]),
+                                                                  acc[rb][cb], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {  // the 6 reads of the next column block spread over this one's 12 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+      vo = nvo;
+      if (++since == p.flush) {
+        since = 0;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tot[rb][cb][e] += acc[rb][cb][e]; acc[rb][cb][e] = 0.f; }
+      }
+    };
+#pragma unroll 1
+    for (int s = 0; s < p.NS; s += 2) {
+      kstep(s, A, nA);
+      if (s + 1 < p.NS) kstep(s + 1, nA, A);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy request of the last step
+
+    // ---- epilogue: accumulator element e of (rb, cb) = output channel cot*64 + half*32 + rb*16 + 4g + e at position cb*16 + m16
+    {
+      const int cob = cur.cot * 64 + half * 32 + 4 * g;
+      float* yn = p.y + ((long)cur.n * p.K + cob) * S + (long)cur.z * HW;
+      float bv[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[rb][e] = p.bias ? p.bias[cob + rb * 16 + e] : 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const unsigned f = (unsigned)(cur.q0 + pg * NCB * 16 + cb * 16 + m16);
+        const unsigned yy = fdiv(f, p.mP);
+        const unsigned xx = f - yy * p.P;
+        if ((int)yy < p.H && (int)xx < p.W) {
+          float* yv = yn + (long)yy * p.W + xx;
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[(long)(rb * 16 + e) * S] = (tot[rb][cb][e] + acc[rb][cb][e]) + bv[rb][e];
+        }
+      }
+    }
+    if (!more_tiles) break;
+    ring = (ring + NB) % 3;
+    cur = nxt;
+    tcur = tnext;
+  }
+}
+
+struct XPlan {
+  int NCB, fsub, P, HP, TPP, UB, npb, lds;
+  int UBt, npbt, ldst;  // the tail launch's brick (PT / fsub positions)
+  long full, rem;       // main tiles in whole rounds of 256 / left over
+  bool ok;
+};
+
+bool x_brick(int PT, int P, int KS, int& UB, int& npb, int& lds) {
+  const int U = PT + (KS - 1) * (P + 1);
+  UB = (U + 63) / 64 * 64;
+  npb = 3 * UB / 64;
+  lds = 3 * npb * 1024;
+  return npb <= 8 * kMaxJ && lds <= kLdsMax;
+}
+
+int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round of whole tiles (A/B)
+  static const int m = getenv("NC_S3X_TAIL") ? atoi(getenv("NC_S3X_TAIL")) : 1;
+  return m;
+}
+
+XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
+  XPlan best{};
+  double best_cost = 1e30;
+  const int P = W + KS - 1;
+  const long HP = (long)H * P;
+  for (int NCB : {6, 4, 2}) {
+    XPlan pl{};
+    pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
+    const int PT = 64 * NCB;
+    if (!x_brick(PT, P, KS, pl.UB, pl.npb, pl.lds)) continue;
+    pl.TPP = (int)((HP + PT - 1) / PT);
+    const long ntiles = (long)N * D * pl.TPP * KT;
+    pl.full = ntiles / 256 * 256;
+    pl.rem = ntiles - pl.full;
+    // time in units of "positions per workgroup"; a tile costs its positions plus a fixed part (prologue, epilogue, halo)
+    const double fixed = 56;
+    double cost = (double)(pl.full / 256) * (PT + fixed);
+    pl.fsub = 1;
+    if (pl.rem) {
+      int f = 1;  // the left-over tiles in thirds (6 -> 2 column blocks per wave) or halves (4 -> 2) when they then fit one round
+      if (x_tail_mode() && NCB > 2 && pl.rem * (NCB / 2) <= 256) f = NCB / 2;
+      pl.fsub = f;
+      cost += PT / f + fixed;
+    }
+    if (!x_brick(PT / pl.fsub, P, KS, pl.UBt, pl.npbt, pl.ldst)) continue;
+    if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
+  }
+  return best;
+}
+
+template <int KS, int NCB>
+int launch_x(const XParams& p, int lds, hipStream_t s) {
+  auto kern = k_conv_s3x<KS, NCB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+      set_error("conv_s3x: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
+  return check_launch("conv_s3x");
+}
+
+template <int KS>
+int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
+  if (NCB == 6) return launch_x<KS, 6>(p, lds, s);
+  if (NCB == 4) return launch_x<KS, 4>(p, lds, s);
+  return launch_x<KS, 2>(p, lds, s);
+}
+
+}  // namespace
+
+size_t s3x_packed_bytes(int Cin, int Kout, int KS) {
+  const int NS = KS * KS * KS * (Cin / 8) / 4;
+  return (size_t)(Kout / 64) * 2 * NS * 6 * 1024;
+}
+
+bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
+  if (KS != 3 && KS != 5) return false;
+  if (Cin % 32 || Kout % 64) return false;  // whole k-steps: (Cin / 8) * KS^3 taps in fours
+  if ((long)D * H * W * 48 >= (1l << 31)) return false;  // byte offsets inside one block's three terms stay below the kOut mark
+  if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
+  return x_plan(N, D, H, W, Kout / 64, KS).ok;
+}
+
+// xs: S3 input; wp_ws: >= s3x_packed_bytes scratch for the packed weights
+int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
+             long si, int flip, void* wp_ws, hipStream_t s) {
+  const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS);
+  if (!pl.ok) { set_error("conv_s3x: shape not covered"); return NC_ERR_SHAPE; }
+  const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4;
+  const long total = (long)(s3x_packed_bytes(Cin, Kout, KS) / 2);
+  hipLaunchKernelGGL(k_pack_w_s3x, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip,
+                     total);
+  if (int e = check_launch("pack_w_s3x")) return e;
+  XParams p{};
+  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y;
+  p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.NS = NS; p.mP = magic(pl.P);
+  static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 2;
+  p.flush = flush > 0 ? flush : 1 << 30;
+  if (pl.full) {
+    p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
+    p.t_begin = 0; p.t_count = (int)pl.full; p.tiles_per_xcd = (int)cdiv(pl.full, 8);
+    const int e = KS == 3 ? launch_x_ncb<3>(pl.NCB, p, pl.lds, s) : launch_x_ncb<5>(pl.NCB, p, pl.lds, s);
+    if (e) return e;
+  }
+  if (pl.rem) {
+    p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
+    p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    const int e = KS == 3 ? launch_x_ncb<3>(pl.NCB / pl.fsub, p, pl.ldst, s) : launch_x_ncb<5>(pl.NCB / pl.fsub, p, pl.ldst, s);
+    if (e) return e;
+  }
+  return NC_OK;
+}
+
+}  // namespace nc

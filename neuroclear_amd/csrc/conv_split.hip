@@ -522,6 +522,10 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
                        (long)Cin * S);
     if (int e = check_launch("split3")) return e;
   }
+  // the tap-stream kernel (conv_s3x.hip: 16x16x32 MFMAs, no zero tap) takes every shape it covers; NC_S3X=0: the pair kernel below
+  static const int use_x = getenv("NC_S3X") ? atoi(getenv("NC_S3X")) : 1;
+  if (use_x && s3x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS) && s3x_packed_bytes(Cin, Kout, KS) <= wb)
+    return conv_s3x(xs, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, wp, s);
   const long total = (long)(s_packed_bytes(Cin, Kout, KS) / 2);
   hipLaunchKernelGGL(k_pack_w_s3, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, Cin / 8, KS, so, si, flip, total);
   if (int e = check_launch("pack_w_s3")) return e;
