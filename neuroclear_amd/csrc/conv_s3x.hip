@@ -22,6 +22,7 @@
 //    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,592 tiles at 108^3 cost 10.3 rounds instead of 11.
 // Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -107,6 +108,7 @@ struct XParams {
   int t_begin, t_count;  // first main tile and number of (sub-)tiles of this launch
   int tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
+  long long* dbg;      // NC_S3X_STAMP builds: s_memtime stamps of workgroup 0 / wave 0 (timing experiments only)
 };
 
 struct XTile {
@@ -123,6 +125,9 @@ __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   const int tp = t % p.TPP;
   o.n = t / p.TPP;
   o.q0 = (tp * p.fsub + sub) * PT;
+  // wave-uniform by construction; said explicitly so that descriptors and scalar offsets built from them stay in SGPRs
+  o.cot = __builtin_amdgcn_readfirstlane(o.cot); o.z = __builtin_amdgcn_readfirstlane(o.z);
+  o.n = __builtin_amdgcn_readfirstlane(o.n); o.q0 = __builtin_amdgcn_readfirstlane(o.q0);
   return o;
 }
 
@@ -206,11 +211,17 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(soff + (rb * 3 + t) * 1024) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"
+                     : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * 3 + t) * 1024) : "memory");
   };
-  // all vector-memory operations but this wave's 6 youngest (the A fragments requested last) are complete: A is ready
-  auto wait_a = [&](u32x4 (&A)[2][3]) {
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  // All vector-memory operations of this wave but its 6 youngest (the A fragments requested last) are complete -- `stored`: but
+  // the 6 and the 2 * NCB stores of the previous tile issued by the step before.  The count is chosen by a scalar branch around
+  // bare s_waitcnt instructions; ONE statement behind the branch ties the fragment registers to the wait (a tie inside either arm
+  // makes the compiler copy the still-in-flight registers in front of the wait).
+  auto wait_a = [&](u32x4 (&A)[2][3], bool stored) {
+    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NCB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
   };
 
   // ---- B fragments: unit (slot, term, position + tap) of the ring, read as two 8-byte halves (odd lane groups: upper first)
@@ -234,28 +245,91 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     }
   };
 
-  // ---- prologue: brick 0 of the first tile
+  // ---- results leave through a buffer descriptor over one sample's output: a lane whose position is a pad column or lies
+  // beyond the plane stores to an out-of-range offset, which the hardware drops -- the NUMBER of store instructions is fixed,
+  // and the hand-placed vmcnt waits below can count them.
+  // The stores of tile t are issued inside the first kStoreSteps k-steps of tile t + 1 (the finished sums wait in `tot`, which
+  // the new tile does not touch before its first accumulator restart): the write burst of 256 workgroups finishing together and
+  // its drain (vmcnt is in-order: any later wait for a load also waits for older stores) cost ~20 us per tile when the epilogue
+  // stood between two tiles.
+  constexpr int kStoreSteps = 4;
+  constexpr int kPairs = 2 * NCB;                      // (row block, column block) pairs, four stores each
+  constexpr int kPairsPerStep = (kPairs + kStoreSteps - 1) / kStoreSteps;
+  static_assert(kPairs % kStoreSteps == 0, "store pairs per step must be whole");
+  f32x4 acc[2][NCB], tot[2][NCB];
+  // bias of the tile whose sums wait in `tot`: requested in that tile's last k-step by the same hand-counted kind of load as the
+  // weights (an empty descriptor when there is no bias: zeros), complete at the wait of the next step
+  u32x4 brsrc;
+  {
+    const unsigned long long ba = (unsigned long long)p.bias;
+    brsrc.x = __builtin_amdgcn_readfirstlane((unsigned)ba);
+    brsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu);
+    brsrc.z = p.bias ? (unsigned)p.K * 4u : 0u;
+    brsrc.w = 0x00020000u;
+  }
+  u32x4 bv[2];
+  auto load_bias = [&](const XTile& t) {
+    const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bv[rb]) : "v"(bo + rb * 64), "s"(brsrc) : "memory");
+  };
+  auto store_pairs = [&](const XTile& t, const int p0, const int p1) {  // pairs p0 .. p1 - 1 of tile t from `tot`, then tot = 0
+    const int cob = t.cot * 64 + half * 32 + 4 * g;
+    const __amdgpu_buffer_rsrc_t ys =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + (long)t.n * p.K * S, 0, (unsigned)((long)p.K * S * 4), 0x00020000);
+#pragma unroll
+    for (int pr = 0; pr < kPairs; ++pr) {
+      if (pr < p0 || pr >= p1) continue;
+      const int rb = pr / NCB, cb = pr % NCB;
+      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);
+      const unsigned yy = fdiv(f, p.mP);
+      const unsigned xx = f - yy * p.P;
+      const bool ok = (int)yy < p.H && (int)xx < p.W;
+      const unsigned vo0 = ok ? (unsigned)(((long)(cob + rb * 16) * S + (long)t.z * HW + yy * p.W + xx) * 4) : kOut;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
+        const float v = tot[rb][cb][e] + __uint_as_float(bu);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * S * 4) : kOut, 0, 0);
+        tot[rb][cb][e] = 0.f;
+      }
+    }
+  };
+
+#ifdef NC_S3X_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(NC_S3X_PRIO);  // (experiment: static priority for the younger half)
+#endif
+  // ---- prologue: brick 0 and the first A fragments of the first tile
   decode_pieces(cur);
   int ring = 0;  // ring slot of brick 0 of the current tile
   issue_brick(cur, 0, 0);
+  u32x4 A[2][3], nA[2][3];
+  load_a(A, wtile(cur.cot));
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[rb][cb][e] = 0.f; tot[rb][cb][e] = 0.f; }
+  bool have_prev = false;
+  XTile prv = cur;
 
+#ifdef NC_S3X_STAMP
+  if (p.dbg && tid == 0) p.dbg[4000 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();  // per-workgroup start / end, 100 MHz
+  int nstamp = 0;
+#define STAMP() do { if (p.dbg && blockIdx.x == 0 && tid == 0 && nstamp < 4000) p.dbg[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
   while (true) {
+    STAMP();
     XTile nx{};
     const int tnext = next_tile(tcur + nslot, nx);
     const bool more_tiles = tnext >= 0;
     nxt = nx;
-
-    f32x4 acc[2][NCB], tot[2][NCB];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[rb][cb][e] = 0.f; tot[rb][cb][e] = 0.f; }
-
     const int wt = wtile(cur.cot);
-    u32x4 A[2][3], nA[2][3];
-    load_a(A, wt);
+    const int wt_next = more_tiles ? wtile(nxt.cot) : wt;
     int na = 0;  // next brick of this tile to arrive (brick 0 was requested during the previous tile / in the prologue)
 
     // per-lane tap state: lane group g is at tap tpl of the brick in slot sl
@@ -269,18 +343,25 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     u32x4 B[2][3];
     int since = 0;
 
-    // One k-step.  Ac = this step's A fragments (requested one step ago), An receives the next step's.  Order of the vector-memory
-    // operations of a wave: [A of step s + 1] then, when a brick arrives, [its successor's DMA pieces] -- so "all but the 6
-    // youngest complete" at the top of a step covers this step's A fragments AND every DMA piece requested before this step.
-    auto kstep = [&](int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
-      const bool last = s + 1 == p.NS;
-      load_a(An, last ? wt : wt + (s + 1) * (6 * 1024));  // (last step: a dummy request keeps the count at 6)
-      wait_a(Ac);
+    // One k-step.  Ac = this step's A fragments (requested one step ago; step 0: during the last step of the previous tile), An
+    // receives the next step's.  Order of a wave's vector-memory operations in a step: [A of step s + 1], then, when a brick
+    // arrives, [its successor's DMA pieces], then [the previous tile's stores of this step].  "All but the 6 youngest complete"
+    // at the top of a step therefore covers this step's A fragments and every DMA piece requested before this step; behind a
+    // step that stored, the count is 6 + its stores.
+    // `ph` (compile time): the step number for the first kStoreSteps steps of a tile, which carry the previous tile's stores; kStoreSteps
+    // for every later step
+    auto kstep = [&](auto ph, int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
+      constexpr int PH = decltype(ph)::value;
+      const bool last = PH == kStoreSteps && s + 1 == p.NS;
+      load_a(An, last ? wt_next : wt + (s + 1) * (6 * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
+      wait_a(Ac, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));  // (the step before this one stored)
       // brick `na` is first used by k-step s + 1 (brick 0: by step 0): it is complete in LDS for THIS wave's pieces; the barrier
       // makes that true for everybody's, and says everybody is done with brick na - 2 (last tap consumed in k-step s - 1 at the
       // latest, KS^2 > 6), whose slot the brick after `na` is requested into
       if (na < NB && 4 * s + 7 >= T2 * na) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (tried: waves 4 .. 7 -- the SIMD partners of waves 0 .. 3 -- issuing their DMA pieces one k-step later, so that the two
+        // partners are not away from the matrix pipe at the same moment: 1.5-2 % slower)
         if (na + 1 < NB) {
           issue_brick(cur, na + 1, (ring + na + 1) % 3);
         } else if (more_tiles) {
@@ -289,7 +370,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         }
         ++na;
       }
-      if (s == 0) read_b(B[0], vo, 0);
+      if (last) load_bias(cur);  // (complete at the next step's wait: it is older than that step's 6 A requests)
+      if constexpr (PH < kStoreSteps) {
+        if (have_prev) {
+          asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
+          store_pairs(prv, PH * kPairsPerStep, (PH + 1) * kPairsPerStep);
+        }
+      }
+      if constexpr (PH == 0) read_b(B[0], vo, 0);
       // next k-step's tap state
       tpl += 4;
       if (tpl >= T2) { tpl -= T2; sl = sl == 2 ? 0 : sl + 1; }
@@ -316,7 +404,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         }
       }
       vo = nvo;
-      if (++since == p.flush) {
+      if (++since == p.flush || last) {
         since = 0;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -326,41 +414,35 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
             for (int e = 0; e < 4; ++e) { tot[rb][cb][e] += acc[rb][cb][e]; acc[rb][cb][e] = 0.f; }
       }
     };
+    static_assert(kStoreSteps == 4, "the four peeled steps below");
+    STAMP();
+    kstep(std::integral_constant<int, 0>{}, 0, A, nA);
+    STAMP();
+    kstep(std::integral_constant<int, 1>{}, 1, nA, A);
+    STAMP();
+    kstep(std::integral_constant<int, 2>{}, 2, A, nA);
+    STAMP();
+    kstep(std::integral_constant<int, 3>{}, 3, nA, A);
+    STAMP();
 #pragma unroll 1
-    for (int s = 0; s < p.NS; s += 2) {
-      kstep(s, A, nA);
-      if (s + 1 < p.NS) kstep(s + 1, nA, A);
+    for (int s = 4; s < p.NS; s += 2) {  // NS is even: step 0 of the next tile finds its fragments in A again
+      kstep(std::integral_constant<int, 4>{}, s, A, nA);
+      kstep(std::integral_constant<int, 4>{}, s + 1, nA, A);
+      STAMP();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy request of the last step
-
-    // ---- epilogue: accumulator element e of (rb, cb) = output channel cot*64 + half*32 + rb*16 + 4g + e at position cb*16 + m16
-    {
-      const int cob = cur.cot * 64 + half * 32 + 4 * g;
-      float* yn = p.y + ((long)cur.n * p.K + cob) * S + (long)cur.z * HW;
-      float bv[2][4];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[rb][e] = p.bias ? p.bias[cob + rb * 16 + e] : 0.f;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const unsigned f = (unsigned)(cur.q0 + pg * NCB * 16 + cb * 16 + m16);
-        const unsigned yy = fdiv(f, p.mP);
-        const unsigned xx = f - yy * p.P;
-        if ((int)yy < p.H && (int)xx < p.W) {
-          float* yv = yn + (long)yy * p.W + xx;
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) yv[(long)(rb * 16 + e) * S] = (tot[rb][cb][e] + acc[rb][cb][e]) + bv[rb][e];
-        }
-      }
-    }
+    prv = cur;
+    have_prev = true;
     if (!more_tiles) break;
     ring = (ring + NB) % 3;
     cur = nxt;
     tcur = tnext;
   }
+  // the last tile's results (and the dummy request of its last step)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1])::"memory");
+  store_pairs(prv, 0, kPairs);
+#ifdef NC_S3X_STAMP
+  if (p.dbg && tid == 0) p.dbg[4001 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 struct XPlan {
@@ -444,7 +526,8 @@ size_t s3x_packed_bytes(int Cin, int Kout, int KS) {
 
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if (KS != 3 && KS != 5) return false;
-  if (Cin % 32 || Kout % 64) return false;  // whole k-steps: (Cin / 8) * KS^3 taps in fours
+  if (Cin % 64 || Kout % 64) return false;  // an even number of whole k-steps: (Cin / 8) * KS^3 taps in fours
+  if ((long)Kout * D * H * W * 4 >= (1l << 31)) return false;  // byte offsets inside one sample's output
   if ((long)D * H * W * 48 >= (1l << 31)) return false;  // byte offsets inside one block's three terms stay below the kOut mark
   if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
   return x_plan(N, D, H, W, Kout / 64, KS).ok;
@@ -465,8 +548,11 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
   p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.NS = NS; p.mP = magic(pl.P);
-  static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 2;
-  p.flush = flush > 0 ? flush : 1 << 30;
+#ifdef NC_S3X_STAMP
+  p.dbg = (long long*)((char*)wp_ws + s3x_packed_bytes(Cin, Kout, KS));  // (the workspace has slack behind the packed weights in the timing tool)
+#endif
+  static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 4;
+  p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;  // >= 4: the previous tile's sums leave `tot` during the first four k-steps
   if (pl.full) {
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
     p.t_begin = 0; p.t_count = (int)pl.full; p.tiles_per_xcd = (int)cdiv(pl.full, 8);
