@@ -40,7 +40,14 @@ typedef const volatile __attribute__((address_space(3))) unsigned long long* lds
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kLdsMax = 160 * 1024;
-constexpr int kMaxJ = 7;  // brick pieces (1 KiB) per wave
+#ifndef NC_S3X_DMAW
+#define NC_S3X_DMAW 4
+#endif
+// Waves that issue the LDS-DMA pieces of a brick: the first kDmaWaves of the 8.  4 = one wave of each SIMD pair (waves w and w + 4
+// share a SIMD): issuing ~10 pieces keeps a wave away from the matrix pipe for ~1,000 cycles, which its partner -- with no pieces of
+// its own -- fills with MFMAs; with all 8 issuing, both partners are away at the same moment right behind the barrier.
+constexpr int kDmaWaves = NC_S3X_DMAW;
+constexpr int kMaxPieces = 56;  // 1 KiB pieces of a brick (three terms)
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
 unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
@@ -51,7 +58,10 @@ __device__ __forceinline__ unsigned short bf16_bits(float f) {
 }
 __device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
 __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {  // conv_split.hip split3
-  const float a0 = bf16_val(v);
+  float a0 = bf16_val(v);
+  // a finite |v| above the largest finite bf16 (0x7F7F = 3.3895e38) rounds to infinity: take that largest bf16 instead, the remainders
+  // carry the rest exactly.  v = +-inf / NaN: a0 = v and the remainders are NaN -- a non-finite input gives NaN in every output it touches
+  if (__builtin_isinf(a0) && !__builtin_isinf(v)) a0 = __builtin_copysignf(3.3895313892515355e38f, v);
   const float r1 = v - a0;
   const float a1 = bf16_val(r1);
   const float r2 = r1 - a1;
@@ -163,21 +173,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   // through a buffer descriptor over the three terms of ONE 8-channel block: a lane whose unit is padding asks for an offset
   // beyond the descriptor's range and the hardware delivers zeros (no zero page, no 64-bit address arithmetic per lane)
   constexpr unsigned kOut = 0x80000000u;
-  unsigned off[kMaxJ];  // per-lane byte offset of piece wave + 8j inside the block, relative to plane 0 -- or kOut
-  auto decode_pieces = [&](const XTile& t) {
-#pragma unroll
-    for (int j = 0; j < kMaxJ; ++j) {
-      const unsigned u = (unsigned)((wave + kWaves * j) * 64 + lane);
-      const unsigned term = fdiv(u, p.mUB);
-      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
-      const unsigned rr = fdiv(F, p.mP);
-      const int xx = (int)(F - rr * p.P) - PAD;
-      const int yy = (int)rr - PAD;
-      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      off[j] = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
-    }
-  };
   auto issue_brick = [&](const XTile& t, int bi, int slot) {
+    if (wave >= kDmaWaves) return;
     const int chunk = bi / KS, dz = bi - chunk * KS;
     const int zz = t.z + dz - PAD;
     const bool zok = (unsigned)zz < (unsigned)p.D;
@@ -186,10 +183,21 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(3 * S * 16) : 0u, 0x00020000);
     const int soff = zok ? (int)(zz * HW * 16) : 0;
     unsigned char* buf = lds_raw + slot * BB;
-#pragma unroll
-    for (int j = 0; j < kMaxJ; ++j) {
-      const int pc = wave + kWaves * j;
-      if (pc < p.npb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, off[j], soff, 0, 0);
+#pragma unroll 1
+    for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
+      // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms, relative to plane 0), or kOut:
+      // computed at issue time by the issuing waves (~12 vector instructions per piece, in the shadow of the SIMD partner's MFMAs)
+      // rather than kept in registers per tile.  (Written in line: as a lambda called from this lambda it made hipcc drop the
+      // kernel's host-side handle.)
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned term = fdiv(u, p.mUB);
+      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
+      const unsigned rr = fdiv(F, p.mP);
+      const int xx = (int)(F - rr * p.P) - PAD;
+      const int yy = (int)rr - PAD;
+      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, soff, 0, 0);
     }
   };
 
@@ -301,7 +309,6 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   if (wave >= 4) __builtin_amdgcn_s_setprio(NC_S3X_PRIO);  // (experiment: static priority for the younger half)
 #endif
   // ---- prologue: brick 0 and the first A fragments of the first tile
-  decode_pieces(cur);
   int ring = 0;  // ring slot of brick 0 of the current tile
   issue_brick(cur, 0, 0);
   u32x4 A[2][3], nA[2][3];
@@ -365,7 +372,6 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         if (na + 1 < NB) {
           issue_brick(cur, na + 1, (ring + na + 1) % 3);
         } else if (more_tiles) {
-          decode_pieces(nxt);
           issue_brick(nxt, 0, (ring + NB) % 3);
         }
         ++na;
@@ -457,7 +463,7 @@ bool x_brick(int PT, int P, int KS, int& UB, int& npb, int& lds) {
   UB = (U + 63) / 64 * 64;
   npb = 3 * UB / 64;
   lds = 3 * npb * 1024;
-  return npb <= 8 * kMaxJ && lds <= kLdsMax;
+  return npb <= kMaxPieces && lds <= kLdsMax;
 }
 
 int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round of whole tiles (A/B)
@@ -470,7 +476,9 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
   double best_cost = 1e30;
   const int P = W + KS - 1;
   const long HP = (long)H * P;
-  for (int NCB : {6, 4, 2}) {
+  static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
+  for (int NCB : {8, 6, 4, 2}) {
+    if (NCB > ncb_max) continue;
     XPlan pl{};
     pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
     const int PT = 64 * NCB;
@@ -484,8 +492,11 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
     double cost = (double)(pl.full / 256) * (PT + fixed);
     pl.fsub = 1;
     if (pl.rem) {
-      int f = 1;  // the left-over tiles in thirds (6 -> 2 column blocks per wave) or halves (4 -> 2) when they then fit one round
-      if (x_tail_mode() && NCB > 2 && pl.rem * (NCB / 2) <= 256) f = NCB / 2;
+      int f = 1;  // the left-over tiles in quarters / thirds / halves (8, 6, 4 -> 2 or 4 column blocks per wave) when they then fit one round
+      if (x_tail_mode() && NCB > 2) {
+        if (pl.rem * (NCB / 2) <= 256) f = NCB / 2;
+        else if (NCB == 8 && pl.rem * 2 <= 256) f = 2;
+      }
       pl.fsub = f;
       cost += PT / f + fixed;
     }
@@ -512,6 +523,7 @@ int launch_x(const XParams& p, int lds, hipStream_t s) {
 
 template <int KS>
 int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
+  if (NCB == 8) return launch_x<KS, 8>(p, lds, s);
   if (NCB == 6) return launch_x<KS, 6>(p, lds, s);
   if (NCB == 4) return launch_x<KS, 4>(p, lds, s);
   return launch_x<KS, 2>(p, lds, s);

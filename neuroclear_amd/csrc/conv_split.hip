@@ -67,7 +67,10 @@ __device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
 
 // the three terms of an fp32 value (round to nearest each: the remainders are exact, the third term is exact)
 __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {
-  const float a0 = bf16_val(v);
+  float a0 = bf16_val(v);
+  // a finite |v| above the largest finite bf16 (0x7F7F = 3.3895e38) rounds to infinity: take that largest bf16 instead, the remainders
+  // carry the rest exactly.  v = +-inf / NaN: a0 = v and the remainders are NaN -- a non-finite input gives NaN in every output it touches
+  if (__builtin_isinf(a0) && !__builtin_isinf(v)) a0 = __builtin_copysignf(3.3895313892515355e38f, v);
   const float r1 = v - a0;
   const float a1 = bf16_val(r1);
   const float r2 = r1 - a1;
@@ -764,6 +767,213 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
   for (++nflush; nflush < p.NF; ++nflush) write_partial(false);  // slots this workgroup did not need: zeros
 }
 
+// The same weight gradient on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock under it than under 32x32x16, tools/mfma_rate.hip):
+// K-dim = 32 voxels per MFMA, a wave's 32 k x 32 c block is 2 x 2 tiles of 16 x 16.  Lane group g = lane / 16 supplies voxels 8g .. 8g + 7
+// of a k-step for channel lane % 16 of a 16-channel block (two transposing reads of 4 voxels).  Same workgroup shape, LDS images, DMA
+// and partial layout as k_wgrad_s3; the fragment reads of tap j + 1 are issued in front of the MFMAs of tap j (the old loop read a
+// tap's fragments and multiplied them in one breath: matrix pipe busy 0.57-0.61, waves parked a third of the time).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(const i32x4& a, const i32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int KS>
+__global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int PAD = KS / 2, T2 = KS * KS;
+  constexpr int ZR = KS == 3 ? 3 : 1, NS = ZR + 1, NDG = KS / ZR, TW = ZR * T2;
+  constexpr int TG = (TW + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 1, tg = wave >> 1;
+  const int t0 = tg * (TW / 4) + (tg < TW % 4 ? tg : TW % 4);
+  const int ntap = TW / 4 + (tg < TW % 4 ? 1 : 0);
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+
+  const int G = gridDim.x, xcd = blockIdx.x & 7;
+  const int wg = (G >> 3) * xcd + ((G & 7) < xcd ? (G & 7) : xcd) + (blockIdx.x >> 3);
+  const int pair = wg % p.npairs, wi = wg / p.npairs;
+  if (wi >= p.nwp) return;
+  const int dzg = pair % NDG, kc = pair / NDG;
+  const int kt = kc / p.nct, ct = kc % p.nct;
+  const int zsh = dzg * ZR - PAD;
+  const long s_lo = p.steps * wi / p.nwp, s_hi = p.steps * (wi + 1) / p.nwp;
+
+  unsigned char* const xring = lds_raw;
+  unsigned char* const dyb = lds_raw + NS * p.xslot;
+  auto slot_of = [&](int pz) { return ((pz + 16) & (NS - 1)) * p.xslot; };
+
+  auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
+    const bool zok = (unsigned)pz < (unsigned)p.D;
+    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S + (long)(zok ? pz : 0) * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npx; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned sb = fdiv(u, p.mXUp);
+      const unsigned ur = u - sb * p.XUp;
+      const unsigned ty = fdiv(ur, p.mXp);
+      const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
+      const bool ok = zok && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
+    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S + (long)z * HW;
+#pragma unroll 1
+    for (int pc = wave; pc < p.npd; pc += kWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned sb = fdiv(u, p.mPTp);
+      const unsigned rho = u - sb * p.PTp;
+      const unsigned ty = fdiv(rho, p.mTx);
+      const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
+      const bool ok = sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
+      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+    }
+  };
+
+  // transposed-read roles: lane = 16g + 4q + pp: voxel row 8g + 4*s2 + q of the k-step, channels 4pp .. 4pp + 3 of a 16-channel block
+  // (= 8-channel sub-blocks 2*blk + (pp >> 1), byte (pp & 1) * 8 of the unit)
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const unsigned a_term = (unsigned)p.PTp * 16, b_term = (unsigned)p.XUp * 16;
+  unsigned a_lane[2], b_lane[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    a_lane[b] = (unsigned)((((mt * 4 + 2 * b + (pp >> 1)) * 3) * p.PTp) * 16 + (pp & 1) * 8);
+    b_lane[b] = (unsigned)((((2 * b + (pp >> 1)) * 3) * p.XUp) * 16 + (pp & 1) * 8);
+  }
+
+  f32x4 acc[TG][2][2];
+#pragma unroll
+  for (int j = 0; j < TG; ++j)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][a][b][e] = 0.f;
+
+  int tdz[TG], toff[TG];
+#pragma unroll
+  for (int j = 0; j < TG; ++j) {
+    const int t = t0 + j < TW ? t0 + j : TW - 1;
+    const int dz = t / T2, dy = (t / KS) % KS, dx = t % KS;
+    tdz[j] = dz;
+    toff[j] = (dy * p.Xp + dx) * 16;
+  }
+
+  // partial slot f: part[wg][f][tap][k 0..63][c 0..31]; accumulator element e of (rb, cb) = k mt*32 + rb*16 + 4g + e, c cb*16 + lane%16
+  int nflush = 0, since = 0;
+  auto write_partial = [&](bool live) {
+    float* pw = p.part + ((long)wg * p.NF + nflush) * TW * 64 * 32;
+    const int m16 = lane & 15;
+#pragma unroll
+    for (int j = 0; j < TG; ++j)
+      if (j < ntap) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + a * 16 + 4 * g) * 32 + b * 16 + m16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              pt[e * 32] = live ? acc[j][a][b][e] : 0.f;
+              acc[j][a][b][e] = 0.f;
+            }
+          }
+      }
+  };
+
+  long step = s_lo;
+  bool fresh = true;
+  int n = 0, y0 = 0, x0 = 0, z = 0;
+  while (step < s_hi) {
+    if (fresh) {
+      long j = step;
+      z = (int)(j % p.D); j /= p.D;
+      const int xb = (int)(j % p.XB); j /= p.XB;
+      const int yb = (int)(j % p.YB);
+      n = (int)(j / p.YB);
+      y0 = yb * p.Ty; x0 = xb * p.Tx;
+      __syncthreads();
+#pragma unroll
+      for (int l = 0; l < ZR; ++l) issue_x(n, y0, x0, z + zsh + l, xring + slot_of(z + zsh + l));
+      issue_dy(n, y0, x0, z, dyb + (z & 1) * p.dybuf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      fresh = false;
+    }
+    const bool cont = z + 1 < p.D && step + 1 < s_hi;
+    if (cont) {
+      issue_x(n, y0, x0, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
+      issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
+    }
+    if (since == p.F && nflush + 1 < p.NF) {
+      write_partial(true);
+      ++nflush;
+      since = 0;
+    }
+    ++since;
+    // ---- multiply: NK k-steps of 32 voxels x ntap taps x (2 x 2 tiles) x 6 term products
+    const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf);
+    unsigned sb[TG];
+#pragma unroll
+    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(slot_of(z + zsh + tdz[j]) + toff[j]);
+#pragma unroll 1
+    for (int s = 0; s < p.NK; ++s) {
+      unsigned rho[2], bo[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        rho[s2] = (unsigned)(32 * s + 8 * g + 4 * s2 + q);
+        const unsigned rc = rho[s2] < (unsigned)p.PT ? rho[s2] : (unsigned)p.PT - 1;  // padded positions: dY = 0, X any finite
+        const unsigned ty = fdiv(rc, p.mTx);
+        bo[s2] = (ty * p.Xp + (rc - ty * p.Tx)) * 16;
+      }
+      i32x4 A[2][3];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          A[a][t] = tr_frag(lds_raw, abase + a_lane[a] + t * a_term + rho[0] * 16, abase + a_lane[a] + t * a_term + rho[1] * 16);
+      // units u = (tap j, 16-channel block b of c): the three terms of unit u + 1 are read in front of the 12 MFMAs of unit u
+      i32x4 B[2][3];
+      auto read_b = [&](i32x4 (&Bf)[3], int j, int b) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) Bf[t] = tr_frag(lds_raw, sb[j] + b_lane[b] + t * b_term + bo[0], sb[j] + b_lane[b] + t * b_term + bo[1]);
+      };
+      read_b(B[0], 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2 * TG; ++u) {
+        const int j = u >> 1, b = u & 1;
+        if (j < ntap) {
+          if (u + 1 < 2 * TG) {
+            if (((u + 1) >> 1) < ntap) read_b(B[(u + 1) & 1], (u + 1) >> 1, (u + 1) & 1);
+          }
+          constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int m = 0; m < 6; ++m)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[j][a][b] = mfma16(A[a][TA[m]], B[u & 1][TB[m]], acc[j][a][b]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {  // the 6 reads of the next unit spread over this unit's 12 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++step;
+    if (cont) ++z; else fresh = true;
+  }
+
+  write_partial(nflush < p.NF);
+  for (++nflush; nflush < p.NF; ++nflush) write_partial(false);
+}
+
 // dw[k][c][tap] = sum over the nwp workgroups of pair (k/64, c/32, tap / TW), in workgroup order
 __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict__ part, float* __restrict__ dw, int C, int T3, int TW,
                                                          int nct, int npairs, int nwp, int NF, long total) {
@@ -788,7 +998,13 @@ struct WsPlan {
 
 int pad_4mod8(int v) { return v + ((4 - (v & 7)) & 7); }  // sub-block stride that keeps the transposed reads conflict-free
 
+int ws_kstep() {  // voxels per k-step: 32 = the 16x16x32 kernel (default), 16 = the 32x32x16 kernel (NC_S3X_WGRAD=0)
+  static const int x = getenv("NC_S3X_WGRAD") ? atoi(getenv("NC_S3X_WGRAD")) : 1;
+  return x ? 32 : 16;
+}
+
 WsPlan ws_plan(const ConvDims& d) {
+  const int KV = ws_kstep();
   WsPlan best{};
   double best_cost = 1e30;
   const int KS = d.kd;
@@ -799,14 +1015,14 @@ WsPlan ws_plan(const ConvDims& d) {
       pl.Ty = Ty; pl.Tx = Tx;
       pl.XB = (d.W + Tx - 1) / Tx; pl.YB = (d.H + Ty - 1) / Ty;
       pl.Xp = Tx + KS - 1; pl.XU = (Ty + KS - 1) * pl.Xp; pl.XUp = pad_4mod8(pl.XU + KS);  // + KS: tap reads of the clamped tail
-      pl.PT = Ty * Tx; pl.NK = (pl.PT + 15) / 16; pl.PTp = pad_4mod8(pl.NK * 16);
+      pl.PT = Ty * Tx; pl.NK = (pl.PT + KV - 1) / KV; pl.PTp = pad_4mod8(pl.NK * KV);
       pl.npx = (12 * pl.XUp + 63) / 64; pl.npd = (24 * pl.PTp + 63) / 64;
       pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
       if ((KS == 3 ? 4 : 2) * pl.xslot + 2 * pl.dybuf > kLdsMax) continue;
-      if (pl.NK < 3) continue;
+      if (pl.NK * KV < 48) continue;
       // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
       const double useful = (double)d.H * d.W;
-      const double mfma = (double)pl.YB * pl.XB * pl.NK * 16;
+      const double mfma = (double)pl.YB * pl.XB * pl.NK * KV;
       const double stage = (double)pl.YB * pl.XB * (12.0 * pl.XUp + 24.0 * pl.PTp) / 72.0;
       const double cost = (mfma + 0.15 * stage) / useful;
       if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
@@ -877,14 +1093,19 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
       set_error("wgrad_s3: cannot raise dynamic LDS limit");
       return NC_ERR_HIP;
     }
     attr_done = true;
   }
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
-  if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  if (ws_kstep() == 32) {
+    if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3x<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+    else hipLaunchKernelGGL(k_wgrad_s3x<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  } else if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   else hipLaunchKernelGGL(k_wgrad_s3<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   if (int e = check_launch("wgrad_s3")) return e;
   const long total = (long)d.K * d.C * T3;

@@ -215,7 +215,17 @@ def apollo_specs():
                        [(n, S.patchgan_spec(2)) for n in APOLLO_NETS[2:]])
 
 
-def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_step_36.npz'):
+def struct_crop(seed, size, vol=96):
+    """A size^3 crop of the seeded structured volume (neuroclear_amd.util.seed.structured_volume) around its brightest voxel, as the
+    float32 [0, 1] tensor the networks see -- mostly dark background with a few blurred beads / tubes."""
+    v = S.structured_volume(seed, vol)
+    c = np.array(np.unravel_index(int(np.argmax(v)), v.shape))
+    lo = np.clip(c - size // 2, 0, vol - size)
+    crop = v[lo[0]:lo[0] + size, lo[1]:lo[1] + size, lo[2]:lo[2] + size]
+    return (crop.astype(np.float32) / np.float32(65535.0))[None, None]
+
+
+def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_step_36.npz', real_np=None):
     """batch > 1 pins the per-plane batch semantics of the LSGAN means (every netD call of the reference sees the whole
     batch of ONE plane, apollo:169-193)."""
     import contextlib
@@ -225,7 +235,7 @@ def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_st
         model = AxialToLateralGANApolloModel(_opt_train('axial_to_lateral_gan_apollo'))
     for i, (name, spec) in enumerate(apollo_specs().items()):
         load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 40 + i))
-    real = torch.from_numpy(rand_input(real_seed, (batch, 1, size, size, size)))
+    real = torch.from_numpy(rand_input(real_seed, (batch, 1, size, size, size)) if real_np is None else real_np)
     losses_per_step, upd = [], {}
     before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in APOLLO_NETS}
     np.random.seed(step_seed)
@@ -253,7 +263,7 @@ def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_st
     np.savez_compressed(os.path.join(OUT, fname), size=size, step_seed=step_seed, real_seed=real_seed, batch=batch,
                         net_seed0=40, loss_names=np.array(model.loss_names), losses=np.array(losses_per_step),
                         draws=np.array(draws), fake0=fake0, rec0=rec0,
-                        **{'upd_' + n: v for n, v in upd.items()})
+                        **({} if real_np is None else {'real': real_np}), **{'upd_' + n: v for n, v in upd.items()})
     print('apollo', dict(zip(model.loss_names, losses_per_step[0])))
     print('draws', draws)
 
@@ -261,7 +271,7 @@ def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_st
 ATHENA_NETS = ['G_A', 'G_B', 'D_A_yz', 'D_A_xy', 'D_A_xz', 'D_B_yz', 'D_B_xy', 'D_B_xz']
 
 
-def gen_athena():
+def gen_athena(fname='athena_step_36.npz', real_np=None):
     import contextlib
     import io
     from models.axial_to_lateral_gan_athena_model import AxialToLateralGANAthenaModel
@@ -272,7 +282,7 @@ def gen_athena():
     specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 6
     for i, (name, spec) in enumerate(zip(ATHENA_NETS, specs)):
         load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 60 + i))
-    real = torch.from_numpy(rand_input(654, (1, 1, size, size, size)))
+    real = torch.from_numpy(rand_input(654, (1, 1, size, size, size)) if real_np is None else real_np)
     before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in ATHENA_NETS}
     losses = []
     for it in range(2):
@@ -283,10 +293,33 @@ def gen_athena():
     for n in ATHENA_NETS:
         after = [p.detach() for p in getattr(model, 'net' + n).parameters()]
         upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
-    np.savez_compressed(os.path.join(OUT, 'athena_step_36.npz'), size=size, real_seed=654, net_seed0=60,
+    np.savez_compressed(os.path.join(OUT, fname), size=size, real_seed=654, net_seed0=60,
                         loss_names=np.array(model.loss_names), losses=np.array(losses),
-                        **{'upd_' + n: v for n, v in upd.items()})
+                        **({} if real_np is None else {'real': real_np}), **{'upd_' + n: v for n, v in upd.items()})
     print('athena', dict(zip(model.loss_names, losses[0])))
+
+
+def gen_structured(networks):
+    """Row h: the same reference runs on STRUCTURED inputs (sparse, dark, anisotropically blurred: struct_crop) instead of uniform
+    noise: unet_deconv forward + backward at 32^3, one Apollo and one Athena step at 36^3.  The inputs are stored in the fixtures
+    (and regenerated from the seed by tests/test_structured.py, which pins the generator's bytes)."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [], dimension=3)
+    seed = 71
+    load_sd(net, S.weights_from_seed(S.unet_deconv_spec(), seed))
+    xn = struct_crop(5, 32)
+    x = torch.from_numpy(xn).requires_grad_(True)
+    y = net(x)
+    r = torch.from_numpy(rand_input(200 + seed, y.shape))
+    (y * r).mean().backward()
+    l2, sm, samp = grad_summary([(k, p.grad) for k, p in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, 'unet_deconv_struct_32.npz'), seed=seed, vol_seed=5, r_seed=200 + seed, x=xn,
+                        y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm, g_samp=samp)
+    print('unet_deconv structured', float(y.mean()), float(xn.min()), float(xn.max()))
+    gen_apollo(size=36, step_seed=2468, real_np=struct_crop(6, 36), fname='apollo_step_struct_36.npz')
+    gen_athena(fname='athena_step_struct_36.npz', real_np=struct_crop(7, 36))
 
 
 def gen_nets_wide(networks):
@@ -532,3 +565,5 @@ if __name__ == '__main__':
         gen_postproc()
     if 'sn' in which:
         gen_sn(networks)
+    if 'structured' in which or not sys.argv[1:]:
+        gen_structured(networks)

@@ -323,3 +323,115 @@ def test_switch_toggled_between_forward_and_backward(kind):
         # (two fp32 evaluations of this gradient differ by ~1e-4: ten InstanceNorm backward passes amplify rounding -- the golden
         #  tests allow 2e-2; a stale or missing operand copy would be an O(1) difference)
         assert rel < 5e-3, (k, rel)
+
+
+# ---- adversarial inputs (every other comparison above uses randn operands of one scale) --------------------------------------
+def _fp64_err(y, ref):
+    e = y.double().cpu() - ref
+    sc = ref.pow(2).mean().sqrt().item()
+    return e.abs().max().item() / sc, e.pow(2).mean().sqrt().item() / sc
+
+
+def _both_kernels(x, w, b, pd):
+    from neuroclear_amd import ops
+    prev = ops.set_conv_split(False)
+    y32 = ops.conv_fwd_raw(x, w, b, 1, pd)
+    ops.set_conv_split(prev)
+    return y32, fwd_split(x, w, b)
+
+
+@pytest.mark.parametrize('C,K,n,ks', [(64, 64, (12, 20, 27), 3), (16, 64, (6, 17, 30), 3), (64, 64, (8, 14, 19), 5)])
+def test_split_conv_large_mean_input(C, K, n, ks):
+    """Inputs 1000 +- 1 (a reduction that mixes a large common part with small differences: what an un-normalised bright volume
+    or a big-mean activation looks like): forward error against fp64 not above the fp32 MFMA kernel's; the weight gradient against a
+    zero-mean dY is a CANCELLING sum (1000 * sum(dY) + sum(dY * delta)) and is judged the same way."""
+    torch.manual_seed(21)
+    pd = ks // 2
+    x = 1000.0 + torch.randn(1, C, *n, device=DEV)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV) * 0.02
+    b = torch.randn(K, device=DEV)
+    ref = F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=pd)
+    y32, ys = _both_kernels(x, w, b, pd)
+    (m32, r32), (ms, rs) = _fp64_err(y32, ref), _fp64_err(ys, ref)
+    print('big mean fwd fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+    assert rs <= 1.3 * r32 + 2e-8 and ms <= 2.0 * m32 + 2e-7, (rs, r32, ms, m32)
+    if C % 32 == 0:
+        from neuroclear_amd import ops
+        dy = torch.randn(1, K, *n, device=DEV)
+        refw = torch.nn.grad.conv3d_weight(x.double().cpu(), w.shape, dy.double().cpu(), padding=pd)
+        prev = ops.set_conv_split(False)
+        w32 = ops.conv_wgrad_raw(x, dy, w.shape, 1, pd, False)[0]
+        ops.set_conv_split(prev)
+        wsp = wgrad_split(x, dy, ks)
+        (m32, r32), (ms, rs) = _fp64_err(w32, refw), _fp64_err(wsp, refw)
+        print('big mean wgrad fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+        assert rs <= 1.3 * r32 + 2e-8 and ms <= 2.0 * m32 + 3e-7, (rs, r32, ms, m32)
+
+
+def test_split_conv_zero_channels_and_zero_bricks():
+    """Channels that are exactly zero over the whole volume, whole planes of zeros, and an all-zero input: zeros contribute exact
+    zeros (every term of 0 is 0), so the all-zero input gives the bias bit for bit and the rest stays within the usual bounds."""
+    torch.manual_seed(22)
+    x = torch.randn(1, 64, 10, 18, 27, device=DEV)
+    x[:, ::2] = 0.0          # every other channel: half of each 8-channel unit is zero
+    x[:, 8:24] = 0.0         # two whole 8-channel blocks
+    x[:, :, 3:6] = 0.0       # three whole planes: bricks of zeros in the middle of the volume
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.02
+    b = torch.randn(64, device=DEV)
+    ref = F.conv3d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    y32, ys = _both_kernels(x, w, b, 1)
+    (m32, r32), (ms, rs) = _fp64_err(y32, ref), _fp64_err(ys, ref)
+    assert rs <= 1.3 * r32 + 2e-8 and ms <= 2.0 * m32 + 2e-7, (rs, r32, ms, m32)
+    assert torch.equal(ys[:, :, 4], b.view(1, 64, 1, 1).expand(1, 64, 18, 27))  # plane 4 sees only zero planes: exactly the bias
+    z = fwd_split(torch.zeros_like(x), w, b)
+    assert torch.equal(z, b.view(1, 64, 1, 1, 1).expand_as(z))
+    assert torch.equal(dgrad_split(torch.zeros(1, 64, 10, 18, 27, device=DEV), w), torch.zeros_like(x))
+
+
+@pytest.mark.parametrize('scale,bound', [(1e-30, 4e-7), (1e-34, 2e-4), (1e-36, 5e-2)])
+def test_split_conv_tiny_magnitudes(scale, bound):
+    """The three terms of a value v are ~v, ~2^-8 v, ~2^-16 v: below |v| ~ 2^-110 the later terms fall under bf16's normal range
+    (2^-126) and the matrix core treats them as zero, so the result degrades from 24 to 16 to 8 significant bits -- it does not blow
+    up and stays finite.  (fp32 arithmetic on such values is itself at the edge of its range: |w x| ~ 1e-38.)  The bounds are the
+    measured behaviour with a margin; at 1e-30 (all terms normal) the ordinary bound holds."""
+    torch.manual_seed(23)
+    x = torch.randn(1, 64, 8, 14, 27, device=DEV) * scale
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.02
+    ref = F.conv3d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    ys = fwd_split(x, w, None)
+    ms, rs = _fp64_err(ys, ref)
+    print('scale %g: split max %.2e rms %.2e' % (scale, ms, rs))
+    assert bool(torch.isfinite(ys).all()) and rs < bound, (scale, rs)
+
+
+def test_split_conv_values_beyond_the_bf16_range_and_non_finite_inputs():
+    """(i) A finite fp32 value above the largest finite bf16 (3.3895e38 < |v| <= 3.4028e38) still splits exactly (its first term is the
+    largest finite bf16, not infinity) and convolves to a finite, accurate result.  (ii) THE PROPAGATION RULE for non-finite inputs: an
+    inf or a NaN input element makes every output it touches (its 3^3 neighbourhood, all output channels) non-finite -- on the
+    split-operand kernels always NaN (inf - inf inside the split; the fp32 MFMA kernels give inf or NaN there) -- and leaves every other
+    output bit-identical to the result without it."""
+    torch.manual_seed(24)
+    big = torch.tensor([3.4e38, -3.4028234e38, 3.39e38, 1.0], device=DEV).repeat(2, 8, 1)[:, :, :4].contiguous()  # [2][8][4]
+    t = to_s3(big).view(torch.bfloat16).view(2, 1, 3, 4, 8).float()
+    assert torch.equal(((t[:, :, 0] + t[:, :, 1]) + t[:, :, 2]).permute(0, 1, 3, 2).reshape(2, 8, 4), big)
+    assert bool(torch.isfinite(t).all())
+    x = torch.randn(1, 64, 8, 12, 20, device=DEV)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 1e-3
+    clean = fwd_split(x, w, None)
+    xb = x.clone()
+    xb[0, 5, 4, 6, 7] = 3.4e38
+    yb = fwd_split(xb, w, None)
+    refb = F.conv3d(xb.double().cpu(), w.double().cpu(), None, padding=1)
+    assert bool(torch.isfinite(yb).all())
+    e = (yb.double().cpu() - refb).abs()
+    assert float((e / refb.abs().clamp_min(1e30)).max()) < 1e-6  # relative to the huge contributions where they dominate
+    for bad in (float('inf'), float('-inf'), float('nan')):
+        xn = x.clone()
+        xn[0, 5, 4, 6, 7] = bad
+        for y in _both_kernels(xn, w, None, 1):
+            touched = torch.zeros_like(y, dtype=torch.bool)
+            touched[:, :, 3:6, 5:8, 6:9] = True
+            assert not bool(torch.isfinite(y[touched]).any()), bad
+        ys = fwd_split(xn, w, None)
+        assert bool(torch.isnan(ys[touched]).all()), bad
+        assert torch.equal(ys[~touched], clean[~touched]), bad

@@ -1,0 +1,131 @@
+"""GPU parity on STRUCTURED inputs (row h): the HIP path against what the reference computes on crops of the structured
+synthetic volume (sparse, dark, blurred along z -- fixtures from oracle/gen_golden.py `structured`), at the fp32 tolerances of
+tests/test_gpu_nets.py, and BASELINE configs[0] (256^3, dice 64, overlap 8) on the structured volume with a PSNR line.
+Uniform-noise inputs never produce near-constant channels, small InstanceNorm variances or sums that mix magnitudes; these do."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from neuroclear_amd.models import networks  # noqa: E402
+from neuroclear_amd.util import seed as S  # noqa: E402
+
+DEV = 'cuda'
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def load(net, spec, seed):
+    net.load_state_dict(S.state_dict_from_seed(spec, seed, DEV))
+    return net
+
+
+def rel2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def _opt(model):
+    return Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t', preprocess='none',
+                     gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10, min_projection_depth=2,
+                     lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64, ndf=64, netG='unet_deconv',
+                     netG_B='deep_linear_gen', netD='basic', n_layers_D=3, norm='instance', no_dropout=True, init_type='kaiming',
+                     init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB', model=model, conversion_plane=['yz', 'xy'], pool_size=50)
+
+
+def test_unet_deconv_on_a_structured_crop(golden_dir):
+    g = G(golden_dir, 'unet_deconv_struct_32.npz')
+    net = load(networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0]), S.unet_deconv_spec(), int(g['seed']))
+    x = torch.from_numpy(g['x']).to(DEV).requires_grad_(True)
+    y = net(x)
+    assert float(np.abs(y.detach().cpu().numpy() - g['y']).max()) < 2e-5
+    with torch.no_grad():
+        assert float((net(x.detach()) - y.detach()).abs().max()) < 1e-5  # whole-network inference entry point
+    r = torch.from_numpy(np.random.default_rng(int(g['r_seed'])).random(tuple(y.shape), dtype=np.float32)).to(DEV)
+    (y * r).mean().backward()
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < 2e-2
+    for i, (k, p) in enumerate(net.named_parameters()):
+        l2 = float(np.sqrt((p.grad.detach().cpu().numpy().astype(np.float64) ** 2).sum()))
+        assert abs(l2 - g['g_l2'][i]) <= 2e-2 * g['g_l2'][i] + 1e-6, (k, l2, g['g_l2'][i])
+
+
+@pytest.mark.parametrize('model_name,fname,nets', [
+    ('axial_to_lateral_gan_apollo', 'apollo_step_struct_36.npz', ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']),
+    ('axial_to_lateral_gan_athena', 'athena_step_struct_36.npz', ['G_A', 'G_B', 'D_A_yz', 'D_A_xy', 'D_A_xz', 'D_B_yz', 'D_B_xy', 'D_B_xz'])])
+def test_step_on_a_structured_crop(golden_dir, model_name, fname, nets):
+    from neuroclear_amd.models import create_model
+    g = G(golden_dir, fname)
+    model = create_model(_opt(model_name))
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * (len(nets) - 2)
+    for i, (n, sp) in enumerate(zip(nets, specs)):
+        load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
+    before = {n: [p.detach().clone() for p in getattr(model, 'net' + n).parameters()] for n in nets}
+    real = torch.from_numpy(g['real'])
+    if 'step_seed' in g:
+        np.random.seed(int(g['step_seed']))
+    names = [str(s) for s in g['loss_names']]
+    for it in range(2):
+        model.set_input({'A': real, 'A_paths': 'x'})
+        model.optimize_parameters()
+        L = model.get_current_losses()
+        got = np.array([L[k] for k in names])
+        print(it, got, g['losses'][it])
+        np.testing.assert_allclose(got, g['losses'][it], rtol=2e-5 if it == 0 else 5e-3, err_msg='step %d' % it)
+        if it == 0 and 'fake0' in g:
+            assert float(np.abs(model.fake.detach().cpu().numpy() - g['fake0']).max()) < 2e-5
+    for n in nets:
+        ps = list(getattr(model, 'net' + n).parameters())
+        upd = np.array([float((a.detach() - b).double().norm()) for a, b in zip(ps, before[n])])
+        sel = np.array([a.dim() > 1 for a in ps])
+        np.testing.assert_allclose(upd[sel], g['upd_' + n][sel], rtol=5e-2, err_msg=n)
+
+
+def test_config0_diced_inference_256_structured():
+    """BASELINE configs[0] on the structured 256^3 volume: every cube through the HIP network; three cubes end to end against the CPU
+    oracle; the oracle's overlap-add of the product's cube outputs gives the product's uint16 volume bit for bit; PSNR lines (the
+    reference's report, util/util.py:114-119 through neuroclear_amd.util.util.get_psnr) of input and output against the isotropic
+    ground truth -- with seeded random weights the network is no deconvolver, the line documents the plumbing, not image quality."""
+    from neuroclear_amd.data.diceImage_dataset import DiceImageDataSet
+    from neuroclear_amd.util import util as nutil
+    from neuroclear_amd.util.assemble_dice import Assemble_Dice
+    from oracle import dice as odice
+    from oracle import nets as onets
+    vol, truth = S.structured_volume(11, 256, with_truth=True)
+    R, ov, b = 64, 8, 8
+    opt = Namespace(dice_size=[R] * 3, overlap=ov, border_cut=b, gpu_ids=[0], skip_real=True, data_type='uint16', histogram_match=False,
+                    normalize_intensity=False)
+    sd_np = S.weights_from_seed(S.unet_deconv_spec(), 21)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict({k: torch.from_numpy(v).to(DEV) for k, v in sd_np.items()})
+    ds = DiceImageDataSet(opt, volume=vol)
+    assert ds.size() == (288, 288, 288) and len(ds) == 125
+    asm = Assemble_Dice(opt, vol.shape)
+    outs = []
+    with torch.no_grad():
+        for i in range(len(ds)):
+            y = net(ds[i]['A'].unsqueeze(0))
+            outs.append(y.reshape(80, 80, 80).cpu().numpy())
+            asm.addToStack(dict(fake=y))
+    asm.assemble_all()
+    got = asm.getDict()['fake']
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    refl = odice.reflect_pad(padded, b)
+    sd_t = onets.to_torch(sd_np)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    dark = int(np.argmin([float(o.std()) for o in outs]))  # the most featureless cube: smallest variances inside the network
+    for i in sorted({0, 62, dark}):
+        cube = odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b))
+        with torch.no_grad():
+            ref = onets.unet_deconv(sd_t, torch.from_numpy(cube)[None, None]).numpy()[0, 0]
+        assert float(np.abs(outs[i] - ref).max()) < 2e-5, i
+    assert np.array_equal(got, odice.assemble(outs, padded.shape, vol.shape, R, ov, b, 'uint16'))
+    n8 = lambda a: nutil.normalize(nutil.standardize(a), data_type=np.uint8)  # noqa: E731  (test_dice.py:244-253)
+    print('PSNR input vs isotropic truth %.2f dB, network output vs truth %.2f dB (seeded random weights)' % (
+        nutil.get_psnr(n8(vol), n8(truth), 255), nutil.get_psnr(n8(got), n8(truth), 255)))
