@@ -8,7 +8,13 @@
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors on the Python side), dense, fp32 unless
  *    the name says otherwise; activations are NCDHW (2-D data: D = 1, kd = 1);
- *  - `stream` is a hipStream_t passed as void*; nothing here synchronises, allocates or frees (graph-capture safe);
+ *  - `stream` is a hipStream_t passed as void*; nothing here allocates or frees, and nothing synchronises -- with ONE exception:
+ *    the image-staged PatchGAN kernels (nc_conv_* on 2-D 4x4 layers at large batches, conv2d_img.hip) time their candidate tile
+ *    shapes on the FIRST call of a problem shape: a hipDeviceSynchronize plus a few timed launches, skipped when the stream is
+ *    being captured.  nc_sconv_set_tune(0) (or NC_SCONV_TUNE=0) switches that off for the whole process: then the rule holds
+ *    without exception (a fixed heuristic picks the shape; results are bit-identical either way);
+ *  - process-wide switches (nc_set_conv_split, nc_set_s3_fusion, nc_sconv_set_tune, nc_sconv_set_cfg, nc_set_force_direct) are
+ *    atomics read once per call: flip them between calls, not while other host threads are inside the library;
  *  - scratch memory comes from the caller: `ws` / `ws_bytes`; query the size with the matching *_ws_bytes();
  *  - return value: 0 = ok, negative = NC_ERR_*; nc_last_error() gives a thread-local message.
  */
@@ -48,6 +54,9 @@ void nc_set_force_direct(int on);
  * first call (NC_SCONV_TUNE=0: a fixed heuristic).  Every shape gives the same bits; this pins shape `cfg` (0-based, -1 =
  * back to automatic) so that a test can check exactly that. */
 void nc_sconv_set_cfg(int cfg);
+/* 1 (default; NC_SCONV_TUNE): time the candidate shapes on the first call of a problem shape (synchronises once per shape, see
+ * Conventions); 0: never time, never synchronise -- the heuristic shape; -1: back to the environment's choice. */
+void nc_sconv_set_tune(int on);
 
 /* ---- Convolution: nn.Conv3d / nn.Conv2d (models/networks.py:361-369; used at :420-425,:442,:460-469 (U-Net 3^3),
  *      :899-911 (deep_linear 7^3/5^3/3^3/1^3), :507-508 (1x1 tail), :1030-1057 (PatchGAN 4x4 s2/s1)).
@@ -262,17 +271,20 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
 size_t nc_unet_deconv_param_floats(void);
 size_t nc_unet_deconv_saved_floats(int N, int S0, int S1, int S2);
 size_t nc_unet_deconv_train_ws_bytes(int N, int S0, int S1, int S2);
+/* `kept` (HOST word, out, may be NULL): bit i set = the forward left the three-term (S3) copy of layer i's input in `saved`; hand the
+ * same word to the backward that reads this `saved` buffer (0 is always valid: the backward then converts the inputs again).  The
+ * word travels with the caller's record of the forward (the autograd context), there is no library-side table. */
 int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2,
-                             void* ws, size_t ws_bytes, void* stream);
+                             void* ws, size_t ws_bytes, void* stream, unsigned* kept);
 int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, const float* saved, const float* dy, float* dx,
-                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream);
+                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept);
 size_t nc_deep_linear_param_floats(void);
 size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2);
 size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2);
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved /* or NULL */, int N, int S0, int S1,
-                       int S2, void* ws, size_t ws_bytes, void* stream);
+                       int S2, void* ws, size_t ws_bytes, void* stream, unsigned* kept /* as above */);
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
-                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream);
+                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept);
 
 /* ---- The 16-bit END-TO-END path (BASELINE.json configs[3]): operators between which activations and gradients exist in
  *      HBM only as 16-bit "C8" tensors [N][C/8][S][8] (nc_to_c8's layout).  A tensor argument (ptr, ctot, c0) means

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <vector>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace nc {
@@ -58,9 +60,9 @@ static bool pg1_on(const ConvDims& d) {
 // Split-operand kernels (conv_split.hip): the fp32 3^3 / 5^3 convolutions they cover run as six bf16 MFMA products of an exact
 // three-term operand split (same operands, fp32 accumulation, error against fp64 not above the fp32 MFMA kernel's:
 // tests/test_gpu_split.py).  On by default; nc_set_conv_split(0) or NC_CONV_SPLIT=0 put those layers back on the fp32 MFMA kernels.
-static int g_split = getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 1;
+static std::atomic<int> g_split{getenv("NC_CONV_SPLIT") ? atoi(getenv("NC_CONV_SPLIT")) : 1};  // process-wide; read once per call
 // NC_S3_FUSE=0 (nc_set_s3_fusion(0)): nc_unet_deconv_fwd converts every convolution input to S3 in a separate pass (A/B, tests)
-static int g_s3_fuse = getenv("NC_S3_FUSE") ? atoi(getenv("NC_S3_FUSE")) : 1;
+static std::atomic<int> g_s3_fuse{getenv("NC_S3_FUSE") ? atoi(getenv("NC_S3_FUSE")) : 1};
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
@@ -119,6 +121,7 @@ const char* nc_last_error(void) { return g_err; }
 int nc_version(void) { return 100; }
 void nc_set_force_direct(int on) { g_force_direct = on; }
 void nc_sconv_set_cfg(int cfg) { sconv_set_cfg(cfg); }
+void nc_sconv_set_tune(int on) { sconv_set_tune(on); }
 void nc_set_conv_split(int on) { g_split = on; }
 void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }

@@ -92,6 +92,7 @@ size_t sconv_ws_bytes(const ConvDims& d);
 int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 void sconv_set_cfg(int cfg);
+void sconv_set_tune(int on);
 bool sconv_wgrad_supported(const ConvDims& d);
 size_t sconv_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_sconv(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);

@@ -21,6 +21,7 @@
 // v_mfma_f32_32x32x2_f32 (exact fp32): the two k values of an MFMA are two input channels of one tap.
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -337,7 +338,10 @@ struct TuneKey {
 std::map<TuneKey, int> g_tuned;
 std::mutex g_tune_mu;
 int g_cfg_override = -1;  // nc_sconv_set_cfg (tests)
+std::atomic<int> g_tune_mode{-1};  // nc_sconv_set_tune: 0 never time (heuristic plan), 1 time on first use, -1 = NC_SCONV_TUNE (default 1)
 bool tune_on() {
+  const int m = g_tune_mode.load();
+  if (m >= 0) return m != 0;
   static const bool on = !(getenv("NC_SCONV_TUNE") && atoi(getenv("NC_SCONV_TUNE")) == 0);
   return on;
 }
@@ -811,5 +815,6 @@ int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims&
 }
 
 void sconv_set_cfg(int cfg) { g_cfg_override = cfg; }
+void sconv_set_tune(int on) { g_tune_mode = on; }
 
 }  // namespace nc

@@ -9,8 +9,6 @@
 //
 // Parameter blob = the tensors in state-dict order, packed back to back.  `saved` receives what the
 // backward needs (raw conv outputs, activations, InstanceNorm statistics); sizes from the *_saved_floats queries.
-#include <mutex>
-#include <unordered_map>
 
 #include "common.hpp"
 
@@ -22,22 +20,11 @@ namespace {
 
 size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-// Which S3 (three-term) copies of convolution inputs did the last forward into a `saved` buffer leave there (bit i = layer i)?
-// The forward of a layer that runs on the split-operand kernels converts its input INTO the saved buffer (conv_fwd_keep) and the
-// backward hands that tensor to the weight gradient instead of converting x again; the mask is host state because the decision
-// (library switch, shape coverage) is host state -- a backward whose `saved` has no entry, or a layer whose bit is clear, converts.
-std::mutex g_keep_mu;
-std::unordered_map<const void*, unsigned> g_keep;
-void keep_set(const void* saved, unsigned mask) {
-  std::lock_guard<std::mutex> lk(g_keep_mu);
-  if (g_keep.size() > 4096) g_keep.clear();
-  g_keep[saved] = mask;
-}
-unsigned keep_get(const void* saved) {
-  std::lock_guard<std::mutex> lk(g_keep_mu);
-  auto it = g_keep.find(saved);
-  return it == g_keep.end() ? 0u : it->second;
-}
+// Which S3 (three-term) copies of convolution inputs a training forward left in its `saved` buffer is a bit mask (bit i = layer i) that
+// the forward RETURNS to the caller (`kept`, a host word) and the caller hands to the backward of the same `saved` buffer: the
+// forward of a layer that runs on the split-operand kernels converts its input INTO the saved buffer (conv_fwd_keep) and the backward
+// gives that tensor to the weight gradient instead of converting x again.  The decision (library switch, shape coverage) is host
+// state, so the mask is host data; it travels with the autograd context that owns `saved`, not with a table keyed by its address.
 size_t s3_floats(size_t elems) { return up64((elems * 6 + 3) / 4); }
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -51,7 +38,7 @@ struct UPlan {
   long S[3];           // voxels per level
   // saved (floats): activations, raw conv outputs, statistics
   size_t a1, cat1, p1, a2, cat2, p2, b1, b2, b3, e2a, e2b, e1, t1, raw[10], mean[10], rstd[10], saved;
-  size_t xs3[10];      // S3 copy of block i's input (i >= 1), see g_keep
+  size_t xs3[10];      // S3 copy of block i's input (i >= 1), see `kept`
   // backward scratch (floats)
   size_t G1, G2, G3, H1, H2, H3, Q1, Q2, s1, s2, T, grads;
   size_t conv_ws, in_ws, convT_ws;  // bytes
@@ -148,7 +135,7 @@ size_t nc_unet_deconv_train_ws_bytes(int N, int S0, int S1, int S2) {
 }
 
 int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2,
-                             void* ws, size_t ws_bytes, void* stream) {
+                             void* ws, size_t ws_bytes, void* stream, unsigned* kept) {
   if (!params || !x || !y || !saved) { set_error("unet_deconv_train_fwd: null pointer"); return NC_ERR_ARG; }
   UPlan p;
   if (!u_plan(p, N, S0, S1, S2)) {
@@ -161,7 +148,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   void* iws = (char*)ws + align256(p.conv_ws);
   float* V = saved;
   const float* P = params;
-  keep_set(saved, 0);
+  if (kept) *kept = 0;
   // conv (3^3, pad 1) -> raw; statistics; normalise + ReLU into `out`, where sample n's K planes start at
   // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer)
   unsigned kept_mask = 0;
@@ -207,14 +194,14 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   NC_TRY(nc_conv_fwd(V + p.e1, P + o.w[12], P + o.b[12], V + p.t1, N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
   // one_by_one_2 + sigmoid: y doubles as the buffer of the pre-sigmoid value (the sigmoid kernel is elementwise in place)
   NC_TRY(nc_conv_fwd(V + p.t1, P + o.w[13], P + o.b[13], y, N, 1, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
-  keep_set(saved, kept_mask);
+  if (kept) *kept = kept_mask;
   return nc_sigmoid_fwd(y, y, (long)N * S, stream);
 }
 
 // dparams: packed like params, OVERWRITTEN with this call's parameter gradients.  dx nullable (the U-Net's input is the
 // real volume in the Apollo / Athena steps: its gradient -- the data gradient of the first convolution -- is skipped).
 int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, const float* saved, const float* dy, float* dx,
-                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream) {
+                       float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept) {
   if (!params || !x || !y || !saved || !dy || !dparams) { set_error("unet_deconv_bwd: null pointer"); return NC_ERR_ARG; }
   UPlan p;
   if (!u_plan(p, N, S0, S1, S2)) { set_error("unet_deconv_bwd: bad shape"); return NC_ERR_SHAPE; }
@@ -230,7 +217,7 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
   float* DP = dparams;
   const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
-  const unsigned kept_mask = keep_get(saved);
+  const unsigned kept_mask = kept;
   // backward of block i: g = gradient at the block's (post-ReLU) output, dense [N][K][S]; `in` = the block's input.
   // draw <- InstanceNorm/ReLU backward (+ the conv's bias gradient); dW <- wgrad; gin (nullable) <- dgrad
   auto block_bwd = [&](int i, const float* g, const float* in, float* draw, float* gin) -> int {
@@ -302,7 +289,7 @@ struct LPlan {
   long S;
   size_t w[6], params;        // floats into the packed blob
   size_t act[5], saved;       // outputs of layers 0..4 (inputs of layers 1..5)
-  size_t xs3[6];              // S3 copy of the input of layer i (the 5^3 and 3^3 layers), see g_keep
+  size_t xs3[6];              // S3 copy of the input of layer i (the 5^3 and 3^3 layers), see `kept`
   size_t g[2], grads;         // gradient ping-pong
   size_t conv_ws;
 };
@@ -353,7 +340,7 @@ size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2) {
 
 // saved == NULL: inference -- the intermediate activations ping-pong through the workspace instead
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2, void* ws,
-                       size_t ws_bytes, void* stream) {
+                       size_t ws_bytes, void* stream, unsigned* kept) {
   if (!params || !x || !y) { set_error("deep_linear_fwd: null pointer"); return NC_ERR_ARG; }
   LPlan p;
   if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_fwd: bad shape"); return NC_ERR_SHAPE; }
@@ -362,7 +349,7 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
   float* G = (float*)((char*)ws + align256(p.conv_ws));
   const float* in = x;
   unsigned kept_mask = 0;
-  if (saved) keep_set(saved, 0);
+  if (kept) *kept = 0;
   for (int i = 0; i < 6; ++i) {
     const LLayer& l = kLL[i];
     float* out = i == 5 ? y : (saved ? saved + p.act[i] : G + p.g[i & 1]);
@@ -375,13 +362,13 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
     if (kept) kept_mask |= 1u << i;
     in = out;
   }
-  if (saved) keep_set(saved, kept_mask);
+  if (kept) *kept = kept_mask;
   return NC_OK;
 }
 
 // dx nullable; dparams overwritten
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
-                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream) {
+                       int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept) {
   if (!params || !x || !saved || !dy || !dparams) { set_error("deep_linear_bwd: null pointer"); return NC_ERR_ARG; }
   LPlan p;
   if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_bwd: bad shape"); return NC_ERR_SHAPE; }
@@ -389,7 +376,7 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
   void* cws = ws;
   float* G = (float*)((char*)ws + align256(p.conv_ws));
   const float* g = dy;
-  const unsigned kept_mask = keep_get(saved);
+  const unsigned kept_mask = kept;
   for (int i = 5; i >= 0; --i) {
     const LLayer& l = kLL[i];
     const float* in = i == 0 ? x : saved + p.act[i - 1];

@@ -39,7 +39,9 @@ class FlatAdam(torch.optim.Optimizer):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p.data)
-            p.grad = self.grad[off:off + k].view_as(p.data)
+            # .grad stays None until a backward delivers one: with a view of self.grad here, a backward BEFORE the first zero_grad()
+            # would have its whole-network call write the slice and AccumulateGrad then add the same memory to itself (2 x the gradient)
+            p.grad = None
             off += k
         self.state_step = 0
         ops.register_flat_grad(self.flat, self.grad)
@@ -104,6 +106,11 @@ class FlatAdam(torch.optim.Optimizer):
     def _grad_ready(self, bi):
         b = self._buckets[bi]
         b['seen'] += 1
+        if b['seen'] > b['n'] or b['work'] is not None:
+            # a second backward into this optimizer before all_reduce_mean(): its gradients are being ADDED into slices whose
+            # exchange is already in flight (or done) -- the averaged result would silently miss them
+            raise RuntimeError('FlatAdam: gradients arrived for a bucket whose all-reduce was already issued; call all_reduce_mean() / '
+                               'zero_grad() between backward passes, or construct the optimizer with overlap_all_reduce=False')
         if b['seen'] == b['n'] and self._overlap_armed:
             # only when every gradient of the range already sits in the flat buffer (written there by the whole-network
             # backward calls); otherwise all_reduce_mean() collects them first and exchanges the range synchronously

@@ -1078,6 +1078,15 @@ def patchgan(x, params, n_layers, ndf, dimension):
 
 
 # ---- whole-network generators (nc_unet_deconv_train_fwd / _bwd, nc_deep_linear_fwd / _bwd): one C call per direction --
+def _grad_target(ctx, first):
+    """Where a whole-network backward writes its packed parameter gradients: the optimizer's flat gradient slice when at least one
+    parameter wants a gradient (the kernels OVERWRITE the slice), a scratch tensor otherwise -- a backward through frozen parameters
+    (set_requires_grad(False)) must not touch what FlatAdam.step would apply."""
+    if any(ctx.needs_input_grad[first:]):
+        return _grad_destination(ctx.packed)
+    return torch.empty_like(ctx.packed)
+
+
 def _param_grads(ctx, dpar, shapes, first):
     grads = [None] * len(shapes)
     off = 0
@@ -1109,8 +1118,10 @@ class _UnetDeconvTrain(torch.autograd.Function):
         ws = workspace(L.nc_unet_deconv_train_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'unet_train')
         y = torch.empty_like(x)
         e0 = _prof_begin()
+        kept = ctypes.c_uint(0)  # which three-term input copies the forward left in `saved`: travels with this context
         check(L.nc_unet_deconv_train_fwd(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), I(N), I(S0), I(S1), I(S2), _ptr(ws),
-                                         Z(ws.numel()), _stream()), 'nc_unet_deconv_train_fwd')
+                                         Z(ws.numel()), _stream(), ctypes.byref(kept)), 'nc_unet_deconv_train_fwd')
+        ctx.kept = kept.value
         if e0 is not None:
             _prof_end(e0, 'unet_fwd', 2.0 * 663809 * x.numel())
         ctx.save_for_backward(x, y, saved)
@@ -1128,11 +1139,11 @@ class _UnetDeconvTrain(torch.autograd.Function):
         N, _, S0, S1, S2 = x.shape
         L = lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = _grad_destination(ctx.packed)
+        dpar = _grad_target(ctx, 1)
         ws = workspace(L.nc_unet_deconv_train_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'unet_train')
         e0 = _prof_begin()
         check(L.nc_unet_deconv_bwd(_ptr(ctx.packed), _ptr(x), _ptr(y), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N),
-                                   I(S0), I(S1), I(S2), _ptr(ws), Z(ws.numel()), _stream()), 'nc_unet_deconv_bwd')
+                                   I(S0), I(S1), I(S2), _ptr(ws), Z(ws.numel()), _stream(), ctypes.c_uint(ctx.kept)), 'nc_unet_deconv_bwd')
         if e0 is not None:  # dgrad + wgrad of every layer but the first one's data gradient
             _prof_end(e0, 'unet_bwd', 2.0 * (2 * 663809 - 1728) * x.numel())
         return (dx,) + tuple(_param_grads(ctx, dpar, ctx.shapes, 1))
@@ -1160,8 +1171,10 @@ class _DeepLinear(torch.autograd.Function):
         ws = workspace(L.nc_deep_linear_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'deep_linear')
         y = torch.empty_like(x)
         e0 = _prof_begin()
+        kept = ctypes.c_uint(0)
         check(L.nc_deep_linear_fwd(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), I(N), I(S0), I(S1), I(S2), _ptr(ws),
-                                   Z(ws.numel()), _stream()), 'nc_deep_linear_fwd')
+                                   Z(ws.numel()), _stream(), ctypes.byref(kept)), 'nc_deep_linear_fwd')
+        ctx.kept = kept.value
         if e0 is not None:
             _prof_end(e0, 'deep_linear_fwd', 2.0 * 647120 * x.numel())
         if need:
@@ -1180,11 +1193,11 @@ class _DeepLinear(torch.autograd.Function):
         N, _, S0, S1, S2 = x.shape
         L = lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = _grad_destination(ctx.packed)
+        dpar = _grad_target(ctx, 1)
         ws = workspace(L.nc_deep_linear_ws_bytes(I(N), I(S0), I(S1), I(S2)), x.device, 'deep_linear')
         e0 = _prof_begin()
         check(L.nc_deep_linear_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(N), I(S0), I(S1),
-                                   I(S2), _ptr(ws), Z(ws.numel()), _stream()), 'nc_deep_linear_bwd')
+                                   I(S2), _ptr(ws), Z(ws.numel()), _stream(), ctypes.c_uint(ctx.kept)), 'nc_deep_linear_bwd')
         if e0 is not None:
             _prof_end(e0, 'deep_linear_bwd', 2.0 * (2 * 647120 - (0 if dx is not None else 21952)) * x.numel())
         return (dx,) + tuple(_param_grads(ctx, dpar, ctx.shapes, 1))
@@ -1251,7 +1264,7 @@ class _GenLp(torch.autograd.Function):
         pre = 'nc_unet_deconv_lp' if kind == 'unet' else 'nc_deep_linear_lp'
         dims = (I(N), I(S0), I(S1), I(S2))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dpar = _grad_destination(ctx.packed)
+        dpar = _grad_target(ctx, 2)
         ws = workspace(getattr(L, pre + '_ws_bytes')(*dims), x.device, pre)
         dt = _DT['bf16']
         e0 = _prof_begin()

@@ -192,6 +192,53 @@ def _adam_overlap_worker(rank, world, port, out_path):
         loss(ps).backward()
         o.all_reduce_mean()
     ok = ok and torch.allclose(oa.grad, ob.grad, rtol=1e-6, atol=0) and float(ob.grad.abs().sum()) > 0
+
+    # The HOOK-DRIVEN path proper: gradients written straight into slices of the flat gradient buffer (ops._grad_destination) and handed
+    # to autograd as views of it -- what the whole-network backward calls do on the GPU.  With plain autograd gradients (above) every
+    # bucket takes the synchronous fallback; here every bucket's collective must have been issued from inside backward.
+    from neuroclear_amd import ops
+
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *params):
+            ctx.packed = ops._pack_params(params)
+            ctx.shapes = [tuple(q.shape) for q in params]
+            return sum(((q * (rank + 1 + i)) ** 2).sum() for i, q in enumerate(params))
+
+        @staticmethod
+        def backward(ctx, dy):
+            dpar = ops._grad_destination(ctx.packed)
+            off, views = 0, []
+            for i, shp in enumerate(ctx.shapes):
+                n = int(np.prod(shp))
+                dpar[off:off + n].copy_((2.0 * (rank + 1 + i) ** 2 * ctx.packed[off:off + n]) * dy)
+                views.append(dpar[off:off + n].view(shp))
+                off += n
+            return tuple(views)
+
+    pc, oc = build(True)
+    pd, od = build(False)
+    for it in range(2):
+        oc.zero_grad()
+        Direct.apply(*pc).backward()
+        ok = ok and all(b['work'] is not None for b in oc._buckets) and len(oc._buckets) >= 2  # issued by the hooks, all of them
+        ok = ok and all(q.grad.data_ptr() == oc.grad.data_ptr() + 4 * o for q, o in zip(pc, np.cumsum([0] + [q.numel() for q in pc])[:-1]))
+        oc.all_reduce_mean()
+        od.zero_grad()
+        loss(pd).backward()
+        od.all_reduce_mean()
+        ok = ok and torch.allclose(oc.grad, od.grad, rtol=1e-6, atol=0)  # (the Adam launch itself needs the GPU: tests/test_gpu_ops.py)
+    # a second backward into the same optimizer before the exchange was collected must not be averaged silently wrong: it raises
+    oc.zero_grad()
+    Direct.apply(*pc).backward()
+    try:
+        loss(pc).backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and 'all-reduce was already issued' in str(e)
+    for b in oc._buckets:  # drain what was issued, so that every rank leaves the group in step
+        if b['work'] is not None:
+            b['work'].wait()
     if rank == 0:
         np.save(out_path, np.array([int(ok)]))
     dist.barrier()

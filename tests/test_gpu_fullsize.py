@@ -251,3 +251,54 @@ def test_apollo_step_108_streams_and_fused_paths_agree(monkeypatch):
             for k in base[it]:
                 assert base[it][k] == other[it][k], (ds, fp, it, k, base[it][k], other[it][k])
         assert torch.equal(p0, p1), (ds, fp)
+
+
+def _athena_108(monkeypatch, d_streams, reuse, tune, seed=41):
+    import contextlib
+    import io
+    from neuroclear_amd._lib import I, lib
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.models.axial_to_lateral_gan_athena_model import AxialToLateralGANAthenaModel
+    monkeypatch.setattr(AxialToLateralGANAthenaModel, '_d_streams_on', d_streams)
+    monkeypatch.setattr(AxialToLateralGANAthenaModel, '_reuse_on', reuse)
+    lib().nc_sconv_set_tune(I(1 if tune else 0))
+    opt = Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t108a', preprocess='none',
+                    gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10, min_projection_depth=2,
+                    lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64, ndf=64, netG='unet_deconv',
+                    netG_B='deep_linear_gen', netD='basic', n_layers_D=3, norm='instance', no_dropout=True, init_type='kaiming',
+                    init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB', model='axial_to_lateral_gan_athena',
+                    conversion_plane=['yz', 'xy'], pool_size=50)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    v = S.structured_volume(78, 108)
+    real = torch.from_numpy((v.astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(DEV)
+    out = []
+    try:
+        for it in range(2):  # the second step runs on updated weights, with the tile shapes of the first one cached
+            model.set_input({'A': real, 'A_paths': 'x'})
+            model.optimize_parameters()
+            out.append(dict(model.get_current_losses()))
+    finally:
+        lib().nc_sconv_set_tune(I(-1))
+    params = torch.cat([p.detach().reshape(-1) for p in model.optimizer_G.params + model.optimizer_D.params]).clone()
+    return out, params
+
+
+def test_athena_step_108_streams_tuner_and_shared_pass_agree(monkeypatch):
+    """BASELINE configs[4] at its size (every one of the 108 slices of a 108^3 crop through six 2-D discriminators: batches of
+    108-216 planes of 108^2, where the image-staged kernels, their first-call tile-shape tuner, the shared fake-plane pass and the
+    six-stream overlap actually engage): two full optimisation steps on a structured crop with (a) the discriminator work on six HIP
+    streams vs one, (b) the tile-shape tuner on vs the fixed heuristic, (c) the shared pass over the fake planes vs both passes run.
+    Every tile shape accumulates in the same order, no kernel uses atomics and the shared pass evaluates the same planes through the
+    same weights, so every loss and every updated parameter must be BIT-equal -- a missing stream event, a scratch buffer shared
+    between streams or a tuner launch that leaks into results shows up here, where it cannot at the 36^3 of the golden step."""
+    base, p0 = _athena_108(monkeypatch, True, True, True)
+    assert all(np.isfinite(list(s.values())).all() for s in base)
+    for ds, ru, tu in ((False, True, True), (True, True, False), (True, False, True)):
+        other, p1 = _athena_108(monkeypatch, ds, ru, tu)
+        for it in range(2):
+            for k in base[it]:
+                assert base[it][k] == other[it][k], (ds, ru, tu, it, k, base[it][k], other[it][k])
+        assert torch.equal(p0, p1), (ds, ru, tu)

@@ -412,8 +412,8 @@ def test_split_conv_values_beyond_the_bf16_range_and_non_finite_inputs():
     output bit-identical to the result without it."""
     torch.manual_seed(24)
     big = torch.tensor([3.4e38, -3.4028234e38, 3.39e38, 1.0], device=DEV).repeat(2, 8, 1)[:, :, :4].contiguous()  # [2][8][4]
-    t = to_s3(big).view(torch.bfloat16).view(2, 1, 3, 4, 8).float()
-    assert torch.equal(((t[:, :, 0] + t[:, :, 1]) + t[:, :, 2]).permute(0, 1, 3, 2).reshape(2, 8, 4), big)
+    t = to_s3(big).view(torch.bfloat16).view(2, 1, 3, 4, 8).double()  # (summed in fp64: for -FLT_MAX the first two terms alone are -2^128)
+    assert torch.equal(((t[:, :, 0] + t[:, :, 1]) + t[:, :, 2]).permute(0, 1, 3, 2).reshape(2, 8, 4), big.double())
     assert bool(torch.isfinite(t).all())
     x = torch.randn(1, 64, 8, 12, 20, device=DEV)
     w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 1e-3
