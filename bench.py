@@ -52,13 +52,13 @@ MFMA_16BIT_PEAK_TFLOPS = 2500.0  # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dens
 SPLIT_PRODUCTS = 6
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
 ARITHMETIC = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 6 bf16 MFMA products of an exact 3-term operand '
-              'split (csrc/conv_split.hip; error vs fp64 <= the fp32 MFMA kernels\': tests/test_gpu_split.py); NC_CONV_SPLIT=0 = fp32 MFMA kernels')
+              'split (csrc/conv_s3x.hip, conv_split.hip; error vs fp64 <= the fp32 MFMA kernels\': tests/test_gpu_split.py); NC_CONV_SPLIT=0 = fp32 MFMA kernels')
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
-    'fwd_split_k3': 'k_conv_s3<3,*>', 'dgrad_split_k3': 'k_conv_s3<3,*>', 'fwd_split_k5': 'k_conv_s3<5,*>',
-    'dgrad_split_k5': 'k_conv_s3<5,*>', 'wgrad_split_k3': 'k_wgrad_s3<3>', 'wgrad_split_k5': 'k_wgrad_s3<5>',
+    'fwd_split_k3': 'k_conv_s3x<3,*>', 'dgrad_split_k3': 'k_conv_s3x<3,*>', 'fwd_split_k5': 'k_conv_s3x<5,*>',
+    'dgrad_split_k5': 'k_conv_s3x<5,*>', 'wgrad_split_k3': 'k_wgrad_s3x<3>', 'wgrad_split_k5': 'k_wgrad_s3x<5>',
     'fwd_lp_k3': 'k_conv_h<*,3,3,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,3,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>',
     'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
     'fwd_lp_k7': 'k_conv_h<*,7,7,1,*> (pseudo-channel form)', 'dgrad_lp_k7': 'k_conv_h<*,7,7,1,*,1> + k_fold_x8',
@@ -142,6 +142,7 @@ def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
     med = float(np.median(ts))
     del model, real
     m1, r1 = _oracle_apollo(36, 1)
+    m1.step(r1)  # warm-up
     t0 = time.time()
     m1.step(r1)
     t1 = time.time() - t0
@@ -149,8 +150,10 @@ def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
     return dict(value=crop ** 3 / med, unit='voxels/s', cores=ncores, kind='port',
                 sample='Apollo optimize_parameters() on a %d^3 crop (oracle/apollo.py, torch-CPU fp32): 1 warm-up (%.1f s) + '
                        'median of %d steps = %.2f s/step on %d threads' % (crop, warm, reps, med, ncores),
-                one_thread=dict(value=36 ** 3 / t1, unit='voxels/s', cores=1,
-                                sample='1 step on a 36^3 crop, 1 thread, %.1f s (no warm-up)' % t1))
+                one_thread=dict(value=36 ** 3 / t1, unit='voxels/s', cores=1, workload='apollo_train_step_36cube_bs1',
+                                extrapolated=True,
+                                sample='EXTRAPOLATED from a 36^3 crop: 1 warm-up + 1 timed step on 1 thread = %.1f s (a 108^3 step on one '
+                                       'thread takes minutes); the per-voxel rate of the small crop stands in for the 108^3 one' % t1))
 
 
 def cpu_baseline_infer(budget_s=25.0, max_cubes=8):
@@ -209,13 +212,25 @@ def run_train(args, rank, world, dev):
         for opt in model.optimizers:
             dist.broadcast(opt.flat, 0)
     # synthetic uint16 crops (one per batch element), normalised as data/base_dataset.py:134-143
-    vols = [S.random_volume(100 + rank + 1000 * b, crop) for b in range(args.batch)]
+    if args.data == 'structured':  # configs[4]: crops of the structured ("OT-LSM-style") volume, one region per rank and batch element
+        big = S.structured_volume(9, 300)
+        rs = np.random.default_rng(100 + rank)
+        vols = []
+        for b in range(args.batch):
+            z, y, x = (int(rs.integers(0, 300 - crop + 1)) for _ in range(3))
+            vols.append(big[z:z + crop, y:y + crop, x:x + crop])
+    else:
+        vols = [S.random_volume(100 + rank + 1000 * b, crop) for b in range(args.batch)]
     real = torch.stack([torch.from_numpy((v.astype(np.float64) / 65535.0).astype(np.float32))[None] for v in vols]).to(dev)
     data = {'A': real, 'A_paths': 'synthetic'}
+
+    first = {}
 
     def step():
         model.set_input(data)
         model.optimize_parameters()
+        if not first:  # losses of the very first step from the seeded initial weights: comparable between runs of different length
+            first.update({k: round(v, 5) for k, v in model.get_current_losses().items()})
 
     for _ in range(args.warmup):
         step()
@@ -270,7 +285,7 @@ def run_train(args, rank, world, dev):
     losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
     return dt, crop ** 3 * args.batch * args.steps * world, roof, dict(
         workload='%s_train_step_%dcube_bs%d' % (args.model, crop, args.batch), crop=crop, batch_size=args.batch,
-        parallelism='dp%d' % world, gan_mode='lsgan', norm='instance', losses=losses)
+        parallelism='dp%d' % world, gan_mode='lsgan', norm='instance', data=args.data, first_step_losses=dict(first), losses=losses)
 
 
 GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
@@ -373,6 +388,9 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp16'],
                     help='arithmetic of the 3^3/5^3 convolutions; the headline is fp32 (the reference), bf16/fp16 = configs[3]')
     ap.add_argument('--volume', type=int, default=900)
+    ap.add_argument('--data', default='random', choices=['random', 'structured'],
+                    help='training crops: uniform uint16 noise (the north star\'s "synthetic random volumes") or crops of the structured '
+                         'volume of SURVEY.md 8d (seed.structured_volume; configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP events (A/B runs)')
     ap.add_argument('--prof-all', action='store_true',
@@ -426,8 +444,12 @@ def main():
         _ops.set_conv_split(False)
         try:
             dt2, units2, _, cfg2 = run_train(a2, rank, world, dev)
+            f1, f2 = cfg['first_step_losses'], cfg2['first_step_losses']
             out['fp32_mfma_kernels'] = dict(ms_per_step=dt2 / a2.steps * 1e3, value=units2 / dt2, unit='voxels/s', steps=a2.steps,
-                                            losses=cfg2['losses'])
+                                            first_step_losses=f2,  # same seeds, same data: an in-line A/B of the two kernel sets
+                                            first_step_max_rel_diff=max(abs(f1[k] - f2[k]) / max(abs(f2[k]), 1e-12) for k in f2),
+                                            note='losses after %d steps differ from the main run\'s after %d: compare first_step_losses' % (
+                                                a2.steps + a2.warmup, args.steps + args.warmup))
         finally:
             _ops.set_conv_split(True)
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline

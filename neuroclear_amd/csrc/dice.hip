@@ -27,8 +27,13 @@ __host__ __device__ inline int pad_len(int L, int roi, int overlap) {
 // ---- "clean rotation" training augmentation on the device (reference data/base_dataset.py:306-460): every z-slice is
 //      rotated about its centre (cv2.warpAffine, bilinear, zero border) and cropped to the inscribed rectangle; the
 //      reference rotates the WHOLE volume on the host for every training crop.  Here only the voxels of the requested
-//      crop are produced: out[z][y][x] = bilinear(vol[z0 + z], inv * (x0 + x, y0 + y, 1)), rounded to the source integer
+//      crop are produced: out[z][y][x] = warpAffine-bilinear(vol[z0 + z], inv * (x0 + x, y0 + y, 1)), rounded to the source integer
 //      type and normalised (/65535 or /255 in fp64, then fp32) exactly like the crop-only path.
+// The sampling arithmetic is cv2.warpAffine's (flags = INTER_LINEAR, BORDER_CONSTANT 0) as OpenCV 4.5.0 publishes it
+// (modules/imgproc/src/imgwarp.cpp: WarpAffineInvoker + remapBilinear + initInterTab2D): m = the canvas -> source matrix warpAffine
+// derives from the forward one (host: data/rotation.py).  Coordinates are fixed point: cvRound of the column term and of the row term at
+// 2^-10 each, + 2^4, >> 5 -> 5 fractional bits; uint8 blends with the 15-bit integer weights 32 (32 - fy)(32 - fx) ... and a rounding
+// shift, uint16 with the float weights (1 - fy/32)(1 - fx/32) ... in float32, products and sums left to right, then cvRound + saturation.
 template <typename T>
 __global__ void k_rotate_crop(const T* __restrict__ vol, int H, int W, int z0, int y0, int x0, int cz, int cy, int cx,
                               double m00, double m01, double m02, double m10, double m11, double m12, double den,
@@ -37,18 +42,29 @@ __global__ void k_rotate_crop(const T* __restrict__ vol, int H, int W, int z0, i
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % cx), y = (int)((i / cx) % cy), z = (int)(i / ((long)cx * cy));
     const double dx = (double)(x0 + x), dy = (double)(y0 + y);
-    const double sx = m00 * dx + m01 * dy + m02, sy = m10 * dx + m11 * dy + m12;
-    const double fx = floor(sx), fy = floor(sy);
-    const double ax = sx - fx, ay = sy - fy;
-    const long ix = (long)fx, iy = (long)fy;
+    const int ad = (int)rint(m00 * dx * 1024.0), bd = (int)rint(m10 * dx * 1024.0);
+    const int X0 = (int)rint((m01 * dy + m02) * 1024.0) + 16, Y0 = (int)rint((m11 * dy + m12) * 1024.0) + 16;
+    const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;  // arithmetic shifts: floor for negative coordinates, as in OpenCV
+    const int ix = X >> 5, iy = Y >> 5, fx = X & 31, fy = Y & 31;
     const T* sl = vol + (long)(z0 + z) * H * W;
-    auto tap = [&](long yy, long xx) -> double {
-      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (double)sl[yy * W + xx] : 0.0;
+    auto tap = [&](int yy, int xx) -> unsigned {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)sl[(long)yy * W + xx] : 0u;
     };
-    double v = (tap(iy, ix) * (1.0 - ax) + tap(iy, ix + 1) * ax) * (1.0 - ay) +
-               (tap(iy + 1, ix) * (1.0 - ax) + tap(iy + 1, ix + 1) * ax) * ay;
-    v = rint(v);
-    v = v < 0.0 ? 0.0 : (v > vmax ? vmax : v);
+    const unsigned v00 = tap(iy, ix), v01 = tap(iy, ix + 1), v10 = tap(iy + 1, ix), v11 = tap(iy + 1, ix + 1);
+    double v;
+    if (sizeof(T) == 1) {
+      const int w00 = 32 * (32 - fy) * (32 - fx), w01 = 32 * (32 - fy) * fx, w10 = 32 * fy * (32 - fx), w11 = 32 * fy * fx;
+      const int r = (int)(v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+      v = (double)(r < 0 ? 0 : r > 255 ? 255 : r);
+    } else {
+      const float cy0 = 1.f - (float)fy * 0.03125f, cy1 = (float)fy * 0.03125f, cx0 = 1.f - (float)fx * 0.03125f, cx1 = (float)fx * 0.03125f;
+      float r = __fmul_rn((float)v00, __fmul_rn(cy0, cx0));
+      r = __fadd_rn(r, __fmul_rn((float)v01, __fmul_rn(cy0, cx1)));
+      r = __fadd_rn(r, __fmul_rn((float)v10, __fmul_rn(cy1, cx0)));
+      r = __fadd_rn(r, __fmul_rn((float)v11, __fmul_rn(cy1, cx1)));
+      v = (double)rintf(r);
+      v = v < 0.0 ? 0.0 : (v > vmax ? vmax : v);
+    }
     out[i] = (float)(v / den);
   }
 }

@@ -1,7 +1,9 @@
 """Rotation augmentation.  CPU: the product's geometry (neuroclear_amd/data/rotation.py) against
-the oracle's restatement (oracle/rotate.py) and closed-form cases.  GPU: nc_rotate_crop through SingleVolumeDataset
-against the oracle's numpy warp -- the interpolation itself is parity-UNPINNED against OpenCV (not installed here), see
-the headers of both modules."""
+the oracle's restatement (oracle/rotate.py), reference-generated rectangles and closed-form cases; the oracle's restatement of
+cv2.warpAffine's INTER_LINEAR arithmetic (OpenCV 4.5.0: 10 + 5 bit fixed-point coordinates, weights in 1/32 steps, integer blend for
+uint8, float32 blend for uint16) against known answers that follow from the published algorithm by hand.  GPU: nc_rotate_crop through
+SingleVolumeDataset against that restatement, BIT FOR BIT.  (OpenCV cannot be installed here: "restated from the published algorithm",
+not pinned by cv2 outputs.)"""
 import random
 from argparse import Namespace
 
@@ -58,6 +60,57 @@ def test_geometry_closed_form():
     assert abs(int(r.astype(np.int64).sum()) - int(v.astype(np.int64).sum())) <= 0.05 * v.astype(np.int64).sum()
 
 
+def test_warp_affine_known_answers():
+    """Cases whose cv2.warpAffine result follows from the published algorithm without running it.  With X = (cvRound(1024 (M' x
+    terms)) + 16) >> 5 a source coordinate is rounded to the NEAREST 1/32 (ties up), and the weights are exactly (1 - f), f in 1/32 steps."""
+    rng = np.random.default_rng(8)
+    for dtype in (np.uint8, np.uint16):
+        hi = np.iinfo(dtype).max
+        src = rng.integers(0, hi + 1, (9, 14)).astype(dtype)
+        eye = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+        assert np.array_equal(orot.warp_affine_cv(src, eye, 0, 0, 9, 14), src)
+        # integer shift (+3, -2): dst(x, y) = src(x - 3, y + 2), zero outside
+        sh = orot.warp_affine_cv(src, np.array([[1.0, 0, 3], [0, 1.0, -2]]), 0, 0, 9, 14)
+        want = np.zeros_like(src)
+        want[:7, 3:] = src[2:, :11]
+        assert np.array_equal(sh, want)
+        # half a pixel to the right: f = 16/32 on the pair (x - 1, x); uint16 rounds the float sum half-to-even, uint8 adds 2^14 and shifts
+        half = orot.warp_affine_cv(src, np.array([[1.0, 0, 0.5], [0, 1.0, 0]]), 0, 0, 9, 14)
+        a = np.concatenate([np.zeros((9, 1), np.int64), src[:, :-1].astype(np.int64)], axis=1)
+        b = src.astype(np.int64)
+        want = (a + b + 1) // 2 if dtype == np.uint8 else np.rint((a + b) / 2.0).astype(np.int64)
+        assert np.array_equal(half.astype(np.int64), want)
+        # 1/64 of a pixel: the source coordinate x - 1/64 is a tie between x - 1/32 and x and rounds up to x (no interpolation) ...
+        assert np.array_equal(orot.warp_affine_cv(src, np.array([[1.0, 0, 1.0 / 64], [0, 1.0, 0]]), 0, 0, 9, 14), src)
+        # ... while x + 1/64 rounds up to x + 1/32: weights 31/32 and 1/32 on (x, x + 1)
+        q = orot.warp_affine_cv(src, np.array([[1.0, 0, -1.0 / 64], [0, 1.0, 0]]), 0, 0, 9, 14)
+        nxt = np.concatenate([src[:, 1:].astype(np.int64), np.zeros((9, 1), np.int64)], axis=1)
+        if dtype == np.uint8:
+            want = (b * (32 * 32 * 31) + nxt * (32 * 32) + (1 << 14)) >> 15
+        else:
+            want = np.rint((b.astype(np.float32) * np.float32(31 / 32) + nxt.astype(np.float32) * np.float32(1 / 32)).astype(np.float64)).astype(np.int64)
+        assert np.array_equal(q.astype(np.int64), want)
+        # a quarter turn moves samples without interpolating.  The reference turns about (w/2, h/2) -- half a pixel off the centre of the
+        # pixel grid -- so the turned image lands one row low: row 0 is border, the rest is np.rot90 without its last row
+        sq = rng.integers(0, hi + 1, (12, 12)).astype(dtype)
+        plan = orot.clean_rotation_plan(12, 12, 90)
+        r = orot.warp_affine_cv(sq, plan['affine'], 0, 0, plan['new_h'], plan['new_w'])
+        assert r.shape == (12, 12) and not r[0].any() and np.array_equal(r[1:], np.rot90(sq)[:-1])
+    # the fixed-point result stays next to the textbook bilinear value: coordinates are off by at most 1/64 pixel per axis
+    v = (rng.random((1, 40, 60)) * 65535).astype(np.uint16)
+    plan = orot.clean_rotation_plan(40, 60, 33)
+    x1, y1, x2, y2 = plan['rect']
+    fixed = orot.warp_affine_cv(v[0], plan['affine'], x1, y1, y2 - y1, x2 - x1).astype(np.float64)
+    exact = orot.warp_bilinear(v[0], plan['inv'], x1, y1, y2 - y1, x2 - x1).astype(np.float64)
+    assert np.abs(fixed - exact).max() < 65535 * 2 / 64 and not np.array_equal(fixed, exact)
+
+
+def test_product_inverse_is_warp_affines():
+    for h, w, ang in ((40, 60, 33), (108, 108, 271), (33, 17, 5)):
+        inv, _ = rotation.rotate_clean_plan(h, w, ang)
+        assert np.array_equal(inv, orot.cv_invert_affine(orot.clean_rotation_plan(h, w, ang)['affine'])), (h, w, ang)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('mode,dtype', [('random3Drotate', np.uint16), ('random3Drotate', np.uint8),
                                         ('random90rotate', np.uint16)])
@@ -83,7 +136,5 @@ def test_rotated_crop_on_device(mode, dtype):
         y = random.randint(0, rot.shape[1] - 16)
         x = random.randint(0, rot.shape[2] - 20)
         ref = (rot[z:z + 12, y:y + 16, x:x + 20] / float(np.iinfo(dtype).max)).astype(np.float32)
-        err = np.abs(got[0, 0].cpu().numpy() - ref) * np.iinfo(dtype).max
-        # identical arithmetic (fp64 bilinear, round-half-even) on both sides: at most a tie broken differently
-        assert err.max() <= 1.0 + 1e-3, (angle, err.max())
-        assert (err > 1e-3).mean() < 1e-3
+        # the same fixed-point arithmetic on both sides (cv2.warpAffine's, restated): bit for bit
+        assert np.array_equal(got[0, 0].cpu().numpy(), ref), (angle, float(np.abs(got[0, 0].cpu().numpy() - ref).max() * np.iinfo(dtype).max))
