@@ -132,6 +132,12 @@ int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, cons
 size_t nc_instnorm_bwd_dbias_ws_bytes(int NC, long S);
 int nc_instnorm_act_bwd_dbias(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
+/* The same backward with dx delivered ONLY as an S3 tensor [N][C/8][3][S][8] bf16 (the three-term operand form of the split-operand
+ * convolutions, nc_to_s3): dx is the dY of the convolution in front of the norm, and when that convolution's gradients run on the
+ * split-operand kernels nothing else reads it (nc_unet_deconv_bwd writes it straight into the convolution's workspace).  Values are bit
+ * for bit those nc_instnorm_act_bwd_dbias stores; C % 8 == 0, S > 2048 (longer than the short-instance path), N * C <= 65535. */
+int nc_instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs, float* dbias,
+                                 int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 /* The normalise + activate pass and its backward for the 16-bit convolution path: next to the fp32 result they emit it
  * in the C8 operand layout (nc_to_c8) of the convolution that consumes it -- yh for the next layer's forward, dxh (the
  * gradient at the previous convolution's output) for its data / weight gradient -- which saves those conversion passes.
@@ -201,6 +207,11 @@ int nc_assemble_scatter_add(const float* cube, float* acc, int P0, int P1, int P
                             int index, void* stream);
 int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2,
                          int roi, int overlap, void* stream);
+/* The same for planes [z0, z0 + nz) of the volume: acc_slab holds the PADDED planes from za (<= z0) on, out [nz][L1][L2] (sharded
+ * inference: every rank finalises the z-slab it owns, neuroclear_amd/test_dice.py assemble='slab').  nc_assemble_scatter_add adds into
+ * such a slab when it is given the slab's address minus za * P1 * P2 floats (it only touches the planes of its cube). */
+int nc_assemble_finalize_slab(const float* acc_slab, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2, int roi,
+                              int overlap, int z0, int nz, int za, void* stream);
 
 /* ---- --normalize_intensity (util/assemble_dice.py:188-192): merged = (acc / count) * 8 on the padded volume;
  *      nc_radix_hist = one pass of an exact radix select (order-preserving 32-bit key of a float: pass 0 bins key >> 20,

@@ -364,6 +364,47 @@ int conv_fwd_keep(const float* x, const float* w, const float* bias, float* y, i
   return nc_conv_fwd(x, w, bias, y, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2, ws, ws_bytes, stream);
 }
 
+// Does the 3^3 / 5^3 layer run forward AND weight gradient on the split-operand kernels (then producers may hand it its input in S3 form)?
+bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks) {
+  ConvDims d;
+  return make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) && fwd_path(d) == 9 && wgrad_path(d) == 9;
+}
+
+// forward of such a layer whose input already exists in S3 form (written by the producer: act_split3 / split3_into)
+int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks, void* ws,
+                 size_t ws_bytes, void* stream) {
+  ConvDims d;
+  if (!xs || !w || !y) { set_error("conv_fwd_pre: null pointer"); return NC_ERR_ARG; }
+  if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || fwd_path(d) != 9) { set_error("conv_fwd_pre: layer not on the split-operand kernels"); return NC_ERR_SHAPE; }
+  ProfScope ps(0, 9, d, 0, (hipStream_t)stream);
+  return conv_fwd_s3(nullptr, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+// Can the backward of the layer take dY in S3 form at the head of its workspace (conv_bwd_pre)?  want_dx: the data gradient is needed too
+bool conv_bwd_pre_supported(int N, int C, int D, int H, int W, int K, int ks, bool want_dx, size_t ws_bytes) {
+  ConvDims d;
+  return make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) && wgrad_path(d) == 9 && s3_bwd_ws_bytes(d) && ws_bytes >= s3_bwd_ws_bytes(d) &&
+         (!want_dx || dgrad_path(d) == 9);
+}
+// data (dx nullable) + weight gradient with dY ALREADY in S3 form at the start of ws (where conv_bwd_s3's conversion phase puts it);
+// xs (nullable): the layer's input in S3 form, else it is converted from x
+int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, float* dw, int N, int C, int D, int H, int W, int K, int ks,
+                 void* ws, size_t ws_bytes, void* stream) {
+  ConvDims d;
+  hipStream_t s = (hipStream_t)stream;
+  if (!conv_bwd_pre_supported(N, C, D, H, W, K, ks, dx != nullptr, ws_bytes) || !make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2)) {
+    set_error("conv_bwd_pre: layer not on the split-operand kernels");
+    return NC_ERR_SHAPE;
+  }
+  if ((!x && !xs) || !w || !dw || !ws) { set_error("conv_bwd_pre: null pointer"); return NC_ERR_ARG; }
+  if (dx) {
+    ProfScope ps(1, 9, d, 0, s);
+    if (int e = conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 1)) return e;
+  }
+  ProfScope ps(2, 9, d, 0, s);
+  return conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 2, xs);
+}
+
 int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* w, float* dx, float* dw, int N, int C, int D, int H,
                   int W, int K, int ks, void* ws, size_t ws_bytes, void* stream) {
   ConvDims d;

@@ -162,6 +162,16 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS);
 size_t s3x_packed_bytes(int Cin, int Kout, int KS);
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s);
+bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);
+int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks, void* ws,
+                 size_t ws_bytes, void* stream);
+bool conv_bwd_pre_supported(int N, int C, int D, int H, int W, int K, int ks, bool want_dx, size_t ws_bytes);
+int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, float* dw, int N, int C, int D, int H, int W, int K, int ks,
+                 void* ws, size_t ws_bytes, void* stream);
+// norm_act.hip: InstanceNorm + activation backward with dx written in S3 form only
+bool instnorm_bwd_s3_supported(int N, int C, long S);
+int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,

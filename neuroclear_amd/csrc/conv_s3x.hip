@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "s3_common.hpp"
 
 namespace nc {
 namespace {
@@ -52,21 +53,8 @@ constexpr int kMaxPieces = 56;  // 1 KiB pieces of a brick (three terms)
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
 unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
 
-__device__ __forceinline__ unsigned short bf16_bits(float f) {
-  const __bf16 v = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, v);
-}
-__device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
-__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {  // conv_split.hip split3
-  float a0 = bf16_val(v);
-  // a finite |v| above the largest finite bf16 (0x7F7F = 3.3895e38) rounds to infinity: take that largest bf16 instead, the remainders
-  // carry the rest exactly.  v = +-inf / NaN: a0 = v and the remainders are NaN -- a non-finite input gives NaN in every output it touches
-  if (__builtin_isinf(a0) && !__builtin_isinf(v)) a0 = __builtin_copysignf(3.3895313892515355e38f, v);
-  const float r1 = v - a0;
-  const float a1 = bf16_val(r1);
-  const float r2 = r1 - a1;
-  t[0] = bf16_bits(a0); t[1] = bf16_bits(a1); t[2] = bf16_bits(r2);
-}
+// (the split itself: s3_common.hpp)
+__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_split(v, t); }
 
 // Packed weights: [cot = co/64][half = (co/32)%2][k-step s][f = rb*3 + term][lane][8] bf16.  Lane l = (g = l/16, m = l%16) holds
 // output channel cot*64 + half*32 + rb*16 + m at tap T = 4s + g of the tile's tap stream: brick T / KS^2 = chunk*KS + dz,

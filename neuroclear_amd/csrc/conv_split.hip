@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "s3_common.hpp"
 
 namespace nc {
 NC_ZERO_PAGE()
@@ -59,23 +60,8 @@ __device__ __forceinline__ f32x16 mfma(const i32x4& a, const i32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ unsigned short bf16_bits(float f) {
-  const __bf16 v = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, v);
-}
-__device__ __forceinline__ float bf16_val(float f) { return (float)(__bf16)f; }
-
-// the three terms of an fp32 value (round to nearest each: the remainders are exact, the third term is exact)
-__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) {
-  float a0 = bf16_val(v);
-  // a finite |v| above the largest finite bf16 (0x7F7F = 3.3895e38) rounds to infinity: take that largest bf16 instead, the remainders
-  // carry the rest exactly.  v = +-inf / NaN: a0 = v and the remainders are NaN -- a non-finite input gives NaN in every output it touches
-  if (__builtin_isinf(a0) && !__builtin_isinf(v)) a0 = __builtin_copysignf(3.3895313892515355e38f, v);
-  const float r1 = v - a0;
-  const float a1 = bf16_val(r1);
-  const float r2 = r1 - a1;
-  t[0] = bf16_bits(a0); t[1] = bf16_bits(a1); t[2] = bf16_bits(r2);
-}
+// (the split itself: s3_common.hpp)
+__device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_split(v, t); }
 
 // fp32 NCDHW -> S3.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, three 16-byte stores.  The C
 // channels land at blocks ob0 .. ob0 + C/8 - 1 of an S3 tensor with `oblocks` blocks per sample (a half of a concat buffer).

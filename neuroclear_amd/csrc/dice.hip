@@ -122,6 +122,24 @@ __global__ void k_finalize(const float* __restrict__ acc, T* __restrict__ out, D
   }
 }
 
+// The same for a z-slab: planes [z0, z0 + nz) of the (un-padded) volume from an accumulator that holds the padded planes from `za`
+// on (multi-GPU inference: every rank finalises the slab it owns, test_dice.py assemble='slab').
+template <typename T>
+__global__ void k_finalize_slab(const float* __restrict__ acc, T* __restrict__ out, DiceGeom g, float scale, int z0, int nz, int za) {
+  const long total = (long)nz * g.L1 * g.L2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % g.L2), y = (int)((i / g.L2) % g.L1), z = z0 + (int)(i / ((long)g.L2 * g.L1));
+    float v = acc[((long)(z - za) * g.P1 + y) * g.P2 + x];
+    if (g.overlap > 0) {
+      const float cnt = (float)(cover_count(z, g.n0, g.step, g.roi) * cover_count(y, g.n1, g.step, g.roi) *
+                                cover_count(x, g.n2, g.step, g.roi));
+      v = (v / cnt) * 8;
+    }
+    v = v * scale;
+    out[i] = (T)v;
+  }
+}
+
 // ---- intensity normalisation of the assembled volume (reference util/assemble_dice.py:188-192: np.percentile over the
 //      merged, still padded volume, then skimage.exposure.rescale_intensity(in_range=(p_lo, p_hi))).
 //      k_merge: merged = (acc / count) * 8 over the padded volume.  k_radix_hist: one pass of an exact radix select on
@@ -269,6 +287,25 @@ int nc_assemble_finalize(const float* acc, void* out, int out_is_u16, int P0, in
   else
     hipLaunchKernelGGL(k_finalize<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc, (uint8_t*)out, g, 255.f);
   return check_launch("assemble_finalize");
+}
+
+int nc_assemble_finalize_slab(const float* acc_slab, void* out, int out_is_u16, int P0, int P1, int P2, int L0, int L1, int L2, int roi,
+                              int overlap, int z0, int nz, int za, void* stream) {
+  if (!acc_slab || !out) { set_error("assemble_finalize_slab: null pointer"); return NC_ERR_ARG; }
+  if (overlap < 1) { set_error("assemble_finalize_slab: overlap must be >= 1 (util/assemble_dice.py:170)"); return NC_ERR_SHAPE; }
+  DiceGeom g;
+  if (!make_geom(g, L0, L1, L2, roi, overlap, 1) || g.P0 != P0 || g.P1 != P1 || g.P2 != P2) {
+    set_error("assemble_finalize_slab: padded size does not match pad_for_dicing of the original size");
+    return NC_ERR_SHAPE;
+  }
+  if (z0 < 0 || nz < 1 || z0 + nz > L0 || za < 0 || za > z0) { set_error("assemble_finalize_slab: bad slab"); return NC_ERR_SHAPE; }
+  const long total = (long)nz * L1 * L2;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_u16)
+    hipLaunchKernelGGL(k_finalize_slab<uint16_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc_slab, (uint16_t*)out, g, 65535.f, z0, nz, za);
+  else
+    hipLaunchKernelGGL(k_finalize_slab<uint8_t>, dim3(flat_grid(total)), dim3(256), 0, s, acc_slab, (uint8_t*)out, g, 255.f, z0, nz, za);
+  return check_launch("assemble_finalize_slab");
 }
 
 int nc_assemble_merge(const float* acc, float* merged, int L0, int L1, int L2, int roi, int overlap, void* stream) {

@@ -10,6 +10,8 @@
 // Parameter blob = the tensors in state-dict order, packed back to back.  `saved` receives what the
 // backward needs (raw conv outputs, activations, InstanceNorm statistics); sizes from the *_saved_floats queries.
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace nc;
@@ -149,18 +151,42 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   float* V = saved;
   const float* P = params;
   if (kept) *kept = 0;
+  hipStream_t hs = (hipStream_t)stream;
+  // Which blocks run on the split-operand kernels (forward and weight gradient)?  Their input is wanted in S3 form, and the producer of
+  // that input -- the normalisation + ReLU pass of the block in front, or the conversion of a transposed convolution's output -- writes
+  // the S3 form straight into the consumer's slot of `saved` (xs3[i]) instead of a separate conversion pass over the fp32 tensor
+  // (k_act_split3; a block fed by a max-pool still converts inside conv_fwd_keep).  NC_S3_TRAIN_FUSE=0: every block converts for itself.
+  static const bool fuse_on = !(getenv("NC_S3_TRAIN_FUSE") && atoi(getenv("NC_S3_TRAIN_FUSE")) == 0);
+  bool use[10], pre[10];
+  for (int i = 0; i < 10; ++i) {
+    const UBlock& b = kUB[i];
+    const int* d = p.d[b.lvl];
+    use[i] = fuse_on && i >= 1 && conv_keep_supported(N, b.C, d[0], d[1], d[2], b.K, 3);
+    pre[i] = false;
+  }
   // conv (3^3, pad 1) -> raw; statistics; normalise + ReLU into `out`, where sample n's K planes start at
-  // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer)
+  // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer).
+  // to >= 0: block `to` consumes this output as channels [0, K) of its `to_ctot`-channel input
   unsigned kept_mask = 0;
-  auto block = [&](int i, const float* in, float* out, size_t out_stride) -> int {
+  auto block = [&](int i, const float* in, float* out, size_t out_stride, int to, int to_ctot) -> int {
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     const long S = p.S[b.lvl];
-    bool kept = false;
-    NC_TRY(conv_fwd_keep(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream,
-                         i >= 1 ? (void*)(V + p.xs3[i]) : nullptr, &kept));
-    if (kept) kept_mask |= 1u << i;
+    if (pre[i]) {  // the producers left the S3 input in saved
+      NC_TRY(conv_fwd_pre(V + p.xs3[i], P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream));
+      kept_mask |= 1u << i;
+    } else {
+      bool kept1 = false;
+      NC_TRY(conv_fwd_keep(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream,
+                           i >= 1 ? (void*)(V + p.xs3[i]) : nullptr, &kept1));
+      if (kept1) kept_mask |= 1u << i;
+    }
     NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
+    if (to >= 0 && use[to]) {  // fp32 (the backward of the pool / the fallback paths read it) AND the consumer's S3 operand in one pass
+      NC_TRY(act_split3(V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, (long)out_stride, V + p.xs3[to], N, b.K, S, to_ctot, 0, hs));
+      if (to_ctot == b.K) pre[to] = true;  // (a concat input is complete once its second half has been converted, below)
+      return NC_OK;
+    }
     if (out_stride == (size_t)b.K * S || N == 1)
       return nc_instnorm_act_fwd(V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, N * b.K, S, stream);
     for (int n = 0; n < N; ++n)
@@ -170,26 +196,34 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   };
   const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
-  NC_TRY(block(0, x, V + p.a1, (size_t)64 * S));
-  NC_TRY(block(1, V + p.a1, V + p.cat1, (size_t)128 * S));
+  NC_TRY(block(0, x, V + p.a1, (size_t)64 * S, 1, 64));
+  NC_TRY(block(1, V + p.a1, V + p.cat1, (size_t)128 * S, 9, 128));
   for (int n = 0; n < N; ++n)
     NC_TRY(nc_maxpool2_fwd(V + p.cat1 + (size_t)n * 128 * S, V + p.p1 + (size_t)n * 64 * Sh, 64, d0[0], d0[1], d0[2], stream));
-  NC_TRY(block(2, V + p.p1, V + p.a2, (size_t)128 * Sh));
-  NC_TRY(block(3, V + p.a2, V + p.cat2, (size_t)256 * Sh));
+  NC_TRY(block(2, V + p.p1, V + p.a2, (size_t)128 * Sh, 3, 128));
+  NC_TRY(block(3, V + p.a2, V + p.cat2, (size_t)256 * Sh, 7, 256));
   for (int n = 0; n < N; ++n)
     NC_TRY(nc_maxpool2_fwd(V + p.cat2 + (size_t)n * 256 * Sh, V + p.p2 + (size_t)n * 128 * Sq, 128, d1[0], d1[1], d1[2], stream));
-  NC_TRY(block(4, V + p.p2, V + p.b1, (size_t)256 * Sq));
-  NC_TRY(block(5, V + p.b1, V + p.b2, (size_t)256 * Sq));
-  NC_TRY(block(6, V + p.b2, V + p.b3, (size_t)256 * Sq));
+  NC_TRY(block(4, V + p.p2, V + p.b1, (size_t)256 * Sq, 5, 256));
+  NC_TRY(block(5, V + p.b1, V + p.b2, (size_t)256 * Sq, 6, 256));
+  NC_TRY(block(6, V + p.b2, V + p.b3, (size_t)256 * Sq, -1, 0));
   for (int n = 0; n < N; ++n)  // t_conv2 writes the second half of cat2
     NC_TRY(nc_convT_k2s2_fwd(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
                              1, 256, d2[0], d2[1], d2[2], 128, stream));
-  NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh));
-  NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh));
+  if (use[7]) {  // ... and its S3 form completes block 7's input (the first half came from block 3's normalisation pass)
+    NC_TRY(split3_into(V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
+    pre[7] = true;
+  }
+  NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh, 8, 128));
+  NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh, -1, 0));
   for (int n = 0; n < N; ++n)  // t_conv1 writes the second half of cat1
     NC_TRY(nc_convT_k2s2_fwd(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
                              1, 128, d1[0], d1[1], d1[2], 64, stream));
-  NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S));
+  if (use[9]) {
+    NC_TRY(split3_into(V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
+    pre[9] = true;
+  }
+  NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S, -1, 0));
   // the 1x1 tail
   NC_TRY(nc_conv_fwd(V + p.e1, P + o.w[12], P + o.b[12], V + p.t1, N, 64, d0[0], d0[1], d0[2], 1, 1, 1, 1, 1, 0, cws, p.conv_ws, stream));
   // one_by_one_2 + sigmoid: y doubles as the buffer of the pre-sigmoid value (the sigmoid kernel is elementwise in place)
@@ -218,16 +252,25 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
   const long S = p.S[0], Sh = p.S[1], Sq = p.S[2];
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
   const unsigned kept_mask = kept;
+  static const bool fuse_bwd = !(getenv("NC_S3_TRAIN_FUSE") && atoi(getenv("NC_S3_TRAIN_FUSE")) == 0) &&
+                               !(getenv("NC_S3_TRAIN_FUSE_BWD") && atoi(getenv("NC_S3_TRAIN_FUSE_BWD")) == 0);
   // backward of block i: g = gradient at the block's (post-ReLU) output, dense [N][K][S]; `in` = the block's input.
   // draw <- InstanceNorm/ReLU backward (+ the conv's bias gradient); dW <- wgrad; gin (nullable) <- dgrad
   auto block_bwd = [&](int i, const float* g, const float* in, float* draw, float* gin) -> int {
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     const long Sl = p.S[b.lvl];
+    const void* xs = (kept_mask >> i) & 1 ? (const void*)(V + p.xs3[i]) : nullptr;
+    // the norm's backward writes the convolution's dY straight in S3 form at the head of the convolution workspace (where the
+    // conversion phase of the split-operand backward would put it): no fp32 tensor, no conversion pass
+    if (fuse_bwd && i >= 1 && conv_bwd_pre_supported(N, b.C, d[0], d[1], d[2], b.K, 3, gin != nullptr, p.conv_ws) &&
+        instnorm_bwd_s3_supported(N, b.K, Sl)) {
+      NC_TRY(instnorm_act_bwd_dbias_s3(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
+      return conv_bwd_pre(in, xs, P + o.w[i], gin, DP + o.w[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
+    }
     NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
                                      p.in_ws, stream));
-    return conv_bwd_keep(in, (kept_mask >> i) & 1 ? (const void*)(V + p.xs3[i]) : nullptr, draw, P + o.w[i], gin, DP + o.w[i], N, b.C,
-                         d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
+    return conv_bwd_keep(in, xs, draw, P + o.w[i], gin, DP + o.w[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
   };
   // gradient of the second half of a concat buffer as a dense tensor
   auto upper_half = [&](const float* dcat, int Ctot, long Sl, const float** out) -> int {

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "s3_common.hpp"
 
 namespace nc {
 
@@ -131,6 +132,17 @@ __global__ __launch_bounds__(256) void k_in_bwd_sums(const float* __restrict__ d
   block_reduce2(s1, s2, part + ((long)inst * splits + sp) * 2);
 }
 
+// dx of InstanceNorm (affine = False) + (Leaky)ReLU for one element, with every rounding spelled out: the fp32, 16-bit (C8) and three-term (S3)
+// forms of this backward must store the SAME value (tests compare the whole-network calls with the layer-by-layer path bit for bit),
+// which the compiler's own choice of fused multiply-adds per kernel does not guarantee.
+__device__ __forceinline__ float in_bwd_value(float xv, float gy, float m, float r, float m1, float m2, float slope) {
+  const float xh = (xv - m) * r;
+  const float g = xh > 0.f ? gy : gy * slope;
+  float p = xh * m2;
+  asm("" : "+v"(p));  // (keeps the backend from fusing this product into the subtraction: hipcc contracts at -ffp-contract=fast)
+  return r * ((g - m1) - p);
+}
+
 __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       float slope, long S, int splits,
@@ -149,9 +161,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply(const float* __restrict__ 
   float* o = dx + (long)inst * S;
   double rs = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
-    const float xh = (px[i] - m) * r;
-    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
-    const float v = r * (g - m1 - xh * m2);
+    const float v = in_bwd_value(px[i], pg[i], m, r, m1, m2, slope);
     o[i] = v;
     rs += (double)v;
   }
@@ -265,9 +275,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_rows(const float* __restrict__ d
   double rs = 0.0;
 #pragma unroll 4
   for (int i = sub; i < S; i += G) {
-    const float xh = (px[i] - m) * r;
-    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
-    const float v = r * (g - m1 - xh * m2);
+    const float v = in_bwd_value(px[i], pg[i], m, r, m1, m2, slope);
     o[i] = v;
     rs += (double)v;
   }
@@ -379,9 +387,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_c8(const float* __restrict
     unsigned short e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = (px[j * S + v] - m[j]) * r[j];
-      const float g = xh > 0.f ? pg[j * S + v] : pg[j * S + v] * slope;
-      const float t = r[j] * (g - m1[j] - xh * m2[j]);
+      const float t = in_bwd_value(px[j * S + v], pg[j * S + v], m[j], r[j], m1[j], m2[j], slope);
       o[j * S + v] = t;
       rs[j] += (double)t;
       e[j] = cvt16n<DT>(t);
@@ -389,6 +395,62 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_c8(const float* __restrict
     dxh[ncb * S + v] = pack8(e);
   }
   if (rowpart) {  // per-channel sums of this block's share of dx (the convolution's bias gradient, see k_in_bwd_apply)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double a = rs[j];
+      for (int of = 32; of > 0; of >>= 1) a += __shfl_down(a, of);
+      if (lane == 0) red[j][wv] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      rowpart[(ncb * 8 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
+// The same backward with dx written ONLY in the three-term S3 layout of the split-operand convolutions (s3_common.hpp): dx is the dY
+// of the convolution in front of the norm, and when that convolution's gradients run on the split-operand kernels nothing else reads
+// it -- no fp32 tensor, no separate conversion pass.  Arithmetic and partial-sum order are k_in_bwd_apply's (the same voxels per
+// thread, the same reduction tree per channel): the values split here are bit for bit the values the fp32 pass would have stored.
+__global__ __launch_bounds__(256) void k_in_bwd_apply_s3(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float slope, long S, int splits, const double* __restrict__ part,
+                                                         uint4* __restrict__ dxs, int cblocks, double* __restrict__ rowpart) {
+  __shared__ float sm[2][8];
+  __shared__ double red[8][4];
+  const long ncb = blockIdx.y;
+  if (threadIdx.x < 8) {
+    const long inst = ncb * 8 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < splits; ++k) {
+      s1 += part[(inst * splits + k) * 2];
+      s2 += part[(inst * splits + k) * 2 + 1];
+    }
+    sm[0][threadIdx.x] = (float)(s1 / (double)S);
+    sm[1][threadIdx.x] = (float)(s2 / (double)S);
+  }
+  __syncthreads();
+  float m[8], r[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = mean[ncb * 8 + j]; r[j] = rstd[ncb * 8 + j]; m1[j] = sm[0][j]; m2[j] = sm[1][j]; }
+  const float* px = x + ncb * 8 * S;
+  const float* pg = dy + ncb * 8 * S;
+  double rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rs[j] = 0.0;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    unsigned short e[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = in_bwd_value(px[j * S + v], pg[j * S + v], m[j], r[j], m1[j], m2[j], slope);
+      rs[j] += (double)t;
+      s3_split(t, e[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dxs[(ncb * 3 + t) * S + v] = s3_unit(e, t);  // [N][C/8][3][S] units: block index ncb = n * C/8 + cb
+  }
+  if (rowpart) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -651,6 +713,36 @@ int nc_instnorm_act_bwd_c8(const float* dy, const float* x, const float* mean, c
                        (const double*)ws, dx, (uint4*)dxh, rowpart);
   if (dbias) hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
   return check_launch("instnorm_act_bwd_c8");
+}
+
+}  // extern "C"
+namespace nc {
+// nc_instnorm_act_bwd_dbias with dx delivered as an S3 tensor [N][C/8][3][S][8] bf16 (gen_nets.hip: the dY of a split-operand
+// convolution).  false: this shape takes the short-instance path, which has no S3 form (the caller uses the fp32 entry point).
+bool instnorm_bwd_s3_supported(int N, int C, long S) { return N >= 1 && C >= 8 && C % 8 == 0 && S >= 1 && !rows_path(S) && (long)N * C <= 65535; }
+int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !dxs || !dbias) { set_error("instnorm_act_bwd_dbias_s3: null pointer"); return NC_ERR_ARG; }
+  if (!instnorm_bwd_s3_supported(N, C, S)) { set_error("instnorm_act_bwd_dbias_s3: bad shape"); return NC_ERR_SHAPE; }
+  const int NC = N * C;
+  if (!ws || ws_bytes < nc_instnorm_bwd_dbias_ws_bytes(NC, S)) { set_error("instnorm_act_bwd_dbias_s3: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(NC, S);
+  hipLaunchKernelGGL(k_in_bwd_sums, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws);
+  long bx = cdiv(S, 1024);
+  if (bx > 1024) bx = 1024;
+  double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
+  hipLaunchKernelGGL(k_in_bwd_apply_s3, dim3((unsigned)bx, (unsigned)(NC / 8)), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                     (const double*)ws, (uint4*)dxs, C / 8, rowpart);
+  hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
+  return check_launch("instnorm_act_bwd_dbias_s3");
+}
+}  // namespace nc
+extern "C" {
+
+int nc_instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs, float* dbias,
+                                 int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
+  return instnorm_act_bwd_dbias_s3(dy, x, mean, rstd, slope, dxs, dbias, N, C, S, ws, ws_bytes, stream);
 }
 
 int nc_leaky_relu_fwd(const float* x, float slope, float* y, long n, void* stream) {

@@ -9,6 +9,11 @@ i % world (cubes are independent units; no data-path collective is needed to COM
     accumulator on its own GPU, then one RCCL reduce(sum) to rank 0 -- no per-round synchronisation, no tile traffic.
     fp32 addition order then differs from the reference's sequential index order (util/assemble_dice.py:167-173) by
     <= 1 ulp per voxel, which can flip the truncating integer cast by 1 LSB (tolerance +-1 LSB, SURVEY.md 8e);
+  * assemble='slab' (default for world > 1): rank r computes a CONTIGUOUS range of cubes (z-major numbering: two or three z-layers)
+    into an accumulator that holds only those planes; one point-to-point exchange hands every rank the contributions to the z-slab
+    it OWNS (1/world of the padded volume), which it finalises (/ count, x 65535, truncating cast) itself; the uint16 slabs are
+    gathered on rank 0.  No rank holds or receives a whole fp32 volume (assemble='reduce' moved 7 x 3.5 GB into rank 0 for 900^3
+    on 8 GPUs; this moves ~1 GB between neighbours and 1.46 GB of uint16 to rank 0).  Same +-1 LSB note as 'reduce';
   * assemble='gather': lock-step rounds, each round's tiles gathered to rank 0 and overlap-added there in index order
     -- bit-identical to the single-GPU / reference result; the verification mode.
 `main()` keeps the reference's command line for the flags that matter on this path."""
@@ -66,6 +71,78 @@ def sharded_cube_loop_reduce(n, rank, world, produce, add_local, accumulator):
         dist.reduce(accumulator(), dst=0, op=dist.ReduceOp.SUM)
 
 
+def slab_plan(steps, step, roi, P0, world):
+    """assemble='slab': who computes which cubes, which planes that leaves in each rank's local accumulator, and which planes of the
+    padded volume each rank OWNS (finalises and ships).  Cubes are numbered z-major, so rank r's contiguous share
+    [n r / world, n (r + 1) / world) covers two or three z-layers of cubes (<= 1 cube of imbalance; 729 cubes on 8 ranks: 91 or 92
+    each); the owner slabs cut the padded z axis into `world` equal ranges.  Pure arithmetic: every rank computes the same plan."""
+    nz, ny, nx = steps
+    n = nz * ny * nx
+    cubes = [(r * n // world, (r + 1) * n // world) for r in range(world)]
+    local = []
+    for a, b in cubes:
+        local.append((0, 0) if a == b else ((a // (ny * nx)) * step, ((b - 1) // (ny * nx)) * step + roi))
+    own = [(r * P0 // world, (r + 1) * P0 // world) for r in range(world)]
+    return dict(cubes=cubes, local=local, own=own)
+
+
+def slab_exchange(rank, world, plan, local_acc, own_acc):
+    """The one exchange step of assemble='slab' (device-free: gloo on CPU, RCCL over xGMI on the GPUs): every rank sends each owner
+    the planes of its local accumulator that fall into the owner's slab -- point-to-point pieces to at most three neighbours, nothing to
+    a root -- and adds what it receives into `own_acc` in ascending source-rank order (its own share in its turn: deterministic).
+    local_acc [local planes, P1, P2] starts at plane plan['local'][rank][0]; own_acc [owned planes, P1, P2] must be zero."""
+    import torch.distributed as dist
+
+    def overlap(a, b):
+        lo, hi = max(a[0], b[0]), min(a[1], b[1])
+        return (lo, hi) if lo < hi else None
+    ops, recv = [], {}
+    for src in range(world):
+        for dst in range(world):
+            ov = overlap(plan['local'][src], plan['own'][dst])
+            if ov is None or src == dst:
+                continue
+            if rank == src:
+                piece = local_acc[ov[0] - plan['local'][src][0]:ov[1] - plan['local'][src][0]].contiguous()
+                ops.append(dist.P2POp(dist.isend, piece, dst))
+            elif rank == dst:
+                buf = torch.empty((ov[1] - ov[0],) + tuple(own_acc.shape[1:]), dtype=own_acc.dtype, device=own_acc.device)
+                recv[src] = (ov, buf)
+                ops.append(dist.P2POp(dist.irecv, buf, src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    o0 = plan['own'][rank][0]
+    for src in range(world):
+        if src == rank:
+            ov = overlap(plan['local'][rank], plan['own'][rank])
+            if ov is not None:
+                own_acc[ov[0] - o0:ov[1] - o0] += local_acc[ov[0] - plan['local'][rank][0]:ov[1] - plan['local'][rank][0]]
+        elif src in recv:
+            ov, buf = recv[src]
+            own_acc[ov[0] - o0:ov[1] - o0] += buf
+
+
+def slab_gather(rank, world, plan, out_slab, L0, dst=0):
+    """The finalised integer slabs (planes own & [0, L0)) travel to rank `dst`: 2 bytes per voxel instead of the fp32 accumulators of
+    assemble='reduce'.  Returns the list of slabs in rank order on `dst`, None elsewhere."""
+    import torch.distributed as dist
+    sizes = [max(0, min(b, L0) - min(a, L0)) for a, b in plan['own']]
+    if rank != dst:
+        if sizes[rank]:
+            dist.send(out_slab.contiguous(), dst)
+        return None
+    parts = []
+    for r in range(world):
+        if r == dst:
+            parts.append(out_slab)
+        elif sizes[r]:
+            buf = torch.empty((sizes[r],) + tuple(out_slab.shape[1:]), dtype=out_slab.dtype, device=out_slab.device)
+            dist.recv(buf, r)
+            parts.append(buf)
+    return parts
+
+
 def broadcast_parameters(net, src=0):
     """One broadcast of the packed parameter blob (state-dict order) from rank `src`; every rank then holds identical
     weights.  A no-op without an initialised process group."""
@@ -90,21 +167,33 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     with_real: also assemble the input cubes (the reference's 'real' visual, test_dice.py without --skip_real) and return
     (fake, real); the dice -> assemble round trip of the input is the input up to 1 LSB of the truncating cast."""
     if assemble is None:
-        assemble = 'reduce' if world > 1 else 'gather'
-    if assemble not in ('reduce', 'gather'):
-        raise ValueError("assemble must be 'reduce' or 'gather'")
+        assemble = ('reduce' if with_real else 'slab') if world > 1 else 'gather'
+    if assemble not in ('reduce', 'gather', 'slab'):
+        raise ValueError("assemble must be 'slab', 'reduce' or 'gather'")
+    if assemble == 'slab' and (with_real or getattr(opt, 'normalize_intensity', False)):
+        raise NotImplementedError("assemble='slab' finalises per rank: use assemble='reduce' with --normalize_intensity (percentiles of the "
+                                  "whole volume) or with_real")
     if broadcast and world > 1:
         broadcast_parameters(netG, 0)
     ds = DiceImageDataSet(opt, volume=volume)
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
-    local_acc = assemble == 'reduce' or rank == 0
+    local_acc = assemble in ('reduce', 'slab') or rank == 0
     if with_real and assemble == 'gather' and world > 1:
         raise NotImplementedError("with_real needs assemble='reduce' when sharded")
+    plan = None
+    if assemble == 'slab':
+        from .util import util as U
+        size0 = ds.size_original()
+        padded = U.padded_shape(size0, opt.dice_size[0], opt.overlap)
+        steps = U.grid_steps(padded, opt.dice_size[0], opt.overlap)
+        plan = slab_plan(steps, opt.dice_size[0] - opt.overlap, opt.dice_size[0], padded[0], world)
+        if max_cubes is not None:  # warm-up runs: the first cubes of every rank's own range
+            plan['cubes'] = [(a, min(b, a + max(1, max_cubes // world))) for a, b in plan['cubes']]
     if with_real:
         import copy
         opt = copy.copy(opt)
         opt.skip_real = False
-    asm = Assemble_Dice(opt, ds.size_original()) if local_acc else None
+    asm = Assemble_Dice(opt, ds.size_original(), slab=plan['local'][rank] if plan else None) if local_acc else None
     E = opt.dice_size[0] + 2 * opt.border_cut
     hm = bool(getattr(opt, 'histogram_match', False))  # the producing rank matches its own cube (it holds the input)
 
@@ -115,7 +204,7 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     # 2: 2.87, 3: 2.69, 4: 2.70, 6: 3.61 (the working sets of six cubes no longer share the caches).  Not in the lock-step gather
     # rounds of world > 1 (the tiles go straight into a collective there).
     nstreams = int(os.environ.get('NC_INFER_STREAMS', '3'))
-    piped = ds.device.type == 'cuda' and nstreams > 1 and (world == 1 or assemble == 'reduce')
+    piped = ds.device.type == 'cuda' and nstreams > 1 and (world == 1 or assemble in ('reduce', 'slab'))
     main = torch.cuda.current_stream(ds.device) if piped else None
     side = _side_streams(ds.device, nstreams) if piped else []
     for st in side:
@@ -154,6 +243,19 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
         asm.add_cube('fake', tile, j)
 
     with torch.no_grad():
+        if assemble == 'slab':
+            a, b = plan['cubes'][rank]
+            for i in range(a, b):
+                add_fake(i, produce(i))
+            o0, o1 = plan['own'][rank]
+            own = torch.zeros((o1 - o0,) + tuple(asm.image_size[1:]), dtype=torch.float32, device=ds.device)
+            slab_exchange(rank, world, plan, asm.acc['fake'], own)
+            out_slab = asm.finalize_slab(own, o0, o1)
+            parts = slab_gather(rank, world, plan, out_slab, asm.image_size_original[0])
+            if rank != 0:
+                return None
+            host = torch.cat(parts, 0).cpu().numpy()
+            return host.view(np.uint16) if asm.imtype == 'uint16' else host
         if assemble == 'reduce':
             sharded_cube_loop_reduce(n, rank, world, produce, add_local=add_fake, accumulator=lambda: asm.acc['fake'])
             if with_real and world > 1:

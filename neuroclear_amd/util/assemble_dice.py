@@ -47,8 +47,10 @@ def match_cube(fake, real, roi_size, border_cut, device):
 
 
 class Assemble_Dice:
-    def __init__(self, opt, image_size_original=None):
-        """image_size_original: (z, y, x) of the un-padded volume; when omitted it is taken from opt.volume_shape."""
+    def __init__(self, opt, image_size_original=None, slab=None):
+        """image_size_original: (z, y, x) of the un-padded volume; when omitted it is taken from opt.volume_shape.
+        slab = (za, zb): the accumulators hold only the padded planes [za, zb) (sharded inference, test_dice.py assemble='slab':
+        a rank's cubes touch two or three z-layers); add_cube then accepts only cubes inside that range."""
         if image_size_original is None:
             image_size_original = opt.volume_shape
         self.image_size_original = tuple(int(s) for s in image_size_original)
@@ -76,10 +78,12 @@ class Assemble_Dice:
         self.acc = OrderedDict()
         self.count = OrderedDict()
         self.visual_ret = OrderedDict()
+        self.slab = None if slab is None else (int(slab[0]), int(slab[1]))
+        shape = self.image_size if self.slab is None else (self.slab[1] - self.slab[0],) + tuple(self.image_size[1:])
         for name in self.visual_names:
             if self.skip_real and name == 'real':
                 continue
-            self.acc[name] = torch.zeros(self.image_size, dtype=torch.float32, device=self.device)
+            self.acc[name] = torch.zeros(shape, dtype=torch.float32, device=self.device)
             self.count[name] = 0
 
     def indexTo3DIndex(self, index):
@@ -100,7 +104,13 @@ class Assemble_Dice:
             cube = cube.to(self.device, torch.float32)
         cube = cube.contiguous()
         P0, P1, P2 = self.image_size
-        check(lib().nc_assemble_scatter_add(P(cube.data_ptr()), P(self.acc[name].data_ptr()), I(P0), I(P1), I(P2),
+        base = self.acc[name].data_ptr()
+        if self.slab is not None:  # the kernel indexes absolute planes: hand it where plane 0 WOULD be (it only touches the cube's planes)
+            z0 = self.indexToCoordinates(int(index))[0]
+            if z0 < self.slab[0] or z0 + self.roi_size > self.slab[1]:
+                raise AssertionError('cube %d lies outside the planes [%d, %d) of this accumulator' % (index, self.slab[0], self.slab[1]))
+            base -= self.slab[0] * P1 * P2 * 4
+        check(lib().nc_assemble_scatter_add(P(cube.data_ptr()), P(base), I(P0), I(P1), I(P2),
                                             I(self.roi_size), I(self.overlap), I(self.border_cut), I(int(index)),
                                             P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_scatter_add')
 
@@ -118,7 +128,23 @@ class Assemble_Dice:
             self.add_cube(name, cube[name], self.count[name])
             self.count[name] += 1
 
+    def finalize_slab(self, own_acc, za, zb):
+        """(acc / count) * 8 * scale and the truncating cast for the padded planes [za, zb) held in own_acc (already complete: every
+        rank's contributions added): returns the device tensor of the planes [za, zb) & [0, L0) of the un-padded volume."""
+        L0, L1, L2 = self.image_size_original
+        P0, P1, P2 = self.image_size
+        z0, z1 = min(za, L0), min(zb, L0)
+        u16 = self.imtype == 'uint16'
+        out = torch.empty((z1 - z0, L1, L2), dtype=torch.int16 if u16 else torch.uint8, device=self.device)
+        if z1 > z0:
+            check(lib().nc_assemble_finalize_slab(P(own_acc.data_ptr()), P(out.data_ptr()), I(1 if u16 else 0), I(P0), I(P1), I(P2), I(L0),
+                                                  I(L1), I(L2), I(self.roi_size), I(self.overlap), I(z0), I(z1 - z0), I(za),
+                                                  P(torch.cuda.current_stream().cuda_stream)), 'nc_assemble_finalize_slab')
+        return out
+
     def assemble_all(self):
+        if self.slab is not None:
+            raise Exception('a slab accumulator is finalised by its owner ranks (finalize_slab), not by assemble_all')
         L0, L1, L2 = self.image_size_original
         P0, P1, P2 = self.image_size
         for name, acc in self.acc.items():

@@ -1,7 +1,8 @@
 """CPU, world_size 2 and 3, gloo: the N > 1 paths that need no GPU code --
  * the cube sharding schedules of diced inference (neuroclear_amd.test_dice): 'gather' (lock-step rounds, tiles to rank 0,
-   bit-identical to the single-process order) and 'reduce' (each rank overlap-adds its own cubes, one reduce(sum);
-   +-1 LSB), both checked against the oracle's single-process assemble; 125 cubes = an odd count, like 729;
+   bit-identical to the single-process order), 'reduce' (each rank overlap-adds its own cubes, one reduce(sum); +-1 LSB) and
+   'slab' (contiguous cube ranges, one point-to-point exchange of owned z-slabs, per-rank finalisation, integer slabs to rank 0;
+   +-1 LSB), all checked against the oracle's single-process assemble; 125 cubes = an odd count, like 729;
  * the weight broadcast in front of the loop (broadcast_parameters);
  * the gradient exchange of the flat optimizer buffers (FlatAdam.all_reduce_mean, bucketed / asynchronous form too)."""
 import os
@@ -126,6 +127,67 @@ def test_sharded_dice_loop_reduce(tmp_path, world):
     mp.spawn(_dice_reduce_worker, args=(world, port, out), nprocs=world, join=True)
     d, n, bc = np.load(out)
     assert d <= 1 and n == 125 and bc == 1
+
+
+def _dice_slab_worker(rank, world, port, out_path):
+    _init(rank, world, port)
+    from neuroclear_amd.test_dice import slab_exchange, slab_gather, slab_plan
+    from neuroclear_amd.util import seed as S
+    from oracle import dice as odice
+    vol = S.random_volume(3, (50, 50, 50))
+    R, ov, b = 16, 4, 2
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    n = steps[0] * steps[1] * steps[2]
+    refl = odice.reflect_pad(padded, b)
+    step = R - ov
+    plan = slab_plan(steps, step, R, padded.shape[0], world)
+    ok = plan['cubes'][0][0] == 0 and plan['cubes'][-1][1] == n and all(plan['cubes'][r][1] == plan['cubes'][r + 1][0] for r in range(world - 1))
+    ok = ok and max(c[1] - c[0] for c in plan['cubes']) - min(c[1] - c[0] for c in plan['cubes']) <= 1  # <= 1 cube of imbalance
+    ok = ok and plan['own'][0][0] == 0 and plan['own'][-1][1] == padded.shape[0]
+
+    def net(x):
+        return x * 0.75 + 0.01
+    za, zb = plan['local'][rank]
+    local = torch.zeros((zb - za,) + padded.shape[1:], dtype=torch.float32)
+    for i in range(*plan['cubes'][rank]):
+        tile = net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b))))
+        zi, yi, xi = i // (steps[1] * steps[2]), (i % (steps[1] * steps[2])) // steps[2], i % steps[2]
+        z, y, x = zi * step, yi * step, xi * step
+        assert za <= z and z + R <= zb  # every cube of the rank lies inside the planes its accumulator holds
+        local[z - za:z - za + R, y:y + R, x:x + R] += tile[b:-b, b:-b, b:-b] / 8
+    ok = ok and (zb - za) < padded.shape[0]  # the point of the exercise: no rank holds the whole volume
+    o0, o1 = plan['own'][rank]
+    own = torch.zeros((o1 - o0,) + padded.shape[1:], dtype=torch.float32)
+    slab_exchange(rank, world, plan, local, own)
+    # finalise the owned planes: count volume, (acc / count) * 8 * 65535, truncating cast, crop of the dicing pad (oracle arithmetic on a
+    # volume that is zero outside the slab: only the slab's planes are kept)
+    full = np.zeros(padded.shape, np.float32)
+    full[o0:o1] = own.numpy()
+    fin = odice.finalize(full, padded.shape, vol.shape, R, ov, 'uint16')
+    z0, z1 = min(o0, vol.shape[0]), min(o1, vol.shape[0])
+    slab = torch.from_numpy(fin[z0:z1].astype(np.int32))
+    parts = slab_gather(rank, world, plan, slab, vol.shape[0])
+    if rank == 0:
+        got = torch.cat(parts, 0).numpy().astype(np.int64)
+        ref = odice.assemble([net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b)))).numpy() for i in range(n)],
+                             padded.shape, vol.shape, R, ov, b, 'uint16')
+        d = int(np.abs(got - ref.astype(np.int64)).max()) if got.shape == ref.shape else 99
+        np.save(out_path, np.array([d, n, int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3, 4])
+def test_sharded_dice_loop_slab(tmp_path, world):
+    """assemble='slab': contiguous cube ranges, local accumulators of a few z-layers, ONE point-to-point exchange of the planes each
+    rank owns, per-rank finalisation, integer slabs to rank 0 -- against the oracle's single-process assemble (+-1 LSB: the order in
+    which the ranks' partial sums meet differs from the index order)."""
+    port = _free_port()
+    out = str(tmp_path / 's.npy')
+    mp.spawn(_dice_slab_worker, args=(world, port, out), nprocs=world, join=True)
+    d, n, ok = np.load(out)
+    assert d <= 1 and n == 125 and ok == 1
 
 
 def _adam_worker(rank, world, port, out_path):

@@ -302,3 +302,24 @@ def test_athena_step_108_streams_tuner_and_shared_pass_agree(monkeypatch):
             for k in base[it]:
                 assert base[it][k] == other[it][k], (ds, ru, tu, it, k, base[it][k], other[it][k])
         assert torch.equal(p0, p1), (ds, ru, tu)
+
+
+def test_diced_inference_slab_mode_single_rank_is_bit_identical():
+    """assemble='slab' with one rank walks the same code as the sharded run (slab accumulator addressed through a shifted base pointer,
+    owner-side nc_assemble_finalize_slab, integer slabs concatenated) and adds the cubes in index order, so it must reproduce the
+    in-order assembler bit for bit; the multi-rank schedule itself is covered on CPU (tests/test_dist_cpu.py, gloo, world 2-4)."""
+    from neuroclear_amd.test_dice import diced_inference, slab_plan
+    from neuroclear_amd.util import util as U
+    vol = S.structured_volume(13, (150, 96, 110))
+    opt = Namespace(dice_size=[48] * 3, overlap=8, border_cut=4, gpu_ids=[0], skip_real=True, data_type='uint16', histogram_match=False,
+                    normalize_intensity=False)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict({k: torch.from_numpy(v).to(DEV) for k, v in S.weights_from_seed(S.unet_deconv_spec(), 22).items()})
+    a = diced_inference(net, vol, opt, assemble='gather')
+    b = diced_inference(net, vol, opt, assemble='slab')
+    assert a.dtype == np.uint16 and a.shape == vol.shape and np.array_equal(a, b)
+    # the plan for 8 ranks on the 900^3 geometry: 91 or 92 cubes each, at most three z-layers (330 of 960 planes) per local accumulator
+    padded = U.padded_shape((900, 900, 900), 120, 15)
+    plan = slab_plan(U.grid_steps(padded, 120, 15), 105, 120, padded[0], 8)
+    assert sorted({c[1] - c[0] for c in plan['cubes']}) == [91, 92] and max(z[1] - z[0] for z in plan['local']) <= 330
+    assert [o[1] - o[0] for o in plan['own']] == [120] * 8

@@ -437,3 +437,29 @@ def test_patchgan_first_layer_kernels(B, K, H, W):
     assert float((db.double() - refb).abs().max()) <= 2e-5 * float(refb.abs().max() + 1)
     dw2, _ = ops.conv_wgrad_raw(x, dy, w.shape, 2, 1, False)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize('N,C,S,slope', [(1, 64, 4096, 0.0), (2, 16, 2500, 0.2), (1, 128, 27 * 27 * 27, 0.0)])
+def test_instnorm_backward_in_s3_form_is_the_fp32_backward_split(N, C, S, slope):
+    """nc_instnorm_act_bwd_dbias_s3 (the dY of a split-operand convolution written by the norm's backward, no fp32 tensor in between)
+    must store exactly the three-term form of what nc_instnorm_act_bwd_dbias stores in fp32 -- the whole-network backward relies on
+    it for bit-equality with the layer-by-layer path -- and the same bias gradient."""
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import F, I, L_, Z, check, lib
+    torch.manual_seed(6)
+    x = torch.randn(N, C, S, device=DEV) * 2 + 0.5
+    dy = torch.randn(N, C, S, device=DEV)
+    mean = x.mean(2).reshape(-1).contiguous()
+    rstd = (1.0 / (x.var(2, unbiased=False) + 1e-5).sqrt()).reshape(-1).contiguous()
+    L = lib()
+    wsb = L.nc_instnorm_bwd_dbias_ws_bytes(I(N * C), L_(S))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dx, db = torch.empty_like(x), torch.empty(C, device=DEV)
+    check(L.nc_instnorm_act_bwd_dbias(ops._ptr(dy), ops._ptr(x), ops._ptr(mean), ops._ptr(rstd), F(slope), ops._ptr(dx), ops._ptr(db),
+                                      I(N), I(C), L_(S), ops._ptr(ws), Z(wsb), ops._stream()), 'nc_instnorm_act_bwd_dbias')
+    ref = torch.empty(N * C * S * 6, dtype=torch.uint8, device=DEV)
+    check(L.nc_to_s3(ops._ptr(dx), ops._ptr(ref), I(N), I(C), L_(S), ops._stream()), 'nc_to_s3')
+    out, db2 = torch.empty_like(ref), torch.empty(C, device=DEV)
+    check(L.nc_instnorm_act_bwd_dbias_s3(ops._ptr(dy), ops._ptr(x), ops._ptr(mean), ops._ptr(rstd), F(slope), ops._ptr(out), ops._ptr(db2),
+                                         I(N), I(C), L_(S), ops._ptr(ws), Z(wsb), ops._stream()), 'nc_instnorm_act_bwd_dbias_s3')
+    assert torch.equal(out, ref) and torch.equal(db, db2)
