@@ -309,9 +309,10 @@ def pmc_traffic_cube(split=False):
 
 
 def run_infer(args, rank, world, dev, steps=None, warmup=None):
-    """configs[2]: 900^3 synthetic volume, dice 120 / overlap 15 / border_cut 10 -> 729 cubes of 140^3, cube i on rank
-    i % world; rank 0's weights are broadcast (RCCL), every rank overlap-adds its own cubes into its own accumulator and
-    ONE reduce(sum) lands the volume on rank 0 (neuroclear_amd/test_dice.py)."""
+    """configs[2]: 900^3 synthetic volume, dice 120 / overlap 15 / border_cut 10 -> 729 cubes of 140^3, a contiguous range of
+    cubes per rank; rank 0's weights are broadcast (RCCL), every rank overlap-adds its own cubes into an accumulator of the two or
+    three z-layers they touch, ONE point-to-point exchange gives every rank the z-slab it owns, which it finalises; the uint16
+    slabs are gathered on rank 0 (neuroclear_amd/test_dice.py, assemble='slab')."""
     import torch
     import torch.distributed as dist
     from neuroclear_amd.test_dice import diced_inference
@@ -378,8 +379,9 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                     event_ms_per_cube=round(ms_events / len(ev), 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
     return dt, L ** 3 * steps, roof, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
-                                          parallelism='cubes%%%d' % world, cubes=ncubes,
-                                          assemble='reduce' if world > 1 else 'in-order',
+                                          parallelism=('contiguous cube ranges over %d ranks' % world) if world > 1 else 'cubes%1', cubes=ncubes,
+                                          assemble='slab (owned z-slabs exchanged point to point, finalised per rank, uint16 slabs gathered)'
+                                          if world > 1 else 'in-order',
                                           computed_voxels_per_s=round(computed * steps / dt))
 
 
