@@ -554,8 +554,13 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     if (f7) NC_TRY(split3_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, hs));
     NC_TRY(block(7, W + u.cat2, f7 ? W + u.s_cat2 : nullptr, f8 ? nullptr : W + u.a2, f8 ? W + u.s_a2 : nullptr, 128, 0, 256, 128, h0, h1, h2));
     NC_TRY(block(8, W + u.a2, f8 ? W + u.s_a2 : nullptr, W + u.a2b, nullptr, 0, 0, 128, 128, h0, h1, h2));
-    NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
-    if (f9) NC_TRY(split3_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, hs));
+    if (f9 && convT_fwd_s3_supported(1, 128, h0, h1, h2, 64)) {  // the transposed convolution writes block 9's operand form itself; in the
+      // inference forward nothing else reads its output, so the fp32 half of cat1 is not written at all
+      NC_TRY(convT_fwd_s3(W + u.a2b, P + o.w[11], P + o.b[11], nullptr, W + u.s_cat1, 128, 64, 1, 128, h0, h1, h2, 64, stream));
+    } else {
+      NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
+      if (f9) NC_TRY(split3_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, hs));
+    }
     NC_TRY(block(9, W + u.cat1, f9 ? W + u.s_cat1 : nullptr, W + u.a1, nullptr, 0, 0, 128, 64, S0, S1, S2));
     NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
     NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));

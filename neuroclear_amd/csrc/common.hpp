@@ -172,6 +172,10 @@ int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, floa
 bool instnorm_bwd_s3_supported(int N, int C, long S);
 int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
+// convt.hip: ConvTranspose3d(k 2, s 2) forward that also (or only: y NULL) writes the S3 form of its output
+bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K);
+int convT_fwd_s3(const float* x, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H,
+                 int W, int K, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "s3_common.hpp"
 
 namespace nc {
 
@@ -58,7 +59,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int CH>  // C / 2, compile time: the input values of a tile live in registers
 __global__ __launch_bounds__(256, 2) void k_convT_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int C, int D, int H,
-                                                           int W, int K, int N) {
+                                                           int W, int K, int N, uint2* __restrict__ ys, int oblocks, int ob0) {
   extern __shared__ float wl[];  // [CH][4][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h = lane >> 5;
@@ -106,14 +107,34 @@ __global__ __launch_bounds__(256, 2) void k_convT_fwd_mfma(const float* __restri
     }
     if (!valid) continue;
     const int ix = (int)(p % W), iy = (int)((p / W) % H), iz = (int)(p / ((long)W * H));
+    if (y) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      float* yk = y + ((long)n * K + k) * S2;
+      for (int e = 0; e < 16; ++e) {
+        const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float* yk = y + ((long)n * K + k) * S2;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float2* dst = reinterpret_cast<float2*>(yk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
-        *dst = make_float2(acc[b * 2][e] + bb[e], acc[b * 2 + 1][e] + bb[e]);
+        for (int b = 0; b < 2; ++b) {
+          float2* dst = reinterpret_cast<float2*>(yk + ((long)(2 * iz + a) * H2 + (2 * iy + b)) * W2 + 2 * ix);
+          *dst = make_float2(acc[b * 2][e] + bb[e], acc[b * 2 + 1][e] + bb[e]);
+        }
+      }
+    }
+    // the three-term (S3) form of the same values for a split-operand convolution that consumes them (conv_split.hip): accumulator
+    // rows 4u .. 4u + 3 of this lane are channels 4h .. 4h + 3 of 8-channel block kt * 4 + u -- one 8-byte half of a unit per term
+    if (ys) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long blk = ((long)n * oblocks + ob0 + kt * 4 + u) * 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long o = ((long)(2 * iz + a) * H2 + (2 * iy + (q >> 1))) * W2 + 2 * ix + (q & 1);
+          unsigned short t3[4][3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s3_split(acc[q][4 * u + i] + bb[4 * u + i], t3[i]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            ys[((blk + t) * S2 + o) * 2 + h] = make_uint2(t3[0][t] | ((unsigned)t3[1][t] << 16), t3[2][t] | ((unsigned)t3[3][t] << 16));
+        }
       }
     }
   }
@@ -246,9 +267,34 @@ static int convT_check(const char* what, int N, int C, int D, int H, int W, int 
   return NC_OK;
 }
 
+}  // extern "C"
+namespace nc {
+// Can the transposed convolution write the S3 form of its output itself (convT_fwd_s3)?  Only the matrix-core kernel does.
+bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K) {
+  static const bool mfma_on = !(getenv("NC_CONVT_MFMA") && atoi(getenv("NC_CONVT_MFMA")) == 0);
+  const long S = (long)D * H * W;
+  return mfma_on && !g_force_direct && K % 32 == 0 && C == 128 && (long)N * K * 8 * S < (1L << 40);
+}
+static int convT_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K,
+                          void* ys, int ctot, int c0, void* stream);
+// y (nullable) = the fp32 output; ys = channels [c0, c0 + K) of a ctot-channel S3 tensor [N][ctot/8][3][8S][8] bf16
+int convT_fwd_s3(const float* x, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H,
+                 int W, int K, void* stream) {
+  if (!x || !w || !ys) { set_error("convT_fwd_s3: null pointer"); return NC_ERR_ARG; }
+  if (!convT_fwd_s3_supported(N, C, D, H, W, K) || ctot % 8 || c0 % 8) { set_error("convT_fwd_s3: shape not covered"); return NC_ERR_SHAPE; }
+  return convT_fwd_impl(x, w, bias, y, N, C, D, H, W, K, ys, ctot, c0, stream);
+}
+}  // namespace nc
+extern "C" {
+
 int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W,
                       int K, void* stream) {
   if (!x || !w || !y) { set_error("convT_fwd: null pointer"); return NC_ERR_ARG; }
+  return convT_fwd_impl(x, w, bias, y, N, C, D, H, W, K, nullptr, 0, 0, stream);
+}
+}  // extern "C"
+static int nc::convT_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K,
+                              void* ys, int ctot, int c0, void* stream) {
   if (int e = convT_check("convT_fwd", N, C, D, H, W, K)) return e;
   const long S = (long)D * H * W;
   hipStream_t s = (hipStream_t)stream;
@@ -265,11 +311,12 @@ int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* 
         set_error("convT_fwd: cannot raise dynamic LDS limit");
         return NC_ERR_HIP;
       }
-      hipLaunchKernelGGL(kern, g, dim3(256), lds, s, x, w, bias, y, C, D, H, W, K, N);
+      hipLaunchKernelGGL(kern, g, dim3(256), lds, s, x, w, bias, y, C, D, H, W, K, N, (uint2*)ys, ctot / 8, c0 / 8);
       return check_launch("convT_fwd_mfma");
     };
     return launch(k_convT_fwd_mfma<64>);
   }
+  if (ys || !y) { set_error("convT_fwd: the S3 output needs the matrix-core kernel"); return NC_ERR_SHAPE; }
   const int kt = pick(K, 4, 2, 1);
   dim3 grid((unsigned)cdiv(S, 256), K / kt, N);
   if (kt == 4) hipLaunchKernelGGL(k_convT_fwd<4>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
@@ -277,6 +324,7 @@ int nc_convT_k2s2_fwd(const float* x, const float* w, const float* bias, float* 
   else hipLaunchKernelGGL(k_convT_fwd<1>, grid, dim3(256), 0, s, x, w, bias, y, C, D, H, W, K);
   return check_launch("convT_fwd");
 }
+extern "C" {
 
 int nc_convT_k2s2_dgrad(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W, int K,
                         void* ws, size_t ws_bytes, void* stream) {

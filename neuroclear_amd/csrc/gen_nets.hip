@@ -216,11 +216,17 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   }
   NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh, 8, 128));
   NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh, -1, 0));
-  for (int n = 0; n < N; ++n)  // t_conv1 writes the second half of cat1
-    NC_TRY(nc_convT_k2s2_fwd(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
-                             1, 128, d1[0], d1[1], d1[2], 64, stream));
+  const bool ct_s3 = use[9] && convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64);  // t_conv1 writes the S3 form of its output itself
+  for (int n = 0; n < N; ++n) {  // t_conv1 writes the second half of cat1
+    if (ct_s3)
+      NC_TRY(convT_fwd_s3(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
+                          (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, stream));
+    else
+      NC_TRY(nc_convT_k2s2_fwd(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
+                               1, 128, d1[0], d1[1], d1[2], 64, stream));
+  }
   if (use[9]) {
-    NC_TRY(split3_into(V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
+    if (!ct_s3) NC_TRY(split3_into(V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
     pre[9] = true;
   }
   NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S, -1, 0));
