@@ -9,8 +9,11 @@
 //    input plane of one chunk are a "brick"; k-steps straddle bricks, so the bricks live in an LDS RING of three
 //    (in use / arrived / loading) filled by LDS-DMA, one barrier per brick.  conv_split.hip's pairing spent 10 % of the
 //    3^3 MFMAs on a zero-weight tenth tap;
-//  * a brick is the flat range [q0, q0 + PT + (KS-1)(P+1)) of the zero-padded plane (pitch P = W + KS - 1), not whole rows:
-//    37-40 KB for 512 positions and three terms, so three of them fit and NO weights go through LDS;
+//  * output positions are ONE flat axis per sample, q = (z Hp + y) P + x over the zero-padded volume (P = W + KS - 1, Hp = H + KS - 1):
+//    a tile is 64 output channels x PT consecutive q whatever the plane size (27^3 .. 140^3 all run 512-position tiles; pad rows and
+//    columns are computed and dropped), tap (dz, dy, dx) is the constant offset dz Hp P + dy P + dx, and the brick of (chunk, dz) is
+//    the flat range [q0 + dz Hp P, + PT + (KS-1)(P+1)) -- 37-40 KB for 512 positions and three terms, so three bricks fit and NO
+//    weights go through LDS;
 //  * weights stream from global memory (L2-resident) straight into registers as MFMA A fragments, one k-step ahead, through
 //    a buffer descriptor with scalar offsets: [cot][co half][k-step][row block][term][lane][8] bf16, 1 KiB per fragment;
 //  * 8 waves = 2 halves of the 64 output channels x 4 groups of NCB*16 positions; per k-step a wave holds its 6 A fragments
@@ -19,7 +22,9 @@
 //    swapped to match): every read instruction touches each of the 64 banks exactly once whatever the tap offsets of the
 //    groups are (one ds_read_b128 would be 2-way conflicted for every pair of taps that is not a multiple of 16 units apart);
 //  * tile quantisation: the launch covers whole rounds of 256 tiles with NCB = 8 (512 positions) and the remainder with a
-//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,592 tiles at 108^3 cost 10.3 rounds instead of 11.
+//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,5xx tiles at 108^3 cost 10.3 rounds instead of 11;
+//  * the LDS-DMA pieces of a brick are issued by ONE wave of each SIMD pair (waves 0..3), source offsets computed at issue time: its
+//    partner keeps the matrix pipe busy meanwhile (-4 %); the stores of a tile are issued inside the first four k-steps of the next.
 // Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
 #include <cstdlib>
 #include <type_traits>
@@ -95,14 +100,14 @@ struct XParams {
   const float* bias;   // nullable
   float* y;            // fp32 NCDHW output
   int N, NCH, D, H, W, K;
-  int P;               // row pitch of the padded plane, W + KS - 1
-  int HP;              // H * P: flattened output positions of a plane (pad columns included)
-  int TPP, KT;         // main-tiling tiles per plane, K / 64
+  int P, Hp;           // row pitch W + KS - 1 and rows H + KS - 1 of the zero-padded volume: plane pitch Hp * P
+  int Q;               // flattened output positions of a sample, (D - 1) Hp P + (H - 1) P + W (pad rows / columns included)
+  int TPS, KT;         // main-tiling tiles per sample, K / 64
   int fsub;            // this launch's tiles are 1 / fsub of a main tile (tile index = main index * fsub + sub)
   int UB;              // units per term of a brick (multiple of 64)
   int npb;             // 1 KiB pieces per brick (three terms)
   int NS;              // k-steps per tile
-  unsigned mP, mUB;
+  unsigned mP, mHp, mUB;
   int t_begin, t_count;  // first main tile and number of (sub-)tiles of this launch
   int tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
@@ -110,21 +115,20 @@ struct XParams {
 };
 
 struct XTile {
-  int n, cot, z, q0;
+  int n, cot, q0;  // sample, 64-channel output tile, first flattened position
 };
 
 template <int PT>
 __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   int t = p.t_begin + idx / p.fsub;
   const int sub = idx % p.fsub;
-  XTile o;  // output-channel tile fastest, then z: neighbouring planes share input planes in L2
+  XTile o;  // output-channel tile fastest, then position: neighbouring tiles share rows and planes of the input in L2
   o.cot = t % p.KT; t /= p.KT;
-  o.z = t % p.D; t /= p.D;
-  const int tp = t % p.TPP;
-  o.n = t / p.TPP;
-  o.q0 = (tp * p.fsub + sub) * PT;
+  const int tq = t % p.TPS;
+  o.n = t / p.TPS;
+  o.q0 = (tq * p.fsub + sub) * PT;
   // wave-uniform by construction; said explicitly so that descriptors and scalar offsets built from them stay in SGPRs
-  o.cot = __builtin_amdgcn_readfirstlane(o.cot); o.z = __builtin_amdgcn_readfirstlane(o.z);
+  o.cot = __builtin_amdgcn_readfirstlane(o.cot);
   o.n = __builtin_amdgcn_readfirstlane(o.n); o.q0 = __builtin_amdgcn_readfirstlane(o.q0);
   return o;
 }
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   const int m16 = lane & 15, g = lane >> 4;
   const int half = wave & 1, pg = wave >> 1;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int PPp = p.Hp * p.P;    // plane pitch of the padded volume
   const int NB = p.NCH * KS;     // bricks per tile
   const int BB = p.npb * 1024;   // bytes per ring slot
 
@@ -146,10 +151,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   int t_hi = t_lo + p.tiles_per_xcd;
   if (t_hi > p.t_count) t_hi = p.t_count;
   // the (sub-)tiles of this workgroup: t_lo + wslot, + nslot, ...; sub-tiles that start beyond the plane are empty
-  auto next_tile = [&](int t, XTile& o) {
+  auto next_tile = [&](int t, XTile& o) __attribute__((always_inline)) {
     for (; t < t_hi; t += nslot) {
       o = x_decode<PT>(p, t);
-      if (o.q0 < p.HP) return t;
+      if (o.q0 < p.Q) return t;
     }
     return -1;
   };
@@ -161,31 +166,28 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   // through a buffer descriptor over the three terms of ONE 8-channel block: a lane whose unit is padding asks for an offset
   // beyond the descriptor's range and the hardware delivers zeros (no zero page, no 64-bit address arithmetic per lane)
   constexpr unsigned kOut = 0x80000000u;
-  auto issue_brick = [&](const XTile& t, int bi, int slot) {
+  auto issue_brick = [&](const XTile& t, int bi, int slot) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
     const int chunk = bi / KS, dz = bi - chunk * KS;
-    const int zz = t.z + dz - PAD;
-    const bool zok = (unsigned)zz < (unsigned)p.D;
     const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * 3 * S;
-    // a plane outside the volume: an empty descriptor, every lane reads zeros
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(3 * S * 16) : 0u, 0x00020000);
-    const int soff = zok ? (int)(zz * HW * 16) : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(3 * S * 16), 0x00020000);
+    const unsigned Fb = (unsigned)(t.q0 + dz * PPp);  // first padded flat position of this brick
     unsigned char* buf = lds_raw + slot * BB;
 #pragma unroll 1
     for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
-      // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms, relative to plane 0), or kOut:
-      // computed at issue time by the issuing waves (~12 vector instructions per piece, in the shadow of the SIMD partner's MFMAs)
-      // rather than kept in registers per tile.  (Written in line: as a lambda called from this lambda it made hipcc drop the
-      // kernel's host-side handle.)
+      // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms), or kOut: unit u of a term is
+      // padded flat position Fb + u = ((z + PAD) Hp + (y + PAD)) P + (x + PAD).  Computed at issue time by the issuing waves (~15 vector
+      // instructions per piece, in the shadow of the SIMD partner's MFMAs) rather than kept in registers per tile.  (Written in line: as a
+      // lambda called from this lambda it made hipcc drop the kernel's host-side handle.)
       const unsigned u = (unsigned)(pc * 64 + lane);
       const unsigned term = fdiv(u, p.mUB);
-      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
-      const unsigned rr = fdiv(F, p.mP);
-      const int xx = (int)(F - rr * p.P) - PAD;
-      const int yy = (int)rr - PAD;
-      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, soff, 0, 0);
+      const unsigned F = Fb + (u - term * p.UB);
+      const unsigned R = fdiv(F, p.mP);          // padded row index (all planes)
+      const unsigned zp = fdiv(R, p.mHp);
+      const int xx = (int)(F - R * p.P) - PAD, yy = (int)(R - zp * p.Hp) - PAD, zz = (int)zp - PAD;
+      const bool ok = term < 3u && (unsigned)zz < (unsigned)p.D && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)((zz * p.H + yy) * p.W + xx)) * 16u : kOut;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, 0, 0, 0);
     }
   };
 
@@ -197,11 +199,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const unsigned long long wa = (unsigned long long)p.wp;
     wrsrc.x = __builtin_amdgcn_readfirstlane((unsigned)wa);
     wrsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
-    wrsrc.z = 0x7fffffffu;
-    wrsrc.w = 0x00020000u;
+    wrsrc.z = __builtin_amdgcn_readfirstlane(0x7fffffffu);
+    wrsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   const int wvoff = lane * 16;
-  auto wtile = [&](int cot) { return ((cot * 2 + half) * p.NS) * (6 * 1024); };
+  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (6 * 1024); };
   auto load_a = [&](u32x4 (&A)[2][3], int soff) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   const unsigned term_b = (unsigned)p.UB * 16;
   const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)lds_raw;
   struct BAddr { unsigned lo[3], hi[3]; };  // per term: address of the half read first / second (column block 0)
-  auto b_addr = [&](unsigned vo) {
+  auto b_addr = [&](unsigned vo) __attribute__((always_inline)) {
     BAddr a;
 #pragma unroll
     for (int t = 0; t < 3; ++t) { a.lo[t] = lds_base + vo + t * term_b; a.hi[t] = a.lo[t] ^ 8u; }
@@ -260,17 +262,17 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const unsigned long long ba = (unsigned long long)p.bias;
     brsrc.x = __builtin_amdgcn_readfirstlane((unsigned)ba);
     brsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu);
-    brsrc.z = p.bias ? (unsigned)p.K * 4u : 0u;
-    brsrc.w = 0x00020000u;
+    brsrc.z = __builtin_amdgcn_readfirstlane(p.bias ? (unsigned)p.K * 4u : 0u);
+    brsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   u32x4 bv[2];
-  auto load_bias = [&](const XTile& t) {
+  auto load_bias = [&](const XTile& t) __attribute__((always_inline)) {
     const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bv[rb]) : "v"(bo + rb * 64), "s"(brsrc) : "memory");
   };
-  auto store_pairs = [&](const XTile& t, const int p0, const int p1) {  // pairs p0 .. p1 - 1 of tile t from `tot`, then tot = 0
+  auto store_pairs = [&](const XTile& t, const int p0, const int p1) __attribute__((always_inline)) {  // pairs p0 .. p1 - 1 of tile t from `tot`, then tot = 0
     const int cob = t.cot * 64 + half * 32 + 4 * g;
     const __amdgpu_buffer_rsrc_t ys =
         __builtin_amdgcn_make_buffer_rsrc(p.y + (long)t.n * p.K * S, 0, (unsigned)((long)p.K * S * 4), 0x00020000);
@@ -278,11 +280,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     for (int pr = 0; pr < kPairs; ++pr) {
       if (pr < p0 || pr >= p1) continue;
       const int rb = pr / NCB, cb = pr % NCB;
-      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);
-      const unsigned yy = fdiv(f, p.mP);
-      const unsigned xx = f - yy * p.P;
-      const bool ok = (int)yy < p.H && (int)xx < p.W;
-      const unsigned vo0 = ok ? (unsigned)(((long)(cob + rb * 16) * S + (long)t.z * HW + yy * p.W + xx) * 4) : kOut;
+      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);  // = (z Hp + y) P + x
+      const unsigned R = fdiv(f, p.mP);
+      const unsigned zz = fdiv(R, p.mHp);
+      const unsigned xx = f - R * p.P, yy = R - zz * p.Hp;
+      const bool ok = (int)zz < p.D && (int)yy < p.H && (int)xx < p.W;
+      const unsigned vo0 = ok ? (unsigned)(((long)(cob + rb * 16) * S + (long)zz * HW + yy * p.W + xx) * 4) : kOut;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 
     // per-lane tap state: lane group g is at tap tpl of the brick in slot sl
     int tpl = g, sl = ring;
-    auto b_off = [&]() {
+    auto b_off = [&]() __attribute__((always_inline)) {
       const int dy = KS == 3 ? (tpl * 11) >> 5 : (tpl * 13) >> 6;
       const int dx = tpl - dy * KS;
       return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 }
 
 struct XPlan {
-  int NCB, fsub, P, HP, TPP, UB, npb, lds;
+  int NCB, fsub, P, Hp, Q, TPS, UB, npb, lds;
   int UBt, npbt, ldst;  // the tail launch's brick (PT / fsub positions)
   long full, rem;       // main tiles in whole rounds of 256 / left over
   bool ok;
@@ -462,17 +465,17 @@ int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round
 XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
   XPlan best{};
   double best_cost = 1e30;
-  const int P = W + KS - 1;
-  const long HP = (long)H * P;
+  const int P = W + KS - 1, Hp = H + KS - 1;
+  const long Q = (long)(D - 1) * Hp * P + (long)(H - 1) * P + W;  // flattened positions of a sample, pad rows / columns included
   static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
   for (int NCB : {8, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
     XPlan pl{};
-    pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
+    pl.NCB = NCB; pl.P = P; pl.Hp = Hp; pl.Q = (int)Q;
     const int PT = 64 * NCB;
     if (!x_brick(PT, P, KS, pl.UB, pl.npb, pl.lds)) continue;
-    pl.TPP = (int)((HP + PT - 1) / PT);
-    const long ntiles = (long)N * D * pl.TPP * KT;
+    pl.TPS = (int)((Q + PT - 1) / PT);
+    const long ntiles = (long)N * pl.TPS * KT;
     pl.full = ntiles / 256 * 256;
     pl.rem = ntiles - pl.full;
     // time in units of "positions per workgroup"; a tile costs its positions plus a fixed part (prologue, epilogue, halo)
@@ -529,7 +532,7 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if (Cin % 64 || Kout % 64) return false;  // an even number of whole k-steps: (Cin / 8) * KS^3 taps in fours
   if ((long)Kout * D * H * W * 4 >= (1l << 31)) return false;  // byte offsets inside one sample's output
   if ((long)D * H * W * 48 >= (1l << 31)) return false;  // byte offsets inside one block's three terms stay below the kOut mark
-  if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
+  if ((long)(D + KS) * (H + KS) * (W + KS) >= (1l << 31) / (W + KS)) return false;  // the magic divisions by P and Hp stay exact
   return x_plan(N, D, H, W, Kout / 64, KS).ok;
 }
 
@@ -546,8 +549,8 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
   XParams p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y;
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
-  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
-  p.NS = NS; p.mP = magic(pl.P);
+  p.P = pl.P; p.Hp = pl.Hp; p.Q = pl.Q; p.TPS = pl.TPS; p.KT = Kout / 64;
+  p.NS = NS; p.mP = magic(pl.P); p.mHp = magic(pl.Hp);
 #ifdef NC_S3X_STAMP
   p.dbg = (long long*)((char*)wp_ws + s3x_packed_bytes(Cin, Kout, KS));  // (the workspace has slack behind the packed weights in the timing tool)
 #endif

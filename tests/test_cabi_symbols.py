@@ -33,3 +33,32 @@ def test_no_cpu_fallback():
         ops.conv(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 3, 3, 3), None, 1, 1)
     with pytest.raises(_lib.NcError):
         ops.instance_norm_act(torch.zeros(1, 2, 4, 4, 4))
+
+
+def test_hand_counted_loads_are_not_touched_in_flight(tmp_path):
+    """conv_s3x.hip issues its weight / bias loads as inline assembly and waits for them with hand-placed s_waitcnt (the compiler's own
+    vmcnt bookkeeping would wait for freshly issued LDS-DMA in front of every k-step).  The compiler does not know those registers are in
+    flight: this compiles the kernel as the Makefile does, keeps the ISA, and checks (tools/check_asm_loads.py) that no instruction reads
+    or overwrites a destination register between its load and the next vmcnt wait, and that nothing in the kernels is a function call
+    (a lambda left out of line spills live -- possibly in-flight -- registers around the call)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'neuroclear_amd', 'csrc', 'conv_s3x.hip')
+    obj = str(tmp_path / 'conv_s3x.o')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-function', '-Wno-int-to-pointer-cast',
+                    '-save-temps=obj', '-c', src, '-o', obj], check=True, capture_output=True, cwd=os.path.dirname(src))
+    asm = str(tmp_path / 'conv_s3x-hip-amdgcn-amd-amdhsa-gfx950.s')
+    assert os.path.exists(asm)
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import check_asm_loads
+    assert check_asm_loads.main(asm, 'k_conv_s3x') == 0
+    text = open(asm).read()
+    assert 's_swappc_b64' not in text and '.vgpr_spill_count: 0' in text
+    for line in text.splitlines():
+        if '.vgpr_spill_count:' in line or '.sgpr_spill_count:' in line and False:
+            assert line.strip().endswith(' 0'), line
