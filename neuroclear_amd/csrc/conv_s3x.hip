@@ -9,11 +9,8 @@
 //    input plane of one chunk are a "brick"; k-steps straddle bricks, so the bricks live in an LDS RING of three
 //    (in use / arrived / loading) filled by LDS-DMA, one barrier per brick.  conv_split.hip's pairing spent 10 % of the
 //    3^3 MFMAs on a zero-weight tenth tap;
-//  * output positions are ONE flat axis per sample, q = (z Hp + y) P + x over the zero-padded volume (P = W + KS - 1, Hp = H + KS - 1):
-//    a tile is 64 output channels x PT consecutive q whatever the plane size (27^3 .. 140^3 all run 512-position tiles; pad rows and
-//    columns are computed and dropped), tap (dz, dy, dx) is the constant offset dz Hp P + dy P + dx, and the brick of (chunk, dz) is
-//    the flat range [q0 + dz Hp P, + PT + (KS-1)(P+1)) -- 37-40 KB for 512 positions and three terms, so three bricks fit and NO
-//    weights go through LDS;
+//  * a brick is the flat range [q0, q0 + PT + (KS-1)(P+1)) of the zero-padded plane (pitch P = W + KS - 1), not whole rows:
+//    37-40 KB for 512 positions and three terms, so three of them fit and NO weights go through LDS;
 //  * weights stream from global memory (L2-resident) straight into registers as MFMA A fragments, one k-step ahead, through
 //    a buffer descriptor with scalar offsets: [cot][co half][k-step][row block][term][lane][8] bf16, 1 KiB per fragment;
 //  * 8 waves = 2 halves of the 64 output channels x 4 groups of NCB*16 positions; per k-step a wave holds its 6 A fragments
@@ -22,9 +19,12 @@
 //    swapped to match): every read instruction touches each of the 64 banks exactly once whatever the tap offsets of the
 //    groups are (one ds_read_b128 would be 2-way conflicted for every pair of taps that is not a multiple of 16 units apart);
 //  * tile quantisation: the launch covers whole rounds of 256 tiles with NCB = 8 (512 positions) and the remainder with a
-//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,5xx tiles at 108^3 cost 10.3 rounds instead of 11;
+//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,592 tiles at 108^3 cost 10.3 rounds instead of 11;
 //  * the LDS-DMA pieces of a brick are issued by ONE wave of each SIMD pair (waves 0..3), source offsets computed at issue time: its
 //    partner keeps the matrix pipe busy meanwhile (-4 %); the stores of a tile are issued inside the first four k-steps of the next.
+// Tried and dropped: output positions as ONE flat axis per sample (q = (z Hp + y) P + x over the padded volume, 512-position tiles at
+// every plane size, z-neighbours enumerated side by side).  In isolation the 27^3 layers gained 25 %; in the step it made no difference
+// and the 900^3 inference ran 2.3 % slower (pad rows computed and dropped; same-box A/B) -- tiles stay inside one output plane.
 // Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
 #include <cstdlib>
 #include <type_traits>
@@ -100,14 +100,14 @@ struct XParams {
   const float* bias;   // nullable
   float* y;            // fp32 NCDHW output
   int N, NCH, D, H, W, K;
-  int P, Hp;           // row pitch W + KS - 1 and rows H + KS - 1 of the zero-padded volume: plane pitch Hp * P
-  int Q;               // flattened output positions of a sample, (D - 1) Hp P + (H - 1) P + W (pad rows / columns included)
-  int TPS, KT;         // main-tiling tiles per sample, K / 64
+  int P;               // row pitch of the padded plane, W + KS - 1
+  int HP;              // H * P: flattened output positions of a plane (pad columns included)
+  int TPP, KT;         // main-tiling tiles per plane, K / 64
   int fsub;            // this launch's tiles are 1 / fsub of a main tile (tile index = main index * fsub + sub)
   int UB;              // units per term of a brick (multiple of 64)
   int npb;             // 1 KiB pieces per brick (three terms)
   int NS;              // k-steps per tile
-  unsigned mP, mHp, mUB;
+  unsigned mP, mUB;
   int t_begin, t_count;  // first main tile and number of (sub-)tiles of this launch
   int tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
@@ -115,20 +115,21 @@ struct XParams {
 };
 
 struct XTile {
-  int n, cot, q0;  // sample, 64-channel output tile, first flattened position
+  int n, cot, z, q0;
 };
 
 template <int PT>
 __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   int t = p.t_begin + idx / p.fsub;
   const int sub = idx % p.fsub;
-  XTile o;  // output-channel tile fastest, then position: neighbouring tiles share rows and planes of the input in L2
+  XTile o;  // output-channel tile fastest, then z: neighbouring planes share input planes in L2
   o.cot = t % p.KT; t /= p.KT;
-  const int tq = t % p.TPS;
-  o.n = t / p.TPS;
-  o.q0 = (tq * p.fsub + sub) * PT;
+  o.z = t % p.D; t /= p.D;
+  const int tp = t % p.TPP;
+  o.n = t / p.TPP;
+  o.q0 = (tp * p.fsub + sub) * PT;
   // wave-uniform by construction; said explicitly so that descriptors and scalar offsets built from them stay in SGPRs
-  o.cot = __builtin_amdgcn_readfirstlane(o.cot);
+  o.cot = __builtin_amdgcn_readfirstlane(o.cot); o.z = __builtin_amdgcn_readfirstlane(o.z);
   o.n = __builtin_amdgcn_readfirstlane(o.n); o.q0 = __builtin_amdgcn_readfirstlane(o.q0);
   return o;
 }
@@ -142,7 +143,6 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   const int m16 = lane & 15, g = lane >> 4;
   const int half = wave & 1, pg = wave >> 1;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
-  const int PPp = p.Hp * p.P;    // plane pitch of the padded volume
   const int NB = p.NCH * KS;     // bricks per tile
   const int BB = p.npb * 1024;   // bytes per ring slot
 
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   auto next_tile = [&](int t, XTile& o) __attribute__((always_inline)) {
     for (; t < t_hi; t += nslot) {
       o = x_decode<PT>(p, t);
-      if (o.q0 < p.Q) return t;
+      if (o.q0 < p.HP) return t;
     }
     return -1;
   };
@@ -169,25 +169,28 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   auto issue_brick = [&](const XTile& t, int bi, int slot) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
     const int chunk = bi / KS, dz = bi - chunk * KS;
+    const int zz = t.z + dz - PAD;
+    const bool zok = (unsigned)zz < (unsigned)p.D;
     const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * 3 * S;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(3 * S * 16), 0x00020000);
-    const unsigned Fb = (unsigned)(t.q0 + dz * PPp);  // first padded flat position of this brick
+    // a plane outside the volume: an empty descriptor, every lane reads zeros
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(3 * S * 16) : 0u, 0x00020000);
+    const int soff = zok ? (int)(zz * HW * 16) : 0;
     unsigned char* buf = lds_raw + slot * BB;
 #pragma unroll 1
     for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
-      // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms), or kOut: unit u of a term is
-      // padded flat position Fb + u = ((z + PAD) Hp + (y + PAD)) P + (x + PAD).  Computed at issue time by the issuing waves (~15 vector
-      // instructions per piece, in the shadow of the SIMD partner's MFMAs) rather than kept in registers per tile.  (Written in line: as a
-      // lambda called from this lambda it made hipcc drop the kernel's host-side handle.)
+      // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms, relative to plane 0), or kOut:
+      // computed at issue time by the issuing waves (~12 vector instructions per piece, in the shadow of the SIMD partner's MFMAs)
+      // rather than kept in registers per tile.  (Written in line: as a lambda called from this lambda it made hipcc drop the
+      // kernel's host-side handle.)
       const unsigned u = (unsigned)(pc * 64 + lane);
       const unsigned term = fdiv(u, p.mUB);
-      const unsigned F = Fb + (u - term * p.UB);
-      const unsigned R = fdiv(F, p.mP);          // padded row index (all planes)
-      const unsigned zp = fdiv(R, p.mHp);
-      const int xx = (int)(F - R * p.P) - PAD, yy = (int)(R - zp * p.Hp) - PAD, zz = (int)zp - PAD;
-      const bool ok = term < 3u && (unsigned)zz < (unsigned)p.D && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)((zz * p.H + yy) * p.W + xx)) * 16u : kOut;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, 0, 0, 0);
+      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
+      const unsigned rr = fdiv(F, p.mP);
+      const int xx = (int)(F - rr * p.P) - PAD;
+      const int yy = (int)rr - PAD;
+      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, soff, 0, 0);
     }
   };
 
@@ -280,12 +283,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     for (int pr = 0; pr < kPairs; ++pr) {
       if (pr < p0 || pr >= p1) continue;
       const int rb = pr / NCB, cb = pr % NCB;
-      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);  // = (z Hp + y) P + x
-      const unsigned R = fdiv(f, p.mP);
-      const unsigned zz = fdiv(R, p.mHp);
-      const unsigned xx = f - R * p.P, yy = R - zz * p.Hp;
-      const bool ok = (int)zz < p.D && (int)yy < p.H && (int)xx < p.W;
-      const unsigned vo0 = ok ? (unsigned)(((long)(cob + rb * 16) * S + (long)zz * HW + yy * p.W + xx) * 4) : kOut;
+      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);
+      const unsigned yy = fdiv(f, p.mP);
+      const unsigned xx = f - yy * p.P;
+      const bool ok = (int)yy < p.H && (int)xx < p.W;
+      const unsigned vo0 = ok ? (unsigned)(((long)(cob + rb * 16) * S + (long)t.z * HW + yy * p.W + xx) * 4) : kOut;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 }
 
 struct XPlan {
-  int NCB, fsub, P, Hp, Q, TPS, UB, npb, lds;
+  int NCB, fsub, P, HP, TPP, UB, npb, lds;
   int UBt, npbt, ldst;  // the tail launch's brick (PT / fsub positions)
   long full, rem;       // main tiles in whole rounds of 256 / left over
   bool ok;
@@ -465,17 +467,17 @@ int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round
 XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
   XPlan best{};
   double best_cost = 1e30;
-  const int P = W + KS - 1, Hp = H + KS - 1;
-  const long Q = (long)(D - 1) * Hp * P + (long)(H - 1) * P + W;  // flattened positions of a sample, pad rows / columns included
+  const int P = W + KS - 1;
+  const long HP = (long)H * P;
   static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
   for (int NCB : {8, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
     XPlan pl{};
-    pl.NCB = NCB; pl.P = P; pl.Hp = Hp; pl.Q = (int)Q;
+    pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
     const int PT = 64 * NCB;
     if (!x_brick(PT, P, KS, pl.UB, pl.npb, pl.lds)) continue;
-    pl.TPS = (int)((Q + PT - 1) / PT);
-    const long ntiles = (long)N * pl.TPS * KT;
+    pl.TPP = (int)((HP + PT - 1) / PT);
+    const long ntiles = (long)N * D * pl.TPP * KT;
     pl.full = ntiles / 256 * 256;
     pl.rem = ntiles - pl.full;
     // time in units of "positions per workgroup"; a tile costs its positions plus a fixed part (prologue, epilogue, halo)
@@ -532,7 +534,7 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if (Cin % 64 || Kout % 64) return false;  // an even number of whole k-steps: (Cin / 8) * KS^3 taps in fours
   if ((long)Kout * D * H * W * 4 >= (1l << 31)) return false;  // byte offsets inside one sample's output
   if ((long)D * H * W * 48 >= (1l << 31)) return false;  // byte offsets inside one block's three terms stay below the kOut mark
-  if ((long)(D + KS) * (H + KS) * (W + KS) >= (1l << 31) / (W + KS)) return false;  // the magic divisions by P and Hp stay exact
+  if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
   return x_plan(N, D, H, W, Kout / 64, KS).ok;
 }
 
@@ -549,8 +551,8 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
   XParams p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y;
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
-  p.P = pl.P; p.Hp = pl.Hp; p.Q = pl.Q; p.TPS = pl.TPS; p.KT = Kout / 64;
-  p.NS = NS; p.mP = magic(pl.P); p.mHp = magic(pl.Hp);
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.NS = NS; p.mP = magic(pl.P);
 #ifdef NC_S3X_STAMP
   p.dbg = (long long*)((char*)wp_ws + s3x_packed_bytes(Cin, Kout, KS));  // (the workspace has slack behind the packed weights in the timing tool)
 #endif
