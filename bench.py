@@ -76,14 +76,14 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
 
 def pmc_traffic(tag, crop=108, batch=1):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    (profiles/r03_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
     if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
         return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
     if '_lp_' not in tag and (crop != 108 or batch != 1):
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
             return round(json.load(f)['split_classes' if '_split_' in tag else 'classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
     except Exception:
         return None
@@ -302,7 +302,7 @@ GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE
 def pmc_traffic_cube(split=False):
     """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh, tools/pmc_split.sh)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
             return round(json.load(f)['inference_cube_140_split' if split else 'inference_cube_140']['hbm_bytes_per_cube'])
     except Exception:
         return None
@@ -372,7 +372,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         extra = dict(peak_is='bf16 dense MFMA peak %.0f / %d MFMA products per fp32 product' % (MFMA_16BIT_PEAK_TFLOPS, SPLIT_PRODUCTS),
                      vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4)) if split else {}
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
-                                        'profiles/r02_infer_kernel_stats.csv)' % ('k_conv_s3<3,*>' if split else 'k_conv_mfma<3,*>'),
+                                        'profiles/r03_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*>' if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
                     frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), launches=len(ev),
                     cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include <atomic>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -22,14 +23,16 @@ void set_error(const char* fmt, ...) {
 
 // ---- live launch profiler (bench.py): HIP events on the launch stream around every convolution entry point --------
 struct ProfRec { int cls; double flop; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;  // launches come from the main thread (forward) and the autograd engine's thread (backward)
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static double g_prof_min_flop = 0.0;
 
 ProfScope::ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t stream) : idx(-1), s(stream) {
   if (!g_prof_on) return;
   const double flop = 2.0 * d.C * d.K * d.kd * d.kh * d.kw * ((double)d.N * d.Do * d.Ho * d.Wo);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (flop < g_prof_min_flop) return;
   auto get = [&]() {
     hipEvent_t e;
@@ -44,7 +47,9 @@ ProfScope::ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t st
   idx = (int)g_prof.size() - 1;
 }
 ProfScope::~ProfScope() {
-  if (idx >= 0) (void)hipEventRecord(g_prof[idx].e1, s);
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].e1, s);
 }
 
 // NC_SCONV=0 switches the image-staged kernels of the PatchGAN layers off (A/B runs against the gather GEMM)
@@ -97,6 +102,7 @@ using namespace nc;
 extern "C" {
 
 void nc_prof_begin(double min_flop) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (ProfRec& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
   g_prof.clear();
   g_prof_min_flop = min_flop;
@@ -107,6 +113,7 @@ void nc_prof_begin(double min_flop) {
 // cls / flop / ms (cls encoding: see ProfScope).  The caller synchronises the device first.
 int nc_prof_end(int max, int* cls, double* flop, float* ms) {
   g_prof_on = false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   const int n = (int)g_prof.size();
   for (int i = 0; i < n && i < max; ++i) {
     float t = 0.f;
