@@ -754,26 +754,52 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
 }
 
 // The same weight gradient on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock under it than under 32x32x16, tools/mfma_rate.hip):
-// K-dim = 32 voxels per MFMA, a wave's 32 k x 32 c block is 2 x 2 tiles of 16 x 16.  Lane group g = lane / 16 supplies voxels 8g .. 8g + 7
-// of a k-step for channel lane % 16 of a 16-channel block (two transposing reads of 4 voxels).  Same workgroup shape, LDS images, DMA
-// and partial layout as k_wgrad_s3; the fragment reads of tap j + 1 are issued in front of the MFMAs of tap j (the old loop read a
-// tap's fragments and multiplied them in one breath: matrix pipe busy 0.57-0.61, waves parked a third of the time).
+// K-dim = 32 voxels per MFMA.  Same LDS images and partial layout as k_wgrad_s3; what differs (ablation builds of the first 16x16x32
+// version, tools/ws_variant.sh: staging DMA 18 % of the time, the B fragment reads 10 %, the step barrier 1 %):
+//  * wave tile = all 64 k of the workgroup x 7 "units" (tap, 16-channel block of c): 12 A fragments per k-step serve 7 x 24 MFMAs and
+//    a unit's three B fragments 24 MFMAs (the 32 k x 32 c x 7 taps tile read 48 fragments per 168 MFMAs, this one 33);
+//  * staging through buffer descriptors: a lane's source offset per 1 KiB piece depends on the tile only, not on z, so it is computed
+//    once per tile and kept in registers (kWP pieces per wave and image); a step's DMA is one instruction per piece with the plane as
+//    scalar offset; padding lanes (and whole planes outside the volume) ask beyond the descriptor's range and get zeros from the
+//    hardware -- no zero page, no per-lane 64-bit addresses, no divisions per step.
+// Lane group g = lane / 16 supplies voxels 8g .. 8g + 7 of a k-step for channel lane % 16 of a 16-channel block (two transposing reads).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(const i32x4& a, const i32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+
+// The staging DMA of k_wgrad_s3x is inline assembly on purpose: with the builtin the compiler knows that LDS writes are in flight and
+// orders every LDS read behind them (s_waitcnt vmcnt(0) at the head of each k-step, i.e. each step waited for its own staging
+// requests -- which are for the NEXT step -- before multiplying: 16 % of the kernel's time).  The kernel waits by hand where the data
+// are needed: vmcnt(0) + barrier at the end of a step.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 dma_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = __builtin_amdgcn_readfirstlane(0x00020000u);
+  return r;
+}
+__device__ __forceinline__ void dma16(const u32x4& rs, const unsigned char* lds_dst, unsigned voff, int soff) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lptr_t)lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(m), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+
+constexpr int kWP = 6;  // 1 KiB pieces per wave of an X slot / a dY buffer (planner: npx, npd <= 8 * kWP)
 
 template <int KS>
 __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS;
   constexpr int ZR = KS == 3 ? 3 : 1, NS = ZR + 1, NDG = KS / ZR, TW = ZR * T2;
-  constexpr int TG = (TW + 3) / 4;
+  constexpr int UW = 2 * TW, NU = (UW + 7) / 8;  // units (tap, c-block) of the workgroup / most units of a wave
+  constexpr unsigned kOut = 0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = wave & 1, tg = wave >> 1;
-  const int t0 = tg * (TW / 4) + (tg < TW % 4 ? tg : TW % 4);
-  const int ntap = TW / 4 + (tg < TW % 4 ? 1 : 0);
+  const int u0 = wave * (UW / 8) + (wave < UW % 8 ? wave : UW % 8);
+  const int nu = UW / 8 + (wave < UW % 8 ? 1 : 0);
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
 
   const int G = gridDim.x, xcd = blockIdx.x & 7;
@@ -787,93 +813,103 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
 
   unsigned char* const xring = lds_raw;
   unsigned char* const dyb = lds_raw + NS * p.xslot;
-  auto slot_of = [&](int pz) { return ((pz + 16) & (NS - 1)) * p.xslot; };
+  auto slot_of = [&](int pz) __attribute__((always_inline)) { return ((pz + 16) & (NS - 1)) * p.xslot; };
 
-  auto issue_x = [&](int n, int y0, int x0, int pz, unsigned char* slot) {
-    const bool zok = (unsigned)pz < (unsigned)p.D;
-    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S + (long)(zok ? pz : 0) * HW;
-#pragma unroll 1
-    for (int pc = wave; pc < p.npx; pc += kWaves) {
-      const unsigned u = (unsigned)(pc * 64 + lane);
-      const unsigned sb = fdiv(u, p.mXUp);
-      const unsigned ur = u - sb * p.XUp;
-      const unsigned ty = fdiv(ur, p.mXp);
-      const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
-      const bool ok = zok && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+  // per-tile source offsets (bytes inside the 12 / 24 sub-blocks of this (sample, c-tile) / (sample, k-tile), plane 0) of the pieces
+  // wave + 8 i; kOut = padding
+  unsigned xo[kWP], yo[kWP];
+  auto tile_offsets = [&](int y0, int x0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kWP; ++i) {
+      const int pc = wave + kWaves * i;
+      {
+        const unsigned u = (unsigned)(pc * 64 + lane);
+        const unsigned sb = fdiv(u, p.mXUp);  // sub-block = block * 3 + term
+        const unsigned ur = u - sb * p.XUp;
+        const unsigned ty = fdiv(ur, p.mXp);
+        const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
+        const bool ok = pc < p.npx && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        xo[i] = ok ? (sb * (unsigned)S + (unsigned)(y * p.W + x)) * 16u : kOut;
+      }
+      {
+        const unsigned u = (unsigned)(pc * 64 + lane);
+        const unsigned sb = fdiv(u, p.mPTp);
+        const unsigned rho = u - sb * p.PTp;
+        const unsigned ty = fdiv(rho, p.mTx);
+        const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
+        const bool ok = pc < p.npd && sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
+        yo[i] = ok ? (sb * (unsigned)S + (unsigned)(y * p.W + x)) * 16u : kOut;
+      }
     }
   };
-  auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
-    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S + (long)z * HW;
-#pragma unroll 1
-    for (int pc = wave; pc < p.npd; pc += kWaves) {
-      const unsigned u = (unsigned)(pc * 64 + lane);
-      const unsigned sb = fdiv(u, p.mPTp);
-      const unsigned rho = u - sb * p.PTp;
-      const unsigned ty = fdiv(rho, p.mTx);
-      const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
-      const bool ok = sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
-      const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
-    }
+  auto issue_x = [&](int n, int pz, unsigned char* slot) __attribute__((always_inline)) {
+    const bool zok = (unsigned)pz < (unsigned)p.D;
+    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S;
+    const u32x4 rs = dma_rsrc(base, zok ? (unsigned)(12 * S * 16) : 0u);
+    const int soff = __builtin_amdgcn_readfirstlane(zok ? (int)(pz * HW * 16) : 0);
+#pragma unroll
+    for (int i = 0; i < kWP; ++i)
+      if (wave + kWaves * i < p.npx) dma16(rs, slot + (wave + kWaves * i) * 1024, xo[i], soff);
+  };
+  auto issue_dy = [&](int n, int z, unsigned char* buf) __attribute__((always_inline)) {
+    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S;
+    const u32x4 rs = dma_rsrc(base, (unsigned)(24 * S * 16));
+    const int soff = __builtin_amdgcn_readfirstlane((int)(z * HW * 16));
+#pragma unroll
+    for (int i = 0; i < kWP; ++i)
+      if (wave + kWaves * i < p.npd) dma16(rs, buf + (wave + kWaves * i) * 1024, yo[i], soff);
   };
 
   // transposed-read roles: lane = 16g + 4q + pp: voxel row 8g + 4*s2 + q of the k-step, channels 4pp .. 4pp + 3 of a 16-channel block
   // (= 8-channel sub-blocks 2*blk + (pp >> 1), byte (pp & 1) * 8 of the unit)
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const unsigned a_term = (unsigned)p.PTp * 16, b_term = (unsigned)p.XUp * 16;
-  unsigned a_lane[2], b_lane[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    a_lane[b] = (unsigned)((((mt * 4 + 2 * b + (pp >> 1)) * 3) * p.PTp) * 16 + (pp & 1) * 8);
-    b_lane[b] = (unsigned)((((2 * b + (pp >> 1)) * 3) * p.XUp) * 16 + (pp & 1) * 8);
-  }
+  const unsigned a_lane = (unsigned)((((pp >> 1) * 3) * p.PTp) * 16 + (pp & 1) * 8), a_blk = 6u * a_term;  // + a * a_blk: k rows 16a ..
+  const unsigned b_lane = (unsigned)((((pp >> 1) * 3) * p.XUp) * 16 + (pp & 1) * 8), b_blk = 6u * b_term;  // + b * b_blk: c 16b ..
 
-  f32x4 acc[TG][2][2];
+  f32x4 acc[NU][4];
 #pragma unroll
-  for (int j = 0; j < TG; ++j)
+  for (int j = 0; j < NU; ++j)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[j][a][b][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[j][a][e] = 0.f;
 
-  int tdz[TG], toff[TG];
+  int udz[NU];
+  unsigned uoff[NU];  // unit j of this wave = (tap, c-block): kernel plane and byte offset inside an X slot (tap shift + c-block + lane)
 #pragma unroll
-  for (int j = 0; j < TG; ++j) {
-    const int t = t0 + j < TW ? t0 + j : TW - 1;
+  for (int j = 0; j < NU; ++j) {
+    const int u = u0 + j < UW ? u0 + j : UW - 1;
+    const int t = u >> 1, b = u & 1;
     const int dz = t / T2, dy = (t / KS) % KS, dx = t % KS;
-    tdz[j] = dz;
-    toff[j] = (dy * p.Xp + dx) * 16;
+    udz[j] = dz;
+    uoff[j] = (unsigned)((dy * p.Xp + dx) * 16) + b * b_blk + b_lane;
   }
 
-  // partial slot f: part[wg][f][tap][k 0..63][c 0..31]; accumulator element e of (rb, cb) = k mt*32 + rb*16 + 4g + e, c cb*16 + lane%16
+  // partial slot f: part[wg][f][tap][k 0..63][c 0..31]; accumulator element e of (unit (tap, b), a) = k a*16 + 4g + e, c b*16 + lane%16
   int nflush = 0, since = 0;
-  auto write_partial = [&](bool live) {
+  auto write_partial = [&](bool live) __attribute__((always_inline)) {
     float* pw = p.part + ((long)wg * p.NF + nflush) * TW * 64 * 32;
     const int m16 = lane & 15;
 #pragma unroll
-    for (int j = 0; j < TG; ++j)
-      if (j < ntap) {
+    for (int j = 0; j < NU; ++j)
+      if (j < nu) {
+        const int u = u0 + j;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a) {
+          float* pt = pw + ((long)(u >> 1) * 64 + a * 16 + 4 * g) * 32 + (u & 1) * 16 + m16;
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            float* pt = pw + ((long)(t0 + j) * 64 + mt * 32 + a * 16 + 4 * g) * 32 + b * 16 + m16;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              pt[e * 32] = live ? acc[j][a][b][e] : 0.f;
-              acc[j][a][b][e] = 0.f;
-            }
+          for (int e = 0; e < 4; ++e) {
+            pt[e * 32] = live ? acc[j][a][e] : 0.f;
+            acc[j][a][e] = 0.f;
           }
+        }
       }
   };
 
   long step = s_lo;
   bool fresh = true;
-  int n = 0, y0 = 0, x0 = 0, z = 0;
+  int n = 0, z = 0;
   while (step < s_hi) {
     if (fresh) {
       long j = step;
@@ -881,31 +917,33 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
       const int xb = (int)(j % p.XB); j /= p.XB;
       const int yb = (int)(j % p.YB);
       n = (int)(j / p.YB);
-      y0 = yb * p.Ty; x0 = xb * p.Tx;
+      tile_offsets(yb * p.Ty, xb * p.Tx);
       __syncthreads();
 #pragma unroll
-      for (int l = 0; l < ZR; ++l) issue_x(n, y0, x0, z + zsh + l, xring + slot_of(z + zsh + l));
-      issue_dy(n, y0, x0, z, dyb + (z & 1) * p.dybuf);
+      for (int l = 0; l < ZR; ++l) issue_x(n, z + zsh + l, xring + slot_of(z + zsh + l));
+      issue_dy(n, z, dyb + (z & 1) * p.dybuf);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       fresh = false;
     }
     const bool cont = z + 1 < p.D && step + 1 < s_hi;
+#ifndef NC_WA_NODMA
     if (cont) {
-      issue_x(n, y0, x0, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
-      issue_dy(n, y0, x0, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
+      issue_x(n, z + 1 + zsh + ZR - 1, xring + slot_of(z + 1 + zsh + ZR - 1));
+      issue_dy(n, z + 1, dyb + ((z + 1) & 1) * p.dybuf);
     }
+#endif
     if (since == p.F && nflush + 1 < p.NF) {
       write_partial(true);
       ++nflush;
       since = 0;
     }
     ++since;
-    // ---- multiply: NK k-steps of 32 voxels x ntap taps x (2 x 2 tiles) x 6 term products
-    const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf);
-    unsigned sb[TG];
+    // ---- multiply: NK k-steps of 32 voxels x nu units x 4 row blocks x 6 term products
+    const unsigned abase = (unsigned)(NS * p.xslot + (z & 1) * p.dybuf) + a_lane;
+    unsigned sb[NU];
 #pragma unroll
-    for (int j = 0; j < TG; ++j) sb[j] = (unsigned)(slot_of(z + zsh + tdz[j]) + toff[j]);
+    for (int j = 0; j < NU; ++j) sb[j] = (unsigned)slot_of(z + zsh + udz[j]) + uoff[j];
 #pragma unroll 1
     for (int s = 0; s < p.NK; ++s) {
       unsigned rho[2], bo[2];
@@ -916,42 +954,48 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
         const unsigned ty = fdiv(rc, p.mTx);
         bo[s2] = (ty * p.Xp + (rc - ty * p.Tx)) * 16;
       }
-      i32x4 A[2][3];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          A[a][t] = tr_frag(lds_raw, abase + a_lane[a] + t * a_term + rho[0] * 16, abase + a_lane[a] + t * a_term + rho[1] * 16);
-      // units u = (tap j, 16-channel block b of c): the three terms of unit u + 1 are read in front of the 12 MFMAs of unit u
-      i32x4 B[2][3];
-      auto read_b = [&](i32x4 (&Bf)[3], int j, int b) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) Bf[t] = tr_frag(lds_raw, sb[j] + b_lane[b] + t * b_term + bo[0], sb[j] + b_lane[b] + t * b_term + bo[1]);
+      // One k-step: 12 A + 3 B fragments (30 reads) up front in the order the products need them, then per unit the 6 reads of the next
+      // unit's B fragments spread over its 24 MFMAs.  The order is pinned with sched_group_barrier: left alone the scheduler sinks
+      // every read next to its first use and the k-step pays an LDS round trip a dozen times.
+      i32x4 A[4][3], B[2][3];
+      auto read_b1 = [&](i32x4& Bf, int j, int t) __attribute__((always_inline)) {
+        Bf = tr_frag(lds_raw, sb[j] + t * b_term + bo[0], sb[j] + t * b_term + bo[1]);
       };
-      read_b(B[0], 0, 0);
 #pragma unroll
-      for (int u = 0; u < 2 * TG; ++u) {
-        const int j = u >> 1, b = u & 1;
-        if (j < ntap) {
-          if (u + 1 < 2 * TG) {
-            if (((u + 1) >> 1) < ntap) read_b(B[(u + 1) & 1], (u + 1) >> 1, (u + 1) & 1);
+      for (int t = 2; t >= 0; --t) {  // the first products use the smallest terms: A2 B0, A1 B1, A0 B2, ...
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          A[a][t] = tr_frag(lds_raw, abase + a * a_blk + t * a_term + rho[0] * 16, abase + a * a_blk + t * a_term + rho[1] * 16);
+        read_b1(B[0][2 - t], 0, 2 - t);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 30, 0);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        if (j + 1 < NU || nu == NU) {  // (units past a wave's last are clamped: their reads are harmless, their products are skipped)
+#ifndef NC_WA_NOB
+          if (j + 1 < NU) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) read_b1(B[(j + 1) & 1][t], j + 1, t);
           }
+#endif
           constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
           constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
           for (int m = 0; m < 6; ++m)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) acc[j][a][b] = mfma16(A[a][TA[m]], B[u & 1][TB[m]], acc[j][a][b]);
+            for (int a = 0; a < 4; ++a) acc[j][a] = mfma16(A[a][TA[m]], B[j & 1][TB[m]], acc[j][a]);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {  // the 6 reads of the next unit spread over this unit's 12 MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
         }
       }
     }
+#ifndef NC_WA_NOBAR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
     ++step;
     if (cont) ++z; else fresh = true;
   }
@@ -1007,8 +1051,11 @@ int ws_kstep() {  // voxels per k-step: 32 = the 16x16x32 kernel (default), 16 =
   return x ? 32 : 16;
 }
 
+// k_wgrad_s3x addresses a (sample, k-tile)'s 24 sub-blocks through one buffer descriptor with 32-bit offsets (bit 31 = "padding")
+int ws_kv(const ConvDims& d) { return ws_kstep() == 32 && (long)d.D * d.H * d.W * 384 < (1l << 31) ? 32 : 16; }
+
 WsPlan ws_plan(const ConvDims& d) {
-  const int KV = ws_kstep();
+  const int KV = ws_kv(d);
   WsPlan best{};
   double best_cost = 1e30;
   const int KS = d.kd;
@@ -1024,6 +1071,7 @@ WsPlan ws_plan(const ConvDims& d) {
       pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
       if ((KS == 3 ? 4 : 2) * pl.xslot + 2 * pl.dybuf > kLdsMax) continue;
       if (pl.NK * KV < 48) continue;
+      if (KV == 32 && (pl.npx > kWaves * kWP || pl.npd > kWaves * kWP)) continue;  // k_wgrad_s3x keeps a tile's DMA offsets in registers
       // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
       const double useful = (double)d.H * d.W;
       const double mfma = (double)pl.YB * pl.XB * pl.NK * KV;
@@ -1106,7 +1154,7 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
     attr_done = true;
   }
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
-  if (ws_kstep() == 32) {
+  if (ws_kv(d) == 32) {
     if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3x<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
     else hipLaunchKernelGGL(k_wgrad_s3x<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   } else if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
