@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
                      : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * 3 + t) * 1024) : "memory");
   };
   // All vector-memory operations of this wave but its 6 youngest (the A fragments requested last) are complete -- `stored`: but
-  // the 6 and the 2 * NCB stores of the previous tile issued by the step before.  The count is chosen by a scalar branch around
+  // the 6 and the stores of the previous tile issued by the step before (2 * NCB; odd NCB: fewer in the fourth step).  The count is chosen by a scalar branch around
   // bare s_waitcnt instructions; ONE statement behind the branch ties the fragment registers to the wait (a tie inside either arm
   // makes the compiler copy the still-in-flight registers in front of the wait).
-  auto wait_a = [&](u32x4 (&A)[2][3], bool stored) {
-    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NCB) : "memory");
+  auto wait_a = [&](u32x4 (&A)[2][3], auto nst, bool stored) {  // nst: stores the step before issued when it stored (compile time)
+    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + decltype(nst)::value) : "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
   };
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   constexpr int kStoreSteps = 4;
   constexpr int kPairs = 2 * NCB;                      // (row block, column block) pairs, four stores each
   constexpr int kPairsPerStep = (kPairs + kStoreSteps - 1) / kStoreSteps;
-  static_assert(kPairs % kStoreSteps == 0, "store pairs per step must be whole");
+  // (odd NCB: the last of the four steps carries fewer pairs)
   f32x4 acc[2][NCB], tot[2][NCB];
   // bias of the tile whose sums wait in `tot`: requested in that tile's last k-step by the same hand-counted kind of load as the
   // weights (an empty descriptor when there is no bias: zeros), complete at the wait of the next step
@@ -350,23 +350,31 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     // step that stored, the count is 6 + its stores.
     // `ph` (compile time): the step number for the first kStoreSteps steps of a tile, which carry the previous tile's stores; kStoreSteps
     // for every later step
-    auto kstep = [&](auto ph, int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
+    auto kstep = [&](auto ph, auto par, int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
       constexpr int PH = decltype(ph)::value;
+      // odd NCB: a step's last column block leaves the next step's first fragments in B[1] -- odd steps walk the two buffers the other way round
+      constexpr int PAR = (NCB & 1) ? decltype(par)::value : 0;
       const bool last = PH == kStoreSteps && s + 1 == p.NS;
       load_a(An, last ? wt_next : wt + (s + 1) * (6 * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
-      wait_a(Ac, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));  // (the step before this one stored)
+      constexpr int PPH = PH >= 1 && PH < kStoreSteps ? PH - 1 : kStoreSteps - 1;  // the step before this one, if it stored
+      constexpr int PPairs = kPairs - PPH * kPairsPerStep < kPairsPerStep ? kPairs - PPH * kPairsPerStep : kPairsPerStep;
+      wait_a(Ac, std::integral_constant<int, 4 * PPairs>{}, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));
       // brick `na` is first used by k-step s + 1 (brick 0: by step 0): it is complete in LDS for THIS wave's pieces; the barrier
       // makes that true for everybody's, and says everybody is done with brick na - 2 (last tap consumed in k-step s - 1 at the
       // latest, KS^2 > 6), whose slot the brick after `na` is requested into
       if (na < NB && 4 * s + 7 >= T2 * na) {
+#ifndef NC_XA_NOBAR
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         // (tried: waves 4 .. 7 -- the SIMD partners of waves 0 .. 3 -- issuing their DMA pieces one k-step later, so that the two
         // partners are not away from the matrix pipe at the same moment: 1.5-2 % slower)
+#ifndef NC_XA_NODMA
         if (na + 1 < NB) {
           issue_brick(cur, na + 1, (ring + na + 1) % 3);
         } else if (more_tiles) {
           issue_brick(nxt, 0, (ring + NB) % 3);
         }
+#endif
         ++na;
       }
       if (last) load_bias(cur);  // (complete at the next step's wait: it is older than that step's 6 A requests)
@@ -376,15 +384,15 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
           store_pairs(prv, PH * kPairsPerStep, (PH + 1) * kPairsPerStep);
         }
       }
-      if constexpr (PH == 0) read_b(B[0], vo, 0);
+      if constexpr (PH == 0) read_b(B[PAR], vo, 0);
       // next k-step's tap state
       tpl += 4;
       if (tpl >= T2) { tpl -= T2; sl = sl == 2 ? 0 : sl + 1; }
       const BAddr nvo = b_addr(b_off());
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        u32x4(&Bc)[3] = B[cb & 1];
-        u32x4(&Bn)[3] = B[(cb + 1) & 1];
+        u32x4(&Bc)[3] = B[(cb + PAR) & 1];
+        u32x4(&Bn)[3] = B[(cb + PAR + 1) & 1];
         if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
         else if (!last) read_b(Bn, nvo, 0);
         // six products per (row block, column block), smallest first: (term of A, term of B)
@@ -415,18 +423,18 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     };
     static_assert(kStoreSteps == 4, "the four peeled steps below");
     STAMP();
-    kstep(std::integral_constant<int, 0>{}, 0, A, nA);
+    kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, A, nA);
     STAMP();
-    kstep(std::integral_constant<int, 1>{}, 1, nA, A);
+    kstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 1, nA, A);
     STAMP();
-    kstep(std::integral_constant<int, 2>{}, 2, A, nA);
+    kstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, 2, A, nA);
     STAMP();
-    kstep(std::integral_constant<int, 3>{}, 3, nA, A);
+    kstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, 3, nA, A);
     STAMP();
 #pragma unroll 1
     for (int s = 4; s < p.NS; s += 2) {  // NS is even: step 0 of the next tile finds its fragments in A again
-      kstep(std::integral_constant<int, 4>{}, s, A, nA);
-      kstep(std::integral_constant<int, 4>{}, s + 1, nA, A);
+      kstep(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, s, A, nA);
+      kstep(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, s + 1, nA, A);
       STAMP();
     }
     prv = cur;
@@ -470,8 +478,10 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
   const int P = W + KS - 1;
   const long HP = (long)H * P;
   static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
-  for (int NCB : {8, 6, 4, 2}) {
+  for (int NCB : {8, 7, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
+    static const int odd_ok = getenv("NC_S3X_NCB7") ? atoi(getenv("NC_S3X_NCB7")) : 1;  // NC_S3X_NCB7=0: even column-block counts only (A/B)
+    if ((NCB & 1) && !odd_ok) continue;
     XPlan pl{};
     pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
     const int PT = 64 * NCB;
@@ -486,7 +496,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
     pl.fsub = 1;
     if (pl.rem) {
       int f = 1;  // the left-over tiles in quarters / thirds / halves (8, 6, 4 -> 2 or 4 column blocks per wave) when they then fit one round
-      if (x_tail_mode() && NCB > 2) {
+      if (x_tail_mode() && NCB > 2 && NCB % 2 == 0) {
         if (pl.rem * (NCB / 2) <= 256) f = NCB / 2;
         else if (NCB == 8 && pl.rem * 2 <= 256) f = 2;
       }
@@ -517,6 +527,7 @@ int launch_x(const XParams& p, int lds, hipStream_t s) {
 template <int KS>
 int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
   if (NCB == 8) return launch_x<KS, 8>(p, lds, s);
+  if (NCB == 7) return launch_x<KS, 7>(p, lds, s);
   if (NCB == 6) return launch_x<KS, 6>(p, lds, s);
   if (NCB == 4) return launch_x<KS, 4>(p, lds, s);
   return launch_x<KS, 2>(p, lds, s);
@@ -558,13 +569,14 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
 #endif
   static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 4;
   p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;  // >= 4: the previous tile's sums leave `tot` during the first four k-steps
-  if (pl.full) {
+  const bool one = pl.rem && pl.fsub == 1;  // the left-over tiles are whole tiles: one launch, some workgroups take one tile more
+  if (pl.full || one) {
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
-    p.t_begin = 0; p.t_count = (int)pl.full; p.tiles_per_xcd = (int)cdiv(pl.full, 8);
+    p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
     const int e = KS == 3 ? launch_x_ncb<3>(pl.NCB, p, pl.lds, s) : launch_x_ncb<5>(pl.NCB, p, pl.lds, s);
     if (e) return e;
   }
-  if (pl.rem) {
+  if (pl.rem && !one) {
     p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
     p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
     const int e = KS == 3 ? launch_x_ncb<3>(pl.NCB / pl.fsub, p, pl.ldst, s) : launch_x_ncb<5>(pl.NCB / pl.fsub, p, pl.ldst, s);

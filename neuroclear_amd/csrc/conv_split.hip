@@ -846,18 +846,34 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
     const bool zok = (unsigned)pz < (unsigned)p.D;
     const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S;
     const u32x4 rs = dma_rsrc(base, zok ? (unsigned)(12 * S * 16) : 0u);
+#ifdef NC_WA_SAMESRC
+    const int soff = 0;
+#else
     const int soff = __builtin_amdgcn_readfirstlane(zok ? (int)(pz * HW * 16) : 0);
+#endif
 #pragma unroll
     for (int i = 0; i < kWP; ++i)
+#ifdef NC_WA_ZEROSRC
+      if (wave + kWaves * i < p.npx) dma16(rs, slot + (wave + kWaves * i) * 1024, kOut, soff);
+#else
       if (wave + kWaves * i < p.npx) dma16(rs, slot + (wave + kWaves * i) * 1024, xo[i], soff);
+#endif
   };
   auto issue_dy = [&](int n, int z, unsigned char* buf) __attribute__((always_inline)) {
     const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S;
     const u32x4 rs = dma_rsrc(base, (unsigned)(24 * S * 16));
+#ifdef NC_WA_SAMESRC
+    const int soff = 0;
+#else
     const int soff = __builtin_amdgcn_readfirstlane((int)(z * HW * 16));
+#endif
 #pragma unroll
     for (int i = 0; i < kWP; ++i)
+#ifdef NC_WA_ZEROSRC
+      if (wave + kWaves * i < p.npd) dma16(rs, buf + (wave + kWaves * i) * 1024, kOut, soff);
+#else
       if (wave + kWaves * i < p.npd) dma16(rs, buf + (wave + kWaves * i) * 1024, yo[i], soff);
+#endif
   };
 
   // transposed-read roles: lane = 16g + 4q + pp: voxel row 8g + 4*s2 + q of the k-step, channels 4pp .. 4pp + 3 of a 16-channel block

@@ -11,12 +11,13 @@ from tools.split_conv import fwd_split, split_ws, to_s3  # noqa: E402
 
 dev = 'cuda'
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-x = torch.randn(1, C, 33, 108, 108, device=dev)
+DZ = int(sys.argv[2]) if len(sys.argv) > 2 else 33
+x = torch.randn(1, C, DZ, 108, 108, device=dev)
 w = torch.randn(64, C, 3, 3, 3, device=dev) * 0.05
 xs = to_s3(x)
 for _ in range(3):
     fwd_split(x, w, None, xs)
-ws = split_ws(1, C, 33, 108, 108, 64, 3)
+ws = split_ws(1, C, DZ, 108, 108, 64, 3)
 ws.zero_()
 fwd_split(x, w, None, xs)
 torch.cuda.synchronize()

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../neuroclear_amd/csrc"
 make -j8 >/dev/null
 mkdir -p abl
 tag=$1; shift
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-int-to-pointer-cast"
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-int-to-pointer-cast -Wno-inline-asm"
 /opt/rocm/bin/hipcc $FL "$@" -c conv_s3x.hip -o abl/conv_s3x_$tag.o
 objs=$(ls *.o | grep -v "^conv_s3x.o$")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o abl/libnc_hip_s3x_$tag.so $objs abl/conv_s3x_$tag.o
