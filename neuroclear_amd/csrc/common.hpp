@@ -177,6 +177,10 @@ bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K);
 int convT_fwd_s3(const float* x, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H,
                  int W, int K, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);
+// conv_split.hip: the 16x16x32 weight-gradient kernel on C8 (16-bit) operands; ws = the partial sums (c8x_wgrad_part_bytes)
+bool c8x_wgrad_supported(const ConvDims& d);
+size_t c8x_wgrad_part_bytes(const ConvDims& d);
+int conv_wgrad_c8x(const void* xh, const void* dyh, float* dw, const ConvDims& d, int dtype, void* ws, size_t wsb, hipStream_t s);
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s);

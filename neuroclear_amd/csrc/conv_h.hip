@@ -1028,6 +1028,7 @@ int run_wh(const float* x, const void* xh_pre, const float* dy, const void* dyh_
   if (!dyh_pre)
     hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dyh, S, d.K);
   if (int e = check_launch("to_c8")) return e;
+  if (c8x_wgrad_supported(d) && c8x_wgrad_part_bytes(d) <= wsb - xb - yb) return conv_wgrad_c8x(xh, dyh, dw, d, DT, part, wsb - xb - yb, s);
   WhParams p{};
   p.xh = xh; p.dyh = dyh; p.part = part; p.zeros = zeros;
   p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;

@@ -764,8 +764,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
 //    hardware -- no zero page, no per-lane 64-bit addresses, no divisions per step.
 // Lane group g = lane / 16 supplies voxels 8g .. 8g + 7 of a k-step for channel lane % 16 of a 16-channel block (two transposing reads).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int DT>
 __device__ __forceinline__ f32x4 mfma16(const i32x4& a, const i32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  if constexpr (DT == NC_DT_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // The staging DMA of k_wgrad_s3x is inline assembly on purpose: with the builtin the compiler knows that LDS writes are in flight and
@@ -789,7 +792,9 @@ __device__ __forceinline__ void dma16(const u32x4& rs, const unsigned char* lds_
 
 constexpr int kWP = 6;  // 1 KiB pieces per wave of an X slot / a dY buffer (planner: npx, npd <= 8 * kWP)
 
-template <int KS>
+// NT = 3: S3 operands (three bf16 terms, six products per fp32 product); NT = 1: the 16-bit operands of the --precision path (C8 layout =
+// the same tensor with one term; DT picks v_mfma_f32_16x16x32_bf16 / _f16).
+template <int KS, int NT, int DT>
 __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS;
@@ -824,11 +829,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
       const int pc = wave + kWaves * i;
       {
         const unsigned u = (unsigned)(pc * 64 + lane);
-        const unsigned sb = fdiv(u, p.mXUp);  // sub-block = block * 3 + term
+        const unsigned sb = fdiv(u, p.mXUp);  // sub-block = block * NT + term
         const unsigned ur = u - sb * p.XUp;
         const unsigned ty = fdiv(ur, p.mXp);
         const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
-        const bool ok = pc < p.npx && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const bool ok = pc < p.npx && sb < 4u * NT && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         xo[i] = ok ? (sb * (unsigned)S + (unsigned)(y * p.W + x)) * 16u : kOut;
       }
       {
@@ -837,15 +842,15 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
         const unsigned rho = u - sb * p.PTp;
         const unsigned ty = fdiv(rho, p.mTx);
         const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
-        const bool ok = pc < p.npd && sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
+        const bool ok = pc < p.npd && sb < 8u * NT && rho < (unsigned)p.PT && y < p.H && x < p.W;
         yo[i] = ok ? (sb * (unsigned)S + (unsigned)(y * p.W + x)) * 16u : kOut;
       }
     }
   };
   auto issue_x = [&](int n, int pz, unsigned char* slot) __attribute__((always_inline)) {
     const bool zok = (unsigned)pz < (unsigned)p.D;
-    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * 3 * S;
-    const u32x4 rs = dma_rsrc(base, zok ? (unsigned)(12 * S * 16) : 0u);
+    const uint4* base = p.xs + ((long)n * (p.C / 8) + ct * 4) * NT * S;
+    const u32x4 rs = dma_rsrc(base, zok ? (unsigned)(4 * NT * S * 16) : 0u);
 #ifdef NC_WA_SAMESRC
     const int soff = 0;
 #else
@@ -860,8 +865,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
 #endif
   };
   auto issue_dy = [&](int n, int z, unsigned char* buf) __attribute__((always_inline)) {
-    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * 3 * S;
-    const u32x4 rs = dma_rsrc(base, (unsigned)(24 * S * 16));
+    const uint4* base = p.dys + ((long)n * (p.K / 8) + kt * 8) * NT * S;
+    const u32x4 rs = dma_rsrc(base, (unsigned)(8 * NT * S * 16));
 #ifdef NC_WA_SAMESRC
     const int soff = 0;
 #else
@@ -880,8 +885,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
   // (= 8-channel sub-blocks 2*blk + (pp >> 1), byte (pp & 1) * 8 of the unit)
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const unsigned a_term = (unsigned)p.PTp * 16, b_term = (unsigned)p.XUp * 16;
-  const unsigned a_lane = (unsigned)((((pp >> 1) * 3) * p.PTp) * 16 + (pp & 1) * 8), a_blk = 6u * a_term;  // + a * a_blk: k rows 16a ..
-  const unsigned b_lane = (unsigned)((((pp >> 1) * 3) * p.XUp) * 16 + (pp & 1) * 8), b_blk = 6u * b_term;  // + b * b_blk: c 16b ..
+  const unsigned a_lane = (unsigned)((((pp >> 1) * NT) * p.PTp) * 16 + (pp & 1) * 8), a_blk = 2u * NT * a_term;  // + a * a_blk: k rows 16a ..
+  const unsigned b_lane = (unsigned)((((pp >> 1) * NT) * p.XUp) * 16 + (pp & 1) * 8), b_blk = 2u * NT * b_term;  // + b * b_blk: c 16b ..
 
   f32x4 acc[NU][4];
 #pragma unroll
@@ -960,9 +965,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
     unsigned sb[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) sb[j] = (unsigned)slot_of(z + zsh + udz[j]) + uoff[j];
-#pragma unroll 1
-    for (int s = 0; s < p.NK; ++s) {
-      unsigned rho[2], bo[2];
+    auto kstep_addr = [&](int s, unsigned (&rho)[2], unsigned (&bo)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         rho[s2] = (unsigned)(32 * s + 8 * g + 4 * s2 + q);
@@ -970,43 +973,87 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
         const unsigned ty = fdiv(rc, p.mTx);
         bo[s2] = (ty * p.Xp + (rc - ty * p.Tx)) * 16;
       }
-      // One k-step: 12 A + 3 B fragments (30 reads) up front in the order the products need them, then per unit the 6 reads of the next
-      // unit's B fragments spread over its 24 MFMAs.  The order is pinned with sched_group_barrier: left alone the scheduler sinks
-      // every read next to its first use and the k-step pays an LDS round trip a dozen times.
-      i32x4 A[4][3], B[2][3];
+    };
+    if constexpr (NT == 1) {
+      // One term: a k-step is 4 A + NU B fragments and 4 NU MFMAs -- too short to hide a unit's reads under the unit before.  B slot j
+      // (unit j) is free once unit j has been multiplied and is refilled with the NEXT k-step's fragment four units later; the A
+      // fragments are double-buffered (the reads of k-step s + 1 spread over k-step s).
+      i32x4 Fa[2][4], Fb[NU];
+      unsigned rho[2], bo[2], nrho[2], nbo[2];
+      kstep_addr(0, rho, bo);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) Fa[0][a] = tr_frag(lds_raw, abase + a * a_blk + rho[0] * 16, abase + a * a_blk + rho[1] * 16);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) Fb[j] = tr_frag(lds_raw, sb[j] + bo[0], sb[j] + bo[1]);
+      auto kstep1 = [&](auto cur, int s) __attribute__((always_inline)) {
+        constexpr int CU = decltype(cur)::value;
+        const bool more = s + 1 < p.NK;
+        kstep_addr(more ? s + 1 : s, nrho, nbo);  // (last k-step: harmless re-reads)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          if (j < 4) Fa[CU ^ 1][j] = tr_frag(lds_raw, abase + j * a_blk + nrho[0] * 16, abase + j * a_blk + nrho[1] * 16);
+          if (j + 1 < NU || nu == NU) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[j][a] = mfma16<DT>(Fa[CU][a], Fb[j], acc[j][a]);
+          }
+          if (j >= 3) {  // refill the slots units j - 3 (.. and, behind the last unit, the rest) have left
+            Fb[j - 3] = tr_frag(lds_raw, sb[j - 3] + nbo[0], sb[j - 3] + nbo[1]);
+          }
+        }
+#pragma unroll
+        for (int j = NU - 3; j < NU; ++j) Fb[j] = tr_frag(lds_raw, sb[j] + nbo[0], sb[j] + nbo[1]);
+      };
+      int s = 0;
+#pragma unroll 1
+      for (; s + 1 < p.NK; s += 2) {
+        kstep1(std::integral_constant<int, 0>{}, s);
+        kstep1(std::integral_constant<int, 1>{}, s + 1);
+      }
+      if (s < p.NK) kstep1(std::integral_constant<int, 0>{}, s);
+    } else {
+#pragma unroll 1
+    for (int s = 0; s < p.NK; ++s) {
+      unsigned rho[2], bo[2];
+      kstep_addr(s, rho, bo);
+      // One k-step: 4 NT A + NT B fragments up front in the order the products need them, then per unit the reads of the next unit's B
+      // fragments spread over its MFMAs.  The order is pinned with sched_group_barrier: left alone the scheduler sinks every read next to
+      // its first use and the k-step pays an LDS round trip a dozen times.
+      constexpr int NP = NT == 3 ? 6 : 1;  // products per (row block, unit), smallest first: (term of A, term of B)
+      constexpr int TA[6] = {NT - 1, 1, 0, 1, 0, 0};
+      constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+      i32x4 A[4][NT], B[2][NT];
       auto read_b1 = [&](i32x4& Bf, int j, int t) __attribute__((always_inline)) {
         Bf = tr_frag(lds_raw, sb[j] + t * b_term + bo[0], sb[j] + t * b_term + bo[1]);
       };
 #pragma unroll
-      for (int t = 2; t >= 0; --t) {  // the first products use the smallest terms: A2 B0, A1 B1, A0 B2, ...
+      for (int t = NT - 1; t >= 0; --t) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
           A[a][t] = tr_frag(lds_raw, abase + a * a_blk + t * a_term + rho[0] * 16, abase + a * a_blk + t * a_term + rho[1] * 16);
-        read_b1(B[0][2 - t], 0, 2 - t);
+        read_b1(B[0][NT - 1 - t], 0, NT - 1 - t);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 30, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10 * NT, 0);
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
         if (j + 1 < NU || nu == NU) {  // (units past a wave's last are clamped: their reads are harmless, their products are skipped)
 #ifndef NC_WA_NOB
           if (j + 1 < NU) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) read_b1(B[(j + 1) & 1][t], j + 1, t);
+            for (int t = 0; t < NT; ++t) read_b1(B[(j + 1) & 1][t], j + 1, t);
           }
 #endif
-          constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
-          constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-          for (int m = 0; m < 6; ++m)
+          for (int m = 0; m < NP; ++m)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[j][a] = mfma16(A[a][TA[m]], B[j & 1][TB[m]], acc[j][a]);
+            for (int a = 0; a < 4; ++a) acc[j][a] = mfma16<DT>(A[a][TA[m]], B[j & 1][TB[m]], acc[j][a]);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
+          for (int k = 0; k < NP; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NT == 3 ? 1 : 2, 0);
           }
         }
       }
+    }
     }
 #ifndef NC_WA_NOBAR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1067,11 +1114,11 @@ int ws_kstep() {  // voxels per k-step: 32 = the 16x16x32 kernel (default), 16 =
   return x ? 32 : 16;
 }
 
-// k_wgrad_s3x addresses a (sample, k-tile)'s 24 sub-blocks through one buffer descriptor with 32-bit offsets (bit 31 = "padding")
-int ws_kv(const ConvDims& d) { return ws_kstep() == 32 && (long)d.D * d.H * d.W * 384 < (1l << 31) ? 32 : 16; }
+// k_wgrad_s3x addresses a (sample, k-tile)'s 8 NT sub-blocks through one buffer descriptor with 32-bit offsets (bit 31 = "padding")
+int ws_kv(const ConvDims& d, int NT = 3) { return (NT == 1 || ws_kstep() == 32) && (long)d.D * d.H * d.W * 128 * NT < (1l << 31) ? 32 : 16; }
 
-WsPlan ws_plan(const ConvDims& d) {
-  const int KV = ws_kv(d);
+WsPlan ws_plan(const ConvDims& d, int NT = 3) {
+  const int KV = ws_kv(d, NT);
   WsPlan best{};
   double best_cost = 1e30;
   const int KS = d.kd;
@@ -1083,7 +1130,7 @@ WsPlan ws_plan(const ConvDims& d) {
       pl.XB = (d.W + Tx - 1) / Tx; pl.YB = (d.H + Ty - 1) / Ty;
       pl.Xp = Tx + KS - 1; pl.XU = (Ty + KS - 1) * pl.Xp; pl.XUp = pad_4mod8(pl.XU + KS);  // + KS: tap reads of the clamped tail
       pl.PT = Ty * Tx; pl.NK = (pl.PT + KV - 1) / KV; pl.PTp = pad_4mod8(pl.NK * KV);
-      pl.npx = (12 * pl.XUp + 63) / 64; pl.npd = (24 * pl.PTp + 63) / 64;
+      pl.npx = (4 * NT * pl.XUp + 63) / 64; pl.npd = (8 * NT * pl.PTp + 63) / 64;
       pl.xslot = pl.npx * 1024; pl.dybuf = pl.npd * 1024;
       if ((KS == 3 ? 4 : 2) * pl.xslot + 2 * pl.dybuf > kLdsMax) continue;
       if (pl.NK * KV < 48) continue;
@@ -1091,7 +1138,7 @@ WsPlan ws_plan(const ConvDims& d) {
       // cost per useful position: MFMA time (k-steps incl. padding and tile overhang) + a staging term
       const double useful = (double)d.H * d.W;
       const double mfma = (double)pl.YB * pl.XB * pl.NK * KV;
-      const double stage = (double)pl.YB * pl.XB * (12.0 * pl.XUp + 24.0 * pl.PTp) / 72.0;
+      const double stage = (double)pl.YB * pl.XB * (4.0 * pl.XUp + 8.0 * pl.PTp) / 24.0;
       const double cost = (mfma + 0.15 * stage) / useful;
       if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
     }
@@ -1162,8 +1209,8 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3, 3, NC_DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5, 3, NC_DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
       set_error("wgrad_s3: cannot raise dynamic LDS limit");
       return NC_ERR_HIP;
     }
@@ -1171,8 +1218,8 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   }
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
   if (ws_kv(d) == 32) {
-    if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3x<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
-    else hipLaunchKernelGGL(k_wgrad_s3x<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+    if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 3, NC_DT_BF16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+    else hipLaunchKernelGGL((k_wgrad_s3x<5, 3, NC_DT_BF16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   } else if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   else hipLaunchKernelGGL(k_wgrad_s3<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   if (int e = check_launch("wgrad_s3")) return e;
@@ -1182,7 +1229,66 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   return check_launch("wgrad_s3_reduce");
 }
 
+// The same kernel on the 16-bit operands of the --precision path (C8 = one term), conv_h.hip's k_wgrad_h replaced: xh / dyh in C8,
+// dw fp32; ws: the partial sums only.
+bool wsx_shape_ok(const ConvDims& d) {
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
+  if (d.C % 32 || d.K % 64) return false;
+  if ((d.K / 64) * (d.C / 32) * (d.kd == 5 ? 5 : 1) > 256) return false;
+  if (ws_kv(d, 1) != 32) return false;
+  return ws_plan(d, 1).ok;
+}
+
+template <int DT>
+int run_wsx(const void* xh, const void* dyh, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
+  const WsPlan pl = ws_plan(d, 1);
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  const int nwp = ws_nwp(d, pl, npairs);
+  const long steps = (long)d.N * pl.YB * pl.XB * d.D;
+  if (!ws || wsb < (size_t)npairs * nwp * TW * 64 * 32 * 4) { set_error("wgrad_c8x: workspace too small"); return NC_ERR_WS; }
+  WsParams p{};
+  p.xs = (const uint4*)xh; p.dys = (const uint4*)dyh; p.part = (float*)ws; p.zeros = nullptr;
+  p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
+  p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
+  p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
+  p.F = 1 << 30; p.NF = 1;  // exact 16-bit products, fp32 accumulation: no accumulator restarts
+  p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3, 1, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5, 1, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
+      set_error("wgrad_c8x: cannot raise dynamic LDS limit");
+      return NC_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int lds = NS * pl.xslot + 2 * pl.dybuf;
+  if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 1, DT>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  else hipLaunchKernelGGL((k_wgrad_s3x<5, 1, DT>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  if (int e = check_launch("wgrad_c8x")) return e;
+  const long total = (long)d.K * d.C * T3;
+  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, (const float*)ws, dw, d.C, T3, TW, d.C / 32, npairs, nwp, 1,
+                     total);
+  return check_launch("wgrad_c8x_reduce");
+}
+
 }  // namespace
+
+bool c8x_wgrad_supported(const ConvDims& d) {
+  static const int on = getenv("NC_HX_WGRAD") ? atoi(getenv("NC_HX_WGRAD")) : 1;  // NC_HX_WGRAD=0: conv_h.hip's k_wgrad_h (A/B)
+  return on && wsx_shape_ok(d);
+}
+size_t c8x_wgrad_part_bytes(const ConvDims& d) {
+  const int T3 = d.kd * d.kh * d.kw, TW = d.kd == 3 ? 27 : 25;
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  return (size_t)npairs * ws_nwp(d, ws_plan(d, 1), npairs) * TW * 64 * 32 * 4;
+}
+int conv_wgrad_c8x(const void* xh, const void* dyh, float* dw, const ConvDims& d, int dtype, void* ws, size_t wsb, hipStream_t s) {
+  return dtype == NC_DT_F16 ? run_wsx<NC_DT_F16>(xh, dyh, dw, d, ws, wsb, s) : run_wsx<NC_DT_BF16>(xh, dyh, dw, d, ws, wsb, s);
+}
 
 bool s3_fwd_supported(const ConvDims& d) { return s_shape_ok(d, d.C, d.K); }
 bool s3_dgrad_supported(const ConvDims& d) { return s_shape_ok(d, d.K, d.C); }
