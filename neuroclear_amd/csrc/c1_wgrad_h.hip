@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
     const uint4* src = p.gc8 + ((long)n * 8 + wave) * S + ((long)z * p.H + y) * p.W;
     unsigned short* dst = Gs + ((long)buf * 8 + wave) * p.PX * 8;
     for (int u0 = 0; u0 < p.W; u0 += 64)
-      if (u0 + lane < p.W) __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)(dst + (long)u0 * 8), 16, 0, 0);
+      if (u0 + lane < p.W) nc_dma_lds16((src + u0 + lane), nc_lds_addr((dst + (long)u0 * 8)));
   };
   auto stage_x = [&](int yy) {  // input row yy (may be outside the plane) of this group's 4 dz planes -> ring slot (yy + P) & 7
     const int slot = (yy + P) & 7;
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(512) k_c1_wgrad_p(const CwParams p) {
         const bool ok = dz < KS && (unsigned)zz < (unsigned)p.D && (unsigned)yy < (unsigned)p.H;
         const unsigned short* src =
             ok ? p.xp + (((long)n * 8 + j) * R + (long)zz * p.H + yy) * p.PX + lane * 8 : reinterpret_cast<const unsigned short*>(p.zeros);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(XPs + (((long)dl * 8 + slot) * 8 + j) * p.PL), 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr((XPs + (((long)dl * 8 + slot) * 8 + j) * p.PL)));
       }
     }
   };

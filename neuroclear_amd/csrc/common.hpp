@@ -22,6 +22,31 @@ inline int check_launch(const char* what) {
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// LDS-DMA (one 16-byte / 4-byte unit per lane from a per-lane global address into LDS at lds_addr + lane * size)
+// as inline assembly.  With __builtin_amdgcn_global_load_lds the compiler books the request as a FLAT access that may touch LDS:
+// from then on every LDS-read wait in the kernel is lgkmcnt(0) (flat operations may return out of order), i.e. a software-pipelined
+// fragment loop waits for the reads it has JUST issued, and any LDS read behind an outstanding request is preceded by vmcnt(0).
+// The caller waits by hand (s_waitcnt vmcnt + barrier) where the staged data are needed.
+#if defined(__HIP_DEVICE_COMPILE__)
+// lds_addr: LDS byte address (nc_lds_addr(pointer into the kernel's LDS array)), wave-uniform
+__device__ __forceinline__ unsigned nc_lds_addr(const void* lds_ptr) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds_ptr;
+}
+__device__ __forceinline__ void nc_dma_lds16(const void* src, unsigned lds_addr) {
+  const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(src) : "memory", "m0");
+}
+__device__ __forceinline__ void nc_dma_lds4(const void* src, unsigned lds_addr) {
+  const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(m), "v"(src) : "memory", "m0");
+}
+#else  // (host pass: declarations only)
+__device__ unsigned nc_lds_addr(const void* lds_ptr);
+__device__ void nc_dma_lds16(const void* src, unsigned lds_addr);
+__device__ void nc_dma_lds4(const void* src, unsigned lds_addr);
+#endif
+
+
 // 256 B of zeros in the code object of a translation unit: the source of padding / out-of-range lanes of LDS-DMA copies
 // (no memset launch per convolution).  NC_ZERO_PAGE() once at namespace scope, nc_zero_page() = its device address.
 #define NC_ZERO_PAGE()                                                                          \

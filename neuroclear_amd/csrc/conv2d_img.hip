@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
         const int s = s0 + lane;
         const int o = s < used ? tab[s] : -1;
         const float* src = o >= 0 ? xc + (long)ci * Sin + o : g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bd + (long)ci * p.CS + s0), 4, 0, 0);
+        nc_dma_lds4(src, nc_lds_addr((bd + (long)ci * p.CS + s0)));
       }
     }
   };
@@ -543,8 +543,7 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
       if (valid) {
 #pragma unroll 8
         for (int ch = wave * 32; ch < wave * 32 + 32; ++ch)
-          __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.dy + (dyo + (unsigned)(ch * HW)) * 4u), (lptr_t)(As + ch * kWAP), 4, 0,
-                                           0);
+          nc_dma_lds4(((const char*)p.dy + (dyo + (unsigned)(ch * HW)) * 4u), nc_lds_addr((As + ch * kWAP)));
       } else {
         for (int ch = wave * 32; ch < wave * 32 + 32; ++ch) As[ch * kWAP + lane] = 0.f;
       }
@@ -572,14 +571,12 @@ __global__ void __launch_bounds__(256, 2) k_swgrad(const WParams p) {
           const int ro = __builtin_amdgcn_readlane(rowoff, r);
           if (ro >= 0) {
             if (colok && lane < p.pitch)
-              __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)(ro + co + lane - 1) * 4u), (lptr_t)(xd + r * p.pitch), 4,
-                                               0, 0);
+              nc_dma_lds4(((const char*)p.x + (unsigned)(ro + co + lane - 1) * 4u), nc_lds_addr((xd + r * p.pitch)));
 #pragma unroll 1
             for (int cc = 64; cc < p.pitch; cc += 64) {
               const int col = cc + lane;
               if ((unsigned)(col - 1) < (unsigned)p.Wi)
-                __builtin_amdgcn_global_load_lds((gptr_t)((const char*)p.x + (unsigned)(ro + co + col - 1) * 4u),
-                                                 (lptr_t)(xd + r * p.pitch + cc), 4, 0, 0);
+                nc_dma_lds4(((const char*)p.x + (unsigned)(ro + co + col - 1) * 4u), nc_lds_addr((xd + r * p.pitch + cc)));
             }
           } else {
             for (int col = lane; col < p.pitch; col += 64) xd[r * p.pitch + col] = 0.f;

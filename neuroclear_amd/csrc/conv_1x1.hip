@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void k_wgrad_1x1(W1Params p) {
       if (j < p.npd + p.npx) {
         const float* base = j >= p.npd ? xb : db;
         const float* src = (goff[i] >= 0 && gcol[i] < vleft) ? base + goff[i] : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + j * 256), 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr((buf + j * 256)));
       }
     }
   };
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void k_flat_1x1(F1Params p) {
       const int j = wave + 8 * i;
       if (j < p.npi) {
         const float* src = (goff[i] >= 0 && gcol[i] < vleft) ? xb + goff[i] : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + j * 256), 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr((buf + j * 256)));
       }
     }
   };

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void k_wgrad_c1(C1wParams p) {
       const int zz = z + gxp - PAD;
       const bool ok = gxp >= 0 && yy >= 0 && yy < p.H && zz >= 0 && zz < p.D;
       const float* src = ok ? p.x + (long)n * S + (long)zz * HW + (long)yy * p.W + gxc : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xT + (cnt % RING) * SXs + wave * 256), 16, 0, 0);
+      nc_dma_lds16(src, nc_lds_addr((xT + (cnt % RING) * SXs + wave * 256)));
     }
     if (with_dy) {
       const float* dbse = p.dy + (long)n * 64 * S + (long)z * HW + (long)(yy - PAD) * p.W;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void k_wgrad_c1(C1wParams p) {
         const int j = wave + 8 * i;
         if (j < npd) {
           const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+          nc_dma_lds16(src, nc_lds_addr((ds + j * 256)));
         }
       }
     }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512) void k_dgrad_to1(T1Params p) {
       const int jj = wave + 8 * i;
       if (jj < npd) {
         const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + jj * 256), 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr((ds + jj * 256)));
       }
     }
   };

@@ -239,6 +239,7 @@ __device__ __forceinline__ HTile h_decode(const HParams& p, long t) {
 template <int DT, int KZ, int KY, int KX, bool PAIR, int VB, int NA>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  const unsigned lds0 = nc_lds_addr(lds_raw);
   constexpr int PADZ = KZ / 2, PADY = KY / 2, PADX = KX / 2, T2 = KY * KX;
   // !PAIR (3^3): a k-step = 16 channels (two C8 blocks) at one tap.  PAIR (5^3, and the 8-pseudo-channel layers): a k-step
   // = 8 channels (one C8 block) at TWO taps, lane half h taking tap 2i + h (an odd tap count ends in a zero-weight tap):
@@ -285,14 +286,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
       const int pc = wave + kWaves * j;
       if (pc < p.npb) {
         const uint4* src = off[j] >= 0 ? plane + off[j] : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+        nc_dma_lds16(src, lds0 + (unsigned)(buf - lds_raw) + pc * 1024);
       }
     }
     const uint4* ws = p.wp + (((long)tcot * p.NCH + chunk) * KZ + dz) * (KSTEPS * 128) + lane;
     unsigned char* wb = buf + p.npb * 1024;
 #pragma unroll 1
     for (int pw = wave; pw < p.npw; pw += kWaves)
-      __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
+      nc_dma_lds16(ws + pw * 64, lds0 + (unsigned)(wb - lds_raw) + pw * 1024);
   };
 
   unsigned char* const buf0 = lds_raw;
@@ -347,71 +348,63 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_h(const HParams p) {
           const int o0 = (t0 / KX) * p.P + t0 % KX, o1 = (t1 / KX) * p.P + t1 % KX;
           return h ? o1 : o0;
         };
-        i32x4 a0 = wrow[0], a1 = wrow[64], b[VB], na0, na1, nb[VB];
+        // (fully unrolled with the two fragment sets named statically: the rolled loop carried them through register copies and an
+        //  lgkmcnt(0) behind the first MFMA of every k-step -- the next k-step's reads were waited for at once)
+        i32x4 A[2][2], B[2][VB];
+        A[0][0] = wrow[0]; A[0][1] = wrow[64];
         {
           const i32x4* bp = brow + boff(0);
 #pragma unroll
-          for (int v = 0; v < VB; ++v) b[v] = bp[v * 32];
+          for (int v = 0; v < VB; ++v) B[0][v] = bp[v * 32];
         }
-#pragma unroll 1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int i = 0; i < KSTEPS; ++i) {
-          const int in = i + 1 < KSTEPS ? i + 1 : i;  // after the last k-step: a harmless re-read
-          const i32x4* wn = wrow + in * 128;
-          const i32x4* bnp = brow + boff(in);
-          na0 = wn[0]; na1 = wn[64];
+          const int c = i & 1, n = c ^ 1;
+          if (i + 1 < KSTEPS) {
+            const i32x4* wn = wrow + (i + 1) * 128;
+            const i32x4* bnp = brow + boff(i + 1);
+            A[n][0] = wn[0]; A[n][1] = wn[64];
 #pragma unroll
-          for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
-#pragma unroll
-          for (int v = 0; v < VB; ++v) {
-            acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
-            if constexpr (NA == 2) acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
+            for (int v = 0; v < VB; ++v) B[n][v] = bnp[v * 32];
           }
-          __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, NA * VB, 0);
-          a0 = na0; a1 = na1;
-#pragma unroll
-          for (int v = 0; v < VB; ++v) b[v] = nb[v];
+          __builtin_amdgcn_sched_barrier(0);  // the reads of k-step i + 1 stay in front of the MFMAs of k-step i (the group-barrier
+#pragma unroll                                //  form of this hint was not honoured: every read sank to just in front of its wait)
+          for (int v = 0; v < VB; ++v) {
+            acc[0][v] = mfma16<DT>(A[c][0], B[c][v], acc[0][v]);
+            if constexpr (NA == 2) acc[1][v] = mfma16<DT>(A[c][1], B[c][v], acc[1][v]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
       // A fragments: unit ((t*2 + a)*2 + h)*32 + r of the stage's weights; B fragments: unit h*RP + position + tap
       const i32x4* wrow = reinterpret_cast<const i32x4*>(bc + p.npb * 1024) + h * 32 + r;
       const i32x4* brow = reinterpret_cast<const i32x4*>(bc) + h * p.RP + qb + cur.xoff;
       // Software pipeline over the taps of the plane, pinned with sched_group_barrier: the 2 + VB LDS reads of tap
-      // t+1 are issued in front of the 2*VB MFMAs of tap t (the row loop is not unrolled so that the loop-carried
-      // operands keep the machine scheduler from re-merging the stages).
-      i32x4 a0 = wrow[0], a1 = wrow[64], b[VB], na0, na1, nb[VB];
+      // t+1 are issued in front of the 2*VB MFMAs of tap t.  Fully unrolled, the two fragment sets named statically (the rolled
+      // row loop carried them through 12 register copies per tap and waited lgkmcnt(0) behind the first MFMA of every tap).
+      i32x4 A[2][2], B[2][VB];
+      A[0][0] = wrow[0]; A[0][1] = wrow[64];
 #pragma unroll
-      for (int v = 0; v < VB; ++v) b[v] = brow[v * 32];
-#pragma unroll 1
-      for (int dy = 0; dy < KY; ++dy) {
-        const bool last_row = dy == KY - 1;
-        const i32x4* wrow_n = last_row ? wrow : wrow + KX * 128;  // after the last row: any in-range address
-        const i32x4* brow_n = last_row ? brow : brow + p.P;
+      for (int v = 0; v < VB; ++v) B[0][v] = brow[v * 32];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dx = 0; dx < KX; ++dx) {
-          const i32x4* wn = dx + 1 < KX ? wrow + (dx + 1) * 128 : wrow_n;
-          const i32x4* bnp = dx + 1 < KX ? brow + dx + 1 : brow_n;
-          if (p.ablate & 8) {
-            na0 = a0; na1 = a1;
+      for (int t = 0; t < T2; ++t) {
+        const int c = t & 1, n = c ^ 1;
+        if (t + 1 < T2) {
+          const i32x4* wn = wrow + (t + 1) * 128;
+          const i32x4* bnp = brow + ((t + 1) / KX) * p.P + (t + 1) % KX;
+          A[n][0] = wn[0]; A[n][1] = wn[64];
 #pragma unroll
-            for (int v = 0; v < VB; ++v) nb[v] = b[v];
-          } else {
-            na0 = wn[0]; na1 = wn[64];
-#pragma unroll
-            for (int v = 0; v < VB; ++v) nb[v] = bnp[v * 32];
-          }
-#pragma unroll
-          for (int v = 0; v < VB; ++v) {
-            acc[0][v] = mfma16<DT>(a0, b[v], acc[0][v]);
-            if constexpr (NA == 2) acc[1][v] = mfma16<DT>(a1, b[v], acc[1][v]);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x100, 2 + VB, 0);  // DS reads of the next tap ...
-          __builtin_amdgcn_sched_group_barrier(0x008, NA * VB, 0);  // ... then this tap's MFMAs
-          a0 = na0; a1 = na1;
-#pragma unroll
-          for (int v = 0; v < VB; ++v) b[v] = nb[v];
+          for (int v = 0; v < VB; ++v) B[n][v] = bnp[v * 32];
         }
-        wrow = wrow_n; brow = brow_n;
+        __builtin_amdgcn_sched_barrier(0);  // the reads of tap t + 1 stay in front of the MFMAs of tap t
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+          acc[0][v] = mfma16<DT>(A[c][0], B[c][v], acc[0][v]);
+          if constexpr (NA == 2) acc[1][v] = mfma16<DT>(A[c][1], B[c][v], acc[1][v]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       }
       chunk = nchunk; dzi = ndz;
@@ -827,7 +820,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
       const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
       const bool ok = zok && cb < 4u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       const uint4* src = ok ? base + (long)cb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+      nc_dma_lds16(src, nc_lds_addr((slot + pc * 1024)));
     }
   };
   auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
@@ -842,7 +835,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_h(const WhParams p) {
       const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
       const bool ok = cb < 8u && rho < (unsigned)p.PT && y < p.H && x < p.W;
       const uint4* src = ok ? base + (long)cb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+      nc_dma_lds16(src, nc_lds_addr((buf + pc * 1024)));
     }
   };
 

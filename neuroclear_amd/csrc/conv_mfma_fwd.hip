@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_conv_mfma(FwdParams p) {
       const float* src = (NC_ABLATE & 16) ? p.x + lane * 4 : (ok ? xt + off : p.zeros);
       float* dst = bd + j * 64 * 4;  // wave-uniform
       if (!TAIL || cic >= (unsigned)CK || (int)x != wfull)
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr(dst));
     }
     if constexpr (TAIL) {
 #pragma unroll

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void k_wgrad_dma(WdParams p) {
         const int j = wave + 8 * i;
         if (j < npx) {
           const float* src = (row_ok && gx[i] >= 0) ? xbse + gx[i] : p.zeros;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + j * 256), 16, 0, 0);
+          nc_dma_lds16(src, nc_lds_addr((xs + j * 256)));
         }
       }
       if (with_dy) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void k_wgrad_dma(WdParams p) {
           const int j = wave + 8 * i;
           if (j < npd) {
             const float* src = gd[i] >= 0 ? dbse + gd[i] : p.zeros;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+            nc_dma_lds16(src, nc_lds_addr((ds + j * 256)));
           }
         }
       }
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(WrParams p) {
       if (j < npx) {
         const int yy = y0 - PAD + gxr[i];
         const float* src = (gx[i] >= 0 && yy >= 0 && yy < p.H) ? xbse + gx[i] : p.zeros;
-        if (gx[i] != -2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xs + j * 256), 16, 0, 0);
+        if (gx[i] != -2) nc_dma_lds16(src, nc_lds_addr((xs + j * 256)));
       }
     }
 #pragma unroll
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(512) void k_wgrad_rows(WrParams p) {
       const int j = wave + 8 * i;
       if (j < npd) {
         const float* src = (gd[i] >= 0 && y0 + gdr[i] < p.H) ? dbse + gd[i] : p.zeros;
-        if (gd[i] != -2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ds + j * 256), 16, 0, 0);
+        if (gd[i] != -2) nc_dma_lds16(src, nc_lds_addr((ds + j * 256)));
       }
     }
     if (tw && tl_lofs >= 0) {

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
       const int pc = wave + kWaves * j;
       if (pc < p.npb) {
         const uint4* src = off[j] >= 0 ? plane + off[j] : p.zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+        nc_dma_lds16(src, nc_lds_addr((buf + pc * 1024)));
       }
     }
   };
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3(const SParams p) {
     const int npw = (NC_S3_ABLATE & 4) ? 0 : (qe - qa) * kPairPieces;
 #pragma unroll 1
     for (int pw = wave; pw < npw; pw += kWaves)
-      __builtin_amdgcn_global_load_lds((gptr_t)(ws + pw * 64), (lptr_t)(wb + pw * 1024), 16, 0, 0);
+      nc_dma_lds16((ws + pw * 64), nc_lds_addr((wb + pw * 1024)));
   };
 
   const int BB = p.npb * 1024;
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
       const int y = y0 - PAD + (int)ty, x = x0 - PAD + (int)(ur - ty * p.Xp);
       const bool ok = zok && sb < 12u && ur < (unsigned)p.XU && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+      nc_dma_lds16(src, nc_lds_addr((slot + pc * 1024)));
     }
   };
   auto issue_dy = [&](int n, int y0, int x0, int z, unsigned char* buf) {
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
       const int y = y0 + (int)ty, x = x0 + (int)(rho - ty * p.Tx);
       const bool ok = sb < 24u && rho < (unsigned)p.PT && y < p.H && x < p.W;
       const uint4* src = ok ? base + (long)sb * S + (long)y * p.W + x : p.zeros;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + pc * 1024), 16, 0, 0);
+      nc_dma_lds16(src, nc_lds_addr((buf + pc * 1024)));
     }
   };
 
