@@ -21,7 +21,7 @@ def kernel_class(name):
         return 'wgrad_mfma_k3'
     if 'k_wgrad_mfma<5' in name or 'k_wgrad_dma<5' in name:
         return 'wgrad_mfma_k5'
-    for kern, cls in (('k_conv_s3x<3, 8', 'conv_split_k3'), ('k_conv_s3x<3, 6', 'conv_split_k3_small'), ('k_conv_s3x<3, 4', 'conv_split_k3_small'),
+    for kern, cls in (('k_conv_s3x<3, 8', 'conv_split_k3'), ('k_conv_s3x<3, 7', 'conv_split_k3'), ('k_conv_s3x<5, 7', 'conv_split_k5'), ('k_conv_s3x<3, 6', 'conv_split_k3_small'), ('k_conv_s3x<3, 4', 'conv_split_k3_small'),
                       ('k_conv_s3x<3, 2', 'conv_split_k3_tail'), ('k_conv_s3x<5, 8', 'conv_split_k5'), ('k_conv_s3x<5', 'conv_split_k5_tail'),
                       ('k_conv_s3<3', 'conv_split_k3'), ('k_conv_s3<5', 'conv_split_k5'), ('k_wgrad_s3x<3', 'wgrad_split_k3'),
                       ('k_wgrad_s3x<5', 'wgrad_split_k5'), ('k_wgrad_s3<3', 'wgrad_split_k3'), ('k_wgrad_s3<5', 'wgrad_split_k5'),
