@@ -62,3 +62,18 @@ def test_hand_counted_loads_are_not_touched_in_flight(tmp_path):
     for line in text.splitlines():
         if '.vgpr_spill_count:' in line or '.sgpr_spill_count:' in line and False:
             assert line.strip().endswith(' 0'), line
+
+
+def test_lds_dma_is_not_issued_through_the_builtin():
+    """__builtin_amdgcn_global_load_lds makes hipcc book a FLAT access that may touch LDS: every later LDS-read wait in the kernel
+    becomes lgkmcnt(0) and LDS reads behind an outstanding request get vmcnt(0).  The kernels issue the same
+    instruction through common.hpp's nc_dma_lds16 / nc_dma_lds4 (inline assembly) and wait by hand -- keep it that way."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for f in glob.glob(os.path.join(root, 'neuroclear_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'neuroclear_amd', 'csrc', '*.hpp')):
+        for n, line in enumerate(open(f), 1):
+            code = line.split('//')[0]
+            if '__builtin_amdgcn_global_load_lds' in code:
+                bad.append('%s:%d' % (os.path.basename(f), n))
+    assert not bad, bad
