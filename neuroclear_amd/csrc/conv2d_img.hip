@@ -190,6 +190,14 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
   };
 
   stage(0, buf0);
+  // The weights of channel pair i + 1 are requested while pair i is multiplied (the pairs of all chunks are one linear stream): a
+  // request issued right in front of its use waited out the L2 round trip every pair -- and, vmcnt retiring in order, the staging
+  // requests of the next chunk issued just before it.  (The last pair re-requests itself.)
+  float2 aw[T], awn[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) aw[t] = wload(aptr + t * kstep_b);
+  const int npairs_all = p.C / 2;
+  int pair_i = 0;
   for (int q = 0; q < nchunks; ++q) {
     float* cur = (q & 1) ? buf1 : buf0;
     float* nxt = (q & 1) ? buf0 : buf1;
@@ -199,10 +207,10 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
 #pragma unroll 1
     for (int cp = 0; cp < p.CK / 2; ++cp) {
       const float* cb = cur + (long)(2 * cp + h) * p.CS;
-      float2 aw[T];
+      ++pair_i;
+      if (pair_i < npairs_all) aptr += T * kstep_b;
 #pragma unroll
-      for (int t = 0; t < T; ++t) aw[t] = wload(aptr + t * kstep_b);
-      aptr += T * kstep_b;
+      for (int t = 0; t < T; ++t) awn[t] = wload(aptr + t * kstep_b);
 #pragma unroll
       for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
@@ -217,6 +225,8 @@ __global__ void __launch_bounds__(WM* WN * 64) k_sconv(const SParams P) {
             acc[1][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ty * TX + tx].y, bv[v], acc[1][v], 0, 0, 0);
           }
         }
+#pragma unroll
+      for (int t = 0; t < T; ++t) aw[t] = awn[t];
     }
   }
 
