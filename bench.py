@@ -232,14 +232,6 @@ def run_train(args, rank, world, dev):
         if not first:  # losses of the very first step from the seeded initial weights: comparable between runs of different length
             first.update({k: round(v, 5) for k, v in model.get_current_losses().items()})
 
-    if os.environ.get('NC_MAIN_PRIO', '0') != '0':  # (experiment) the generators' stream at high priority, the discriminator streams stay low
-        hp = torch.cuda.Stream(priority=-1)
-        hp.wait_stream(torch.cuda.current_stream())
-        _inner = step
-
-        def step():  # noqa: F811
-            with torch.cuda.stream(hp):
-                _inner()
     for _ in range(args.warmup):
         step()
     if world > 1:
