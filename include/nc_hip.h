@@ -389,6 +389,15 @@ int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float*
 int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const void* dys, float* dw, int N, int C, int D, int H, int W,
                         int K, int ks, void* ws, size_t ws_bytes, void* stream); /* nc_conv_wgrad (weights only) */
 
+/* ConvTranspose3d(kernel 2, stride 2) forward -- nn.ConvTranspose3d at networks.py:471-478 -- on the same arithmetic (csrc/convt_s3.hip):
+ * C % 32 == 0 (<= 256), K % 16 == 0.  xs: the input in S3 form, or NULL (x is converted into the workspace); y (nullable): fp32 output
+ * [N][K][2D][2H][2W]; ys (nullable): channels [ys_c0, ys_c0 + K) of a ys_ctot-channel S3 tensor of the output volume.  At least one of y / ys. */
+int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K);
+int nc_convT_k2s2_split_active(int N, int C, int D, int H, int W, int K); /* supported AND nc_get_conv_split(): what the whole-network calls do */
+size_t nc_convT_k2s2_split_ws_bytes(int N, int C, int D, int H, int W, int K);
+int nc_convT_k2s2_fwd_split(const float* x, const void* xs, const float* w, const float* bias, float* y, void* ys, int ys_ctot, int ys_c0,
+                            int N, int C, int D, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

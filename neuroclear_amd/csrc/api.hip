@@ -556,12 +556,31 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
     NC_TRY(block(4, W + u.p2, nullptr, f5 ? nullptr : W + u.b1, f5 ? W + u.s_b1 : nullptr, 256, 0, 128, 256, q0, q1, q2));
     NC_TRY(block(5, W + u.b1, f5 ? W + u.s_b1 : nullptr, f6 ? nullptr : W + u.b2, f6 ? W + u.s_b2 : nullptr, 256, 0, 256, 256, q0, q1, q2));
-    NC_TRY(block(6, W + u.b2, f6 ? W + u.s_b2 : nullptr, W + u.b1, nullptr, 0, 0, 256, 256, q0, q1, q2));
-    NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
-    if (f7) NC_TRY(split3_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, hs));
+    // The transposed convolutions on the bf16 matrix cores (convt_s3.hip; with the split-operand kernels switched on).  They take
+    // their input in S3 form: the block in front leaves its output ONLY in that form (in a slot that is free by then: s_b1 after
+    // block 5, s_cat2 after block 7) -- or, with the fusion switched off, in fp32 and a separate pass converts it (the same bits) --
+    // and they write the S3 form of the upper half of the concatenation themselves when the next convolution takes it (in the
+    // inference forward nothing else reads it, so no fp32 copy is written), fp32 otherwise.
+    const bool sp = g_split != 0, fuse = g_s3_fuse != 0;
+    const bool t10 = sp && convT_s3x_supported(1, 256, q0, q1, q2, 128) && u.conv_ws_bytes >= convT_s3x_ws_bytes(256, 128);
+    const bool t11 = sp && convT_s3x_supported(1, 128, h0, h1, h2, 64) && u.conv_ws_bytes >= convT_s3x_ws_bytes(128, 64);
+    const bool b6s3 = t10 && fuse, b8s3 = t11 && fuse;
+    NC_TRY(block(6, W + u.b2, f6 ? W + u.s_b2 : nullptr, b6s3 ? nullptr : W + u.b1, b6s3 ? W + u.s_b1 : nullptr, 256, 0, 256, 256, q0, q1, q2));
+    if (t10) {
+      if (!b6s3) NC_TRY(split3_into(W + u.b1, 256 * Sq, W + u.s_b1, 1, 256, Sq, 256, 0, hs));
+      NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], f7 ? nullptr : W + u.cat2 + 128 * Sh, f7 ? W + u.s_cat2 : nullptr, 256, 128, 1,
+                           256, q0, q1, q2, 128, cws, u.conv_ws_bytes, hs));
+    } else {
+      NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
+      if (f7) NC_TRY(split3_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, hs));
+    }
     NC_TRY(block(7, W + u.cat2, f7 ? W + u.s_cat2 : nullptr, f8 ? nullptr : W + u.a2, f8 ? W + u.s_a2 : nullptr, 128, 0, 256, 128, h0, h1, h2));
-    NC_TRY(block(8, W + u.a2, f8 ? W + u.s_a2 : nullptr, W + u.a2b, nullptr, 0, 0, 128, 128, h0, h1, h2));
-    if (f9 && convT_fwd_s3_supported(1, 128, h0, h1, h2, 64)) {  // the transposed convolution writes block 9's operand form itself; in the
+    NC_TRY(block(8, W + u.a2, f8 ? W + u.s_a2 : nullptr, b8s3 ? nullptr : W + u.a2b, b8s3 ? W + u.s_cat2 : nullptr, 128, 0, 128, 128, h0, h1, h2));
+    if (t11) {
+      if (!b8s3) NC_TRY(split3_into(W + u.a2b, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 128, 0, hs));
+      NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], f9 ? nullptr : W + u.cat1 + 64 * S, f9 ? W + u.s_cat1 : nullptr, 128, 64, 1, 128,
+                           h0, h1, h2, 64, cws, u.conv_ws_bytes, hs));
+    } else if (f9 && convT_fwd_s3_supported(1, 128, h0, h1, h2, 64)) {  // the transposed convolution writes block 9's operand form itself; in the
       // inference forward nothing else reads its output, so the fp32 half of cat1 is not written at all
       NC_TRY(convT_fwd_s3(W + u.a2b, P + o.w[11], P + o.b[11], nullptr, W + u.s_cat1, 128, 64, 1, 128, h0, h1, h2, 64, stream));
     } else {

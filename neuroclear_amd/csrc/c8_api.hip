@@ -183,4 +183,29 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
   return conv_wgrad_s3(x, xs, dy, dys, dw, d, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ConvTranspose3d(k = 2, s = 2) forward on the same arithmetic (convt_s3.hip): xs = the input in S3 form, or NULL (then x is converted
+// into the workspace); y (nullable) fp32 output, ys (nullable) channels [ys_c0, ys_c0 + K) of a ys_ctot-channel S3 tensor
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K) { return convT_s3x_supported(N, C, D, H, W, K) ? 1 : 0; }
+// ... and does the library take it by itself (nc_unet_deconv_fwd / _train_fwd; the layer-by-layer host path mirrors the choice)?
+int nc_convT_k2s2_split_active(int N, int C, int D, int H, int W, int K) { return nc_get_conv_split() && convT_s3x_supported(N, C, D, H, W, K) ? 1 : 0; }
+size_t nc_convT_k2s2_split_ws_bytes(int N, int C, int D, int H, int W, int K) {
+  if (!convT_s3x_supported(N, C, D, H, W, K)) return 0;
+  return al256(convT_s3x_ws_bytes(C, K)) + al256(s3_tensor_bytes(N, C, (long)D * H * W)) + 256;
+}
+int nc_convT_k2s2_fwd_split(const float* x, const void* xs, const float* w, const float* bias, float* y, void* ys, int ys_ctot, int ys_c0,
+                            int N, int C, int D, int H, int W, int K, void* ws, size_t ws_bytes, void* stream) {
+  if ((!x && !xs) || !w || (!y && !ys) || !ws) { set_error("convT_k2s2_fwd_split: null pointer"); return NC_ERR_ARG; }
+  if (!convT_s3x_supported(N, C, D, H, W, K)) { set_error("convT_k2s2_fwd_split: shape not covered"); return NC_ERR_SHAPE; }
+  const size_t wb = al256(convT_s3x_ws_bytes(C, K));
+  const long S = (long)D * H * W;
+  if (ws_bytes < wb + (xs ? 0 : al256(s3_tensor_bytes(N, C, S)))) { set_error("convT_k2s2_fwd_split: workspace too small"); return NC_ERR_WS; }
+  if (!xs) {
+    void* t = (char*)ws + wb;
+    if (int e = split3_to(x, t, N, C, S, (hipStream_t)stream)) return e;
+    xs = t;
+  }
+  return convT_fwd_s3x(xs, w, bias, y, ys, ys ? ys_ctot : 8, ys ? ys_c0 : 0, N, C, D, H, W, K, ws, wb, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -199,6 +199,11 @@ int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 // convt.hip: ConvTranspose3d(k 2, s 2) forward that also (or only: y NULL) writes the S3 form of its output
 bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K);
+// convt_s3.hip: the same forward on the bf16 matrix cores from an S3 input (three-term split, six products per fp32 product)
+bool convT_s3x_supported(int N, int C, int D, int H, int W, int K);
+size_t convT_s3x_ws_bytes(int C, int K);
+int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H, int W,
+                  int K, void* ws, size_t wsb, hipStream_t s);
 int convT_fwd_s3(const float* x, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H,
                  int W, int K, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);

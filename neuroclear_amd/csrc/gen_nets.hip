@@ -207,18 +207,35 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   NC_TRY(block(4, V + p.p2, V + p.b1, (size_t)256 * Sq, 5, 256));
   NC_TRY(block(5, V + p.b1, V + p.b2, (size_t)256 * Sq, 6, 256));
   NC_TRY(block(6, V + p.b2, V + p.b3, (size_t)256 * Sq, -1, 0));
-  for (int n = 0; n < N; ++n)  // t_conv2 writes the second half of cat2
-    NC_TRY(nc_convT_k2s2_fwd(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
-                             1, 256, d2[0], d2[1], d2[2], 128, stream));
+  // The transposed convolutions run on the bf16 matrix cores from an S3 copy of their input (convt_s3.hip; the fp32 input stays in
+  // `saved` for their backward) whenever the split-operand kernels are on (the layer-by-layer host path makes the same choice:
+  // nc_convT_k2s2_split_active), and write the S3 form of their half of the concatenation themselves when the consuming block takes it
+  const bool ct2 = nc_convT_k2s2_split_active(1, 256, d2[0], d2[1], d2[2], 128) &&
+                   p.conv_ws >= nc_convT_k2s2_split_ws_bytes(1, 256, d2[0], d2[1], d2[2], 128);
+  for (int n = 0; n < N; ++n) {  // t_conv2 writes the second half of cat2
+    if (ct2)
+      NC_TRY(nc_convT_k2s2_fwd_split(V + p.b3 + (size_t)n * 256 * Sq, nullptr, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
+                                     use[7] ? (char*)(V + p.xs3[7]) + (size_t)n * 256 * Sh * 6 : nullptr, 256, 128, 1, 256, d2[0], d2[1], d2[2], 128, cws,
+                                     p.conv_ws, stream));
+    else
+      NC_TRY(nc_convT_k2s2_fwd(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
+                               1, 256, d2[0], d2[1], d2[2], 128, stream));
+  }
   if (use[7]) {  // ... and its S3 form completes block 7's input (the first half came from block 3's normalisation pass)
-    NC_TRY(split3_into(V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
+    if (!ct2) NC_TRY(split3_into(V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
     pre[7] = true;
   }
   NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh, 8, 128));
   NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh, -1, 0));
-  const bool ct_s3 = use[9] && convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64);  // t_conv1 writes the S3 form of its output itself
+  const bool ct1 = nc_convT_k2s2_split_active(1, 128, d1[0], d1[1], d1[2], 64) &&
+                   p.conv_ws >= nc_convT_k2s2_split_ws_bytes(1, 128, d1[0], d1[1], d1[2], 64);
+  const bool ct_s3 = use[9] && (ct1 || convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64));  // t_conv1 writes the S3 form of its output itself
   for (int n = 0; n < N; ++n) {  // t_conv1 writes the second half of cat1
-    if (ct_s3)
+    if (ct1)
+      NC_TRY(nc_convT_k2s2_fwd_split(V + p.e2b + (size_t)n * 128 * Sh, nullptr, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
+                                     use[9] ? (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6 : nullptr, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, cws,
+                                     p.conv_ws, stream));
+    else if (ct_s3)
       NC_TRY(convT_fwd_s3(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
                           (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, stream));
     else

@@ -436,8 +436,15 @@ class _ConvT(torch.autograd.Function):
         N, C, D, H, W = x.shape
         K = w.shape[1]
         y = torch.empty((N, K, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-        check(lib().nc_convT_k2s2_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K),
-                                      _stream()), 'nc_convT_k2s2_fwd')
+        if lib().nc_convT_k2s2_split_active(I(1), I(C), I(D), I(H), I(W), I(K)):
+            # the split-operand kernel of csrc/convt_s3.hip, sample by sample: exactly what the whole-network calls do
+            ws = workspace(lib().nc_convT_k2s2_split_ws_bytes(I(1), I(C), I(D), I(H), I(W), I(K)), x.device, 'ws_convT_split')
+            for n in range(N):
+                check(lib().nc_convT_k2s2_fwd_split(_ptr(x[n]), None, _ptr(w), _ptr(b), _ptr(y[n]), None, I(0), I(0), I(1), I(C), I(D), I(H), I(W),
+                                                    I(K), _ptr(ws), Z(ws.numel()), _stream()), 'nc_convT_k2s2_fwd_split')
+        else:
+            check(lib().nc_convT_k2s2_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), I(N), I(C), I(D), I(H), I(W), I(K),
+                                          _stream()), 'nc_convT_k2s2_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
