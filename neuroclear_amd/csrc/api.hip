@@ -71,7 +71,7 @@ static std::atomic<int> g_s3_fuse{getenv("NC_S3_FUSE") ? atoi(getenv("NC_S3_FUSE
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
-  return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
+  return (c1k3_fwd_supported(d) || mfma_fwd_supported(d)) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
@@ -210,6 +210,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   const int path = fwd_path(d);
   ProfScope ps(0, path, d, 0, s);
   if (path == 9) return conv_fwd_s3(x, nullptr, w, bias, y, d, ws, ws_bytes, s);
+  if (!g_force_direct && c1k3_fwd_supported(d)) return conv_fwd_c1k3(x, w, bias, y, d, s);  // 1 -> K channels, 3^3: its own fp32 MFMA kernel
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && k1_fwd_supported(d)) return conv_fwd_k1(x, w, bias, y, d, s);

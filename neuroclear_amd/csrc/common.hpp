@@ -87,6 +87,9 @@ static constexpr size_t kBiasGradWsBytes = 64 * 1024 * sizeof(double);  // K * s
 
 // ---- MFMA implicit-GEMM kernels, conv_mfma.hip
 bool mfma_fwd_supported(const ConvDims& d);
+// conv_c1k3.hip: 1 -> K channels, 3^3, stride 1, padding 1 forward (the U-Net's first layer)
+bool c1k3_fwd_supported(const ConvDims& d);
+int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s);
 bool mfma_dgrad_supported(const ConvDims& d);
 bool mfma_wgrad_supported(const ConvDims& d);
 size_t mfma_ws_bytes(const ConvDims& d);
