@@ -18,8 +18,9 @@
 //    read as two ds_read_b64 -- lane groups 1 and 3 read the upper half first (their packed weights have the channel halves
 //    swapped to match): every read instruction touches each of the 64 banks exactly once whatever the tap offsets of the
 //    groups are (one ds_read_b128 would be 2-way conflicted for every pair of taps that is not a multiple of 16 units apart);
-//  * tile quantisation: the launch covers whole rounds of 256 tiles with NCB = 8 (512 positions) and the remainder with a
-//    second launch of half or quarter tiles (NCB = 4 / 2) -- 2,592 tiles at 108^3 cost 10.3 rounds instead of 11;
+//  * tile quantisation: the launch covers whole rounds of 256 tiles (NCB = 8: 512 positions, 7: 448, 6: 384 -- the planner picks per
+//    plane size; 54^2 / 27^2 / 35^2 planes quantise best at 448) and the remainder with a second launch of half / third / quarter
+//    tiles (NCB = 4 / 2) when those fit one round, else as whole tiles in the same launch -- 2,592 tiles at 108^3 cost 10.3 rounds, not 11;
 //  * the LDS-DMA pieces of a brick are issued by ONE wave of each SIMD pair (waves 0..3), source offsets computed at issue time: its
 //    partner keeps the matrix pipe busy meanwhile (-4 %); the stores of a tile are issued inside the first four k-steps of the next.
 // Tried and dropped: output positions as ONE flat axis per sample (q = (z Hp + y) P + x over the padded volume, 512-position tiles at

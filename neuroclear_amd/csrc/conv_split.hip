@@ -18,6 +18,8 @@
 // terms (3 x the 16-bit bytes, 6 x the MFMAs: a third of the 16-bit kernel's staging traffic per MFMA), two stage buffers,
 // tile = 64 output channels x 512 flattened positions of one output plane on 8 waves (2 x 2 accumulator tiles each).  5^3: the
 // 13 tap pairs of a plane come in four sub-stages of weights over one staged brick.  k_wgrad_s3 (below) is the weight gradient.
+// (Round 3: these two are the fallbacks -- NC_S3X=0 / NC_S3X_WGRAD=0, shapes the tap-stream kernel does not cover; the default forward
+// and data gradient are conv_s3x.hip's k_conv_s3x, the default weight gradient is k_wgrad_s3x below, also on 16-bit operands.)
 // Accuracy: the matrix core's rounding error grows with the running sum in its accumulator, so the accumulators restart per
 // stage group (forward / dgrad) or every 64 steps (wgrad) and the pieces are added in fp32 -- with that the error against fp64
 // is below the fp32 MFMA kernels' at every shape tested ("Split-operand fp32 convolutions").
