@@ -334,16 +334,19 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         ev.append((e0, e1))
         return y
     t0 = time.perf_counter()
+    per_volume = []  # seconds of each volume (rank-local clock; diced_inference ends with the result on rank 0's host)
     for _ in range(steps):
+        tv = time.perf_counter()
         out = diced_inference(net, vol, opt, rank, world, on_cube=None if args.no_prof else on_cube)
+        per_volume.append(time.perf_counter() - tv)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt] + per_volume, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, per_volume = float(t[0].item()), [float(v) for v in t[1:].tolist()]
     del out
     from neuroclear_amd.util import util as U
     padded = U.padded_shape((L, L, L), 120, 15)
@@ -374,7 +377,9 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                                           parallelism=('contiguous cube ranges over %d ranks' % world) if world > 1 else 'cubes%1', cubes=ncubes,
                                           assemble='slab (owned z-slabs exchanged point to point, finalised per rank, uint16 slabs gathered)'
                                           if world > 1 else 'in-order',
-                                          computed_voxels_per_s=round(computed * steps / dt))
+                                          computed_voxels_per_s=round(computed * steps / dt),
+                                          seconds_per_volume=dict(median=float(np.median(per_volume)), min=min(per_volume),
+                                                                  max=max(per_volume), n=len(per_volume)))
 
 
 def main():
@@ -400,6 +405,25 @@ def main():
                          'events around the ~700 small PatchGAN launches of a step cost more than those kernels)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it (the reference's own multi-GPU run needs none either:
+        # nn.DataParallel inside `python train.py --gpu_ids 0,1,...`, models/networks.py:132-136): start the N ranks as a CHILD
+        # torch.distributed.run and leave with its return code.  Nothing in this process has touched the GPU yet (a process that
+        # has initialised HIP must never exec another program on this pool), and device_count() does not initialise it.
+        import subprocess
+        import torch
+        env = dict(os.environ)
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and 'NC_DIST_BACKEND' not in env:
+            # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share GPUs and talk over gloo
+            # -- a dry run of the sharded code path, labelled as such on the JSON line
+            env['NC_DIST_BACKEND'] = 'gloo'
+            print('note: --gpus %d on a box with %d GPU(s): ranks share devices, collectives over gloo (dry run of the sharded path)'
+                  % (args.gpus, ndev), file=sys.stderr)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+               '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -410,12 +434,8 @@ def main():
     dev = torch.device('cuda', local % torch.cuda.device_count())  # (single-GPU dry runs of the N > 1 path)
     torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('NC_DIST_BACKEND', 'nccl')  # 'nccl' IS RCCL on ROCm; gloo only for dry runs
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        from neuroclear_amd.util.dist import init_process_group
+        init_process_group(dev)  # 'nccl' IS RCCL on ROCm; NC_DIST_BACKEND=gloo = dry run with ranks sharing a GPU
     if args.gpus != world:
         if rank == 0:
             print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
@@ -438,7 +458,10 @@ def main():
         out['arithmetic'] = ARITHMETIC
     if roof:
         out['roofline'] = roof
-    if headline and split_on:
+    if world > 1:
+        out['dist'] = dict(backend=dist.get_backend(), devices=torch.cuda.device_count(),
+                           ranks_share_devices=torch.cuda.device_count() < world)
+    if headline and split_on and world == 1:
         # the same step with those layers on the fp32 MFMA kernels (v_mfma_f32_32x32x2_f32), for comparison
         import copy
         a2 = copy.copy(args)
@@ -470,9 +493,11 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=1, warmup=1)
+        isteps = 3  # three whole volumes: the boxes of this pool differ by ~8 % and one volume has no spread to show
+        idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=isteps, warmup=1)
         inf = dict(metric='voxels/sec (useful output voxels of the %d^3 volume, assemble included)' % args.volume,
-                   value=iunits / idt, unit='voxels/s', seconds_per_volume=idt, n_gpus=world, scaling='strong',
+                   value=iunits / idt, unit='voxels/s', seconds_per_volume=idt / isteps, steps=isteps,
+                   seconds_per_volume_spread=icfg.pop('seconds_per_volume'), n_gpus=world, scaling='strong',
                    dtype='f32', config=icfg)
         if split_on:
             inf['arithmetic'] = ARITHMETIC

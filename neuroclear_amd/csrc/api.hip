@@ -6,6 +6,8 @@
 
 #include <atomic>
 #include <mutex>
+#include <set>
+#include <utility>
 
 #include "common.hpp"
 
@@ -20,6 +22,23 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+int raise_dyn_lds(const void* kernel, int bytes, const char* who) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("%s: hipGetDevice failed", who); return NC_ERR_HIP; }
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({kernel, dev})) return NC_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot raise dynamic LDS limit to %d bytes", who, bytes);
+    return NC_ERR_HIP;
+  }
+  done.insert({kernel, dev});
+  return NC_OK;
+}
+
 
 // ---- live launch profiler (bench.py): HIP events on the launch stream around every convolution entry point --------
 struct ProfRec { int cls; double flop; hipEvent_t e0, e1; };

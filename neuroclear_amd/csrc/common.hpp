@@ -22,6 +22,13 @@ inline int check_launch(const char* what) {
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per (kernel, DEVICE): the
+// attribute belongs to the code object loaded on that device, so a process that drives several GPUs (the reference's nn.DataParallel
+// shape) needs it on each.  Thread-safe (launches come from the calling thread and from autograd's); defined in api.hip.
+int raise_dyn_lds(const void* kernel, int bytes, const char* who);
+template <typename K>
+inline int raise_dyn_lds(K kernel, int bytes, const char* who) { return raise_dyn_lds(reinterpret_cast<const void*>(kernel), bytes, who); }
+
 // LDS-DMA (one 16-byte / 4-byte unit per lane from a per-lane global address into LDS at lds_addr + lane * size)
 // as inline assembly.  With __builtin_amdgcn_global_load_lds the compiler books the request as a FLAT access that may touch LDS:
 // from then on every LDS-read wait in the kernel is lgkmcnt(0) (flat operations may return out of order), i.e. a software-pipelined

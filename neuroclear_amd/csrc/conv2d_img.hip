@@ -413,14 +413,7 @@ int run_tuned(int dir, int B, int C, int M, int Hu, int Wu, int si, int rspan, i
 template <int TY, int TX, int DT, int WM, int WN, int VB>
 int launch_sconv_cfg(const SPlan& pl, const SParams& p, long max_ncol, int nclass, hipStream_t s) {
   auto kern = k_sconv<TY, TX, DT, WM, WN, VB>;
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) {
-      set_error("sconv: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLds, "sconv")) return e;
   const dim3 grid((unsigned)cdiv(max_ncol, WM * VB * 32), (unsigned)(p.M / (64 * WN)), (unsigned)nclass);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), pl.lds, s, p);
   return check_launch("sconv");

@@ -177,15 +177,7 @@ int conv_wgrad_1x1(const float* x, const float* dy, float* dw, const ConvDims& d
   p.nchunks = (long)d.N * p.cps;
   const int nwg = wg1_nwg(d);
   const int lds_bytes = 2 * (p.npd + p.npx) * 256 * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_1x1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      set_error("wgrad_1x1: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(k_wgrad_1x1, 160 * 1024, "wgrad_1x1")) return e;
   hipLaunchKernelGGL(k_wgrad_1x1, dim3(nwg), dim3(512), lds_bytes, s, p);
   if (int e = check_launch("wgrad_1x1")) return e;
   hipLaunchKernelGGL(k_wgrad_1x1_reduce, dim3((d.K * d.C + 3) / 4), dim3(256), 0, s, (const float*)ws, dw, nwg, d.K,
@@ -325,15 +317,7 @@ static int launch_flat(const float* in, const float* w, const float* bias, float
   const int nwg = (int)(p.nchunks < 512 ? p.nchunks : 512);
   const int MB = (M + 15) / 16;
   const int lds_bytes = (2 * p.npi * 256 + MB * 16 * kPitchO) * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_1x1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      set_error("flat_1x1: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(k_flat_1x1, 160 * 1024, "flat_1x1")) return e;
   hipLaunchKernelGGL(k_flat_1x1, dim3(nwg), dim3(512), lds_bytes, s, p);
   return check_launch("flat_1x1");
 }

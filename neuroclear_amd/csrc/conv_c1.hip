@@ -343,15 +343,7 @@ size_t c1_wgrad_ws_bytes(const ConvDims& d) {
 template <int KS>
 static int launch_c1w(const C1wParams& p, int lds_bytes, hipStream_t s) {
   auto kern = k_wgrad_c1<KS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      set_error("wgrad_c1: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, 160 * 1024, "wgrad_c1")) return e;
   hipLaunchKernelGGL(kern, dim3(p.parts), dim3(512), lds_bytes, s, p);
   return check_launch("wgrad_c1");
 }
@@ -595,15 +587,7 @@ int conv_dgrad_to1_mfma(const float* dy, const float* w, float* dx, const ConvDi
   const long rows = (long)d.N * d.D * d.H;
   p.parts = (int)(rows < 64 ? rows : 64);
   const int lds_bytes = (2 * p.SD + 8 * 16 * kZsPitch + 2 * 8 * 128) * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgrad_to1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      set_error("dgrad_to1: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(k_dgrad_to1, 160 * 1024, "dgrad_to1")) return e;
   hipLaunchKernelGGL(k_dgrad_to1, dim3(p.parts, 4), dim3(512), lds_bytes, s, p);
   if (int e = check_launch("dgrad_to1")) return e;
   }

@@ -110,7 +110,9 @@ bool c1k3_fwd_supported(const ConvDims& d) {
   static const bool on = !(getenv("NC_C1K3") && atoi(getenv("NC_C1K3")) == 0);  // A/B switch: the general brick kernel
   if (!on || d.C != 1 || d.K % 64 || d.kd != 3 || d.kh != 3 || d.kw != 3) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 1 || d.ph != 1 || d.pw != 1) return false;
-  return d.W >= 8 && d.W <= 2048 && (long)d.N * d.K * d.D * d.H * d.W < (1L << 40);
+  // the smallest tile (one output row: 3 planes x 3 rows of W + 2 floats) has to fit the 48 KB the launch stays within
+  if ((size_t)36 * (d.W + 2) > 48 * 1024) return false;
+  return d.W >= 8 && (long)d.N * d.K * d.D * d.H * d.W < (1L << 40);
 }
 
 int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s) {

@@ -531,15 +531,7 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 template <int DT, int KZ, int KY, int KX, bool PAIR, int VB, int NA>
 int launch_h(const HParams& p, int lds, hipStream_t s) {
   auto kern = k_conv_h<DT, KZ, KY, KX, PAIR, VB, NA>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxH) !=
-        hipSuccess) {
-      set_error("conv_h: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMaxH, "conv_h")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_h");
 }
@@ -1031,17 +1023,8 @@ int run_wh(const float* x, const void* xh_pre, const float* dy, const void* dyh_
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
   static const int ablate = getenv("NC_H_ABLATE") ? atoi(getenv("NC_H_ABLATE")) : 0;
   p.ablate = ablate;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h<DT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMaxH) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h<DT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMaxH) != hipSuccess) {
-      set_error("wgrad_h: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds((k_wgrad_h<DT, 3>), kLdsMaxH, "wgrad_h")) return e;
+  if (int e = raise_dyn_lds((k_wgrad_h<DT, 5>), kLdsMaxH, "wgrad_h")) return e;
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
   if (KS == 3) hipLaunchKernelGGL((k_wgrad_h<DT, 3>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   else hipLaunchKernelGGL((k_wgrad_h<DT, 5>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);

@@ -519,15 +519,7 @@ static size_t part_bytes(const Cfg& g) { return (size_t)2 * kNumWG * 32 * g.VB *
 template <int KS, int CK, int WM, int WN, int VB, bool TAIL>
 static int launch_one_t(const FwdParams& p, int lds_bytes, hipStream_t s) {
   auto kern = k_conv_mfma<KS, CK, WM, WN, VB, TAIL>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMax) != hipSuccess) {
-      set_error("conv_mfma: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMax, "conv_mfma")) return e;
   hipLaunchKernelGGL(kern, dim3(kNumWG), dim3(WM * WN * 64), lds_bytes, s, p);
   if (int e = check_launch("conv_mfma")) return e;
   hipLaunchKernelGGL((k_conv_fixup<WM, WN, VB>), dim3(kNumWG - 1), dim3(WM * WN * 64), 0, s, p);

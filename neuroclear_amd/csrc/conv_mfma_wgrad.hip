@@ -778,15 +778,7 @@ size_t mfma_ws_bytes(const ConvDims& d) {
 template <int KS, int AB>
 static int launch_wg(const WgParams& p, dim3 grid, int lds_bytes, hipStream_t s) {
   auto kern = k_wgrad_mfma<KS, AB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMaxW) != hipSuccess) {
-      set_error("wgrad_mfma: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMaxW, "wgrad_mfma")) return e;
   hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, s, p);
   return check_launch("wgrad_mfma");
 }
@@ -794,15 +786,7 @@ static int launch_wg(const WgParams& p, dim3 grid, int lds_bytes, hipStream_t s)
 template <int KS, int AB>
 static int launch_wd(const WdParams& p, dim3 grid, int lds_bytes, hipStream_t s) {
   auto kern = k_wgrad_dma<KS, AB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMaxW) != hipSuccess) {
-      set_error("wgrad_dma: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMaxW, "wgrad_dma")) return e;
   hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, s, p);
   return check_launch("wgrad_dma");
 }
@@ -850,15 +834,7 @@ static int conv_wgrad_rows(const float* x, const float* dy, float* dw, const Con
   p.CB = d.C / 32; p.KBK = d.K / 64; p.parts = pl.parts;
   p.mPRc = wmagic(pl.PRc); p.mPAc = wmagic(pl.PAc); p.mWg = wmagic(pl.Wg);
   auto kern = k_wgrad_rows<3>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLdsMaxW) != hipSuccess) {
-      set_error("wgrad_rows: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMaxW, "wgrad_rows")) return e;
   hipLaunchKernelGGL(kern, dim3(pl.parts, pl.G), dim3(512), pl.lds_bytes, s, p);
   if (int e = check_launch("wgrad_rows")) return e;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(1024), dim3(256), 0, s, (const float*)ws, dw, d.C, d.K, d.kd, 32, pl.parts,

@@ -513,14 +513,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
 template <int KS, int NCB>
 int launch_x(const XParams& p, int lds, hipStream_t s) {
   auto kern = k_conv_s3x<KS, NCB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
-      set_error("conv_s3x: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
 }

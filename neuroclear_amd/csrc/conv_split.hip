@@ -482,14 +482,7 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 template <int KS, int VB>
 int launch_s3(const SParams& p, int lds, hipStream_t s) {
   auto kern = k_conv_s3<KS, VB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
-      set_error("conv_s3: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3");
 }
@@ -1207,17 +1200,10 @@ int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
   p.F = ws_flush_steps(); p.NF = NF;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3, 3, NC_DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5, 3, NC_DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
-      set_error("wgrad_s3: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds(k_wgrad_s3<3>, kLdsMax, "wgrad_s3")) return e;
+  if (int e = raise_dyn_lds(k_wgrad_s3<5>, kLdsMax, "wgrad_s3")) return e;
+  if (int e = raise_dyn_lds((k_wgrad_s3x<3, 3, NC_DT_BF16>), kLdsMax, "wgrad_s3")) return e;
+  if (int e = raise_dyn_lds((k_wgrad_s3x<5, 3, NC_DT_BF16>), kLdsMax, "wgrad_s3")) return e;
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
   if (ws_kv(d) == 32) {
     if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 3, NC_DT_BF16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
@@ -1258,15 +1244,8 @@ int run_wsx(const void* xh, const void* dyh, float* dw, const ConvDims& d, void*
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
   p.F = 1 << 30; p.NF = 1;  // exact 16-bit products, fp32 accumulation: no accumulator restarts
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<3, 1, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_s3x<5, 1, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax) != hipSuccess) {
-      set_error("wgrad_c8x: cannot raise dynamic LDS limit");
-      return NC_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  if (int e = raise_dyn_lds((k_wgrad_s3x<3, 1, DT>), kLdsMax, "wgrad_c8x")) return e;
+  if (int e = raise_dyn_lds((k_wgrad_s3x<5, 1, DT>), kLdsMax, "wgrad_c8x")) return e;
   const int lds = NS * pl.xslot + 2 * pl.dybuf;
   if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 1, DT>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   else hipLaunchKernelGGL((k_wgrad_s3x<5, 1, DT>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);

@@ -210,14 +210,7 @@ int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, v
   const unsigned grid = (unsigned)(8 * p.ngroups * per_xcd);
   const size_t lds = (size_t)(C / 32) * QN * 3 * 1024;
   auto launch = [&](auto kern) -> int {
-    static bool done = false;
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-        set_error("convT_fwd_s3x: cannot raise dynamic LDS limit");
-        return NC_ERR_HIP;
-      }
-      done = true;
-    }
+    if (int e = raise_dyn_lds(kern, 160 * 1024, "convT_fwd_s3x")) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kTThreads), lds, s, p);
     return check_launch("convT_s3");
   };

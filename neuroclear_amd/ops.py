@@ -908,7 +908,7 @@ class _PatchGAN(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         want_p = any(ctx.needs_input_grad[2:])
         dx = torch.empty_like(x) if want_x else None
-        dpar = _grad_destination(ctx.packed) if want_p else None
+        dpar = _grad_target(ctx, 3) if want_p else None
         L = lib()
         ws = workspace(L.nc_patchgan_ws_bytes(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
         check(L.nc_patchgan_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(B), I(D), I(H),
@@ -1046,7 +1046,7 @@ class _PatchGANJoinReal(torch.autograd.Function):
             raise _lib.NcError('fused PatchGAN: the parameters were updated between this forward and its backward')
         dy = dy.contiguous()
         want_p = any(ctx.needs_input_grad[3:])
-        dpar = _grad_destination(ctx.packed) if want_p else None
+        dpar = _grad_target(ctx, 3) if want_p else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         L = lib()
         ws = workspace(L.nc_patchgan_ws_bytes(I(2 * B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
@@ -1086,10 +1086,12 @@ def patchgan(x, params, n_layers, ndf, dimension):
 
 # ---- whole-network generators (nc_unet_deconv_train_fwd / _bwd, nc_deep_linear_fwd / _bwd): one C call per direction --
 def _grad_target(ctx, first):
-    """Where a whole-network backward writes its packed parameter gradients: the optimizer's flat gradient slice when at least one
-    parameter wants a gradient (the kernels OVERWRITE the slice), a scratch tensor otherwise -- a backward through frozen parameters
-    (set_requires_grad(False)) must not touch what FlatAdam.step would apply."""
-    if any(ctx.needs_input_grad[first:]):
+    """Where a whole-network backward writes its packed parameter gradients: the optimizer's flat gradient slice when EVERY parameter
+    wants a gradient (the kernels OVERWRITE the whole slice), a scratch tensor otherwise -- with all parameters frozen
+    (set_requires_grad(False)) nothing is handed on; with SOME frozen, autograd receives views of the scratch tensor for the others
+    (FlatAdam._collect copies them into the flat buffer) and the frozen ranges of the flat gradient keep the zeros of zero_grad, so
+    FlatAdam.step leaves those parameters where they are."""
+    if all(ctx.needs_input_grad[first:]):
         return _grad_destination(ctx.packed)
     return torch.empty_like(ctx.packed)
 

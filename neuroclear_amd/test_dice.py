@@ -5,7 +5,7 @@ addToStack` followed by `assemble_all`).
 i % world (cubes are independent units; no data-path collective is needed to COMPUTE them).  Around the loop:
   * the weights are replicated by ONE RCCL broadcast of rank 0's packed parameter blob (28.3 MB for unet_deconv) --
     the reference's replication point is nn.DataParallel at models/networks.py:132-136;
-  * assemble='reduce' (default for world > 1): every rank overlap-adds its own cubes into its own padded fp32
+  * assemble='reduce' (default for world > 1 when the whole volume is needed on one rank: --normalize_intensity, with_real): every rank overlap-adds its own cubes into its own padded fp32
     accumulator on its own GPU, then one RCCL reduce(sum) to rank 0 -- no per-round synchronisation, no tile traffic.
     fp32 addition order then differs from the reference's sequential index order (util/assemble_dice.py:167-173) by
     <= 1 ulp per voxel, which can flip the truncating integer cast by 1 LSB (tolerance +-1 LSB, SURVEY.md 8e);
@@ -92,6 +92,8 @@ def slab_exchange(rank, world, plan, local_acc, own_acc):
     a root -- and adds what it receives into `own_acc` in ascending source-rank order (its own share in its turn: deterministic).
     local_acc [local planes, P1, P2] starts at plane plan['local'][rank][0]; own_acc [owned planes, P1, P2] must be zero."""
     import torch.distributed as dist
+    from .util.dist import p2p_fence
+    p2p_fence(local_acc)
 
     def overlap(a, b):
         lo, hi = max(a[0], b[0]), min(a[1], b[1])
@@ -112,6 +114,7 @@ def slab_exchange(rank, world, plan, local_acc, own_acc):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        p2p_fence(own_acc)
     o0 = plan['own'][rank][0]
     for src in range(world):
         if src == rank:
@@ -127,10 +130,13 @@ def slab_gather(rank, world, plan, out_slab, L0, dst=0):
     """The finalised integer slabs (planes own & [0, L0)) travel to rank `dst`: 2 bytes per voxel instead of the fp32 accumulators of
     assemble='reduce'.  Returns the list of slabs in rank order on `dst`, None elsewhere."""
     import torch.distributed as dist
+    from .util.dist import p2p_fence
+    out_slab = out_slab.contiguous()
+    p2p_fence(out_slab)
     sizes = [max(0, min(b, L0) - min(a, L0)) for a, b in plan['own']]
     if rank != dst:
         if sizes[rank]:
-            dist.send(out_slab.contiguous(), dst)
+            dist.send(out_slab, dst)
         return None
     parts = []
     for r in range(world):
@@ -167,7 +173,10 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     with_real: also assemble the input cubes (the reference's 'real' visual, test_dice.py without --skip_real) and return
     (fake, real); the dice -> assemble round trip of the input is the input up to 1 LSB of the truncating cast."""
     if assemble is None:
-        assemble = ('reduce' if with_real else 'slab') if world > 1 else 'gather'
+        # 'slab' finalises per rank, so anything that needs the WHOLE volume on one rank (the percentiles of --normalize_intensity,
+        # the second visual of with_real) takes the one-reduce form; only an explicit assemble='slab' with those raises
+        whole = with_real or getattr(opt, 'normalize_intensity', False)
+        assemble = ('reduce' if whole else 'slab') if world > 1 else 'gather'
     if assemble not in ('reduce', 'gather', 'slab'):
         raise ValueError("assemble must be 'slab', 'reduce' or 'gather'")
     if assemble == 'slab' and (with_real or getattr(opt, 'normalize_intensity', False)):
@@ -383,10 +392,10 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
-        import torch.distributed as dist
-        opt.gpu_ids = [int(os.environ.get('LOCAL_RANK', '0'))]
+        from .util.dist import init_process_group
+        opt.gpu_ids = [int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()]
         torch.cuda.set_device(opt.gpu_ids[0])
-        dist.init_process_group('nccl')
+        init_process_group(torch.device('cuda', opt.gpu_ids[0]))
     model = models.create_model(opt)
     model.setup(opt)
     from .data.diceImage_dataset import _load_volume

@@ -22,10 +22,10 @@ def main(argv=None):
     rank = int(os.environ.get('RANK', '0'))
     opt = TrainOptions().parse(argv)
     if world > 1:
-        import torch.distributed as dist
-        opt.gpu_ids = [int(os.environ.get('LOCAL_RANK', '0'))]
+        from .util.dist import init_process_group
+        opt.gpu_ids = [int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()]
         torch.cuda.set_device(opt.gpu_ids[0])
-        dist.init_process_group('nccl')
+        init_process_group(torch.device('cuda', opt.gpu_ids[0]))
     dataset = SingleVolumeDataset(opt)
     model = create_model(opt)
     model.setup(opt)

@@ -1,0 +1,176 @@
+"""The N > 1 path with the DEVICE code underneath it: two real processes, both on the one GPU of the test box, talking over gloo
+(RCCL refuses two ranks on one device; NC_DIST_BACKEND=gloo is the dry-run backend of neuroclear_amd/util/dist.py).  What the CPU
+tests of tests/test_dist_cpu.py cannot see: the slab accumulator behind a shifted base pointer on a rank that does not start at plane
+0, the owner-side finalisation kernel, CUDA tensors through broadcast / batch_isend_irecv / send / recv, the hook-driven bucketed
+all-reduce issued from inside the whole-network backward calls, and `bench.py --gpus 2` launching its own ranks.
+SURVEY.md 8(e); reference replication point: models/networks.py:132-136."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      NC_DIST_BACKEND='gloo')
+    torch.cuda.set_device(0)
+    from neuroclear_amd.util.dist import init_process_group
+    assert init_process_group(torch.device('cuda', 0)) == (rank, world)
+
+
+def _dice_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    _init(rank, world, port)
+    from neuroclear_amd.models import networks
+    from neuroclear_amd.test_dice import diced_inference
+    from neuroclear_amd.util import seed as S
+    vol = S.structured_volume(13, (150, 96, 110))
+    opt = Namespace(dice_size=[48] * 3, overlap=8, border_cut=4, gpu_ids=[0], skip_real=True, data_type='uint16', histogram_match=False,
+                    normalize_intensity=False)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    # rank 1 starts from OTHER weights: only the broadcast in front of the loop can make the sharded result right
+    net.load_state_dict({k: torch.from_numpy(v).cuda() for k, v in S.weights_from_seed(S.unet_deconv_spec(), 22 + rank).items()})
+    slab = diced_inference(net, vol, opt, rank, world, assemble='slab')
+    gath = diced_inference(net, vol, opt, rank, world, assemble='gather')
+    dflt = diced_inference(net, vol, opt, rank, world)  # the default of world > 1 is 'slab'
+    o2 = Namespace(**vars(opt))
+    o2.normalize_intensity, o2.sat_level = True, [0.25, 99.75]
+    norm = diced_inference(net, vol, o2, rank, world)  # ... unless the whole volume is needed on rank 0: 'reduce' 
+    if rank == 0:
+        one = diced_inference(net, vol, opt, 0, 1, assemble='gather', broadcast=False)
+        norm1 = diced_inference(net, vol, o2, 0, 1, broadcast=False)
+        d = np.abs(slab.astype(np.int64) - one.astype(np.int64))
+        dn = np.abs(norm.astype(np.int64) - norm1.astype(np.int64))
+        np.save(out_path, np.array([int(np.array_equal(gath, one)), int(d.max()), int(np.array_equal(dflt, slab)),
+                                    int(slab.shape == vol.shape and slab.dtype == np.uint16), int((d > 0).sum()), int(dn.max())]))
+    else:
+        assert slab is None and gath is None and dflt is None and norm is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_diced_inference(tmp_path):
+    """Rank 1 computes the upper half of the cubes into an accumulator that starts at plane 80 (not 0), receives nothing it does not
+    own, finalises its own z-slab and ships uint16: +-1 LSB of the single-rank volume (fp32 order of the overlap-add); 'gather' keeps
+    the reference's summation order: bit for bit."""
+    out = str(tmp_path / 'd.npy')
+    mp.spawn(_dice_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    gather_eq, max_lsb, default_is_slab, shape_ok, n_diff, norm_lsb = np.load(out)
+    assert gather_eq == 1 and shape_ok == 1 and default_is_slab == 1
+    assert max_lsb <= 1, max_lsb
+    assert n_diff < 0.01 * 150 * 96 * 110  # the LSB flips are the rare exception, not a systematic offset
+    assert norm_lsb <= 2, norm_lsb  # (percentiles of a volume that differs by 1 ulp here and there, then a second truncating cast)
+
+
+def _apollo_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    _init(rank, world, port)
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.util import seed as S
+    opt = Namespace(gpu_ids=[0], isTrain=True, image_dimension=3, checkpoints_dir='/tmp/nc_ckpt', name='t', preprocess='none',
+                    gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10, min_projection_depth=2,
+                    lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64, ndf=64, netG='unet_deconv',
+                    netG_B='deep_linear_gen', netD='basic', n_layers_D=3, norm='instance', no_dropout=True, init_type='kaiming',
+                    init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB', model='axial_to_lateral_gan_apollo')
+    nets = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
+    specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 4
+
+    def build(overlap):
+        m = create_model(opt)
+        for i, (n, sp) in enumerate(zip(nets, specs)):
+            getattr(m, 'net' + n).load_state_dict(S.state_dict_from_seed(sp, 40 + i, 'cuda'))
+        m.optimizer_G._overlap = overlap  # (read at the first zero_grad: the hooks are armed there)
+        return m
+
+    issued = []
+    plain = dist.all_reduce
+
+    def counting(t, *a, **k):
+        issued.append((bool(k.get('async_op', False)), t.numel()))
+        return plain(t, *a, **k)
+    dist.all_reduce = counting
+    # every rank trains on its OWN crop: the averaged gradient differs from either rank's
+    real = torch.from_numpy((S.random_volume(300 + rank, 36).astype(np.float64) / 65535.0).astype(np.float32))[None, None].cuda()
+    res = []
+    grads = {}
+    for overlap in (True, False):
+        m = build(overlap)
+        np.random.seed(5)
+        issued.clear()
+        g = []
+        for it in range(2):
+            m.set_input({'A': real, 'A_paths': 'x'})
+            m.optimize_parameters()
+            g.append((m.optimizer_G.grad.clone(), m.optimizer_D.grad.clone()))  # G's averaged gradient (D's buffer is zeroed after step)
+        grads[overlap] = g
+        flat_g = m.optimizer_G.flat.clone()
+        n_async = sum(1 for a, _ in issued if a)
+        res.append((n_async, len(issued), flat_g, m.optimizer_D.flat.clone()))
+    ok = []
+    for it in range(2):
+        a, b = grads[True][it][0], grads[False][it][0]
+        ok.append(bool(torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(b.abs().max()))) and float(b.abs().max()) > 0)
+    # the bucketed exchange really ran from the hooks (>= 2 ranges per step, two steps), the synchronous model issued none
+    ok.append(res[0][0] >= 4 and res[1][0] == 0)
+    # both models end on the same weights, and both ranks on the same weights (identical replicas stay identical)
+    ok.append(bool(torch.allclose(res[0][2], res[1][2], rtol=0, atol=2e-7)) and bool(torch.allclose(res[0][3], res[1][3], rtol=0, atol=2e-7)))
+    both = [torch.empty_like(res[0][2]) for _ in range(world)]
+    plain_gather = dist.all_gather
+    plain_gather(both, res[0][2])
+    ok.append(bool(torch.equal(both[0], both[1])))
+    dist.all_reduce = plain
+    if rank == 0:
+        np.save(out_path, np.array([int(v) for v in ok] + [res[0][0], res[0][1], res[1][1]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_apollo_bucketed_all_reduce(tmp_path):
+    """Two Apollo steps at 36^3 on two ranks with different crops: the hook-driven, bucketed all-reduce of optimizer_G (issued from
+    inside nc_unet_deconv_bwd / nc_deep_linear_bwd's autograd nodes, racing the side-stream discriminator passes) leaves the gradients
+    and the weights the one synchronous all-reduce leaves, and the replicas stay identical."""
+    out = str(tmp_path / 'a.npy')
+    mp.spawn(_apollo_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    assert list(r[:5]) == [1, 1, 1, 1, 1], r
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: a child torch.distributed.run with two ranks (sharing the one GPU over
+    gloo here), ONE JSON line from rank 0 with n_gpus 2 and twice the voxels of a step."""
+    env = dict(os.environ, NC_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'train',
+                        '--crop', '36', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['dist']['backend'] == 'gloo' and j['dist']['ranks_share_devices']
+    assert abs(j['value'] * j['ms_per_step'] / 1e3 - 2 * 36 ** 3) < 1e-3 * 2 * 36 ** 3
+    # the sharded inference leg through the same launcher (a 230^3 volume: 27 cubes of 140^3, 13 + 14)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'infer',
+                        '--volume', '230', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['config']['cubes'] == 27
