@@ -13,7 +13,7 @@
  *    shapes on the FIRST call of a problem shape: a hipDeviceSynchronize plus a few timed launches, skipped when the stream is
  *    being captured.  nc_sconv_set_tune(0) (or NC_SCONV_TUNE=0) switches that off for the whole process: then the rule holds
  *    without exception (a fixed heuristic picks the shape; results are bit-identical either way);
- *  - process-wide switches (nc_set_conv_split, nc_set_s3_fusion, nc_sconv_set_tune, nc_sconv_set_cfg, nc_set_force_direct) are
+ *  - process-wide switches (nc_set_conv_split, nc_set_c8x_mode, nc_set_s3_fusion, nc_sconv_set_tune, nc_sconv_set_cfg, nc_set_force_direct) are
  *    atomics read once per call: flip them between calls, not while other host threads are inside the library;
  *  - scratch memory comes from the caller: `ws` / `ws_bytes`; query the size with the matching *_ws_bytes();
  *  - return value: 0 = ok, negative = NC_ERR_*; nc_last_error() gives a thread-local message.
@@ -376,6 +376,14 @@ void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at 
                                   * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
+void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the
+                                  * *_lp whole-network calls; csrc/conv_c8x.hip): 1 (default; NC_C8X at load time) = the tap-stream kernel
+                                  * k_conv_c8x where its 512-position tiles fill the launch's rounds of 512 workgroups to >= 60 %, k_conv_h elsewhere (a few planes); 2 = k_conv_c8x
+                                  * wherever the shape fits (channels read and written % 64 == 0); 0 = k_conv_h everywhere.  Both kernels multiply
+                                  * the same 16-bit operands and accumulate in fp32; only the summation order differs */
+int nc_get_c8x_mode(void);
+int nc_conv_lp_uses_c8x(int what /* 0 forward, 1 data gradient */, int fp32_out, int N, int C, int D, int H, int W, int K, int ks); /* 1: under
+                                  * the current mode this call runs on k_conv_c8x (layer C -> K channels; fp32_out: nc_conv_*_lp, else the C8 forms) */
 void nc_set_s3_fusion(int on); /* 1 (default; NC_S3_FUSE): nc_unet_deconv_fwd has InstanceNorm + ReLU write the three-term form of a
                                 * layer that only feeds a split-operand convolution; 0: separate conversion passes (bit-identical) */
 int nc_conv_split_supported(int what, int N, int C, int D, int H, int W, int K, int kd, int kh, int kw, int stride, int pad);

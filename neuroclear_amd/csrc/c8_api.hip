@@ -188,6 +188,13 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K) { return convT_s3x_supported(N, C, D, H, W, K) ? 1 : 0; }
 // ... and does the library take it by itself (nc_unet_deconv_fwd / _train_fwd; the layer-by-layer host path mirrors the choice)?
+int nc_conv_lp_uses_c8x(int what, int fp32_out, int N, int C, int D, int H, int W, int K, int ks) {
+  if (what == 0) return c8x_supported(N, C, D, H, W, K, ks, fp32_out != 0) ? 1 : 0;
+  if (what == 1) return c8x_supported(N, K, D, H, W, C, ks, fp32_out != 0) ? 1 : 0;
+  return 0;
+}
+void nc_set_c8x_mode(int mode) { c8x_set_mode(mode); }
+int nc_get_c8x_mode(void) { return c8x_get_mode(); }
 int nc_convT_k2s2_split_active(int N, int C, int D, int H, int W, int K) { return nc_get_conv_split() && convT_s3x_supported(N, C, D, H, W, K) ? 1 : 0; }
 size_t nc_convT_k2s2_split_ws_bytes(int N, int C, int D, int H, int W, int K) {
   if (!convT_s3x_supported(N, C, D, H, W, K)) return 0;

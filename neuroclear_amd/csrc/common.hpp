@@ -210,6 +210,13 @@ int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean
 // convt.hip: ConvTranspose3d(k 2, s 2) forward that also (or only: y NULL) writes the S3 form of its output
 bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K);
 // convt_s3.hip: the same forward on the bf16 matrix cores from an S3 input (three-term split, six products per fp32 product)
+// conv_c8x.hip: the tap-stream form of the 16-bit forward / data-gradient kernel (C8 in, C8 or fp32 out; packed weights in wp_ws)
+size_t c8x_packed_bytes(int Cin, int Kout, int KS);
+void c8x_set_mode(int m);
+int c8x_get_mode();
+bool c8x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS, bool fp32_out);
+int conv_c8x(const void* xh, const float* w, const float* bias, float* y, void* yh, int ctot, int c0, int N, int Cin, int D, int H, int W,
+             int Kout, int KS, long so, long si, int flip, int diffuse, int dt, void* wp_ws, hipStream_t s);
 bool convT_s3x_supported(int N, int C, int D, int H, int W, int K);
 size_t convT_s3x_ws_bytes(int C, int K);
 int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H, int W,

@@ -564,6 +564,9 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
     hipLaunchKernelGGL((k_to_c8<DT>), dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xh, S, Cin);
     if (int e = check_launch("to_c8")) return e;
   }
+  // the tap-stream kernel (conv_c8x.hip) wherever it covers the shape and its 512-position tiles quantise well; NC_C8X=0: never
+  if (c8x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS, yh == nullptr) && wb >= c8x_packed_bytes(Cin, Kout, KS))
+    return conv_c8x(xh, w, bias, yh ? nullptr : y, yh, ctot, c0, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, g_wdiffuse, DT, wp, s);
   const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
   if (g_wdiffuse)
     hipLaunchKernelGGL((k_pack_w_h_diff<DT>), dim3((unsigned)cdiv((long)Cin * Kout, 256)), dim3(256), 0, s, w, wp, Cin, Kout, KS, so, si,
