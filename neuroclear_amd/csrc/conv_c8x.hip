@@ -499,8 +499,10 @@ __global__ void __launch_bounds__(kThreadsC, 2) k_conv_c8x(const CParams p) {
           npend = my_pieces;
           y1 = my_pieces;
         } else if (more_tiles) {
-          issue_brick(nxt, b - NB, (ring + b) % RING);  // (two or one bricks per tile: offsets of another tile, computed on the spot)
-          y1 = my_pieces;
+          // (two or one bricks per tile: offsets of another tile, computed on the spot.  These pieces go out AHEAD of this step's A
+          //  loads, i.e. they are older than them and must not be counted in y1: the wait two steps on would let that many operations
+          //  too many stay in flight and hand the MFMAs fragments that have not arrived)
+          issue_brick(nxt, b - NB, (ring + b) % RING);
         }
         ++na;
       }

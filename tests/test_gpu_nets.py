@@ -102,8 +102,10 @@ def test_patchgan(golden_dir, tag):
     assert relmax(y.detach().cpu().numpy(), g['y']) < 5e-4
     r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
     (y * r).mean().backward()
-    assert rel2(x.grad.cpu().numpy(), g['dx']) < 2e-2
-    check_grads(g, net, 2e-2)
+    # LeakyReLU has a kink but no dead branch: a decision that differs changes one element's slope 0.2 <-> 1, not the whole path --
+    # measured 6e-7 .. 1e-6 against fp64 (tests/test_gpu_grad_fp64.py); the bound for ReLU / max-pool networks stays 2e-2
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < 1e-3
+    check_grads(g, net, 1e-3)
 
 
 def test_blocks(golden_dir):
@@ -503,8 +505,8 @@ def test_discriminators_wide(golden_dir, name, kind):
     assert relmax(y.detach().cpu().numpy(), g['y']) < 5e-4
     r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
     (y * r).mean().backward()
-    assert rel2(x.grad.cpu().numpy(), g['dx']) < 2e-2
-    check_grads(g, net, 2e-2)
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < 1e-3
+    check_grads(g, net, 1e-3)
 
 
 @pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32', 'deconv_basic_24_b2'])
