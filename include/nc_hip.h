@@ -183,6 +183,12 @@ int nc_volume_slices(const float* src, float* dst, int N, int C, int D, int H, i
 size_t nc_loss_ws_bytes(long n);
 int nc_mse_const_fwd(const float* pred, long n, float target, float* out, void* ws, size_t ws_bytes, void* stream);
 int nc_mse_const_bwd(const float* pred, long n, float target, const float* gscale, float* dpred, void* stream);
+/* GANLoss('vanilla') = nn.BCEWithLogitsLoss against the constant label (networks.py:278, 308-313): mean(max(p,0) - p t + log(1 + exp(-|p|)));
+ * GANLoss('wgangp') = -+mean(p) (networks.py:314-318): nc_mean_fwd gives mean(p), the caller applies the sign (gscale carries it backward). */
+int nc_bce_logits_const_fwd(const float* pred, long n, float target, float* out, void* ws, size_t ws_bytes, void* stream);
+int nc_bce_logits_const_bwd(const float* pred, long n, float target, const float* gscale, float* dpred, void* stream);
+int nc_mean_fwd(const float* pred, long n, float* out, void* ws, size_t ws_bytes, void* stream);
+int nc_mean_bwd(long n, const float* gscale, float* dpred, void* stream);
 int nc_l1_fwd(const float* a, const float* b, long n, float* out, void* ws, size_t ws_bytes, void* stream);
 int nc_l1_bwd(const float* a, const float* b, long n, const float* gscale, float* da, void* stream);
 

@@ -96,11 +96,19 @@ __global__ void k_slices(const float* __restrict__ src, float* __restrict__ dst,
 }
 
 // ---------------------------------------------------------------- losses
-// mode 0: (p - target)^2 ; mode 1: |a - b|.  Two-stage deterministic reduction (fp64 partials, fixed order).
+// mode 0: (p - target)^2 ; mode 1: |a - b| ; mode 2: binary cross entropy of the logit p against the constant `target`
+// (nn.BCEWithLogitsLoss, networks.py:278: max(p, 0) - p t + log(1 + exp(-|p|)), torch's stable form) ; mode 3: p itself (the
+// 'wgangp' objective -+mean(p), networks.py:314-318; the sign is applied by the caller).  Two-stage deterministic reduction (fp64
+// partials, fixed order).
 __global__ __launch_bounds__(256) void k_loss_partial(const float* __restrict__ a, const float* __restrict__ b,
                                                       float target, int mode, long n, double* __restrict__ part) {
   double acc = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (mode >= 2) {
+      const float x = a[i];
+      acc += mode == 3 ? (double)x : (double)(fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x))));
+      continue;
+    }
     const float d = mode == 0 ? a[i] - target : a[i] - b[i];
     acc += mode == 0 ? (double)d * (double)d : (double)fabsf(d);
   }
@@ -122,6 +130,13 @@ __global__ void k_mse_bwd(const float* __restrict__ p, long n, float target, con
   const float g = gscale[0] * (2.0f / (float)n);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dp[i] = (p[i] - target) * g;
+}
+// d/dp mean(BCEWithLogits(p, t)) = (sigmoid(p) - t) / n ; d/dp mean(p) = 1 / n  (mode 3; gscale carries the sign)
+__global__ void k_logit_bwd(const float* __restrict__ p, long n, float target, int mode, const float* __restrict__ gscale,
+                            float* __restrict__ dp) {
+  const float g = gscale[0] / (float)n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dp[i] = mode == 3 ? g : (1.f / (1.f + expf(-p[i])) - target) * g;
 }
 __global__ void k_l1_bwd(const float* __restrict__ a, const float* __restrict__ b, long n,
                          const float* __restrict__ gscale, float* __restrict__ da) {
@@ -232,6 +247,22 @@ static int loss_fwd(const char* what, const float* a, const float* b, float targ
 }
 int nc_mse_const_fwd(const float* pred, long n, float target, float* out, void* ws, size_t ws_bytes, void* stream) {
   return loss_fwd("mse_const_fwd", pred, nullptr, target, 0, n, out, ws, ws_bytes, stream);
+}
+int nc_bce_logits_const_fwd(const float* pred, long n, float target, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return loss_fwd("bce_logits_const_fwd", pred, nullptr, target, 2, n, out, ws, ws_bytes, stream);
+}
+int nc_mean_fwd(const float* pred, long n, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return loss_fwd("mean_fwd", pred, nullptr, 0.f, 3, n, out, ws, ws_bytes, stream);
+}
+int nc_bce_logits_const_bwd(const float* pred, long n, float target, const float* gscale, float* dpred, void* stream) {
+  if (!pred || !gscale || !dpred) { set_error("bce_logits_const_bwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_logit_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, pred, n, target, 2, gscale, dpred);
+  return check_launch("bce_logits_const_bwd");
+}
+int nc_mean_bwd(long n, const float* gscale, float* dpred, void* stream) {
+  if (!gscale || !dpred) { set_error("mean_bwd: null pointer"); return NC_ERR_ARG; }
+  hipLaunchKernelGGL(k_logit_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, n, 0.f, 3, gscale, dpred);
+  return check_launch("mean_bwd");
 }
 int nc_l1_fwd(const float* a, const float* b, long n, float* out, void* ws, size_t ws_bytes, void* stream) {
   return loss_fwd("l1_fwd", a, b, 0.f, 1, n, out, ws, ws_bytes, stream);

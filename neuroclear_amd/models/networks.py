@@ -530,7 +530,8 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
 
 
 class GANLoss(nn.Module):
-    """networks.py:252-319.  'lsgan' (the README configuration) runs on the fused MSE-vs-constant kernel."""
+    """networks.py:252-319.  'lsgan' (the README configuration) runs on the fused MSE-vs-constant kernel, 'vanilla' on the
+    BCE-with-logits-vs-constant kernel, 'wgangp' (any name containing 'wgan', as in the reference) on the mean kernel."""
 
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
         super().__init__()
@@ -538,12 +539,13 @@ class GANLoss(nn.Module):
         self.register_buffer('fake_label', torch.tensor(target_fake_label))
         self.gan_mode = gan_mode
         self._real, self._fake = float(target_real_label), float(target_fake_label)
-        if gan_mode == 'lsgan':
-            pass
-        elif gan_mode == 'vanilla' or 'wgan' in gan_mode:
-            raise NotImplementedError('gan mode %s is outside the MI355X hot path (north_star: LSGAN)' % gan_mode)
-        else:
+        if gan_mode not in ('lsgan', 'vanilla') and 'wgan' not in gan_mode:
             raise NotImplementedError('gan mode %s not implemented' % gan_mode)
 
     def __call__(self, prediction, target_is_real):
-        return ops.mse_const(prediction, self._real if target_is_real else self._fake)
+        if self.gan_mode == 'lsgan':
+            return ops.mse_const(prediction, self._real if target_is_real else self._fake)
+        if self.gan_mode == 'vanilla':
+            return ops.bce_logits_const(prediction, self._real if target_is_real else self._fake)
+        m = ops.mean(prediction)  # 'wgan*': networks.py:314-318
+        return -m if target_is_real else m

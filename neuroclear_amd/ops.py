@@ -762,6 +762,60 @@ def mse_const(pred, target):
     return _MseConst.apply(pred, float(target))
 
 
+class _BceLogitsConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        _chk(pred)
+        _f32(pred)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        ws = workspace(lib().nc_loss_ws_bytes(L_(pred.numel())), pred.device, 'loss')
+        check(lib().nc_bce_logits_const_fwd(_ptr(pred), L_(pred.numel()), F(target), _ptr(out), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_bce_logits_const_fwd')
+        ctx.save_for_backward(pred)
+        ctx.target = target
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (pred,) = ctx.saved_tensors
+        g = g.contiguous()
+        dp = torch.empty_like(pred)
+        check(lib().nc_bce_logits_const_bwd(_ptr(pred), L_(pred.numel()), F(ctx.target), _ptr(g), _ptr(dp), _stream()),
+              'nc_bce_logits_const_bwd')
+        return dp, None
+
+
+def bce_logits_const(pred, target):
+    """GANLoss('vanilla') (models/networks.py:278, 308-313): nn.BCEWithLogitsLoss of the logits against a constant label."""
+    return _BceLogitsConst.apply(pred, float(target))
+
+
+class _Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred):
+        pred = pred.contiguous()
+        _chk(pred)
+        _f32(pred)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        ws = workspace(lib().nc_loss_ws_bytes(L_(pred.numel())), pred.device, 'loss')
+        check(lib().nc_mean_fwd(_ptr(pred), L_(pred.numel()), _ptr(out), _ptr(ws), Z(ws.numel()), _stream()), 'nc_mean_fwd')
+        ctx.shape = pred.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dp = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().nc_mean_bwd(L_(dp.numel()), _ptr(g), _ptr(dp), _stream()), 'nc_mean_bwd')
+        return dp
+
+
+def mean(pred):
+    """prediction.mean() of GANLoss('wgangp') (models/networks.py:314-318); the caller negates it for real targets."""
+    return _Mean.apply(pred)
+
+
 class _L1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -54,8 +54,9 @@ def _mip(vol, depth, axis):
 
 class ApolloOracle:
     def __init__(self, sds, lr=1e-4, beta1=0.1, lambda_A=5.0, lambda_plane=(1, 1, 1), projection_depth=10,
-                 randomize_projection_depth=True, min_projection_depth=2):
+                 randomize_projection_depth=True, min_projection_depth=2, gan_mode='lsgan'):
         self.n = Nets(sds)
+        self.gan = lambda pred, flag: nets.gan_loss(pred, flag, gan_mode)  # networks.GANLoss(opt.gan_mode), apollo:127
         s = float(sum(lambda_plane))
         self.w_target, self.w_slice, self.w_proj = [f / s for f in lambda_plane]  # apollo:81-82
         self.lambda_A = lambda_A
@@ -81,13 +82,13 @@ class ApolloOracle:
         # ---- generators (apollo:255-283)
         self.n.set_requires_grad(APOLLO_D, False)
         self.opt_G.zero_grad()
-        L['G_A_lateral'] = nets.lsgan(self.D('D_A_lateral', _mip(fake, self.depth, 0)), True) * self.w_target
-        L['G_A_axial'] = nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 1)), True) * self.w_slice + \
-            nets.lsgan(self.D('D_A_axial', _mip(fake, self.depth, 2)), True) * self.w_slice
+        L['G_A_lateral'] = self.gan(self.D('D_A_lateral', _mip(fake, self.depth, 0)), True) * self.w_target
+        L['G_A_axial'] = self.gan(self.D('D_A_axial', _mip(fake, self.depth, 1)), True) * self.w_slice + \
+            self.gan(self.D('D_A_axial', _mip(fake, self.depth, 2)), True) * self.w_slice
         L['G_A'] = L['G_A_lateral'] + L['G_A_axial'] * 0.5
-        L['G_B_lateral'] = nets.lsgan(self.D('D_B_lateral', _slice(rec, 0)), True) * self.w_target
-        L['G_B_axial'] = nets.lsgan(self.D('D_B_axial', _slice(rec, 1)), True) * self.w_slice + \
-            nets.lsgan(self.D('D_B_axial', _slice(rec, 2)), True) * self.w_slice
+        L['G_B_lateral'] = self.gan(self.D('D_B_lateral', _slice(rec, 0)), True) * self.w_target
+        L['G_B_axial'] = self.gan(self.D('D_B_axial', _slice(rec, 1)), True) * self.w_slice + \
+            self.gan(self.D('D_B_axial', _slice(rec, 2)), True) * self.w_slice
         L['G_B'] = L['G_B_lateral'] + L['G_B_axial'] * 0.5
         L['cycle'] = nets.l1(rec, real) * self.lambda_A
         (L['G_A'] + L['G_B'] + L['cycle']).backward()
@@ -102,14 +103,14 @@ class ApolloOracle:
         def d_proj(name, ax_real, ax_fake):  # backward_D_projection apollo:195-223
             pr = self.D(name, _slice(real, ax_real))
             pf = self.D(name, _mip(fd, self.depth, ax_fake))
-            loss = (nets.lsgan(pr, True) + nets.lsgan(pf, False)) * 0.5
+            loss = (self.gan(pr, True) + self.gan(pf, False)) * 0.5
             loss.backward()
             return loss
 
         def d_slice(name, ax_real, ax_fake):  # backward_D_slice apollo:169-193
             pr = self.D(name, _slice(real, ax_real))
             pf = self.D(name, _slice(rd, ax_fake))
-            loss = (nets.lsgan(pr, True) + nets.lsgan(pf, False)) * 0.5
+            loss = (self.gan(pr, True) + self.gan(pf, False)) * 0.5
             loss.backward()
             return loss
 

@@ -225,14 +225,14 @@ def struct_crop(seed, size, vol=96):
     return (crop.astype(np.float32) / np.float32(65535.0))[None, None]
 
 
-def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_step_36.npz', real_np=None):
+def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_step_36.npz', real_np=None, extra=None):
     """batch > 1 pins the per-plane batch semantics of the LSGAN means (every netD call of the reference sees the whole
     batch of ONE plane, apollo:169-193)."""
     import contextlib
     import io
     from models.axial_to_lateral_gan_apollo_model import AxialToLateralGANApolloModel
     with contextlib.redirect_stdout(io.StringIO()):
-        model = AxialToLateralGANApolloModel(_opt_train('axial_to_lateral_gan_apollo'))
+        model = AxialToLateralGANApolloModel(_opt_train('axial_to_lateral_gan_apollo', extra))
     for i, (name, spec) in enumerate(apollo_specs().items()):
         load_sd(getattr(model, 'net' + name), S.weights_from_seed(spec, 40 + i))
     real = torch.from_numpy(rand_input(real_seed, (batch, 1, size, size, size)) if real_np is None else real_np)
@@ -262,6 +262,7 @@ def gen_apollo(size=36, step_seed=1234, batch=1, real_seed=321, fname='apollo_st
         upd[n] = np.array([float((a - b).double().norm()) for a, b in zip(after, before[n])])
     np.savez_compressed(os.path.join(OUT, fname), size=size, step_seed=step_seed, real_seed=real_seed, batch=batch,
                         net_seed0=40, loss_names=np.array(model.loss_names), losses=np.array(losses_per_step),
+                        gan_mode=(extra or {}).get('gan_mode', 'lsgan'),
                         draws=np.array(draws), fake0=fake0, rec0=rec0,
                         **({} if real_np is None else {'real': real_np}), **{'upd_' + n: v for n, v in upd.items()})
     print('apollo', dict(zip(model.loss_names, losses_per_step[0])))
@@ -410,6 +411,23 @@ def gen_dryops(only=None):
         print('dryops', tag, dict(zip(model.loss_names, losses[0])))
 
 
+def gen_ganloss(networks):
+    """networks.GANLoss for its three objectives (networks.py:252-319) on PatchGAN-shaped predictions: loss values and the gradients."""
+    out = {}
+    for mode in ('lsgan', 'vanilla', 'wgangp'):
+        crit = networks.GANLoss(mode)
+        for tag, shape, seed in (('a', (4, 1, 11, 11), 61), ('b', (2, 1, 2, 2), 62), ('c', (1, 1, 5, 6, 7), 63)):
+            for flag in (True, False):
+                p = torch.from_numpy(rand_input(seed, shape) * 6 - 3).requires_grad_(True)  # logits in (-3, 3)
+                loss = crit(p, flag)
+                loss.backward()
+                key = '%s_%s_%d' % (mode, tag, int(flag))
+                out[key + '_loss'] = np.float32(loss.item())
+                out[key + '_grad'] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'ganloss_modes.npz'), **out)
+    print('ganloss', {k: float(v) for k, v in out.items() if k.endswith('_loss') and '_a_' in k})
+
+
 def gen_dice():
     import data as refdata  # noqa: F401  (registers the package the assembler imports)
     from util.assemble_dice import Assemble_Dice
@@ -551,6 +569,10 @@ if __name__ == '__main__':
         gen_apollo()
     if 'apollo_b2' in which or not sys.argv[1:]:
         gen_apollo(size=24, step_seed=4242, batch=2, real_seed=322, fname='apollo_step_24_b2.npz')
+    if 'ganloss' in which or not sys.argv[1:]:
+        gen_ganloss(networks)
+        gen_apollo(size=24, step_seed=777, batch=1, real_seed=323, fname='apollo_step_24_vanilla.npz', extra={'gan_mode': 'vanilla'})
+        gen_apollo(size=24, step_seed=778, batch=1, real_seed=324, fname='apollo_step_24_wgangp.npz', extra={'gan_mode': 'wgangp'})
     if 'dryops' in which:
         gen_dryops()
     if 'dryops_b2' in which:

@@ -142,6 +142,18 @@ def lsgan(pred, target_is_real):
     return F.mse_loss(pred, t)
 
 
+def gan_loss(pred, target_is_real, mode='lsgan'):
+    """GANLoss.__call__ (networks.py:299-319) for its three objectives: 'lsgan' MSE, 'vanilla' BCE-with-logits against the constant
+    label, 'wgan*' -+mean(prediction)."""
+    if mode == 'lsgan':
+        return lsgan(pred, target_is_real)
+    if mode == 'vanilla':
+        return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, 1.0 if target_is_real else 0.0))
+    if 'wgan' in mode:
+        return -pred.mean() if target_is_real else pred.mean()
+    raise NotImplementedError('gan mode %s not implemented' % mode)
+
+
 def l1(a, b):
     return F.l1_loss(a, b)
 

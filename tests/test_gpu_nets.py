@@ -197,7 +197,8 @@ APOLLO_NETS = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_later
 
 
 @pytest.mark.parametrize('fname,d_streams', [('apollo_step_36.npz', True), ('apollo_step_24_b2.npz', True),
-                                             ('apollo_step_24_b2.npz', False)])
+                                             ('apollo_step_24_b2.npz', False), ('apollo_step_24_vanilla.npz', True),
+                                             ('apollo_step_24_wgangp.npz', True)])
 def test_apollo_step(golden_dir, fname, d_streams, monkeypatch):
     """One + one optimize_parameters() against the reference's own losses; the batch-2 fixture pins the per-plane batch
     split of the batched discriminator passes (each LSGAN mean runs over the whole batch of ONE plane)."""
@@ -206,7 +207,9 @@ def test_apollo_step(golden_dir, fname, d_streams, monkeypatch):
     monkeypatch.setattr(AxialToLateralGANApolloModel, '_d_streams_on', d_streams)
     g = G(golden_dir, fname)
     size, batch = int(g['size']), int(g['batch']) if 'batch' in g else 1
-    model = create_model(_apollo_opt())
+    opt = _apollo_opt()
+    opt.gan_mode = str(g['gan_mode']) if 'gan_mode' in g else 'lsgan'  # (--gan_mode vanilla | wgangp: networks.py:252-319)
+    model = create_model(opt)
     specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 4
     for i, (n, sp) in enumerate(zip(APOLLO_NETS, specs)):
         load(getattr(model, 'net' + n), sp, int(g['net_seed0']) + i)
@@ -727,3 +730,21 @@ def test_partly_frozen_parameters_are_not_updated(which):
             assert torch.equal(g, full[off:off + n]), i
             assert float(full[off:off + n].abs().max()) == 0.0 or float(moved) > 0.0, i
         off += n
+
+
+def test_gan_loss_modes(golden_dir):
+    """networks.GANLoss for 'lsgan' | 'vanilla' | 'wgangp' against the reference's own values and gradients (models/networks.py:252-319),
+    and the NotImplementedError of an unknown objective."""
+    g = G(golden_dir, 'ganloss_modes.npz')
+    for mode in ('lsgan', 'vanilla', 'wgangp'):
+        crit = networks.GANLoss(mode).to(DEV)
+        for tag, shape, seed in (('a', (4, 1, 11, 11), 61), ('b', (2, 1, 2, 2), 62), ('c', (1, 1, 5, 6, 7), 63)):
+            for flag in (True, False):
+                p = torch.from_numpy(rnd(seed, shape) * 6 - 3).to(DEV).requires_grad_(True)
+                loss = crit(p, flag)
+                (loss * 1.0).backward()
+                key = '%s_%s_%d' % (mode, tag, int(flag))
+                np.testing.assert_allclose(float(loss), g[key + '_loss'], rtol=2e-6, atol=1e-7)
+                np.testing.assert_allclose(p.grad.cpu().numpy(), g[key + '_grad'], rtol=2e-5, atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        networks.GANLoss('hinge')

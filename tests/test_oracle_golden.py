@@ -74,14 +74,14 @@ def test_patchgan(golden_dir, tag):
     _check_grads(g, sd, tol=1e-3)
 
 
-@pytest.mark.parametrize('fname', ['apollo_step_36.npz', 'apollo_step_24_b2.npz'])
+@pytest.mark.parametrize('fname', ['apollo_step_36.npz', 'apollo_step_24_b2.npz', 'apollo_step_24_vanilla.npz', 'apollo_step_24_wgangp.npz'])
 def test_apollo_step(golden_dir, fname):
     g = G(golden_dir, fname)
     size, batch = int(g['size']), int(g['batch']) if 'batch' in g else 1
     specs = [('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] + \
         [(n, S.patchgan_spec(2)) for n in apollo.APOLLO_D]
     sds = {n: S.weights_from_seed(sp, int(g['net_seed0']) + i) for i, (n, sp) in enumerate(specs)}
-    model = apollo.ApolloOracle(sds)
+    model = apollo.ApolloOracle(sds, gan_mode=str(g['gan_mode']) if 'gan_mode' in g else 'lsgan')
     before = {n: [p.detach().clone() for p in model.n.sd[n].values()] for n in sds}
     real = torch.from_numpy(rnd(g['real_seed'], (batch, 1, size, size, size)))
     np.random.seed(int(g['step_seed']))
@@ -246,3 +246,20 @@ def test_patchgan_sn(golden_dir, tag):
         assert abs(l2 - g['g_l2'][i]) <= 1e-3 * max(1e-9, g['g_l2'][i]), k
     us = np.concatenate([sd[k].detach().numpy().ravel() for k in sd if k.endswith('weight_u')])
     np.testing.assert_allclose(us, g['u_final'], atol=1e-5)
+
+
+def test_gan_loss_modes(golden_dir):
+    """oracle nets.gan_loss against the reference's GANLoss('lsgan' | 'vanilla' | 'wgangp') (models/networks.py:252-319): values and
+    gradients on PatchGAN-shaped predictions."""
+    g = G(golden_dir, 'ganloss_modes.npz')
+    for mode in ('lsgan', 'vanilla', 'wgangp'):
+        for tag, shape, seed in (('a', (4, 1, 11, 11), 61), ('b', (2, 1, 2, 2), 62), ('c', (1, 1, 5, 6, 7), 63)):
+            for flag in (True, False):
+                p = torch.from_numpy(rnd(seed, shape) * 6 - 3).requires_grad_(True)
+                loss = nets.gan_loss(p, flag, mode)
+                loss.backward()
+                key = '%s_%s_%d' % (mode, tag, int(flag))
+                np.testing.assert_allclose(loss.item(), g[key + '_loss'], rtol=1e-6, atol=1e-7)
+                np.testing.assert_allclose(p.grad.numpy(), g[key + '_grad'], rtol=1e-6, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        nets.gan_loss(torch.zeros(1), True, 'hinge')
