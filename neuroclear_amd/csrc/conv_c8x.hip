@@ -442,9 +442,14 @@ __global__ void __launch_bounds__(kThreadsC, 2) k_conv_c8x(const CParams p) {
 #pragma unroll
   for (int b = 0; b < RING - 2; ++b) issue_brick(cur, b, b);
   tile_offsets(cur);
-  u32x4 A0[4], A1[4], A2[4];  // fragment sets in rotation: step t of a tile multiplies set t % 3 and requests step t + 2 into set (t + 2) % 3
+  // Fragment sets in rotation.  3^3: requested AD = 2 k-steps ahead, three sets -- step t of a tile multiplies set t % 3 and requests step
+  // t + 2 into set (t + 2) % 3; the 27 Cin / 32 k-steps of a tile are a multiple of three, so every tile starts on set 0.  5^3: 250 Cin / 64
+  // k-steps are not; its bricks last 6.25 k-steps (a brick arrives in one step of six), so it runs with AD = 1 and two sets in turn (an even
+  // number of steps) rather than exchange registers whose contents are still in flight at a tile's end.
+  constexpr int AD = KS == 3 ? 2 : 1;
+  u32x4 A0[4], A1[4], A2[4];
   load_a(A0, wtile(cur.cot));
-  load_a(A1, wtile(cur.cot) + 4096);
+  if (AD == 2) load_a(A1, wtile(cur.cot) + 4096);
   zero_acc();
 
   int tpl = g, sl = ring;  // per-lane tap state: lane group g is at in-plane tap tpl of the brick in slot sl
@@ -479,10 +484,10 @@ __global__ void __launch_bounds__(kThreadsC, 2) k_conv_c8x(const CParams p) {
     // One k-step.  Ac: this step's fragments; An: receives those of step s + 2.
     auto kstep = [&](int s, u32x4 (&Ac)[4], u32x4 (&An)[4]) __attribute__((always_inline)) {
       const bool last = s + 1 == p.NS;
-      const int s2 = s + 2;
+      const int s2 = s + AD;
       const int aoff = __builtin_amdgcn_readfirstlane(s2 < p.NS ? wt + s2 * 4096 : wt_next + (s2 - p.NS) * 4096);  // (beyond the last tile: a dummy request)
       STAMP(0);
-      wait_vm(4 + y1 + y2);
+      wait_vm(AD == 2 ? 4 + y1 + y2 : y1);  // (AD = 1: this step's fragments were the previous step's requests; only what it issued behind them is younger)
       asm volatile("" : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Ac[2]), "+v"(Ac[3])::"memory");
       y2 = y1; y1 = 0;
       STAMP(1);
@@ -539,36 +544,26 @@ __global__ void __launch_bounds__(kThreadsC, 2) k_conv_c8x(const CParams p) {
       vo = nvo;
       STAMP(3);
     };
-    int s = 0;
+    if constexpr (AD == 2) {
 #pragma unroll 1
-    for (; s + 3 <= p.NS; s += 3) {
-      kstep(s, A0, A2);
-      kstep(s + 1, A1, A0);
-      kstep(s + 2, A2, A1);
+      for (int s = 0; s < p.NS; s += 3) {
+        kstep(s, A0, A2);
+        kstep(s + 1, A1, A0);
+        kstep(s + 2, A2, A1);
+      }
+    } else {
+#pragma unroll 1
+      for (int s = 0; s < p.NS; s += 2) {
+        kstep(s, A0, A1);
+        kstep(s + 1, A1, A0);
+      }
     }
-    const int rem = p.NS - s;  // 5^3 layers: NS = 250 Cin / 64 is no multiple of three
-    if (rem >= 1) kstep(s, A0, A2);
-    if (rem == 2) kstep(s + 1, A1, A0);
     epilogue(cur);
     y1 += nstores;
 #ifdef NC_C8X_STAMP
     if (p.dbg && blockIdx.x == 0 && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); tsum[4] += t_ - tprev; tprev = t_; }
 #endif
     if (!more_tiles) break;
-    if (rem) {
-      // the next tile's first two sets sit in (A1, A2) / (A2, A0): move them to (A0, A1).  They have to have arrived for that -- an
-      // exposed wait per tile of 250+ k-steps (everything older than the stores just issued)
-      wait_vm(nstores);
-      asm volatile("" : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(A1[0]), "+v"(A1[1]), "+v"(A1[2]), "+v"(A1[3]), "+v"(A2[0]),
-                   "+v"(A2[1]), "+v"(A2[2]), "+v"(A2[3])::"memory");
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const u32x4 t0 = A0[rb], t1 = A1[rb], t2 = A2[rb];
-        if (rem == 1) { A0[rb] = t1; A1[rb] = t2; }
-        else { A0[rb] = t2; A1[rb] = t0; }
-      }
-      y2 = 0;
-    }
     zero_acc();
     ring = (ring + NB) % RING;
     cur = nxt;
@@ -633,7 +628,7 @@ size_t c8x_packed_bytes(int Cin, int Kout, int KS) {
 // Cin / Kout: channels of the tensor read / written by THIS call (the data gradient swaps the layer's)
 bool c8x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS, bool fp32_out) {
   if (!c8x_mode() || (KS != 3 && KS != 5)) return false;
-  if (Cin % 32 || Kout % 64) return false;  // whole k-steps: (Cin / 8) * KS^3 taps in fours
+  if (Cin % (KS == 3 ? 32 : 64) || Kout % 64) return false;  // whole k-steps ((Cin / 8) * KS^3 taps in fours): 3^3 a multiple of three, 5^3 an even number
   const long S = (long)D * H * W;
   if (S * 16 >= (1l << 31)) return false;  // byte offsets inside one 8-channel block stay below the out-of-range mark
   if (fp32_out ? (long)Kout * S * 4 >= (1l << 31) : (long)(Kout / 8) * S * 16 >= (1l << 31)) return false;

@@ -35,5 +35,5 @@ def p2p_fence(t):
     """Call before handing a CUDA tensor to send / recv / batch_isend_irecv.  RCCL orders the transfer behind the current stream by
     itself; gloo does not (see the module docstring): drain the device first."""
     import torch.distributed as dist
-    if t.is_cuda and dist.get_backend() == 'gloo':
+    if t.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'gloo':
         torch.cuda.synchronize(t.device)

