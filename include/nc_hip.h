@@ -126,6 +126,16 @@ int nc_instnorm_act_fwd(const float* x, const float* mean, const float* rstd, fl
                         void* stream);
 int nc_instnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, float slope, float* dx,
                         int NC, long S, void* ws, size_t ws_bytes, void* stream);
+/* --norm batch: nn.BatchNorm{2,3}d(affine=True, track_running_stats=True) (+ the ReLU / LeakyReLU behind it) of get_norm_layer
+ * (models/networks.py:30-31) -- statistics over (N, spatial) per channel; training: running statistics updated in place (momentum, unbiased
+ * variance), evaluation (training = 0): the running statistics are used.  mean / rstd: [C]; ws: nc_instnorm_ws_bytes(N * C, S); N * C <= 65535. */
+int nc_batchnorm_stats(const float* x, int N, int C, long S, float eps, float momentum, int training, float* mean, float* rstd,
+                       float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream);
+int nc_batchnorm_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, float* y,
+                         int N, int C, long S, void* stream);
+int nc_batchnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         float slope, int training, float* dx, float* dgamma, float* dbeta, float* coef /* 2 C floats of scratch */, int N, int C,
+                         long S, void* ws, size_t ws_bytes, void* stream);
 /* Same backward, and dbias[C] = the per-channel sum of dx over samples and voxels: dx is the gradient at the output of
  * the convolution in front of the norm (networks.py:420-423), so this IS that convolution's bias gradient -- taken
  * while dx is in registers instead of by a second pass over dx (nc_conv_wgrad with dbias = NULL then). */

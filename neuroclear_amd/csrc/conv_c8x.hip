@@ -53,6 +53,9 @@ constexpr int kNCB = 8, kPT = kWavesC * kNCB * 16;  // 512 positions per tile
 // timing experiments only (tools/variant.sh): 1 no barrier, 2 no brick DMA, 4 no B-fragment reads, 8 no A-fragment loads, 16 no stores,
 // 32 no MFMAs, 64 no hand-placed vmcnt waits
 constexpr int kAbl = NC_C8X_ABL;
+#ifndef NC_C8X_BD
+#define NC_C8X_BD 2
+#endif
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned m) { return __umulhi(n, m); }
 unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(kThreadsC, 2) k_conv_c8x(const CParams p) {
   // step's pieces: at the top of step s everything younger than them -- y2, the 4 loads of step s - 1, y1 -- may stay in flight, so a
   // brick piece has two to three k-steps to land and a tile's stores two.
   int y1 = 0, y2 = 0;
-  constexpr int BD = 2;      // B fragments are requested BD column blocks ahead
+  constexpr int BD = NC_C8X_BD;     // B fragments are requested BD column blocks ahead
   u32x4 B[2 * BD];
 
 #ifdef NC_C8X_STAMP

@@ -552,6 +552,120 @@ static unsigned flat_grid(long n, int per_block = 256) {
 
 using namespace nc;
 
+// ---------------------------------------------------------------- BatchNorm{2,3}d(affine, running statistics) + (Leaky)ReLU
+// --norm batch (reference models/networks.py:30-31: functools.partial(nn.BatchNorm3d / 2d, affine=True, track_running_stats=True); the
+// reference's default --norm, although its README configuration and the north star use instance).  Statistics over (N, spatial) per
+// channel from the same fp64 per-instance partial sums the instance norm takes (k_in_stats), then one fused apply pass
+//   y = act((x - mean_c) * rstd_c * gamma_c + beta_c).
+// Training: biased variance for the normalisation, running_mean / running_var updated with `momentum` and the UNBIASED variance, as
+// torch does; evaluation: the running statistics.
+__global__ void k_bn_finalize(const double* __restrict__ part, int N, int C, int splits, long S, float eps, float momentum,
+                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                              float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < splits; ++k) {
+      s += part[(((long)n * C + c) * splits + k) * 2];
+      q += part[(((long)n * C + c) * splits + k) * 2 + 1];
+    }
+  const double M = (double)N * (double)S;
+  const double m = s / M;
+  double var = q / M - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+  if (running_var) {
+    const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+// evaluation mode: mean / rstd from the running statistics
+__global__ void k_bn_running(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C, float eps,
+                             float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  rstd[c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+}
+__device__ __forceinline__ float bn_value(float xv, float m, float r, float g, float b) {
+  float xh = (xv - m) * r;
+  asm("" : "+v"(xh));  // (the same rounding points in forward and backward: x-hat first, then the affine map)
+  return xh * g + b;
+}
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                    float* __restrict__ y, int C, long S) {
+  const int inst = blockIdx.y, c = inst % C;
+  const float m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+  const float* p = x + (long)inst * S;
+  float* o = y + (long)inst * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    const float v = bn_value(p[i], m, r, g, b);
+    o[i] = v > 0.f ? v : v * slope;
+  }
+}
+// backward pass 1: per (instance, split) s1 = sum(gz), s2 = sum(gz * xhat), gz = dy * act'(z)
+__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float slope, int C, long S, int splits,
+                                                     double* __restrict__ part) {
+  const int inst = blockIdx.y, sp = blockIdx.x, c = inst % C;
+  long b0, e;
+  chunk_range(S, splits, sp, b0, e);
+  const float m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+  const float* px = x + (long)inst * S;
+  const float* pg = dy + (long)inst * S;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = b0 + threadIdx.x; i < e; i += 256) {
+    float xh = (px[i] - m) * r;
+    asm("" : "+v"(xh));
+    const float z = xh * g + b;
+    const float gz = z > 0.f ? pg[i] : pg[i] * slope;
+    s1 += (double)gz;
+    s2 = fma((double)gz, (double)xh, s2);
+  }
+  block_reduce2(s1, s2, part + ((long)inst * splits + sp) * 2);
+}
+// per channel: dbeta = sum gz, dgamma = sum gz xhat (over all instances and splits, fixed order); coef = (dbeta / M, dgamma / M)
+__global__ void k_bn_bwd_finalize(const double* __restrict__ part, int N, int C, int splits, long S, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < splits; ++k) {
+      s1 += part[(((long)n * C + c) * splits + k) * 2];
+      s2 += part[(((long)n * C + c) * splits + k) * 2 + 1];
+    }
+  const double M = (double)N * (double)S;
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  coef[2 * c] = (float)(s1 / M);
+  coef[2 * c + 1] = (float)(s2 / M);
+}
+// dx = gamma rstd (gz - mean(gz) - xhat mean(gz xhat))  (training);  dx = gamma rstd gz  (evaluation: the statistics are constants)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float slope, const float* __restrict__ coef,
+                                                      int training, float* __restrict__ dx, int C, long S) {
+  const int inst = blockIdx.y, c = inst % C;
+  const float m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+  const float m1 = training ? coef[2 * c] : 0.f, m2 = training ? coef[2 * c + 1] : 0.f;
+  const float* px = x + (long)inst * S;
+  const float* pg = dy + (long)inst * S;
+  float* o = dx + (long)inst * S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < S; i += (long)gridDim.x * 256) {
+    float xh = (px[i] - m) * r;
+    asm("" : "+v"(xh));
+    const float z = xh * g + b;
+    const float gz = z > 0.f ? pg[i] : pg[i] * slope;
+    o[i] = (g * r) * ((gz - m1) - xh * m2);
+  }
+}
+
 extern "C" {
 
 size_t nc_instnorm_ws_bytes(int NC, long S) {
@@ -808,4 +922,49 @@ int nc_maxpool2_bwd_add(const float* dy, const float* x, const float* skip, floa
   return check_launch("maxpool2_bwd_add");
 }
 
+
+// BatchNorm + activation (see the kernels above).  ws: nc_instnorm_ws_bytes(N * C, S) bytes.  mean / rstd: [C] outputs of the statistics
+// call, inputs of the others.  running_mean / running_var: [C], updated in place (training) or read (evaluation); nullable in training.
+int nc_batchnorm_stats(const float* x, int N, int C, long S, float eps, float momentum, int training, float* mean, float* rstd,
+                       float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !mean || !rstd) { set_error("batchnorm_stats: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_stats: bad shape N=%d C=%d S=%ld", N, C, S); return NC_ERR_SHAPE; }
+  hipStream_t s = (hipStream_t)stream;
+  if (!training) {
+    if (!running_mean || !running_var) { set_error("batchnorm_stats: evaluation mode needs the running statistics"); return NC_ERR_ARG; }
+    hipLaunchKernelGGL(k_bn_running, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, s, running_mean, running_var, C, eps, mean, rstd);
+    return check_launch("batchnorm_stats");
+  }
+  if (!ws || ws_bytes < nc_instnorm_ws_bytes(N * C, S)) { set_error("batchnorm_stats: workspace too small"); return NC_ERR_WS; }
+  const int splits = pick_splits(N * C, S);
+  hipLaunchKernelGGL(k_in_stats, dim3(splits, N * C), dim3(256), 0, s, x, S, splits, (double*)ws);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, N, C, splits, S, eps, momentum, mean, rstd,
+                     running_mean, running_var);
+  return check_launch("batchnorm_stats");
+}
+int nc_batchnorm_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, float* y,
+                         int N, int C, long S, void* stream) {
+  if (!x || !mean || !rstd || !gamma || !beta || !y) { set_error("batchnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
+  long bx = cdiv(S, 1024 * 4);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_bn_act_fwd, dim3((unsigned)bx, N * C), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, slope, y, C, S);
+  return check_launch("batchnorm_act_fwd");
+}
+// dgamma / dbeta: [C] outputs (always computed); coef: 2 C floats of scratch
+int nc_batchnorm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         float slope, int training, float* dx, float* dgamma, float* dbeta, float* coef, int N, int C, long S, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !coef) { set_error("batchnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
+  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (!ws || ws_bytes < nc_instnorm_ws_bytes(N * C, S)) { set_error("batchnorm_act_bwd: workspace too small"); return NC_ERR_WS; }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = pick_splits(N * C, S);
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(splits, N * C), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, slope, C, S, splits, (double*)ws);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, N, C, splits, S, dgamma, dbeta, coef);
+  long bx = cdiv(S, 1024 * 4);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)bx, N * C), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, slope, coef, training, dx, C, S);
+  return check_launch("batchnorm_act_bwd");
+}
 }  // extern "C"

@@ -3,8 +3,8 @@
 Same factory names, argument meaning, state-dict keys and error behaviour as the reference for the networks that
 BASELINE.json's north_star names -- `unet_deconv` (:478-538), `deep_linear_gen` (:893-917), `basic` / `n_layers`
 PatchGAN (:1009-1067) -- plus, as the first widening row, `unet_vanilla` (:540-608) and the `pixel`
-discriminator (:1147-1179), which are built from the same kernels; InstanceNorm (:20-44), `GANLoss('lsgan')` (:252-319), `init_net` (:122-137),
-`get_scheduler` (:50-86).  Every forward/backward runs HIP kernels from libnc_hip.so through neuroclear_amd.ops;
+discriminator (:1147-1179), which are built from the same kernels; `get_norm_layer` (:20-44: instance -- the hot path -- and batch),
+`GANLoss` (:252-319: lsgan -- the hot path -- vanilla, wgangp), `init_net` (:122-137), `get_scheduler` (:50-86).  Every forward/backward runs HIP kernels from libnc_hip.so through neuroclear_amd.ops;
 there is no torch.nn.functional compute and no CPU fallback.  Networks outside the scope table (SURVEY.md 8a:
 resnet, VGG, linear kernels, spectral-norm D, ...) raise NotImplementedError exactly like an unknown name does in
 the reference (:196, :246).
@@ -42,6 +42,34 @@ class InstanceNormAct(nn.Module):
         return '%d, slope=%g (HIP fused IN+act)' % (self.num_features, self.slope)
 
 
+class BatchNormAct(nn.Module):
+    """nn.BatchNorm{2,3}d(num_features, affine=True, track_running_stats=True) (get_norm_layer('batch'), networks.py:30-31) fused with the
+    activation behind it.  Parameters and buffers carry torch's names (weight, bias, running_mean, running_var, num_batches_tracked), so
+    checkpoints of the reference load as they are."""
+
+    def __init__(self, num_features, slope=0.0, eps=1e-5, momentum=0.1, dimension=3):
+        super().__init__()
+        self.num_features, self.slope, self.eps, self.momentum, self.dimension = num_features, slope, eps, momentum, dimension
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.momentum, self.eps,
+                                  self.slope)
+
+    def extra_repr(self):
+        return '%d, slope=%g (HIP fused BN%dd+act)' % (self.num_features, self.slope, self.dimension)
+
+
+def _is_instance_norm(norm_layer):
+    return norm_layer is not None and getattr(norm_layer, 'func', norm_layer) is InstanceNormAct
+
+
 class FusedActivation(nn.Module):
     """Placeholder at the Sequential index where the reference has nn.ReLU()/nn.LeakyReLU(): the activation is
     applied by the preceding InstanceNormAct kernel, this module is the identity."""
@@ -66,8 +94,7 @@ def get_norm_layer(norm_type='instance', dimension=3):
     if norm_type in ('none', 'spectral'):
         return None
     if norm_type == 'batch':
-        raise NotImplementedError('normalization layer [batch] is outside the MI355X hot path (SURVEY.md 8a); '
-                                  'the reference configs use --norm instance')
+        return functools.partial(BatchNormAct, dimension=dimension)
     raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
 
 
@@ -105,6 +132,9 @@ def init_weights(net, init_type='normal', init_gain=0.02):
                 raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
             if hasattr(m, 'bias') and m.bias is not None:
                 init.constant_(m.bias.data, 0.0)
+        elif isinstance(m, BatchNormAct) and m.dimension == 3:  # the reference tests for 'BatchNorm3d' only (networks.py:115-117)
+            init.normal_(m.weight.data, 1.0, init_gain)
+            init.constant_(m.bias.data, 0.0)
     net.apply(init_func)
 
 
@@ -321,7 +351,7 @@ class Unet_deconv(nn.Module):
         self.ex_conv1_1 = last_conv(start_nc * 2, start_nc, 3, 1, 1, norm_layer, dimension)
         self.one_by_one = Conv(start_nc, output_nc, 1, 1, 0, dimension=dimension)
         self.one_by_one_2 = Conv(output_nc, output_nc, 1, 1, 0, dimension=dimension)
-        self._fusable = norm_layer is not None and input_nc == 1 and output_nc == 1
+        self._fusable = _is_instance_norm(norm_layer) and input_nc == 1 and output_nc == 1
 
     def _packed_params(self):
         """The 28 tensors in state-dict order as one flat blob: a zero-copy view of FlatAdam's buffer when the
@@ -430,7 +460,7 @@ class NLayerDiscriminator(nn.Module):
         super().__init__()
         if use_sigmoid:
             raise NotImplementedError('use_sigmoid=True is never set by the hot-path models (apollo:108-123)')
-        use_bias = norm_layer is not None  # InstanceNorm -> bias (reference: use_bias = norm is InstanceNorm)
+        use_bias = _is_instance_norm(norm_layer)  # reference networks.py:1025-1028: use_bias = (norm is InstanceNorm)
         kw, padw = 4, 1
         seq = [Conv(input_nc, ndf, kw, 2, padw, dimension=dimension), LeakyReLU(0.2)]
         nf_mult = 1
@@ -447,7 +477,7 @@ class NLayerDiscriminator(nn.Module):
         # chains are host-enqueue-bound otherwise.  Same kernels in the same order; NC_FUSED_PATCHGAN=0 or an
         # architecture the entry point does not cover (no norm, other input channels) takes the op-by-op path.
         self._cfg = (n_layers, ndf, dimension)
-        self._fusable = norm_layer is not None and input_nc == 1 and 1 <= n_layers <= 6
+        self._fusable = _is_instance_norm(norm_layer) and input_nc == 1 and 1 <= n_layers <= 6
 
     def _fused_on(self, input):
         return self._fusable and input.is_cuda and os.environ.get('NC_FUSED_PATCHGAN', '1') != '0'
@@ -479,7 +509,7 @@ class PixelDiscriminator(nn.Module):
 
     def __init__(self, input_nc, ndf=64, norm_layer=None, dimension=3):
         super().__init__()
-        use_bias = norm_layer is not None
+        use_bias = _is_instance_norm(norm_layer)
         seq = [Conv(input_nc, ndf, 1, 1, 0, dimension=dimension), LeakyReLU(0.2),
                Conv(ndf, ndf * 2, 1, 1, 0, bias=use_bias, dimension=dimension)]
         seq += [norm_layer(ndf * 2, 0.2), FusedActivation()] if norm_layer else [Identity(), LeakyReLU(0.2)]

@@ -556,6 +556,51 @@ def instance_norm_act(x, slope=0.0, eps=1e-5, link=None, nxt=None):
     return _InstNormAct.apply(x, float(slope), float(eps), link, nxt)
 
 
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        x = x.contiguous()
+        _chk(x, gamma, beta)
+        _f32(x, gamma, beta)
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        L = lib()
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(L.nc_instnorm_ws_bytes(I(N * C), L_(S)), x.device, 'bn')
+        check(L.nc_batchnorm_stats(_ptr(x), I(N), I(C), L_(S), F(eps), F(momentum), I(1 if training else 0), _ptr(mean), _ptr(rstd),
+                                   _ptr(running_mean), _ptr(running_var), _ptr(ws), Z(ws.numel()), _stream()), 'nc_batchnorm_stats')
+        y = torch.empty_like(x)
+        check(L.nc_batchnorm_act_fwd(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), F(slope), _ptr(y), I(N), I(C), L_(S), _stream()),
+              'nc_batchnorm_act_fwd')
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.cfg = (bool(training), float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        training, slope = ctx.cfg
+        dy = dy.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        S = x.numel() // (N * C)
+        L = lib()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        coef = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        ws = workspace(L.nc_instnorm_ws_bytes(I(N * C), L_(S)), x.device, 'bn')
+        check(L.nc_batchnorm_act_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), F(slope), I(1 if training else 0),
+                                     _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(coef), I(N), I(C), L_(S), _ptr(ws), Z(ws.numel()), _stream()),
+              'nc_batchnorm_act_bwd')
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=0.0):
+    """nn.BatchNorm{2,3}d(affine=True, track_running_stats=True) (models/networks.py:30-31, --norm batch) followed by ReLU (slope 0) /
+    LeakyReLU(slope); running_mean / running_var are updated in place in training mode and used in evaluation mode."""
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), float(slope))
+
+
 class _LeakyReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope):

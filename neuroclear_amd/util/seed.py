@@ -141,6 +141,51 @@ def pixel_spec(dimension=2, input_nc=1, ndf=64):
             ('net.5.weight', (1, ndf * 2) + k), ('net.5.bias', (1,))]
 
 
+def with_batch_norm(spec, norm_index=lambda conv_key: None):
+    """The (key, shape) list of the same network built with --norm batch (networks.py:30-31): behind every convolution that is followed
+    by a norm layer -- `norm_index(conv weight key)` gives that layer's key prefix, or None -- the five BatchNorm entries in state-dict
+    order (weight, bias, running_mean, running_var, num_batches_tracked)."""
+    out = []
+    pending = None
+    for key, shape in spec:
+        if pending is not None and not key.startswith(pending[0]):
+            out.extend(pending[1])
+            pending = None
+        out.append((key, shape))
+        if key.endswith('.weight') and len(shape) > 1:
+            nk = norm_index(key)
+            if nk is not None:
+                c = shape[0]
+                pending = (key[:-len('weight')], [(nk + '.weight', (c,)), (nk + '.bias', (c,)), (nk + '.running_mean', (c,)),
+                                                  (nk + '.running_var', (c,)), (nk + '.num_batches_tracked', ())])
+    if pending is not None:
+        out.extend(pending[1])
+    return out
+
+
+def _block_norm(conv_key):
+    # '<block>.convolution.<i>.weight' -> '<block>.convolution.<i + 1>' (Sequential: conv, norm, relu)
+    parts = conv_key.split('.')
+    if len(parts) >= 4 and parts[-3] == 'convolution':
+        return '.'.join(parts[:-2] + [str(int(parts[-2]) + 1)])
+    return None
+
+
+def unet_deconv_bn_spec(dimension=3):
+    """Unet_deconv with BatchNorm layers (the convolutions keep their biases: double_conv does not look at the norm, networks.py:420)."""
+    return with_batch_norm(unet_deconv_spec(dimension), _block_norm)
+
+
+def patchgan_bn_spec(dimension=2, input_nc=1, ndf=64, n_layers=3):
+    """NLayerDiscriminator with BatchNorm: the convolutions in front of a norm layer carry NO bias (use_bias is True for InstanceNorm
+    only, networks.py:1025-1028); BatchNorm sits at Sequential index conv + 1."""
+    base = patchgan_spec(dimension, input_nc, ndf, n_layers)
+    last = max(int(k.split('.')[1]) for k, _ in base)
+    normed = {k.split('.')[1] for k, _ in base if k.endswith('.weight') and k.split('.')[1] not in ('0', str(last))}
+    spec = [(k, sh) for k, sh in base if not (k.endswith('.bias') and k.split('.')[1] in normed)]
+    return with_batch_norm(spec, lambda key: 'model.%d' % (int(key.split('.')[1]) + 1) if key.split('.')[1] in normed else None)
+
+
 def _fan_in(key, shape):
     # torch's _calculate_fan_in_and_fan_out: fan_in = size(1) * receptive field -- for ConvTranspose weights
     # (Cin, Cout, k..) that is Cout * k^d, which is what kaiming_normal_ in the reference ends up using.
@@ -155,7 +200,13 @@ def weights_from_seed(spec, seed, bias_scale=0.1):
     out = OrderedDict()
     for idx, (key, shape) in enumerate(spec):
         rng = np.random.default_rng([int(seed), idx])
-        if key.endswith('.weight') or key.endswith('.weight_orig'):
+        if key.endswith('.num_batches_tracked'):
+            out[key] = np.zeros(shape, np.int64)
+        elif key.endswith('.running_var'):
+            out[key] = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif key.endswith('.weight') and len(shape) == 1:  # BatchNorm gamma: around one, away from zero
+            out[key] = rng.uniform(0.8, 1.2, size=shape).astype(np.float32)
+        elif key.endswith('.weight') or key.endswith('.weight_orig'):
             std = np.sqrt(2.0 / _fan_in(key, shape))
             out[key] = (rng.standard_normal(shape) * std).astype(np.float32)
         elif key.endswith('.weight_u') or key.endswith('.weight_v'):  # spectral-norm power-iteration vectors: unit length

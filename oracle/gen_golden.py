@@ -428,6 +428,38 @@ def gen_ganloss(networks):
     print('ganloss', {k: float(v) for k, v in out.items() if k.endswith('_loss') and '_a_' in k})
 
 
+def gen_batchnorm(networks):
+    """--norm batch (networks.py:30-31): unet_deconv and the 2-D PatchGAN built with BatchNorm by the reference's own factories -- one
+    training-mode forward + backward (outputs, gradients, the running statistics it leaves) and an evaluation-mode forward after it."""
+    import contextlib
+    import io
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    cases = (('unet_deconv_bn_16', lambda: networks.define_G(1, 1, 64, 'unet_deconv', 'batch', False, 'kaiming', 0.02, [], dimension=3),
+              S.unet_deconv_bn_spec(), (2, 1, 16, 16, 16), 31),
+             ('patchgan_bn_2d_36', lambda: networks.define_D(1, 64, 'basic', 3, 'batch', 'kaiming', 0.02, False, [], dimension=2),
+              S.patchgan_bn_spec(2), (3, 1, 36, 36), 32))
+    for tag, make, spec, shape, seed in cases:
+        with quiet:
+            net = make()
+        assert [k for k, _ in spec] == list(net.state_dict().keys()), (tag, [k for k, _ in spec][:12], list(net.state_dict().keys())[:12])
+        load_sd(net, S.weights_from_seed(spec, seed))
+        net.train()
+        x = torch.from_numpy(rand_input(100 + seed, shape)).requires_grad_(True)
+        y = net(x)
+        r = torch.from_numpy(rand_input(200 + seed, y.shape))
+        (y * r).mean().backward()
+        named = [(k, p.grad) for k, p in net.named_parameters()]
+        l2, sm, samp = grad_summary(named)
+        stats = {('buf_' + k): v.numpy().copy() for k, v in net.state_dict().items() if 'running_' in k or 'num_batches' in k}
+        net.eval()
+        with torch.no_grad():
+            y_eval = net(torch.from_numpy(rand_input(300 + seed, shape)))
+        np.savez_compressed(os.path.join(OUT, tag + '.npz'), seed=seed, shape=np.array(shape), x_seed=100 + seed, r_seed=200 + seed,
+                            xe_seed=300 + seed, y=y.detach().numpy(), dx=x.grad.numpy(), g_l2=l2, g_sum=sm, g_samp=samp,
+                            g_names=np.array([k for k, _ in named]), y_eval=y_eval.numpy(), **stats)
+        print(tag, tuple(y.shape), float(y.mean()), float(y_eval.mean()))
+
+
 def gen_dice():
     import data as refdata  # noqa: F401  (registers the package the assembler imports)
     from util.assemble_dice import Assemble_Dice
@@ -569,6 +601,8 @@ if __name__ == '__main__':
         gen_apollo()
     if 'apollo_b2' in which or not sys.argv[1:]:
         gen_apollo(size=24, step_seed=4242, batch=2, real_seed=322, fname='apollo_step_24_b2.npz')
+    if 'batchnorm' in which or not sys.argv[1:]:
+        gen_batchnorm(networks)
     if 'ganloss' in which or not sys.argv[1:]:
         gen_ganloss(networks)
         gen_apollo(size=24, step_seed=777, batch=1, real_seed=323, fname='apollo_step_24_vanilla.npz', extra={'gan_mode': 'vanilla'})

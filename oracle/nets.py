@@ -17,6 +17,7 @@ reference's key names):
 Parity pin: ``tests/test_oracle_golden.py`` checks every function here against ``tests/golden/*.npz``, which were
 produced by importing the reference itself in the build container (``oracle/gen_golden.py``).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -27,6 +28,19 @@ def _in_act(x, slope):
     # get_norm_layer('instance'): affine=False, track_running_stats=False (networks.py:33-34) => same in train/eval
     x = F.instance_norm(x, eps=EPS)
     return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+
+
+def _bn_act(x, sd, name, slope, training):
+    # get_norm_layer('batch'): nn.BatchNorm{2,3}d(affine=True, track_running_stats=True) (networks.py:30-31); training mode normalises with
+    # the batch statistics and updates sd[name + '.running_*'] IN PLACE (momentum 0.1, unbiased variance), evaluation uses them
+    if training:
+        sd[name + '.num_batches_tracked'] += 1
+    x = F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'], sd[name + '.bias'], training, 0.1, EPS)
+    return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+
+
+def _norm_act(x, sd, name, slope, norm, training):
+    return _in_act(x, slope) if norm == 'instance' else _bn_act(x, sd, name, slope, training)
 
 
 def _conv(x, sd, name, stride=1, padding=0):
@@ -42,22 +56,24 @@ def _convT(x, sd, name):
     return fn(x, w, sd[name + '.bias'], stride=2)
 
 
-def _block(x, sd, prefix, idxs):
+def _block(x, sd, prefix, idxs, norm='instance', training=True):
     for i in idxs:
-        x = _in_act(_conv(x, sd, '%s.convolution.%d' % (prefix, i), padding=1), 0.0)
+        x = _norm_act(_conv(x, sd, '%s.convolution.%d' % (prefix, i), padding=1), sd, '%s.convolution.%d' % (prefix, i + 1), 0.0, norm, training)
     return x
 
 
-def unet_deconv(sd, x, taps=None):
-    """networks.py:512-538.  ``taps`` (optional dict) receives the five stage outputs named as in the reference."""
+def unet_deconv(sd, x, taps=None, norm='instance', training=True):
+    """networks.py:512-538.  ``taps`` (optional dict) receives the five stage outputs named as in the reference.  norm: 'instance'
+    (the hot path) or 'batch' (--norm batch; `training` picks batch or running statistics)."""
     pool = F.max_pool3d if x.dim() == 5 else F.max_pool2d
-    conv1 = _block(x, sd, 'double_conv1', (0, 3))
-    conv2 = _block(pool(conv1, 2), sd, 'double_conv2', (0, 3))
-    bottom = _block(pool(conv2, 2), sd, 'bottom_layer', (0, 3, 6))
+    kw = dict(norm=norm, training=training)
+    conv1 = _block(x, sd, 'double_conv1', (0, 3), **kw)
+    conv2 = _block(pool(conv1, 2), sd, 'double_conv2', (0, 3), **kw)
+    bottom = _block(pool(conv2, 2), sd, 'bottom_layer', (0, 3, 6), **kw)
     cat2 = torch.cat([conv2, _convT(bottom, sd, 't_conv2')], 1)
-    ex2 = _block(cat2, sd, 'ex_double_conv2', (0, 3))
+    ex2 = _block(cat2, sd, 'ex_double_conv2', (0, 3), **kw)
     cat1 = torch.cat([conv1, _convT(ex2, sd, 't_conv1')], 1)
-    ex1 = _block(cat1, sd, 'ex_conv1_1', (0,))
+    ex1 = _block(cat1, sd, 'ex_conv1_1', (0,), **kw)
     y = _conv(_conv(ex1, sd, 'one_by_one'), sd, 'one_by_one_2')
     if taps is not None:
         taps.update(conv1=conv1, conv2=conv2, conv_bottom=bottom, ex_conv2=ex2, ex_conv1=ex1)
@@ -75,15 +91,15 @@ def deep_linear(sd, x):
     return _conv(x, sd, 'final_layer')
 
 
-def patchgan(sd, x, n_layers=3):
-    """networks.py:1030-1066 with instance norm: conv(s2)+LReLU, (conv(s2)+IN+LReLU)x(n_layers-1),
-    conv(s1)+IN+LReLU, conv(s1) head.  kernel 4, padding 1 everywhere."""
+def patchgan(sd, x, n_layers=3, norm='instance', training=True):
+    """networks.py:1030-1066: conv(s2)+LReLU, (conv(s2)+norm+LReLU)x(n_layers-1), conv(s1)+norm+LReLU, conv(s1) head.  kernel 4,
+    padding 1 everywhere.  norm 'instance' (every conv biased) or 'batch' (the normed convs carry no bias: sd simply has none)."""
     x = F.leaky_relu(_conv(x, sd, 'model.0', stride=2, padding=1), 0.2)
     idx = 2
     for _ in range(1, n_layers):
-        x = _in_act(_conv(x, sd, 'model.%d' % idx, stride=2, padding=1), 0.2)
+        x = _norm_act(_conv(x, sd, 'model.%d' % idx, stride=2, padding=1), sd, 'model.%d' % (idx + 1), 0.2, norm, training)
         idx += 3
-    x = _in_act(_conv(x, sd, 'model.%d' % idx, stride=1, padding=1), 0.2)
+    x = _norm_act(_conv(x, sd, 'model.%d' % idx, stride=1, padding=1), sd, 'model.%d' % (idx + 1), 0.2, norm, training)
     idx += 3
     return _conv(x, sd, 'model.%d' % idx, stride=1, padding=1)
 
@@ -161,7 +177,8 @@ def l1(a, b):
 def to_torch(sd_np, requires_grad=False):
     out = {}
     for k, v in sd_np.items():
-        t = torch.from_numpy(v).clone()
-        t.requires_grad_(requires_grad)
+        t = torch.from_numpy(np.asarray(v)).clone()
+        # (BatchNorm buffers -- running statistics, the step counter -- are state, not parameters)
+        t.requires_grad_(requires_grad and t.is_floating_point() and '.running_' not in k)
         out[k] = t
     return out

@@ -753,3 +753,40 @@ def test_gan_loss_modes(golden_dir):
                 np.testing.assert_allclose(p.grad.cpu().numpy(), g[key + '_grad'], rtol=2e-5, atol=1e-8)
     with pytest.raises(NotImplementedError):
         networks.GANLoss('hinge')
+
+
+@pytest.mark.parametrize('tag', ['unet_deconv_bn_16', 'patchgan_bn_2d_36'])
+def test_batch_norm_networks(golden_dir, tag):
+    """--norm batch (models/networks.py:30-31, nn.BatchNorm{2,3}d with affine parameters and running statistics) behind the same
+    factories: training-mode forward + backward against the reference's values, the running statistics and the step counter it leaves,
+    an evaluation-mode forward on them, and the state-dict keys (a reference checkpoint loads as it is)."""
+    g = G(golden_dir, tag + '.npz')
+    unet = tag.startswith('unet')
+    spec = S.unet_deconv_bn_spec() if unet else S.patchgan_bn_spec(2)
+    net = (networks.define_G(1, 1, 64, 'unet_deconv', 'batch', False, 'kaiming', 0.02, [0]) if unet else
+           networks.define_D(1, 64, 'basic', 3, 'batch', 'kaiming', 0.02, False, [0], dimension=2))
+    assert list(net.state_dict().keys()) == [k for k, _ in spec]
+    load(net, spec, int(g['seed']))
+    net.train()
+    shape = tuple(int(v) for v in g['shape'])
+    x = torch.from_numpy(rnd(g['x_seed'], shape)).to(DEV).requires_grad_(True)
+    y = net(x)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g['y'], atol=2e-5, rtol=5e-4)
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    assert rel2(x.grad.cpu().numpy(), g['dx']) < (2e-2 if unet else 1e-3)
+    names = [str(n) for n in g['g_names']]
+    params = dict(net.named_parameters())
+    for i, k in enumerate(names):
+        l2 = float(params[k].grad.double().norm())
+        assert abs(l2 - g['g_l2'][i]) <= (2e-2 if unet else 1e-3) * g['g_l2'][i] + 1e-6, (k, l2, g['g_l2'][i])
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith('buf_'):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], rtol=2e-5, atol=1e-6, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        ye = net(torch.from_numpy(rnd(g['xe_seed'], shape)).to(DEV))
+    np.testing.assert_allclose(ye.cpu().numpy(), g['y_eval'], atol=2e-5, rtol=5e-4)
+    with pytest.raises(NotImplementedError):
+        networks.get_norm_layer('layer', 3)

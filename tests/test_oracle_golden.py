@@ -263,3 +263,29 @@ def test_gan_loss_modes(golden_dir):
                 np.testing.assert_allclose(p.grad.numpy(), g[key + '_grad'], rtol=1e-6, atol=1e-9)
     with pytest.raises(NotImplementedError):
         nets.gan_loss(torch.zeros(1), True, 'hinge')
+
+
+@pytest.mark.parametrize('tag', ['unet_deconv_bn_16', 'patchgan_bn_2d_36'])
+def test_batch_norm_networks(golden_dir, tag):
+    """--norm batch (networks.py:30-31): the oracle's unet_deconv / patchgan with BatchNorm against the reference's own factories --
+    training-mode forward + backward, the running statistics it leaves, and an evaluation-mode forward on them."""
+    g = G(golden_dir, tag + '.npz')
+    unet = tag.startswith('unet')
+    spec = S.unet_deconv_bn_spec() if unet else S.patchgan_bn_spec(2)
+    sd = nets.to_torch(S.weights_from_seed(spec, int(g['seed'])), requires_grad=True)
+    shape = tuple(int(v) for v in g['shape'])
+    x = torch.from_numpy(rnd(g['x_seed'], shape)).requires_grad_(True)
+    fn = (lambda xx, tr: nets.unet_deconv(sd, xx, None, 'batch', tr)) if unet else (lambda xx, tr: nets.patchgan(sd, xx, 3, 'batch', tr))
+    y = fn(x, True)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], atol=2e-6, rtol=2e-5)
+    (y * torch.from_numpy(rnd(g['r_seed'], y.shape))).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['dx'], rtol=1e-3, atol=1e-3 * float(np.abs(g['dx']).max()))
+    for i, k in enumerate(str(n) for n in g['g_names']):
+        l2 = float(sd[k].grad.double().norm())
+        assert abs(l2 - g['g_l2'][i]) <= 2e-3 * g['g_l2'][i] + 1e-6, (k, l2, g['g_l2'][i])
+    for k in g.files:
+        if k.startswith('buf_'):
+            np.testing.assert_allclose(sd[k[4:]].detach().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        ye = fn(torch.from_numpy(rnd(g['xe_seed'], shape)), False)
+    np.testing.assert_allclose(ye.numpy(), g['y_eval'], atol=2e-6, rtol=2e-5)
