@@ -65,6 +65,11 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 }
 
 
+# `roofline.traffic` is NOT measured in this process (counters cannot be read from inside it): it is the figure of the committed offline PMC
+# passes of the same command, on whatever box those ran on
+TRAFFIC_FILE = 'r03_pmc_traffic.json'
+TRAFFIC_SOURCE = 'profiles/%s (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % TRAFFIC_FILE
+
 PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
              'dgrad_mfma_k5': 'conv_mfma_k5', 'wgrad_mfma_k3': 'wgrad_mfma_k3', 'wgrad_mfma_k5': 'wgrad_mfma_k5',
              # 16-bit classes: measured on ONE shape (64 -> 64, 4 x 148^3), so only reported for that workload
@@ -83,7 +88,7 @@ def pmc_traffic(tag, crop=108, batch=1):
     if '_lp_' not in tag and (crop != 108 or batch != 1):
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
             return round(json.load(f)['split_classes' if '_split_' in tag else 'classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
     except Exception:
         return None
@@ -274,7 +279,7 @@ def run_train(args, rank, world, dev):
                          bf16_tflops=round(ach * SPLIT_PRODUCTS, 1), vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
         roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
                     peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
-                    traffic=pmc_traffic(top, crop, args.batch), launches=n, avg_launch_ms=round(ms / n, 4),
+                    traffic=pmc_traffic(top, crop, args.batch), traffic_source=TRAFFIC_SOURCE, launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
@@ -294,7 +299,7 @@ GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE
 def pmc_traffic_cube(split=False):
     """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh, tools/pmc_split.sh)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
             return round(json.load(f)['inference_cube_140_split' if split else 'inference_cube_140']['hbm_bytes_per_cube'])
     except Exception:
         return None
@@ -369,7 +374,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
                                         'profiles/r03_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*>' if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
-                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), launches=len(ev),
+                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), traffic_source=TRAFFIC_SOURCE, launches=len(ev),
                     cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     event_ms_per_cube=round(ms_events / len(ev), 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
