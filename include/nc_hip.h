@@ -393,7 +393,7 @@ void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at 
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
 void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the
-                                  * *_lp whole-network calls; csrc/conv_c8x.hip): 1 (default; NC_C8X at load time) = the tap-stream kernel
+                                  * *_lp whole-network calls; csrc/conv_c8x.hip): 1 (default; NC_C8X at load time) = for 3^3 layers the tap-stream kernel
                                   * k_conv_c8x where its 512-position tiles fill the launch's rounds of 512 workgroups to >= 60 %, k_conv_h elsewhere (a few planes); 2 = k_conv_c8x
                                   * wherever the shape fits (channels read and written % 64 == 0); 0 = k_conv_h everywhere.  Both kernels multiply
                                   * the same 16-bit operands and accumulate in fp32; only the summation order differs */

@@ -158,12 +158,30 @@ struct CTile {
   int n, cot, z, q0;
 };
 
+// Tile order: output-channel tile fastest, then kTileGroup in-plane neighbours of one plane, then z, then the next group of in-plane tiles,
+// then the sample.  The workgroups of an XCD (64 consecutive tiles at any moment) therefore work on 4 neighbouring tiles x 16 consecutive
+// planes: a tile's halo rows ((KS - 1)(P + 1) of its 512 + ... units: +59 % at 148^2) are its in-plane neighbour's own rows, and a plane is
+// the dz = 0 / 1 / 2 brick of three z-neighbours -- both re-reads hit that XCD's L2 while the data are there.  (z-major order of whole
+// planes, the round-1 order of k_conv_h, leaves the in-plane neighbour 148 tiles = 2.3 rounds away: at 4 x 148^3 the input no longer
+// fits the 256 MB infinity cache and the halo comes from HBM again -- 1.49 x the algorithmic bytes.)
+constexpr int kTileGroup = 4;
 __device__ __forceinline__ CTile c_decode(const CParams& p, int t) {
-  CTile o;  // output-channel tile fastest, then z: neighbouring planes share input planes in L2
+  CTile o;
   o.cot = t % p.KT; t /= p.KT;
-  o.z = t % p.D; t /= p.D;
-  const int tp = t % p.TPP;
-  o.n = t / p.TPP;
+  const int per_n = p.TPP * p.D;
+  o.n = t / per_n;
+  const int u = t - o.n * per_n;
+  const int full = (p.TPP / kTileGroup) * kTileGroup * p.D;  // tiles in whole groups
+  int tp;
+  if (u < full) {
+    const int grp = u / (kTileGroup * p.D), rem = u - grp * (kTileGroup * p.D);
+    o.z = rem / kTileGroup;
+    tp = grp * kTileGroup + (rem - o.z * kTileGroup);
+  } else {
+    const int L = p.TPP % kTileGroup, v = u - full;  // the last, narrower group
+    o.z = v / L;
+    tp = (p.TPP / kTileGroup) * kTileGroup + (v - o.z * L);
+  }
   o.q0 = tp * kPT;
   o.cot = __builtin_amdgcn_readfirstlane(o.cot); o.z = __builtin_amdgcn_readfirstlane(o.z);
   o.n = __builtin_amdgcn_readfirstlane(o.n); o.q0 = __builtin_amdgcn_readfirstlane(o.q0);
@@ -636,6 +654,10 @@ bool c8x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS, bool f
   if (S * 16 >= (1l << 31)) return false;  // byte offsets inside one 8-channel block stay below the out-of-range mark
   if (fp32_out ? (long)Kout * S * 4 >= (1l << 31) : (long)(Kout / 8) * S * 16 >= (1l << 31)) return false;
   if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
+  // 5^3: k_conv_h's pair mode (26 taps x 8 channels per stage, weights shared through LDS by all eight waves, MFMA busy 0.72) is the
+  // better kernel in the step -- same-box A/B of the configs[3] step, profiles/r04_ab_c8x.txt: 1,340-1,400 against 1,200-1,300 TFLOP/s --
+  // and gives the same bits; the tap-stream kernel takes 5^3 only on request (mode 2: tests, timing)
+  if (KS == 5 && c8x_mode() < 2) return false;
   const CPlan pl = c_plan(N, D, H, W, Kout, KS);
   if (!pl.ok) return false;
   // launches that fill only a fraction of ONE round of 512 workgroups (a few planes) run better on k_conv_h's 256-position tiles; from

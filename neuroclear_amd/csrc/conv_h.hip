@@ -219,15 +219,29 @@ struct HTile {
   int n, cot, z, q0, yf, xoff;
 };
 
+// Tile order (round 4, as conv_c8x.hip): output-channel tile fastest, then kHGroup in-plane neighbours of one plane, then z, then the next
+// group of in-plane tiles, then the sample -- the 32 workgroups of an XCD work on 4 neighbouring tiles x 8 consecutive planes at a time, so
+// a tile's halo rows (its in-plane neighbour's own rows: 612 of 1024 + 612 units per brick at 5^3, 148^2) and the planes it shares with
+// its z-neighbours are re-read from that XCD's L2 while they are there.  (Whole planes in z-major order left the in-plane neighbour
+// 148 tiles away; at 4 x 148^3 the input no longer fits the 256 MB infinity cache and the 5^3 forward moved 2.2 x its algorithmic bytes.)
+constexpr int kHGroup = 4;
 __device__ __forceinline__ HTile h_decode(const HParams& p, long t) {
   HTile o;
-  // order: output-channel tile fastest, then z, then the position tile, then the sample -- the 32 workgroups of an XCD
-  // work on ~32 consecutive planes of ONE position tile at a time, so the input plane a workgroup stages for dz is the
-  // plane its two z-neighbours stage for dz -+ 1 at about the same moment: two of three fetches hit that XCD's L2
   o.cot = (int)(t % p.KT); t /= p.KT;
-  o.z = (int)(t % p.D); t /= p.D;
-  const int tp = (int)(t % p.TPP);
-  o.n = (int)(t / p.TPP);
+  const int per_n = p.TPP * p.D;
+  o.n = (int)(t / per_n);
+  const int u = (int)(t - (long)o.n * per_n);
+  const int full = (p.TPP / kHGroup) * kHGroup * p.D;
+  int tp;
+  if (u < full) {
+    const int grp = u / (kHGroup * p.D), rem = u - grp * (kHGroup * p.D);
+    o.z = rem / kHGroup;
+    tp = grp * kHGroup + (rem - o.z * kHGroup);
+  } else {
+    const int L = p.TPP % kHGroup, v = u - full;
+    o.z = v / L;
+    tp = (p.TPP / kHGroup) * kHGroup + (v - o.z * L);
+  }
   o.q0 = tp * p.PT;
   o.yf = (int)fdiv((unsigned)o.q0, p.mP);
   o.xoff = o.q0 - o.yf * p.P;
