@@ -59,8 +59,8 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
     'fwd_split_k3': 'k_conv_s3x<3,*>', 'dgrad_split_k3': 'k_conv_s3x<3,*>', 'fwd_split_k5': 'k_conv_s3x<5,*>',
     'dgrad_split_k5': 'k_conv_s3x<5,*>', 'wgrad_split_k3': 'k_wgrad_s3x<3>', 'wgrad_split_k5': 'k_wgrad_s3x<5>',
-    'fwd_lp_k3': 'k_conv_h<*,3,3,3,*>', 'dgrad_lp_k3': 'k_conv_h<*,3,3,3,*>', 'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>',
-    'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_h<*,3>', 'wgrad_lp_k5': 'k_wgrad_h<*,5>',
+    'fwd_lp_k3': 'k_conv_c8x<*,3> (k_conv_h<*,3,3,3,*> for launches of a few planes)', 'dgrad_lp_k3': 'k_conv_c8x<*,3>',
+    'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>', 'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_s3x<3,1,*>', 'wgrad_lp_k5': 'k_wgrad_s3x<5,1,*>',
     'fwd_lp_k7': 'k_conv_h<*,7,7,1,*> (pseudo-channel form)', 'dgrad_lp_k7': 'k_conv_h<*,7,7,1,*,1> + k_fold_x8',
 }
 

@@ -166,6 +166,15 @@ def broadcast_parameters(net, src=0):
             off += k
 
 
+def default_assemble(world, with_real=False, normalize_intensity=False):
+    """The assembly mode diced_inference picks when the caller names none: in-order on one rank; 'slab' on several -- unless something
+    needs the WHOLE volume on one rank (the percentiles of --normalize_intensity, the second visual of with_real): 'slab' finalises per
+    rank, so those take the one-reduce form.  Only an explicit assemble='slab' together with them raises."""
+    if world <= 1:
+        return 'gather'
+    return 'reduce' if (with_real or normalize_intensity) else 'slab'
+
+
 def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble=None, broadcast=True, on_cube=None,
                     with_real=False):
     """volume: uint8/uint16 ndarray (original size).  Returns the assembled uint8/uint16 ndarray on rank 0.
@@ -173,10 +182,7 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     with_real: also assemble the input cubes (the reference's 'real' visual, test_dice.py without --skip_real) and return
     (fake, real); the dice -> assemble round trip of the input is the input up to 1 LSB of the truncating cast."""
     if assemble is None:
-        # 'slab' finalises per rank, so anything that needs the WHOLE volume on one rank (the percentiles of --normalize_intensity,
-        # the second visual of with_real) takes the one-reduce form; only an explicit assemble='slab' with those raises
-        whole = with_real or getattr(opt, 'normalize_intensity', False)
-        assemble = ('reduce' if whole else 'slab') if world > 1 else 'gather'
+        assemble = default_assemble(world, with_real, getattr(opt, 'normalize_intensity', False))
     if assemble not in ('reduce', 'gather', 'slab'):
         raise ValueError("assemble must be 'slab', 'reduce' or 'gather'")
     if assemble == 'slab' and (with_real or getattr(opt, 'normalize_intensity', False)):

@@ -315,3 +315,12 @@ def test_flat_adam_bucketed_async_all_reduce(tmp_path, world):
     out = str(tmp_path / 'b.npy')
     mp.spawn(_adam_overlap_worker, args=(world, port, out), nprocs=world, join=True)
     assert np.load(out)[0] == 1
+
+
+def test_default_assemble_mode():
+    """`torchrun ... test_dice --skip_real --normalize_intensity` (assemble=None) must run: the default of world > 1 is 'slab' only when
+    nothing needs the whole volume on one rank (the sharded run itself: tests/test_gpu_dist.py)."""
+    from neuroclear_amd.test_dice import default_assemble
+    assert default_assemble(1) == 'gather' and default_assemble(1, normalize_intensity=True) == 'gather'
+    assert default_assemble(8) == 'slab'
+    assert default_assemble(8, normalize_intensity=True) == 'reduce' and default_assemble(2, with_real=True) == 'reduce'
