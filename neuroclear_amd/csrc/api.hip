@@ -90,11 +90,13 @@ static std::atomic<int> g_s3_fuse{getenv("NC_S3_FUSE") ? atoi(getenv("NC_S3_FUSE
 static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
+  if (g_split && p2d_fwd_supported(d)) return 10;
   return (c1k3_fwd_supported(d) || mfma_fwd_supported(d)) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_dgrad_supported(d)) return 9;
+  if (g_split && p2d_dgrad_supported(d)) return 10;
   return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
                                                                                               : pg1_on(d)             ? 8
                                                                                               : sconv_on(d, 1)        ? 7
@@ -196,6 +198,10 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     const size_t sc = pg1_ws_bytes(d);
     if (sc > b) b = sc;
   }
+  if (g_split) {
+    const size_t sc = p2d_ws_bytes(d);
+    if (sc > b) b = sc;
+  }
   if (g_split && (s3_fwd_supported(d) || s3_dgrad_supported(d))) {
     const size_t sc = s3_ws_bytes(d);
     if (sc > b) b = sc;
@@ -229,6 +235,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   const int path = fwd_path(d);
   ProfScope ps(0, path, d, 0, s);
   if (path == 9) return conv_fwd_s3(x, nullptr, w, bias, y, d, ws, ws_bytes, s);
+  if (path == 10) return conv_fwd_p2d(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && c1k3_fwd_supported(d)) return conv_fwd_c1k3(x, w, bias, y, d, s);  // 1 -> K channels, 3^3: its own fp32 MFMA kernel
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
@@ -247,6 +254,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   const int path = dgrad_path(d);
   ProfScope ps(1, path, d, 0, s);
   if (path == 9) return conv_dgrad_s3(dy, nullptr, w, dx, d, ws, ws_bytes, s);
+  if (path == 10) return conv_dgrad_p2d(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);

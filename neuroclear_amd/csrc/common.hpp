@@ -124,6 +124,12 @@ int conv_wgrad_gemm(const float* x, const float* dy, float* dw, const ConvDims& 
 bool sconv_fwd_supported(const ConvDims& d);
 bool sconv_dgrad_supported(const ConvDims& d);
 size_t sconv_ws_bytes(const ConvDims& d);
+// conv_p2d.hip: the PatchGAN's 4 x 4 stride-1 layer at Athena's batches on the split-operand arithmetic (forward, data gradient)
+bool p2d_fwd_supported(const ConvDims& d);
+bool p2d_dgrad_supported(const ConvDims& d);
+size_t p2d_ws_bytes(const ConvDims& d);
+int conv_fwd_p2d(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+int conv_dgrad_p2d(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 void sconv_set_cfg(int cfg);
