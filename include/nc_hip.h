@@ -416,6 +416,12 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
 /* ConvTranspose3d(kernel 2, stride 2) forward -- nn.ConvTranspose3d at networks.py:471-478 -- on the same arithmetic (csrc/convt_s3.hip):
  * C % 32 == 0 (<= 256), K % 16 == 0.  xs: the input in S3 form, or NULL (x is converted into the workspace); y (nullable): fp32 output
  * [N][K][2D][2H][2W]; ys (nullable): channels [ys_c0, ys_c0 + K) of a ys_ctot-channel S3 tensor of the output volume.  At least one of y / ys. */
+/* Conv2d 4 x 4, stride 1, padding 1 of the PatchGAN (networks.py:1049-1055) at batches of >= 8192 output pixels on the same arithmetic
+ * (csrc/conv_p2d.hip; forward and data gradient; channels % 64 == 0): 1 when nc_conv_fwd (what 0) / nc_conv_dgrad (what 1) -- and with them
+ * nc_patchgan_fwd / _bwd -- take it for this call under the current switches (nc_set_conv_split; NC_P2D=0 at load time: never).  Smaller
+ * batches and the stride-2 layers run on the image-staged fp32 MFMA kernels (conv2d_img.hip) or the gather GEMM. */
+int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad);
+
 int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K);
 int nc_convT_k2s2_split_active(int N, int C, int D, int H, int W, int K); /* supported AND nc_get_conv_split(): what the whole-network calls do */
 size_t nc_convT_k2s2_split_ws_bytes(int N, int C, int D, int H, int W, int K);

@@ -154,6 +154,12 @@ void nc_set_conv_split(int on) { g_split = on; }
 void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
 
+int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad) {
+  ConvDims d;
+  if (!make_dims(d, N, C, 1, H, W, K, 1, k, k, stride, pad) || g_force_direct || !g_split) return 0;
+  return what == 0 ? (p2d_fwd_supported(d) ? 1 : 0) : what == 1 ? (p2d_dgrad_supported(d) ? 1 : 0) : 0;
+}
+
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
   ConvDims d;
   const int e = (kd == 1 && kh == 1 && kw == 1) ? 256 : 32;  // pointwise: a plane large enough for the flat kernel

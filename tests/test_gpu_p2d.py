@@ -1,0 +1,97 @@
+"""GPU parity of the split-operand PatchGAN kernel k_conv_p2d (csrc/conv_p2d.hip): Conv2d 4 x 4, stride 1, padding 1 -- the 256 -> 512 layer of
+NLayerDiscriminator (models/networks.py:1049-1055) -- forward and data gradient at Athena's batches, fp32 operands as exact three-term bf16
+sums, six bf16 MFMA products per fp32 product.  Criteria of tests/test_gpu_split.py: against an fp64 convolution the error must be no worse
+than 1.3 x rms / 2 x max of the fp32 MFMA kernel's own (the image-staged k_sconv, reached with ops.set_conv_split(False)); plus determinism,
+ragged planes / partial last tiles / several output-channel tiles, the bias, the batch threshold, and non-finite inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def L():
+    from neuroclear_amd._lib import lib
+    return lib()
+
+
+CASES = [  # B, C, K, H, W
+    (216, 256, 512, 13, 13),   # the layer at Athena's discriminator-loss batch (real + fake planes of a 108^3 cube)
+    (108, 256, 512, 13, 13),   # ... at its generator-loss batch
+    (70, 128, 64, 17, 12),     # ragged plane, one output-channel tile, 12,320 positions = 24.06 tiles of 512
+    (33, 64, 192, 19, 21),     # three output-channel tiles, planes larger than a tile
+    (300, 64, 64, 7, 8),       # tiny planes: a tile spans ten of them
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_p2d_against_fp64(case):
+    from neuroclear_amd import ops
+    B, C, K, H, W = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, 4, 4, device=DEV, generator=g) * 0.02
+    b = torch.randn(K, device=DEV, generator=g)
+    assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, 1, 1) == 1 and L().nc_conv2d_split_active(1, B, C, H, W, K, 4, 1, 1) == 1
+    ys = ops.conv_fwd_raw(x, w, b, 1, 1)
+    dy = torch.randn(ys.shape, device=DEV, generator=g)
+    ds = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+    for _ in range(2):  # run to run: bit for bit
+        assert torch.equal(ys, ops.conv_fwd_raw(x, w, b, 1, 1)) and torch.equal(ds, ops.conv_dgrad_raw(dy, w, x.shape, 1, 1))
+    prev = ops.set_conv_split(False)
+    try:
+        assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, 1, 1) == 0
+        y32 = ops.conv_fwd_raw(x, w, b, 1, 1)
+        d32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+    finally:
+        ops.set_conv_split(prev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+
+    def err(y, r):
+        s = r.pow(2).mean().sqrt().item()
+        e = y.double() - r
+        return e.abs().max().item() / s, e.pow(2).mean().sqrt().item() / s
+    for name, got, got32, r in (('fwd', ys, y32, ref), ('dgrad', ds, d32, refd)):
+        m32, r32 = err(got32, r)
+        ms, rs = err(got, r)
+        print(case, name, 'fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+        assert rs <= 1.3 * r32 + 2e-8 and rs < 4e-7, (name, rs, r32)
+        assert ms <= 2.0 * m32 + 2e-7, (name, ms, m32)
+
+
+def test_p2d_threshold_and_scope():
+    """Small batches (Apollo's 1-4 planes per discriminator), the stride-2 layers and other kernel sizes stay where they were."""
+    q = L().nc_conv2d_split_active
+    assert q(0, 216, 256, 13, 13, 512, 4, 1, 1) == 1
+    assert q(0, 4, 256, 13, 13, 512, 4, 1, 1) == 0          # 576 positions
+    assert q(0, 216, 128, 27, 27, 256, 4, 2, 1) == 0        # stride 2: k_sconv
+    assert q(0, 216, 256, 13, 13, 512, 3, 1, 1) == 0
+    assert q(0, 216, 48, 13, 13, 512, 4, 1, 1) == 0 and q(1, 216, 256, 13, 13, 96, 4, 1, 1) == 0   # channels % 64
+
+
+def test_p2d_nonfinite_inputs_follow_the_split_rule():
+    """An inf / NaN input element makes every output it touches NaN and leaves every other output bit-identical (the propagation rule of
+    the split-operand kernels, tests/test_gpu_split.py); a value beyond the largest finite bf16 still splits exactly."""
+    from neuroclear_amd import ops
+    B, C, K, H, W = 80, 64, 64, 13, 13
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, 4, 4, device=DEV, generator=g) * 0.02
+    y = ops.conv_fwd_raw(x, w, None, 1, 1)
+    x2 = x.clone()
+    x2[5, 7, 6, 6] = float('inf')
+    x2[40, 3, 0, 12] = float('nan')
+    y2 = ops.conv_fwd_raw(x2, w, None, 1, 1)
+    touched = torch.zeros_like(y, dtype=torch.bool)
+    # output (y, x) reads input rows y - 1 .. y + 2: input row i is touched by outputs i - 2 .. i + 1 (inside the 12 x 12 output plane)
+    touched[5, :, 4:8, 4:8] = True      # input (6, 6)
+    touched[40, :, 0:2, 10:12] = True   # input (0, 12): rows 0..1, columns 10..11
+    assert bool(torch.isnan(y2[touched]).all()) and torch.equal(y2[~touched], y[~touched])
+    x3 = x.clone()
+    x3[9, 1, 2, 2] = 3.39e38  # finite, above the largest finite bf16
+    y3 = ops.conv_fwd_raw(x3, w, None, 1, 1)
+    ref = F.conv2d(x3.double(), w.double(), padding=1)
+    assert bool(torch.isfinite(y3).all()) and float((y3.double() - ref).abs().max() / ref.abs().max()) < 1e-6
