@@ -416,10 +416,12 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
 /* ConvTranspose3d(kernel 2, stride 2) forward -- nn.ConvTranspose3d at networks.py:471-478 -- on the same arithmetic (csrc/convt_s3.hip):
  * C % 32 == 0 (<= 256), K % 16 == 0.  xs: the input in S3 form, or NULL (x is converted into the workspace); y (nullable): fp32 output
  * [N][K][2D][2H][2W]; ys (nullable): channels [ys_c0, ys_c0 + K) of a ys_ctot-channel S3 tensor of the output volume.  At least one of y / ys. */
-/* Conv2d 4 x 4, stride 1, padding 1 of the PatchGAN (networks.py:1049-1055) at batches of >= 8192 output pixels on the same arithmetic
- * (csrc/conv_p2d.hip; forward and data gradient; channels % 64 == 0): 1 when nc_conv_fwd (what 0) / nc_conv_dgrad (what 1) -- and with them
- * nc_patchgan_fwd / _bwd -- take it for this call under the current switches (nc_set_conv_split; NC_P2D=0 at load time: never).  Smaller
- * batches and the stride-2 layers run on the image-staged fp32 MFMA kernels (conv2d_img.hip) or the gather GEMM. */
+/* Conv2d 4 x 4, padding 1, stride 1 or 2 of the PatchGAN (networks.py:1037-1055: the 64 -> 128, 128 -> 256 and 256 -> 512 layers) at batches of
+ * >= 8192 output pixels on the same arithmetic (csrc/conv_p2d.hip; forward and data gradient; channels % 64 == 0 on the written side, % 16 /
+ * % 64 on the read side): 1 when nc_conv_fwd (what 0) / nc_conv_dgrad (what 1) -- and with them nc_patchgan_fwd / _bwd -- take it for this call
+ * under the current switches (nc_set_conv_split; NC_P2D at load time: bit 0 the stride-1 layer, bit 1 the stride-2 layers, 0 = never).
+ * Smaller batches, the one-channel first layer and head, and every weight gradient run on the kernels of conv2d_img.hip / patchgan_edge.hip /
+ * the gather GEMM. */
 int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad);
 
 int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K);

@@ -1,17 +1,25 @@
-// fp32 Conv2d 4x4, stride 1, padding 1 -- the PatchGAN's 256 -> 512 layer (models/networks.py:1049-1055; 60 % of a discriminator pass'
-// convolution FLOPs) -- forward and data gradient at Athena's batches (108-216 planes of 13 x 13), on the bf16 matrix cores with the exact
-// three-term operand split of conv_split.hip: the tap-stream kernel of conv_s3x.hip carried over to a FLAT BATCH of small planes.
+// fp32 Conv2d 4 x 4, padding 1, stride 1 and 2 -- the PatchGAN's 256 -> 512, 128 -> 256 and 64 -> 128 layers (models/networks.py:1037-1055;
+// all of a discriminator pass' convolution FLOPs but the one-channel first layer and head) -- forward and data gradient at Athena's batches
+// (108-216 planes of 13^2 .. 54^2), on the bf16 matrix cores with the exact three-term operand split of conv_split.hip: the tap-stream kernel
+// of conv_s3x.hip carried over to a FLAT BATCH of small planes.
 //
-//  * the input is converted once per call into the S3 form of a zero-padded flat batch: [chunk of 8 channels][term][b][Hp][Wp] units
-//    (Hp = H + 2 pad; forward pad 1, data gradient = the same convolution of dy with flipped, channel-transposed weights and pad 2), so a
-//    tap (dy, dx) is the constant offset dy * Wp + dx and a brick is a contiguous range of one chunk: no padding logic in the kernel;
+//  * the input is converted once per call into the S3 form of a zero-padded flat batch: [brick][term][(sub-brick)][b][Hp][Wp] units, so a
+//    tap is a constant unit offset and a brick is a contiguous range: no padding logic in the kernel.  Stride 1: Hp = H + 2 pad (forward pad
+//    1; data gradient = the same convolution of dy with flipped, channel-transposed weights and pad 2), brick = one 8-channel chunk, tap
+//    (dy, dx) = offset dy * Wp + dx.  Stride 2 forward: a space-to-depth image of the padded input -- 4 x 4 stride 2 is 2 x 2 stride 1
+//    over 4 parities; brick = (chunk, row parity) with the two column parities as sub-bricks.  Stride 2 data gradient: output parity class
+//    (ry, rx) of dx is a 2 x 2 stride-1 convolution of dy (padded by 1, window base shifted by (ry, rx)) with the taps (3 - 2a - ry,
+//    3 - 2b - rx); brick = two chunks of dy channels as sub-bricks; four launches over ONE converted dy;
 //  * output positions are ONLY the valid ones, f = (b, y < Ho, x < Wo) flattened -- enumerating the padded grid instead would spend 36 % of
 //    the MFMAs on dropped positions at 13 x 13.  A lane keeps the LDS offset of its position in every column block (NCB registers per tile);
-//    a tile's brick spans the 3-4 planes its positions touch;
-//  * the K-dim is one stream of taps (chunk, dy, dx): 16 taps = four k-steps per brick exactly (k-step j of a brick = row dy = j, lane group g =
-//    column dx = g), bricks in a ring of three filled by LDS-DMA, weights streamed into registers one k-step ahead, deferred stores, the
-//    hand-counted waits -- all as in conv_s3x.hip, which see.
-// The weight gradient of these layers stays on k_swgrad (conv2d_img.hip), the stride-2 layers on k_sconv.
+//    a tile's brick spans the planes its positions touch;
+//  * the K-dim is one stream of taps: a brick is 16 taps = four k-steps (stride 1: k-step j = tap row j, lane group g = tap column g) or
+//    8 taps = two k-steps (stride 2: k-step j = sub-brick j, lane group g = tap (g / 2, g % 2)), bricks in a ring of three filled by
+//    LDS-DMA, weights streamed into registers one k-step ahead, deferred stores, the hand-counted waits -- all as in conv_s3x.hip, which see.
+// Measured at 216 planes (tools/p2d_check.py; k_sconv = the image-staged fp32 MFMA kernel of conv2d_img.hip): 256 -> 512 forward 0.66 ms
+// (1.09), data gradient 0.83 (1.49); 128 -> 256 stride 2 0.33 (0.43) / 0.33 (0.46); 64 -> 128 stride 2 0.37 (0.42) / 0.39 (0.48) -- the
+// stride-2 figures include the space-to-depth / padding conversion, a third of their time at 64 channels; error against fp64 2e-7 of the rms
+// (k_sconv: 5e-7 .. 1.5e-6).  Athena step 101.7 -> 87.2 ms.  The weight gradients of these layers stay on k_swgrad.
 #include <cstdlib>
 #include <type_traits>
 
@@ -48,12 +56,16 @@ unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
 __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_split(v, t); }
 
 // Packed weights: [cot = co/64][half = (co/32)%2][k-step s][f = rb*3 + term][lane][8] bf16.  Lane l = (g = l/16, m = l%16) holds
-// output channel cot*64 + half*32 + rb*16 + m at tap T = 4s + g of the tile's tap stream: chunk T / 16, tap T % 16 = (dy, dx) = (T % 16 / 4, g);
-// element j = input channel chunk*8 + (g odd ? (j + 4) % 8 : j)  (the B fragment of an odd lane group is read upper half first).
-// fwd:   w[co][ci][tap]                      (so = C*16, si = 16, flip = 0)
-// dgrad: w[co as "ci"][ci as "co"][15 - tap]   (so = 16, si = C*16, flip = 1)
+// output channel cot*64 + half*32 + rb*16 + m at tap T = 4s + g of the tile's tap stream; element j = input channel chunk*8 + (g odd ?
+// (j + 4) % 8 : j)  (the B fragment of an odd lane group is read upper half first).  (chunk, kernel tap) of stream tap T:
+//   mode 0 (4 x 4, stride 1):        chunk T / 16, tap T % 16 = (dy, dx) = (T % 16 / 4, g)            (flip: 15 - tap, the data gradient)
+//   mode 1 (stride 2 forward, S2D):  brick T / 8 = (chunk, row parity py), sub-brick j = T / 4 % 2 = column parity px, g = (a, b):
+//                                    tap (2a + py, 2b + px)
+//   mode 2 (stride 2 data gradient, output parity class (ry, rx)): brick T / 8 = pair of dy chunks, chunk 2 * brick + j, g = (a, b):
+//                                    tap (3 - 2a - ry, 3 - 2b - rx)  (dx[2u + ry] = sum_a w[.., 3 - 2a - ry] dy[u + ry + a - 1])
+// w element = w[co * so + ci * si + tap]: forward so = C*16, si = 16; data gradients so = 16, si = C*16 (co = the layer's input channel).
 __global__ void __launch_bounds__(256) k_pack_w_p2d(const float* __restrict__ w, unsigned short* __restrict__ wp, int NS, long so, long si,
-                                                    int flip, long total) {
+                                                    int mode, int flip, int ry, int rx, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7);
@@ -66,18 +78,27 @@ __global__ void __launch_bounds__(256) k_pack_w_p2d(const float* __restrict__ w,
   const int rb = f / 3, term = f % 3;
   const int g = lane >> 4, m = lane & 15;
   const int T = 4 * s + g;
-  const int chunk = T >> 4, tap = T & 15;
+  int chunk, tap;
+  if (mode == 0) {
+    chunk = T >> 4; tap = T & 15;
+    if (flip) tap = 15 - tap;
+  } else {
+    const int bi = T >> 3, sub = (T >> 2) & 1, a = g >> 1, b = g & 1;
+    if (mode == 1) { chunk = bi >> 1; tap = (2 * a + (bi & 1)) * 4 + 2 * b + sub; }
+    else { chunk = 2 * bi + sub; tap = (3 - 2 * a - ry) * 4 + (3 - 2 * b - rx); }
+  }
   const int jj = (g & 1) ? ((j + 4) & 7) : j;
   const long co = cot * 64 + half * 32 + rb * 16 + m, ci = chunk * 8 + jj;
   unsigned short t[3];
-  split3(w[co * so + ci * si + (flip ? 15 - tap : tap)], t);
+  split3(w[co * so + ci * si + tap], t);
   wp[i] = t[term];
 }
 
-// fp32 NCHW [B][C][H][W] -> the S3 form of the zero-padded flat batch: unit ((chunk*3 + term) * TOT + b*PP + yp*Wp + xp), PP = Hp*Wp,
-// Hp = H + 2 pad.  One thread per (chunk, padded position): 8 strided loads (coalesced along x), three 16-byte stores.
+// fp32 NCHW [B][C][H][W] -> the S3 form of the zero-padded flat batch, PP = Hp*Wp, Hp = H + 2 pad.  pairs = 0: unit ((chunk*3 + term) *
+// TOT + i), i = b*PP + yp*Wp + xp; pairs = 1 (stride-2 data gradient): bricks of two chunks, unit (((chunk/2)*3 + term)*2 + chunk%2) * TOT + i.
+// One thread per (chunk, padded position): 8 strided loads (coalesced along x), three 16-byte stores.
 __global__ void __launch_bounds__(256) k_pad_split3_2d(const float* __restrict__ x, uint4* __restrict__ xs, int C, int H, int W, int pad, int Hp,
-                                                       int Wp, long TOT, long npos) {
+                                                       int Wp, long TOT, long npos, int pairs) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // b*PP + yp*Wp + xp
   if (i >= npos) return;
   const int chunk = blockIdx.y;
@@ -94,7 +115,33 @@ __global__ void __launch_bounds__(256) k_pad_split3_2d(const float* __restrict__
     s3_split(v, e[j]);
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) xs[((long)chunk * 3 + t) * TOT + i] = s3_unit(e, t);
+  for (int t = 0; t < 3; ++t) {
+    const long u = pairs ? (((long)(chunk >> 1) * 3 + t) * 2 + (chunk & 1)) * TOT + i : ((long)chunk * 3 + t) * TOT + i;
+    xs[u] = s3_unit(e, t);
+  }
+}
+
+// Space-to-depth of the zero-padded (pad 1, extended to even extents) input of a stride-2 layer: parity (py, px) of chunk c is sub-brick px of
+// brick 2c + py, position (yq, xq) of plane b = x_pad[2 yq + py][2 xq + px].  grid.y = chunk*4 + parity.
+__global__ void __launch_bounds__(256) k_s2d_split3(const float* __restrict__ x, uint4* __restrict__ xs, int C, int H, int W, int Hq, int Wq,
+                                                    long TOT, long npos) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // b*PPq + yq*Wq + xq
+  if (i >= npos) return;
+  const int chunk = blockIdx.y >> 2, py = (blockIdx.y >> 1) & 1, px = blockIdx.y & 1;
+  const int PP = Hq * Wq;
+  const int b = (int)(i / PP), r = (int)(i - (long)b * PP);
+  const int yq = r / Wq, xq = r - yq * Wq;
+  const int yy = 2 * yq + py - 1, xx = 2 * xq + px - 1;
+  unsigned short e[8][3];
+  const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+  const float* src = x + (((long)b * C + chunk * 8) * H + (in ? yy : 0)) * W + (in ? xx : 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = in ? src[(long)j * H * W] : 0.f;
+    s3_split(v, e[j]);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) xs[(((long)(chunk * 2 + py) * 3 + t) * 2 + px) * TOT + i] = s3_unit(e, t);
 }
 
 struct PParams {
@@ -102,16 +149,20 @@ struct PParams {
   const uint4* wp;     // packed weights
   const float* bias;   // nullable
   float* y;            // fp32 [B][K][Ho][Wo] output
-  int B, NCH, K;
+  int B, NB, K;        // planes, bricks per tile, output channels
   int Wp, PP;          // padded row pitch, padded plane size Hp * Wp
+  int qbase;           // offset of tap (0, 0) of position (0, 0) inside a plane (the parity classes of a stride-2 data gradient)
+  int UBq;             // M1: units per sub-brick (UB = 2 UBq)
+  long sB, sC, sY, sX, obase;  // output strides (elements) of plane, channel, row, column; offset of position (0, 0)
+  long out_elems;      // size of the whole output
   int Ho, Wo, HoWo;    // valid output plane
   long TOT;            // units per (chunk, term): B * PP (+ slack)
   long npos;           // output positions B * Ho * Wo
   int NPT, KT;         // position tiles, K / 64
   int UB;              // units per term of a brick (multiple of 64)
   int npb;             // 1 KiB pieces per brick (three terms)
-  int NS;              // k-steps per tile = 4 * NCH
-  unsigned mUB, mHoWo, mWo;
+  int NS;              // k-steps per tile: 4 per brick (16 taps), M1: 2 per brick (8 taps)
+  unsigned mUB, mUBq, mHoWo, mWo;
   int t_count, tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
 };
@@ -125,7 +176,7 @@ struct PTile {
 __device__ __forceinline__ unsigned p_q(const PParams& p, unsigned f) {
   const unsigned b = fdiv(f, p.mHoWo), r = f - b * p.HoWo;
   const unsigned yy = fdiv(r, p.mWo), xx = r - yy * p.Wo;
-  return b * p.PP + yy * p.Wp + xx;
+  return b * p.PP + yy * p.Wp + xx + p.qbase;
 }
 
 template <int PT>
@@ -138,15 +189,19 @@ __device__ __forceinline__ PTile p_decode(const PParams& p, int t) {
   return o;
 }
 
-template <int NCB>
+// M1 = false: 4 x 4 taps of ONE padded plane set per brick (k-step j of a brick = tap row j, lane group g = tap column g).
+// M1 = true:  2 x 2 taps over TWO sub-bricks per brick (k-step j of a brick = sub-brick j, lane group g = tap (g / 2, g % 2)): the stride-2
+//             layers -- forward over a space-to-depth image (sub-bricks = the two column parities of one row parity of a chunk), data
+//             gradient per output-parity class over dy (sub-bricks = two consecutive chunks of dy channels).
+template <int NCB, bool M1>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-  constexpr int T2 = 16, PT = 64 * NCB;
+  constexpr int T2 = M1 ? 8 : 16, PT = 64 * NCB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
   const int half = wave & 1, pg = wave >> 1;
-  const int NB = p.NCH;          // bricks per tile: one per 8-channel chunk (16 taps = four k-steps)
+  const int NB = p.NB;           // bricks per tile
   const int BB = p.npb * 1024;   // bytes per ring slot
 
   const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -168,16 +223,19 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   constexpr unsigned kOut = 0x80000000u;
   auto issue_brick = [&](const PTile& t, int bi, int slot) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
-    const uint4* blk = p.xs + (long)bi * 3 * p.TOT;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(3 * p.TOT * 16), 0x00020000);
+    constexpr int NSUB = M1 ? 2 : 1;
+    const uint4* blk = p.xs + (long)bi * 3 * NSUB * p.TOT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(3 * NSUB * p.TOT * 16), 0x00020000);
     unsigned char* buf = lds_raw + slot * BB;
 #pragma unroll 1
     for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
       const unsigned u = (unsigned)(pc * 64 + lane);
       const unsigned term = fdiv(u, p.mUB);
-      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
+      unsigned within = u - term * p.UB, sub = 0;
+      if (M1) { sub = fdiv(within, p.mUBq); within -= sub * p.UBq; }
+      const unsigned F = (unsigned)t.q0 + within;
       const bool ok = term < 3u && (long)F < p.TOT;
-      const unsigned po = ok ? (unsigned)(term * (unsigned)p.TOT + F) * 16u : kOut;
+      const unsigned po = ok ? (unsigned)((term * NSUB + sub) * (unsigned)p.TOT + F) * 16u : kOut;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, 0, 0, 0);
     }
   };
@@ -276,20 +334,21 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   };
   auto store_pairs = [&](const PTile& t, const int p0, const int p1) __attribute__((always_inline)) {  // pairs p0 .. p1 - 1 of tile t from `tot`, then tot = 0
     const int cob = t.cot * 64 + half * 32 + 4 * g;
-    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)((long)p.B * p.K * p.HoWo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)(p.out_elems * 4), 0x00020000);
 #pragma unroll
     for (int pr = 0; pr < kPairs; ++pr) {
       if (pr < p0 || pr >= p1) continue;
       const int rb = pr / NCB, cb = pr % NCB;
       const unsigned f = (unsigned)(t.f0 + pg * NCB * 16 + cb * 16 + m16);
-      const unsigned b = fdiv(f, p.mHoWo), r = f - b * p.HoWo;  // out[((b K + co) Ho + y) Wo + x] = (b K + co) HoWo + r
+      const unsigned b = fdiv(f, p.mHoWo), r = f - b * p.HoWo;
+      const unsigned yy = fdiv(r, p.mWo), xx = r - yy * p.Wo;
       const bool ok = (long)f < p.npos;
-      const unsigned vo0 = ok ? (unsigned)(((long)(b * p.K + cob + rb * 16) * p.HoWo + r) * 4) : kOut;
+      const unsigned vo0 = ok ? (unsigned)((b * p.sB + (cob + rb * 16) * p.sC + yy * p.sY + xx * p.sX + p.obase) * 4) : kOut;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
         const float v = tot[rb][cb][e] + __uint_as_float(bu);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * p.HoWo * 4) : kOut, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * p.sC * 4) : kOut, 0, 0);
         tot[rb][cb][e] = 0.f;
       }
     }
@@ -323,8 +382,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
 
     // per-lane tap state: lane group g is at tap tpl of the brick in slot sl
     int tpl = g, sl = ring;
-    auto b_off = [&]() __attribute__((always_inline)) {  // tap tpl = (dy, dx) = (tpl / 4, tpl % 4) of the brick in slot sl
-      return (unsigned)(sl * BB + ((tpl >> 2) * p.Wp + (tpl & 3)) * 16);
+    auto b_off = [&]() __attribute__((always_inline)) {  // tap tpl of the brick in slot sl
+      if (M1) return (unsigned)(sl * BB + ((tpl >> 2) * p.UBq + ((tpl >> 1) & 1) * p.Wp + (tpl & 1)) * 16);  // sub-brick tpl / 4, tap (a, b)
+      return (unsigned)(sl * BB + ((tpl >> 2) * p.Wp + (tpl & 3)) * 16);                                    // tap (dy, dx) = (tpl / 4, tpl % 4)
     };
     BAddr vo = b_addr(b_off());
     u32x4 B[2][3];
@@ -438,7 +498,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
 }
 
 struct P2Plan {
-  int NCB, NPT, UB, npb, lds;
+  int NCB, NPT, UBq, UB, npb, lds;
   long ntiles;
   bool ok;
 };
@@ -448,11 +508,11 @@ long p2_q(long f, int HoWo, int Wo, int PP, int Wp) {
   return b * PP + (r / Wo) * Wp + r % Wo;
 }
 
-// position tiles of 64 NCB valid outputs; a tile's brick spans from its first position's unit to its last position's last tap
-P2Plan p2_plan(int B, int Ho, int Wo, int PP, int Wp, int KT) {
+// position tiles of 64 NCB valid outputs; a tile's (sub-)brick spans from its first position's unit to its last position's last tap
+// (tapext units further); nsub sub-bricks per brick
+P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, int nsub) {
   P2Plan best{};
   double best_cost = 1e30;
-  const long npos = (long)B * Ho * Wo;
   static const int ncb_max = getenv("NC_P2D_NCB") ? atoi(getenv("NC_P2D_NCB")) : 8;
   for (int NCB : {8, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
@@ -463,93 +523,144 @@ P2Plan p2_plan(int B, int Ho, int Wo, int PP, int Wp, int KT) {
     long umax = 0;
     for (int t = 0; t < pl.NPT; ++t) {
       const long f0 = (long)t * PT, f1 = (f0 + PT - 1 < npos ? f0 + PT - 1 : npos - 1);
-      const long u = p2_q(f1, Ho * Wo, Wo, PP, Wp) - p2_q(f0, Ho * Wo, Wo, PP, Wp) + 3 * Wp + 4;
+      const long u = p2_q(f1, Ho * Wo, Wo, PP, Wp) - p2_q(f0, Ho * Wo, Wo, PP, Wp) + tapext;
       if (u > umax) umax = u;
     }
-    pl.UB = (int)((umax + 63) / 64 * 64);
+    const int align = 64 / nsub;  // the three terms of a brick are whole 1 KiB pieces
+    pl.UBq = (int)((umax + align - 1) / align * align);
+    pl.UB = nsub * pl.UBq;
     pl.npb = 3 * pl.UB / 64;
     pl.lds = 3 * pl.npb * 1024;
     if (pl.npb > kMaxPieces || pl.lds > kLdsMax) continue;
     pl.ntiles = (long)pl.NPT * KT;
     const double rounds = (double)((pl.ntiles + 255) / 256);
-    const double cost = rounds * (PT + 48);  // a tile costs its positions plus a fixed part (prologue, epilogue, the brick's extra planes)
+    // a tile costs its positions plus a fixed part (prologue, epilogue, the brick's extra planes); narrow tiles pay twice the weight loads per MFMA
+    const double cost = rounds * (PT + 48) * (NCB <= 2 ? 1.5 : NCB <= 4 ? 1.15 : 1.0);
     if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
   }
   return best;
 }
 
-template <int NCB>
+template <int NCB, bool M1>
 int launch_p(const PParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_p2d<NCB>;
+  auto kern = k_conv_p2d<NCB, M1>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_p2d")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_p2d");
 }
+template <bool M1>
+int launch_p_ncb(int NCB, const PParams& p, int lds, hipStream_t s) {
+  switch (NCB) {
+    case 8: return launch_p<8, M1>(p, lds, s);
+    case 6: return launch_p<6, M1>(p, lds, s);
+    case 4: return launch_p<4, M1>(p, lds, s);
+    default: return launch_p<2, M1>(p, lds, s);
+  }
+}
 
-size_t p2_packed_bytes(int Cin, int Kout) { return (size_t)(Kout / 64) * 2 * (Cin / 8 * 4) * 6 * 1024; }
+size_t p2_packed_bytes(int NS, int Kout) { return (size_t)(Kout / 64) * 2 * NS * 6 * 1024; }
 size_t p2_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// One problem of the kernel: a valid KT x KT stride-1 convolution over planes of PP = Hp x Wp units, positions (b, y < Ho, x < Wo)
 struct P2Geom {
-  int B, Cin, Hin, Win, pad, Hp, Wp, PP, Ho, Wo, Kout;
+  int kind;        // 0: 4 x 4 stride 1 (forward / data gradient); 1: stride-2 forward over the S2D image; 2: stride-2 data gradient (four classes)
+  int B, Cin, Kout;          // planes, channels read, channels written (of the GEMM)
+  int Hin, Win, pad;         // the tensor that is read, and its zero border (kind 0 / 2)
+  int Hp, Wp, PP;            // plane of units the taps walk over
+  int Ho, Wo;                // valid outputs per plane (kind 2: of the largest class)
+  int NB, NS, tapext, nsub;
   long TOT;
+  size_t xs_bytes;
 };
 P2Geom p2_geom(const ConvDims& d, int dgrad) {
   P2Geom g{};
   g.B = d.N;
-  if (!dgrad) { g.Cin = d.C; g.Kout = d.K; g.Hin = d.H; g.Win = d.W; g.pad = 1; }
-  else { g.Cin = d.K; g.Kout = d.C; g.Hin = d.Ho; g.Win = d.Wo; g.pad = 2; }  // dx = conv(dy padded by k - 1 - p = 2, flipped transposed w)
-  g.Hp = g.Hin + 2 * g.pad; g.Wp = g.Win + 2 * g.pad; g.PP = g.Hp * g.Wp;
-  g.Ho = g.Hp - 3; g.Wo = g.Wp - 3;
+  if (d.sh == 1) {
+    g.kind = 0;
+    if (!dgrad) { g.Cin = d.C; g.Kout = d.K; g.Hin = d.H; g.Win = d.W; g.pad = 1; }
+    else { g.Cin = d.K; g.Kout = d.C; g.Hin = d.Ho; g.Win = d.Wo; g.pad = 2; }  // dx = conv(dy padded by k - 1 - p = 2, flipped transposed w)
+    g.Hp = g.Hin + 2 * g.pad; g.Wp = g.Win + 2 * g.pad;
+    g.Ho = g.Hp - 3; g.Wo = g.Wp - 3;
+    g.NB = g.Cin / 8; g.NS = 4 * g.NB; g.tapext = 3 * g.Wp + 4; g.nsub = 1;
+  } else if (!dgrad) {
+    g.kind = 1;
+    g.Cin = d.C; g.Kout = d.K; g.Hin = d.H; g.Win = d.W; g.pad = 1;
+    g.Hp = (d.H + 3) / 2; g.Wp = (d.W + 3) / 2;  // S2D of the input padded by 1 and extended to even extents
+    g.Ho = d.Ho; g.Wo = d.Wo;
+    g.NB = g.Cin / 8 * 2; g.NS = 2 * g.NB; g.tapext = g.Wp + 2; g.nsub = 2;
+  } else {
+    g.kind = 2;
+    g.Cin = d.K; g.Kout = d.C; g.Hin = d.Ho; g.Win = d.Wo; g.pad = 1;
+    g.Hp = g.Hin + 2; g.Wp = g.Win + 2;
+    g.Ho = (d.H + 1) / 2; g.Wo = (d.W + 1) / 2;  // class (0, 0): the most positions
+    g.NB = g.Cin / 16; g.NS = 2 * g.NB; g.tapext = g.Wp + 2; g.nsub = 2;
+  }
+  g.PP = g.Hp * g.Wp;
   g.TOT = (long)g.B * g.PP + 64;  // (slack: a brick's last piece may reach past the batch by less than a piece)
+  g.xs_bytes = p2_align((size_t)g.NB * 3 * g.nsub * g.TOT * 16);
   return g;
 }
 
 bool p2_shape(const ConvDims& d, int dgrad) {
-  static const bool on = !(getenv("NC_P2D") && atoi(getenv("NC_P2D")) == 0);  // A/B switch: the image-staged fp32 kernels of conv2d_img.hip
-  if (!on) return false;
-  if (d.D != 1 || d.kd != 1 || d.kh != 4 || d.kw != 4 || d.sh != 1 || d.sw != 1 || d.ph != 1 || d.pw != 1) return false;
+  static const int on = getenv("NC_P2D") ? atoi(getenv("NC_P2D")) : 3;  // A/B switch: bit 0 = the stride-1 layer, bit 1 = the stride-2 layers; 0: the image-staged fp32 kernels of conv2d_img.hip
+  if (d.D != 1 || d.kd != 1 || d.kh != 4 || d.kw != 4 || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.ph != 1 || d.pw != 1) return false;
+  if (!(on & (d.sh == 1 ? 1 : 2))) return false;
   const P2Geom g = p2_geom(d, dgrad);
-  if (g.Cin % 64 || g.Kout % 64 || g.Cin < 64) return false;
-  if ((long)g.B * g.Ho * g.Wo < 8192) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
-  if (3 * g.TOT * 16 >= (1l << 31) || (long)g.B * g.Kout * g.Ho * g.Wo * 4 >= (1l << 31)) return false;
-  return p2_plan(g.B, g.Ho, g.Wo, g.PP, g.Wp, g.Kout / 64).ok;
+  if (g.Kout % 64 || g.Cin % (g.kind == 0 ? 64 : 16) || g.NS < 8 || (g.NS & 1)) return false;
+  if ((long)g.B * g.Ho * g.Wo < (g.kind == 2 ? 4096 : 8192)) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
+  if (3 * g.nsub * g.TOT * 16 >= (1l << 31) || (long)d.N * d.K * d.Ho * d.Wo * 4 >= (1l << 31) || (long)d.N * d.C * d.H * d.W * 4 >= (1l << 31)) return false;
+  return p2_plan((long)g.B * g.Ho * g.Wo, g.Ho, g.Wo, g.PP, g.Wp, g.Kout / 64, g.tapext, g.nsub).ok;
 }
 
 int run_p2d(const float* in, const float* w, const float* bias, float* out, const ConvDims& d, int dgrad, void* ws, size_t wsb, hipStream_t s) {
   const P2Geom g = p2_geom(d, dgrad);
-  const P2Plan pl = p2_plan(g.B, g.Ho, g.Wo, g.PP, g.Wp, g.Kout / 64);
-  if (!pl.ok) { set_error("conv_p2d: shape not covered"); return NC_ERR_SHAPE; }
-  const int NCH = g.Cin / 8;
-  const size_t xb = p2_align((size_t)NCH * 3 * g.TOT * 16), wb = p2_align(p2_packed_bytes(g.Cin, g.Kout));
-  if (!ws || wsb < xb + wb + 256) { set_error("conv_p2d: workspace too small"); return NC_ERR_WS; }
+  const size_t wb = p2_align(p2_packed_bytes(g.NS, g.Kout));
+  if (!ws || wsb < g.xs_bytes + wb + 256) { set_error("conv_p2d: workspace too small"); return NC_ERR_WS; }
   uint4* xs = (uint4*)ws;
-  unsigned short* wp = (unsigned short*)((char*)ws + xb);
+  unsigned short* wp = (unsigned short*)((char*)ws + g.xs_bytes);
   const long npad = (long)g.B * g.PP;
-  hipLaunchKernelGGL(k_pad_split3_2d, dim3((unsigned)cdiv(npad, 256), (unsigned)NCH), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.pad, g.Hp, g.Wp,
-                     g.TOT, npad);
-  const int NS = NCH * 4;
-  const long total = (long)(p2_packed_bytes(g.Cin, g.Kout) / 2);
-  // forward: w[co][ci][tap]; data gradient: w[co as ci][ci as co][15 - tap] (ConvDims: weights are [d.K][d.C][4][4])
+  if (g.kind == 1)
+    hipLaunchKernelGGL(k_s2d_split3, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8 * 4)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.Hp, g.Wp, g.TOT, npad);
+  else
+    hipLaunchKernelGGL(k_pad_split3_2d, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.pad, g.Hp, g.Wp,
+                       g.TOT, npad, g.kind == 2 ? 1 : 0);
+  if (int e = check_launch("conv_p2d convert")) return e;
+  const long total = (long)(p2_packed_bytes(g.NS, g.Kout) / 2);
+  // forward: w[co][ci][tap]; data gradients: w[co as ci][ci as co][..] (ConvDims: weights are [d.K][d.C][4][4])
   const long so = dgrad ? 16 : (long)d.C * 16, si = dgrad ? (long)d.C * 16 : 16;
-  hipLaunchKernelGGL(k_pack_w_p2d, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, NS, so, si, dgrad ? 1 : 0, total);
-  if (int e = check_launch("conv_p2d prep")) return e;
-  PParams p{};
-  p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = out;
-  p.B = g.B; p.NCH = NCH; p.K = g.Kout;
-  p.Wp = g.Wp; p.PP = g.PP; p.Ho = g.Ho; p.Wo = g.Wo; p.HoWo = g.Ho * g.Wo;
-  p.TOT = g.TOT; p.npos = (long)g.B * g.Ho * g.Wo;
-  p.NPT = pl.NPT; p.KT = g.Kout / 64;
-  p.UB = pl.UB; p.npb = pl.npb; p.NS = NS;
-  p.mUB = magic(pl.UB); p.mHoWo = magic(p.HoWo); p.mWo = magic(g.Wo);
-  p.t_count = (int)pl.ntiles; p.tiles_per_xcd = (int)cdiv(pl.ntiles, 8);
   static const int flush = getenv("NC_P2D_FLUSH") ? atoi(getenv("NC_P2D_FLUSH")) : 4;
-  p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
-  switch (pl.NCB) {
-    case 8: return launch_p<8>(p, pl.lds, s);
-    case 6: return launch_p<6>(p, pl.lds, s);
-    case 4: return launch_p<4>(p, pl.lds, s);
-    default: return launch_p<2>(p, pl.lds, s);
+  const int nclass = g.kind == 2 ? 4 : 1;
+  for (int cls = 0; cls < nclass; ++cls) {
+    const int ry = cls >> 1, rx = cls & 1;
+    PParams p{};
+    p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = out;
+    p.B = g.B; p.NB = g.NB; p.K = g.Kout; p.NS = g.NS;
+    p.Wp = g.Wp; p.PP = g.PP; p.TOT = g.TOT; p.KT = g.Kout / 64;
+    if (g.kind == 2) {  // dx[b][c][2u + ry][2v + rx], u < ceil((H - ry) / 2)
+      p.Ho = (d.H - ry + 1) / 2; p.Wo = (d.W - rx + 1) / 2;
+      p.qbase = ry * g.Wp + rx;
+      p.sB = (long)d.C * d.H * d.W; p.sC = (long)d.H * d.W; p.sY = 2 * d.W; p.sX = 2; p.obase = (long)ry * d.W + rx;
+      p.out_elems = (long)d.N * d.C * d.H * d.W;
+    } else {
+      p.Ho = g.Ho; p.Wo = g.Wo;
+      p.sB = (long)g.Kout * g.Ho * g.Wo; p.sC = (long)g.Ho * g.Wo; p.sY = g.Wo; p.sX = 1;
+      p.out_elems = (long)g.B * g.Kout * g.Ho * g.Wo;
+    }
+    if (p.Ho < 1 || p.Wo < 1) continue;
+    p.HoWo = p.Ho * p.Wo;
+    p.npos = (long)g.B * p.HoWo;
+    const P2Plan pl = p2_plan(p.npos, p.Ho, p.Wo, g.PP, g.Wp, p.KT, g.tapext, g.nsub);
+    if (!pl.ok) { set_error("conv_p2d: shape not covered"); return NC_ERR_SHAPE; }
+    p.NPT = pl.NPT; p.UB = pl.UB; p.UBq = pl.UBq; p.npb = pl.npb;
+    p.mUB = magic(pl.UB); p.mUBq = magic(pl.UBq); p.mHoWo = magic(p.HoWo); p.mWo = magic(p.Wo);
+    p.t_count = (int)pl.ntiles; p.tiles_per_xcd = (int)cdiv(pl.ntiles, 8);
+    p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
+    hipLaunchKernelGGL(k_pack_w_p2d, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g.NS, so, si, g.kind, g.kind == 0 && dgrad ? 1 : 0, ry, rx, total);
+    if (int e = check_launch("conv_p2d pack")) return e;
+    const int e = g.kind == 0 ? launch_p_ncb<false>(pl.NCB, p, pl.lds, s) : launch_p_ncb<true>(pl.NCB, p, pl.lds, s);
+    if (e) return e;
   }
+  return NC_OK;
 }
 
 }  // namespace
@@ -561,7 +672,7 @@ size_t p2d_ws_bytes(const ConvDims& d) {
   for (int dg = 0; dg < 2; ++dg) {
     if (!p2_shape(d, dg)) continue;
     const P2Geom g = p2_geom(d, dg);
-    const size_t n = p2_align((size_t)(g.Cin / 8) * 3 * g.TOT * 16) + p2_align(p2_packed_bytes(g.Cin, g.Kout)) + 512;
+    const size_t n = g.xs_bytes + p2_align(p2_packed_bytes(g.NS, g.Kout)) + 512;
     if (n > b) b = n;
   }
   return b;

@@ -1,8 +1,9 @@
-"""GPU parity of the split-operand PatchGAN kernel k_conv_p2d (csrc/conv_p2d.hip): Conv2d 4 x 4, stride 1, padding 1 -- the 256 -> 512 layer of
-NLayerDiscriminator (models/networks.py:1049-1055) -- forward and data gradient at Athena's batches, fp32 operands as exact three-term bf16
-sums, six bf16 MFMA products per fp32 product.  Criteria of tests/test_gpu_split.py: against an fp64 convolution the error must be no worse
-than 1.3 x rms / 2 x max of the fp32 MFMA kernel's own (the image-staged k_sconv, reached with ops.set_conv_split(False)); plus determinism,
-ragged planes / partial last tiles / several output-channel tiles, the bias, the batch threshold, and non-finite inputs."""
+"""GPU parity of the split-operand PatchGAN kernels k_conv_p2d (csrc/conv_p2d.hip): Conv2d 4 x 4, padding 1, stride 1 (the 256 -> 512 layer of
+NLayerDiscriminator, models/networks.py:1049-1055) and stride 2 (the 64 -> 128 and 128 -> 256 layers, :1037-1046; forward over a
+space-to-depth image, data gradient as four output-parity classes) -- forward and data gradient at Athena's batches, fp32 operands as exact
+three-term bf16 sums, six bf16 MFMA products per fp32 product.  Criteria of tests/test_gpu_split.py: against an fp64 convolution the error
+must be no worse than 1.3 x rms / 2 x max of the fp32 MFMA kernel's own (the image-staged k_sconv, reached with ops.set_conv_split(False));
+plus determinism, ragged / odd planes, partial last tiles, several output-channel tiles, the bias, the batch threshold, non-finite inputs."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,38 +18,42 @@ def L():
     return lib()
 
 
-CASES = [  # B, C, K, H, W
-    (216, 256, 512, 13, 13),   # the layer at Athena's discriminator-loss batch (real + fake planes of a 108^3 cube)
-    (108, 256, 512, 13, 13),   # ... at its generator-loss batch
-    (70, 128, 64, 17, 12),     # ragged plane, one output-channel tile, 12,320 positions = 24.06 tiles of 512
-    (33, 64, 192, 19, 21),     # three output-channel tiles, planes larger than a tile
-    (300, 64, 64, 7, 8),       # tiny planes: a tile spans ten of them
+CASES = [  # B, C, K, H, W, stride
+    (216, 256, 512, 13, 13, 1),   # the stride-1 layer at Athena's discriminator-loss batch (real + fake planes of a 108^3 cube)
+    (108, 256, 512, 13, 13, 1),   # ... at its generator-loss batch
+    (70, 128, 64, 17, 12, 1),     # ragged plane, one output-channel tile, 12,320 positions = 24.06 tiles of 512
+    (33, 64, 192, 19, 21, 1),     # three output-channel tiles, planes larger than a tile
+    (300, 64, 64, 7, 8, 1),       # tiny planes: a tile spans ten of them
+    (216, 64, 128, 54, 54, 2),    # the stride-2 layers at Athena's batches: even planes (28 x 28 space-to-depth) ...
+    (108, 128, 256, 27, 27, 2),   # ... and odd ones (the padded plane is extended to 30 x 30; the parity classes of the data gradient differ in size)
+    (90, 64, 64, 21, 30, 2),      # odd x even
+    (128, 128, 128, 19, 17, 2),
 ]
 
 
 @pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
 def test_p2d_against_fp64(case):
     from neuroclear_amd import ops
-    B, C, K, H, W = case
+    B, C, K, H, W, st = case
     g = torch.Generator(device=DEV).manual_seed(11)
     x = torch.randn(B, C, H, W, device=DEV, generator=g)
     w = torch.randn(K, C, 4, 4, device=DEV, generator=g) * 0.02
     b = torch.randn(K, device=DEV, generator=g)
-    assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, 1, 1) == 1 and L().nc_conv2d_split_active(1, B, C, H, W, K, 4, 1, 1) == 1
-    ys = ops.conv_fwd_raw(x, w, b, 1, 1)
+    assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, st, 1) == 1 and L().nc_conv2d_split_active(1, B, C, H, W, K, 4, st, 1) == 1
+    ys = ops.conv_fwd_raw(x, w, b, st, 1)
     dy = torch.randn(ys.shape, device=DEV, generator=g)
-    ds = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+    ds = ops.conv_dgrad_raw(dy, w, x.shape, st, 1)
     for _ in range(2):  # run to run: bit for bit
-        assert torch.equal(ys, ops.conv_fwd_raw(x, w, b, 1, 1)) and torch.equal(ds, ops.conv_dgrad_raw(dy, w, x.shape, 1, 1))
+        assert torch.equal(ys, ops.conv_fwd_raw(x, w, b, st, 1)) and torch.equal(ds, ops.conv_dgrad_raw(dy, w, x.shape, st, 1))
     prev = ops.set_conv_split(False)
     try:
-        assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, 1, 1) == 0
-        y32 = ops.conv_fwd_raw(x, w, b, 1, 1)
-        d32 = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+        assert L().nc_conv2d_split_active(0, B, C, H, W, K, 4, st, 1) == 0
+        y32 = ops.conv_fwd_raw(x, w, b, st, 1)
+        d32 = ops.conv_dgrad_raw(dy, w, x.shape, st, 1)
     finally:
         ops.set_conv_split(prev)
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
-    refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=1)
+    refd = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride=st, padding=1)
 
     def err(y, r):
         s = r.pow(2).mean().sqrt().item()
@@ -63,11 +68,15 @@ def test_p2d_against_fp64(case):
 
 
 def test_p2d_threshold_and_scope():
-    """Small batches (Apollo's 1-4 planes per discriminator), the stride-2 layers and other kernel sizes stay where they were."""
+    """Small batches (Apollo's 1-4 planes per discriminator), the one-channel first layer, the one-channel head and other kernel sizes stay
+    where they were."""
     q = L().nc_conv2d_split_active
-    assert q(0, 216, 256, 13, 13, 512, 4, 1, 1) == 1
+    assert q(0, 216, 256, 13, 13, 512, 4, 1, 1) == 1 and q(1, 216, 256, 13, 13, 512, 4, 1, 1) == 1
+    assert q(0, 216, 128, 27, 27, 256, 4, 2, 1) == 1 and q(1, 216, 64, 54, 54, 128, 4, 2, 1) == 1
     assert q(0, 4, 256, 13, 13, 512, 4, 1, 1) == 0          # 576 positions
-    assert q(0, 216, 128, 27, 27, 256, 4, 2, 1) == 0        # stride 2: k_sconv
+    assert q(0, 4, 64, 54, 54, 128, 4, 2, 1) == 0
+    assert q(0, 216, 1, 108, 108, 64, 4, 2, 1) == 0         # the first layer: k_pg1
+    assert q(0, 216, 512, 12, 12, 1, 4, 1, 1) == 0          # the head
     assert q(0, 216, 256, 13, 13, 512, 3, 1, 1) == 0
     assert q(0, 216, 48, 13, 13, 512, 4, 1, 1) == 0 and q(1, 216, 256, 13, 13, 96, 4, 1, 1) == 0   # channels % 64
 
