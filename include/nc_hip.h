@@ -418,10 +418,11 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
  * [N][K][2D][2H][2W]; ys (nullable): channels [ys_c0, ys_c0 + K) of a ys_ctot-channel S3 tensor of the output volume.  At least one of y / ys. */
 /* Conv2d 4 x 4, padding 1, stride 1 or 2 of the PatchGAN (networks.py:1037-1055: the 64 -> 128, 128 -> 256 and 256 -> 512 layers) at batches of
  * >= 8192 output pixels on the same arithmetic (csrc/conv_p2d.hip; forward and data gradient; channels % 64 == 0 on the written side, % 16 /
- * % 64 on the read side): 1 when nc_conv_fwd (what 0) / nc_conv_dgrad (what 1) -- and with them nc_patchgan_fwd / _bwd -- take it for this call
- * under the current switches (nc_set_conv_split; NC_P2D at load time: bit 0 the stride-1 layer, bit 1 the stride-2 layers, 0 = never).
- * Smaller batches, the one-channel first layer and head, and every weight gradient run on the kernels of conv2d_img.hip / patchgan_edge.hip /
- * the gather GEMM. */
+ * % 64 on the read side) and the stride-1 layer's weight gradient (csrc/wgrad_p2d.hip; C % 32 == 0, K % 64 == 0): 1 when nc_conv_fwd (what 0) /
+ * nc_conv_dgrad (what 1) / nc_conv_wgrad (what 2) -- and with them nc_patchgan_fwd / _bwd -- take it for this call under the current switches
+ * (nc_set_conv_split; NC_P2D at load time: bit 0 the stride-1 layer forward / data gradient, bit 1 the stride-2 layers, bit 2 the stride-1 weight
+ * gradient, 0 = never).  Smaller batches, the one-channel first layer and head, and the stride-2 weight gradients run on the kernels of
+ * conv2d_img.hip / patchgan_edge.hip / the gather GEMM. */
 int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad);
 
 int nc_convT_k2s2_split_supported(int N, int C, int D, int H, int W, int K);

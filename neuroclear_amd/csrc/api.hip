@@ -110,6 +110,7 @@ static bool sconv_wgrad_on(const ConvDims& d) {
 static int wgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_wgrad_supported(d)) return 9;
+  if (g_split && p2d_wgrad_supported(d)) return 10;
   return mfma_wgrad_supported(d) ? 1 : wgrad_1x1_supported(d) ? 3 : c1_wgrad_supported(d) ? 4 : k1_wgrad_supported(d) ? 5
                                                                                             : pg1_on(d)              ? 8
                                                                                             : sconv_wgrad_on(d)      ? 7
@@ -157,7 +158,7 @@ int nc_get_conv_split(void) { return g_split; }
 int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad) {
   ConvDims d;
   if (!make_dims(d, N, C, 1, H, W, K, 1, k, k, stride, pad) || g_force_direct || !g_split) return 0;
-  return what == 0 ? (p2d_fwd_supported(d) ? 1 : 0) : what == 1 ? (p2d_dgrad_supported(d) ? 1 : 0) : 0;
+  return what == 0 ? (p2d_fwd_supported(d) ? 1 : 0) : what == 1 ? (p2d_dgrad_supported(d) ? 1 : 0) : what == 2 ? (p2d_wgrad_supported(d) ? 1 : 0) : 0;
 }
 
 int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) {
@@ -205,7 +206,9 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     if (sc > b) b = sc;
   }
   if (g_split) {
-    const size_t sc = p2d_ws_bytes(d);
+    size_t sc = p2d_ws_bytes(d);
+    if (sc > b) b = sc;
+    sc = p2d_wgrad_ws_bytes(d);
     if (sc > b) b = sc;
   }
   if (g_split && (s3_fwd_supported(d) || s3_dgrad_supported(d))) {
@@ -346,6 +349,7 @@ int nc_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int 
   const int path = wgrad_path(d);
   ProfScope ps(2, path, d, 0, s);
   if (path == 9) e = conv_wgrad_s3(x, nullptr, dy, nullptr, dw, d, ws, ws_bytes, s);
+  else if (path == 10) e = conv_wgrad_p2d(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && mfma_wgrad_supported(d)) e = conv_wgrad_mfma(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && wgrad_1x1_supported(d)) e = conv_wgrad_1x1(x, dy, dw, d, ws, ws_bytes, s);
   else if (!g_force_direct && c1_wgrad_supported(d)) e = conv_wgrad_c1(x, dy, dw, d, ws, ws_bytes, s);

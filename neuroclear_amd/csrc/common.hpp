@@ -130,6 +130,10 @@ bool p2d_dgrad_supported(const ConvDims& d);
 size_t p2d_ws_bytes(const ConvDims& d);
 int conv_fwd_p2d(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_p2d(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+// wgrad_p2d.hip: the weight gradient of the stride-1 layer on the same arithmetic
+bool p2d_wgrad_supported(const ConvDims& d);
+size_t p2d_wgrad_ws_bytes(const ConvDims& d);
+int conv_wgrad_p2d(const float* x, const float* dy, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_fwd_sconv(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_sconv(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 void sconv_set_cfg(int cfg);

@@ -602,7 +602,7 @@ P2Geom p2_geom(const ConvDims& d, int dgrad) {
 }
 
 bool p2_shape(const ConvDims& d, int dgrad) {
-  static const int on = getenv("NC_P2D") ? atoi(getenv("NC_P2D")) : 3;  // A/B switch: bit 0 = the stride-1 layer, bit 1 = the stride-2 layers; 0: the image-staged fp32 kernels of conv2d_img.hip
+  static const int on = getenv("NC_P2D") ? atoi(getenv("NC_P2D")) : 7;  // A/B switch: bit 0 = the stride-1 layer, bit 1 = the stride-2 layers; 0: the image-staged fp32 kernels of conv2d_img.hip
   if (d.D != 1 || d.kd != 1 || d.kh != 4 || d.kw != 4 || d.sh != d.sw || (d.sh != 1 && d.sh != 2) || d.ph != 1 || d.pw != 1) return false;
   if (!(on & (d.sh == 1 ? 1 : 2))) return false;
   const P2Geom g = p2_geom(d, dgrad);

@@ -3,7 +3,8 @@ NLayerDiscriminator, models/networks.py:1049-1055) and stride 2 (the 64 -> 128 a
 space-to-depth image, data gradient as four output-parity classes) -- forward and data gradient at Athena's batches, fp32 operands as exact
 three-term bf16 sums, six bf16 MFMA products per fp32 product.  Criteria of tests/test_gpu_split.py: against an fp64 convolution the error
 must be no worse than 1.3 x rms / 2 x max of the fp32 MFMA kernel's own (the image-staged k_sconv, reached with ops.set_conv_split(False));
-plus determinism, ragged / odd planes, partial last tiles, several output-channel tiles, the bias, the batch threshold, non-finite inputs."""
+plus determinism, ragged / odd planes, partial last tiles, several output-channel tiles, the bias, the batch threshold, non-finite inputs.
+The stride-1 layer's weight gradient (k_wgrad_p2d, csrc/wgrad_p2d.hip) is held to the same criteria against k_swgrad."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -65,6 +66,69 @@ def test_p2d_against_fp64(case):
         print(case, name, 'fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
         assert rs <= 1.3 * r32 + 2e-8 and rs < 4e-7, (name, rs, r32)
         assert ms <= 2.0 * m32 + 2e-7, (name, ms, m32)
+
+
+WCASES = [  # B, C, K, H, W (stride 1)
+    (216, 256, 512, 13, 13),   # the 256 -> 512 layer at Athena's discriminator-loss batch: 64 (k, c) pairs x 4 workgroups, 44 tiles of 5 planes
+    (108, 256, 512, 13, 13),
+    (70, 128, 64, 17, 12),     # ragged plane; 4 pairs x 64 workgroups: a workgroup's share starts in the middle of a tile
+    (33, 64, 192, 19, 21),     # 33 planes: the last tile is partly beyond the batch (zero planes of the converted tensors)
+    (300, 64, 64, 7, 8),       # tiny planes
+    (128, 32, 64, 13, 13),     # one c-tile
+    (16, 32, 128, 40, 41),     # rows longer than a k-step
+]
+
+
+@pytest.mark.parametrize('case', WCASES, ids=[str(c) for c in WCASES])
+def test_p2d_wgrad_against_fp64(case):
+    from neuroclear_amd import ops
+    B, C, K, H, W = case
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    dy = torch.randn(B, K, H - 1, W - 1, device=DEV, generator=g)
+    assert L().nc_conv2d_split_active(2, B, C, H, W, K, 4, 1, 1) == 1
+    dw, db = ops.conv_wgrad_raw(x, dy, (K, C, 4, 4), 1, 1, True)
+    for _ in range(2):
+        assert torch.equal(dw, ops.conv_wgrad_raw(x, dy, (K, C, 4, 4), 1, 1, False)[0])
+    prev = ops.set_conv_split(False)
+    try:
+        assert L().nc_conv2d_split_active(2, B, C, H, W, K, 4, 1, 1) == 0
+        dw32 = ops.conv_wgrad_raw(x, dy, (K, C, 4, 4), 1, 1, False)[0]
+    finally:
+        ops.set_conv_split(prev)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (K, C, 4, 4), dy.double(), stride=1, padding=1)
+
+    def err(y, r):
+        s = r.pow(2).mean().sqrt().item()
+        e = y.double() - r
+        return e.abs().max().item() / s, e.pow(2).mean().sqrt().item() / s
+    m32, r32 = err(dw32, ref)
+    ms, rs = err(dw, ref)
+    print(case, 'wgrad fp32 max %.2e rms %.2e | split max %.2e rms %.2e' % (m32, r32, ms, rs))
+    assert rs <= 1.3 * r32 + 2e-8 and ms <= 2.0 * m32 + 2e-7, (ms, rs, m32, r32)
+    assert torch.allclose(db, dy.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_p2d_wgrad_zero_dy_planes_and_scope():
+    """Planes whose dy is zero contribute nothing, whatever the input holds there (finite); the stride-2 layers, small batches and other
+    channel counts stay on k_swgrad."""
+    from neuroclear_amd import ops
+    B, C, K, H, W = 96, 64, 64, 13, 13
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    dy = torch.randn(B, K, H - 1, W - 1, device=DEV, generator=g)
+    dy[40:] = 0
+    x2 = x.clone()
+    x2[40:] = 1e30
+    a = ops.conv_wgrad_raw(x, dy, (K, C, 4, 4), 1, 1, False)[0]
+    b = ops.conv_wgrad_raw(x2, dy, (K, C, 4, 4), 1, 1, False)[0]
+    assert torch.equal(a, b)
+    ref = torch.nn.grad.conv2d_weight(x[:40].double(), (K, C, 4, 4), dy[:40].double(), stride=1, padding=1)
+    assert float((a.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    q = L().nc_conv2d_split_active
+    assert q(2, 216, 256, 13, 13, 512, 4, 1, 1) == 1
+    assert q(2, 216, 128, 27, 27, 256, 4, 2, 1) == 0 and q(2, 4, 256, 13, 13, 512, 4, 1, 1) == 0
+    assert q(2, 216, 48, 13, 13, 512, 4, 1, 1) == 0 and q(2, 216, 256, 13, 13, 96, 4, 1, 1) == 0
 
 
 def test_p2d_threshold_and_scope():

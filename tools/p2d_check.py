@@ -52,3 +52,15 @@ for B, C, K, H, W, st in ((216, 256, 512, 13, 13, 1), (108, 256, 512, 13, 13, 1)
     ops.set_conv_split(True)
     print('      fwd %.3f ms %.0f TF (k_sconv %.3f ms %.0f TF) | dgrad %.3f ms %.0f TF (k_sconv %.3f ms %.0f TF)' % (
         ts[0], fl / ts[0] / 1e9, t0[0], fl / t0[0] / 1e9, ts[1], fl / ts[1] / 1e9, t0[1], fl / t0[1] / 1e9), flush=True)
+    # weight gradient (csrc/wgrad_p2d.hip where it applies; k_swgrad otherwise and with the split kernels off)
+    act = L.nc_conv2d_split_active(2, B, C, H, W, K, 4, st, 1)
+    dw, _ = ops.conv_wgrad_raw(x, dy, w.shape, st, 1, False)
+    dw2, _ = ops.conv_wgrad_raw(x, dy, w.shape, st, 1, False)
+    ops.set_conv_split(False)
+    dw0, _ = ops.conv_wgrad_raw(x, dy, w.shape, st, 1, False)
+    tw0 = timeit(lambda: ops.conv_wgrad_raw(x, dy, w.shape, st, 1, False))
+    ops.set_conv_split(True)
+    tw = timeit(lambda: ops.conv_wgrad_raw(x, dy, w.shape, st, 1, False))
+    dwr = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=st, padding=1)
+    print('      wgrad split-active %d err %.2e/%.2e  k_swgrad %.2e/%.2e | rerun equal %s | %.3f ms %.0f TF (k_swgrad %.3f ms %.0f TF)' % (
+        (act,) + err(dw, dwr) + err(dw0, dwr) + (torch.equal(dw, dw2), tw, fl / tw / 1e9, tw0, fl / tw0 / 1e9)), flush=True)

@@ -33,7 +33,8 @@ def main(d, out=None, flt=None):
                       '%.3f' % (e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 1024)) if gui else '',
                       '%.3f' % (e.get('SQ_WAIT_ANY', 0.0) / wc), '%.3f' % (e.get('SQ_WAIT_INST_ANY', 0.0) / wc),
                       '%.3f' % (e.get('SQ_ACTIVE_INST_ANY', 0.0) / wc)])
-    txt = '\n'.join(','.join(str(c) for c in l) for l in lines)
+    q = lambda c: '"%s"' % c if ',' in str(c) else str(c)
+    txt = '\n'.join(','.join(q(c) for c in l) for l in lines)
     if out:
         open(out, 'w').write(txt + '\n')
     print(txt)
