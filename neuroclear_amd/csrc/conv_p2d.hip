@@ -607,7 +607,8 @@ bool p2_shape(const ConvDims& d, int dgrad) {
   if (!(on & (d.sh == 1 ? 1 : 2))) return false;
   const P2Geom g = p2_geom(d, dgrad);
   if (g.Kout % 64 || g.Cin % (g.kind == 0 ? 64 : 16) || g.NS < 8 || (g.NS & 1)) return false;
-  if ((long)g.B * g.Ho * g.Wo < (g.kind == 2 ? 4096 : 8192)) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
+  static const long minpos = getenv("NC_P2D_MIN") ? atol(getenv("NC_P2D_MIN")) : 8192;
+  if ((long)g.B * g.Ho * g.Wo < (g.kind == 2 ? minpos / 2 : minpos)) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
   if (3 * g.nsub * g.TOT * 16 >= (1l << 31) || (long)d.N * d.K * d.Ho * d.Wo * 4 >= (1l << 31) || (long)d.N * d.C * d.H * d.W * 4 >= (1l << 31)) return false;
   return p2_plan((long)g.B * g.Ho * g.Wo, g.Ho, g.Wo, g.PP, g.Wp, g.Kout / 64, g.tapext, g.nsub).ok;
 }

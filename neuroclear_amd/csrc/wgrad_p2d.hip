@@ -383,7 +383,8 @@ bool q_shape(const ConvDims& d) {
   if (!(on & 4)) return false;
   if (d.D != 1 || d.kd != 1 || d.kh != 4 || d.kw != 4 || d.sh != 1 || d.sw != 1 || d.ph != 1 || d.pw != 1) return false;
   if (d.C % 32 || d.K % 64 || (d.K / 64) * (d.C / 32) > 256) return false;
-  if ((long)d.N * d.Ho * d.Wo < 8192) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
+  static const long minpos = getenv("NC_P2D_MIN") ? atol(getenv("NC_P2D_MIN")) : 8192;
+  if ((long)d.N * d.Ho * d.Wo < minpos) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
   const QPlan pl = q_plan(d);
   if (!pl.ok) return false;
   return 12 * pl.TOTx * 16 < (1l << 31) && 24 * pl.TOTy * 16 < (1l << 31);
