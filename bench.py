@@ -53,6 +53,11 @@ SPLIT_PRODUCTS = 6
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
 ARITHMETIC = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 6 bf16 MFMA products of an exact 3-term operand '
               'split (csrc/conv_s3x.hip, conv_split.hip; error vs fp64 <= the fp32 MFMA kernels\': tests/test_gpu_split.py); NC_CONV_SPLIT=0 = fp32 MFMA kernels')
+# Inference forward (nc_unet_deconv_fwd), round 4: the TWO-term fp16 form -- operands as two fp16 terms of the tensor times a power of two,
+# three MFMA products per fp32 product (csrc/conv_s3x.hip NT = 2, csrc/h2.hip).  Its roofline is the 16-bit dense peak / 3.
+ARITHMETIC_H2 = ('fp32 operands, fp32 accumulation; 3^3 convolution products as 3 fp16 MFMA products of a 2-term operand split of the tensor times '
+                 'a per-tensor power of two (csrc/conv_s3x.hip NT = 2, csrc/h2.hip; error vs fp64 <= the three-term form\'s and the fp32 MFMA '
+                 'kernels\': tests/test_gpu_h2.py); NC_SPLIT_TERMS=3 = the three-term bf16 form (6 products), NC_CONV_SPLIT=0 = fp32 MFMA kernels')
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
@@ -368,11 +373,14 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         ach = flop * len(ev) / ms / 1e9
         from neuroclear_amd._lib import lib
         split = bool(lib().nc_get_conv_split())
-        peak = MFMA_SPLIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-        extra = dict(peak_is='bf16 dense MFMA peak %.0f / %d MFMA products per fp32 product' % (MFMA_16BIT_PEAK_TFLOPS, SPLIT_PRODUCTS),
+        terms = int(lib().nc_unet_deconv_fwd_terms(140, 140, 140)) if split else 0  # 2: the two-term fp16 form (3 products), 3: three-term bf16 (6)
+        products = 3 if terms == 2 else SPLIT_PRODUCTS
+        peak = MFMA_16BIT_PEAK_TFLOPS / products if split else MFMA_F32_PEAK_TFLOPS
+        extra = dict(peak_is='%s dense MFMA peak %.0f / %d MFMA products per fp32 product' % ('fp16' if terms == 2 else 'bf16', MFMA_16BIT_PEAK_TFLOPS, products),
+                     split_terms=terms, frac_of_six_product_roof=round(ach / MFMA_SPLIT_PEAK_TFLOPS, 4),
                      vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4)) if split else {}
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
-                                        'profiles/r03_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*>' if split else 'k_conv_mfma<3,*>'),
+                                        'profiles/r04_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
                     frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), traffic_source=TRAFFIC_SOURCE, launches=len(ev),
                     cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
@@ -460,7 +468,7 @@ def main():
     from neuroclear_amd._lib import lib as _lib
     split_on = bool(_lib().nc_get_conv_split()) and args.precision == 'fp32'
     if split_on:
-        out['arithmetic'] = ARITHMETIC
+        out['arithmetic'] = ARITHMETIC_H2 if (roof or {}).get('split_terms') == 2 else ARITHMETIC
     if roof:
         out['roofline'] = roof
     if world > 1:
@@ -505,7 +513,7 @@ def main():
                    seconds_per_volume_spread=icfg.pop('seconds_per_volume'), n_gpus=world, scaling='strong',
                    dtype='f32', config=icfg)
         if split_on:
-            inf['arithmetic'] = ARITHMETIC
+            inf['arithmetic'] = ARITHMETIC_H2 if (iroof or {}).get('split_terms') == 2 else ARITHMETIC
         if iroof:
             inf['roofline'] = iroof
         if cpu:

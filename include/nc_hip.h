@@ -392,6 +392,18 @@ void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at 
                                   * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
+/* The TWO-TERM form (round 4; csrc/conv_s3x.hip NT = 2, csrc/h2.hip, s3_common.hpp): each operand as two fp16 terms of the tensor times a
+ * power of two (chosen per tensor from its largest finite magnitude, or from a bound known by construction; results scaled back exactly) and
+ * THREE fp16 MFMA products per fp32 product -- half the matrix work of the three-term bf16 form at the same error against fp64
+ * (tests/test_gpu_h2.py).  terms = 3: three-term everywhere; 2: two-term wherever it exists -- nc_conv_fwd / nc_conv_dgrad from fp32 operands
+ * and the inference forward nc_unet_deconv_fwd; 0 (default; NC_SPLIT_TERMS at load time): two-term in nc_unet_deconv_fwd only, so that the
+ * layer-by-layer calls stay bit-identical to the training calls, which are three-term throughout.  In nc_unet_deconv_fwd InstanceNorm outputs
+ * are converted with the power of two their bound sqrt(voxels) allows, the transposed convolutions' outputs with a measured one, and the
+ * ratio of the two is folded into the consuming layer's weights. */
+void nc_set_split_terms(int terms);
+int nc_get_split_terms(void);
+int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the
+                                                       * current switches; 3: on the three-term form (or the fp32 kernels); 0: bad size */
 void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the
                                   * *_lp whole-network calls; csrc/conv_c8x.hip): 1 (default; NC_C8X at load time) = for 3^3 layers the tap-stream kernel
                                   * k_conv_c8x where its 512-position tiles fill the launch's rounds of 512 workgroups to >= 60 %, k_conv_h elsewhere (a few planes); 2 = k_conv_c8x

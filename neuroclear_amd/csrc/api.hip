@@ -154,6 +154,8 @@ void nc_sconv_set_tune(int on) { sconv_set_tune(on); }
 void nc_set_conv_split(int on) { g_split = on; }
 void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
+void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
+int nc_get_split_terms(void) { return s3x_get_terms(); }
 
 int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad) {
   ConvDims d;
@@ -500,6 +502,7 @@ UnetOff unet_offsets() {
 struct UnetWs {
   size_t raw, cat1, a1, p1, cat2, a2, a2b, p2, b1, b2, t1, t2, mean, rstd, in_ws, conv_ws, total;
   size_t s_a1, s_cat1, s_a2, s_cat2, s_b1, s_b2;  // S3 (three-term bf16) forms of the convolution inputs, conv_split.hip
+  size_t cells;  // H2 mode (nc_set_split_terms(2)): scale cells of the convolution inputs, h2.hip
   size_t in_ws_bytes, conv_ws_bytes;
 };
 UnetWs unet_ws(int S0, int S1, int S2) {
@@ -525,10 +528,28 @@ UnetWs unet_ws(int S0, int S1, int S2) {
   auto take3 = [&](size_t elems) { return take((elems * 6 + 3) / 4); };  // 6 bytes per element
   u.s_a1 = take3(64 * S); u.s_cat1 = take3(128 * S); u.s_a2 = take3(128 * Sh); u.s_cat2 = take3(256 * Sh);
   u.s_b1 = take3(256 * Sq); u.s_b2 = take3(256 * Sq);
+  u.cells = take(64);
   u.total = off;
   return u;
 }
 }  // namespace
+
+// H2 mode of the whole-network forward: every 3^3 layer must be one the tap-stream kernel covers
+static bool unet_h2_ok(int S0, int S1, int S2, size_t conv_ws_bytes) {
+  const int h0 = S0 / 2, h1 = S1 / 2, h2 = S2 / 2, q0 = S0 / 4, q1 = S1 / 4, q2 = S2 / 4;
+  return g_split && g_s3_fuse && s3x_get_terms() != 3 && s3x_supported(1, 64, S0, S1, S2, 64, 3) && s3x_supported(1, 128, S0, S1, S2, 64, 3) &&
+         s3x_supported(1, 64, h0, h1, h2, 128, 3) && s3x_supported(1, 128, h0, h1, h2, 128, 3) && s3x_supported(1, 256, h0, h1, h2, 128, 3) &&
+         s3x_supported(1, 128, q0, q1, q2, 256, 3) && s3x_supported(1, 256, q0, q1, q2, 256, 3) &&
+         conv_ws_bytes >= 256 + s3x_packed_bytes(256, 256, 3, 2) + 256;
+}
+
+int nc_unet_deconv_fwd_terms(int S0, int S1, int S2) {
+  if (S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return 0;
+  ConvDims d;
+  const bool f = make_dims(d, 1, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1) && fwd_path(d) == 9 && make_dims(d, 1, 256, S0 / 4, S1 / 4, S2 / 4, 256, 3, 3, 3, 1, 1) &&
+                 fwd_path(d) == 9;
+  return f && unet_h2_ok(S0, S1, S2, unet_ws(S0, S1, S2).conv_ws_bytes) ? 2 : 3;
+}
 
 size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2) {
   (void)N;
@@ -565,10 +586,20 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
   };
   // conv (3^3, pad 1) + InstanceNorm + ReLU: in (fp32) or in3 (S3, when the convolution takes it) -> raw -> out (fp32, nullable)
   // and / or out3 (channels c0 .. of an S3 tensor with ctot channels, nullable)
+  // H2 mode: in3 / out3 are H2 tensors (two fp16 terms of the tensor times a power of two, h2.hip); in_a / in_b: the cells of the input's
+  // channels [0, split_c) / [split_c, C) (a concatenation), out_cell: the cell the output is converted with
+  unsigned* cells = (unsigned*)(W + u.cells);
   auto block = [&](int id, const float* in, const void* in3, float* out, void* out3, int ctot, int c0, int C, int K, int D, int H,
-                   int Wd) -> int {
+                   int Wd, const unsigned* in_a = nullptr, const unsigned* in_b = nullptr, int split_c = 0,
+                   const unsigned* out_cell = nullptr) -> int {
     const long Sl = (long)D * H * Wd;
-    if (in3) {
+    if (in3 && in_a) {
+      ConvDims d;
+      make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1);
+      ProfScope ps(0, 9, d, 0, hs);
+      NC_TRY(conv_s3x_h2(in3, in_a, in_b, in_b ? split_c : C, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, (long)C * 27, 27, 0,
+                         (unsigned*)cws, (char*)cws + 256, hs));
+    } else if (in3) {
       ConvDims d;
       make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1);
       ProfScope ps(0, 9, d, 0, hs);
@@ -577,15 +608,63 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
     }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
+    if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, out_cell, hs);
     if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
     return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
   };
   const bool f1 = split_in(64, 64, S0, S1, S2), f9 = split_in(128, 64, S0, S1, S2);
   const bool f3 = split_in(128, 128, h0, h1, h2), f7 = split_in(256, 128, h0, h1, h2), f8 = f3;
   const bool f5 = split_in(256, 256, q0, q1, q2), f6 = f5;
+  // H2 mode: every 3^3 layer on k_conv_s3x<3, NCB, 2>.  The outputs of InstanceNorm + ReLU are bounded by sqrt(voxels) by construction
+  // (cells 0..2, one per level); the transposed convolutions' halves of the concatenations are measured (cells 3, 4).
+  const bool use_h2 = f1 && f3 && f5 && f7 && f9 && unet_h2_ok(S0, S1, S2, u.conv_ws_bytes);
+  if (use_h2) {
+    NC_TRY(h2_set_cell(cells + 0, sqrtf((float)S), hs));
+    NC_TRY(h2_set_cell(cells + 1, sqrtf((float)Sh), hs));
+    NC_TRY(h2_set_cell(cells + 2, sqrtf((float)Sq), hs));
+  }
   for (int n = 0; n < N; ++n) {
     const float* xn = x + (long)n * S;
     float* yn = y + (long)n * S;
+    if (use_h2) {
+      const unsigned *c0 = cells, *c1 = cells + 1, *c2 = cells + 2;
+      NC_TRY(h2_zero_cells(cells + 3, 2, hs));
+      NC_TRY(block(0, xn, nullptr, nullptr, W + u.s_a1, 64, 0, 1, 64, S0, S1, S2, nullptr, nullptr, 0, c0));
+      NC_TRY(block(1, nullptr, W + u.s_a1, W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0));
+      NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
+      // a max-pool of InstanceNorm outputs keeps their bound: converted with the upper level's cell, into a slot nobody needs yet (the
+      // upper half of s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it)
+      void* p1h = W + u.s_cat2 + 128 * Sh;
+      NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, 1, 64, Sh, 64, 0, c0, hs));
+      NC_TRY(block(2, nullptr, p1h, nullptr, W + u.s_a2, 128, 0, 64, 128, h0, h1, h2, c0, nullptr, 0, c1));
+      NC_TRY(block(3, nullptr, W + u.s_a2, W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1));
+      NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
+      NC_TRY(split2h_into(W + u.p2, 128 * Sq, W + u.s_b2, 1, 128, Sq, 128, 0, c1, hs));
+      NC_TRY(block(4, nullptr, W + u.s_b2, nullptr, W + u.s_b1, 256, 0, 128, 256, q0, q1, q2, c1, nullptr, 0, c2));
+      NC_TRY(block(5, nullptr, W + u.s_b1, nullptr, W + u.s_b2, 256, 0, 256, 256, q0, q1, q2, c2, nullptr, 0, c2));
+      // the transposed convolutions keep their three-term S3 input (small tensors) and write fp32; their halves of the concatenations
+      // are measured and converted, the ratio of the two halves' powers of two goes into the consumer's weights
+      const bool t10 = convT_s3x_supported(1, 256, q0, q1, q2, 128) && u.conv_ws_bytes >= convT_s3x_ws_bytes(256, 128);
+      const bool t11 = convT_s3x_supported(1, 128, h0, h1, h2, 64) && u.conv_ws_bytes >= convT_s3x_ws_bytes(128, 64);
+      NC_TRY(block(6, nullptr, W + u.s_b2, t10 ? nullptr : W + u.b1, t10 ? W + u.s_b1 : nullptr, 256, 0, 256, 256, q0, q1, q2, c2));
+      if (t10) NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, nullptr, 256, 128, 1, 256, q0, q1, q2, 128, cws,
+                                    u.conv_ws_bytes, hs));
+      else NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
+      NC_TRY(h2_absmax(W + u.cat2 + 128 * Sh, 128 * Sh, cells + 3, hs));
+      NC_TRY(split2h_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, cells + 3, hs));
+      NC_TRY(block(7, nullptr, W + u.s_cat2, nullptr, W + u.s_a2, 128, 0, 256, 128, h0, h1, h2, c1, cells + 3, 128, c1));
+      NC_TRY(block(8, nullptr, W + u.s_a2, t11 ? nullptr : W + u.a2b, t11 ? W + u.s_cat2 : nullptr, 128, 0, 128, 128, h0, h1, h2, c1));
+      if (t11) NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, nullptr, 128, 64, 1, 128, h0, h1, h2, 64, cws,
+                                    u.conv_ws_bytes, hs));
+      else NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
+      NC_TRY(h2_absmax(W + u.cat1 + 64 * S, 64 * S, cells + 4, hs));
+      NC_TRY(split2h_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, cells + 4, hs));
+      NC_TRY(block(9, nullptr, W + u.s_cat1, W + u.a1, nullptr, 0, 0, 128, 64, S0, S1, S2, c0, cells + 4, 64));
+      NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
+      NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
+      NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S, stream));
+      continue;
+    }
     NC_TRY(block(0, xn, nullptr, f1 ? nullptr : W + u.a1, f1 ? W + u.s_a1 : nullptr, 64, 0, 1, 64, S0, S1, S2));
     NC_TRY(block(1, W + u.a1, f1 ? W + u.s_a1 : nullptr, W + u.cat1, f9 ? W + u.s_cat1 : nullptr, 128, 0, 64, 64, S0, S1, S2));
     NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));

@@ -204,7 +204,22 @@ int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* 
                   int W, int K, int ks, void* ws, size_t ws_bytes, void* stream);
 // conv_s3x.hip: the tap-stream form of the split-operand forward / data-gradient kernel (S3 input, packed weights in wp_ws)
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS);
-size_t s3x_packed_bytes(int Cin, int Kout, int KS);
+size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT = 3);
+// NT = 2 (two-term fp16 split, three products; s3_common.hpp) from the fp32 input: ws >= s3x_h2_ws_bytes
+void s3x_set_terms(int t);
+int s3x_get_terms();
+size_t s3x_h2_ws_bytes(int N, int Cin, long S, int Kout, int KS);
+int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
+                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s);
+int conv_s3x_h2_from_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
+                         long si, int flip, void* ws, size_t wsb, hipStream_t s);
+// h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
+int h2_zero_cells(unsigned* cells, int n, hipStream_t s);
+int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
+int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s);
+int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s);
+int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
+                int c0, const unsigned* cell, hipStream_t s);
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s);
 bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);

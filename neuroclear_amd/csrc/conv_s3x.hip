@@ -27,6 +27,7 @@
 // every plane size, z-neighbours enumerated side by side).  In isolation the 27^3 layers gained 25 %; in the step it made no difference
 // and the 900^3 inference ran 2.3 % slower (pad rows computed and dropped; same-box A/B) -- tiles stay inside one output plane.
 // Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -38,6 +39,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -68,19 +70,22 @@ __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_spl
 // group is read upper half first).
 // fwd:   w[co][ci][tap]                   (so = C*T3, si = T3, flip = 0)
 // dgrad: w[co as "ci"][ci as "co"][T3-1-tap]  (so = T3, si = C*T3, flip = 1)
+// NT = 2: the two fp16 terms of w * 2^k (h2_split), k from the tensor's absmax cell.
+template <int NT>
 __global__ void __launch_bounds__(256) k_pack_w_s3x(const float* __restrict__ w, unsigned short* __restrict__ wp, int NCH, int KS, int NS,
-                                                    long so, long si, int flip, long total) {
+                                                    long so, long si, int flip, long total, const unsigned* __restrict__ amax, int split_c,
+                                                    const unsigned* __restrict__ cell_a, const unsigned* __restrict__ cell_b) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int T2 = KS * KS, T3 = T2 * KS, NB = NCH * KS;
   const int j = (int)(i & 7);
   long q = i >> 3;
   const int lane = (int)(q & 63); q >>= 6;
-  const int f = (int)(q % 6); q /= 6;
+  const int f = (int)(q % (2 * NT)); q /= 2 * NT;
   const int s = (int)(q % NS); q /= NS;
   const int half = (int)(q & 1);
   const int cot = (int)(q >> 1);
-  const int rb = f / 3, term = f % 3;
+  const int rb = f / NT, term = f % NT;
   const int g = lane >> 4, m = lane & 15;
   const int T = 4 * s + g;
   const int bi = T / T2, tp = T % T2;
@@ -90,9 +95,30 @@ __global__ void __launch_bounds__(256) k_pack_w_s3x(const float* __restrict__ w,
     const int jj = (g & 1) ? ((j + 4) & 7) : j;
     const long co = cot * 64 + half * 32 + rb * 16 + m, ci = chunk * 8 + jj;
     const int tap = dz * T2 + tp;
-    split3(w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)], t);
+    const float v = w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)];
+    if constexpr (NT == 3) split3(v, t);
+    else h2_split(v * (ci >= split_c ? h2_group_factor(*cell_a, *cell_b) : 1.f) * h2_scale(*amax), t);
   }
   wp[i] = t[term];
+}
+
+// Largest finite |w'| of the weights as the pack sees them: w' = w * 2^(kA - kB) for the input channels of the second scale group (a
+// concatenation whose halves were converted with different powers of two: folding the ratio into the weights makes the sum uniform in 2^kA).
+__global__ void __launch_bounds__(256) k_absmax_w(const float* __restrict__ w, long n, int T3, int C, int split_c, const unsigned* __restrict__ cell_a,
+                                                  const unsigned* __restrict__ cell_b, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const float gf = split_c < C ? h2_group_factor(*cell_a, *cell_b) : 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ci = (int)((i / T3) % C);
+    const unsigned b = __float_as_uint(w[i] * (ci >= split_c ? gf : 1.f)) & 0x7fffffffu;
+    if (b < 0x7f800000u && b > m) m = b;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned q = (unsigned)__shfl_xor((int)m, o);
+    m = q > m ? q : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 struct XParams {
@@ -112,6 +138,7 @@ struct XParams {
   int t_begin, t_count;  // first main tile and number of (sub-)tiles of this launch
   int tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
+  const unsigned *amax_x, *amax_w;  // NT = 2: the cells of the input and of the weights (the result is scaled back by 2^-(kx + kw))
   long long* dbg;      // NC_S3X_STAMP builds: s_memtime stamps of workgroup 0 / wave 0 (timing experiments only)
 };
 
@@ -135,7 +162,7 @@ __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   return o;
 }
 
-template <int KS, int NCB>
+template <int KS, int NCB, int NT>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS, PT = 64 * NCB;
@@ -172,9 +199,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const int chunk = bi / KS, dz = bi - chunk * KS;
     const int zz = t.z + dz - PAD;
     const bool zok = (unsigned)zz < (unsigned)p.D;
-    const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * 3 * S;
+    const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * NT * S;
     // a plane outside the volume: an empty descriptor, every lane reads zeros
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(3 * S * 16) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(NT * S * 16) : 0u, 0x00020000);
     const int soff = zok ? (int)(zz * HW * 16) : 0;
     unsigned char* buf = lds_raw + slot * BB;
 #pragma unroll 1
@@ -189,7 +216,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       const unsigned rr = fdiv(F, p.mP);
       const int xx = (int)(F - rr * p.P) - PAD;
       const int yy = (int)rr - PAD;
-      const bool ok = term < 3u && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, soff, 0, 0);
     }
@@ -207,39 +234,40 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     wrsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   const int wvoff = lane * 16;
-  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (6 * 1024); };
-  auto load_a = [&](u32x4 (&A)[2][3], int soff) {
+  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (2 * NT * 1024); };
+  auto load_a = [&](u32x4 (&A)[2][NT], int soff) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"
-                     : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * 3 + t) * 1024) : "memory");
+                     : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * NT + t) * 1024) : "memory");
   };
   // All vector-memory operations of this wave but its 6 youngest (the A fragments requested last) are complete -- `stored`: but
   // the 6 and the stores of the previous tile issued by the step before (2 * NCB; odd NCB: fewer in the fourth step).  The count is chosen by a scalar branch around
   // bare s_waitcnt instructions; ONE statement behind the branch ties the fragment registers to the wait (a tie inside either arm
   // makes the compiler copy the still-in-flight registers in front of the wait).
-  auto wait_a = [&](u32x4 (&A)[2][3], auto nst, bool stored) {  // nst: stores the step before issued when it stored (compile time)
-    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + decltype(nst)::value) : "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  auto wait_a = [&](u32x4 (&A)[2][NT], auto nst, bool stored) {  // nst: stores the step before issued when it stored (compile time)
+    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT + decltype(nst)::value) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT) : "memory");
+    if constexpr (NT == 3) asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+    else asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1])::"memory");
   };
 
   // ---- B fragments: unit (slot, term, position + tap) of the ring, read as two 8-byte halves (odd lane groups: upper first)
   const unsigned lane_b = (unsigned)(((pg * NCB * 16 + m16) * 16) + (g & 1) * 8);
   const unsigned term_b = (unsigned)p.UB * 16;
   const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)lds_raw;
-  struct BAddr { unsigned lo[3], hi[3]; };  // per term: address of the half read first / second (column block 0)
+  struct BAddr { unsigned lo[NT], hi[NT]; };  // per term: address of the half read first / second (column block 0)
   auto b_addr = [&](unsigned vo) __attribute__((always_inline)) {
     BAddr a;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { a.lo[t] = lds_base + vo + t * term_b; a.hi[t] = a.lo[t] ^ 8u; }
+    for (int t = 0; t < NT; ++t) { a.lo[t] = lds_base + vo + t * term_b; a.hi[t] = a.lo[t] ^ 8u; }
     return a;
   };
-  auto read_b = [&](u32x4 (&B)[3], const BAddr& a, int cb) {
+  auto read_b = [&](u32x4 (&B)[NT], const BAddr& a, int cb) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
       u64x2 v;
       v.x = *(lds64_t)(a.lo[t] + cb * 256);  // volatile: two ds_read_b64, never one ds_read2_b64
       v.y = *(lds64_t)(a.hi[t] + cb * 256);
@@ -269,6 +297,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     brsrc.z = __builtin_amdgcn_readfirstlane(p.bias ? (unsigned)p.K * 4u : 0u);
     brsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
+  // NT = 2: both operands were scaled by powers of two before the split; the sums are scaled back (exactly) on their way out
+  // (one factor after the other: their product could leave the fp32 range where neither does)
+  float oscx = 1.f, oscw = 1.f;
+  if constexpr (NT == 2) { oscx = h2_inv_scale(*p.amax_x); oscw = h2_inv_scale(*p.amax_w); }
   u32x4 bv[2];
   auto load_bias = [&](const XTile& t) __attribute__((always_inline)) {
     const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
@@ -292,7 +324,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
-        const float v = tot[rb][cb][e] + __uint_as_float(bu);
+        const float v = NT == 2 ? tot[rb][cb][e] * oscx * oscw + __uint_as_float(bu) : tot[rb][cb][e] + __uint_as_float(bu);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * S * 4) : kOut, 0, 0);
         tot[rb][cb][e] = 0.f;
       }
@@ -305,7 +337,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   // ---- prologue: brick 0 and the first A fragments of the first tile
   int ring = 0;  // ring slot of brick 0 of the current tile
   issue_brick(cur, 0, 0);
-  u32x4 A[2][3], nA[2][3];
+  u32x4 A[2][NT], nA[2][NT];
   load_a(A, wtile(cur.cot));
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
@@ -341,7 +373,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
     };
     BAddr vo = b_addr(b_off());
-    u32x4 B[2][3];
+    u32x4 B[2][NT];
     int since = 0;
 
     // One k-step.  Ac = this step's A fragments (requested one step ago; step 0: during the last step of the previous tile), An
@@ -351,12 +383,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     // step that stored, the count is 6 + its stores.
     // `ph` (compile time): the step number for the first kStoreSteps steps of a tile, which carry the previous tile's stores; kStoreSteps
     // for every later step
-    auto kstep = [&](auto ph, auto par, int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
+    auto kstep = [&](auto ph, auto par, int s, u32x4 (&Ac)[2][NT], u32x4 (&An)[2][NT]) {
       constexpr int PH = decltype(ph)::value;
       // odd NCB: a step's last column block leaves the next step's first fragments in B[1] -- odd steps walk the two buffers the other way round
       constexpr int PAR = (NCB & 1) ? decltype(par)::value : 0;
       const bool last = PH == kStoreSteps && s + 1 == p.NS;
-      load_a(An, last ? wt_next : wt + (s + 1) * (6 * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
+      load_a(An, last ? wt_next : wt + (s + 1) * (2 * NT * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
       constexpr int PPH = PH >= 1 && PH < kStoreSteps ? PH - 1 : kStoreSteps - 1;  // the step before this one, if it stored
       constexpr int PPairs = kPairs - PPH * kPairsPerStep < kPairsPerStep ? kPairs - PPH * kPairsPerStep : kPairsPerStep;
       wait_a(Ac, std::integral_constant<int, 4 * PPairs>{}, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));
@@ -392,23 +424,37 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       const BAddr nvo = b_addr(b_off());
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        u32x4(&Bc)[3] = B[(cb + PAR) & 1];
-        u32x4(&Bn)[3] = B[(cb + PAR + 1) & 1];
+        u32x4(&Bc)[NT] = B[(cb + PAR) & 1];
+        u32x4(&Bn)[NT] = B[(cb + PAR + 1) & 1];
         if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
         else if (!last) read_b(Bn, nvo, 0);
-        // six products per (row block, column block), smallest first: (term of A, term of B)
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+        // six (NT = 2: three) products per (row block, column block), smallest first: (term of A, term of B)
+        constexpr int NP = NT == 3 ? 6 : 3;
+        constexpr int TA[6] = {NT - 1, NT == 3 ? 1 : 0, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, NT == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
-        for (int m = 0; m < 6; ++m)
+        for (int m = 0; m < NP; ++m)
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ac[rb][TA[m]]), __builtin_bit_cast(bf16x8, Bc[TB[m]]),
-                                                                  acc[rb][cb], 0, 0, 0);
+          for (int rb = 0; rb < 2; ++rb) {
+            if constexpr (NT == 3)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ac[rb][TA[m]]), __builtin_bit_cast(bf16x8, Bc[TB[m]]),
+                                                                    acc[rb][cb], 0, 0, 0);
+            else
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ac[rb][TA[m]]), __builtin_bit_cast(f16x8, Bc[TB[m]]),
+                                                                   acc[rb][cb], 0, 0, 0);
+          }
+        if constexpr (NT == 3) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {  // the 6 reads of the next column block spread over this one's 12 MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          for (int k = 0; k < 6; ++k) {  // the 6 reads of the next column block spread over this one's 12 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        } else {
+          // the 4 reads of the next column block spread over this one's 6 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
       vo = nvo;
@@ -460,10 +506,10 @@ struct XPlan {
   bool ok;
 };
 
-bool x_brick(int PT, int P, int KS, int& UB, int& npb, int& lds) {
+bool x_brick(int PT, int P, int KS, int NT, int& UB, int& npb, int& lds) {
   const int U = PT + (KS - 1) * (P + 1);
   UB = (U + 63) / 64 * 64;
-  npb = 3 * UB / 64;
+  npb = NT * UB / 64;
   lds = 3 * npb * 1024;
   return npb <= kMaxPieces && lds <= kLdsMax;
 }
@@ -473,7 +519,7 @@ int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round
   return m;
 }
 
-XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
+XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
   XPlan best{};
   double best_cost = 1e30;
   const int P = W + KS - 1;
@@ -486,7 +532,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
     XPlan pl{};
     pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
     const int PT = 64 * NCB;
-    if (!x_brick(PT, P, KS, pl.UB, pl.npb, pl.lds)) continue;
+    if (!x_brick(PT, P, KS, NT, pl.UB, pl.npb, pl.lds)) continue;
     pl.TPP = (int)((HP + PT - 1) / PT);
     const long ntiles = (long)N * D * pl.TPP * KT;
     pl.full = ntiles / 256 * 256;
@@ -504,35 +550,43 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS) {
       pl.fsub = f;
       cost += PT / f + fixed;
     }
-    if (!x_brick(PT / pl.fsub, P, KS, pl.UBt, pl.npbt, pl.ldst)) continue;
+    if (!x_brick(PT / pl.fsub, P, KS, NT, pl.UBt, pl.npbt, pl.ldst)) continue;
     if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
   }
   return best;
 }
 
-template <int KS, int NCB>
+template <int KS, int NCB, int NT>
 int launch_x(const XParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_s3x<KS, NCB>;
+  auto kern = k_conv_s3x<KS, NCB, NT>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
 }
 
-template <int KS>
+template <int KS, int NT = 3>
 int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
-  if (NCB == 8) return launch_x<KS, 8>(p, lds, s);
-  if (NCB == 7) return launch_x<KS, 7>(p, lds, s);
-  if (NCB == 6) return launch_x<KS, 6>(p, lds, s);
-  if (NCB == 4) return launch_x<KS, 4>(p, lds, s);
-  return launch_x<KS, 2>(p, lds, s);
+  if (NCB == 8) return launch_x<KS, 8, NT>(p, lds, s);
+  if (NCB == 7) return launch_x<KS, 7, NT>(p, lds, s);
+  if (NCB == 6) return launch_x<KS, 6, NT>(p, lds, s);
+  if (NCB == 4) return launch_x<KS, 4, NT>(p, lds, s);
+  return launch_x<KS, 2, NT>(p, lds, s);
 }
 
 }  // namespace
 
-size_t s3x_packed_bytes(int Cin, int Kout, int KS) {
+size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
   const int NS = KS * KS * KS * (Cin / 8) / 4;
-  return (size_t)(Kout / 64) * 2 * NS * 6 * 1024;
+  return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024;
 }
+
+// NC_SPLIT_TERMS / nc_set_split_terms: which form of the split the fp32 3^3 / 5^3 layers use where both exist -- the three-term bf16 form (six
+// MFMA products per fp32 product) or the two-term fp16 form (three; s3_common.hpp).  3: three-term everywhere; 2: two-term everywhere it
+// exists (the layer-by-layer forward / data gradient from fp32 operands, and the inference forward nc_unet_deconv_fwd); 0 (default): two-term in
+// the inference forward only -- the layer-by-layer calls stay bit-identical to the training calls, which are three-term throughout.
+static std::atomic<int> g_terms{getenv("NC_SPLIT_TERMS") ? atoi(getenv("NC_SPLIT_TERMS")) : 0};
+void s3x_set_terms(int t) { g_terms = (t == 2 || t == 3) ? t : 0; }
+int s3x_get_terms() { return g_terms; }
 
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if (KS != 3 && KS != 5) return false;
@@ -543,6 +597,66 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   return x_plan(N, D, H, W, Kout / 64, KS).ok;
 }
 
+size_t s3x_h2_ws_bytes(int N, int Cin, long S, int Kout, int KS) {
+  return 256 + (((size_t)N * Cin * S * 4 + 255) & ~(size_t)255) + s3x_packed_bytes(Cin, Kout, KS, 2) + 256;
+}
+
+// The convolution from an H2 input (h2.hip).  cell_a: the input's cell; a concatenated input whose channels [split_c, Cin) were converted with
+// another cell passes that as cell_b (forward layout of w only), else split_c = Cin.  wcell: one zeroed-by-us cell for the weights,
+// wp_ws >= s3x_packed_bytes(.., 2).
+int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
+                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s) {
+  const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
+  if (!pl.ok) { set_error("conv_s3x_h2: shape not covered"); return NC_ERR_SHAPE; }
+  if (split_c < Cin && (flip || !cell_b || split_c % 8)) { set_error("conv_s3x_h2: scale groups only for the forward weight layout"); return NC_ERR_ARG; }
+  const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4, T3 = KS * KS * KS;
+  if (int e = h2_zero_cells(wcell, 1, s)) return e;
+  const long nw = (long)Kout * Cin * T3;
+  if (!cell_b) cell_b = cell_a;
+  // (the group test below reads the input channel as (i / T3) % Cin: the forward layout [co][ci][tap]; data gradients have no groups)
+  hipLaunchKernelGGL(k_absmax_w, dim3((unsigned)(cdiv(nw, 256 * 4) < 1024 ? cdiv(nw, 256 * 4) : 1024)), dim3(256), 0, s, w, nw, T3, Cin,
+                     flip ? Cin : split_c, cell_a, cell_b, wcell);
+  const long total = (long)(s3x_packed_bytes(Cin, Kout, KS, 2) / 2);
+  hipLaunchKernelGGL(k_pack_w_s3x<2>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip, total,
+                     (const unsigned*)wcell, flip ? Cin : split_c, cell_a, cell_b);
+  if (int e = check_launch("conv_s3x_h2 pack")) return e;
+  XParams p{};
+  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y; p.amax_x = cell_a; p.amax_w = wcell;
+  p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.NS = NS; p.mP = magic(pl.P);
+  static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 4;
+  p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
+  const bool one = pl.rem && pl.fsub == 1;
+  if (pl.full || one) {
+    p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
+    p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds, s);
+    if (e) return e;
+  }
+  if (pl.rem && !one) {
+    p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
+    p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst, s) : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst, s);
+    if (e) return e;
+  }
+  return NC_OK;
+}
+
+// ... from the fp32 input: ws = [cells | H2 input | packed weights]
+int conv_s3x_h2_from_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
+                         long si, int flip, void* ws, size_t wsb, hipStream_t s) {
+  const long S = (long)D * H * W;
+  if (!ws || wsb < s3x_h2_ws_bytes(N, Cin, S, Kout, KS)) { set_error("conv_s3x_h2: workspace too small"); return NC_ERR_WS; }
+  unsigned* cells = (unsigned*)ws;
+  void* xs = (char*)ws + 256;
+  void* wp_ws = (char*)xs + (((size_t)N * Cin * S * 4 + 255) & ~(size_t)255);
+  if (int e = h2_zero_cells(cells, 2, s)) return e;
+  if (int e = h2_absmax(x, (long)N * Cin * S, cells, s)) return e;
+  if (int e = split2h_into(x, (long)Cin * S, xs, N, Cin, S, Cin, 0, cells, s)) return e;
+  return conv_s3x_h2(xs, cells, nullptr, Cin, w, bias, y, N, Cin, D, H, W, Kout, KS, so, si, flip, cells + 1, wp_ws, s);
+}
+
 // xs: S3 input; wp_ws: >= s3x_packed_bytes scratch for the packed weights
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s) {
@@ -550,8 +664,8 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
   if (!pl.ok) { set_error("conv_s3x: shape not covered"); return NC_ERR_SHAPE; }
   const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4;
   const long total = (long)(s3x_packed_bytes(Cin, Kout, KS) / 2);
-  hipLaunchKernelGGL(k_pack_w_s3x, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip,
-                     total);
+  hipLaunchKernelGGL(k_pack_w_s3x<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip,
+                     total, (const unsigned*)nullptr, Cin, (const unsigned*)nullptr, (const unsigned*)nullptr);
   if (int e = check_launch("pack_w_s3x")) return e;
   XParams p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y;

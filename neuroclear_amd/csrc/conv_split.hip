@@ -494,6 +494,10 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
   const int KS = d.kd;
   const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
+  // NC_SPLIT_TERMS=2: the two-term fp16 form of the tap-stream kernel, from the fp32 input (no S3 tensor to share with anybody)
+  if (s3x_get_terms() == 2 && !xs_pre && !xs_keep && s3x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS) &&
+      wsb >= s3x_h2_ws_bytes(d.N, Cin, S, Kout, KS))
+    return conv_s3x_h2_from_f32(x, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, ws, wsb, s);
   const size_t xb = (xs_pre || xs_keep) ? 0 : align256((size_t)d.N * Cin * S * 6);
   const size_t wb = align256(s_packed_bytes(Cin, Kout, KS));
   if (!ws || wsb < xb + wb + 256) { set_error("conv_s3: workspace too small"); return NC_ERR_WS; }

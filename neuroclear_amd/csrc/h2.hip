@@ -1,0 +1,117 @@
+// "H2" operands: an fp32 tensor as TWO fp16 terms of the tensor times a power of two (s3_common.hpp), the input form of k_conv_s3x<KS, NCB, 2>
+// (three fp16 MFMA products per fp32 product where the three-term bf16 form needs six).  Layout: [N][C/8][2 terms][voxels][8] fp16 = 16-byte
+// units like S3 with two sub-blocks.  The power of two comes from a CELL, one unsigned per tensor holding the float bits of a magnitude that
+// bounds the tensor from above within a factor of two: the largest finite |x| (k_absmax; atomicMax, order-independent, deterministic), or a
+// bound known by construction (h2_set_cell: |InstanceNorm output| <= sqrt(S - 1)).
+#include "common.hpp"
+#include "s3_common.hpp"
+
+namespace nc {
+namespace {
+
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ cell) {
+  unsigned m = 0;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = x4[i];
+    const unsigned b[4] = {__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu, __float_as_uint(v.z) & 0x7fffffffu,
+                           __float_as_uint(v.w) & 0x7fffffffu};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (b[j] < 0x7f800000u && b[j] > m) m = b[j];  // non-finite elements do not set the scale: they become NaN terms of their own
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const unsigned b = __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu;
+    if (b < 0x7f800000u && b > m) m = b;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned q = (unsigned)__shfl_xor((int)m, o);
+    m = q > m ? q : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(cell, m);
+}
+
+__global__ void k_set_cells(unsigned* cells, int n, unsigned bits) {
+  if ((int)threadIdx.x < n) cells[threadIdx.x] = bits;
+}
+
+// fp32 [N][C][S] (samples xstride floats apart) -> channels ob0*8 .. of an H2 tensor with `oblocks` 8-channel blocks per sample
+__global__ void __launch_bounds__(256) k_split2h(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks, int ob0,
+                                                 long xstride, const unsigned* __restrict__ cell) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const float sc = h2_scale(*cell);
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
+  unsigned short e[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h2_split(xs[j * S] * sc, e[j]);
+  const long ob = (long)n * oblocks + ob0 + cb;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
+}
+
+// InstanceNorm normalisation + (Leaky)ReLU (k_act_split3's arithmetic, operation for operation) writing the H2 form -- and the fp32 tensor too
+// when y != NULL
+__global__ void __launch_bounds__(256) k_act_split2h(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float slope, float* __restrict__ y, long ystride, uint4* __restrict__ out, long S, int cblocks,
+                                                     int oblocks, int ob0, const unsigned* __restrict__ cell) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const float sc = h2_scale(*cell);
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  const long c0 = (long)blockIdx.y * 8;
+  const float* xs = x + c0 * S + v;
+  float* ys = y ? y + (long)n * ystride + (long)cb * 8 * S + v : nullptr;
+  unsigned short e[8][3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float t = (xs[j * S] - mean[c0 + j]) * rstd[c0 + j];
+    t = t > 0.f ? t : t * slope;
+    if (ys) ys[j * S] = t;
+    asm("" : "+v"(t));  // the scaling must see the ROUNDED activation (s3_common.hpp: no contraction into the split)
+    h2_split(t * sc, e[j]);
+  }
+  const long ob = (long)n * oblocks + ob0 + cb;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
+}
+
+}  // namespace
+
+int h2_zero_cells(unsigned* cells, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, cells, n, 0u);
+  return check_launch("h2_zero_cells");
+}
+int h2_set_cell(unsigned* cell, float bound, hipStream_t s) {
+  unsigned bits;
+  static_assert(sizeof(bits) == sizeof(bound), "");
+  __builtin_memcpy(&bits, &bound, 4);
+  hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, cell, 1, bits);
+  return check_launch("h2_set_cell");
+}
+int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s) {  // *cell = max(*cell, largest finite |x|)
+  if ((unsigned long long)x & 15) { set_error("h2_absmax: the tensor must be 16-byte aligned"); return NC_ERR_ARG; }
+  long blocks = cdiv(n, 256 * 4 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n, cell);
+  return check_launch("h2_absmax");
+}
+int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s) {
+  if (C % 8 || ctot % 8 || c0 % 8) { set_error("split2h: channels must be multiples of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_split2h, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8, xstride,
+                     cell);
+  return check_launch("split2h");
+}
+int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
+                int c0, const unsigned* cell, hipStream_t s) {
+  if (C % 8 || ctot % 8 || c0 % 8) { set_error("act_split2h: channels must be multiples of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_act_split2h, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, mean, rstd, slope, y, ystride,
+                     (uint4*)ys, S, C / 8, ctot / 8, c0 / 8, cell);
+  return check_launch("act_split2h");
+}
+
+}  // namespace nc

@@ -36,4 +36,31 @@ __device__ __forceinline__ uint4 s3_unit(const unsigned short (&e)[8][3], int t)
   return o;
 }
 
+// ---- "H2": the two-term fp16 split of a SCALED fp32 value (conv_s3x.hip, NT = 2).  a * 2^k = a0 + a1 + r with a0 = fp16(a * 2^k), a1 = fp16(rest):
+// 22-24 significant bits in two terms (fp16 carries 11), so THREE fp16 MFMA products a0 b0 + a0 b1 + a1 b0 make one fp32 product to ~2^-23 --
+// where bf16 (8 bits a term) needs three terms and six products.  The price is fp16's range: k is chosen per TENSOR from its largest finite
+// magnitude (one atomicMax cell; max |a| 2^k in [2^14, 2^15), so nothing overflows and elements down to 2^-17 of the largest keep both terms
+// normal; below that the second term goes subnormal and the ABSOLUTE error stays <= 2^-25 / 2^k), and results are scaled back exactly.
+__device__ __forceinline__ int h2_exp(unsigned amax_bits) {  // amax_bits: float bits of the largest finite |a| (0 for an all-zero tensor)
+  const int e = (int)(amax_bits >> 23);
+  const int k = e ? 14 - (e - 127) : 0;
+  return k > 126 ? 126 : k;  // (e = 255 cannot happen: non-finite elements are left out of the maximum)
+}
+__device__ __forceinline__ float h2_scale(unsigned amax_bits) { return __uint_as_float((unsigned)(127 + h2_exp(amax_bits)) << 23); }
+__device__ __forceinline__ float h2_inv_scale(unsigned amax_bits) { return __uint_as_float((unsigned)(127 - h2_exp(amax_bits)) << 23); }
+// 2^(kA - kB): what a value converted with cell B must be multiplied by to stand in a sum converted with cell A
+__device__ __forceinline__ float h2_group_factor(unsigned cell_a, unsigned cell_b) {
+  int d = h2_exp(cell_a) - h2_exp(cell_b);
+  d = d < -126 ? -126 : d > 127 ? 127 : d;
+  return __uint_as_float((unsigned)(127 + d) << 23);
+}
+// v = the element times h2_scale.  Non-finite v: a0 = v, a1 = NaN -- every output it touches becomes NaN, as with the three-term split.
+__device__ __forceinline__ void h2_split(float v, unsigned short (&t)[3]) {
+  asm("" : "+v"(v));
+  const _Float16 a0 = (_Float16)v;
+  const float r = v - (float)a0;
+  const _Float16 a1 = (_Float16)r;
+  t[0] = __builtin_bit_cast(unsigned short, a0); t[1] = __builtin_bit_cast(unsigned short, a1); t[2] = 0;
+}
+
 }  // namespace nc

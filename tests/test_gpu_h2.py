@@ -1,0 +1,177 @@
+"""GPU parity of the two-term fp16 form of the split-operand convolutions (csrc/conv_s3x.hip NT = 2, csrc/h2.hip; nc_set_split_terms(2)).
+
+An fp32 operand times a power of two chosen per TENSOR is the sum of two fp16 terms to 2^-23; three fp16 MFMA products a0 b0 + a0 b1 + a1 b0
+make one fp32 product (the three-term bf16 form of tests/test_gpu_split.py needs six).  Same reference call sites (models/networks.py:420-425,
+460-469, 900-902), same criteria: against an fp64 convolution the error must not exceed the fp32 MFMA kernel's (rms <= 1.3 x, max <= 2 x) nor
+the three-term form's by more than 1.3 x; bit-identical run to run; the non-finite rule; tensors at the ends of the fp32 range; and the
+whole-network inference forward (nc_unet_deconv_fwd) against the reference-generated goldens, with the power-of-two ratio of a
+concatenation's halves folded into the consumer's weights."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from neuroclear_amd.models import networks
+from neuroclear_amd.util import seed as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def L():
+    from neuroclear_amd._lib import lib
+    return lib()
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    from neuroclear_amd import ops
+    prev = ops.set_conv_split(True)
+    t = L().nc_get_split_terms()
+    yield
+    L().nc_set_split_terms(t)
+    ops.set_conv_split(prev)
+
+
+def data(kind, shape, g):
+    x = torch.randn(shape, device=DEV, generator=g)
+    if kind == 'relu':
+        return x.clamp_min(0)
+    if kind == 'grad':      # gradient-like: tiny, log-normal magnitudes
+        return x * 1e-5 * torch.exp(2 * torch.randn(shape, device=DEV, generator=g))
+    if kind == 'outlier':   # one element 900 sigma out (an InstanceNorm output can reach sqrt(voxels))
+        x.view(-1)[12345] = 900.0
+    return x
+
+
+def err(a, r):
+    s = r.pow(2).mean().sqrt().item()
+    e = a.double() - r
+    return e.abs().max().item() / s, e.pow(2).mean().sqrt().item() / s
+
+
+CASES = [(1, 64, 64, 32, 3, 'relu'), (1, 64, 64, 32, 3, 'grad'), (1, 64, 64, 32, 3, 'outlier'), (2, 128, 64, 20, 3, 'randn'), (1, 64, 128, 27, 3, 'relu'),
+         (1, 64, 64, 24, 5, 'randn'), (1, 256, 256, 12, 3, 'relu')]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
+def test_h2_layer_against_fp64(case):
+    from neuroclear_amd import ops
+    N, C, K, E, ks, kind = case
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = data(kind, (N, C, E, E, E), g)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV, generator=g) * (2.0 / (C * ks ** 3)) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g) * 0.1
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=ks // 2)
+    dy = data('grad' if kind == 'grad' else 'randn', tuple(ref.shape), g)
+    refd = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=ks // 2)
+    res = {}
+    for name, split, terms in (('fp32', False, 3), ('t3', True, 3), ('t2', True, 2)):
+        ops.set_conv_split(split)
+        L().nc_set_split_terms(terms)
+        y = ops.conv_fwd_raw(x, w, b, 1, ks // 2)
+        dx = ops.conv_dgrad_raw(dy, w, x.shape, 1, ks // 2)
+        if name == 't2':
+            assert torch.equal(y, ops.conv_fwd_raw(x, w, b, 1, ks // 2)) and torch.equal(dx, ops.conv_dgrad_raw(dy, w, x.shape, 1, ks // 2))
+        res[name] = (err(y, ref), err(dx, refd))
+    for i, what in enumerate(('fwd', 'dgrad')):
+        (m32, r32), (m3, r3), (m2, r2) = res['fp32'][i], res['t3'][i], res['t2'][i]
+        print(case, what, 'fp32 %.2e/%.2e  three-term %.2e/%.2e  two-term %.2e/%.2e' % (m32, r32, m3, r3, m2, r2))
+        assert r2 <= 1.3 * r32 + 2e-8 and m2 <= 2.0 * m32 + 2e-7, (what, m2, r2, m32, r32)
+        assert r2 <= 1.3 * r3 + 2e-8, (what, r2, r3)
+
+
+@pytest.mark.parametrize('scale', [1e-30, 1e-12, 1e12, 1e30])
+def test_h2_range(scale):
+    """The power of two follows the tensor: inputs and weights far from 1 keep the same RELATIVE error (the fp16 terms never see the
+    magnitude), results are scaled back exactly."""
+    from neuroclear_amd import ops
+    L().nc_set_split_terms(2)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(1, 64, 16, 16, 16, device=DEV, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 0.03
+    y1 = ops.conv_fwd_raw(x, w, None, 1, 1)
+    ys = ops.conv_fwd_raw(x * scale, w, None, 1, 1)
+    yw = ops.conv_fwd_raw(x, w * 2.0 ** -40, None, 1, 1)
+    s2 = float(torch.tensor(scale).log2().round().exp2())  # compare through a power of two: exact
+    y2 = ops.conv_fwd_raw(x * s2, w, None, 1, 1)
+    assert torch.equal(y2, y1 * s2)
+    assert torch.equal(yw, y1 * 2.0 ** -40)
+    ref = F.conv3d(x.double() * scale, w.double(), padding=1)
+    assert err(ys, ref)[1] < 3e-7
+    z = ops.conv_fwd_raw(torch.zeros_like(x), w, None, 1, 1)
+    assert float(z.abs().max()) == 0.0
+
+
+def test_h2_nonfinite_inputs_follow_the_split_rule():
+    """An inf / NaN input element makes every output it touches NaN and leaves every other output bit-identical: non-finite elements are left
+    out of the tensor's maximum."""
+    from neuroclear_amd import ops
+    L().nc_set_split_terms(2)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(1, 64, 16, 16, 16, device=DEV, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 0.03
+    y = ops.conv_fwd_raw(x, w, None, 1, 1)
+    x2 = x.clone()
+    x2[0, 7, 6, 6, 6] = float('inf')
+    x2[0, 3, 0, 15, 2] = float('nan')
+    y2 = ops.conv_fwd_raw(x2, w, None, 1, 1)
+    touched = torch.zeros_like(y, dtype=torch.bool)
+    touched[0, :, 5:8, 5:8, 5:8] = True
+    touched[0, :, 0:2, 14:16, 1:4] = True
+    assert bool(torch.isnan(y2[touched]).all()) and torch.equal(y2[~touched], y[~touched])
+
+
+def rnd(seed, shape):
+    return np.random.default_rng(int(seed)).random(tuple(int(s) for s in shape), dtype=np.float32)
+
+
+@pytest.mark.parametrize('size', [16, 32])
+def test_h2_unet_inference_golden(golden_dir, size):
+    import os
+    g = np.load(os.path.join(golden_dir, 'unet_deconv_%d.npz' % size))
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), int(g['seed']), DEV))
+    x = torch.from_numpy(rnd(g['x_seed'], (1, 1, size, size, size))).to(DEV)
+    L().nc_set_split_terms(2)
+    assert L().nc_unet_deconv_fwd_terms(size, size, size) == 2
+    with torch.no_grad():
+        y = net(x)
+        assert torch.equal(y, net(x))
+    assert float(np.abs(y.cpu().numpy() - g['y']).max()) < 2e-5
+    L().nc_set_split_terms(0)   # the default: two-term in the inference forward only
+    assert L().nc_unet_deconv_fwd_terms(size, size, size) == 2
+    with torch.no_grad():
+        assert torch.equal(y, net(x))
+    L().nc_set_split_terms(3)
+    assert L().nc_unet_deconv_fwd_terms(size, size, size) == 3
+    with torch.no_grad():
+        y3 = net(x)
+    assert float((y - y3).abs().max()) < 1e-5
+
+
+def test_h2_unet_scale_groups_at_108():
+    """The halves of a concatenation carry different powers of two (InstanceNorm output: bound sqrt(voxels); transposed convolution: measured)
+    and the ratio goes into the consumer's weights.  With the transposed convolutions' weights scaled by 2^12 / 2^-12 the ratio is far from 1:
+    the two-term forward must still follow the three-term one."""
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    sd = S.state_dict_from_seed(S.unet_deconv_spec(), 4, DEV)
+    x = torch.rand((1, 1, 108, 108, 108), generator=torch.Generator().manual_seed(3)).to(DEV)
+    for f1, f2 in ((1.0, 1.0), (4096.0, 1.0 / 4096), (1.0 / 4096, 4096.0)):
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        for k in sd2:
+            if k.startswith('t_conv1'):
+                sd2[k] *= f1
+            if k.startswith('t_conv2'):
+                sd2[k] *= f2
+        net.load_state_dict(sd2)
+        out = {}
+        for terms in (3, 2):
+            L().nc_set_split_terms(terms)
+            assert L().nc_unet_deconv_fwd_terms(108, 108, 108) == terms
+            with torch.no_grad():
+                out[terms] = net(x)
+        d = float((out[2] - out[3]).abs().max())
+        print(f1, f2, 'max |two-term - three-term| = %.2e' % d, 'range', float(out[3].min()), float(out[3].max()))
+        assert d < 1e-5

@@ -281,15 +281,22 @@ def test_whole_network_inference_with_and_without_the_split_kernels():
         y_off = net(x).clone()
         ops.set_conv_split(True)
     assert (y_on - y_off).abs().max().item() < 2e-6
-    # the normalisation pass writing the three-term form itself (default) or a separate conversion pass: the same bits
+    # the normalisation pass writing the three-term form itself or a separate conversion pass: the same bits.  (The inference forward
+    # defaults to the TWO-term form since round 4 -- tests/test_gpu_h2.py; this is about the three-term one.)
     from neuroclear_amd._lib import I, lib
-    lib().nc_set_s3_fusion(I(0))
+    terms = lib().nc_get_split_terms()
+    lib().nc_set_split_terms(I(3))
     try:
+        with torch.no_grad():
+            y_on3 = net(x).clone()
+        lib().nc_set_s3_fusion(I(0))
         with torch.no_grad():
             y_sep = net(x).clone()
     finally:
         lib().nc_set_s3_fusion(I(1))
-    assert torch.equal(y_on, y_sep)
+        lib().nc_set_split_terms(I(terms))
+    assert torch.equal(y_on3, y_sep)
+    assert (y_on3 - y_on).abs().max().item() < 2e-6
 
 
 @pytest.mark.parametrize('kind', ['unet_deconv', 'deep_linear_gen'])
