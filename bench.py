@@ -17,10 +17,12 @@ Extra objects on the JSON line:
   roofline     -- for the kernel class that took most of the timed region: algorithmic FLOP / launch, measured with HIP
                   events on the launch stream inside the timed steps (neuroclear_amd.ops.prof), against the dense MFMA
                   peak of /opt/skills/guides/MI355X_MICROARCH.md for the instruction the class runs on: 157.3 TFLOP/s
-                  (fp32 MFMA), or 2500 / 6 = 416.7 TFLOP/s of fp32 products for the split-operand kernels (six bf16 MFMA
-                  products per fp32 product, csrc/conv_split.hip).
-  arithmetic / fp32_mfma_kernels -- what "f32" is computed with, and the same step with the split-operand layers back on
-                  the fp32 MFMA kernels (3 steps, same process).
+                  (fp32 MFMA), or -- for the split-operand kernels -- the 16-bit dense peak over the MFMA products one fp32
+                  product costs: 2500 / 3 = 833.3 TFLOP/s of fp32 products for the two-term fp16 form (the default since
+                  round 4, csrc/conv_s3x.hip NT = 2), 2500 / 6 = 416.7 for the three-term bf16 form (`frac_of_six_product_roof`
+                  keeps the round-3 yardstick next to `frac`).
+  arithmetic / three_term_split / fp32_mfma_kernels -- what "f32" is computed with, and the same step with the split-operand
+                  layers on the three-term form and on the fp32 MFMA kernels (3 steps each, same process, same seeds).
   cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32) on the host cores of
                   the GPU box, rank 0 and N = 1 only: full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
                   1-thread figure on a bounded 36^3 sample; inference: 140^3 cubes through
@@ -53,9 +55,10 @@ SPLIT_PRODUCTS = 6
 MFMA_SPLIT_PEAK_TFLOPS = MFMA_16BIT_PEAK_TFLOPS / SPLIT_PRODUCTS
 ARITHMETIC = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 6 bf16 MFMA products of an exact 3-term operand '
               'split (csrc/conv_s3x.hip, conv_split.hip; error vs fp64 <= the fp32 MFMA kernels\': tests/test_gpu_split.py); NC_CONV_SPLIT=0 = fp32 MFMA kernels')
-# Inference forward (nc_unet_deconv_fwd), round 4: the TWO-term fp16 form -- operands as two fp16 terms of the tensor times a power of two,
-# three MFMA products per fp32 product (csrc/conv_s3x.hip NT = 2, csrc/h2.hip).  Its roofline is the 16-bit dense peak / 3.
-ARITHMETIC_H2 = ('fp32 operands, fp32 accumulation; 3^3 convolution products as 3 fp16 MFMA products of a 2-term operand split of the tensor times '
+# Round 4, the default: the TWO-term fp16 form -- operands as two fp16 terms of the tensor times a per-tensor power of two, three MFMA products
+# per fp32 product (csrc/conv_s3x.hip NT = 2, csrc/h2.hip, k_wgrad_s3x<KS, 2, f16>).  Its roofline is the 16-bit dense peak / 3; the
+# three-term step is timed next to it (`three_term_split`), as the fp32 MFMA kernels' is (`fp32_mfma_kernels`).
+ARITHMETIC_H2 = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 3 fp16 MFMA products of a 2-term operand split of the tensor times '
                  'a per-tensor power of two (csrc/conv_s3x.hip NT = 2, csrc/h2.hip; error vs fp64 <= the three-term form\'s and the fp32 MFMA '
                  'kernels\': tests/test_gpu_h2.py); NC_SPLIT_TERMS=3 = the three-term bf16 form (6 products), NC_CONV_SPLIT=0 = fp32 MFMA kernels')
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
@@ -277,14 +280,24 @@ def run_train(args, rank, world, dev):
     if top:
         n, ms, flop = stats[top]
         ach = flop / ms / 1e9
-        peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_SPLIT_PEAK_TFLOPS if '_split_' in top else MFMA_F32_PEAK_TFLOPS
+        from neuroclear_amd._lib import lib as _l
+        two = '_split_' in top and int(_l().nc_get_split_terms()) == 2   # the two-term fp16 form: 3 MFMA products per fp32 product
+        products = 3 if two else SPLIT_PRODUCTS
+        peak = MFMA_16BIT_PEAK_TFLOPS if '_lp_' in top else MFMA_16BIT_PEAK_TFLOPS / products if '_split_' in top else MFMA_F32_PEAK_TFLOPS
         extra = {}
         if '_split_' in top:
-            extra = dict(peak_is='bf16 dense MFMA peak %.0f / %d MFMA products per fp32 product' % (MFMA_16BIT_PEAK_TFLOPS, SPLIT_PRODUCTS),
-                         bf16_tflops=round(ach * SPLIT_PRODUCTS, 1), vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
-        roof = dict(bound='mfma', kernel=KERNEL_OF.get(top, top), kernel_class=top, achieved=round(ach, 2),
+            extra = dict(peak_is='%s dense MFMA peak %.0f / %d MFMA products per fp32 product' % ('fp16' if two else 'bf16', MFMA_16BIT_PEAK_TFLOPS, products),
+                         split_terms=2 if two else 3, mfma_tflops=round(ach * products, 1),
+                         frac_of_six_product_roof=round(ach / MFMA_SPLIT_PEAK_TFLOPS, 4), vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
+        kname = KERNEL_OF.get(top, top)
+        if two:
+            kname = kname.replace('k_conv_s3x<3,*>', 'k_conv_s3x<3,*,2>').replace('k_conv_s3x<5,*>', 'k_conv_s3x<5,*,2>').replace(
+                'k_wgrad_s3x<3>', 'k_wgrad_s3x<3,2,f16>').replace('k_wgrad_s3x<5>', 'k_wgrad_s3x<5,2,f16>')
+        roof = dict(bound='mfma', kernel=kname, kernel_class=top, achieved=round(ach, 2),
                     peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
-                    traffic=pmc_traffic(top, crop, args.batch), traffic_source=TRAFFIC_SOURCE, launches=n, avg_launch_ms=round(ms / n, 4),
+                    traffic=None if two else pmc_traffic(top, crop, args.batch),
+                    traffic_source='not collected for the two-term kernels yet (the committed PMC passes are of the three-term ones)' if two else TRAFFIC_SOURCE,
+                    launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
@@ -490,6 +503,17 @@ def main():
                                                 a2.steps + a2.warmup, args.steps + args.warmup))
         finally:
             _ops.set_conv_split(True)
+        if int(_lib().nc_get_split_terms()) == 2:
+            # ... and on the THREE-term bf16 form of the split (six MFMA products per fp32 product: rounds 2-3), same seeds, same data
+            _lib().nc_set_split_terms(3)
+            try:
+                dt3, units3, _, cfg3 = run_train(a2, rank, world, dev)
+                f1, f3 = cfg['first_step_losses'], cfg3['first_step_losses']
+                out['three_term_split'] = dict(ms_per_step=dt3 / a2.steps * 1e3, value=units3 / dt3, unit='voxels/s', steps=a2.steps,
+                                               first_step_losses=f3,
+                                               first_step_max_rel_diff=max(abs(f1[k] - f3[k]) / max(abs(f3[k]), 1e-12) for k in f3))
+            finally:
+                _lib().nc_set_split_terms(2)
     cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if cpu and train_like:
         try:

@@ -392,14 +392,18 @@ void nc_set_conv_split(int on); /* 1 (default; or the value of NC_CONV_SPLIT at 
                                   * whole-network calls built on them take this path for the shapes it covers; 0: the fp32
                                   * MFMA kernels (v_mfma_f32_32x32x2_f32) serve those shapes */
 int nc_get_conv_split(void);
-/* The TWO-TERM form (round 4; csrc/conv_s3x.hip NT = 2, csrc/h2.hip, s3_common.hpp): each operand as two fp16 terms of the tensor times a
- * power of two (chosen per tensor from its largest finite magnitude, or from a bound known by construction; results scaled back exactly) and
- * THREE fp16 MFMA products per fp32 product -- half the matrix work of the three-term bf16 form at the same error against fp64
- * (tests/test_gpu_h2.py).  terms = 3: three-term everywhere; 2: two-term wherever it exists -- nc_conv_fwd / nc_conv_dgrad from fp32 operands
- * and the inference forward nc_unet_deconv_fwd; 0 (default; NC_SPLIT_TERMS at load time): two-term in nc_unet_deconv_fwd only, so that the
- * layer-by-layer calls stay bit-identical to the training calls, which are three-term throughout.  In nc_unet_deconv_fwd InstanceNorm outputs
- * are converted with the power of two their bound sqrt(voxels) allows, the transposed convolutions' outputs with a measured one, and the
- * ratio of the two is folded into the consuming layer's weights. */
+/* The TWO-TERM form (round 4; csrc/conv_s3x.hip NT = 2, csrc/h2.hip, s3_common.hpp; the default): each operand as two fp16 terms of the tensor
+ * times a power of two (chosen per tensor from its largest finite magnitude, or from a bound known by construction; results scaled back
+ * exactly) and THREE fp16 MFMA products per fp32 product -- half the matrix work of the three-term bf16 form at the same error against fp64
+ * (tests/test_gpu_h2.py).  The price is fp16's exponent range WITHIN one tensor: elements below 2^-17 of the tensor's largest magnitude keep
+ * fewer than 22 bits, below 2^-39 they vanish (fp32: 2^-126) -- immaterial for normalised activations and their gradients, wrong for a tensor
+ * that mixes magnitudes 1e12 apart; nc_set_split_terms(3) is for those.  terms = 2 (default; NC_SPLIT_TERMS at load time): two-term wherever
+ * it exists -- nc_conv_fwd / _dgrad / _wgrad / _bwd of the covered shapes (channels % 64) and the whole-network training and inference calls
+ * built on them; 3: three-term everywhere; 0: two-term in the inference forward nc_unet_deconv_fwd only.  The explicit S3 entry points below
+ * (nc_to_s3, nc_conv_*_split) are three-term by definition.  In the whole-network calls InstanceNorm outputs are converted with the power of
+ * two their bound sqrt(voxels) allows, the norm's backward with a bound from its own first pass, everything else with a measured one; the
+ * ratio between the halves of a concatenation is folded into the consuming layer's weights.  Do not change the setting between a training
+ * forward and its backward (the backward then re-converts what the forward kept). */
 void nc_set_split_terms(int terms);
 int nc_get_split_terms(void);
 int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the

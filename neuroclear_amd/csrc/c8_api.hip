@@ -162,6 +162,7 @@ int nc_conv_fwd_split(const float* x, const void* xs, const float* w, const floa
   if ((!x && !xs) || !w || !y) { set_error("conv_fwd_split: null pointer"); return NC_ERR_ARG; }
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_fwd_supported(d)) { set_error("conv_fwd_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(0, 1, d, 1, (hipStream_t)stream);
+  ForceThreeTerm f3;
   return conv_fwd_s3(x, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -171,6 +172,7 @@ int nc_conv_dgrad_split(const float* dy, const void* dys, const float* w, float*
   if ((!dy && !dys) || !w || !dx) { set_error("conv_dgrad_split: null pointer"); return NC_ERR_ARG; }
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_dgrad_supported(d)) { set_error("conv_dgrad_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(1, 1, d, 1, (hipStream_t)stream);
+  ForceThreeTerm f3;
   return conv_dgrad_s3(dy, dys, w, dx, d, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -180,6 +182,7 @@ int nc_conv_wgrad_split(const float* x, const void* xs, const float* dy, const v
   if ((!x && !xs) || (!dy && !dys) || !dw) { set_error("conv_wgrad_split: null pointer"); return NC_ERR_ARG; }
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || !s3_wgrad_supported(d)) { set_error("conv_wgrad_split: shape not covered"); return NC_ERR_SHAPE; }
   ProfScope ps(2, 9, d, 0, (hipStream_t)stream);
+  ForceThreeTerm f3;
   return conv_wgrad_s3(x, xs, dy, dys, dw, d, ws, ws_bytes, (hipStream_t)stream);
 }
 

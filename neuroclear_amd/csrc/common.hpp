@@ -187,6 +187,13 @@ size_t s3_ws_bytes(const ConvDims& d);
 size_t s3_tensor_bytes(int N, int C, long S);
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
 int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
+// (S3 or H2 by the consuming layer d: conv_split.hip)
+bool conv_layer_h2(const ConvDims& d);
+// the explicit S3 entry points (nc_conv_*_split, operands from nc_to_s3) are three-term by definition, whatever nc_set_split_terms says
+struct ForceThreeTerm { ForceThreeTerm(); ~ForceThreeTerm(); };
+int operand_into(const ConvDims& d, const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
+int act_operand(const ConvDims& d, const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C,
+                long S, int ctot, int c0, hipStream_t s);
 int act_split3(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S,
                int ctot, int c0, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
@@ -208,15 +215,18 @@ size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT = 3);
 // NT = 2 (two-term fp16 split, three products; s3_common.hpp) from the fp32 input: ws >= s3x_h2_ws_bytes
 void s3x_set_terms(int t);
 int s3x_get_terms();
-size_t s3x_h2_ws_bytes(int N, int Cin, long S, int Kout, int KS);
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
                 int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s);
-int conv_s3x_h2_from_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
-                         long si, int flip, void* ws, size_t wsb, hipStream_t s);
 // h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
+// an H2 tensor of `elems` elements = elems * 4 bytes of units + (at this byte offset) 256 bytes of cells: [0] the cell of the channels' first
+// half, [1] of the second half (a concatenation converted in two parts; equal to [0] otherwise) -- inside the elems * 6 bytes of an S3 tensor
+inline size_t h2_cells_offset(size_t elems) { return (elems * 4 + 255) & ~(size_t)255; }
+inline unsigned* h2_cells_of(const void* t, size_t elems) { return (unsigned*)((char*)const_cast<void*>(t) + h2_cells_offset(elems)); }
+int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s);
 int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
-int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s);
+int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2 = nullptr);
 int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s);
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
                 int c0, const unsigned* cell, hipStream_t s);

@@ -27,6 +27,13 @@
 // every plane size, z-neighbours enumerated side by side).  In isolation the 27^3 layers gained 25 %; in the step it made no difference
 // and the 900^3 inference ran 2.3 % slower (pad rows computed and dropped; same-box A/B) -- tiles stay inside one output plane.
 // Accuracy: as in conv_split.hip the MFMA accumulators restart every `flush` k-steps and the pieces are added in fp32.
+//
+// Round 4: template parameter NT.  NT = 3 is the kernel above.  NT = 2 is the same kernel on the TWO-TERM fp16 form of the operands ("H2",
+// s3_common.hpp / h2.hip): each operand = two fp16 terms of the tensor times a per-tensor power of two, THREE products a1 b0, a0 b1, a0 b0 per
+// fp32 product on v_mfma_f32_16x16x32_f16, the sums scaled back (exactly) on their way out.  Four A fragments and two B fragments per k-step
+// instead of six and three, bricks of two terms; everything else unchanged.  64 -> 64 at 108^3: 3^3 1.14 -> 0.67 ms, 5^3 4.67 -> 2.63 ms,
+// error against fp64 as the three-term form's (tests/test_gpu_h2.py).  A forward input may be a concatenation whose halves were converted
+// with different powers of two: the ratio is folded into the weights of the second half's input channels when they are packed.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -298,9 +305,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     brsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   // NT = 2: both operands were scaled by powers of two before the split; the sums are scaled back (exactly) on their way out
-  // (one factor after the other: their product could leave the fp32 range where neither does)
+  // (two factors of about equal exponent, one after the other: no intermediate leaves the fp32 range unless the result does)
   float oscx = 1.f, oscw = 1.f;
-  if constexpr (NT == 2) { oscx = h2_inv_scale(*p.amax_x); oscw = h2_inv_scale(*p.amax_w); }
+  if constexpr (NT == 2) { const float2 f = h2_unscale2(*p.amax_x, *p.amax_w); oscx = f.x; oscw = f.y; }
   u32x4 bv[2];
   auto load_bias = [&](const XTile& t) __attribute__((always_inline)) {
     const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
@@ -580,12 +587,12 @@ size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
   return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024;
 }
 
-// NC_SPLIT_TERMS / nc_set_split_terms: which form of the split the fp32 3^3 / 5^3 layers use where both exist -- the three-term bf16 form (six
-// MFMA products per fp32 product) or the two-term fp16 form (three; s3_common.hpp).  3: three-term everywhere; 2: two-term everywhere it
-// exists (the layer-by-layer forward / data gradient from fp32 operands, and the inference forward nc_unet_deconv_fwd); 0 (default): two-term in
-// the inference forward only -- the layer-by-layer calls stay bit-identical to the training calls, which are three-term throughout.
-static std::atomic<int> g_terms{getenv("NC_SPLIT_TERMS") ? atoi(getenv("NC_SPLIT_TERMS")) : 0};
-void s3x_set_terms(int t) { g_terms = (t == 2 || t == 3) ? t : 0; }
+// NC_SPLIT_TERMS / nc_set_split_terms: which form of the split the fp32 3^3 / 5^3 layers use -- the two-term fp16 form (three MFMA products per
+// fp32 product; s3_common.hpp, h2.hip) or the three-term bf16 form (six).  2 (default): two-term wherever it exists -- forward, data gradient
+// and weight gradient, layer by layer and in the whole-network training / inference calls; 3: three-term everywhere; 0: two-term in the
+// inference forward nc_unet_deconv_fwd only.  The explicit S3 entry points (nc_conv_*_split, nc_to_s3) are three-term by definition.
+static std::atomic<int> g_terms{getenv("NC_SPLIT_TERMS") ? atoi(getenv("NC_SPLIT_TERMS")) : 2};
+void s3x_set_terms(int t) { g_terms = (t == 0 || t == 3) ? t : 2; }
 int s3x_get_terms() { return g_terms; }
 
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
@@ -595,10 +602,6 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if ((long)D * H * W * 48 >= (1l << 31)) return false;  // byte offsets inside one block's three terms stay below the kOut mark
   if ((long)H * (W + KS - 1) + 4096 >= (1l << 31)) return false;
   return x_plan(N, D, H, W, Kout / 64, KS).ok;
-}
-
-size_t s3x_h2_ws_bytes(int N, int Cin, long S, int Kout, int KS) {
-  return 256 + (((size_t)N * Cin * S * 4 + 255) & ~(size_t)255) + s3x_packed_bytes(Cin, Kout, KS, 2) + 256;
 }
 
 // The convolution from an H2 input (h2.hip).  cell_a: the input's cell; a concatenated input whose channels [split_c, Cin) were converted with
@@ -641,20 +644,6 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
     if (e) return e;
   }
   return NC_OK;
-}
-
-// ... from the fp32 input: ws = [cells | H2 input | packed weights]
-int conv_s3x_h2_from_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
-                         long si, int flip, void* ws, size_t wsb, hipStream_t s) {
-  const long S = (long)D * H * W;
-  if (!ws || wsb < s3x_h2_ws_bytes(N, Cin, S, Kout, KS)) { set_error("conv_s3x_h2: workspace too small"); return NC_ERR_WS; }
-  unsigned* cells = (unsigned*)ws;
-  void* xs = (char*)ws + 256;
-  void* wp_ws = (char*)xs + (((size_t)N * Cin * S * 4 + 255) & ~(size_t)255);
-  if (int e = h2_zero_cells(cells, 2, s)) return e;
-  if (int e = h2_absmax(x, (long)N * Cin * S, cells, s)) return e;
-  if (int e = split2h_into(x, (long)Cin * S, xs, N, Cin, S, Cin, 0, cells, s)) return e;
-  return conv_s3x_h2(xs, cells, nullptr, Cin, w, bias, y, N, Cin, D, H, W, Kout, KS, so, si, flip, cells + 1, wp_ws, s);
 }
 
 // xs: S3 input; wp_ws: >= s3x_packed_bytes scratch for the packed weights

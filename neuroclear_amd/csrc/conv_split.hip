@@ -487,17 +487,33 @@ int launch_s3(const SParams& p, int lds, hipStream_t s) {
   return check_launch("conv_s3");
 }
 
+// Does this layer use the two-term fp16 operand form (H2) in forward, data gradient AND weight gradient?  (nc_set_split_terms(2) and all
+// three kernels cover it.)  Every producer and consumer of a layer's operands decides with THIS predicate.
+bool s3_layer_h2(const ConvDims& d);
+
 // xs_keep (only without xs_pre): the converted operand is written THERE instead of into the workspace -- the caller keeps it (the
 // weight gradient of the same layer wants the same S3 tensor)
 int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
-           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr) {
+           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr, bool h2 = false) {
   const int KS = d.kd;
   const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
-  // NC_SPLIT_TERMS=2: the two-term fp16 form of the tap-stream kernel, from the fp32 input (no S3 tensor to share with anybody)
-  if (s3x_get_terms() == 2 && !xs_pre && !xs_keep && s3x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS) &&
-      wsb >= s3x_h2_ws_bytes(d.N, Cin, S, Kout, KS))
-    return conv_s3x_h2_from_f32(x, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, ws, wsb, s);
+  // The two-term fp16 form (nc_set_split_terms(2); the caller decided with s3_layer_h2): xs_pre / xs_keep / the workspace hold H2 tensors, cells at
+  // their tails (common.hpp h2_cells_offset); a forward input may be a concatenation converted in two halves (cells [0], [1])
+  if (h2) {
+    const size_t ex = (size_t)d.N * Cin * S;
+    const size_t xb = (xs_pre || xs_keep) ? 0 : h2_cells_offset(ex) + 256;
+    if (!ws || wsb < xb + 256 + s3x_packed_bytes(Cin, Kout, KS, 2) + 256) { set_error("conv_s3 (two-term): workspace too small"); return NC_ERR_WS; }
+    void* xs = xs_pre ? const_cast<void*>(xs_pre) : xs_keep ? xs_keep : ws;
+    unsigned* cells = h2_cells_of(xs, ex);
+    if (!xs_pre) {
+      if (int e = h2_zero_cells(cells, 2, s)) return e;
+      if (int e = h2_absmax(x, (long)ex, cells, s, cells + 1)) return e;
+      if (int e = split2h_into(x, (long)Cin * S, xs, d.N, Cin, S, Cin, 0, cells, s)) return e;
+    }
+    return conv_s3x_h2(xs, cells, cells + 1, flip ? Cin : Cin / 2, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip,
+                       (unsigned*)((char*)ws + xb), (char*)ws + xb + 256, s);
+  }
   const size_t xb = (xs_pre || xs_keep) ? 0 : align256((size_t)d.N * Cin * S * 6);
   const size_t wb = align256(s_packed_bytes(Cin, Kout, KS));
   if (!ws || wsb < xb + wb + 256) { set_error("conv_s3: workspace too small"); return NC_ERR_WS; }
@@ -1017,9 +1033,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
       // One k-step: 4 NT A + NT B fragments up front in the order the products need them, then per unit the reads of the next unit's B
       // fragments spread over its MFMAs.  The order is pinned with sched_group_barrier: left alone the scheduler sinks every read next to
       // its first use and the k-step pays an LDS round trip a dozen times.
-      constexpr int NP = NT == 3 ? 6 : 1;  // products per (row block, unit), smallest first: (term of A, term of B)
-      constexpr int TA[6] = {NT - 1, 1, 0, 1, 0, 0};
-      constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+      constexpr int NP = NT == 3 ? 6 : NT == 2 ? 3 : 1;  // products per (row block, unit), smallest first: (term of A, term of B)
+      constexpr int TA[6] = {NT - 1, NT == 3 ? 1 : 0, 0, 1, 0, 0};
+      constexpr int TB[6] = {0, 1, NT == 3 ? 2 : 0, 0, 1, 0};
       i32x4 A[4][NT], B[2][NT];
       auto read_b1 = [&](i32x4& Bf, int j, int t) __attribute__((always_inline)) {
         Bf = tr_frag(lds_raw, sb[j] + t * b_term + bo[0], sb[j] + t * b_term + bo[1]);
@@ -1045,10 +1061,19 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
           for (int m = 0; m < NP; ++m)
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[j][a] = mfma16<DT>(A[a][TA[m]], B[j & 1][TB[m]], acc[j][a]);
-#pragma unroll
-          for (int k = 0; k < NP; ++k) {
+          if constexpr (NT == 2) {  // the 4 reads of the next unit's fragments over this unit's 12 MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NT == 3 ? 1 : 2, 0);
+            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              if (j + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NT == 3 ? 1 : 2, 0);
+            }
           }
         }
       }
@@ -1070,8 +1095,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
 // 128-byte run of c); its 8 lane groups each add a contiguous eighth of the slots in slot order, and the eight sums are added in group
 // order: a fixed order (deterministic), with eight loads in flight per output instead of one dependent chain of several hundred
 // (the one-thread-per-output form ran at ~1 TB/s: 0.85 ms of the 108^3 step).
+// xcells != NULL (H2 operands): the sums are scaled back by 2^-(kx + ky), kx per half of the input channels (h2.hip)
 __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict__ part, float* __restrict__ dw, int C, int T3, int TW,
-                                                         int nct, int npairs, int nwp, int NF, long total) {
+                                                         int nct, int npairs, int nwp, int NF, long total,
+                                                         const unsigned* __restrict__ xcells = nullptr, const unsigned* __restrict__ ycell = nullptr) {
   __shared__ float red[8][32];
   const int o = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + o;  // (k, tap, c): c fastest -> coalesced partial reads
@@ -1097,6 +1124,7 @@ __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict
     float r = red[0][o];
 #pragma unroll
     for (int g = 1; g < 8; ++g) r += red[g][o];
+    if (xcells) { const float2 f = h2_unscale2(xcells[c >= C / 2 ? 1 : 0], *ycell); r = r * f.x * f.y; }
     dw[((long)k * C + c) * T3 + t] = r;
   }
 }
@@ -1145,6 +1173,16 @@ WsPlan ws_plan(const ConvDims& d, int NT = 3) {
   return best;
 }
 
+static thread_local int tl_force3 = 0;
+bool s3_layer_h2(const ConvDims& d) {
+  if (s3x_get_terms() != 2 || tl_force3) return false;
+  if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5) || d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd)
+    return false;
+  if (d.C % 64 || d.K % 64 || (d.K / 64) * (d.C / 32) * (d.kd == 5 ? 5 : 1) > 256) return false;
+  if (!s3x_supported(d.N, d.C, d.D, d.H, d.W, d.K, d.kd) || !s3x_supported(d.N, d.K, d.D, d.H, d.W, d.C, d.kd)) return false;
+  return ws_kv(d, 2) == 32 && ws_plan(d, 2).ok;
+}
+
 bool ws_shape_ok(const ConvDims& d) {
   if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
   if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
@@ -1171,8 +1209,61 @@ int ws_nwp(const ConvDims& d, const WsPlan& pl, int npairs) {
   return nwp;
 }
 
+// the weight gradient on H2 operands (two fp16 terms, three products): k_wgrad_s3x<KS, 2, f16>; xs_pre / dys_pre: H2 tensors with their cells, or NULL
+// (converted into the workspace with measured cells)
+int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
+              hipStream_t s) {
+  const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
+  const WsPlan pl = ws_plan(d, 2);
+  if (!pl.ok || ws_kv(d, 2) != 32) { set_error("wgrad_s3 (two-term): shape not covered"); return NC_ERR_SHAPE; }
+  const long S = (long)d.D * d.H * d.W;
+  const size_t ex = (size_t)d.N * d.C * S, ey = (size_t)d.N * d.K * S;
+  const size_t xb = xs_pre ? 0 : h2_cells_offset(ex) + 256;
+  const size_t yb = dys_pre ? 0 : h2_cells_offset(ey) + 256;
+  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  const int nwp = ws_nwp(d, pl, npairs);
+  const long steps = (long)d.N * pl.YB * pl.XB * d.D;
+  const int NF = ws_nf(steps, nwp);
+  const size_t pb = align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
+  if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3 (two-term): workspace too small"); return NC_ERR_WS; }
+  void* xs = xs_pre ? const_cast<void*>(xs_pre) : ws;
+  void* dys = dys_pre ? const_cast<void*>(dys_pre) : (void*)((char*)ws + xb);
+  float* part = (float*)((char*)ws + xb + yb);
+  unsigned* xc = h2_cells_of(xs, ex);
+  unsigned* yc = h2_cells_of(dys, ey);
+  if (!xs_pre) {
+    if (int e = h2_zero_cells(xc, 2, s)) return e;
+    if (int e = h2_absmax(x, (long)ex, xc, s, xc + 1)) return e;
+    if (int e = split2h_into(x, (long)d.C * S, xs, d.N, d.C, S, d.C, 0, xc, s)) return e;
+  }
+  if (!dys_pre) {
+    if (int e = h2_zero_cells(yc, 2, s)) return e;
+    if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
+    if (int e = split2h_into(dy, (long)d.K * S, dys, d.N, d.K, S, d.K, 0, yc, s)) return e;
+  }
+  WsParams p{};
+  p.xs = (const uint4*)xs; p.dys = (const uint4*)dys; p.part = part; p.zeros = nullptr;
+  p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
+  p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
+  p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
+  p.F = ws_flush_steps(); p.NF = NF;
+  p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  if (int e = raise_dyn_lds((k_wgrad_s3x<3, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
+  if (int e = raise_dyn_lds((k_wgrad_s3x<5, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
+  const int lds = NS * pl.xslot + 2 * pl.dybuf;
+  if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  else hipLaunchKernelGGL((k_wgrad_s3x<5, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+  if (int e = check_launch("wgrad_h2")) return e;
+  const long total = (long)d.K * d.C * T3;
+  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, (const float*)part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
+                     NF, total, (const unsigned*)xc, (const unsigned*)yc);
+  return check_launch("wgrad_h2_reduce");
+}
+
 int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
            hipStream_t s) {
+  if (s3_layer_h2(d)) return run_ws_h2(x, xs_pre, dy, dys_pre, dw, d, ws, wsb, s);
   const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
   const WsPlan pl = ws_plan(d);
   const long S = (long)d.D * d.H * d.W;
@@ -1313,7 +1404,16 @@ int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, floa
   const long S = (long)d.D * d.H * d.W;
   const size_t A = align256((size_t)d.N * d.K * S * 6);
   if (!ws || wsb < s3_bwd_ws_bytes(d)) { set_error("conv_bwd_s3: workspace too small"); return NC_ERR_WS; }
-  if (phase == 0) return split3_to(dy, ws, d.N, d.K, S, s);
+  if (phase == 0) {
+    if (s3_layer_h2(d)) {  // dY as an H2 tensor (measured cell) where the S3 tensor would stand
+      const size_t ey = (size_t)d.N * d.K * S;
+      unsigned* yc = h2_cells_of(ws, ey);
+      if (int e = h2_zero_cells(yc, 2, s)) return e;
+      if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
+      return split2h_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, yc, s);
+    }
+    return split3_to(dy, ws, d.N, d.K, S, s);
+  }
   if (phase == 1) return conv_dgrad_s3(dy, ws, w, dx, d, (char*)ws + A, wsb - A, s);
   return conv_wgrad_s3(x, xs, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
 }
@@ -1337,10 +1437,38 @@ int act_split3(const float* x, const float* mean, const float* rstd, float slope
   return check_launch("act_split3");
 }
 
+// The operand form of a layer's input, S3 or H2, by s3_layer_h2 of the CONSUMING layer (d).  `into`: channels [c0, c0 + C) of the ctot-channel
+// operand from an fp32 tensor (H2: measured cell of that half; a whole tensor sets both cells); `act`: the same from the normalisation pass
+// (H2: the cell is the bound sqrt(S) of an InstanceNorm output).
+int operand_into(const ConvDims& d, const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s) {
+  if (!s3_layer_h2(d)) return split3_into(x, xstride, xs, N, C, S, ctot, c0, s);
+  if (C != ctot && 2 * C != ctot) { set_error("operand_into: a part must be the whole tensor or a half"); return NC_ERR_SHAPE; }
+  unsigned* cells = h2_cells_of(xs, (size_t)N * ctot * S);
+  unsigned* mine = cells + (c0 ? 1 : 0);
+  if (int e = h2_zero_cells(mine, C == ctot ? 2 : 1, s)) return e;
+  for (int n = 0; n < N; ++n)
+    if (int e = h2_absmax(x + (long)n * xstride, (long)C * S, mine, s, C == ctot ? cells + 1 : nullptr)) return e;
+  return split2h_into(x, xstride, xs, N, C, S, ctot, c0, mine, s);
+}
+int act_operand(const ConvDims& d, const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C,
+                long S, int ctot, int c0, hipStream_t s) {
+  if (!s3_layer_h2(d)) return act_split3(x, mean, rstd, slope, y, ystride, ys, N, C, S, ctot, c0, s);
+  if (C != ctot && 2 * C != ctot) { set_error("act_operand: a part must be the whole tensor or a half"); return NC_ERR_SHAPE; }
+  unsigned* cells = h2_cells_of(ys, (size_t)N * ctot * S);
+  unsigned* mine = cells + (c0 ? 1 : 0);
+  if (int e = h2_set_cell(mine, sqrtf((float)S), s)) return e;
+  if (C == ctot)
+    if (int e = h2_set_cell(cells + 1, sqrtf((float)S), s)) return e;
+  return act_split2h(x, mean, rstd, slope, y, ystride, ys, N, C, S, ctot, c0, mine, s);
+}
+bool conv_layer_h2(const ConvDims& d) { return s3_layer_h2(d); }
+ForceThreeTerm::ForceThreeTerm() { ++tl_force3; }
+ForceThreeTerm::~ForceThreeTerm() { --tl_force3; }
+
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s, void* xs_keep) {
   const int T3 = d.kd * d.kh * d.kw;
-  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, xs_keep);
+  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, xs_keep, s3_layer_h2(d));
 }
 
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
@@ -1348,7 +1476,7 @@ int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, c
   ConvDims t = d;
   t.C = d.K; t.K = d.C;
   const int T3 = d.kd * d.kh * d.kw;
-  return run_s3(dy, dys, w, nullptr, dx, t, d.K, d.C, T3, (long)d.C * T3, 1, ws, wsb, s);
+  return run_s3(dy, dys, w, nullptr, dx, t, d.K, d.C, T3, (long)d.C * T3, 1, ws, wsb, s, nullptr, s3_layer_h2(d));
 }
 
 }  // namespace nc

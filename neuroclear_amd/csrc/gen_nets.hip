@@ -157,12 +157,14 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   // the S3 form straight into the consumer's slot of `saved` (xs3[i]) instead of a separate conversion pass over the fp32 tensor
   // (k_act_split3; a block fed by a max-pool still converts inside conv_fwd_keep).  NC_S3_TRAIN_FUSE=0: every block converts for itself.
   static const bool fuse_on = !(getenv("NC_S3_TRAIN_FUSE") && atoi(getenv("NC_S3_TRAIN_FUSE")) == 0);
-  bool use[10], pre[10];
+  bool use[10], pre[10], h2l[10];  // h2l: the block's operands in the two-term form (nc_set_split_terms(2); conv_split.hip s3_layer_h2)
+  ConvDims cd[10];
   for (int i = 0; i < 10; ++i) {
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     use[i] = fuse_on && i >= 1 && conv_keep_supported(N, b.C, d[0], d[1], d[2], b.K, 3);
     pre[i] = false;
+    h2l[i] = make_dims(cd[i], N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1) && use[i] && conv_layer_h2(cd[i]);
   }
   // conv (3^3, pad 1) -> raw; statistics; normalise + ReLU into `out`, where sample n's K planes start at
   // out + n * out_stride (out_stride = K * S for a dense tensor, Ctot * S for a half of a concat buffer).
@@ -175,15 +177,17 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
     if (pre[i]) {  // the producers left the S3 input in saved
       NC_TRY(conv_fwd_pre(V + p.xs3[i], P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream));
       kept_mask |= 1u << i;
+      if (h2l[i]) kept_mask |= 1u << (16 + i);  // (bits 16..: the kept copy is an H2 tensor -- a backward under another setting of the switch ignores it)
     } else {
       bool kept1 = false;
       NC_TRY(conv_fwd_keep(in, P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream,
                            i >= 1 ? (void*)(V + p.xs3[i]) : nullptr, &kept1));
       if (kept1) kept_mask |= 1u << i;
+      if (kept1 && i >= 1 && conv_layer_h2(cd[i])) kept_mask |= 1u << (16 + i);
     }
     NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
     if (to >= 0 && use[to]) {  // fp32 (the backward of the pool / the fallback paths read it) AND the consumer's S3 operand in one pass
-      NC_TRY(act_split3(V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, (long)out_stride, V + p.xs3[to], N, b.K, S, to_ctot, 0, hs));
+      NC_TRY(act_operand(cd[to], V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, (long)out_stride, V + p.xs3[to], N, b.K, S, to_ctot, 0, hs));
       if (to_ctot == b.K) pre[to] = true;  // (a concat input is complete once its second half has been converted, below)
       return NC_OK;
     }
@@ -215,25 +219,26 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   for (int n = 0; n < N; ++n) {  // t_conv2 writes the second half of cat2
     if (ct2)
       NC_TRY(nc_convT_k2s2_fwd_split(V + p.b3 + (size_t)n * 256 * Sq, nullptr, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
-                                     use[7] ? (char*)(V + p.xs3[7]) + (size_t)n * 256 * Sh * 6 : nullptr, 256, 128, 1, 256, d2[0], d2[1], d2[2], 128, cws,
+                                     use[7] && !h2l[7] ? (char*)(V + p.xs3[7]) + (size_t)n * 256 * Sh * 6 : nullptr, 256, 128, 1, 256, d2[0], d2[1], d2[2], 128, cws,
                                      p.conv_ws, stream));
     else
       NC_TRY(nc_convT_k2s2_fwd(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
                                1, 256, d2[0], d2[1], d2[2], 128, stream));
   }
   if (use[7]) {  // ... and its S3 form completes block 7's input (the first half came from block 3's normalisation pass)
-    if (!ct2) NC_TRY(split3_into(V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
+    // (two-term form: the transposed convolution's half is measured after the fact -- its power of two cannot be known while it is written)
+    if (!ct2 || h2l[7]) NC_TRY(operand_into(cd[7], V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
     pre[7] = true;
   }
   NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh, 8, 128));
   NC_TRY(block(8, V + p.e2a, V + p.e2b, (size_t)128 * Sh, -1, 0));
   const bool ct1 = nc_convT_k2s2_split_active(1, 128, d1[0], d1[1], d1[2], 64) &&
                    p.conv_ws >= nc_convT_k2s2_split_ws_bytes(1, 128, d1[0], d1[1], d1[2], 64);
-  const bool ct_s3 = use[9] && (ct1 || convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64));  // t_conv1 writes the S3 form of its output itself
+  const bool ct_s3 = use[9] && !h2l[9] && (ct1 || convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64));  // t_conv1 writes the S3 form of its output itself
   for (int n = 0; n < N; ++n) {  // t_conv1 writes the second half of cat1
     if (ct1)
       NC_TRY(nc_convT_k2s2_fwd_split(V + p.e2b + (size_t)n * 128 * Sh, nullptr, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
-                                     use[9] ? (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6 : nullptr, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, cws,
+                                     use[9] && !h2l[9] ? (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6 : nullptr, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, cws,
                                      p.conv_ws, stream));
     else if (ct_s3)
       NC_TRY(convT_fwd_s3(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
@@ -243,7 +248,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
                                1, 128, d1[0], d1[1], d1[2], 64, stream));
   }
   if (use[9]) {
-    if (!ct_s3) NC_TRY(split3_into(V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
+    if (!ct_s3) NC_TRY(operand_into(cd[9], V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
     pre[9] = true;
   }
   NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S, -1, 0));
@@ -283,12 +288,17 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     const long Sl = p.S[b.lvl];
-    const void* xs = (kept_mask >> i) & 1 ? (const void*)(V + p.xs3[i]) : nullptr;
+    ConvDims cdk;
+    const bool now_h2 = make_dims(cdk, N, b.C, d[0], d[1], d[2], b.K, 3, 3, 3, 1, 1) && conv_layer_h2(cdk);
+    const void* xs = ((kept_mask >> i) & 1) && (((kept_mask >> (16 + i)) & 1) != 0) == now_h2 ? (const void*)(V + p.xs3[i]) : nullptr;
     // the norm's backward writes the convolution's dY straight in S3 form at the head of the convolution workspace (where the
     // conversion phase of the split-operand backward would put it): no fp32 tensor, no conversion pass
     if (fuse_bwd && i >= 1 && conv_bwd_pre_supported(N, b.C, d[0], d[1], d[2], b.K, 3, gin != nullptr, p.conv_ws) &&
         instnorm_bwd_s3_supported(N, b.K, Sl)) {
-      NC_TRY(instnorm_act_bwd_dbias_s3(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
+      if (now_h2)
+        NC_TRY(instnorm_act_bwd_dbias_h2(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
+      else
+        NC_TRY(instnorm_act_bwd_dbias_s3(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
       return conv_bwd_pre(in, xs, P + o.w[i], gin, DP + o.w[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
     }
     NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
@@ -426,6 +436,8 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
     else
       NC_TRY(nc_conv_fwd(in, params + p.w[i], nullptr, out, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
     if (kept) kept_mask |= 1u << i;
+    ConvDims cdl;
+    if (kept && make_dims(cdl, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2) && conv_layer_h2(cdl)) kept_mask |= 1u << (16 + i);
     in = out;
   }
   if (kept) *kept = kept_mask;
@@ -447,8 +459,11 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     const LLayer& l = kLL[i];
     const float* in = i == 0 ? x : saved + p.act[i - 1];
     float* gin = i == 0 ? dx : G + p.g[i & 1];
+    ConvDims cdl;
+    const bool now_h2 = make_dims(cdl, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2) && conv_layer_h2(cdl);
+    const bool have = ((kept_mask >> i) & 1) && (((kept_mask >> (16 + i)) & 1) != 0) == now_h2;
     if (l.k > 1)
-      NC_TRY(conv_bwd_keep(in, (kept_mask >> i) & 1 ? (const void*)(saved + p.xs3[i]) : nullptr, g, params + p.w[i], gin, dparams + p.w[i],
+      NC_TRY(conv_bwd_keep(in, have ? (const void*)(saved + p.xs3[i]) : nullptr, g, params + p.w[i], gin, dparams + p.w[i],
                            N, l.C, S0, S1, S2, l.K, l.k, cws, p.conv_ws, stream));
     else
       NC_TRY(nc_conv_bwd(in, g, params + p.w[i], gin, dparams + p.w[i], nullptr, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws,

@@ -9,7 +9,7 @@
 namespace nc {
 namespace {
 
-__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ cell) {
+__global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ cell, unsigned* __restrict__ cell2) {
   unsigned m = 0;
   const long n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -30,7 +30,10 @@ __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, lon
     const unsigned q = (unsigned)__shfl_xor((int)m, o);
     m = q > m ? q : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(cell, m);
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicMax(cell, m);
+    if (cell2) atomicMax(cell2, m);
+  }
 }
 
 __global__ void k_set_cells(unsigned* cells, int n, unsigned bits) {
@@ -92,12 +95,12 @@ int h2_set_cell(unsigned* cell, float bound, hipStream_t s) {
   hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, cell, 1, bits);
   return check_launch("h2_set_cell");
 }
-int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s) {  // *cell = max(*cell, largest finite |x|)
+int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2) {  // *cell (and *cell2) = max(itself, largest finite |x|)
   if ((unsigned long long)x & 15) { set_error("h2_absmax: the tensor must be 16-byte aligned"); return NC_ERR_ARG; }
   long blocks = cdiv(n, 256 * 4 * 8);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n, cell);
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n, cell, cell2);
   return check_launch("h2_absmax");
 }
 int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s) {

@@ -465,6 +465,118 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_s3(const float* __restrict
   }
 }
 
+// ---- the same backward writing dx in the H2 form (two fp16 terms of dx * 2^k, s3_common.hpp / h2.hip).  The power of two must be known
+// before the first element is written, and dx is not: pass 1 also takes max |g| and max |xhat| per instance, and
+//   |dx| = r |g - mean(g) - xhat mean(g xhat)| <= r max|g| (2 + max|xhat|)      (|mean(g xhat)| <= rms(g) rms(xhat) <= max|g|)
+// bounds the tensor from above within a small factor -- fp16's exponent range has room for that (s3_common.hpp).
+__global__ __launch_bounds__(256) void k_in_bwd_sums_h2(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float slope, long S, int splits,
+                                                        double* __restrict__ part, unsigned* __restrict__ gmax, unsigned* __restrict__ xmax) {
+  const int inst = blockIdx.y, sp = blockIdx.x;
+  long b, e;
+  chunk_range(S, splits, sp, b, e);
+  const float m = mean[inst], r = rstd[inst];
+  const float* px = x + (long)inst * S;
+  const float* pg = dy + (long)inst * S;
+  double s1 = 0.0, s2 = 0.0;
+  unsigned gm = 0, xm = 0;
+  for (long i = b + threadIdx.x; i < e; i += 256) {
+    const float xh = (px[i] - m) * r;
+    const float g = xh > 0.f ? pg[i] : pg[i] * slope;
+    s1 += (double)g;
+    s2 = fma((double)g, (double)xh, s2);
+    const unsigned gb = __float_as_uint(g) & 0x7fffffffu, xb = __float_as_uint(xh) & 0x7fffffffu;
+    if (gb < 0x7f800000u && gb > gm) gm = gb;
+    if (xb < 0x7f800000u && xb > xm) xm = xb;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned q1 = (unsigned)__shfl_xor((int)gm, o), q2 = (unsigned)__shfl_xor((int)xm, o);
+    gm = q1 > gm ? q1 : gm; xm = q2 > xm ? q2 : xm;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (gm) atomicMax(gmax + inst, gm);
+    if (xm) atomicMax(xmax + inst, xm);
+  }
+  block_reduce2(s1, s2, part + ((long)inst * splits + sp) * 2);
+}
+
+__global__ __launch_bounds__(256) void k_in_bwd_bound(const float* __restrict__ rstd, const unsigned* __restrict__ gmax,
+                                                      const unsigned* __restrict__ xmax, int NC, unsigned* __restrict__ cell) {
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < NC; i += 256) {
+    const float bnd = rstd[i] * __uint_as_float(gmax[i]) * (2.f + __uint_as_float(xmax[i]));
+    const unsigned b = __float_as_uint(bnd) & 0x7fffffffu;
+    if (b < 0x7f800000u && b > m) m = b;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned q = (unsigned)__shfl_xor((int)m, o);
+    m = q > m ? q : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(cell, m);
+}
+
+__global__ void k_zero_u32(unsigned* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_in_bwd_apply_h2(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float slope, long S, int splits, const double* __restrict__ part,
+                                                         uint4* __restrict__ dxs, int cblocks, double* __restrict__ rowpart,
+                                                         const unsigned* __restrict__ cell) {
+  __shared__ float sm[2][8];
+  __shared__ double red[8][4];
+  const long ncb = blockIdx.y;
+  if (threadIdx.x < 8) {
+    const long inst = ncb * 8 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < splits; ++k) {
+      s1 += part[(inst * splits + k) * 2];
+      s2 += part[(inst * splits + k) * 2 + 1];
+    }
+    sm[0][threadIdx.x] = (float)(s1 / (double)S);
+    sm[1][threadIdx.x] = (float)(s2 / (double)S);
+  }
+  __syncthreads();
+  const float sc = h2_scale(*cell);
+  float m[8], r[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = mean[ncb * 8 + j]; r[j] = rstd[ncb * 8 + j]; m1[j] = sm[0][j]; m2[j] = sm[1][j]; }
+  const float* px = x + ncb * 8 * S;
+  const float* pg = dy + ncb * 8 * S;
+  double rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rs[j] = 0.0;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    unsigned short e[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = in_bwd_value(px[j * S + v], pg[j * S + v], m[j], r[j], m1[j], m2[j], slope);
+      rs[j] += (double)t;
+      asm("" : "+v"(t));
+      h2_split(t * sc, e[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dxs[(ncb * 2 + t) * S + v] = s3_unit(e, t);  // [N][C/8][2][S] units
+  }
+  if (rowpart) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double a = rs[j];
+      for (int of = 32; of > 0; of >>= 1) a += __shfl_down(a, of);
+      if (lane == 0) red[j][wv] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      rowpart[(ncb * 8 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
+
 __global__ void k_lrelu_fwd(const float* __restrict__ x, float slope, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = x[i];
@@ -850,6 +962,32 @@ int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean
                      (const double*)ws, (uint4*)dxs, C / 8, rowpart);
   hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
   return check_launch("instnorm_act_bwd_dbias_s3");
+}
+// dxs: an H2 tensor [N][C/8][2][S] with its cell at byte offset h2_cells_offset(N * C * S) (cells[0] = cells[1] = the bound) and two
+// arrays of N * C words of scratch behind the cells -- all inside the N * C * S * 6 bytes an S3 tensor of the same shape takes.
+int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !mean || !rstd || !dxs || !dbias) { set_error("instnorm_act_bwd_dbias_h2: null pointer"); return NC_ERR_ARG; }
+  if (!instnorm_bwd_s3_supported(N, C, S)) { set_error("instnorm_act_bwd_dbias_h2: bad shape"); return NC_ERR_SHAPE; }
+  const int NC = N * C;
+  if (!ws || ws_bytes < nc_instnorm_bwd_dbias_ws_bytes(NC, S)) { set_error("instnorm_act_bwd_dbias_h2: workspace too small"); return NC_ERR_WS; }
+  if ((size_t)NC * S * 2 < 512 + (size_t)NC * 8) { set_error("instnorm_act_bwd_dbias_h2: tensor too small"); return NC_ERR_SHAPE; }
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* cells = (unsigned*)((char*)dxs + h2_cells_offset((size_t)NC * S));
+  unsigned* gmax = cells + 64;
+  unsigned* xmax = gmax + NC;
+  hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)cdiv(64 + 2 * NC, 256)), dim3(256), 0, s, cells, 64 + 2 * NC);
+  const int splits = pick_splits(NC, S);
+  hipLaunchKernelGGL(k_in_bwd_sums_h2, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws, gmax, xmax);
+  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells);
+  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells + 1);
+  long bx = cdiv(S, 1024);
+  if (bx > 1024) bx = 1024;
+  double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
+  hipLaunchKernelGGL(k_in_bwd_apply_h2, dim3((unsigned)bx, (unsigned)(NC / 8)), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                     (const double*)ws, (uint4*)dxs, C / 8, rowpart, (const unsigned*)cells);
+  hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
+  return check_launch("instnorm_act_bwd_dbias_h2");
 }
 }  // namespace nc
 extern "C" {

@@ -48,6 +48,16 @@ __device__ __forceinline__ int h2_exp(unsigned amax_bits) {  // amax_bits: float
 }
 __device__ __forceinline__ float h2_scale(unsigned amax_bits) { return __uint_as_float((unsigned)(127 + h2_exp(amax_bits)) << 23); }
 __device__ __forceinline__ float h2_inv_scale(unsigned amax_bits) { return __uint_as_float((unsigned)(127 - h2_exp(amax_bits)) << 23); }
+// 2^-(ka + kb) as two factors of about equal exponent (f.x * f.y): applied one after the other they scale a sum back without an intermediate
+// overflow or underflow that the result itself would not have
+__device__ __forceinline__ float2 h2_unscale2(unsigned cell_a, unsigned cell_b) {
+  const int e = -(h2_exp(cell_a) + h2_exp(cell_b));
+  const int e1 = e / 2, e2 = e - e1;  // |e| <= 254: both within [-127, 127]
+  float2 f;
+  f.x = __uint_as_float((unsigned)(127 + (e1 < -126 ? -126 : e1)) << 23);
+  f.y = __uint_as_float((unsigned)(127 + (e2 < -126 ? -126 : e2)) << 23);
+  return f;
+}
 // 2^(kA - kB): what a value converted with cell B must be multiplied by to stand in a sum converted with cell A
 __device__ __forceinline__ float h2_group_factor(unsigned cell_a, unsigned cell_b) {
   int d = h2_exp(cell_a) - h2_exp(cell_b);

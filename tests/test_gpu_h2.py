@@ -123,6 +123,33 @@ def test_h2_nonfinite_inputs_follow_the_split_rule():
     assert bool(torch.isnan(y2[touched]).all()) and torch.equal(y2[~touched], y[~touched])
 
 
+WCASES = [(1, 64, 64, 32, 3, 'relu', 'grad'), (2, 128, 64, 20, 3, 'randn', 'randn'), (1, 64, 128, 27, 3, 'relu', 'grad'), (1, 64, 64, 24, 5, 'randn', 'randn'),
+          (1, 256, 256, 12, 3, 'relu', 'randn')]
+
+
+@pytest.mark.parametrize('case', WCASES, ids=[str(c) for c in WCASES])
+def test_h2_wgrad_against_fp64(case):
+    """k_wgrad_s3x<KS, 2, f16>: the weight gradient on two-term operands (both converted with measured powers of two, the sums scaled back)."""
+    from neuroclear_amd import ops
+    N, C, K, E, ks, kx, kg = case
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = data(kx, (N, C, E, E, E), g)
+    dy = data(kg, (N, K, E, E, E), g)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (K, C, ks, ks, ks), dy.double(), padding=ks // 2)
+    res = {}
+    for name, split, terms in (('fp32', False, 3), ('t3', True, 3), ('t2', True, 2)):
+        ops.set_conv_split(split)
+        L().nc_set_split_terms(terms)
+        dw = ops.conv_wgrad_raw(x, dy, (K, C, ks, ks, ks), 1, ks // 2, False)[0]
+        if name == 't2':
+            assert torch.equal(dw, ops.conv_wgrad_raw(x, dy, (K, C, ks, ks, ks), 1, ks // 2, False)[0])
+        res[name] = err(dw, ref)
+    (m32, r32), (m3, r3), (m2, r2) = res['fp32'], res['t3'], res['t2']
+    print(case, 'wgrad fp32 %.2e/%.2e  three-term %.2e/%.2e  two-term %.2e/%.2e' % (m32, r32, m3, r3, m2, r2))
+    assert r2 <= 1.3 * r32 + 2e-8 and m2 <= 2.0 * m32 + 2e-7, (m2, r2, m32, r32)
+    assert r2 <= 1.3 * r3 + 2e-8, (r2, r3)
+
+
 def rnd(seed, shape):
     return np.random.default_rng(int(seed)).random(tuple(int(s) for s in shape), dtype=np.float32)
 
@@ -175,3 +202,36 @@ def test_h2_unet_scale_groups_at_108():
         d = float((out[2] - out[3]).abs().max())
         print(f1, f2, 'max |two-term - three-term| = %.2e' % d, 'range', float(out[3].min()), float(out[3].max()))
         assert d < 1e-5
+
+
+def _rel2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+@pytest.mark.parametrize('kind,size', [('unet_deconv', 32), ('deep_linear', 24)])
+def test_h2_training_goldens(golden_dir, kind, size):
+    """The whole-network training calls with every 3^3 / 5^3 layer on the two-term form (forward, data gradient, weight gradient; InstanceNorm
+    outputs converted with their bound, the norm's backward with a bound from its own first pass, everything else measured) against the
+    reference-generated goldens, at the tolerances of tests/test_gpu_nets.py."""
+    import os
+    g = np.load(os.path.join(golden_dir, '%s_%d.npz' % (kind, size)))
+    spec = S.unet_deconv_spec() if kind == 'unet_deconv' else S.deep_linear_spec()
+    net = networks.define_G(1, 1, 64, 'unet_deconv' if kind == 'unet_deconv' else 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(spec, int(g['seed']), DEV))
+    L().nc_set_split_terms(2)
+    x = torch.from_numpy(rnd(g['x_seed'], (1, 1, size, size, size))).to(DEV).requires_grad_(True)
+    y = net(x)
+    yg = g['y']
+    if kind == 'unet_deconv':
+        assert float(np.abs(y.detach().cpu().numpy() - yg).max()) < 2e-5
+    else:
+        assert float(np.abs(y.detach().cpu().numpy() - yg).max() / np.abs(yg).max()) < 2e-4
+    r = torch.from_numpy(rnd(g['r_seed'], y.shape)).to(DEV)
+    (y * r).mean().backward()
+    tol = 2e-2 if kind == 'unet_deconv' else 1e-3
+    assert _rel2(x.grad.cpu().numpy(), g['dx']) < tol
+    for i, (k, p_) in enumerate(net.named_parameters()):
+        gr = p_.grad.detach().cpu().numpy().ravel()
+        l2 = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(l2 - g['g_l2'][i]) <= tol * g['g_l2'][i] + 1e-6, (k, l2, g['g_l2'][i])

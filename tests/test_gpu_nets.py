@@ -589,11 +589,16 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
 @pytest.mark.parametrize('kind,shape', [('unet', (1, 1, 16, 16, 16)), ('unet', (2, 1, 12, 20, 24)), ('unet', (3, 1, 8, 8, 36)),
                                         ('linear', (1, 1, 16, 16, 16)), ('linear', (2, 1, 9, 14, 21))])
 @pytest.mark.parametrize('want_dx', [False, True])
-def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, monkeypatch):
+@pytest.mark.parametrize('terms', [3, 2])
+def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, terms, monkeypatch):
     """nc_unet_deconv_train_fwd / nc_unet_deconv_bwd and nc_deep_linear_fwd / _bwd (one C call per direction, concat
     halves written in place, skip gradients merged inside the max-pool backward) against the layer-by-layer autograd path
     of the same module: same kernels in the same order, so output, input gradient and all parameter gradients are
     BIT-identical -- batches included (per-sample sub-ranges of the concat buffers)."""
+    from neuroclear_amd._lib import lib
+    prev_terms = lib().nc_get_split_terms()
+    lib().nc_set_split_terms(terms)
+    request_restore = lambda: lib().nc_set_split_terms(prev_terms)
     if kind == 'unet':
         net = load(networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0]),
                    S.unet_deconv_spec(), 31)
@@ -612,16 +617,31 @@ def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, 
         (y * r).sum().backward()
         return y.detach().clone(), (x.grad.clone() if want_dx else None), [p.grad.clone() for p in net.parameters()]
 
-    ya, xa, ga = run(False)
-    yb, xb, gb = run(True)
-    assert torch.equal(ya, yb)
-    if want_dx:
-        assert torch.equal(xa, xb)
-    for (n, _), a, b in zip(net.named_parameters(), ga, gb):
-        assert torch.equal(a, b), n
-    if kind == 'linear':  # inference form (saved == NULL: activations ping-pong through the workspace)
-        with torch.no_grad():
-            assert torch.equal(net(x0), ya)
+    try:
+        ya, xa, ga = run(False)
+        yb, xb, gb = run(True)
+        # The two-term form of the U-Net is the one exception to "bit-identical": the whole-network call converts an InstanceNorm output with
+        # the power of two its bound sqrt(voxels) allows (no pass over the tensor), the layer-by-layer path measures the tensor -- two valid
+        # scalings of the same operands, results equal to fp32 rounding (and a ReLU / max-pool decision may fall the other way: L2 bounds).
+        exact = terms == 3 or kind == 'linear'
+        if exact:
+            assert torch.equal(ya, yb)
+            if want_dx:
+                assert torch.equal(xa, xb)
+            for (n, _), a, b in zip(net.named_parameters(), ga, gb):
+                assert torch.equal(a, b), n
+        else:
+            assert float((ya - yb).abs().max()) < 2e-6
+            if want_dx:
+                assert rel2(xa.cpu().numpy(), xb.cpu().numpy()) < 2e-2
+            for (n, p_), a, b in zip(net.named_parameters(), ga, gb):
+                if p_.dim() > 1:
+                    assert rel2(a.cpu().numpy(), b.cpu().numpy()) < 2e-2, n
+        if kind == 'linear':  # inference form (saved == NULL: activations ping-pong through the workspace)
+            with torch.no_grad():
+                assert torch.equal(net(x0), ya)
+    finally:
+        request_restore()
 
 
 def test_whole_network_backward_writes_gradients_in_place():

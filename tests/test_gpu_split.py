@@ -21,9 +21,15 @@ DEV = 'cuda'
 
 @pytest.fixture(autouse=True)
 def _restore_switch():
+    # this file is about the THREE-term bf16 form (nc_set_split_terms(3)); the two-term fp16 form, the default since round 4, has
+    # tests/test_gpu_h2.py
     from neuroclear_amd import ops
+    from neuroclear_amd._lib import lib
     prev = ops.set_conv_split(True)
+    terms = lib().nc_get_split_terms()
+    lib().nc_set_split_terms(3)
     yield
+    lib().nc_set_split_terms(terms)
     ops.set_conv_split(prev)
 
 
