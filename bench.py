@@ -75,7 +75,7 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 
 # `roofline.traffic` is NOT measured in this process (counters cannot be read from inside it): it is the figure of the committed offline PMC
 # passes of the same command, on whatever box those ran on
-TRAFFIC_FILE = 'r03_pmc_traffic.json'
+TRAFFIC_FILE = 'r04_pmc_traffic.json'
 TRAFFIC_SOURCE = 'profiles/%s (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % TRAFFIC_FILE
 
 PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
@@ -87,9 +87,9 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
              'dgrad_split_k5': 'conv_split_k5', 'wgrad_split_k3': 'wgrad_split_k3', 'wgrad_split_k5': 'wgrad_split_k5'}
 
 
-def pmc_traffic(tag, crop=108, batch=1):
+def pmc_traffic(tag, crop=108, batch=1, three_term=False):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
-    (profiles/r03_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    (profiles/r04_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
     if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
         return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
@@ -97,7 +97,8 @@ def pmc_traffic(tag, crop=108, batch=1):
         return None
     try:
         with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
-            return round(json.load(f)['split_classes' if '_split_' in tag else 'classes'][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
+            key = ('split_classes_three_term' if three_term else 'split_classes') if '_split_' in tag else 'classes'
+            return round(json.load(f)[key][PMC_CLASS[tag]]['hbm_bytes_per_launch'])
     except Exception:
         return None
 
@@ -295,8 +296,7 @@ def run_train(args, rank, world, dev):
                 'k_wgrad_s3x<3>', 'k_wgrad_s3x<3,2,f16>').replace('k_wgrad_s3x<5>', 'k_wgrad_s3x<5,2,f16>')
         roof = dict(bound='mfma', kernel=kname, kernel_class=top, achieved=round(ach, 2),
                     peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
-                    traffic=None if two else pmc_traffic(top, crop, args.batch),
-                    traffic_source='not collected for the two-term kernels yet (the committed PMC passes are of the three-term ones)' if two else TRAFFIC_SOURCE,
+                    traffic=pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two), traffic_source=TRAFFIC_SOURCE,
                     launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
@@ -314,11 +314,12 @@ def run_train(args, rank, world, dev):
 GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
 
 
-def pmc_traffic_cube(split=False):
+def pmc_traffic_cube(split=False, three_term=False):
     """HBM bytes of ONE 140^3 cube forward (all its kernels), from the committed PMC passes (tools/pmc_infer.sh, tools/pmc_split.sh)."""
     try:
         with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
-            return round(json.load(f)['inference_cube_140_split' if split else 'inference_cube_140']['hbm_bytes_per_cube'])
+            key = ('inference_cube_140_three_term' if three_term else 'inference_cube_140_split') if split else 'inference_cube_140'
+            return round(json.load(f)[key]['hbm_bytes_per_cube'])
     except Exception:
         return None
 
@@ -395,7 +396,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
                                         'profiles/r04_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
-                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split), traffic_source=TRAFFIC_SOURCE, launches=len(ev),
+                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split, three_term=split and terms != 2), traffic_source=TRAFFIC_SOURCE, launches=len(ev),
                     cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     event_ms_per_cube=round(ms_events / len(ev), 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))

@@ -25,7 +25,8 @@ def kernel_class(name):
                       ('k_conv_s3x<3, 2', 'conv_split_k3_tail'), ('k_conv_s3x<5, 8', 'conv_split_k5'), ('k_conv_s3x<5', 'conv_split_k5_tail'),
                       ('k_conv_s3<3', 'conv_split_k3'), ('k_conv_s3<5', 'conv_split_k5'), ('k_wgrad_s3x<3', 'wgrad_split_k3'),
                       ('k_wgrad_s3x<5', 'wgrad_split_k5'), ('k_wgrad_s3<3', 'wgrad_split_k3'), ('k_wgrad_s3<5', 'wgrad_split_k5'),
-                      ('k_split3', 'split3'), ('k_act_split3', 'act_split3'), ('k_in_bwd_apply_s3', 'in_bwd_apply_s3')):
+                      ('k_split3', 'split3'), ('k_act_split3', 'act_split3'), ('k_in_bwd_apply_s3', 'in_bwd_apply_s3'),
+                      ('k_split2h', 'split2h'), ('k_act_split2h', 'act_split2h'), ('k_in_bwd_apply_h2', 'in_bwd_apply_h2'), ('k_absmax(', 'absmax')):
         if kern in name:
             return cls
     return None
