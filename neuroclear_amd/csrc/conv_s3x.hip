@@ -201,7 +201,16 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   // through a buffer descriptor over the three terms of ONE 8-channel block: a lane whose unit is padding asks for an offset
   // beyond the descriptor's range and the hardware delivers zeros (no zero page, no 64-bit address arithmetic per lane)
   constexpr unsigned kOut = 0x80000000u;
-  auto issue_brick = [&](const XTile& t, int bi, int slot) __attribute__((always_inline)) {
+  // Two-term form: the per-lane source offsets of a tile's pieces depend on the tile only (chunk and plane are the descriptor and the scalar
+  // offset).  An issuing wave writes its <= kPW of them into an LDS table behind the ring once per tile and reads them back (one ds_read per
+  // piece) for the tile's KS * C/8 - 1 later bricks, instead of ~12 vector instructions per piece and brick: with half the MFMAs per brick the
+  // recomputation is no longer hidden (a build without the DMA is 17 % faster).  (Registers would do -- but an array captured by the lambdas
+  // below makes hipcc drop the kernel's host-side handle, and the three-term kernel has none left.)
+  constexpr int kPW = 8;
+  const bool keep = NT == 2 && p.npb <= kDmaWaves * kPW;
+  typedef volatile __attribute__((address_space(3))) unsigned* lds32_t;
+  const unsigned otab = (unsigned)(unsigned long long)(lptr_t)lds_raw + (unsigned)(3 * BB + ((wave * kPW) * 64 + lane) * 4);  // [wave][piece i][lane]
+  auto issue_brick = [&](const XTile& t, int bi, int slot, bool kept) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
     const int chunk = bi / KS, dz = bi - chunk * KS;
     const int zz = t.z + dz - PAD;
@@ -211,6 +220,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(NT * S * 16) : 0u, 0x00020000);
     const int soff = zok ? (int)(zz * HW * 16) : 0;
     unsigned char* buf = lds_raw + slot * BB;
+    if (kept) {
+#pragma unroll 1
+      for (int i = 0, pc = wave; pc < p.npb; ++i, pc += kDmaWaves)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, *(lds32_t)(otab + i * 256), soff, 0, 0);
+      return;
+    }
 #pragma unroll 1
     for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
       // per-lane byte offset of the unit this lane fetches for piece pc (inside the block's three terms, relative to plane 0), or kOut:
@@ -343,7 +358,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 #endif
   // ---- prologue: brick 0 and the first A fragments of the first tile
   int ring = 0;  // ring slot of brick 0 of the current tile
-  issue_brick(cur, 0, 0);
+  issue_brick(cur, 0, 0, false);
   u32x4 A[2][NT], nA[2][NT];
   load_a(A, wtile(cur.cot));
 #pragma unroll
@@ -368,6 +383,19 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const int tnext = next_tile(tcur + nslot, nx);
     const bool more_tiles = tnext >= 0;
     nxt = nx;
+    if (keep && wave < kDmaWaves) {  // this tile's offsets (brick 0 was requested while the tile before was running: slow path)
+#pragma unroll 1
+      for (int i = 0, pc = wave; pc < p.npb; ++i, pc += kDmaWaves) {
+        const unsigned u = (unsigned)(pc * 64 + lane);
+        const unsigned term = fdiv(u, p.mUB);
+        const unsigned F = (unsigned)cur.q0 + (u - term * p.UB);
+        const unsigned rr = fdiv(F, p.mP);
+        const int xx = (int)(F - rr * p.P) - PAD;
+        const int yy = (int)rr - PAD;
+        const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        *(lds32_t)(otab + i * 256) = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+      }
+    }
     const int wt = wtile(cur.cot);
     const int wt_next = more_tiles ? wtile(nxt.cot) : wt;
     int na = 0;  // next brick of this tile to arrive (brick 0 was requested during the previous tile / in the prologue)
@@ -410,9 +438,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         // partners are not away from the matrix pipe at the same moment: 1.5-2 % slower)
 #ifndef NC_XA_NODMA
         if (na + 1 < NB) {
-          issue_brick(cur, na + 1, (ring + na + 1) % 3);
+          issue_brick(cur, na + 1, (ring + na + 1) % 3, keep);
         } else if (more_tiles) {
-          issue_brick(nxt, 0, (ring + NB) % 3);
+          issue_brick(nxt, 0, (ring + NB) % 3, false);
         }
 #endif
         ++na;
@@ -513,12 +541,13 @@ struct XPlan {
   bool ok;
 };
 
+constexpr int kOffTab = 8192;  // two-term launches: the DMA offset table behind the ring, [4 issuing waves][8 pieces][64 lanes] words
 bool x_brick(int PT, int P, int KS, int NT, int& UB, int& npb, int& lds) {
   const int U = PT + (KS - 1) * (P + 1);
   UB = (U + 63) / 64 * 64;
   npb = NT * UB / 64;
   lds = 3 * npb * 1024;
-  return npb <= kMaxPieces && lds <= kLdsMax;
+  return npb <= kMaxPieces && lds + (NT == 2 ? kOffTab : 0) <= kLdsMax;
 }
 
 int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round of whole tiles (A/B)
@@ -634,13 +663,13 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   if (pl.full || one) {
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
     p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
-    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds, s);
+    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s);
     if (e) return e;
   }
   if (pl.rem && !one) {
     p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
     p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
-    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst, s) : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst, s);
+    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s);
     if (e) return e;
   }
   return NC_OK;
