@@ -608,7 +608,7 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
     }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
-    if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, out_cell, hs);
+    if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs);
     if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
     return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
   };

@@ -229,7 +229,7 @@ int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
 int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2 = nullptr);
 int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s);
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
-                int c0, const unsigned* cell, hipStream_t s);
+                int c0, float bound, unsigned* cell, unsigned* cell2, hipStream_t s);
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s);
 bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);

@@ -1456,10 +1456,7 @@ int act_operand(const ConvDims& d, const float* x, const float* mean, const floa
   if (C != ctot && 2 * C != ctot) { set_error("act_operand: a part must be the whole tensor or a half"); return NC_ERR_SHAPE; }
   unsigned* cells = h2_cells_of(ys, (size_t)N * ctot * S);
   unsigned* mine = cells + (c0 ? 1 : 0);
-  if (int e = h2_set_cell(mine, sqrtf((float)S), s)) return e;
-  if (C == ctot)
-    if (int e = h2_set_cell(cells + 1, sqrtf((float)S), s)) return e;
-  return act_split2h(x, mean, rstd, slope, y, ystride, ys, N, C, S, ctot, c0, mine, s);
+  return act_split2h(x, mean, rstd, slope, y, ystride, ys, N, C, S, ctot, c0, sqrtf((float)S), mine, C == ctot ? cells + 1 : nullptr, s);
 }
 bool conv_layer_h2(const ConvDims& d) { return s3_layer_h2(d); }
 ForceThreeTerm::ForceThreeTerm() { ++tl_force3; }

@@ -104,6 +104,31 @@ def test_h2_range(scale):
     assert float(z.abs().max()) == 0.0
 
 
+def test_h2_range_inside_one_tensor_is_the_documented_limit():
+    """What the two-term form gives up (nc_hip.h): range INSIDE one tensor.  One element at 3.4e38 among N(0, 1): the power of two
+    follows the giant, every ordinary element falls below fp16's subnormals and vanishes.  The result stays finite and is right RELATIVE TO
+    THE TENSOR'S SCALE (the outputs the giant touches are right to 1e-6; the others are 0 where fp32 would have kept O(1) values --
+    1e-38 of the output range); the three-term form (nc_set_split_terms(3)) keeps them, which is what the switch is for."""
+    from neuroclear_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(24)
+    x = torch.randn(1, 64, 8, 12, 20, device=DEV, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 1e-3
+    x[0, 5, 4, 6, 7] = 3.4e38
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    L().nc_set_split_terms(2)
+    y2 = ops.conv_fwd_raw(x, w, None, 1, 1)
+    assert bool(torch.isfinite(y2).all())
+    e2 = (y2.double() - ref).abs()
+    assert float((e2 / ref.abs().clamp_min(1e30)).max()) < 1e-6      # right where the giant dominates
+    assert float(e2.max() / ref.abs().max()) < 1e-6                   # and everywhere relative to the output range
+    touched = torch.zeros_like(y2, dtype=torch.bool)
+    touched[:, :, 3:6, 5:8, 6:9] = True
+    assert float(y2[~touched].abs().max()) < 1e-3 < float(ref[~touched].abs().max())  # the ordinary outputs are gone ...
+    L().nc_set_split_terms(3)
+    y3 = ops.conv_fwd_raw(x, w, None, 1, 1)
+    assert float(((y3.double() - ref).abs() / ref.abs().clamp_min(1e-2))[~touched].max()) < 1e-3   # ... the three-term form keeps them
+
+
 def test_h2_nonfinite_inputs_follow_the_split_rule():
     """An inf / NaN input element makes every output it touches NaN and leaves every other output bit-identical: non-finite elements are left
     out of the tensor's maximum."""
