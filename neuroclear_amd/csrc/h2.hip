@@ -11,6 +11,14 @@ namespace {
 
 __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ cell, unsigned* __restrict__ cell2) {
   unsigned m = 0;
+  // a pointer that is not 16-byte aligned (a view into a larger tensor): up to three leading elements are taken one by one
+  const int head = (int)((4 - (((unsigned long long)x >> 2) & 3)) & 3) < n ? (int)((4 - (((unsigned long long)x >> 2) & 3)) & 3) : (int)n;
+  if (blockIdx.x == 0 && (int)threadIdx.x < head) {
+    const unsigned b = __float_as_uint(x[threadIdx.x]) & 0x7fffffffu;
+    if (b < 0x7f800000u && b > m) m = b;
+  }
+  x += head;
+  n -= head;
   const long n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   auto take = [&](const float4& v) __attribute__((always_inline)) {
@@ -107,7 +115,7 @@ int h2_set_cell(unsigned* cell, float bound, hipStream_t s) {
   return check_launch("h2_set_cell");
 }
 int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2) {  // *cell (and *cell2) = max(itself, largest finite |x|)
-  if ((unsigned long long)x & 15) { set_error("h2_absmax: the tensor must be 16-byte aligned"); return NC_ERR_ARG; }
+  if ((unsigned long long)x & 3) { set_error("h2_absmax: the tensor must be 4-byte aligned"); return NC_ERR_ARG; }
   long blocks = cdiv(n, 256 * 4 * 4);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;

@@ -102,6 +102,11 @@ def test_h2_range(scale):
     assert err(ys, ref)[1] < 3e-7
     z = ops.conv_fwd_raw(torch.zeros_like(x), w, None, 1, 1)
     assert float(z.abs().max()) == 0.0
+    # an input that is a view at an odd float offset of a larger buffer (4-byte aligned only): the measuring pass must not care
+    buf = torch.empty(x.numel() + 3, device=DEV)
+    xv = buf[3:].view(x.shape)
+    xv.copy_(x)
+    assert xv.data_ptr() % 16 != 0 and torch.equal(ops.conv_fwd_raw(xv, w, None, 1, 1), y1)
 
 
 def test_h2_range_inside_one_tensor_is_the_documented_limit():
