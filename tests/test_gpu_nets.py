@@ -196,6 +196,20 @@ def _apollo_opt():
 APOLLO_NETS = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
 
 
+@pytest.fixture
+def three_term():
+    """The three-term bf16 form of the split-operand convolutions (rounds 2-3) for one test; the default is the two-term fp16 form."""
+    from neuroclear_amd._lib import lib
+    t = lib().nc_get_split_terms()
+    lib().nc_set_split_terms(3)
+    yield
+    lib().nc_set_split_terms(t)
+
+
+def test_apollo_step_three_term(golden_dir, three_term, monkeypatch):
+    test_apollo_step(golden_dir, 'apollo_step_36.npz', True, monkeypatch)
+
+
 @pytest.mark.parametrize('fname,d_streams', [('apollo_step_36.npz', True), ('apollo_step_24_b2.npz', True),
                                              ('apollo_step_24_b2.npz', False), ('apollo_step_24_vanilla.npz', True),
                                              ('apollo_step_24_wgangp.npz', True)])
@@ -305,6 +319,10 @@ def test_all_slices_op():
         out = ops.volume_all_slices(v2, axis)
         (h,) = torch.autograd.grad((out * r).sum(), v2)
         assert torch.equal(out, ref.contiguous()) and torch.equal(h, gr), axis
+
+
+def test_athena_step_three_term(golden_dir, three_term):
+    test_athena_step(golden_dir)
 
 
 def test_athena_step(golden_dir):
