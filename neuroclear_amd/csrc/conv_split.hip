@@ -1176,6 +1176,8 @@ WsPlan ws_plan(const ConvDims& d, int NT = 3) {
 static thread_local int tl_force3 = 0;
 bool s3_layer_h2(const ConvDims& d) {
   if (s3x_get_terms() != 2 || tl_force3) return false;
+  static const int use_x = getenv("NC_S3X") ? atoi(getenv("NC_S3X")) : 1;  // (NC_S3X=0 / NC_S3X_WGRAD=0: the round-2 kernels, three-term only)
+  if (!use_x) return false;
   if (d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5) || d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd)
     return false;
   if (d.C % 64 || d.K % 64 || (d.K / 64) * (d.C / 32) * (d.kd == 5 ? 5 : 1) > 256) return false;
