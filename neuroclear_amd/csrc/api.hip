@@ -659,6 +659,20 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       else NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
       NC_TRY(h2_absmax(W + u.cat1 + 64 * S, 64 * S, cells + 4, hs));
       NC_TRY(split2h_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, cells + 4, hs));
+      // the last block's normalisation, the two pointwise layers and the sigmoid in one pass over its raw output (NC_INFER_TAIL=0: separately)
+      static const bool tail = !(getenv("NC_INFER_TAIL") && atoi(getenv("NC_INFER_TAIL")) == 0);
+      if (tail) {
+        {
+          ConvDims d9;
+          make_dims(d9, 1, 128, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+          ProfScope ps(0, 9, d9, 0, hs);
+          NC_TRY(conv_s3x_h2(W + u.s_cat1, c0, cells + 4, 64, P + o.w[9], P + o.b[9], W + u.raw, 1, 128, S0, S1, S2, 64, 3, (long)128 * 27, 27, 0,
+                             (unsigned*)cws, (char*)cws + 256, hs));
+        }
+        NC_TRY(nc_instnorm_stats(W + u.raw, 64, S, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
+        NC_TRY(instnorm_relu_tail_sigmoid(W + u.raw, mean, rstd, P + o.w[12], P + o.b[12], P + o.w[13], P + o.b[13], yn, 64, S, hs));
+        continue;
+      }
       NC_TRY(block(9, nullptr, W + u.s_cat1, W + u.a1, nullptr, 0, 0, 128, 64, S0, S1, S2, c0, cells + 4, 64));
       NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
       NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));

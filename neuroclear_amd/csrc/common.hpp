@@ -222,6 +222,8 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
 // half, [1] of the second half (a concatenation converted in two parts; equal to [0] otherwise) -- inside the elems * 6 bytes of an S3 tensor
 inline size_t h2_cells_offset(size_t elems) { return (elems * 4 + 255) & ~(size_t)255; }
 inline unsigned* h2_cells_of(const void* t, size_t elems) { return (unsigned*)((char*)const_cast<void*>(t) + h2_cells_offset(elems)); }
+int instnorm_relu_tail_sigmoid(const float* x, const float* mean, const float* rstd, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* y, int C, long S, hipStream_t s);
 int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s);

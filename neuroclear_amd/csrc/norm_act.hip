@@ -588,6 +588,28 @@ __global__ void k_lrelu_bwd(const float* __restrict__ dy, const float* __restric
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
 }
+// The inference tail of Unet_deconv in ONE pass over the last block's raw convolution output (networks.py:533-537: InstanceNorm + ReLU,
+// one_by_one 64 -> 1, one_by_one_2 1 -> 1, Sigmoid): y[v] = sigmoid(w2 * (b1 + sum_c w1[c] * relu((x[c][v] - mean[c]) * rstd[c])) + b2).  The
+// separate passes wrote the 64-channel activation and read it back (1.4 GB per 140^3 cube) for one output channel.
+__global__ void __launch_bounds__(256) k_in_act_tail(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ y, long S, int C) {
+  __shared__ float sm[3][256];
+  for (int c = threadIdx.x; c < C; c += 256) { sm[0][c] = mean[c]; sm[1][c] = rstd[c]; sm[2][c] = w1[c]; }
+  __syncthreads();
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float t = (x[(long)c * S + v] - sm[0][c]) * sm[1][c];
+    t = t > 0.f ? t : 0.f;
+    acc = fmaf(sm[2][c], t, acc);
+  }
+  const float t1 = acc + b1[0];
+  const float t2 = fmaf(w2[0], t1, b2[0]);
+  y[v] = 1.f / (1.f + expf(-t2));
+}
+
 __global__ void k_sigmoid_fwd(const float* __restrict__ x, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = 1.f / (1.f + expf(-x[i]));
@@ -988,6 +1010,12 @@ int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean
                      (const double*)ws, (uint4*)dxs, C / 8, rowpart, (const unsigned*)cells);
   hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
   return check_launch("instnorm_act_bwd_dbias_h2");
+}
+int instnorm_relu_tail_sigmoid(const float* x, const float* mean, const float* rstd, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* y, int C, long S, hipStream_t s) {
+  if (C > 256) { set_error("instnorm_relu_tail_sigmoid: at most 256 channels"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_in_act_tail, dim3((unsigned)cdiv(S, 256)), dim3(256), 0, s, x, mean, rstd, w1, b1, w2, b2, y, S, C);
+  return check_launch("instnorm_relu_tail_sigmoid");
 }
 }  // namespace nc
 extern "C" {
