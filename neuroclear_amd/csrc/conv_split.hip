@@ -1198,9 +1198,15 @@ int ws_flush_steps() {
   static const int f = getenv("NC_SPLIT_WFLUSH") ? atoi(getenv("NC_SPLIT_WFLUSH")) : 64;
   return f > 0 ? f : 1 << 30;
 }
-int ws_nf(long steps, int nwp) {  // partial slots per workgroup: ceil(most steps of a workgroup / F)
+// two-term operands: three MFMA roundings of an accumulator per k-step instead of six -- twice the steps give the same number per partial sum
+int ws_flush_steps2() {
+  static const int f = getenv("NC_SPLIT_WFLUSH2") ? atoi(getenv("NC_SPLIT_WFLUSH2")) : 128;
+  return f > 0 ? f : 1 << 30;
+}
+int ws_nf(long steps, int nwp, int F = 0) {  // partial slots per workgroup: ceil(most steps of a workgroup / F)
+  if (!F) F = ws_flush_steps();
   const long most = (steps + nwp - 1) / nwp;
-  const long nf = (most + ws_flush_steps() - 1) / ws_flush_steps();
+  const long nf = (most + F - 1) / F;
   return nf < 1 ? 1 : (int)nf;
 }
 
@@ -1225,7 +1231,7 @@ int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* d
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
   const int nwp = ws_nwp(d, pl, npairs);
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
-  const int NF = ws_nf(steps, nwp);
+  const int NF = ws_nf(steps, nwp, ws_flush_steps2());
   const size_t pb = align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
   if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3 (two-term): workspace too small"); return NC_ERR_WS; }
   void* xs = xs_pre ? const_cast<void*>(xs_pre) : ws;
@@ -1249,7 +1255,7 @@ int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* d
   p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
   p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
-  p.F = ws_flush_steps(); p.NF = NF;
+  p.F = ws_flush_steps2(); p.NF = NF;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
   if (int e = raise_dyn_lds((k_wgrad_s3x<3, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
   if (int e = raise_dyn_lds((k_wgrad_s3x<5, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
