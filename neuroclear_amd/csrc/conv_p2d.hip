@@ -31,6 +31,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -64,18 +65,20 @@ __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_spl
 //   mode 2 (stride 2 data gradient, output parity class (ry, rx)): brick T / 8 = pair of dy chunks, chunk 2 * brick + j, g = (a, b):
 //                                    tap (3 - 2a - ry, 3 - 2b - rx)  (dx[2u + ry] = sum_a w[.., 3 - 2a - ry] dy[u + ry + a - 1])
 // w element = w[co * so + ci * si + tap]: forward so = C*16, si = 16; data gradients so = 16, si = C*16 (co = the layer's input channel).
+// NT = 2: the two fp16 terms of w * 2^k (s3_common.hpp h2_split; k from the weights' cell).
+template <int NT>
 __global__ void __launch_bounds__(256) k_pack_w_p2d(const float* __restrict__ w, unsigned short* __restrict__ wp, int NS, long so, long si,
-                                                    int mode, int flip, int ry, int rx, long total) {
+                                                    int mode, int flip, int ry, int rx, long total, const unsigned* __restrict__ wcell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7);
   long q = i >> 3;
   const int lane = (int)(q & 63); q >>= 6;
-  const int f = (int)(q % 6); q /= 6;
+  const int f = (int)(q % (2 * NT)); q /= 2 * NT;
   const int s = (int)(q % NS); q /= NS;
   const int half = (int)(q & 1);
   const int cot = (int)(q >> 1);
-  const int rb = f / 3, term = f % 3;
+  const int rb = f / NT, term = f % NT;
   const int g = lane >> 4, m = lane & 15;
   const int T = 4 * s + g;
   int chunk, tap;
@@ -90,15 +93,17 @@ __global__ void __launch_bounds__(256) k_pack_w_p2d(const float* __restrict__ w,
   const int jj = (g & 1) ? ((j + 4) & 7) : j;
   const long co = cot * 64 + half * 32 + rb * 16 + m, ci = chunk * 8 + jj;
   unsigned short t[3];
-  split3(w[co * so + ci * si + tap], t);
+  if constexpr (NT == 3) split3(w[co * so + ci * si + tap], t);
+  else h2_split(w[co * so + ci * si + tap] * h2_scale(*wcell), t);
   wp[i] = t[term];
 }
 
 // fp32 NCHW [B][C][H][W] -> the S3 form of the zero-padded flat batch, PP = Hp*Wp, Hp = H + 2 pad.  pairs = 0: unit ((chunk*3 + term) *
 // TOT + i), i = b*PP + yp*Wp + xp; pairs = 1 (stride-2 data gradient): bricks of two chunks, unit (((chunk/2)*3 + term)*2 + chunk%2) * TOT + i.
 // One thread per (chunk, padded position): 8 strided loads (coalesced along x), three 16-byte stores.
+template <int NT>
 __global__ void __launch_bounds__(256) k_pad_split3_2d(const float* __restrict__ x, uint4* __restrict__ xs, int C, int H, int W, int pad, int Hp,
-                                                       int Wp, long TOT, long npos, int pairs) {
+                                                       int Wp, long TOT, long npos, int pairs, const unsigned* __restrict__ cell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // b*PP + yp*Wp + xp
   if (i >= npos) return;
   const int chunk = blockIdx.y;
@@ -109,22 +114,26 @@ __global__ void __launch_bounds__(256) k_pad_split3_2d(const float* __restrict__
   unsigned short e[8][3];
   const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
   const float* src = x + (((long)b * C + chunk * 8) * H + (in ? yy : 0)) * W + (in ? xx : 0);
+  float sc = 1.f;
+  if constexpr (NT == 2) sc = h2_scale(*cell);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = in ? src[(long)j * H * W] : 0.f;
-    s3_split(v, e[j]);
+    if constexpr (NT == 3) s3_split(v, e[j]);
+    else h2_split(v * sc, e[j]);
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const long u = pairs ? (((long)(chunk >> 1) * 3 + t) * 2 + (chunk & 1)) * TOT + i : ((long)chunk * 3 + t) * TOT + i;
+  for (int t = 0; t < NT; ++t) {
+    const long u = pairs ? (((long)(chunk >> 1) * NT + t) * 2 + (chunk & 1)) * TOT + i : ((long)chunk * NT + t) * TOT + i;
     xs[u] = s3_unit(e, t);
   }
 }
 
 // Space-to-depth of the zero-padded (pad 1, extended to even extents) input of a stride-2 layer: parity (py, px) of chunk c is sub-brick px of
 // brick 2c + py, position (yq, xq) of plane b = x_pad[2 yq + py][2 xq + px].  grid.y = chunk*4 + parity.
+template <int NT>
 __global__ void __launch_bounds__(256) k_s2d_split3(const float* __restrict__ x, uint4* __restrict__ xs, int C, int H, int W, int Hq, int Wq,
-                                                    long TOT, long npos) {
+                                                    long TOT, long npos, const unsigned* __restrict__ cell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // b*PPq + yq*Wq + xq
   if (i >= npos) return;
   const int chunk = blockIdx.y >> 2, py = (blockIdx.y >> 1) & 1, px = blockIdx.y & 1;
@@ -135,13 +144,16 @@ __global__ void __launch_bounds__(256) k_s2d_split3(const float* __restrict__ x,
   unsigned short e[8][3];
   const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
   const float* src = x + (((long)b * C + chunk * 8) * H + (in ? yy : 0)) * W + (in ? xx : 0);
+  float sc = 1.f;
+  if constexpr (NT == 2) sc = h2_scale(*cell);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = in ? src[(long)j * H * W] : 0.f;
-    s3_split(v, e[j]);
+    if constexpr (NT == 3) s3_split(v, e[j]);
+    else h2_split(v * sc, e[j]);
   }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) xs[(((long)(chunk * 2 + py) * 3 + t) * 2 + px) * TOT + i] = s3_unit(e, t);
+  for (int t = 0; t < NT; ++t) xs[(((long)(chunk * 2 + py) * NT + t) * 2 + px) * TOT + i] = s3_unit(e, t);
 }
 
 struct PParams {
@@ -165,6 +177,7 @@ struct PParams {
   unsigned mUB, mUBq, mHoWo, mWo;
   int t_count, tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
+  const unsigned *amax_x, *amax_w;  // NT = 2: the cells of the input and of the weights (results scaled back by 2^-(kx + kw))
 };
 
 struct PTile {
@@ -193,7 +206,7 @@ __device__ __forceinline__ PTile p_decode(const PParams& p, int t) {
 // M1 = true:  2 x 2 taps over TWO sub-bricks per brick (k-step j of a brick = sub-brick j, lane group g = tap (g / 2, g % 2)): the stride-2
 //             layers -- forward over a space-to-depth image (sub-bricks = the two column parities of one row parity of a chunk), data
 //             gradient per output-parity class over dy (sub-bricks = two consecutive chunks of dy channels).
-template <int NCB, bool M1>
+template <int NCB, bool M1, int NT = 3>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int T2 = M1 ? 8 : 16, PT = 64 * NCB;
@@ -224,8 +237,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   auto issue_brick = [&](const PTile& t, int bi, int slot) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
     constexpr int NSUB = M1 ? 2 : 1;
-    const uint4* blk = p.xs + (long)bi * 3 * NSUB * p.TOT;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(3 * NSUB * p.TOT * 16), 0x00020000);
+    const uint4* blk = p.xs + (long)bi * NT * NSUB * p.TOT;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, (unsigned)(NT * NSUB * p.TOT * 16), 0x00020000);
     unsigned char* buf = lds_raw + slot * BB;
 #pragma unroll 1
     for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
       unsigned within = u - term * p.UB, sub = 0;
       if (M1) { sub = fdiv(within, p.mUBq); within -= sub * p.UBq; }
       const unsigned F = (unsigned)t.q0 + within;
-      const bool ok = term < 3u && (long)F < p.TOT;
+      const bool ok = term < (unsigned)NT && (long)F < p.TOT;
       const unsigned po = ok ? (unsigned)((term * NSUB + sub) * (unsigned)p.TOT + F) * 16u : kOut;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, 0, 0, 0);
     }
@@ -252,23 +265,24 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
     wrsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   const int wvoff = lane * 16;
-  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (6 * 1024); };
-  auto load_a = [&](u32x4 (&A)[2][3], int soff) {
+  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (2 * NT * 1024); };
+  auto load_a = [&](u32x4 (&A)[2][NT], int soff) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"
-                     : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * 3 + t) * 1024) : "memory");
+                     : "=v"(A[rb][t]) : "v"(wvoff), "s"(wrsrc), "s"(__builtin_amdgcn_readfirstlane(soff) + (rb * NT + t) * 1024) : "memory");
   };
   // All vector-memory operations of this wave but its 6 youngest (the A fragments requested last) are complete -- `stored`: but
   // the 6 and the stores of the previous tile issued by the step before (2 * NCB; odd NCB: fewer in the fourth step).  The count is chosen by a scalar branch around
   // bare s_waitcnt instructions; ONE statement behind the branch ties the fragment registers to the wait (a tie inside either arm
   // makes the compiler copy the still-in-flight registers in front of the wait).
-  auto wait_a = [&](u32x4 (&A)[2][3], auto nst, bool stored) {  // nst: stores the step before issued when it stored (compile time)
-    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + decltype(nst)::value) : "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  auto wait_a = [&](u32x4 (&A)[2][NT], auto nst, bool stored) {  // nst: stores the step before issued when it stored (compile time)
+    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT + decltype(nst)::value) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT) : "memory");
+    if constexpr (NT == 3) asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+    else asm volatile("" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1])::"memory");
   };
 
   // ---- B fragments: unit (slot, term, position + tap) of the ring, read as two 8-byte halves (odd lane groups: upper first).  The
@@ -285,16 +299,16 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
       qoff[cb] = (p_q(p, f) - (unsigned)t.q0) * 16u + (unsigned)((g & 1) * 8);
     }
   };
-  struct BAddr { unsigned lo[3]; };  // per term: slot + tap part of the address of the half read first
+  struct BAddr { unsigned lo[NT]; };  // per term: slot + tap part of the address of the half read first
   auto b_addr = [&](unsigned vo) __attribute__((always_inline)) {
     BAddr a;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) a.lo[t] = lds_base + vo + t * term_b;
+    for (int t = 0; t < NT; ++t) a.lo[t] = lds_base + vo + t * term_b;
     return a;
   };
-  auto read_b = [&](u32x4 (&B)[3], const BAddr& a, int cb) {
+  auto read_b = [&](u32x4 (&B)[NT], const BAddr& a, int cb) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const unsigned lo = a.lo[t] + qoff[cb];
       u64x2 v;
       v.x = *(lds64_t)(lo);  // volatile: two ds_read_b64, never one ds_read2_b64
@@ -325,6 +339,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
     brsrc.z = __builtin_amdgcn_readfirstlane(p.bias ? (unsigned)p.K * 4u : 0u);
     brsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
+  float oscx = 1.f, oscw = 1.f;  // NT = 2: the sums are scaled back by 2^-(kx + kw), as two factors of about equal exponent
+  if constexpr (NT == 2) { const float2 f = h2_unscale2(*p.amax_x, *p.amax_w); oscx = f.x; oscw = f.y; }
   u32x4 bv[2];
   auto load_bias = [&](const PTile& t) __attribute__((always_inline)) {
     const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
@@ -347,7 +363,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
-        const float v = tot[rb][cb][e] + __uint_as_float(bu);
+        const float v = NT == 2 ? tot[rb][cb][e] * oscx * oscw + __uint_as_float(bu) : tot[rb][cb][e] + __uint_as_float(bu);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * p.sC * 4) : kOut, 0, 0);
         tot[rb][cb][e] = 0.f;
       }
@@ -358,7 +374,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
   int ring = 0;  // ring slot of brick 0 of the current tile
   issue_brick(cur, 0, 0);
   tile_offsets(cur);
-  u32x4 A[2][3], nA[2][3];
+  u32x4 A[2][NT], nA[2][NT];
   load_a(A, wtile(cur.cot));
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
@@ -387,7 +403,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
       return (unsigned)(sl * BB + ((tpl >> 2) * p.Wp + (tpl & 3)) * 16);                                    // tap (dy, dx) = (tpl / 4, tpl % 4)
     };
     BAddr vo = b_addr(b_off());
-    u32x4 B[2][3];
+    u32x4 B[2][NT];
     int since = 0;
 
     // One k-step.  Ac = this step's A fragments (requested one step ago; step 0: during the last step of the previous tile), An
@@ -397,12 +413,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
     // step that stored, the count is 6 + its stores.
     // `ph` (compile time): the step number for the first kStoreSteps steps of a tile, which carry the previous tile's stores; kStoreSteps
     // for every later step
-    auto kstep = [&](auto ph, auto par, int s, u32x4 (&Ac)[2][3], u32x4 (&An)[2][3]) {
+    auto kstep = [&](auto ph, auto par, int s, u32x4 (&Ac)[2][NT], u32x4 (&An)[2][NT]) {
       constexpr int PH = decltype(ph)::value;
       // odd NCB: a step's last column block leaves the next step's first fragments in B[1] -- odd steps walk the two buffers the other way round
       constexpr int PAR = (NCB & 1) ? decltype(par)::value : 0;
       const bool last = PH == kStoreSteps && s + 1 == p.NS;
-      load_a(An, last ? wt_next : wt + (s + 1) * (6 * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
+      load_a(An, last ? wt_next : wt + (s + 1) * (2 * NT * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
       constexpr int PPH = PH >= 1 && PH < kStoreSteps ? PH - 1 : kStoreSteps - 1;  // the step before this one, if it stored
       constexpr int PPairs = kPairs - PPH * kPairsPerStep < kPairsPerStep ? kPairs - PPH * kPairsPerStep : kPairsPerStep;
       wait_a(Ac, std::integral_constant<int, 4 * PPairs>{}, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));
@@ -438,23 +454,36 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
       const BAddr nvo = b_addr(b_off());
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        u32x4(&Bc)[3] = B[(cb + PAR) & 1];
-        u32x4(&Bn)[3] = B[(cb + PAR + 1) & 1];
+        u32x4(&Bc)[NT] = B[(cb + PAR) & 1];
+        u32x4(&Bn)[NT] = B[(cb + PAR + 1) & 1];
         if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
         else if (!last) read_b(Bn, nvo, 0);
-        // six products per (row block, column block), smallest first: (term of A, term of B)
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+        // six (NT = 2: three) products per (row block, column block), smallest first: (term of A, term of B)
+        constexpr int NP = NT == 3 ? 6 : 3;
+        constexpr int TA[6] = {NT - 1, NT == 3 ? 1 : 0, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, NT == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
-        for (int m = 0; m < 6; ++m)
+        for (int m = 0; m < NP; ++m)
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ac[rb][TA[m]]), __builtin_bit_cast(bf16x8, Bc[TB[m]]),
-                                                                  acc[rb][cb], 0, 0, 0);
+          for (int rb = 0; rb < 2; ++rb) {
+            if constexpr (NT == 3)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Ac[rb][TA[m]]), __builtin_bit_cast(bf16x8, Bc[TB[m]]),
+                                                                    acc[rb][cb], 0, 0, 0);
+            else
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ac[rb][TA[m]]), __builtin_bit_cast(f16x8, Bc[TB[m]]),
+                                                                   acc[rb][cb], 0, 0, 0);
+          }
+        if constexpr (NT == 3) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {  // the 6 reads of the next column block spread over this one's 12 MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          for (int k = 0; k < 6; ++k) {  // the 6 reads of the next column block spread over this one's 12 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        } else {  // the 4 reads of the next column block spread over this one's 6 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
       vo = nvo;
@@ -510,7 +539,7 @@ long p2_q(long f, int HoWo, int Wo, int PP, int Wp) {
 
 // position tiles of 64 NCB valid outputs; a tile's (sub-)brick spans from its first position's unit to its last position's last tap
 // (tapext units further); nsub sub-bricks per brick
-P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, int nsub) {
+P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, int nsub, int NT = 3) {
   P2Plan best{};
   double best_cost = 1e30;
   static const int ncb_max = getenv("NC_P2D_NCB") ? atoi(getenv("NC_P2D_NCB")) : 8;
@@ -529,7 +558,7 @@ P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, in
     const int align = 64 / nsub;  // the three terms of a brick are whole 1 KiB pieces
     pl.UBq = (int)((umax + align - 1) / align * align);
     pl.UB = nsub * pl.UBq;
-    pl.npb = 3 * pl.UB / 64;
+    pl.npb = NT * pl.UB / 64;
     pl.lds = 3 * pl.npb * 1024;
     if (pl.npb > kMaxPieces || pl.lds > kLdsMax) continue;
     pl.ntiles = (long)pl.NPT * KT;
@@ -541,24 +570,33 @@ P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, in
   return best;
 }
 
-template <int NCB, bool M1>
+template <int NCB, bool M1, int NT>
 int launch_p(const PParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_p2d<NCB, M1>;
+  auto kern = k_conv_p2d<NCB, M1, NT>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_p2d")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_p2d");
 }
-template <bool M1>
+template <bool M1, int NT>
 int launch_p_ncb(int NCB, const PParams& p, int lds, hipStream_t s) {
   switch (NCB) {
-    case 8: return launch_p<8, M1>(p, lds, s);
-    case 6: return launch_p<6, M1>(p, lds, s);
-    case 4: return launch_p<4, M1>(p, lds, s);
-    default: return launch_p<2, M1>(p, lds, s);
+    case 8: return launch_p<8, M1, NT>(p, lds, s);
+    case 6: return launch_p<6, M1, NT>(p, lds, s);
+    case 4: return launch_p<4, M1, NT>(p, lds, s);
+    default: return launch_p<2, M1, NT>(p, lds, s);
   }
 }
+// the operand form (nc_set_split_terms; 2: two fp16 terms of the tensor times a measured power of two, three products; 3: three bf16 terms)
+// Measured (tools/p2d_check.py, 216 planes): the stride-1 layer gains from the two-term form (forward 0.67 -> 0.51 ms, data gradient 0.85 -> 0.70);
+// the stride-2 layers LOSE (0.33-0.39 -> 0.34-0.50 ms): a third of their time is the conversion already, and the two-term form adds a
+// measuring pass over the input.  So: two-term for the stride-1 layer only.  NC_P2D_TERMS = 2 / 3 forces one form for all (A/B).
+int p2_terms(int kind) {
+  static const int forced = getenv("NC_P2D_TERMS") ? atoi(getenv("NC_P2D_TERMS")) : 0;
+  if (forced == 2 || forced == 3) return forced;
+  return s3x_get_terms() == 2 && kind == 0 ? 2 : 3;
+}
 
-size_t p2_packed_bytes(int NS, int Kout) { return (size_t)(Kout / 64) * 2 * NS * 6 * 1024; }
+size_t p2_packed_bytes(int NS, int Kout, int NT = 3) { return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024; }
 size_t p2_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // One problem of the kernel: a valid KT x KT stride-1 convolution over planes of PP = Hp x Wp units, positions (b, y < Ho, x < Wo)
@@ -616,17 +654,30 @@ bool p2_shape(const ConvDims& d, int dgrad) {
 int run_p2d(const float* in, const float* w, const float* bias, float* out, const ConvDims& d, int dgrad, void* ws, size_t wsb, hipStream_t s) {
   const P2Geom g = p2_geom(d, dgrad);
   const size_t wb = p2_align(p2_packed_bytes(g.NS, g.Kout));
-  if (!ws || wsb < g.xs_bytes + wb + 256) { set_error("conv_p2d: workspace too small"); return NC_ERR_WS; }
+  if (!ws || wsb < g.xs_bytes + wb + 512) { set_error("conv_p2d: workspace too small"); return NC_ERR_WS; }
   uint4* xs = (uint4*)ws;
   unsigned short* wp = (unsigned short*)((char*)ws + g.xs_bytes);
+  unsigned* cells = (unsigned*)((char*)ws + g.xs_bytes + wb);  // two-term form: [0] the input's cell, [1] the weights' (h2.hip)
+  const int NT = p2_terms(g.kind);
   const long npad = (long)g.B * g.PP;
-  if (g.kind == 1)
-    hipLaunchKernelGGL(k_s2d_split3, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8 * 4)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.Hp, g.Wp, g.TOT, npad);
+  if (NT == 2) {
+    if (int e = h2_zero_cells(cells, 2, s)) return e;
+    if (int e = h2_absmax(in, (long)g.B * g.Cin * g.Hin * g.Win, cells, s)) return e;
+    if (int e = h2_absmax(w, (long)d.K * d.C * 16, cells + 1, s)) return e;
+    if (g.kind == 1)
+      hipLaunchKernelGGL(k_s2d_split3<2>, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8 * 4)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.Hp, g.Wp, g.TOT, npad,
+                         (const unsigned*)cells);
+    else
+      hipLaunchKernelGGL(k_pad_split3_2d<2>, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.pad, g.Hp, g.Wp,
+                         g.TOT, npad, g.kind == 2 ? 1 : 0, (const unsigned*)cells);
+  } else if (g.kind == 1)
+    hipLaunchKernelGGL(k_s2d_split3<3>, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8 * 4)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.Hp, g.Wp, g.TOT, npad,
+                       (const unsigned*)nullptr);
   else
-    hipLaunchKernelGGL(k_pad_split3_2d, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.pad, g.Hp, g.Wp,
-                       g.TOT, npad, g.kind == 2 ? 1 : 0);
+    hipLaunchKernelGGL(k_pad_split3_2d<3>, dim3((unsigned)cdiv(npad, 256), (unsigned)(g.Cin / 8)), dim3(256), 0, s, in, xs, g.Cin, g.Hin, g.Win, g.pad, g.Hp, g.Wp,
+                       g.TOT, npad, g.kind == 2 ? 1 : 0, (const unsigned*)nullptr);
   if (int e = check_launch("conv_p2d convert")) return e;
-  const long total = (long)(p2_packed_bytes(g.NS, g.Kout) / 2);
+  const long total = (long)(p2_packed_bytes(g.NS, g.Kout, NT) / 2);
   // forward: w[co][ci][tap]; data gradients: w[co as ci][ci as co][..] (ConvDims: weights are [d.K][d.C][4][4])
   const long so = dgrad ? 16 : (long)d.C * 16, si = dgrad ? (long)d.C * 16 : 16;
   static const int flush = getenv("NC_P2D_FLUSH") ? atoi(getenv("NC_P2D_FLUSH")) : 4;
@@ -634,7 +685,7 @@ int run_p2d(const float* in, const float* w, const float* bias, float* out, cons
   for (int cls = 0; cls < nclass; ++cls) {
     const int ry = cls >> 1, rx = cls & 1;
     PParams p{};
-    p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = out;
+    p.xs = xs; p.wp = (const uint4*)wp; p.bias = bias; p.y = out; p.amax_x = cells; p.amax_w = cells + 1;
     p.B = g.B; p.NB = g.NB; p.K = g.Kout; p.NS = g.NS;
     p.Wp = g.Wp; p.PP = g.PP; p.TOT = g.TOT; p.KT = g.Kout / 64;
     if (g.kind == 2) {  // dx[b][c][2u + ry][2v + rx], u < ceil((H - ry) / 2)
@@ -650,15 +701,21 @@ int run_p2d(const float* in, const float* w, const float* bias, float* out, cons
     if (p.Ho < 1 || p.Wo < 1) continue;
     p.HoWo = p.Ho * p.Wo;
     p.npos = (long)g.B * p.HoWo;
-    const P2Plan pl = p2_plan(p.npos, p.Ho, p.Wo, g.PP, g.Wp, p.KT, g.tapext, g.nsub);
+    const P2Plan pl = p2_plan(p.npos, p.Ho, p.Wo, g.PP, g.Wp, p.KT, g.tapext, g.nsub, NT);
     if (!pl.ok) { set_error("conv_p2d: shape not covered"); return NC_ERR_SHAPE; }
     p.NPT = pl.NPT; p.UB = pl.UB; p.UBq = pl.UBq; p.npb = pl.npb;
     p.mUB = magic(pl.UB); p.mUBq = magic(pl.UBq); p.mHoWo = magic(p.HoWo); p.mWo = magic(p.Wo);
     p.t_count = (int)pl.ntiles; p.tiles_per_xcd = (int)cdiv(pl.ntiles, 8);
     p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
-    hipLaunchKernelGGL(k_pack_w_p2d, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g.NS, so, si, g.kind, g.kind == 0 && dgrad ? 1 : 0, ry, rx, total);
+    if (NT == 2)
+      hipLaunchKernelGGL(k_pack_w_p2d<2>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g.NS, so, si, g.kind, g.kind == 0 && dgrad ? 1 : 0, ry, rx, total,
+                         (const unsigned*)(cells + 1));
+    else
+      hipLaunchKernelGGL(k_pack_w_p2d<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g.NS, so, si, g.kind, g.kind == 0 && dgrad ? 1 : 0, ry, rx, total,
+                         (const unsigned*)nullptr);
     if (int e = check_launch("conv_p2d pack")) return e;
-    const int e = g.kind == 0 ? launch_p_ncb<false>(pl.NCB, p, pl.lds, s) : launch_p_ncb<true>(pl.NCB, p, pl.lds, s);
+    const int e = NT == 2 ? (g.kind == 0 ? launch_p_ncb<false, 2>(pl.NCB, p, pl.lds, s) : launch_p_ncb<true, 2>(pl.NCB, p, pl.lds, s))
+                          : (g.kind == 0 ? launch_p_ncb<false, 3>(pl.NCB, p, pl.lds, s) : launch_p_ncb<true, 3>(pl.NCB, p, pl.lds, s));
     if (e) return e;
   }
   return NC_OK;
