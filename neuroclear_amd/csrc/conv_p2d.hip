@@ -589,11 +589,16 @@ int launch_p_ncb(int NCB, const PParams& p, int lds, hipStream_t s) {
 // the operand form (nc_set_split_terms; 2: two fp16 terms of the tensor times a measured power of two, three products; 3: three bf16 terms)
 // Measured (tools/p2d_check.py, 216 planes): the stride-1 layer gains from the two-term form (forward 0.67 -> 0.51 ms, data gradient 0.85 -> 0.70);
 // the stride-2 layers LOSE (0.33-0.39 -> 0.34-0.50 ms): a third of their time is the conversion already, and the two-term form adds a
-// measuring pass over the input.  So: two-term for the stride-1 layer only.  NC_P2D_TERMS = 2 / 3 forces one form for all (A/B).
+// measuring pass over the input.  And a MEASURED power of two depends on which planes share the call: Athena's shared pass over the fake
+// planes (216 planes in one call) and the two separate passes (108 each) then differ in the last bit, where the three-term form is
+// bit-identical (tests/test_gpu_fullsize.py::test_athena_step_108_streams_tuner_and_shared_pass_agree uses exactly that to catch stream and
+// scratch bugs).  So the default stays THREE-term here; NC_P2D_TERMS=1: two-term for the stride-1 layer (Athena 67-68 -> 65.2 ms), =2: for
+// all layers (70.1 ms: slower).  Taking the power of two from the InstanceNorm bound instead (sqrt(H W) per plane, as the generators do) would
+// restore the invariance; it needs the bound handed down from nets.hip.
 int p2_terms(int kind) {
-  static const int forced = getenv("NC_P2D_TERMS") ? atoi(getenv("NC_P2D_TERMS")) : 0;
-  if (forced == 2 || forced == 3) return forced;
-  return s3x_get_terms() == 2 && kind == 0 ? 2 : 3;
+  static const int mode = getenv("NC_P2D_TERMS") ? atoi(getenv("NC_P2D_TERMS")) : 3;
+  if (mode == 2) return 2;
+  return mode == 1 && kind == 0 && s3x_get_terms() == 2 ? 2 : 3;
 }
 
 size_t p2_packed_bytes(int NS, int Kout, int NT = 3) { return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024; }
