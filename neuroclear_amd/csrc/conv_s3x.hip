@@ -125,7 +125,14 @@ __global__ void __launch_bounds__(256) k_absmax_w(const float* __restrict__ w, l
     const unsigned q = (unsigned)__shfl_xor((int)m, o);
     m = q > m ? q : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  __shared__ unsigned wm[4];  // one atomic per block (h2.hip k_absmax)
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = wm[0];
+    for (int k = 1; k < 4; ++k) b = wm[k] > b ? wm[k] : b;
+    if (b) atomicMax(out, b);
+  }
 }
 
 struct XParams {
@@ -646,7 +653,7 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   const long nw = (long)Kout * Cin * T3;
   if (!cell_b) cell_b = cell_a;
   // (the group test below reads the input channel as (i / T3) % Cin: the forward layout [co][ci][tap]; data gradients have no groups)
-  hipLaunchKernelGGL(k_absmax_w, dim3((unsigned)(cdiv(nw, 256 * 4) < 1024 ? cdiv(nw, 256 * 4) : 1024)), dim3(256), 0, s, w, nw, T3, Cin,
+  hipLaunchKernelGGL(k_absmax_w, dim3((unsigned)(cdiv(nw, 256 * 8) < 256 ? cdiv(nw, 256 * 8) : 256)), dim3(256), 0, s, w, nw, T3, Cin,
                      flip ? Cin : split_c, cell_a, cell_b, wcell);
   const long total = (long)(s3x_packed_bytes(Cin, Kout, KS, 2) / 2);
   hipLaunchKernelGGL(k_pack_w_s3x<2>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip, total,

@@ -44,9 +44,17 @@ __global__ void __launch_bounds__(256) k_absmax(const float* __restrict__ x, lon
     const unsigned q = (unsigned)__shfl_xor((int)m, o);
     m = q > m ? q : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) {
-    atomicMax(cell, m);
-    if (cell2) atomicMax(cell2, m);
+  // one atomic per BLOCK: thousands of waves hitting one address serialise (32 K atomics cost 0.15 ms of a 0.28 ms launch)
+  __shared__ unsigned wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = wm[0];
+    for (int k = 1; k < 4; ++k) b = wm[k] > b ? wm[k] : b;
+    if (b) {
+      atomicMax(cell, b);
+      if (cell2) atomicMax(cell2, b);
+    }
   }
 }
 
@@ -116,8 +124,8 @@ int h2_set_cell(unsigned* cell, float bound, hipStream_t s) {
 }
 int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2) {  // *cell (and *cell2) = max(itself, largest finite |x|)
   if ((unsigned long long)x & 3) { set_error("h2_absmax: the tensor must be 4-byte aligned"); return NC_ERR_ARG; }
-  long blocks = cdiv(n, 256 * 4 * 4);
-  if (blocks > 4096) blocks = 4096;
+  long blocks = cdiv(n, 256 * 4 * 8);
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n, cell, cell2);
   return check_launch("h2_absmax");
