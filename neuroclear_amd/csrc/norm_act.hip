@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void k_in_bwd_sums_h2(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_in_bwd_bound(const float* __restrict__ rstd, const unsigned* __restrict__ gmax,
-                                                      const unsigned* __restrict__ xmax, int NC, unsigned* __restrict__ cell) {
+                                                      const unsigned* __restrict__ xmax, int NC, unsigned* __restrict__ cell,
+                                                      unsigned* __restrict__ cell2) {
   unsigned m = 0;
   for (int i = threadIdx.x; i < NC; i += 256) {
     const float bnd = rstd[i] * __uint_as_float(gmax[i]) * (2.f + __uint_as_float(xmax[i]));
@@ -514,7 +515,10 @@ __global__ __launch_bounds__(256) void k_in_bwd_bound(const float* __restrict__ 
     const unsigned q = (unsigned)__shfl_xor((int)m, o);
     m = q > m ? q : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(cell, m);
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicMax(cell, m);
+    atomicMax(cell2, m);
+  }
 }
 
 __global__ void k_zero_u32(unsigned* p, int n) {
@@ -1001,8 +1005,7 @@ int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)cdiv(64 + 2 * NC, 256)), dim3(256), 0, s, cells, 64 + 2 * NC);
   const int splits = pick_splits(NC, S);
   hipLaunchKernelGGL(k_in_bwd_sums_h2, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws, gmax, xmax);
-  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells);
-  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells + 1);
+  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells, cells + 1);
   long bx = cdiv(S, 1024);
   if (bx > 1024) bx = 1024;
   double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
