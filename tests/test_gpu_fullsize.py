@@ -253,6 +253,24 @@ def test_apollo_step_108_streams_and_fused_paths_agree(monkeypatch):
         assert torch.equal(p0, p1), (ds, fp)
 
 
+def test_apollo_step_108_two_term_and_three_term_forms_agree(monkeypatch):
+    """The same two optimisation steps at 108^3 on the two-term fp16 form of the split-operand convolutions (the default) and on the
+    three-term bf16 form: two fp32-accurate evaluations of the same step -- every loss of the first step within 2e-5, of the second (one Adam
+    update apart, ReLU / max-pool decisions may differ) within 5e-3, the generator's output on the updated weights within 1e-4."""
+    from neuroclear_amd._lib import lib
+    assert lib().nc_get_split_terms() == 2
+    two, _, d2 = _apollo_108(monkeypatch, True, True)
+    lib().nc_set_split_terms(3)
+    try:
+        three, _, d3 = _apollo_108(monkeypatch, True, True)
+    finally:
+        lib().nc_set_split_terms(2)
+    assert d2 <= 1e-5 and d3 <= 1e-5
+    for it, tol in ((0, 2e-5), (1, 5e-3)):
+        for k in two[it]:
+            assert abs(two[it][k] - three[it][k]) <= tol * max(abs(three[it][k]), 1e-3), (it, k, two[it][k], three[it][k])
+
+
 def _athena_108(monkeypatch, d_streams, reuse, tune, seed=41):
     import contextlib
     import io
