@@ -228,9 +228,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     const int soff = zok ? (int)(zz * HW * 16) : 0;
     unsigned char* buf = lds_raw + slot * BB;
     if (kept) {
-#pragma unroll 1
-      for (int i = 0, pc = wave; pc < p.npb; ++i, pc += kDmaWaves)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, *(lds32_t)(otab + i * 256), soff, 0, 0);
+      unsigned po[kPW];  // all table reads in flight before the first request (one at a time each waited a full LDS round trip)
+#pragma unroll
+      for (int i = 0; i < kPW; ++i) po[i] = *(lds32_t)(otab + i * 256);
+#pragma unroll
+      for (int i = 0; i < kPW; ++i) {
+        const int pc = wave + kDmaWaves * i;
+        if (pc < p.npb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po[i], soff, 0, 0);
+      }
       return;
     }
 #pragma unroll 1
