@@ -56,6 +56,7 @@ struct TParams3 {
   uint2* ys;          // nullable: S3 output, halves of units: channels [c0, c0 + K) of [N][oblocks][3][8 S][2]
   int N, C, K, D, H, W;
   int oblocks, ob0;
+  const unsigned* h2cell;  // nullable: ys is an H2 tensor (two fp16 terms of y * 2^k, h2.hip) and this its cell -- a BOUND of |y| set before the launch
   int ngroups;        // (K / 16) * (8 / QN)
   long ntiles;        // N * ceil(S / 512)
 };
@@ -160,7 +161,16 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) yk[(long)e * S2] = val[e];
         }
-        if (p.ys) {
+        if (p.ys && p.h2cell) {
+          unsigned short t3[4][3];
+          const float sc = h2_scale(*p.h2cell);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h2_split(val[e] * sc, t3[e]);
+          const long blk = ((long)n * p.oblocks + p.ob0 + kg * 2 + (g >> 1)) * 2;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            p.ys[((blk + t) * S2 + o) * 2 + (g & 1)] = make_uint2(t3[0][t] | ((unsigned)t3[1][t] << 16), t3[2][t] | ((unsigned)t3[3][t] << 16));
+        } else if (p.ys) {
           unsigned short t3[4][3];
 #pragma unroll
           for (int e = 0; e < 4; ++e) s3_split(val[e], t3[e]);
@@ -172,6 +182,30 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
       }
     }
   }
+}
+
+// |y| of ConvTranspose3d(k 2, s 2) is bounded without looking at y: every output voxel receives exactly ONE tap per input channel, so
+// |y[co]| <= max over (co, tap) of sum_ci |w[ci][co][tap]| * max|x| + max|b|.  With x an InstanceNorm output (max|x| <= sqrt(S)) the bound is
+// loose by 2^7-2^9 against typical values -- inside what fp16's exponent range forgives (s3_common.hpp) -- and it lets the kernel write the
+// H2 form of its output itself.  One block; cell <- float bits of the bound.
+__global__ void __launch_bounds__(256) k_convT_bound(const float* __restrict__ w, const float* __restrict__ bias, int C, int K, float in_bound,
+                                                     unsigned* __restrict__ cell) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int kq = threadIdx.x; kq < K * 8; kq += 256) {
+    float sabs = 0.f;
+    for (int ci = 0; ci < C; ++ci) sabs += fabsf(w[(long)ci * K * 8 + kq]);
+    const float b = bias ? fabsf(bias[kq >> 3]) : 0.f;
+    const float v = sabs * in_bound + b;
+    m = v > m ? v : m;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *cell = __float_as_uint(red[0] * 1.001f) & 0x7fffffffu;
 }
 
 int qn_for(int C) { return (C / 32) * 8 * 3 * 1024 <= 128 * 1024 ? 8 : 4; }
@@ -188,8 +222,14 @@ bool convT_s3x_supported(int N, int C, int D, int H, int W, int K) {
 size_t convT_s3x_ws_bytes(int C, int K) { return (size_t)C * K * 8 * 3 * 2 + 256; }
 
 // xs: the input in S3 form; y (nullable) fp32 output; ys (nullable) channels [c0, c0 + K) of a ctot-channel S3 tensor; ws: packed weights
+int convT_h2_bound(const float* w, const float* bias, int C, int K, float in_bound, unsigned* cell, hipStream_t s) {
+  hipLaunchKernelGGL(k_convT_bound, dim3(1), dim3(256), 0, s, w, bias, C, K, in_bound, cell);
+  return check_launch("convT_h2_bound");
+}
+
+// h2cell (nullable): ys is an H2 tensor (4 bytes per element) and *h2cell the bound its power of two comes from (convT_h2_bound)
 int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H, int W,
-                  int K, void* ws, size_t wsb, hipStream_t s) {
+                  int K, void* ws, size_t wsb, hipStream_t s, const unsigned* h2cell) {
   if (!xs || !w || (!y && !ys) || !ws) { set_error("convT_fwd_s3x: null pointer"); return NC_ERR_ARG; }
   if (!convT_s3x_supported(N, C, D, H, W, K) || ctot % 8 || c0 % 8) { set_error("convT_fwd_s3x: shape not covered"); return NC_ERR_SHAPE; }
   if (wsb < convT_s3x_ws_bytes(C, K)) { set_error("convT_fwd_s3x: workspace too small"); return NC_ERR_WS; }
@@ -201,7 +241,7 @@ int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, v
   TParams3 p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)ws; p.bias = bias; p.y = y; p.ys = (uint2*)ys;
   p.N = N; p.C = C; p.K = K; p.D = D; p.H = H; p.W = W;
-  p.oblocks = ctot / 8; p.ob0 = c0 / 8;
+  p.oblocks = ctot / 8; p.ob0 = c0 / 8; p.h2cell = ys ? h2cell : nullptr;
   p.ngroups = (K / 16) * (8 / QN);
   p.ntiles = (long)N * cdiv(S, 512);
   // 256 workgroups (one per CU: the weights take most of its LDS), a whole number of tile slots per XCD
