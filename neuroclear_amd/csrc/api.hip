@@ -630,16 +630,26 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       const unsigned *c0 = cells, *c1 = cells + 1, *c2 = cells + 2;
       NC_TRY(h2_zero_cells(cells + 3, 2, hs));
       NC_TRY(block(0, xn, nullptr, nullptr, W + u.s_a1, 64, 0, 1, 64, S0, S1, S2, nullptr, nullptr, 0, c0));
-      NC_TRY(block(1, nullptr, W + u.s_a1, W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0));
-      NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
-      // a max-pool of InstanceNorm outputs keeps their bound: converted with the upper level's cell, into a slot nobody needs yet (the
-      // upper half of s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it)
+      // The max-pools work on the H2 tensors themselves (the winner's two terms are the pooled element's terms, same cell: h2.hip): blocks 1
+      // and 3 write NO fp32 activation, and nothing is converted.  The pooled tensors go into slots nobody needs yet (the upper half of
+      // s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it).  NC_POOL_H2=0: fp32 pool + conversion (A/B)
+      static const bool pool_h2 = !(getenv("NC_POOL_H2") && atoi(getenv("NC_POOL_H2")) == 0);
       void* p1h = W + u.s_cat2 + 128 * Sh;
-      NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, 1, 64, Sh, 64, 0, c0, hs));
+      NC_TRY(block(1, nullptr, W + u.s_a1, pool_h2 ? nullptr : W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0));
+      if (pool_h2) {
+        NC_TRY(maxpool2_h2(W + u.s_cat1, p1h, 1, 64, 128, S0, S1, S2, hs));
+      } else {
+        NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
+        NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, 1, 64, Sh, 64, 0, c0, hs));
+      }
       NC_TRY(block(2, nullptr, p1h, nullptr, W + u.s_a2, 128, 0, 64, 128, h0, h1, h2, c0, nullptr, 0, c1));
-      NC_TRY(block(3, nullptr, W + u.s_a2, W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1));
-      NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
-      NC_TRY(split2h_into(W + u.p2, 128 * Sq, W + u.s_b2, 1, 128, Sq, 128, 0, c1, hs));
+      NC_TRY(block(3, nullptr, W + u.s_a2, pool_h2 ? nullptr : W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1));
+      if (pool_h2) {
+        NC_TRY(maxpool2_h2(W + u.s_cat2, W + u.s_b2, 1, 128, 256, h0, h1, h2, hs));
+      } else {
+        NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
+        NC_TRY(split2h_into(W + u.p2, 128 * Sq, W + u.s_b2, 1, 128, Sq, 128, 0, c1, hs));
+      }
       NC_TRY(block(4, nullptr, W + u.s_b2, nullptr, W + u.s_b1, 256, 0, 128, 256, q0, q1, q2, c1, nullptr, 0, c2));
       NC_TRY(block(5, nullptr, W + u.s_b1, nullptr, W + u.s_b2, 256, 0, 256, 256, q0, q1, q2, c2, nullptr, 0, c2));
       // the transposed convolutions keep their three-term S3 input (small tensors) and write fp32; their halves of the concatenations

@@ -226,6 +226,7 @@ int instnorm_relu_tail_sigmoid(const float* x, const float* mean, const float* r
                                const float* b2, float* y, int C, long S, hipStream_t s);
 int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
                               float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
+int maxpool2_h2(const void* in, void* out, int N, int C, int ctot, int D, int H, int W, hipStream_t s);
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s);
 int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
 int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2 = nullptr);

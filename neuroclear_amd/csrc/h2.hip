@@ -109,7 +109,53 @@ __global__ void __launch_bounds__(256) k_act_split2h(const float* __restrict__ x
   for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
 }
 
+// MaxPool3d(2) on an H2 tensor: the value of an element is (a0 + a1) / 2^k exactly, the larger value has the larger a0 + a1, and the winner's
+// two terms ARE the pooled element's terms (same cell) -- so the pool needs no fp32 tensor on either side.  One thread per (8-channel block,
+// output voxel): eight 16-byte units per term in, one out.  in: channels [0, 8 * cblocks) of a tensor with `iblocks` blocks per sample.
+__global__ void __launch_bounds__(256) k_maxpool2_h2(const uint4* __restrict__ in, uint4* __restrict__ out, int cblocks, int iblocks, int D, int H,
+                                                     int W) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long So = (long)Do * Ho * Wo, S = (long)D * H * W;
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= So) return;
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  const int xo = (int)(v % Wo), yo = (int)((v / Wo) % Ho), zo = (int)(v / ((long)Wo * Ho));
+  const uint4* i0 = in + ((long)n * iblocks + cb) * 2 * S;
+  float best[8];
+  unsigned short t0[8], t1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; t0[j] = 0; t1[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long u = ((long)(2 * zo + (k >> 2)) * H + (2 * yo + ((k >> 1) & 1))) * W + 2 * xo + (k & 1);
+    const uint4 a = i0[u], b = i0[S + u];
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned short h0 = (unsigned short)(aw[j >> 1] >> ((j & 1) * 16)), h1 = (unsigned short)(bw[j >> 1] >> ((j & 1) * 16));
+      const float val = (float)__builtin_bit_cast(_Float16, h0) + (float)__builtin_bit_cast(_Float16, h1);
+      // (first maximum in scan order, as nc_maxpool2_fwd; NaN never wins over a number, a plane of NaNs yields the first element's terms)
+      if (val > best[j] || k == 0) { best[j] = val; t0[j] = h0; t1[j] = h1; }
+    }
+  }
+  uint4 o0, o1;
+  o0.x = t0[0] | ((unsigned)t0[1] << 16); o0.y = t0[2] | ((unsigned)t0[3] << 16); o0.z = t0[4] | ((unsigned)t0[5] << 16); o0.w = t0[6] | ((unsigned)t0[7] << 16);
+  o1.x = t1[0] | ((unsigned)t1[1] << 16); o1.y = t1[2] | ((unsigned)t1[3] << 16); o1.z = t1[4] | ((unsigned)t1[5] << 16); o1.w = t1[6] | ((unsigned)t1[7] << 16);
+  uint4* o = out + ((long)n * cblocks + cb) * 2 * So;
+  o[v] = o0;
+  o[So + v] = o1;
+}
+
 }  // namespace
+
+// channels [0, C) of an H2 tensor with ctot channels per sample -> a dense H2 tensor of C channels at half the resolution (same cell)
+int maxpool2_h2(const void* in, void* out, int N, int C, int ctot, int D, int H, int W, hipStream_t s) {
+  if (C % 8 || ctot % 8 || (D | H | W) & 1) { set_error("maxpool2_h2: channels % 8, even extents"); return NC_ERR_SHAPE; }
+  const long So = (long)(D / 2) * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(k_maxpool2_h2, dim3((unsigned)cdiv(So, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, C / 8, ctot / 8, D, H,
+                     W);
+  return check_launch("maxpool2_h2");
+}
 
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, cells, n, 0u);
