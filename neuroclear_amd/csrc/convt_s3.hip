@@ -187,25 +187,24 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
 // |y| of ConvTranspose3d(k 2, s 2) is bounded without looking at y: every output voxel receives exactly ONE tap per input channel, so
 // |y[co]| <= max over (co, tap) of sum_ci |w[ci][co][tap]| * max|x| + max|b|.  With x an InstanceNorm output (max|x| <= sqrt(S)) the bound is
 // loose by 2^7-2^9 against typical values -- inside what fp16's exponent range forgives (s3_common.hpp) -- and it lets the kernel write the
-// H2 form of its output itself.  One block; cell <- float bits of the bound.
+// H2 form of its output itself.  cell (zeroed by the caller) <- float bits of the bound, atomicMax over the blocks.
 __global__ void __launch_bounds__(256) k_convT_bound(const float* __restrict__ w, const float* __restrict__ bias, int C, int K, float in_bound,
                                                      unsigned* __restrict__ cell) {
   __shared__ float red[256];
-  float m = 0.f;
-  for (int kq = threadIdx.x; kq < K * 8; kq += 256) {
+  const int kq = blockIdx.x * 256 + threadIdx.x;  // one (output channel, tap) column per thread: coalesced over the columns
+  float v = 0.f;
+  if (kq < K * 8) {
     float sabs = 0.f;
     for (int ci = 0; ci < C; ++ci) sabs += fabsf(w[(long)ci * K * 8 + kq]);
-    const float b = bias ? fabsf(bias[kq >> 3]) : 0.f;
-    const float v = sabs * in_bound + b;
-    m = v > m ? v : m;
+    v = sabs * in_bound + (bias ? fabsf(bias[kq >> 3]) : 0.f);
   }
-  red[threadIdx.x] = m;
+  red[threadIdx.x] = v;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *cell = __float_as_uint(red[0] * 1.001f) & 0x7fffffffu;
+  if (threadIdx.x == 0) atomicMax(cell, __float_as_uint(red[0] * 1.001f) & 0x7fffffffu);  // (the cell was zeroed by the caller)
 }
 
 int qn_for(int C) { return (C / 32) * 8 * 3 * 1024 <= 128 * 1024 ? 8 : 4; }
@@ -223,7 +222,7 @@ size_t convT_s3x_ws_bytes(int C, int K) { return (size_t)C * K * 8 * 3 * 2 + 256
 
 // xs: the input in S3 form; y (nullable) fp32 output; ys (nullable) channels [c0, c0 + K) of a ctot-channel S3 tensor; ws: packed weights
 int convT_h2_bound(const float* w, const float* bias, int C, int K, float in_bound, unsigned* cell, hipStream_t s) {
-  hipLaunchKernelGGL(k_convT_bound, dim3(1), dim3(256), 0, s, w, bias, C, K, in_bound, cell);
+  hipLaunchKernelGGL(k_convT_bound, dim3((unsigned)cdiv((long)K * 8, 256)), dim3(256), 0, s, w, bias, C, K, in_bound, cell);
   return check_launch("convT_h2_bound");
 }
 
