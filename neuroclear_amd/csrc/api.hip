@@ -656,14 +656,16 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // are measured and converted, the ratio of the two halves' powers of two goes into the consumer's weights
       const bool t10 = convT_s3x_supported(1, 256, q0, q1, q2, 128) && u.conv_ws_bytes >= convT_s3x_ws_bytes(256, 128);
       const bool t11 = convT_s3x_supported(1, 128, h0, h1, h2, 64) && u.conv_ws_bytes >= convT_s3x_ws_bytes(128, 64);
-      NC_TRY(block(6, nullptr, W + u.s_b2, t10 ? nullptr : W + u.b1, t10 ? W + u.s_b1 : nullptr, 256, 0, 256, 256, q0, q1, q2, c2));
+      static const bool ct_h2 = !(getenv("NC_CONVT_H2") && atoi(getenv("NC_CONVT_H2")) == 0);  // 0: three-term input, fp32 output measured and converted (A/B)
+      const bool t10h = t10 && ct_h2, t11h = t11 && ct_h2;  // the two-term transposed convolution: H2 in (the block's output, bound sqrt(S)), H2 out
+      NC_TRY(block(6, nullptr, W + u.s_b2, t10 ? nullptr : W + u.b1, t10 ? W + u.s_b1 : nullptr, 256, 0, 256, 256, q0, q1, q2, c2, nullptr, 0,
+                   t10h ? c2 : nullptr));
       // (the matrix-core transposed convolution writes the H2 form of its half itself, with a BOUND for its power of two -- every output
       // voxel gets one tap per input channel, convt_s3.hip; the fp32 kernel's output is measured and converted)
-      static const bool ct_h2 = !(getenv("NC_CONVT_H2") && atoi(getenv("NC_CONVT_H2")) == 0);  // 0: fp32 output, measured and converted (A/B)
-      if (t10 && ct_h2) {
+      if (t10h) {
         NC_TRY(convT_h2_bound(P + o.w[10], P + o.b[10], 256, 128, sqrtf((float)Sq), cells + 3, hs));
         NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], nullptr, W + u.s_cat2, 256, 128, 1, 256, q0, q1, q2, 128, cws, u.conv_ws_bytes, hs,
-                             cells + 3));
+                             cells + 3, c2));
       } else {
         if (t10) NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, nullptr, 256, 128, 1, 256, q0, q1, q2, 128, cws,
                                       u.conv_ws_bytes, hs));
@@ -672,11 +674,12 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
         NC_TRY(split2h_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, cells + 3, hs));
       }
       NC_TRY(block(7, nullptr, W + u.s_cat2, nullptr, W + u.s_a2, 128, 0, 256, 128, h0, h1, h2, c1, cells + 3, 128, c1));
-      NC_TRY(block(8, nullptr, W + u.s_a2, t11 ? nullptr : W + u.a2b, t11 ? W + u.s_cat2 : nullptr, 128, 0, 128, 128, h0, h1, h2, c1));
-      if (t11 && ct_h2) {
+      NC_TRY(block(8, nullptr, W + u.s_a2, t11 ? nullptr : W + u.a2b, t11 ? W + u.s_cat2 : nullptr, 128, 0, 128, 128, h0, h1, h2, c1, nullptr, 0,
+                   t11h ? c1 : nullptr));
+      if (t11h) {
         NC_TRY(convT_h2_bound(P + o.w[11], P + o.b[11], 128, 64, sqrtf((float)Sh), cells + 4, hs));
         NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], nullptr, W + u.s_cat1, 128, 64, 1, 128, h0, h1, h2, 64, cws, u.conv_ws_bytes, hs,
-                             cells + 4));
+                             cells + 4, c1));
       } else {
         if (t11) NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, nullptr, 128, 64, 1, 128, h0, h1, h2, 64, cws,
                                       u.conv_ws_bytes, hs));

@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTWaves = 8;
@@ -28,13 +29,16 @@ constexpr int kTThreads = kTWaves * 64;
 constexpr int kTCB = 4;  // column blocks (16 voxels) per wave and tile
 
 // wp[kg][qg][s][ql][term][lane][8] bf16: lane (m = lane % 16, g = lane / 16) = W[ci = (4 s + g) 8 + j][k = kg 16 + m][q = qg QN + ql]
-__global__ void __launch_bounds__(256) k_pack_wT_s3(const float* __restrict__ w, unsigned short* __restrict__ wp, int C, int K, int QN, long total) {
+// NT = 2: the two fp16 terms of w * 2^k, k from the weights' cell (h2.hip)
+template <int NT>
+__global__ void __launch_bounds__(256) k_pack_wT_s3(const float* __restrict__ w, unsigned short* __restrict__ wp, int C, int K, int QN, long total,
+                                                    const unsigned* __restrict__ wcell) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7);
   long r = i >> 3;
   const int lane = (int)(r & 63); r >>= 6;
-  const int term = (int)(r % 3); r /= 3;
+  const int term = (int)(r % NT); r /= NT;
   const int ql = (int)(r % QN); r /= QN;
   const int NS = C / 32;
   const int s = (int)(r % NS); r /= NS;
@@ -44,7 +48,8 @@ __global__ void __launch_bounds__(256) k_pack_wT_s3(const float* __restrict__ w,
   const int m = lane & 15, g = lane >> 4;
   const int ci = (4 * s + g) * 8 + j, k = kg * 16 + m, q = qg * QN + ql;
   unsigned short t[3];
-  s3_split(w[((long)ci * K + k) * 8 + q], t);
+  if constexpr (NT == 3) s3_split(w[((long)ci * K + k) * 8 + q], t);
+  else h2_split(w[((long)ci * K + k) * 8 + q] * h2_scale(*wcell), t);
   wp[i] = t[term];
 }
 
@@ -56,12 +61,13 @@ struct TParams3 {
   uint2* ys;          // nullable: S3 output, halves of units: channels [c0, c0 + K) of [N][oblocks][3][8 S][2]
   int N, C, K, D, H, W;
   int oblocks, ob0;
+  const unsigned *xcell, *wcell;  // NT = 2: the input is an H2 tensor with this cell, the packed weights carry that one
   const unsigned* h2cell;  // nullable: ys is an H2 tensor (two fp16 terms of y * 2^k, h2.hip) and this its cell -- a BOUND of |y| set before the launch
   int ngroups;        // (K / 16) * (8 / QN)
   long ntiles;        // N * ceil(S / 512)
 };
 
-template <int QN>
+template <int QN, int NT = 3>
 __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,9 +85,9 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
 
   // this workgroup's weights -> LDS (A fragments, 1 KiB each: [s][ql][term][lane])
   {
-    const uint4* src = p.wp + (long)grp * NS * QN * 3 * 64;
+    const uint4* src = p.wp + (long)grp * NS * QN * NT * 64;
     uint4* dst = reinterpret_cast<uint4*>(lds_raw);
-    for (int i = tid; i < NS * QN * 3 * 64; i += kTThreads) dst[i] = src[i];
+    for (int i = tid; i < NS * QN * NT * 64; i += kTThreads) dst[i] = src[i];
   }
   __syncthreads();
   const i32x4* const wl = reinterpret_cast<const i32x4*>(lds_raw) + lane;
@@ -92,6 +98,8 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
   float bb[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) bb[e] = p.bias ? p.bias[kg * 16 + 4 * g + e] : 0.f;
+  float oscx = 1.f, oscw = 1.f;  // NT = 2: the sums are scaled back by 2^-(kx + kw)
+  if constexpr (NT == 2) { const float2 f = h2_unscale2(*p.xcell, *p.wcell); oscx = f.x; oscw = f.y; }
 
   for (long tile = slot; tile < p.ntiles; tile += nslots) {
     const int n = (int)(tile / tiles_per_n);
@@ -108,39 +116,46 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
     for (int q = 0; q < QN; ++q)
 #pragma unroll
       for (int cb = 0; cb < kTCB; ++cb) acc[q][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint4* const xn = p.xs + (long)n * (p.C / 8) * 3 * S;
-    i32x4 B[kTCB][3];
+    const uint4* const xn = p.xs + (long)n * (p.C / 8) * NT * S;
+    i32x4 B[kTCB][NT];
     auto load_b = [&](int s) __attribute__((always_inline)) {
-      const uint4* xc = xn + (long)(4 * s + g) * 3 * S;
+      const uint4* xc = xn + (long)(4 * s + g) * NT * S;
 #pragma unroll
       for (int cb = 0; cb < kTCB; ++cb)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) B[cb][t] = __builtin_bit_cast(i32x4, xc[(long)t * S + vv[cb]]);
+        for (int t = 0; t < NT; ++t) B[cb][t] = __builtin_bit_cast(i32x4, xc[(long)t * S + vv[cb]]);
     };
     load_b(0);
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
-      i32x4 Bc[kTCB][3];
+      i32x4 Bc[kTCB][NT];
 #pragma unroll
       for (int cb = 0; cb < kTCB; ++cb)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) Bc[cb][t] = B[cb][t];
+        for (int t = 0; t < NT; ++t) Bc[cb][t] = B[cb][t];
       if (s + 1 < NS) load_b(s + 1);  // the next k-step's units are requested while this one is multiplied
-      const i32x4* ws = wl + (long)s * QN * 3 * 64;
+      const i32x4* ws = wl + (long)s * QN * NT * 64;
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        const i32x4 A0 = ws[(q * 3 + 0) * 64], A1 = ws[(q * 3 + 1) * 64], A2 = ws[(q * 3 + 2) * 64];
-        // six products per fp32 product, smallest first: (term of A, term of B); the four column blocks alternate so that consecutive
-        // MFMAs go to different accumulators
-        const i32x4 A[3] = {A0, A1, A2};
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+        // six (NT = 2: three) products per fp32 product, smallest first: (term of A, term of B); the four column blocks alternate so that
+        // consecutive MFMAs go to different accumulators
+        i32x4 A[NT];
 #pragma unroll
-        for (int m = 0; m < 6; ++m)
+        for (int t = 0; t < NT; ++t) A[t] = ws[(q * NT + t) * 64];
+        constexpr int NP = NT == 3 ? 6 : 3;
+        constexpr int TA[6] = {NT - 1, NT == 3 ? 1 : 0, 0, 1, 0, 0};
+        constexpr int TB[6] = {0, 1, NT == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
-          for (int cb = 0; cb < kTCB; ++cb)
-            acc[q][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[TA[m]]), __builtin_bit_cast(bf16x8, Bc[cb][TB[m]]),
-                                                                 acc[q][cb], 0, 0, 0);
+        for (int m = 0; m < NP; ++m)
+#pragma unroll
+          for (int cb = 0; cb < kTCB; ++cb) {
+            if constexpr (NT == 3)
+              acc[q][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[TA[m]]), __builtin_bit_cast(bf16x8, Bc[cb][TB[m]]),
+                                                                   acc[q][cb], 0, 0, 0);
+            else
+              acc[q][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[TA[m]]), __builtin_bit_cast(f16x8, Bc[cb][TB[m]]),
+                                                                  acc[q][cb], 0, 0, 0);
+          }
       }
     }
     // ---- results: accumulator element e of (q, cb) = channel kg 16 + 4 g + e at voxel cb 16 + m16, sub-position qg QN + q
@@ -155,7 +170,7 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
         const long o = ((long)(2 * iz + (qq >> 2)) * H2 + (2 * iy + ((qq >> 1) & 1))) * W2 + 2 * ix + (qq & 1);
         float val[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = acc[q][cb][e] + bb[e];
+        for (int e = 0; e < 4; ++e) val[e] = NT == 2 ? acc[q][cb][e] * oscx * oscw + bb[e] : acc[q][cb][e] + bb[e];
         if (p.y) {
           float* yk = p.y + ((long)n * p.K + kg * 16 + 4 * g) * S2 + o;
 #pragma unroll
@@ -226,34 +241,45 @@ int convT_h2_bound(const float* w, const float* bias, int C, int K, float in_bou
   return check_launch("convT_h2_bound");
 }
 
-// h2cell (nullable): ys is an H2 tensor (4 bytes per element) and *h2cell the bound its power of two comes from (convT_h2_bound)
+// h2cell (nullable): ys is an H2 tensor (4 bytes per element) and *h2cell the bound its power of two comes from (convT_h2_bound).
+// xcell (nullable): the INPUT xs is an H2 tensor with this cell -- the two-term form of the kernel (three products; the weights' cell is
+// measured into the workspace behind the packed weights)
 int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H, int W,
-                  int K, void* ws, size_t wsb, hipStream_t s, const unsigned* h2cell) {
+                  int K, void* ws, size_t wsb, hipStream_t s, const unsigned* h2cell, const unsigned* xcell) {
   if (!xs || !w || (!y && !ys) || !ws) { set_error("convT_fwd_s3x: null pointer"); return NC_ERR_ARG; }
   if (!convT_s3x_supported(N, C, D, H, W, K) || ctot % 8 || c0 % 8) { set_error("convT_fwd_s3x: shape not covered"); return NC_ERR_SHAPE; }
   if (wsb < convT_s3x_ws_bytes(C, K)) { set_error("convT_fwd_s3x: workspace too small"); return NC_ERR_WS; }
   const int QN = qn_for(C);
-  const long total = (long)C * K * 8 * 3;
-  hipLaunchKernelGGL(k_pack_wT_s3, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)ws, C, K, QN, total);
+  const int NT = xcell ? 2 : 3;
+  const long total = (long)C * K * 8 * NT;
+  unsigned* wcell = (unsigned*)((char*)ws + (size_t)C * K * 8 * 3 * 2);  // (the 256 bytes of slack behind the packed weights)
+  if (NT == 2) {
+    if (int e = h2_zero_cells(wcell, 1, s)) return e;
+    if (int e = h2_absmax(w, (long)C * K * 8, wcell, s)) return e;
+    hipLaunchKernelGGL(k_pack_wT_s3<2>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)ws, C, K, QN, total, (const unsigned*)wcell);
+  } else {
+    hipLaunchKernelGGL(k_pack_wT_s3<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)ws, C, K, QN, total, (const unsigned*)nullptr);
+  }
   if (int e = check_launch("pack_wT_s3")) return e;
   const long S = (long)D * H * W;
   TParams3 p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)ws; p.bias = bias; p.y = y; p.ys = (uint2*)ys;
   p.N = N; p.C = C; p.K = K; p.D = D; p.H = H; p.W = W;
-  p.oblocks = ctot / 8; p.ob0 = c0 / 8; p.h2cell = ys ? h2cell : nullptr;
+  p.oblocks = ctot / 8; p.ob0 = c0 / 8; p.h2cell = ys ? h2cell : nullptr; p.xcell = xcell; p.wcell = wcell;
   p.ngroups = (K / 16) * (8 / QN);
   p.ntiles = (long)N * cdiv(S, 512);
   // 256 workgroups (one per CU: the weights take most of its LDS), a whole number of tile slots per XCD
   int per_xcd = 32 / p.ngroups;
   if (per_xcd < 1) per_xcd = 1;
   const unsigned grid = (unsigned)(8 * p.ngroups * per_xcd);
-  const size_t lds = (size_t)(C / 32) * QN * 3 * 1024;
+  const size_t lds = (size_t)(C / 32) * QN * NT * 1024;
   auto launch = [&](auto kern) -> int {
     if (int e = raise_dyn_lds(kern, 160 * 1024, "convT_fwd_s3x")) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kTThreads), lds, s, p);
     return check_launch("convT_s3");
   };
-  return QN == 8 ? launch(k_convT_s3<8>) : launch(k_convT_s3<4>);
+  if (NT == 2) return QN == 8 ? launch(k_convT_s3<8, 2>) : launch(k_convT_s3<4, 2>);
+  return QN == 8 ? launch(k_convT_s3<8, 3>) : launch(k_convT_s3<4, 3>);
 }
 
 }  // namespace nc
