@@ -219,3 +219,22 @@ int nc_convT_k2s2_fwd_split(const float* x, const void* xs, const float* w, cons
 }
 
 }  // extern "C"
+
+namespace nc {
+// ... in the two-term form, for the training forward (gen_nets.hip): x fp32 (an InstanceNorm + ReLU output: bound sqrt(S)) is converted into
+// the workspace, y (fp32) and ys (channels [c0, c0 + K) of an H2 tensor whose cell `out_cell` the caller set with convT_h2_bound) are written
+int convT_fwd_split_h2(const float* x, const float* w, const float* bias, float* y, void* ys, int ys_ctot, int ys_c0, int N, int C, int D, int H,
+                       int W, int K, const unsigned* out_cell, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!x || !w || !ys || !out_cell || !ws) { set_error("convT_fwd_split_h2: null pointer"); return NC_ERR_ARG; }
+  if (!convT_s3x_supported(N, C, D, H, W, K)) { set_error("convT_fwd_split_h2: shape not covered"); return NC_ERR_SHAPE; }
+  const size_t wb = al256(convT_s3x_ws_bytes(C, K));
+  const long S = (long)D * H * W;
+  const size_t ex = (size_t)N * C * S;
+  if (ws_bytes < wb + h2_cells_offset(ex) + 256) { set_error("convT_fwd_split_h2: workspace too small"); return NC_ERR_WS; }
+  void* t = (char*)ws + wb;
+  unsigned* xc = h2_cells_of(t, ex);
+  if (int e = h2_set_cell(xc, sqrtf((float)S), s)) return e;
+  if (int e = split2h_into(x, (long)C * S, t, N, C, S, C, 0, xc, s)) return e;
+  return convT_fwd_s3x(t, w, bias, y, ys, ys_ctot, ys_c0, N, C, D, H, W, K, ws, wb, s, out_cell, xc);
+}
+}  // namespace nc

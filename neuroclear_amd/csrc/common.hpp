@@ -260,6 +260,8 @@ size_t convT_s3x_ws_bytes(int C, int K);
 int convT_fwd_s3x(const void* xs, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H, int W,
                   int K, void* ws, size_t wsb, hipStream_t s, const unsigned* h2cell = nullptr, const unsigned* xcell = nullptr);
 int convT_h2_bound(const float* w, const float* bias, int C, int K, float in_bound, unsigned* cell, hipStream_t s);
+int convT_fwd_split_h2(const float* x, const float* w, const float* bias, float* y, void* ys, int ys_ctot, int ys_c0, int N, int C, int D, int H,
+                       int W, int K, const unsigned* out_cell, void* ws, size_t ws_bytes, hipStream_t s);
 int convT_fwd_s3(const float* x, const float* w, const float* bias, float* y, void* ys, int ctot, int c0, int N, int C, int D, int H,
                  int W, int K, void* stream);
 bool s3_wgrad_supported(const ConvDims& d);

@@ -216,8 +216,21 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   // nc_convT_k2s2_split_active), and write the S3 form of their half of the concatenation themselves when the consuming block takes it
   const bool ct2 = nc_convT_k2s2_split_active(1, 256, d2[0], d2[1], d2[2], 128) &&
                    p.conv_ws >= nc_convT_k2s2_split_ws_bytes(1, 256, d2[0], d2[1], d2[2], 128);
+  // Two-term form: the transposed convolution writes the H2 form of its half itself -- its power of two comes from a BOUND (one tap per input
+  // channel and output voxel: max column sum of |w| times the InstanceNorm bound of its input, convt_s3.hip), so nothing is measured and the
+  // whole forward is independent of what else is in the batch.  NC_CONVT_H2=0: fp32 output, measured and converted.
+  static const bool ct_h2 = !(getenv("NC_CONVT_H2") && atoi(getenv("NC_CONVT_H2")) == 0);
+  const bool ct2h = ct2 && h2l[7] && ct_h2;
+  unsigned* cell7 = h2_cells_of(V + p.xs3[7], (size_t)N * 256 * Sh) + 1;
+  if (ct2h) {
+    NC_TRY(h2_zero_cells(cell7, 1, hs));
+    NC_TRY(convT_h2_bound(P + o.w[10], P + o.b[10], 256, 128, sqrtf((float)Sq), cell7, hs));
+  }
   for (int n = 0; n < N; ++n) {  // t_conv2 writes the second half of cat2
-    if (ct2)
+    if (ct2h)
+      NC_TRY(convT_fwd_split_h2(V + p.b3 + (size_t)n * 256 * Sq, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
+                                (char*)(V + p.xs3[7]) + (size_t)n * 256 * Sh * 4, 256, 128, 1, 256, d2[0], d2[1], d2[2], 128, cell7, cws, p.conv_ws, hs));
+    else if (ct2)
       NC_TRY(nc_convT_k2s2_fwd_split(V + p.b3 + (size_t)n * 256 * Sq, nullptr, P + o.w[10], P + o.b[10], V + p.cat2 + ((size_t)n * 256 + 128) * Sh,
                                      use[7] && !h2l[7] ? (char*)(V + p.xs3[7]) + (size_t)n * 256 * Sh * 6 : nullptr, 256, 128, 1, 256, d2[0], d2[1], d2[2], 128, cws,
                                      p.conv_ws, stream));
@@ -227,7 +240,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   }
   if (use[7]) {  // ... and its S3 form completes block 7's input (the first half came from block 3's normalisation pass)
     // (two-term form: the transposed convolution's half is measured after the fact -- its power of two cannot be known while it is written)
-    if (!ct2 || h2l[7]) NC_TRY(operand_into(cd[7], V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
+    if (!ct2 || (h2l[7] && !ct2h)) NC_TRY(operand_into(cd[7], V + p.cat2 + (size_t)128 * Sh, (long)256 * Sh, V + p.xs3[7], N, 128, Sh, 256, 128, hs));
     pre[7] = true;
   }
   NC_TRY(block(7, V + p.cat2, V + p.e2a, (size_t)128 * Sh, 8, 128));
@@ -235,8 +248,17 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
   const bool ct1 = nc_convT_k2s2_split_active(1, 128, d1[0], d1[1], d1[2], 64) &&
                    p.conv_ws >= nc_convT_k2s2_split_ws_bytes(1, 128, d1[0], d1[1], d1[2], 64);
   const bool ct_s3 = use[9] && !h2l[9] && (ct1 || convT_fwd_s3_supported(1, 128, d1[0], d1[1], d1[2], 64));  // t_conv1 writes the S3 form of its output itself
+  const bool ct1h = ct1 && h2l[9] && ct_h2;
+  unsigned* cell9 = h2_cells_of(V + p.xs3[9], (size_t)N * 128 * S) + 1;
+  if (ct1h) {
+    NC_TRY(h2_zero_cells(cell9, 1, hs));
+    NC_TRY(convT_h2_bound(P + o.w[11], P + o.b[11], 128, 64, sqrtf((float)Sh), cell9, hs));
+  }
   for (int n = 0; n < N; ++n) {  // t_conv1 writes the second half of cat1
-    if (ct1)
+    if (ct1h)
+      NC_TRY(convT_fwd_split_h2(V + p.e2b + (size_t)n * 128 * Sh, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
+                                (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 4, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, cell9, cws, p.conv_ws, hs));
+    else if (ct1)
       NC_TRY(nc_convT_k2s2_fwd_split(V + p.e2b + (size_t)n * 128 * Sh, nullptr, P + o.w[11], P + o.b[11], V + p.cat1 + ((size_t)n * 128 + 64) * S,
                                      use[9] && !h2l[9] ? (char*)(V + p.xs3[9]) + (size_t)n * 128 * S * 6 : nullptr, 128, 64, 1, 128, d1[0], d1[1], d1[2], 64, cws,
                                      p.conv_ws, stream));
@@ -248,7 +270,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
                                1, 128, d1[0], d1[1], d1[2], 64, stream));
   }
   if (use[9]) {
-    if (!ct_s3) NC_TRY(operand_into(cd[9], V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
+    if (!ct_s3 && !ct1h) NC_TRY(operand_into(cd[9], V + p.cat1 + (size_t)64 * S, (long)128 * S, V + p.xs3[9], N, 64, S, 128, 64, hs));
     pre[9] = true;
   }
   NC_TRY(block(9, V + p.cat1, V + p.e1, (size_t)64 * S, -1, 0));
