@@ -1,6 +1,6 @@
 """HBM bytes per 140^3 cube of the diced inference from two --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/prof_r03.sh): all kernels of the
-run summed and divided by the number of cube forwards the run made, COUNTED from the same files (one k_sigmoid_fwd dispatch per
-nc_unet_deconv_fwd call; warm-up cubes included in both numerator and denominator).
+run summed and divided by the number of cube forwards the run made, COUNTED from the same files (one k_sigmoid_fwd -- or, with the fused
+inference tail, k_in_act_tail -- dispatch per nc_unet_deconv_fwd call; warm-up cubes included in both numerator and denominator).
 python tools/pmc_cube.py <fetch_dir> <write_dir> -> JSON on stdout."""
 import csv
 import glob
@@ -16,7 +16,7 @@ def total(d, counter):
             for r in csv.DictReader(fh):
                 if r['Counter_Name'] == counter:
                     t += float(r['Counter_Value'])
-                    if 'k_sigmoid_fwd' in r['Kernel_Name']:
+                    if 'k_sigmoid_fwd' in r['Kernel_Name'] or 'k_in_act_tail' in r['Kernel_Name']:  # (one of the two per cube forward)
                         cubes += 1
     return t, cubes
 
