@@ -180,6 +180,44 @@ def test_h2_wgrad_against_fp64(case):
     assert r2 <= 1.3 * r3 + 2e-8, (r2, r3)
 
 
+def test_h2_random_shapes():
+    """tools/h2_fuzz.py in small: 16 random (batch, channels, extent, kernel, data kind) cases through forward, data gradient and weight
+    gradient -- ragged extents, tile tails, several output-channel tiles, planes smaller than a tile: finite, bit-identical on a second run,
+    and no further from fp64 than 1.3 x the worse of the three-term form and the fp32 MFMA kernels on the same case."""
+    import random
+    from neuroclear_amd import ops
+    rng = random.Random(5)
+    for case in range(16):
+        ks = rng.choice([3, 3, 3, 5])
+        C, K = rng.choice([64, 128, 192, 256]), rng.choice([64, 128, 256])
+        if ks == 5:
+            C, K = 64, rng.choice([64, 128])
+        N = rng.choice([1, 1, 2])
+        D, H, W = rng.randint(2, 14), rng.randint(3, 30), rng.randint(3, 44)
+        g = torch.Generator(device=DEV).manual_seed(2000 + case)
+        x = data(rng.choice(['randn', 'relu', 'grad']), (N, C, D, H, W), g)
+        w = torch.randn(K, C, ks, ks, ks, device=DEV, generator=g) * (2.0 / (C * ks ** 3)) ** 0.5
+        dy = torch.randn(N, K, D, H, W, device=DEV, generator=g) * rng.choice([1.0, 1e-4, 1e3])
+        refs = (F.conv3d(x.double(), w.double(), padding=ks // 2), torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=ks // 2),
+                torch.nn.grad.conv3d_weight(x.double(), w.shape, dy.double(), padding=ks // 2))
+
+        def run():
+            return (ops.conv_fwd_raw(x, w, None, 1, ks // 2), ops.conv_dgrad_raw(dy, w, x.shape, 1, ks // 2),
+                    ops.conv_wgrad_raw(x, dy, w.shape, 1, ks // 2, False)[0])
+        res = {}
+        for name, split, terms in (('t2', True, 2), ('t3', True, 3), ('fp32', False, 3)):
+            ops.set_conv_split(split)
+            L().nc_set_split_terms(terms)
+            out = run()
+            if name == 't2':
+                assert all(torch.equal(a, b) for a, b in zip(out, run())) and all(bool(torch.isfinite(a).all()) for a in out), case
+            res[name] = [err(a, r)[1] for a, r in zip(out, refs)]
+        ops.set_conv_split(True)
+        L().nc_set_split_terms(2)
+        for i, what in enumerate(('fwd', 'dgrad', 'wgrad')):
+            assert res['t2'][i] <= 1.3 * max(res['t3'][i], res['fp32'][i]) + 2e-8, (case, what, (N, C, K, D, H, W, ks), res)
+
+
 def rnd(seed, shape):
     return np.random.default_rng(int(seed)).random(tuple(int(s) for s in shape), dtype=np.float32)
 
