@@ -160,15 +160,31 @@ struct XTile {
   int n, cot, z, q0;
 };
 
+// Tile order: output-channel tile fastest, then GROUPS of kXGroup in-plane neighbours, then z, then the groups of a plane, then samples.
+// The 32 workgroups of an XCD work on consecutive tiles at any one time: with the round-3 order (z right behind the channel tile) those were
+// 32 planes of ONE in-plane tile -- the z-halo hit L2, the in-plane halo (1.44 x a tile's units at 3^3, 1.88 x at 5^3) was fetched again
+// 100+ tiles later; now 4 in-plane neighbours x 8 planes share both (the order conv_c8x.hip / conv_h.hip took in this round).
+constexpr int kXGroup = 4;
 template <int PT>
 __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   int t = p.t_begin + idx / p.fsub;
   const int sub = idx % p.fsub;
-  XTile o;  // output-channel tile fastest, then z: neighbouring planes share input planes in L2
+  XTile o;
   o.cot = t % p.KT; t /= p.KT;
-  o.z = t % p.D; t /= p.D;
-  const int tp = t % p.TPP;
-  o.n = t / p.TPP;
+  const int per_n = p.TPP * p.D;
+  o.n = t / per_n;
+  const int u = t - o.n * per_n;
+  const int full = (p.TPP / kXGroup) * kXGroup * p.D;  // tiles in whole groups
+  int tp;
+  if (u < full) {
+    const int grp = u / (kXGroup * p.D), rem = u - grp * (kXGroup * p.D);
+    o.z = rem / kXGroup;
+    tp = grp * kXGroup + (rem - o.z * kXGroup);
+  } else {
+    const int L = p.TPP % kXGroup, v = u - full;  // the last, narrower group
+    o.z = v / L;
+    tp = (p.TPP / kXGroup) * kXGroup + (v - o.z * L);
+  }
   o.q0 = (tp * p.fsub + sub) * PT;
   // wave-uniform by construction; said explicitly so that descriptors and scalar offsets built from them stay in SGPRs
   o.cot = __builtin_amdgcn_readfirstlane(o.cot); o.z = __builtin_amdgcn_readfirstlane(o.z);
