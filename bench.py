@@ -24,7 +24,7 @@ Extra objects on the JSON line:
   arithmetic / three_term_split / fp32_mfma_kernels -- what "f32" is computed with, and the same step with the split-operand
                   layers on the three-term form and on the fp32 MFMA kernels (3 steps each, same process, same seeds).
   cpu_baseline -- the oracle's CPU restatement of the same step (oracle/apollo.py, torch-CPU fp32) on the host cores of
-                  the GPU box, rank 0 and N = 1 only: full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
+                  the GPU box, rank 0 only (at every N, after the last GPU leg): full 108^3 step, 1 warm-up + median of 3 on all cores, plus a
                   1-thread figure on a bounded 36^3 sample; inference: 140^3 cubes through
                   oracle/nets.py + oracle/dice.py for a bounded time, extrapolated to 729 cubes (stated).
 The inference leg keeps NC_INFER_STREAMS (3) cubes in flight on as many HIP streams; its `roofline.achieved` is therefore all cubes'
@@ -244,7 +244,7 @@ def run_train(args, rank, world, dev):
         model.set_input(data)
         model.optimize_parameters()
         if not first:  # losses of the very first step from the seeded initial weights: comparable between runs of different length
-            first.update({k: round(v, 5) for k, v in model.get_current_losses().items()})
+            first.update({k: float(v) for k, v in model.get_current_losses().items()})  # unrounded: `first_step_max_rel_diff` compares these
 
     for _ in range(args.warmup):
         step()
@@ -515,17 +515,10 @@ def main():
                                                first_step_max_rel_diff=max(abs(f1[k] - f3[k]) / max(abs(f3[k]), 1e-12) for k in f3))
             finally:
                 _lib().nc_set_split_terms(2)
-    cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    if cpu and train_like:
-        try:
-            out['cpu_baseline'] = cpu_baseline_train()
-        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-            out['cpu_baseline'] = dict(error=str(e))
-    if cpu and args.workload == 'infer':
-        try:
-            out['cpu_baseline'] = cpu_baseline_infer()
-        except Exception as e:
-            out['cpu_baseline'] = dict(error=str(e))
+    # CPU legs: rank 0 only, at every N (the other ranks have nothing to add to a host-core figure), and AFTER the last GPU leg and the
+    # process group are done with -- no rank sits in an RCCL call while rank 0 spends a minute on its host cores
+    cpu = rank == 0 and not args.no_cpu_baseline
+    inf = None
     if headline:
         # second half of BASELINE.json's metric: one 900^3 diced inference (configs[2]), strong scaling over ranks
         import gc
@@ -541,16 +534,27 @@ def main():
             inf['arithmetic'] = ARITHMETIC_H2 if (iroof or {}).get('split_terms') == 2 else ARITHMETIC
         if iroof:
             inf['roofline'] = iroof
-        if cpu:
-            try:
-                inf['cpu_baseline'] = cpu_baseline_infer()
-            except Exception as e:
-                inf['cpu_baseline'] = dict(error=str(e))
         out['inference'] = inf
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if cpu and train_like:
+        try:
+            out['cpu_baseline'] = cpu_baseline_train()
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            out['cpu_baseline'] = dict(error=str(e))
+    if cpu and args.workload == 'infer':
+        try:
+            out['cpu_baseline'] = cpu_baseline_infer()
+        except Exception as e:
+            out['cpu_baseline'] = dict(error=str(e))
+    if cpu and inf is not None:
+        try:
+            inf['cpu_baseline'] = cpu_baseline_infer()
+        except Exception as e:
+            inf['cpu_baseline'] = dict(error=str(e))
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -84,9 +84,9 @@ class FlatAdam(torch.optim.Optimizer):
     # bucket is exposed.  xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce is per-link bound: a few
     # buckets of >= 8 MB keep every link busy without paying the ~50 us launch latency too often.
     def enable_overlapped_all_reduce(self, n_buckets=3):
-        """Arm the hooks (idempotent).  Without an initialised process group of size > 1 this does nothing."""
-        dist = torch.distributed
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or self._buckets:
+        """Arm the hooks (idempotent).  Without an initialised process group of size > 1 this does nothing (util.dist.exchange_active)."""
+        from ..util.dist import exchange_active
+        if not exchange_active() or self._buckets:
             return
         total = self.flat.numel()
         target = (total + n_buckets - 1) // n_buckets
@@ -125,11 +125,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def all_reduce_mean(self):
         dist = torch.distributed
-        if not (dist.is_available() and dist.is_initialized()):
+        from ..util.dist import exchange_active
+        if not exchange_active():
             return
         ws = dist.get_world_size()
-        if ws == 1:
-            return
         self._collect()
         if self._buckets:
             for b in self._buckets:

@@ -1007,7 +1007,7 @@ class _PatchGAN(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         want_p = any(ctx.needs_input_grad[2:])
         dx = torch.empty_like(x) if want_x else None
-        dpar = _grad_target(ctx, 3) if want_p else None
+        dpar = _grad_target(ctx, 2) if want_p else None  # (x, cfg, *params): the parameters start at input 2
         L = lib()
         ws = workspace(L.nc_patchgan_ws_bytes(I(B), I(D), I(H), I(W), I(n_layers), I(ndf), I(nd)), x.device, 'patchgan')
         check(L.nc_patchgan_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), I(B), I(D), I(H),

@@ -128,32 +128,37 @@ def slab_exchange(rank, world, plan, local_acc, own_acc):
 
 def slab_gather(rank, world, plan, out_slab, L0, dst=0):
     """The finalised integer slabs (planes own & [0, L0)) travel to rank `dst`: 2 bytes per voxel instead of the fp32 accumulators of
-    assemble='reduce'.  Returns the list of slabs in rank order on `dst`, None elsewhere."""
+    assemble='reduce'.  Returns the list of slabs in rank order on `dst`, None elsewhere.
+    Wire format: BYTES.  ProcessGroupNCCL has no 16-bit integer type (torch/csrc/distributed/c10d/NCCLUtils.hpp: Char, Byte, Int, Long,
+    Half, Float, Double, Bool, BFloat16, Float8*), so an int16 slab cannot cross RCCL as it is; every rank contributes ONE uint8 buffer of
+    the largest slab's size (the slabs differ by the clipped tail of the last rank only) to ONE gather -- a collective, so the same call
+    runs through RCCL in a world of one (tests/test_gpu_rccl.py) and the root posts no per-peer receives."""
     import torch.distributed as dist
     from .util.dist import p2p_fence
     out_slab = out_slab.contiguous()
-    p2p_fence(out_slab)
     sizes = [max(0, min(b, L0) - min(a, L0)) for a, b in plan['own']]
+    if not (dist.is_available() and dist.is_initialized()):
+        return [out_slab] if rank == dst else None
+    plane = int(np.prod(out_slab.shape[1:])) * out_slab.element_size()  # bytes of one finalised plane
+    nbytes = max(sizes) * plane
+    wire = torch.zeros(nbytes, dtype=torch.uint8, device=out_slab.device)
+    wire[:sizes[rank] * plane] = out_slab.view(torch.uint8).reshape(-1)
+    p2p_fence(wire)
+    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+    dist.gather(wire, bufs, dst=dst)
     if rank != dst:
-        if sizes[rank]:
-            dist.send(out_slab, dst)
         return None
-    parts = []
-    for r in range(world):
-        if r == dst:
-            parts.append(out_slab)
-        elif sizes[r]:
-            buf = torch.empty((sizes[r],) + tuple(out_slab.shape[1:]), dtype=out_slab.dtype, device=out_slab.device)
-            dist.recv(buf, r)
-            parts.append(buf)
-    return parts
+    tail = tuple(out_slab.shape[1:])
+    return [out_slab if r == dst else bufs[r][:sizes[r] * plane].view(out_slab.dtype).reshape((sizes[r],) + tail)
+            for r in range(world) if sizes[r] or r == dst]
 
 
 def broadcast_parameters(net, src=0):
     """One broadcast of the packed parameter blob (state-dict order) from rank `src`; every rank then holds identical
     weights.  A no-op without an initialised process group."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    from .util.dist import exchange_active
+    if not exchange_active():
         return
     params = list(net.parameters())
     blob = torch.cat([p.detach().reshape(-1) for p in params])
@@ -188,8 +193,8 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     if assemble == 'slab' and (with_real or getattr(opt, 'normalize_intensity', False)):
         raise NotImplementedError("assemble='slab' finalises per rank: use assemble='reduce' with --normalize_intensity (percentiles of the "
                                   "whole volume) or with_real")
-    if broadcast and world > 1:
-        broadcast_parameters(netG, 0)
+    if broadcast:
+        broadcast_parameters(netG, 0)  # (a no-op without a process group of > 1 rank: util.dist.exchange_active)
     ds = DiceImageDataSet(opt, volume=volume)
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
     local_acc = assemble in ('reduce', 'slab') or rank == 0

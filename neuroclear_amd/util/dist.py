@@ -31,6 +31,18 @@ def init_process_group(device=None):
     return rank, world
 
 
+def exchange_active():
+    """True when the data-parallel exchange steps (weight broadcast, gradient all-reduce, slab gather) have to run: an initialised
+    process group of more than one rank -- or of ONE rank with NC_DIST_WORLD1=1, which sends the same calls through RCCL on a
+    one-GPU box (every collective of a world of one is the identity, so results must equal the run without a group:
+    tests/test_gpu_rccl.py).  That is the only way the RCCL side of this code can be exercised where RCCL refuses two ranks on one
+    device."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('NC_DIST_WORLD1', '0') == '1'
+
+
 def p2p_fence(t):
     """Call before handing a CUDA tensor to send / recv / batch_isend_irecv.  RCCL orders the transfer behind the current stream by
     itself; gloo does not (see the module docstring): drain the device first."""

@@ -166,10 +166,10 @@ def _dice_slab_worker(rank, world, port, out_path):
     full[o0:o1] = own.numpy()
     fin = odice.finalize(full, padded.shape, vol.shape, R, ov, 'uint16')
     z0, z1 = min(o0, vol.shape[0]), min(o1, vol.shape[0])
-    slab = torch.from_numpy(fin[z0:z1].astype(np.int32))
+    slab = torch.from_numpy(np.ascontiguousarray(fin[z0:z1]).view(np.int16))  # the wire dtype of the product: int16 bits of uint16
     parts = slab_gather(rank, world, plan, slab, vol.shape[0])
     if rank == 0:
-        got = torch.cat(parts, 0).numpy().astype(np.int64)
+        got = torch.cat(parts, 0).numpy().view(np.uint16).astype(np.int64)
         ref = odice.assemble([net(torch.from_numpy(odice.normalize(odice.cut_cube(refl, i, steps, R, ov, b)))).numpy() for i in range(n)],
                              padded.shape, vol.shape, R, ov, b, 'uint16')
         d = int(np.abs(got - ref.astype(np.int64)).max()) if got.shape == ref.shape else 99

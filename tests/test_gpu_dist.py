@@ -81,7 +81,7 @@ def test_two_ranks_on_one_gpu_diced_inference(tmp_path):
     assert norm_lsb <= 2, norm_lsb  # (percentiles of a volume that differs by 1 ulp here and there, then a second truncating cast)
 
 
-def _apollo_worker(rank, world, port, out_path):
+def _apollo_worker(rank, world, port, out_path, which='apollo'):
     import torch.distributed as dist
     _init(rank, world, port)
     from neuroclear_amd.models import create_model
@@ -90,14 +90,18 @@ def _apollo_worker(rank, world, port, out_path):
                     gan_mode='lsgan', randomize_projection_depth=True, projection_depth=10, min_projection_depth=2,
                     lambda_plane=[1, 1, 1], lambda_A=5.0, input_nc=1, output_nc=1, ngf=64, ndf=64, netG='unet_deconv',
                     netG_B='deep_linear_gen', netD='basic', n_layers_D=3, norm='instance', no_dropout=True, init_type='kaiming',
-                    init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB', model='axial_to_lateral_gan_apollo')
+                    init_gain=0.02, lr=1e-4, beta1=0.1, direction='AtoB', model='axial_to_lateral_gan_' + which)
+    if which == 'athena':  # BASELINE configs[4]: six discriminators on six streams feed optimizer_D
+        opt.conversion_plane, opt.pool_size = ['yz', 'xy'], 50
     nets = ['G_A', 'G_B', 'D_A_axial', 'D_A_lateral', 'D_B_axial', 'D_B_lateral']
     specs = [S.unet_deconv_spec(), S.deep_linear_spec()] + [S.patchgan_spec(2)] * 4
 
     def build(overlap):
+        torch.manual_seed(40)  # (Athena: the same kaiming draw on both ranks and for both builds)
         m = create_model(opt)
-        for i, (n, sp) in enumerate(zip(nets, specs)):
-            getattr(m, 'net' + n).load_state_dict(S.state_dict_from_seed(sp, 40 + i, 'cuda'))
+        if which == 'apollo':
+            for i, (n, sp) in enumerate(zip(nets, specs)):
+                getattr(m, 'net' + n).load_state_dict(S.state_dict_from_seed(sp, 40 + i, 'cuda'))
         m.optimizer_G._overlap = overlap  # (read at the first zero_grad: the hooks are armed there)
         return m
 
@@ -144,12 +148,13 @@ def _apollo_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_apollo_bucketed_all_reduce(tmp_path):
-    """Two Apollo steps at 36^3 on two ranks with different crops: the hook-driven, bucketed all-reduce of optimizer_G (issued from
+@pytest.mark.parametrize('which', ['apollo', 'athena'])
+def test_two_ranks_on_one_gpu_apollo_bucketed_all_reduce(tmp_path, which):
+    """Two Apollo / Athena steps at 36^3 on two ranks with different crops: the hook-driven, bucketed all-reduce of optimizer_G (issued from
     inside nc_unet_deconv_bwd / nc_deep_linear_bwd's autograd nodes, racing the side-stream discriminator passes) leaves the gradients
     and the weights the one synchronous all-reduce leaves, and the replicas stay identical."""
     out = str(tmp_path / 'a.npy')
-    mp.spawn(_apollo_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_apollo_worker, args=(2, _free_port(), out, which), nprocs=2, join=True)
     r = np.load(out)
     assert list(r[:5]) == [1, 1, 1, 1, 1], r
 

@@ -729,12 +729,14 @@ def test_patchgan_spectral_norm(golden_dir, tag):
     assert np.array_equal(us, us2)
 
 
+@pytest.mark.parametrize('pattern', ['every_third', 'first_only'])
 @pytest.mark.parametrize('which', ['unet_deconv', 'deep_linear_gen', 'patchgan'])
-def test_partly_frozen_parameters_are_not_updated(which):
+def test_partly_frozen_parameters_are_not_updated(which, pattern):
     """Some (not all) parameters of a network with requires_grad off: the whole-network backward must not leave gradients for them
     in the optimizer's flat buffer (FlatAdam.step is one launch over the whole buffer), the others get exactly the gradient of the
     unfrozen run, and a step moves only those.  (base_model.py:221-232 set_requires_grad freezes whole networks; a user freezing an
-    encoder is the partial case.)"""
+    encoder is the partial case.)  'first_only' freezes the FIRST parameter alone (model.0.weight of the PatchGAN): the case an off-by-one
+    in the autograd node's input index misses (_PatchGAN.backward looked at needs_input_grad[3:])."""
     from neuroclear_amd.models.axial_to_lateral_gan_apollo_model import FlatAdam
 
     def build():
@@ -756,7 +758,7 @@ def test_partly_frozen_parameters_are_not_updated(which):
     full = opt.grad.clone()
     net2, opt2, _ = build()
     ps = list(net2.parameters())
-    frozen = [i for i in range(len(ps)) if i % 3 == 1]
+    frozen = [0] if pattern == 'first_only' else [i for i in range(len(ps)) if i % 3 == 1]
     for i in frozen:
         ps[i].requires_grad_(False)
     before = opt2.flat.clone()
