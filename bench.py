@@ -485,6 +485,13 @@ def main():
         out['arithmetic'] = ARITHMETIC_H2 if (roof or {}).get('split_terms') == 2 else ARITHMETIC
     if roof:
         out['roofline'] = roof
+    if split_on and int(_lib().nc_get_split_terms()) == 2:
+        # the range guard of the two-term form (include/nc_hip.h): what it saw during warm-up + timed steps of the main run
+        import ctypes
+        gs = (ctypes.c_ulonglong * 4)()
+        _lib().nc_h2_guard_stats(gs, 1)
+        out['two_term_range_guard'] = dict(on=bool(_lib().nc_get_h2_guard()), tensors_measured=int(gs[0]), calls_fell_back_to_three_terms=int(gs[1]),
+                                           flagged_without_switch=int(gs[2]), largest_low_chunk_share_ppm=int(gs[3]))
     if world > 1:
         out['dist'] = dict(backend=dist.get_backend(), devices=torch.cuda.device_count(),
                            ranks_share_devices=torch.cuda.device_count() < world)

@@ -406,6 +406,20 @@ int nc_get_conv_split(void);
  * forward and its backward (the backward then re-converts what the forward kept). */
 void nc_set_split_terms(int terms);
 int nc_get_split_terms(void);
+/* The RANGE GUARD of the two-term form (round 5; csrc/h2.hip, csrc/common.hpp): wherever a call converts an fp32 operand ITSELF with a measured
+ * power of two -- nc_conv_fwd / _dgrad / _wgrad / _bwd and every dY of the whole-network backward calls that arrives as fp32 -- the conversion
+ * pass also counts the CHUNKS (64 voxels x 8 channels) whose largest magnitude lies below 2^-17 of the tensor's; when more than 1/64 of the
+ * non-zero chunks do (a region of the volume far below an outlier elsewhere: the one case the two-term form degrades, see above), THAT CALL
+ * runs on the exact three-term kernels instead.  The decision is taken on the device (no host synchronisation): both kernel families are
+ * launched and the one whose turn it is not leaves at its first instruction.  Operands whose power of two is a bound by construction
+ * (InstanceNorm outputs and the norm backward's results) are not measured and need no guard; a measured operand that is written into a
+ * caller-owned buffer for later calls (the two activations deep_linear_gen keeps for its weight gradients) is counted but cannot switch.
+ * nc_set_h2_guard(0) / NC_H2_GUARD=0: off (round-4 behaviour).  nc_h2_guard_stats(out, reset): out[0] = tensors measured, out[1] = calls that
+ * fell back to three terms, out[2] = flagged tensors that could not switch, out[3] = the largest share of low chunks seen, in parts per
+ * million; host-visible counters, readable at any time without synchronising (they trail the device by whatever is still queued). */
+void nc_set_h2_guard(int on);
+int nc_get_h2_guard(void);
+int nc_h2_guard_stats(unsigned long long* out4, int reset);
 int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the
                                                        * current switches; 3: on the three-term form (or the fp32 kernels); 0: bad size */
 void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the

@@ -156,6 +156,12 @@ void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
 void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
 int nc_get_split_terms(void) { return s3x_get_terms(); }
+void nc_set_h2_guard(int on) { h2_guard_set(on); }
+int nc_get_h2_guard(void) { return h2_guard_on() ? 1 : 0; }
+int nc_h2_guard_stats(unsigned long long* out4, int reset) {
+  if (!out4) { set_error("h2_guard_stats: null pointer"); return NC_ERR_ARG; }
+  return h2_guard_read(out4, reset);
+}
 
 int nc_conv2d_split_active(int what, int N, int C, int H, int W, int K, int k, int stride, int pad) {
   ConvDims d;

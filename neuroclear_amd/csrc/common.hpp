@@ -186,7 +186,7 @@ bool s3_dgrad_supported(const ConvDims& d);
 size_t s3_ws_bytes(const ConvDims& d);
 size_t s3_tensor_bytes(int N, int C, long S);
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s);
-int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
+int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s, const unsigned* guard = nullptr);
 // (S3 or H2 by the consuming layer d: conv_split.hip)
 bool conv_layer_h2(const ConvDims& d);
 // the explicit S3 entry points (nc_conv_*_split, operands from nc_to_s3) are three-term by definition, whatever nc_set_split_terms says
@@ -216,7 +216,8 @@ size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT = 3);
 void s3x_set_terms(int t);
 int s3x_get_terms();
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
-                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s);
+                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s,
+                const unsigned* guard = nullptr);
 // h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
 // an H2 tensor of `elems` elements = elems * 4 bytes of units + (at this byte offset) 256 bytes of cells: [0] the cell of the channels' first
 // half, [1] of the second half (a concatenation converted in two parts; equal to [0] otherwise) -- inside the elems * 6 bytes of an S3 tensor
@@ -230,11 +231,37 @@ int maxpool2_h2(const void* in, void* out, int N, int C, int ctot, int D, int H,
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s);
 int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
 int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* cell2 = nullptr);
-int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s);
+int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s,
+                 unsigned* guard = nullptr);
+// ---- the RANGE GUARD of the two-term form (round 5; h2.hip).  One power of two per tensor means: an element keeps its 22+ bits only while it
+// is within 2^17 of the tensor's largest magnitude (s3_common.hpp).  Outputs that mix small and large inputs do not care; outputs that see
+// ONLY small ones do (a region of the volume 2^20 below an outlier elsewhere).  So wherever a cell is MEASURED (k_absmax) and the tensor is
+// converted by k_split2h, that pass also counts CHUNKS (a wave's 64 voxels x 8 channels) whose largest magnitude is below 2^-17 of the cell;
+// when more than 1 / kGuardShare of the non-zero chunks are, the call is FLAGGED (8 words: [kGuardLow], [kGuardAll] counts, [kGuardFlag]) and
+// runs on the exact three-term kernels instead -- decided ON THE DEVICE (k_h2_guard_decide), with no host synchronisation: the operand is
+// converted again into the same buffer as S3 (its capacity is the S3 tensor's), and both kernel families are launched, each leaving at
+// its first instruction unless the flag says it is its turn (guard_skip).  Cells that are bounds by construction (InstanceNorm outputs)
+// need no guard.  Counters: nc_h2_guard_stats.
+constexpr int kGuardLow = 0, kGuardAll = 1, kGuardFlag = 2;
+constexpr unsigned kGuardDrop = 17u << 23;          // float bits: 2^-17 below the cell
+constexpr unsigned long long kGuardShare = 64;      // flagged when low * 64 > all
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool guard_skip(const unsigned* guard, int want) {  // want: 0 = a two-term kernel, 1 = a three-term one
+  return guard && (int)(__builtin_nontemporal_load(guard + kGuardFlag) != 0) != want;
+}
+#else
+__device__ bool guard_skip(const unsigned* guard, int want);
+#endif
+bool h2_guard_on();
+void h2_guard_set(int on);
+int h2_guard_read(unsigned long long* out4, int reset);
+int h2_guard_zero(unsigned* g, hipStream_t s, int nwords = 8);
+int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s);
+int h2_to_s3_if(const void* xh, void* xs, int N, int C, long S, const unsigned* cells, const unsigned* guard, hipStream_t s);
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
                 int c0, float bound, unsigned* cell, unsigned* cell2, hipStream_t s);
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
-             long si, int flip, void* wp_ws, hipStream_t s);
+             long si, int flip, void* wp_ws, hipStream_t s, const unsigned* guard = nullptr);
 bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);
 int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks, void* ws,
                  size_t ws_bytes, void* stream);

@@ -154,6 +154,7 @@ struct XParams {
   int flush;           // k-steps between two accumulator restarts
   const unsigned *amax_x, *amax_w;  // NT = 2: the cells of the input and of the weights (the result is scaled back by 2^-(kx + kw))
   long long* dbg;      // NC_S3X_STAMP builds: s_memtime stamps of workgroup 0 / wave 0 (timing experiments only)
+  const unsigned* guard;  // nullable: the range guard's words (common.hpp); the kernel leaves at once unless the flag says it is this form's turn
 };
 
 struct XTile {
@@ -196,6 +197,7 @@ template <int KS, int NCB, int NT>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS, PT = 64 * NCB;
+  if (guard_skip(p.guard, NT == 3)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
@@ -665,7 +667,8 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
 // another cell passes that as cell_b (forward layout of w only), else split_c = Cin.  wcell: one zeroed-by-us cell for the weights,
 // wp_ws >= s3x_packed_bytes(.., 2).
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
-                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s) {
+                int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s,
+                const unsigned* guard) {
   const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
   if (!pl.ok) { set_error("conv_s3x_h2: shape not covered"); return NC_ERR_SHAPE; }
   if (split_c < Cin && (flip || !cell_b || split_c % 8)) { set_error("conv_s3x_h2: scale groups only for the forward weight layout"); return NC_ERR_ARG; }
@@ -681,7 +684,7 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
                      (const unsigned*)wcell, flip ? Cin : split_c, cell_a, cell_b);
   if (int e = check_launch("conv_s3x_h2 pack")) return e;
   XParams p{};
-  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y; p.amax_x = cell_a; p.amax_w = wcell;
+  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y; p.amax_x = cell_a; p.amax_w = wcell; p.guard = guard;
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
   p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.NS = NS; p.mP = magic(pl.P);
@@ -705,7 +708,7 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
 
 // xs: S3 input; wp_ws: >= s3x_packed_bytes scratch for the packed weights
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
-             long si, int flip, void* wp_ws, hipStream_t s) {
+             long si, int flip, void* wp_ws, hipStream_t s, const unsigned* guard) {
   const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS);
   if (!pl.ok) { set_error("conv_s3x: shape not covered"); return NC_ERR_SHAPE; }
   const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4;
@@ -714,7 +717,7 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
                      total, (const unsigned*)nullptr, Cin, (const unsigned*)nullptr, (const unsigned*)nullptr);
   if (int e = check_launch("pack_w_s3x")) return e;
   XParams p{};
-  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y;
+  p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y; p.guard = guard;
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
   p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
   p.NS = NS; p.mP = magic(pl.P);

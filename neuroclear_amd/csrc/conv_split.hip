@@ -67,8 +67,10 @@ __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_spl
 
 // fp32 NCDHW -> S3.  One thread per voxel of one 8-channel block: 8 coalesced dword loads, three 16-byte stores.  The C
 // channels land at blocks ob0 .. ob0 + C/8 - 1 of an S3 tensor with `oblocks` blocks per sample (a half of a concat buffer).
+// guard != NULL: runs only when the range guard has flagged the call (common.hpp) -- the three-term form written over the two-term one.
 __global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks,
-                                                int ob0, long xstride) {
+                                                int ob0, long xstride, const unsigned* __restrict__ guard) {
+  if (guard_skip(guard, 1)) return;
   const long v = (long)blockIdx.x * 256 + threadIdx.x;
   if (v >= S) return;
   const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
@@ -494,25 +496,42 @@ bool s3_layer_h2(const ConvDims& d);
 // xs_keep (only without xs_pre): the converted operand is written THERE instead of into the workspace -- the caller keeps it (the
 // weight gradient of the same layer wants the same S3 tensor)
 int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
-           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr, bool h2 = false) {
+           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr, bool h2 = false, unsigned* guard_pre = nullptr) {
   const int KS = d.kd;
   const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
   // The two-term fp16 form (nc_set_split_terms(2); the caller decided with s3_layer_h2): xs_pre / xs_keep / the workspace hold H2 tensors, cells at
-  // their tails (common.hpp h2_cells_offset); a forward input may be a concatenation converted in two halves (cells [0], [1])
+  // their tails (common.hpp h2_cells_offset); a forward input may be a concatenation converted in two halves (cells [0], [1]).
+  // Range guard (common.hpp): an operand converted HERE from fp32 has a measured cell -- the conversion counts its low chunks, the decision is
+  // taken on the device, and both kernel families are launched (`dual`): the flagged call is converted again as S3 into the same workspace
+  // region and runs on the three-term kernel.  guard_pre: xs_pre is such a region of the caller's (conv_bwd_s3) with its decision already taken.
+  // Workspace: [operand: the S3 tensor's 6 bytes per element | 256 B: guard words, weight cell | packed weights of either form].
   if (h2) {
     const size_t ex = (size_t)d.N * Cin * S;
-    const size_t xb = (xs_pre || xs_keep) ? 0 : h2_cells_offset(ex) + 256;
-    if (!ws || wsb < xb + 256 + s3x_packed_bytes(Cin, Kout, KS, 2) + 256) { set_error("conv_s3 (two-term): workspace too small"); return NC_ERR_WS; }
+    const bool internal = !xs_pre && !xs_keep;
+    const size_t p2 = s3x_packed_bytes(Cin, Kout, KS, 2), p3 = s3x_packed_bytes(Cin, Kout, KS, 3);
+    const size_t xb6 = align256(ex * 6), xb4 = h2_cells_offset(ex) + 256;
+    bool dual = guard_pre || (internal && x && h2_guard_on() && wsb >= xb6 + 256 + p3 + 256);
+    if (guard_pre && wsb < 256 + p3 + 256) { set_error("conv_s3 (two-term, guarded operand): workspace too small"); return NC_ERR_WS; }
+    const size_t xb = !internal ? 0 : dual ? xb6 : xb4;
+    if (!ws || wsb < xb + 256 + p2 + 256) { set_error("conv_s3 (two-term): workspace too small"); return NC_ERR_WS; }
     void* xs = xs_pre ? const_cast<void*>(xs_pre) : xs_keep ? xs_keep : ws;
     unsigned* cells = h2_cells_of(xs, ex);
+    unsigned* gw = (unsigned*)((char*)ws + xb);  // words 0..7: the guard of an operand measured here; word 16: the weights' cell
+    unsigned* guard = guard_pre ? guard_pre : gw;
     if (!xs_pre) {
+      if (int e = h2_guard_zero(gw, s)) return e;
       if (int e = h2_zero_cells(cells, 2, s)) return e;
       if (int e = h2_absmax(x, (long)ex, cells, s, cells + 1)) return e;
-      if (int e = split2h_into(x, (long)Cin * S, xs, d.N, Cin, S, Cin, 0, cells, s)) return e;
+      if (int e = split2h_into(x, (long)Cin * S, xs, d.N, Cin, S, Cin, 0, cells, s, gw)) return e;
+      if (int e = h2_guard_decide(gw, nullptr, nullptr, gw + kGuardFlag, dual, s)) return e;  // (not dual: the event is counted only)
+      if (dual)
+        if (int e = split3_into(x, (long)Cin * S, xs, d.N, Cin, S, Cin, 0, s, gw)) return e;
     }
-    return conv_s3x_h2(xs, cells, cells + 1, flip ? Cin : Cin / 2, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip,
-                       (unsigned*)((char*)ws + xb), (char*)ws + xb + 256, s);
+    if (int e = conv_s3x_h2(xs, cells, cells + 1, flip ? Cin : Cin / 2, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, gw + 16,
+                            (char*)ws + xb + 256, s, dual ? guard : nullptr)) return e;
+    if (dual) return conv_s3x(xs, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, (char*)ws + xb + 256, s, guard);
+    return NC_OK;
   }
   const size_t xb = (xs_pre || xs_keep) ? 0 : align256((size_t)d.N * Cin * S * 6);
   const size_t wb = align256(s_packed_bytes(Cin, Kout, KS));
@@ -523,7 +542,7 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
   if (!zeros) { set_error("conv_s3: no zero page"); return NC_ERR_HIP; }
   if (!xs_pre) {
     hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * Cin / 8)), dim3(256), 0, s, x, xs, S, Cin / 8, Cin / 8, 0,
-                       (long)Cin * S);
+                       (long)Cin * S, (const unsigned*)nullptr);
     if (int e = check_launch("split3")) return e;
   }
   // the tap-stream kernel (conv_s3x.hip: 16x16x32 MFMAs, no zero tap) takes every shape it covers; NC_S3X=0: the pair kernel below
@@ -574,6 +593,7 @@ struct WsParams {
   int npairs, nwp;   // (k-tile, c-tile[, kernel plane]) pairs, workgroups per pair
   long steps;        // N * YB * XB * D  (per pair)
   unsigned mTx, mXp, mXUp, mPTp;
+  const unsigned* guard;  // nullable: the range guard's words (common.hpp)
 };
 
 __device__ __forceinline__ i32x4 tr_frag(const unsigned char* lds, unsigned a0, unsigned a1) {
@@ -585,6 +605,7 @@ __device__ __forceinline__ i32x4 tr_frag(const unsigned char* lds, unsigned a0, 
 template <int KS>
 __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3(const WsParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  if (guard_skip(p.guard, 1)) return;
   // 3^3: one workgroup owns all 27 taps (ZR = 3 kernel planes, 4-slot X ring).  5^3: a workgroup owns the 25 taps of ONE
   // kernel plane (ZR = 1, 2-slot ring) and dz joins (k-tile, c-tile) in the "pair" index.
   constexpr int PAD = KS / 2, T2 = KS * KS;
@@ -812,6 +833,7 @@ constexpr int kWP = 6;  // 1 KiB pieces per wave of an X slot / a dY buffer (pla
 template <int KS, int NT, int DT>
 __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  if (guard_skip(p.guard, NT == 3)) return;
   constexpr int PAD = KS / 2, T2 = KS * KS;
   constexpr int ZR = KS == 3 ? 3 : 1, NS = ZR + 1, NDG = KS / ZR, TW = ZR * T2;
   constexpr int UW = 2 * TW, NU = (UW + 7) / 8;  // units (tap, c-block) of the workgroup / most units of a wave
@@ -1098,8 +1120,10 @@ __global__ void __launch_bounds__(kThreads, 1) k_wgrad_s3x(const WsParams p) {
 // xcells != NULL (H2 operands): the sums are scaled back by 2^-(kx + ky), kx per half of the input channels (h2.hip)
 __global__ void __launch_bounds__(256) k_wgrad_s3_reduce(const float* __restrict__ part, float* __restrict__ dw, int C, int T3, int TW,
                                                          int nct, int npairs, int nwp, int NF, long total,
-                                                         const unsigned* __restrict__ xcells = nullptr, const unsigned* __restrict__ ycell = nullptr) {
+                                                         const unsigned* __restrict__ xcells = nullptr, const unsigned* __restrict__ ycell = nullptr,
+                                                         const unsigned* __restrict__ guard = nullptr) {
   __shared__ float red[8][32];
+  if (guard_skip(guard, xcells ? 0 : 1)) return;
   const int o = threadIdx.x & 31, seg = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + o;  // (k, tap, c): c fastest -> coalesced partial reads
   float sacc = 0.f;
@@ -1217,107 +1241,144 @@ int ws_nwp(const ConvDims& d, const WsPlan& pl, int npairs) {
   return nwp;
 }
 
-// the weight gradient on H2 operands (two fp16 terms, three products): k_wgrad_s3x<KS, 2, f16>; xs_pre / dys_pre: H2 tensors with their cells, or NULL
-// (converted into the workspace with measured cells)
-int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
-              hipStream_t s) {
-  const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
-  const WsPlan pl = ws_plan(d, 2);
-  if (!pl.ok || ws_kv(d, 2) != 32) { set_error("wgrad_s3 (two-term): shape not covered"); return NC_ERR_SHAPE; }
-  const long S = (long)d.D * d.H * d.W;
-  const size_t ex = (size_t)d.N * d.C * S, ey = (size_t)d.N * d.K * S;
-  const size_t xb = xs_pre ? 0 : h2_cells_offset(ex) + 256;
-  const size_t yb = dys_pre ? 0 : h2_cells_offset(ey) + 256;
+// Bytes of the partial-sum area of the weight gradient, two-term (NT = 2) or three-term plan
+size_t ws_part_bytes(const ConvDims& d, int NT) {
+  const int T3 = d.kd * d.kh * d.kw, TW = d.kd == 3 ? 27 : 25;
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
+  const WsPlan pl = NT == 2 ? ws_plan(d, 2) : ws_plan(d);
+  if (!pl.ok) return 0;
   const int nwp = ws_nwp(d, pl, npairs);
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
-  const int NF = ws_nf(steps, nwp, ws_flush_steps2());
-  const size_t pb = align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
-  if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3 (two-term): workspace too small"); return NC_ERR_WS; }
-  void* xs = xs_pre ? const_cast<void*>(xs_pre) : ws;
-  void* dys = dys_pre ? const_cast<void*>(dys_pre) : (void*)((char*)ws + xb);
-  float* part = (float*)((char*)ws + xb + yb);
-  unsigned* xc = h2_cells_of(xs, ex);
-  unsigned* yc = h2_cells_of(dys, ey);
-  if (!xs_pre) {
-    if (int e = h2_zero_cells(xc, 2, s)) return e;
-    if (int e = h2_absmax(x, (long)ex, xc, s, xc + 1)) return e;
-    if (int e = split2h_into(x, (long)d.C * S, xs, d.N, d.C, S, d.C, 0, xc, s)) return e;
-  }
-  if (!dys_pre) {
-    if (int e = h2_zero_cells(yc, 2, s)) return e;
-    if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
-    if (int e = split2h_into(dy, (long)d.K * S, dys, d.N, d.K, S, d.K, 0, yc, s)) return e;
-  }
-  WsParams p{};
-  p.xs = (const uint4*)xs; p.dys = (const uint4*)dys; p.part = part; p.zeros = nullptr;
-  p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
-  p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
-  p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
-  p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
-  p.F = ws_flush_steps2(); p.NF = NF;
-  p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
-  if (int e = raise_dyn_lds((k_wgrad_s3x<3, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
-  if (int e = raise_dyn_lds((k_wgrad_s3x<5, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
-  const int lds = NS * pl.xslot + 2 * pl.dybuf;
-  if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
-  else hipLaunchKernelGGL((k_wgrad_s3x<5, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
-  if (int e = check_launch("wgrad_h2")) return e;
-  const long total = (long)d.K * d.C * T3;
-  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, (const float*)part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
-                     NF, total, (const unsigned*)xc, (const unsigned*)yc);
-  return check_launch("wgrad_h2_reduce");
+  const int NF = NT == 2 ? ws_nf(steps, nwp, ws_flush_steps2()) : ws_nf(steps, nwp);
+  return align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
 }
 
-int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
-           hipStream_t s) {
-  if (s3_layer_h2(d)) return run_ws_h2(x, xs_pre, dy, dys_pre, dw, d, ws, wsb, s);
+// The weight-gradient kernels proper: operands already in their form (NT = 2: H2 with cells xc / yc; NT = 3: S3), partial sums into `part`
+// (>= ws_part_bytes), guard (nullable): the launches leave at once unless the range guard's flag says it is this form's turn.
+int ws_core(int NT, const void* xs, const void* dys, const unsigned* xc, const unsigned* yc, float* dw, const ConvDims& d, float* part, hipStream_t s,
+            const unsigned* guard) {
   const int KS = d.kd, T3 = KS * KS * KS, TW = KS == 3 ? 27 : 25, NS = KS == 3 ? 4 : 2;
-  const WsPlan pl = ws_plan(d);
-  const long S = (long)d.D * d.H * d.W;
-  const size_t xb = xs_pre ? 0 : align256((size_t)d.N * d.C * S * 6);
-  const size_t yb = dys_pre ? 0 : align256((size_t)d.N * d.K * S * 6);
+  const WsPlan pl = NT == 2 ? ws_plan(d, 2) : ws_plan(d);
+  if (!pl.ok || (NT == 2 && ws_kv(d, 2) != 32)) { set_error("wgrad_s3: shape not covered"); return NC_ERR_SHAPE; }
   const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
   const int nwp = ws_nwp(d, pl, npairs);
   const long steps = (long)d.N * pl.YB * pl.XB * d.D;
-  const int NF = ws_nf(steps, nwp);
-  const size_t pb = align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4);
-  if (!ws || wsb < xb + yb + pb + 256) { set_error("wgrad_s3: workspace too small"); return NC_ERR_WS; }
-  uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
-  uint4* dys = dys_pre ? (uint4*)dys_pre : (uint4*)((char*)ws + xb);
-  float* part = (float*)((char*)ws + xb + yb);
-  const uint4* zeros = reinterpret_cast<const uint4*>(nc_zero_page());
-  if (!zeros) { set_error("wgrad_s3: no zero page"); return NC_ERR_HIP; }
-  if (!xs_pre)
-    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.C / 8)), dim3(256), 0, s, x, xs, S, d.C / 8, d.C / 8, 0,
-                       (long)d.C * S);
-  if (!dys_pre)
-    hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(d.N * d.K / 8)), dim3(256), 0, s, dy, dys, S, d.K / 8, d.K / 8, 0,
-                       (long)d.K * S);
-  if (int e = check_launch("split3")) return e;
+  const int F = NT == 2 ? ws_flush_steps2() : ws_flush_steps();
+  const int NF = ws_nf(steps, nwp, F);
   WsParams p{};
-  p.xs = xs; p.dys = dys; p.part = part; p.zeros = zeros;
+  p.xs = (const uint4*)xs; p.dys = (const uint4*)dys; p.part = part; p.guard = guard;
+  p.zeros = NT == 2 ? nullptr : reinterpret_cast<const uint4*>(nc_zero_page());
+  if (NT == 3 && !p.zeros) { set_error("wgrad_s3: no zero page"); return NC_ERR_HIP; }
   p.N = d.N; p.C = d.C; p.K = d.K; p.D = d.D; p.H = d.H; p.W = d.W;
   p.Ty = pl.Ty; p.Tx = pl.Tx; p.YB = pl.YB; p.XB = pl.XB; p.Xp = pl.Xp; p.XU = pl.XU; p.XUp = pl.XUp;
   p.PT = pl.PT; p.PTp = pl.PTp; p.NK = pl.NK; p.npx = pl.npx; p.npd = pl.npd; p.xslot = pl.xslot; p.dybuf = pl.dybuf;
   p.nct = d.C / 32; p.npairs = npairs; p.nwp = nwp; p.steps = steps;
-  p.F = ws_flush_steps(); p.NF = NF;
+  p.F = F; p.NF = NF;
   p.mTx = magic(pl.Tx); p.mXp = magic(pl.Xp); p.mXUp = magic(pl.XUp); p.mPTp = magic(pl.PTp);
+  const int lds = NS * pl.xslot + 2 * pl.dybuf;
+  const long total = (long)d.K * d.C * T3;
+  if (NT == 2) {
+    if (int e = raise_dyn_lds((k_wgrad_s3x<3, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
+    if (int e = raise_dyn_lds((k_wgrad_s3x<5, 2, NC_DT_F16>), kLdsMax, "wgrad_h2")) return e;
+    if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+    else hipLaunchKernelGGL((k_wgrad_s3x<5, 2, NC_DT_F16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
+    if (int e = check_launch("wgrad_h2")) return e;
+    hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, (const float*)part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
+                       NF, total, xc, yc, guard);
+    return check_launch("wgrad_h2_reduce");
+  }
   if (int e = raise_dyn_lds(k_wgrad_s3<3>, kLdsMax, "wgrad_s3")) return e;
   if (int e = raise_dyn_lds(k_wgrad_s3<5>, kLdsMax, "wgrad_s3")) return e;
   if (int e = raise_dyn_lds((k_wgrad_s3x<3, 3, NC_DT_BF16>), kLdsMax, "wgrad_s3")) return e;
   if (int e = raise_dyn_lds((k_wgrad_s3x<5, 3, NC_DT_BF16>), kLdsMax, "wgrad_s3")) return e;
-  const int lds = NS * pl.xslot + 2 * pl.dybuf;
   if (ws_kv(d) == 32) {
     if (KS == 3) hipLaunchKernelGGL((k_wgrad_s3x<3, 3, NC_DT_BF16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
     else hipLaunchKernelGGL((k_wgrad_s3x<5, 3, NC_DT_BF16>), dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   } else if (KS == 3) hipLaunchKernelGGL(k_wgrad_s3<3>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   else hipLaunchKernelGGL(k_wgrad_s3<5>, dim3(npairs * nwp), dim3(kThreads), lds, s, p);
   if (int e = check_launch("wgrad_s3")) return e;
-  const long total = (long)d.K * d.C * T3;
-  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
-                     NF, total);
+  hipLaunchKernelGGL(k_wgrad_s3_reduce, dim3((unsigned)cdiv(total, 32)), dim3(256), 0, s, (const float*)part, dw, d.C, T3, TW, d.C / 32, npairs, nwp,
+                     NF, total, (const unsigned*)nullptr, (const unsigned*)nullptr, guard);
   return check_launch("wgrad_s3_reduce");
+}
+
+// The weight gradient on H2 operands (two fp16 terms, three products): k_wgrad_s3x<KS, 2, f16>; xs_pre / dys_pre: H2 tensors with their cells, or
+// NULL (converted into the workspace with measured cells).  Range guard (common.hpp): an operand converted here counts its low chunks; when
+// the workspace has the room (`dual`), both kernel families are launched and the device-side flag picks one -- the flagged call gets BOTH
+// operands in S3 form (a measured one converted again over its H2 form; a pre-converted H2 one from its fp32 source, or from the H2 terms
+// themselves, into a region of the workspace).  dy_guard: dys_pre is a workspace region of the caller's whose decision was taken when it
+// was converted (conv_bwd_s3): S3 already if its flag is set, and converted to S3 in place if THIS call's x flags it.
+int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
+              hipStream_t s, unsigned* dy_guard) {
+  const long S = (long)d.D * d.H * d.W;
+  const size_t ex = (size_t)d.N * d.C * S, ey = (size_t)d.N * d.K * S;
+  const size_t pb2 = ws_part_bytes(d, 2), pb3 = ws_part_bytes(d, 3);
+  if (!pb2) { set_error("wgrad_s3 (two-term): shape not covered"); return NC_ERR_SHAPE; }
+  const bool measured = !xs_pre || !dys_pre;
+  // dual layout: [X: S3 capacity][Y: S3 capacity, unless dys_pre is the caller's guarded region or ... ][256: guard words][partial sums of either plan]
+  const bool y_in_place = dys_pre && dy_guard;               // the caller's region has the S3 capacity; dy (fp32) is there to convert it again
+  const bool y_copy = dys_pre && !dy_guard;                  // an H2 tensor we may not overwrite: its S3 form goes into the workspace
+  const size_t xb6 = align256(ex * 6), yb6 = y_in_place ? 0 : align256(ey * 6);
+  const size_t pbmax = pb2 > pb3 ? pb2 : pb3;
+  bool dual = (dy_guard || (measured && h2_guard_on())) && pb3 && wsb >= xb6 + yb6 + 256 + pbmax && (y_in_place ? dy != nullptr : true);
+  if (dy_guard && !dual) { set_error("wgrad_s3 (two-term, guarded dY): workspace too small"); return NC_ERR_WS; }
+  (void)y_copy;
+  const size_t xb = dual ? xb6 : (xs_pre ? 0 : h2_cells_offset(ex) + 256);
+  const size_t yb = dual ? yb6 : (dys_pre ? 0 : h2_cells_offset(ey) + 256);
+  if (!ws || wsb < xb + yb + 256 + (dual ? pbmax : pb2)) { set_error("wgrad_s3 (two-term): workspace too small"); return NC_ERR_WS; }
+  void* X = ws;
+  void* Y = (char*)ws + xb;
+  unsigned* gw = (unsigned*)((char*)ws + xb + yb);  // words 0..7: guard of x, 8..15: guard of dy, 16..23: the call's flag words
+  float* part = (float*)((char*)ws + xb + yb + 256);
+  void* xs = xs_pre ? const_cast<void*>(xs_pre) : X;
+  void* dys = dys_pre ? const_cast<void*>(dys_pre) : Y;
+  unsigned* xc = h2_cells_of(xs, ex);
+  unsigned* yc = h2_cells_of(dys, ey);
+  unsigned *gx = nullptr, *gy = nullptr, *call = gw + 16;
+  if (measured || dy_guard)
+    if (int e = h2_guard_zero(gw, s, 24)) return e;
+  if (!xs_pre) {
+    gx = gw;
+    if (int e = h2_zero_cells(xc, 2, s)) return e;
+    if (int e = h2_absmax(x, (long)ex, xc, s, xc + 1)) return e;
+    if (int e = split2h_into(x, (long)d.C * S, xs, d.N, d.C, S, d.C, 0, xc, s, gx)) return e;
+  }
+  if (!dys_pre) {
+    gy = gw + 8;
+    if (int e = h2_zero_cells(yc, 2, s)) return e;
+    if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
+    if (int e = split2h_into(dy, (long)d.K * S, dys, d.N, d.K, S, d.K, 0, yc, s, gy)) return e;
+  }
+  if (measured || dy_guard)
+    if (int e = h2_guard_decide(gx, gy, dy_guard, call + kGuardFlag, dual, s)) return e;
+  if (int e = ws_core(2, xs, dys, xc, yc, dw, d, part, s, dual ? call : nullptr)) return e;
+  if (!dual) return NC_OK;
+  // the flagged call: both operands as S3 tensors
+  const void* xs3 = X;
+  if (x) { if (int e = split3_into(x, (long)d.C * S, X, d.N, d.C, S, d.C, 0, s, call)) return e; }
+  else if (int e = h2_to_s3_if(xs_pre, X, d.N, d.C, S, xc, call, s)) return e;
+  const void* ys3 = y_in_place ? dys : Y;
+  if (dy) { if (int e = split3_into(dy, (long)d.K * S, const_cast<void*>(ys3), d.N, d.K, S, d.K, 0, s, call)) return e; }
+  else if (int e = h2_to_s3_if(dys_pre, Y, d.N, d.K, S, yc, call, s)) return e;
+  return ws_core(3, xs3, ys3, nullptr, nullptr, dw, d, part, s, call);
+}
+
+int run_ws(const float* x, const void* xs_pre, const float* dy, const void* dys_pre, float* dw, const ConvDims& d, void* ws, size_t wsb,
+           hipStream_t s, unsigned* dy_guard = nullptr) {
+  if (s3_layer_h2(d)) return run_ws_h2(x, xs_pre, dy, dys_pre, dw, d, ws, wsb, s, dy_guard);
+  const long S = (long)d.D * d.H * d.W;
+  const size_t xb = xs_pre ? 0 : align256((size_t)d.N * d.C * S * 6);
+  const size_t yb = dys_pre ? 0 : align256((size_t)d.N * d.K * S * 6);
+  const size_t pb = ws_part_bytes(d, 3);
+  if (!ws || !pb || wsb < xb + yb + pb + 256) { set_error("wgrad_s3: workspace too small"); return NC_ERR_WS; }
+  uint4* xs = xs_pre ? (uint4*)xs_pre : (uint4*)ws;
+  uint4* dys = dys_pre ? (uint4*)dys_pre : (uint4*)((char*)ws + xb);
+  float* part = (float*)((char*)ws + xb + yb);
+  if (!xs_pre)
+    if (int e = split3_into(x, (long)d.C * S, xs, d.N, d.C, S, d.C, 0, s)) return e;
+  if (!dys_pre)
+    if (int e = split3_into(dy, (long)d.K * S, dys, d.N, d.K, S, d.K, 0, s)) return e;
+  return ws_core(3, xs, dys, nullptr, nullptr, dw, d, part, s, nullptr);
 }
 
 // The same kernel on the 16-bit operands of the --precision path (C8 = one term), conv_h.hip's k_wgrad_h replaced: xh / dyh in C8,
@@ -1380,59 +1441,81 @@ size_t s3_ws_bytes(const ConvDims& d) {
   const long S = (long)d.D * d.H * d.W;
   const int cmax = d.C > d.K ? d.C : d.K;
   const int c64 = (d.C + 63) / 64 * 64, k64 = (d.K + 63) / 64 * 64;  // either may be the 64-multiple "output" side
-  return align256((size_t)d.N * cmax * S * 6) + align256(s_packed_bytes(c64, k64, d.kd)) + 512;
+  size_t pk = align256(s_packed_bytes(c64, k64, d.kd));
+  const size_t p3 = align256(s3x_packed_bytes(c64, k64, d.kd, 3));  // (the guarded two-term call packs either form here)
+  if (p3 > pk) pk = p3;
+  return align256((size_t)d.N * cmax * S * 6) + pk + 768;
 }
 size_t s3_tensor_bytes(int N, int C, long S) { return (size_t)N * C * S * 6; }
 bool s3_wgrad_supported(const ConvDims& d) { return ws_shape_ok(d); }
+// [X: S3 capacity | dY: S3 capacity | 256 B guard words | partial sums of the larger of the two plans (two-term / three-term)]
 size_t s3_wgrad_ws_bytes(const ConvDims& d) {
   if (!ws_shape_ok(d)) return 0;
   const long S = (long)d.D * d.H * d.W;
-  const int T3 = d.kd * d.kh * d.kw, TW = d.kd == 3 ? 27 : 25;
-  const int npairs = (d.K / 64) * (d.C / 32) * (T3 / TW);
-  const WsPlan pl = ws_plan(d);
-  const int nwp = ws_nwp(d, pl, npairs);
-  const int NF = ws_nf((long)d.N * pl.YB * pl.XB * d.D, nwp);
-  return align256((size_t)d.N * d.C * S * 6) + align256((size_t)d.N * d.K * S * 6) + align256((size_t)npairs * nwp * NF * TW * 64 * 32 * 4) + 512;
+  size_t pb = ws_part_bytes(d, 3);
+  if (ws_kv(d, 2) == 32 && ws_plan(d, 2).ok) { const size_t p2 = ws_part_bytes(d, 2); if (p2 > pb) pb = p2; }
+  return align256((size_t)d.N * d.C * S * 6) + align256((size_t)d.N * d.K * S * 6) + pb + 768;
 }
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s) {
   return run_ws(x, xs, dy, dys, dw, d, ws, wsb, s);
 }
-// data + weight gradient of one layer with dY converted once: [S3 of dY | scratch of whichever kernel runs]
+// data + weight gradient of one layer with dY converted once: [dY operand: S3 capacity | 256 B: its guard words | scratch of whichever kernel runs]
 size_t s3_bwd_ws_bytes(const ConvDims& d) {
   if (!ws_shape_ok(d)) return 0;
   const long S = (long)d.D * d.H * d.W;
-  const size_t A = align256((size_t)d.N * d.K * S * 6);
-  const size_t dg = s_shape_ok(d, d.K, d.C) ? align256(s_packed_bytes(d.K, d.C, d.kd)) + 512 : 0;  // (the data gradient is optional)
+  const size_t A = align256((size_t)d.N * d.K * S * 6) + 256;
+  size_t dg = 0;
+  if (s_shape_ok(d, d.K, d.C)) {  // (the data gradient is optional)
+    dg = align256(s_packed_bytes(d.K, d.C, d.kd));
+    const size_t p3 = align256(s3x_packed_bytes(d.K, d.C, d.kd, 3));
+    if (p3 > dg) dg = p3;
+    dg += 768;
+  }
   const size_t wg = s3_wgrad_ws_bytes(d) - align256((size_t)d.N * d.K * S * 6);
   return A + (dg > wg ? dg : wg);
 }
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
                 hipStream_t s, int phase, const void* xs) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient (xs: x in S3, or NULL)
   const long S = (long)d.D * d.H * d.W;
-  const size_t A = align256((size_t)d.N * d.K * S * 6);
+  const size_t A = align256((size_t)d.N * d.K * S * 6) + 256;
   if (!ws || wsb < s3_bwd_ws_bytes(d)) { set_error("conv_bwd_s3: workspace too small"); return NC_ERR_WS; }
+  // dy != NULL: dY is converted here (phase 0) with a MEASURED cell -- the range guard applies (common.hpp): its words sit behind the operand
+  // region, phase 0 takes the decision and, flagged, writes the S3 form over the H2 one; phases 1 and 2 launch both kernel families.
+  // dy == NULL (conv_bwd_pre): the producer (InstanceNorm backward) wrote the H2 form with a bound for a cell: no guard.
+  unsigned* yg = (unsigned*)((char*)ws + A - 256);
+  const bool h2 = s3_layer_h2(d);
+  const bool guarded = h2 && dy && h2_guard_on();
   if (phase == 0) {
-    if (s3_layer_h2(d)) {  // dY as an H2 tensor (measured cell) where the S3 tensor would stand
+    if (h2) {  // dY as an H2 tensor (measured cell) where the S3 tensor would stand
       const size_t ey = (size_t)d.N * d.K * S;
       unsigned* yc = h2_cells_of(ws, ey);
+      if (int e = h2_guard_zero(yg, s)) return e;
       if (int e = h2_zero_cells(yc, 2, s)) return e;
       if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
-      return split2h_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, yc, s);
+      if (int e = split2h_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, yc, s, yg)) return e;
+      if (!guarded) return NC_OK;
+      if (int e = h2_guard_decide(yg, nullptr, nullptr, yg + kGuardFlag, true, s)) return e;
+      return split3_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, s, yg);
     }
     return split3_to(dy, ws, d.N, d.K, S, s);
   }
-  if (phase == 1) return conv_dgrad_s3(dy, ws, w, dx, d, (char*)ws + A, wsb - A, s);
-  return conv_wgrad_s3(x, xs, dy, ws, dw, d, (char*)ws + A, wsb - A, s);
+  if (phase == 1) {
+    ConvDims t = d;
+    t.C = d.K; t.K = d.C;
+    const int T3 = d.kd * d.kh * d.kw;
+    return run_s3(dy, ws, w, nullptr, dx, t, d.K, d.C, T3, (long)d.C * T3, 1, (char*)ws + A, wsb - A, s, nullptr, h2, guarded ? yg : nullptr);
+  }
+  return run_ws(x, xs, dy, ws, dw, d, (char*)ws + A, wsb - A, s, guarded ? yg : nullptr);
 }
 
 int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) { return split3_into(x, (long)C * S, xs, N, C, S, C, 0, s); }
 
 // x: N samples of C channels, `xstride` floats apart; result: channels c0 .. c0 + C - 1 of an S3 tensor with ctot channels
-int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s) {
+int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s, const unsigned* guard) {
   if (C % 8 || ctot % 8 || c0 % 8) { set_error("split3: channels must be multiples of 8"); return NC_ERR_SHAPE; }
   hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8,
-                     xstride);
+                     xstride, guard);
   return check_launch("split3");
 }
 
@@ -1456,7 +1539,12 @@ int operand_into(const ConvDims& d, const float* x, long xstride, void* xs, int 
   if (int e = h2_zero_cells(mine, C == ctot ? 2 : 1, s)) return e;
   for (int n = 0; n < N; ++n)
     if (int e = h2_absmax(x + (long)n * xstride, (long)C * S, mine, s, C == ctot ? cells + 1 : nullptr)) return e;
-  return split2h_into(x, xstride, xs, N, C, S, ctot, c0, mine, s);
+  // range guard, COUNT ONLY: the tensor lives in the caller's buffer and its consumers are launched elsewhere, so a flagged tensor cannot
+  // change kernels here -- it is reported (nc_h2_guard_stats: [2]); guard words in the spare words of the 256-byte cells block
+  unsigned* g = cells + (c0 ? 16 : 8);
+  if (int e = h2_guard_zero(g, s)) return e;
+  if (int e = split2h_into(x, xstride, xs, N, C, S, ctot, c0, mine, s, g)) return e;
+  return h2_guard_decide(g, nullptr, nullptr, g + kGuardFlag, false, s);
 }
 int act_operand(const ConvDims& d, const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C,
                 long S, int ctot, int c0, hipStream_t s) {

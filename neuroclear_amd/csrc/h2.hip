@@ -3,6 +3,10 @@
 // units like S3 with two sub-blocks.  The power of two comes from a CELL, one unsigned per tensor holding the float bits of a magnitude that
 // bounds the tensor from above within a factor of two: the largest finite |x| (k_absmax; atomicMax, order-independent, deterministic), or a
 // bound known by construction (h2_set_cell: |InstanceNorm output| <= sqrt(S - 1)).
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+
 #include "common.hpp"
 #include "s3_common.hpp"
 
@@ -62,20 +66,99 @@ __global__ void k_set_cells(unsigned* cells, int n, unsigned bits) {
   if ((int)threadIdx.x < n) cells[threadIdx.x] = bits;
 }
 
-// fp32 [N][C][S] (samples xstride floats apart) -> channels ob0*8 .. of an H2 tensor with `oblocks` 8-channel blocks per sample
+// fp32 [N][C][S] (samples xstride floats apart) -> channels ob0*8 .. of an H2 tensor with `oblocks` 8-channel blocks per sample.
+// guard != NULL (the RANGE GUARD of a measured cell, common.hpp): a wave's 64 voxels x 8 channels are one CHUNK; the kernel counts the
+// chunks that hold a finite non-zero element (guard[kGuardAll]) and those whose LARGEST magnitude lies below 2^-17 of the cell
+// (guard[kGuardLow]: every element of such a chunk has lost bits of its second term).  Integer atomics: order-independent, deterministic.
 __global__ void __launch_bounds__(256) k_split2h(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks, int ob0,
-                                                 long xstride, const unsigned* __restrict__ cell) {
+                                                 long xstride, const unsigned* __restrict__ cell, unsigned* __restrict__ guard) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool active = v < S;
+  const unsigned cb_bits = *cell;
+  const float sc = h2_scale(cb_bits);
+  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
+  unsigned m = 0;
+  if (active) {
+    const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
+    unsigned short e[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = xs[j * S];
+      const unsigned b = __float_as_uint(f) & 0x7fffffffu;
+      if (b < 0x7f800000u && b > m) m = b;
+      h2_split(f * sc, e[j]);
+    }
+    const long ob = (long)n * oblocks + ob0 + cb;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
+  }
+  if (!guard) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned q = (unsigned)__shfl_xor((int)m, o);
+    m = q > m ? q : m;
+  }
+  __shared__ unsigned cnt[2];
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && m) {
+    atomicAdd(&cnt[kGuardAll], 1u);
+    if (cb_bits > kGuardDrop && m < cb_bits - kGuardDrop) atomicAdd(&cnt[kGuardLow], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(guard + threadIdx.x, cnt[threadIdx.x]);
+}
+
+// The guard's decision, one thread: f = more than 1 / kGuardShare of the non-zero chunks of EITHER tensor measured in this call (ga, gb nullable)
+// lie below 2^-17 of their tensor's cell.  can_flip: the caller launches the three-term kernels behind this (they run when the flag is set,
+// the two-term ones when it is clear); else f is only counted.  prior (nullable): the words of an operand whose decision was taken earlier
+// (conv_bwd_s3's dY): the call's flag is the OR, and the operand's own flag follows it (the caller re-converts that operand too).
+// stats: host-visible counters (nc_h2_guard_stats).
+__global__ void k_h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, int can_flip, unsigned long long* stats) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned f = 0;
+  unsigned long long worst = 0;
+  int n = 0;
+  for (unsigned* g : {ga, gb}) {
+    if (!g) continue;
+    ++n;
+    const unsigned long long lo = g[kGuardLow], all = g[kGuardAll];
+    if (all && lo * kGuardShare > all) f = 1;
+    const unsigned long long ppm = all ? lo * 1000000ull / all : 0;
+    worst = ppm > worst ? ppm : worst;
+  }
+  unsigned F = f && can_flip ? 1u : 0u;
+  if (prior && prior[kGuardFlag]) F = 1u;
+  *flag = F;
+  if (prior) prior[kGuardFlag] = F;
+  if (stats && n) {
+    __hip_atomic_fetch_add(stats + 0, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (f) __hip_atomic_fetch_add(stats + (can_flip ? 1 : 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_max(stats + 3, worst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// An H2 tensor back to fp32 values and on to the S3 form (exact: a0 + a1 has at most 23 significant bits and 2^-k is a power of two), into a
+// SEPARATE buffer -- for the partner of a flagged operand that exists in H2 form only.  Runs when guard[kGuardFlag] is set.
+__global__ void __launch_bounds__(256) k_h2_to_s3_if(const uint4* __restrict__ in, uint4* __restrict__ out, long S, int cblocks,
+                                                      const unsigned* __restrict__ cells, const unsigned* __restrict__ guard) {
+  if (guard_skip(guard, 1)) return;
   const long v = (long)blockIdx.x * 256 + threadIdx.x;
   if (v >= S) return;
-  const float sc = h2_scale(*cell);
-  const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
-  const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
+  const int cb = blockIdx.y % cblocks;
+  const float inv = h2_inv_scale(cells[cb >= cblocks / 2 ? 1 : 0]);
+  const long b = blockIdx.y;
+  const uint4 a = in[(b * 2 + 0) * S + v], r = in[(b * 2 + 1) * S + v];
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, rw[4] = {r.x, r.y, r.z, r.w};
   unsigned short e[8][3];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) h2_split(xs[j * S] * sc, e[j]);
-  const long ob = (long)n * oblocks + ob0 + cb;
+  for (int j = 0; j < 8; ++j) {
+    const unsigned short h0 = (unsigned short)(aw[j >> 1] >> ((j & 1) * 16)), h1 = (unsigned short)(rw[j >> 1] >> ((j & 1) * 16));
+    const float val = ((float)__builtin_bit_cast(_Float16, h0) + (float)__builtin_bit_cast(_Float16, h1)) * inv;
+    s3_split(val, e[j]);
+  }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
+  for (int t = 0; t < 3; ++t) out[(b * 3 + t) * S + v] = s3_unit(e, t);
 }
 
 // InstanceNorm normalisation + (Leaky)ReLU (k_act_split3's arithmetic, operation for operation) writing the H2 form -- and the fp32 tensor too
@@ -176,11 +259,56 @@ int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* c
   hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n, cell, cell2);
   return check_launch("h2_absmax");
 }
-int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s) {
+int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s, unsigned* guard) {
   if (C % 8 || ctot % 8 || c0 % 8) { set_error("split2h: channels must be multiples of 8"); return NC_ERR_SHAPE; }
   hipLaunchKernelGGL(k_split2h, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8, xstride,
-                     cell);
+                     cell, h2_guard_on() ? guard : nullptr);
   return check_launch("split2h");
+}
+
+// ---- the range guard (common.hpp) -----------------------------------------------------------------------------------------------------------
+static std::atomic<int> g_guard{getenv("NC_H2_GUARD") ? atoi(getenv("NC_H2_GUARD")) : 1};
+bool h2_guard_on() { return g_guard != 0; }
+void h2_guard_set(int on) { g_guard = on ? 1 : 0; }
+namespace {
+std::mutex g_stats_mu;
+unsigned long long* g_stats_host = nullptr;  // 4 counters in pinned host memory the device adds to (system-scope atomics): readable without a sync
+unsigned long long* g_stats_dev = nullptr;
+unsigned long long* guard_stats_dev() {
+  std::lock_guard<std::mutex> lk(g_stats_mu);
+  if (!g_stats_host) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    __builtin_memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+    g_stats_host = (unsigned long long*)h;
+    g_stats_dev = (unsigned long long*)d;
+  }
+  return g_stats_dev;
+}
+}  // namespace
+int h2_guard_read(unsigned long long* out4, int reset) {
+  std::lock_guard<std::mutex> lk(g_stats_mu);
+  for (int i = 0; i < 4; ++i) {
+    out4[i] = g_stats_host ? __atomic_load_n(g_stats_host + i, __ATOMIC_RELAXED) : 0;
+    if (reset && g_stats_host) __atomic_store_n(g_stats_host + i, 0ull, __ATOMIC_RELAXED);
+  }
+  return NC_OK;
+}
+int h2_guard_zero(unsigned* g, hipStream_t s, int nwords) {
+  hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, g, nwords, 0u);
+  return check_launch("h2_guard_zero");
+}
+int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s) {
+  if (!h2_guard_on() && !prior) return NC_OK;  // (the words were zeroed: the flag reads 0)
+  hipLaunchKernelGGL(k_h2_guard_decide, dim3(1), dim3(64), 0, s, ga, gb, prior, flag, can_flip ? 1 : 0, guard_stats_dev());
+  return check_launch("h2_guard_decide");
+}
+int h2_to_s3_if(const void* xh, void* xs, int N, int C, long S, const unsigned* cells, const unsigned* guard, hipStream_t s) {
+  if (C % 8) { set_error("h2_to_s3: channels must be a multiple of 8"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_h2_to_s3_if, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, (const uint4*)xh, (uint4*)xs, S, C / 8, cells, guard);
+  return check_launch("h2_to_s3_if");
 }
 // bound: an upper bound of |result| known to the caller (InstanceNorm output: sqrt(S)); written to *cell (and *cell2) by the kernel itself
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,

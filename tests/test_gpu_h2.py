@@ -29,8 +29,10 @@ def _restore():
     from neuroclear_amd import ops
     prev = ops.set_conv_split(True)
     t = L().nc_get_split_terms()
+    gd = L().nc_get_h2_guard()
     yield
     L().nc_set_split_terms(t)
+    L().nc_set_h2_guard(gd)
     ops.set_conv_split(prev)
 
 
@@ -38,8 +40,9 @@ def data(kind, shape, g):
     x = torch.randn(shape, device=DEV, generator=g)
     if kind == 'relu':
         return x.clamp_min(0)
-    if kind == 'grad':      # gradient-like: tiny, log-normal magnitudes
-        return x * 1e-5 * torch.exp(2 * torch.randn(shape, device=DEV, generator=g))
+    if kind in ('grad', 'grad4', 'grad6'):      # gradient-like: tiny, log-normal magnitudes (sigma 2; 4 and 6: heavier tails than any layer shows)
+        sig = {'grad': 2.0, 'grad4': 4.0, 'grad6': 6.0}[kind]
+        return x * 1e-5 * torch.exp(sig * torch.randn(shape, device=DEV, generator=g))
     if kind == 'outlier':   # one element 900 sigma out (an InstanceNorm output can reach sqrt(voxels))
         x.view(-1)[12345] = 900.0
     return x
@@ -51,7 +54,7 @@ def err(a, r):
     return e.abs().max().item() / s, e.pow(2).mean().sqrt().item() / s
 
 
-CASES = [(1, 64, 64, 32, 3, 'relu'), (1, 64, 64, 32, 3, 'grad'), (1, 64, 64, 32, 3, 'outlier'), (2, 128, 64, 20, 3, 'randn'), (1, 64, 128, 27, 3, 'relu'),
+CASES = [(1, 64, 64, 32, 3, 'relu'), (1, 64, 64, 32, 3, 'grad'), (1, 64, 64, 32, 3, 'grad4'), (1, 64, 64, 32, 3, 'grad6'), (1, 64, 64, 32, 3, 'outlier'), (2, 128, 64, 20, 3, 'randn'), (1, 64, 128, 27, 3, 'relu'),
          (1, 64, 64, 24, 5, 'randn'), (1, 256, 256, 12, 3, 'relu')]
 
 
@@ -64,7 +67,7 @@ def test_h2_layer_against_fp64(case):
     w = torch.randn(K, C, ks, ks, ks, device=DEV, generator=g) * (2.0 / (C * ks ** 3)) ** 0.5
     b = torch.randn(K, device=DEV, generator=g) * 0.1
     ref = F.conv3d(x.double(), w.double(), b.double(), padding=ks // 2)
-    dy = data('grad' if kind == 'grad' else 'randn', tuple(ref.shape), g)
+    dy = data(kind if kind.startswith('grad') else 'randn', tuple(ref.shape), g)
     refd = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=ks // 2)
     res = {}
     for name, split, terms in (('fp32', False, 3), ('t3', True, 3), ('t2', True, 2)):
@@ -109,29 +112,162 @@ def test_h2_range(scale):
     assert xv.data_ptr() % 16 != 0 and torch.equal(ops.conv_fwd_raw(xv, w, None, 1, 1), y1)
 
 
+def guard_stats(reset=False):
+    import ctypes
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 4)()
+    assert L().nc_h2_guard_stats(out, 1 if reset else 0) == 0
+    return [int(v) for v in out]
+
+
 def test_h2_range_inside_one_tensor_is_the_documented_limit():
     """What the two-term form gives up (nc_hip.h): range INSIDE one tensor.  One element at 3.4e38 among N(0, 1): the power of two
-    follows the giant, every ordinary element falls below fp16's subnormals and vanishes.  The result stays finite and is right RELATIVE TO
-    THE TENSOR'S SCALE (the outputs the giant touches are right to 1e-6; the others are 0 where fp32 would have kept O(1) values --
-    1e-38 of the output range); the three-term form (nc_set_split_terms(3)) keeps them, which is what the switch is for."""
+    follows the giant, every ordinary element falls below fp16's subnormals and vanishes.  Round 5: the RANGE GUARD sees that (every chunk but
+    the giant's lies below 2^-17 of the cell) and the call runs on the three-term kernels -- the default result is the three-term result bit
+    for bit.  With the guard off (nc_set_h2_guard(0), the round-4 behaviour) the limit shows: the result stays finite and is right RELATIVE TO
+    THE TENSOR'S SCALE (the outputs the giant touches are right to 1e-6; the others are 0 where fp32 would have kept O(1) values)."""
     from neuroclear_amd import ops
     g = torch.Generator(device=DEV).manual_seed(24)
     x = torch.randn(1, 64, 8, 12, 20, device=DEV, generator=g)
     w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 1e-3
     x[0, 5, 4, 6, 7] = 3.4e38
     ref = F.conv3d(x.double(), w.double(), padding=1)
+    touched = torch.zeros_like(ref, dtype=torch.bool)
+    touched[:, :, 3:6, 5:8, 6:9] = True
+    L().nc_set_split_terms(3)
+    y3 = ops.conv_fwd_raw(x, w, None, 1, 1)
+    assert float(((y3.double() - ref).abs() / ref.abs().clamp_min(1e-2))[~touched].max()) < 1e-3   # the three-term form keeps the ordinary outputs
     L().nc_set_split_terms(2)
+    assert L().nc_get_h2_guard() == 1
+    before = guard_stats()
+    yg = ops.conv_fwd_raw(x, w, None, 1, 1)
+    after = guard_stats()
+    assert torch.equal(yg, y3) and after[1] == before[1] + 1 and after[3] > 900000   # flagged: > 90 % of the chunks are low
+    L().nc_set_h2_guard(0)
     y2 = ops.conv_fwd_raw(x, w, None, 1, 1)
+    assert guard_stats() == after                                      # (off: nothing is measured)
     assert bool(torch.isfinite(y2).all())
     e2 = (y2.double() - ref).abs()
     assert float((e2 / ref.abs().clamp_min(1e30)).max()) < 1e-6      # right where the giant dominates
     assert float(e2.max() / ref.abs().max()) < 1e-6                   # and everywhere relative to the output range
-    touched = torch.zeros_like(y2, dtype=torch.bool)
-    touched[:, :, 3:6, 5:8, 6:9] = True
-    assert float(y2[~touched].abs().max()) < 1e-3 < float(ref[~touched].abs().max())  # the ordinary outputs are gone ...
+    assert float(y2[~touched].abs().max()) < 1e-3 < float(ref[~touched].abs().max())  # the ordinary outputs are gone: the documented limit
+
+
+def mixed(kind, shape, g):
+    """Tensors whose magnitudes are spread over SPACE (what the two-term form's one power of two per tensor cannot serve):
+    'outlier_bulk': N(0, 1) x 2^-20 .. 2^-25 (by channel) everywhere, one element of 1.0; 'dark_half': the planes z < D / 2 are 2^-21 of the rest;
+    'dark_channels': the first quarter of the channels (two 8-channel blocks) 2^-22 of the others."""
+    x = torch.randn(shape, device=DEV, generator=g)
+    if kind == 'outlier_bulk':
+        sc = 2.0 ** -(20 + torch.arange(shape[1], device=DEV) % 6).float()
+        x = x * sc.view(1, -1, 1, 1, 1)
+        x[0, 3, shape[2] // 2, shape[3] // 2, shape[4] // 2] = 1.0
+    elif kind == 'dark_half':
+        x[:, :, :shape[2] // 2] *= 2.0 ** -21
+    elif kind == 'dark_channels':
+        x[:, :shape[1] // 4] *= 2.0 ** -22
+    return x
+
+
+def local_rel_err(a, r, box=4):
+    """Error against fp64 RELATIVE TO THE LOCAL output magnitude: rms over boxes of box^3 voxels (all channels), worst box -- what a global rms
+    hides when one region of the volume is 2^20 below another."""
+    e = (a.double() - r).pow(2)
+    pool = torch.nn.functional.avg_pool3d
+    num = pool(e.mean(1, keepdim=True), box, ceil_mode=True)
+    den = pool(r.pow(2).mean(1, keepdim=True), box, ceil_mode=True)
+    return float((num / den.clamp_min(1e-300)).sqrt().max())
+
+
+@pytest.mark.parametrize('kind', ['outlier_bulk', 'dark_half', 'dark_channels'])
+def test_h2_guard_mixed_magnitudes_fall_back_to_three_terms(kind):
+    """The round-4 verdict's case: bulk 2^20-2^25 below one outlier (and two more spatial / channel-wise spreads) through the DEFAULT
+    nc_conv_fwd / nc_conv_dgrad / nc_conv_wgrad / nc_conv_bwd.  The guard flags each call (one count per call), the results are the three-term
+    results bit for bit, they meet the global criteria of every other case (rms <= 1.3 x, max <= 2 x the fp32 MFMA kernel's error) AND are
+    right locally (every 4^3 box of outputs to 5e-7 of ITS OWN magnitude -- fp32 class; with the guard off the dark regions carry the two-term
+    form's ABSOLUTE floor, 2^-40 of the tensor's maximum, which is 1e-6 .. 1e-4 of them)."""
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import I, Z, check
+    N, C, K, E, ks = 1, 64, 64, 24, 3
+    g = torch.Generator(device=DEV).manual_seed(31)
+    x = mixed(kind, (N, C, E, E, E), g)
+    dy = mixed(kind, (N, K, E, E, E), g)
+    w = torch.randn(K, C, ks, ks, ks, device=DEV, generator=g) * (2.0 / (C * ks ** 3)) ** 0.5
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    refd = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=1)
+    refw = torch.nn.grad.conv3d_weight(x.double(), w.shape, dy.double(), padding=1)
+    xo = torch.randn(N, C, E, E, E, device=DEV, generator=g).clamp_min(0)   # an ordinary partner for the one-flagged-operand weight gradients
+
+    def run():
+        return (ops.conv_fwd_raw(x, w, None, 1, 1), ops.conv_dgrad_raw(dy, w, x.shape, 1, 1), ops.conv_wgrad_raw(x, dy, w.shape, 1, 1, False)[0],
+                ops.conv_wgrad_raw(xo, dy, w.shape, 1, 1, False)[0])
+    ops.set_conv_split(False)
+    e32 = [err(a, r) for a, r in zip(run()[:3], (ref, refd, refw))]
+    ops.set_conv_split(True)
     L().nc_set_split_terms(3)
-    y3 = ops.conv_fwd_raw(x, w, None, 1, 1)
-    assert float(((y3.double() - ref).abs() / ref.abs().clamp_min(1e-2))[~touched].max()) < 1e-3   # ... the three-term form keeps them
+    t3 = run()
+    L().nc_set_split_terms(2)
+    before = guard_stats()
+    t2 = run()
+    after = guard_stats()
+    assert after[1] == before[1] + 4 and after[2] == before[2], (before, after)          # every one of the four calls fell back
+    assert all(torch.equal(a, b) for a, b in zip(t2, t3))
+    assert all(torch.equal(a, b) for a, b in zip(t2, run()))
+    for (m2, r2), (m32, r32), what in zip([err(a, r) for a, r in zip(t2[:3], (ref, refd, refw))], e32, ('fwd', 'dgrad', 'wgrad')):
+        assert r2 <= 1.3 * r32 + 2e-8 and m2 <= 2.0 * m32 + 2e-7, (what, m2, r2, m32, r32)
+    if kind == 'dark_channels':  # the weight gradient has one output slice per INPUT channel: the dark channels' slices are the dark outputs
+        def per_channel(a):
+            return float(((a.double() - refw).pow(2).mean((0, 2, 3, 4)) / refw.pow(2).mean((0, 2, 3, 4))).sqrt().max())
+        good = per_channel(t2[2])
+        L().nc_set_h2_guard(0)
+        bad = per_channel(ops.conv_wgrad_raw(x, dy, w.shape, 1, 1, False)[0])
+        L().nc_set_h2_guard(1)
+        print(kind, 'wgrad, worst input channel: guard on %.2e, off %.2e' % (good, bad))
+        assert good < 5e-7 and bad > 4 * good
+    else:  # (every forward / data-gradient output sums over all channels: only the spatial spreads leave dark OUTPUT regions)
+        good = max(local_rel_err(t2[0], ref), local_rel_err(t2[1], refd))
+        L().nc_set_h2_guard(0)
+        bad = local_rel_err(ops.conv_fwd_raw(x, w, None, 1, 1), ref)
+        L().nc_set_h2_guard(1)
+        print(kind, 'worst 4^3 box, error relative to its own magnitude: guard on %.2e, off %.2e' % (good, bad))
+        assert good < 5e-7 and bad > 4 * good                                            # what the guard is for
+    # nc_conv_bwd: dY converted once (flagged there), the data gradient and the weight gradient both follow it; x an ordinary tensor
+    ws = ops.workspace(L().nc_conv_ws_bytes(I(N), I(C), I(E), I(E), I(E), I(K), I(3), I(3), I(3), I(1), I(1)), DEV, 'ws_guard_test')
+    outs = []
+    after = guard_stats()
+    for terms in (3, 2):
+        L().nc_set_split_terms(terms)
+        dx, dw = torch.empty_like(xo), torch.empty_like(w)
+        check(L().nc_conv_bwd(ops._ptr(xo), ops._ptr(dy), ops._ptr(w), ops._ptr(dx), ops._ptr(dw), None, I(N), I(C), I(E), I(E), I(E), I(K), I(3),
+                              I(3), I(3), I(1), I(1), ops._ptr(ws), Z(ws.numel()), ops._stream()), 'nc_conv_bwd')
+        outs.append((dx, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[1][0], t2[1]) and torch.equal(outs[1][1], t2[3])
+    assert guard_stats()[1] == after[1] + 1                                              # one decision (dY's), taken once for both gradients
+
+
+@pytest.mark.parametrize('kind', ['relu', 'randn', 'grad', 'grad4', 'outlier'])
+def test_h2_guard_leaves_ordinary_tensors_alone(kind):
+    """Heavy tails WITHOUT spatial structure (log-normal magnitudes up to sigma = 4, an element 900 sigma out) are the two-term form's home
+    ground -- every output sums over elements of all sizes (test_h2_layer_against_fp64 holds them to the fp32 criteria): no chunk is low, no
+    call falls back, and the result is the guard-off result bit for bit.  (At sigma = 6 the largest of a chunk's 512 elements is itself
+    2^17 below the tensor's largest in a fifth of the chunks: the guard errs on the safe side and that case runs on three terms.)"""
+    from neuroclear_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = data(kind, (1, 64, 24, 24, 24), g)
+    dy = data(kind if kind.startswith('grad') else 'randn', (1, 64, 24, 24, 24), g)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 0.03
+    L().nc_set_split_terms(2)
+
+    def run():
+        return (ops.conv_fwd_raw(x, w, None, 1, 1), ops.conv_dgrad_raw(dy, w, x.shape, 1, 1), ops.conv_wgrad_raw(x, dy, w.shape, 1, 1, False)[0])
+    before = guard_stats()
+    on = run()
+    after = guard_stats()
+    assert after[0] == before[0] + 4 and after[1] == before[1] and after[2] == before[2], (before, after)   # four tensors measured, none flagged
+    L().nc_set_h2_guard(0)
+    off = run()
+    assert all(torch.equal(a, b) for a, b in zip(on, off))
 
 
 def test_h2_nonfinite_inputs_follow_the_split_rule():
