@@ -71,20 +71,21 @@ __device__ __forceinline__ void split3(float v, unsigned short (&t)[3]) { s3_spl
 __global__ void __launch_bounds__(256) k_split3(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks,
                                                 int ob0, long xstride, const unsigned* __restrict__ guard) {
   if (guard_skip(guard, 1)) return;
-  const long v = (long)blockIdx.x * 256 + threadIdx.x;
-  if (v >= S) return;
   const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
-  const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
-  unsigned short e[8][3];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) split3(xs[j * S], e[j]);
   const long ob = (long)n * oblocks + ob0 + cb;
+  // (guarded launches come with a capped grid -- they usually leave at once -- and walk several tiles when they do run)
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
+    unsigned short e[8][3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    uint4 o;
-    o.x = e[0][t] | ((unsigned)e[1][t] << 16); o.y = e[2][t] | ((unsigned)e[3][t] << 16);
-    o.z = e[4][t] | ((unsigned)e[5][t] << 16); o.w = e[6][t] | ((unsigned)e[7][t] << 16);
-    out[(ob * 3 + t) * S + v] = o;
+    for (int j = 0; j < 8; ++j) split3(xs[j * S], e[j]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      uint4 o;
+      o.x = e[0][t] | ((unsigned)e[1][t] << 16); o.y = e[2][t] | ((unsigned)e[3][t] << 16);
+      o.z = e[4][t] | ((unsigned)e[5][t] << 16); o.w = e[6][t] | ((unsigned)e[7][t] << 16);
+      out[(ob * 3 + t) * S + v] = o;
+    }
   }
 }
 
@@ -1514,7 +1515,10 @@ int split3_to(const float* x, void* xs, int N, int C, long S, hipStream_t s) { r
 // x: N samples of C channels, `xstride` floats apart; result: channels c0 .. c0 + C - 1 of an S3 tensor with ctot channels
 int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s, const unsigned* guard) {
   if (C % 8 || ctot % 8 || c0 % 8) { set_error("split3: channels must be multiples of 8"); return NC_ERR_SHAPE; }
-  hipLaunchKernelGGL(k_split3, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8,
+  long bx = cdiv(S, 256);
+  const long ny = (long)N * C / 8;
+  if (guard && bx * ny > 2048) bx = cdiv(2048, ny) < bx ? cdiv(2048, ny) : bx;
+  hipLaunchKernelGGL(k_split3, dim3((unsigned)bx, (unsigned)ny), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8,
                      xstride, guard);
   return check_launch("split3");
 }

@@ -72,38 +72,48 @@ __global__ void k_set_cells(unsigned* cells, int n, unsigned bits) {
 // (guard[kGuardLow]: every element of such a chunk has lost bits of its second term).  Integer atomics: order-independent, deterministic.
 __global__ void __launch_bounds__(256) k_split2h(const float* __restrict__ x, uint4* __restrict__ out, long S, int cblocks, int oblocks, int ob0,
                                                  long xstride, const unsigned* __restrict__ cell, unsigned* __restrict__ guard) {
-  const long v = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool active = v < S;
   const unsigned cb_bits = *cell;
   const float sc = h2_scale(cb_bits);
   const int n = blockIdx.y / cblocks, cb = blockIdx.y % cblocks;
-  unsigned m = 0;
-  if (active) {
-    const float* xs = x + (long)n * xstride + (long)cb * 8 * S + v;
-    unsigned short e[8][3];
+  const float* xb = x + (long)n * xstride + (long)cb * 8 * S;
+  const long ob = (long)n * oblocks + ob0 + cb;
+  unsigned n_all = 0, n_low = 0;  // (lane 0 of each wave counts its wave's chunks)
+  // a block walks several 256-voxel tiles (gridDim.x is capped): the guard's counts leave as ONE pair of atomics per block -- one pair per
+  // tile (39 K blocks on two addresses at 64 x 108^3) cost four times the conversion itself
+  for (long v0 = (long)blockIdx.x * 256; v0 < S; v0 += (long)gridDim.x * 256) {
+    const long v = v0 + threadIdx.x;
+    unsigned m = 0;
+    if (v < S) {
+      unsigned short e[8][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = xs[j * S];
-      const unsigned b = __float_as_uint(f) & 0x7fffffffu;
-      if (b < 0x7f800000u && b > m) m = b;
-      h2_split(f * sc, e[j]);
+      for (int j = 0; j < 8; ++j) {
+        const float f = xb[j * S + v];
+        const unsigned b = __float_as_uint(f) & 0x7fffffffu;
+        if (b < 0x7f800000u && b > m) m = b;
+        h2_split(f * sc, e[j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
     }
-    const long ob = (long)n * oblocks + ob0 + cb;
+    if (guard) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned q = (unsigned)__shfl_xor((int)m, o);
+        m = q > m ? q : m;
+      }
+      if (m) {
+        ++n_all;
+        if (cb_bits > kGuardDrop && m < cb_bits - kGuardDrop) ++n_low;
+      }
+    }
   }
   if (!guard) return;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned q = (unsigned)__shfl_xor((int)m, o);
-    m = q > m ? q : m;
-  }
   __shared__ unsigned cnt[2];
   if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0 && m) {
-    atomicAdd(&cnt[kGuardAll], 1u);
-    if (cb_bits > kGuardDrop && m < cb_bits - kGuardDrop) atomicAdd(&cnt[kGuardLow], 1u);
+  if ((threadIdx.x & 63) == 0) {
+    if (n_all) atomicAdd(&cnt[kGuardAll], n_all);
+    if (n_low) atomicAdd(&cnt[kGuardLow], n_low);
   }
   __syncthreads();
   if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(guard + threadIdx.x, cnt[threadIdx.x]);
@@ -261,7 +271,10 @@ int h2_absmax(const float* x, long n, unsigned* cell, hipStream_t s, unsigned* c
 }
 int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, const unsigned* cell, hipStream_t s, unsigned* guard) {
   if (C % 8 || ctot % 8 || c0 % 8) { set_error("split2h: channels must be multiples of 8"); return NC_ERR_SHAPE; }
-  hipLaunchKernelGGL(k_split2h, dim3((unsigned)cdiv(S, 256), (unsigned)(N * C / 8)), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8, xstride,
+  long bx = cdiv(S, 256);
+  const long ny = (long)N * C / 8;
+  if (guard && h2_guard_on() && bx * ny > 4096) bx = cdiv(4096, ny) < bx ? cdiv(4096, ny) : bx;  // (see the kernel: few atomics)
+  hipLaunchKernelGGL(k_split2h, dim3((unsigned)bx, (unsigned)ny), dim3(256), 0, s, x, (uint4*)xs, S, C / 8, ctot / 8, c0 / 8, xstride,
                      cell, h2_guard_on() ? guard : nullptr);
   return check_launch("split2h");
 }

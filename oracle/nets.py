@@ -56,17 +56,20 @@ def _convT(x, sd, name):
     return fn(x, w, sd[name + '.bias'], stride=2)
 
 
-def _block(x, sd, prefix, idxs, norm='instance', training=True):
+def _block(x, sd, prefix, idxs, norm='instance', training=True, acts=None):
     for i in idxs:
         x = _norm_act(_conv(x, sd, '%s.convolution.%d' % (prefix, i), padding=1), sd, '%s.convolution.%d' % (prefix, i + 1), 0.0, norm, training)
+        if acts is not None:  # every norm + ReLU output, keyed by the module path of the norm layer (tests count ReLU / pool decisions on them)
+            acts['%s.convolution.%d' % (prefix, i + 1)] = x
     return x
 
 
 def unet_deconv(sd, x, taps=None, norm='instance', training=True):
-    """networks.py:512-538.  ``taps`` (optional dict) receives the five stage outputs named as in the reference.  norm: 'instance'
+    """networks.py:512-538.  ``taps`` (optional dict) receives the five stage outputs named as in the reference and, when the caller
+    put an 'acts' dict into it, the output of every norm + ReLU layer there.  norm: 'instance'
     (the hot path) or 'batch' (--norm batch; `training` picks batch or running statistics)."""
     pool = F.max_pool3d if x.dim() == 5 else F.max_pool2d
-    kw = dict(norm=norm, training=training)
+    kw = dict(norm=norm, training=training, acts=taps.pop('acts', None) if taps is not None else None)
     conv1 = _block(x, sd, 'double_conv1', (0, 3), **kw)
     conv2 = _block(pool(conv1, 2), sd, 'double_conv2', (0, 3), **kw)
     bottom = _block(pool(conv2, 2), sd, 'bottom_layer', (0, 3, 6), **kw)
@@ -77,6 +80,8 @@ def unet_deconv(sd, x, taps=None, norm='instance', training=True):
     y = _conv(_conv(ex1, sd, 'one_by_one'), sd, 'one_by_one_2')
     if taps is not None:
         taps.update(conv1=conv1, conv2=conv2, conv_bottom=bottom, ex_conv2=ex2, ex_conv1=ex1)
+        if kw['acts'] is not None:
+            taps['acts'] = kw['acts']
     return torch.sigmoid(y)
 
 

@@ -8,8 +8,7 @@ distance, a wrong-by-1 % weight gradient in one layer lands 10-100 x beyond it.
 
 Through ReLU / max-pool an activation within ~1e-7 of zero (or two pool candidates within 1e-7 of each other) takes the other branch
 under another summation order and moves the gradients of everything upstream by a visible amount: the test COUNTS those decisions
-(stage outputs of the layer-by-layer path vs the fp64 run) and requires a handful, and where a flip happened the bound on the
-layers upstream of it is widened by the flip's own size (measured on the fp32 oracle the same way)."""
+(stage outputs of the layer-by-layer path vs the fp64 run) and runs on a seed at which no side has one (round 5: no widened bounds)."""
 import numpy as np
 import pytest
 import torch
@@ -32,17 +31,22 @@ def rel(a, b):
 def _oracle(fn, sd_np, x_np, r_np, dtype, **kw):
     sd = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in sd_np.items()}
     x = torch.from_numpy(x_np).to(dtype).requires_grad_(True)
-    taps = {}
+    taps = {'acts': {}} if fn is onets.unet_deconv else {}
     y = fn(sd, x, **kw) if fn is not onets.unet_deconv else fn(sd, x, taps)
     (y * torch.from_numpy(r_np).to(dtype)).mean().backward()
-    return y.detach(), x.grad, {k: v.grad for k, v in sd.items()}, {k: v.detach() for k, v in taps.items()}
+    acts = taps.pop('acts', {})  # all ten norm + ReLU outputs (the five stage outputs are among them)
+    return y.detach(), x.grad, {k: v.grad for k, v in sd.items()}, {k: v.detach() for k, v in (acts or taps).items()}
 
 
-def _flips(a, ref):
-    """ReLU decisions (zero pattern) that differ between two post-ReLU stage outputs, and 2x2x2 max-pool winners that differ."""
+_POOLED = ('double_conv1.convolution.4', 'double_conv2.convolution.4')  # the two activations a MaxPool3d(2) reads (networks.py:491,494)
+
+
+def _flips(a, ref, key=None):
+    """ReLU decisions (zero pattern) that differ between two norm + ReLU outputs, and -- for the tensors a pool reads (key None: any) -- 2x2x2
+    max-pool winners that differ."""
     relu = int(((a > 0) != (ref > 0)).sum())
     pool = 0
-    if min(a.shape[2:]) >= 2:
+    if min(a.shape[2:]) >= 2 and (key is None or key in _POOLED):
         ia = F.max_pool3d(a.float(), 2, return_indices=True)[1]
         ib = F.max_pool3d(ref.float(), 2, return_indices=True)[1]
         pool = int((ia != ib).sum())
@@ -57,57 +61,82 @@ def _terms():
     lib().nc_set_split_terms(t)
 
 
+_CLEAN = {}
+
+
+def _hook_acts(net, into):
+    for nm, mod in net.named_modules():
+        if isinstance(mod, networks.InstanceNormAct):
+            mod.register_forward_hook(lambda m, i, o, nm=nm: into.__setitem__(nm, o.detach().cpu()))
+
+
+def _clean_case(terms, monkeypatch, size=16):
+    """A (weight seed, input seed) at which NEITHER the fp32 oracle NOR the product under `terms` takes a ReLU / max-pool decision the fp64
+    run does not take: a single such flip moves the gradients of everything upstream by 1e-3 .. 1e-2 (round 4 widened every tensor's bound
+    to the oracle's worst tensor for that reason, which let a 0.9 % error in any one layer pass).  An activation lands within ~1e-7 of zero
+    a few times per evaluation of the 4.6 M activations at 32^3 (1-4 decisions at every seed tried) and a few times in ten at 16^3, where a
+    seed free of flips on all three sides turns up within a few tries; ALL ten norm + ReLU outputs are compared, not only the stage outputs; the decisions are counted on the layer-by-layer path, to which the fused path is bit-identical (tests/test_gpu_nets.py)."""
+    from neuroclear_amd._lib import lib
+    if terms in _CLEAN:
+        return _CLEAN[terms]
+    lib().nc_set_split_terms(terms)
+    monkeypatch.setattr(networks, '_FUSED_GEN', False)
+    spec = S.unet_deconv_spec()
+    tried = []
+    for seed in range(2, 40):
+        sd_np = S.weights_from_seed(spec, seed)
+        x_np = np.random.default_rng(100 + seed).random((1, 1, size, size, size), dtype=np.float32)
+        r_np = np.random.default_rng(200 + seed).random((1, 1, size, size, size), dtype=np.float32)
+        o64 = _oracle(onets.unet_deconv, sd_np, x_np, r_np, torch.float64)
+        o32 = _oracle(onets.unet_deconv, sd_np, x_np, r_np, torch.float32)
+        n32 = sum(sum(_flips(o32[3][k], o64[3][k], k)) for k in o64[3])
+        net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+        net.load_state_dict(S.state_dict_from_seed(spec, seed, DEV))
+        stages = {}
+        _hook_acts(net, stages)
+        net(torch.from_numpy(x_np).to(DEV).requires_grad_(True))  # (the training forward, layer by layer: no_grad is the whole-network inference call)
+        npd = sum(sum(_flips(stages[k], o64[3][k], k)) for k in o64[3])
+        tried.append((seed, n32, npd))
+        if n32 == 0 and npd == 0:
+            _CLEAN[terms] = (seed, sd_np, x_np, r_np, o64, o32)
+            print('terms %d: flip-free seed %d after %s' % (terms, seed, tried))
+            return _CLEAN[terms]
+    raise AssertionError('no flip-free seed among %s' % tried)
+
+
 @pytest.mark.parametrize('terms', [3, 2])
 @pytest.mark.parametrize('fused', [True, False])
 def test_unet_deconv_gradients_against_fp64(fused, terms, monkeypatch, _terms):
-    size, seed = 32, 2
+    """Every weight tensor of unet_deconv within 3 x the fp32 oracle's OWN distance to the fp64 run (+ 2e-5), for the three-term AND the
+    two-term (default) arithmetic alike, on a case where no side flips a ReLU / pool decision (see _clean_case) -- no widening."""
+    size = 16  # (0.6 M activations: a flip-free seed exists within a few tries; at 32^3 every seed has one to four)
+    seed, sd_np, x_np, r_np, (y64, dx64, g64, t64), (y32, dx32, g32, t32) = _clean_case(terms, monkeypatch, size)
     _terms.nc_set_split_terms(terms)   # 3: the three-term bf16 form of the split-operand kernels, 2: the two-term fp16 form (the default)
     monkeypatch.setattr(networks, '_FUSED_GEN', fused)
     spec = S.unet_deconv_spec()
-    sd_np = S.weights_from_seed(spec, seed)
-    x_np = np.random.default_rng(102).random((1, 1, size, size, size), dtype=np.float32)
-    r_np = np.random.default_rng(202).random((1, 1, size, size, size), dtype=np.float32)
-    y64, dx64, g64, t64 = _oracle(onets.unet_deconv, sd_np, x_np, r_np, torch.float64)
-    y32, dx32, g32, t32 = _oracle(onets.unet_deconv, sd_np, x_np, r_np, torch.float32)
     net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
     net.load_state_dict(S.state_dict_from_seed(spec, seed, DEV))
     stages = {}
-    if not fused:  # stage outputs of the layer-by-layer path, named as the oracle's taps
-        for nm, mod in (('conv1', net.double_conv1), ('conv2', net.double_conv2), ('conv_bottom', net.bottom_layer),
-                        ('ex_conv2', net.ex_double_conv2), ('ex_conv1', net.ex_conv1_1)):
-            mod.register_forward_hook(lambda m, i, o, nm=nm: stages.__setitem__(nm, o.detach().cpu()))
+    if not fused:  # every norm + ReLU output of the layer-by-layer path, named as the oracle's taps
+        _hook_acts(net, stages)
     x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
     y = net(x)
     (y * torch.from_numpy(r_np).to(DEV)).mean().backward()
     assert float((y.detach().cpu().double() - y64).abs().max()) < 2e-6
-    # decisions that differ from the fp64 run: the fp32 oracle's, and (layer-by-layer path) the product's
-    f32 = {k: _flips(t32[k], t64[k]) for k in t64}
-    n32 = sum(a + b for a, b in f32.values())
-    print('fp32 oracle flips (relu, pool) per stage:', f32)
     if stages:
-        fp = {k: _flips(stages[k], t64[k]) for k in t64}
-        npd = sum(a + b for a, b in fp.values())
-        print('product flips (relu, pool) per stage:   ', fp)
-        assert npd <= 3 * n32 + 40, (fp, f32)  # a handful among 4.6 M activations: as many as any fp32 evaluation has
+        assert sum(sum(_flips(stages[k], t64[k], k)) for k in t64) == 0
     e32, ep = rel(dx32, dx64), rel(x.grad, dx64)
     print('dx: fp32 oracle %.2e product %.2e' % (e32, ep))
     assert ep <= 3 * e32 + 2e-5
     worst = 0.0
-    # One ReLU decision that falls the other way than in the fp64 run moves a gradient tensor by 1e-3 .. 1e-2 (the fp32 ORACLE has one inside
-    # double_conv1 at this seed: its distances reach 3e-3).  At this seed the three-term form has none and sits at 1-3e-6 for every tensor; the
-    # two-term form has one in the bottom layer (7e-3 there) -- as legitimate as the oracle's.  So: per tensor within 3 x the oracle's own
-    # distance, or, where a decision differs, within 3 x the oracle's WORST tensor (a 1 % error of a whole layer is 1e-2 and still fails).
-    b_worst = max(rel(g32[k], g64[k]) for k, p in net.named_parameters() if p.dim() >= 2)
     for k, p in net.named_parameters():
         if p.dim() < 2:
             continue  # biases in front of InstanceNorm: true gradient 0, both sides hold rounding noise
         a, b = rel(p.grad, g64[k]), rel(g32[k], g64[k])
-        if terms == 2:
-            b = max(b, b_worst)
         print('  %-38s fp32 oracle %.2e  product %.2e' % (k, b, a))
         worst = max(worst, a / max(b, 1e-7))
-        # a correct fp32 gradient sits at the oracle's own distance or below it (measured here: 1e-6 .. 3e-6 for every tensor, the fp32
-        # oracle 2e-6 .. 3e-3 -- torch-CPU fp32 flips a ReLU inside double_conv1 at this seed); a 1 % error in one layer is 1e-2
+        # a correct fp32 gradient sits at the oracle's own distance or below it (1e-6 .. 3e-6 for every tensor); a 1 % error in one layer
+        # is 1e-2, a 0.1 % error 1e-3
         assert a <= 3 * b + 2e-5, (k, a, b)
     print('worst ratio product / fp32 oracle: %.2f' % worst)
 
