@@ -1097,7 +1097,7 @@ int nc_maxpool2_bwd_add(const float* dy, const float* x, const float* skip, floa
 int nc_batchnorm_stats(const float* x, int N, int C, long S, float eps, float momentum, int training, float* mean, float* rstd,
                        float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !mean || !rstd) { set_error("batchnorm_stats: null pointer"); return NC_ERR_ARG; }
-  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_stats: bad shape N=%d C=%d S=%ld", N, C, S); return NC_ERR_SHAPE; }
+  if (N < 1 || C < 1 || S < 1 || C > 65535 || (long)N * C > 0x7fffffffL) { set_error("batchnorm_stats: bad shape N=%d C=%d S=%ld", N, C, S); return NC_ERR_SHAPE; }
   hipStream_t s = (hipStream_t)stream;
   if (!training) {
     if (!running_mean || !running_var) { set_error("batchnorm_stats: evaluation mode needs the running statistics"); return NC_ERR_ARG; }
@@ -1106,7 +1106,11 @@ int nc_batchnorm_stats(const float* x, int N, int C, long S, float eps, float mo
   }
   if (!ws || ws_bytes < nc_instnorm_ws_bytes(N * C, S)) { set_error("batchnorm_stats: workspace too small"); return NC_ERR_WS; }
   const int splits = pick_splits(N * C, S);
-  hipLaunchKernelGGL(k_in_stats, dim3(splits, N * C), dim3(256), 0, s, x, S, splits, (double*)ws);
+  // (N * C is gridDim.y, at most 65535: whole samples per launch -- a 2-D PatchGAN over 148 slices x 512 channels has 75,776 instances)
+  for (long i0 = 0, step = (long)(65535 / C) * C; i0 < (long)N * C; i0 += step) {
+    const int ni = (long)N * C - i0 < step ? (int)((long)N * C - i0) : (int)step;
+    hipLaunchKernelGGL(k_in_stats, dim3(splits, ni), dim3(256), 0, s, x + i0 * S, S, splits, (double*)ws + i0 * splits * 2);
+  }
   hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, N, C, splits, S, eps, momentum, mean, rstd,
                      running_mean, running_var);
   return check_launch("batchnorm_stats");
@@ -1114,10 +1118,13 @@ int nc_batchnorm_stats(const float* x, int N, int C, long S, float eps, float mo
 int nc_batchnorm_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, float* y,
                          int N, int C, long S, void* stream) {
   if (!x || !mean || !rstd || !gamma || !beta || !y) { set_error("batchnorm_act_fwd: null pointer"); return NC_ERR_ARG; }
-  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
+  if (N < 1 || C < 1 || S < 1 || C > 65535 || (long)N * C > 0x7fffffffL) { set_error("batchnorm_act_fwd: bad shape"); return NC_ERR_SHAPE; }
   long bx = cdiv(S, 1024 * 4);
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(k_bn_act_fwd, dim3((unsigned)bx, N * C), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, slope, y, C, S);
+  for (long i0 = 0, step = (long)(65535 / C) * C; i0 < (long)N * C; i0 += step) {  // whole samples per launch (gridDim.y <= 65535)
+    const int ni = (long)N * C - i0 < step ? (int)((long)N * C - i0) : (int)step;
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3((unsigned)bx, ni), dim3(256), 0, (hipStream_t)stream, x + i0 * S, mean, rstd, gamma, beta, slope, y + i0 * S, C, S);
+  }
   return check_launch("batchnorm_act_fwd");
 }
 // dgamma / dbeta: [C] outputs (always computed); coef: 2 C floats of scratch
@@ -1125,15 +1132,24 @@ int nc_batchnorm_act_bwd(const float* dy, const float* x, const float* mean, con
                          float slope, int training, float* dx, float* dgamma, float* dbeta, float* coef, int N, int C, long S, void* ws,
                          size_t ws_bytes, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !coef) { set_error("batchnorm_act_bwd: null pointer"); return NC_ERR_ARG; }
-  if (N < 1 || C < 1 || S < 1 || (long)N * C > 65535) { set_error("batchnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
+  if (N < 1 || C < 1 || S < 1 || C > 65535 || (long)N * C > 0x7fffffffL) { set_error("batchnorm_act_bwd: bad shape"); return NC_ERR_SHAPE; }
   if (!ws || ws_bytes < nc_instnorm_ws_bytes(N * C, S)) { set_error("batchnorm_act_bwd: workspace too small"); return NC_ERR_WS; }
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(N * C, S);
-  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(splits, N * C), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, slope, C, S, splits, (double*)ws);
+  const long NCl = (long)N * C, step = (long)(65535 / C) * C;  // whole samples per launch (gridDim.y <= 65535)
+  for (long i0 = 0; i0 < NCl; i0 += step) {
+    const int ni = NCl - i0 < step ? (int)(NCl - i0) : (int)step;
+    hipLaunchKernelGGL(k_bn_bwd_sums, dim3(splits, ni), dim3(256), 0, s, dy + i0 * S, x + i0 * S, mean, rstd, gamma, beta, slope, C, S, splits,
+                       (double*)ws + i0 * splits * 2);
+  }
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, s, (const double*)ws, N, C, splits, S, dgamma, dbeta, coef);
   long bx = cdiv(S, 1024 * 4);
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)bx, N * C), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, slope, coef, training, dx, C, S);
+  for (long i0 = 0; i0 < NCl; i0 += step) {
+    const int ni = NCl - i0 < step ? (int)(NCl - i0) : (int)step;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)bx, ni), dim3(256), 0, s, dy + i0 * S, x + i0 * S, mean, rstd, gamma, beta, slope, coef, training,
+                       dx + i0 * S, C, S);
+  }
   return check_launch("batchnorm_act_bwd");
 }
 }  // extern "C"

@@ -32,6 +32,8 @@ def main(argv=None):
     if world > 1:
         for o in model.optimizers:
             torch.distributed.broadcast(o.flat, 0)
+        from .util.dist import broadcast_buffers
+        broadcast_buffers(model)  # (--norm batch: running statistics start equal; afterwards rank-local, rank 0's are saved -- util/dist.py)
     total_iters = opt.load_iter + 1 if opt.load_iter > 0 else 0
     loaded = total_iters
     iter_data_time = time.time()

@@ -49,3 +49,19 @@ def p2p_fence(t):
     import torch.distributed as dist
     if t.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'gloo':
         torch.cuda.synchronize(t.device)
+
+
+def broadcast_buffers(model, src=0):
+    """Rank `src`'s module buffers (BatchNorm running statistics under --norm batch, spectral-norm u / v) to every rank, once at setup.
+    During training every rank updates them from its OWN crops (the reference's nn.DataParallel keeps replica 0's, computed over its share of
+    the batch, models/networks.py:132-136 -- the same rule at a different shard size); rank 0's are the ones a checkpoint saves.  They do not
+    enter the gradient exchange.  Integer buffers (num_batches_tracked: int64) travel as they are -- RCCL has Long."""
+    import torch.distributed as dist
+    if not exchange_active():
+        return
+    for name in getattr(model, 'model_names', []):
+        net = getattr(model, 'net' + name, None)
+        if net is None:
+            continue
+        for b in net.buffers():
+            dist.broadcast(b, src)

@@ -830,3 +830,27 @@ def test_batch_norm_networks(golden_dir, tag):
     np.testing.assert_allclose(ye.cpu().numpy(), g['y_eval'], atol=2e-5, rtol=5e-4)
     with pytest.raises(NotImplementedError):
         networks.get_norm_layer('layer', 3)
+
+
+def test_batch_norm_more_than_65535_instances():
+    """--norm batch on a 2-D PatchGAN over a slice batch (148 slices x 512 channels = 75,776 (sample, channel) instances: more than one
+    launch's gridDim.y): BatchNormAct forward + backward against F.batch_norm + leaky_relu in fp64 (models/networks.py:30-31)."""
+    import torch.nn.functional as F
+    N, C, H, W = 148, 512, 5, 6
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = (torch.randn(N, C, H, W, device=DEV, generator=g) * 2 + 0.5).requires_grad_(True)
+    m = networks.BatchNormAct(C, slope=0.2, dimension=2).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(torch.rand(C, device=DEV, generator=g) + 0.5)
+        m.bias.copy_(torch.randn(C, device=DEV, generator=g) * 0.1)
+    m.train()
+    y = m(x)
+    r = torch.randn(y.shape, device=DEV, generator=g)
+    (y * r).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = m.weight.detach().double().requires_grad_(True), m.bias.detach().double().requires_grad_(True)
+    yd = F.leaky_relu(F.batch_norm(xd, None, None, wd, bd, True, 0.1, 1e-5), 0.2)
+    (yd * r.double()).sum().backward()
+    assert float((y.detach().double() - yd.detach()).abs().max()) < 2e-5
+    for a, b in ((x.grad, xd.grad), (m.weight.grad, wd.grad), (m.bias.grad, bd.grad)):
+        assert float((a.double() - b).norm() / b.norm()) < 1e-5
