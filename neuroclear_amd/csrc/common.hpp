@@ -217,7 +217,11 @@ void s3x_set_terms(int t);
 int s3x_get_terms();
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
                 int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s,
-                const unsigned* guard = nullptr);
+                const unsigned* guard = nullptr, float* stats_part = nullptr);
+// InstanceNorm statistics from the convolution's own epilogue (conv_s3x.hip, template parameter ST): stats_part >= s3x_stats_bytes
+size_t s3x_stats_bytes(int N, int D, int H, int W, int Kout, int KS);
+int s3x_stats_finalize(const float* stats_part, const float* bias, int N, int D, int H, int W, int Kout, int KS, float eps, float* mean, float* rstd,
+                       hipStream_t s);
 // h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
 // an H2 tensor of `elems` elements = elems * 4 bytes of units + (at this byte offset) 256 bytes of cells: [0] the cell of the channels' first
 // half, [1] of the second half (a concatenation converted in two parts; equal to [0] otherwise) -- inside the elems * 6 bytes of an S3 tensor

@@ -59,6 +59,9 @@ constexpr int kLdsMax = 160 * 1024;
 #ifndef NC_S3X_DMAW
 #define NC_S3X_DMAW 4
 #endif
+#ifndef NC_S3X_BDEPTH
+#define NC_S3X_BDEPTH 1  // column blocks the B-fragment reads run ahead of the MFMAs that use them (experiment: 2)
+#endif
 // Waves that issue the LDS-DMA pieces of a brick: the first kDmaWaves of the 8.  4 = one wave of each SIMD pair (waves w and w + 4
 // share a SIMD): issuing ~10 pieces keeps a wave away from the matrix pipe for ~1,000 cycles, which its partner -- with no pieces of
 // its own -- fills with MFMAs; with all 8 issuing, both partners are away at the same moment right behind the barrier.
@@ -99,7 +102,11 @@ __global__ void __launch_bounds__(256) k_pack_w_s3x(const float* __restrict__ w,
   unsigned short t[3] = {0, 0, 0};
   if (bi < NB) {
     const int chunk = bi / KS, dz = bi % KS;
+#ifdef NC_S3X_B128
+    const int jj = j;  // (experiment: one 16-byte read per B fragment, natural channel order)
+#else
     const int jj = (g & 1) ? ((j + 4) & 7) : j;
+#endif
     const long co = cot * 64 + half * 32 + rb * 16 + m, ci = chunk * 8 + jj;
     const int tap = dz * T2 + tp;
     const float v = w[co * so + ci * si + (flip ? T3 - 1 - tap : tap)];
@@ -155,6 +162,7 @@ struct XParams {
   const unsigned *amax_x, *amax_w;  // NT = 2: the cells of the input and of the weights (the result is scaled back by 2^-(kx + kw))
   long long* dbg;      // NC_S3X_STAMP builds: s_memtime stamps of workgroup 0 / wave 0 (timing experiments only)
   const unsigned* guard;  // nullable: the range guard's words (common.hpp); the kernel leaves at once unless the flag says it is this form's turn
+  float2* stats;       // ST launches: [tile of this launch][wave][32 channels] (sum, sum of squares) of the tile's bias-free outputs (see s3x_stats_finalize)
 };
 
 struct XTile {
@@ -193,7 +201,12 @@ __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
   return o;
 }
 
-template <int KS, int NCB, int NT>
+// ST (two-term launches of the inference forward): the epilogue also leaves, per (tile, wave), the sum and the sum of squares of the wave's
+// 32 channels over the tile's valid positions -- of the outputs WITHOUT their bias (the variance does not see it, the mean gets it back;
+// sums of bias-free convolution outputs cancel far less) -- so that InstanceNorm needs no pass of its own over the raw output
+// (k_in_stats read 2.9 GB per 140^3 cube: 0.6 of 11.1 ms).  fp32 within a tile (128 values per channel: 8 per lane, then a butterfly over the
+// 16 lanes of a column block row), fp64 across tiles in s3x_stats_finalize (fixed order: deterministic).
+template <int KS, int NCB, int NT, bool ST = false>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
   constexpr int PAD = KS / 2, T2 = KS * KS, PT = 64 * NCB;
@@ -307,7 +320,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   };
 
   // ---- B fragments: unit (slot, term, position + tap) of the ring, read as two 8-byte halves (odd lane groups: upper first)
+#ifdef NC_S3X_B128
+  const unsigned lane_b = (unsigned)((pg * NCB * 16 + m16) * 16);
+#else
   const unsigned lane_b = (unsigned)(((pg * NCB * 16 + m16) * 16) + (g & 1) * 8);
+#endif
   const unsigned term_b = (unsigned)p.UB * 16;
   const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)lds_raw;
   struct BAddr { unsigned lo[NT], hi[NT]; };  // per term: address of the half read first / second (column block 0)
@@ -320,10 +337,15 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   auto read_b = [&](u32x4 (&B)[NT], const BAddr& a, int cb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#ifdef NC_S3X_B128
+      typedef const volatile __attribute__((address_space(3))) u32x4* lds128_t;
+      B[t] = *(lds128_t)(a.lo[t] + cb * 256);
+#else
       u64x2 v;
       v.x = *(lds64_t)(a.lo[t] + cb * 256);  // volatile: two ds_read_b64, never one ds_read2_b64
       v.y = *(lds64_t)(a.hi[t] + cb * 256);
       B[t] = __builtin_bit_cast(u32x4, v);
+#endif
     }
   };
 
@@ -354,6 +376,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   float oscx = 1.f, oscw = 1.f;
   if constexpr (NT == 2) { const float2 f = h2_unscale2(*p.amax_x, *p.amax_w); oscx = f.x; oscw = f.y; }
   u32x4 bv[2];
+  float st_s[2][4], st_q[2][4];  // ST: this lane's share of the sums of the tile whose results are being stored
   auto load_bias = [&](const XTile& t) __attribute__((always_inline)) {
     const int bo = (t.cot * 64 + half * 32 + 4 * g) * 4;
 #pragma unroll
@@ -378,9 +401,49 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         const unsigned bu = bv[rb][e];  // (a bit_cast straight from the vector element reads element 0)
         const float v = NT == 2 ? tot[rb][cb][e] * oscx * oscw + __uint_as_float(bu) : tot[rb][cb][e] + __uint_as_float(bu);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, ok ? vo0 + (unsigned)(e * S * 4) : kOut, 0, 0);
+        if constexpr (ST) {
+          const float r = ok ? tot[rb][cb][e] * oscx * oscw : 0.f;
+          st_s[rb][e] += r;
+          st_q[rb][e] = __builtin_fmaf(r, r, st_q[rb][e]);
+        }
         tot[rb][cb][e] = 0.f;
       }
     }
+  };
+
+  // ST: the tile's sums leave as ONE 8-byte store per lane (lanes m16 < 8 of every lane group: channel half*32 + 4g + 16 (m16 / 4) + m16 % 4;
+  // the others store out of range) -- a fixed number of store instructions, counted by the waits like the result stores
+  auto stats_zero = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st_s[rb][e] = 0.f; st_q[rb][e] = 0.f; }
+  };
+  auto stats_flush = [&](int tidx) __attribute__((always_inline)) {
+    float ss = 0.f, qq = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = st_s[rb][e], b = st_q[rb][e];
+        // butterfly over the 16 lanes of the row: xor 1, xor 2 (quad permutes), then the mirrors (values are already uniform inside the
+        // quads / the halves they swap)
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, false));
+        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xf, 0xf, false));
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xf, 0xf, false));
+        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, false));
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xf, 0xf, false));
+        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x141, 0xf, 0xf, false));
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x140, 0xf, 0xf, false));
+        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x140, 0xf, 0xf, false));
+        if (m16 == rb * 4 + e) { ss = a; qq = b; }
+      }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, 0x7fffffff, 0x00020000);
+    const unsigned off = m16 < 8 ? (unsigned)((((unsigned)tidx * kWaves + wave) * 32 + g * 8 + m16) * 8) : kOut;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 pk;
+    pk.x = __builtin_bit_cast(unsigned, ss); pk.y = __builtin_bit_cast(unsigned, qq);
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rs, off, 0, 0);
   };
 
 #ifdef NC_S3X_PRIO
@@ -399,6 +462,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       for (int e = 0; e < 4; ++e) { acc[rb][cb][e] = 0.f; tot[rb][cb][e] = 0.f; }
   bool have_prev = false;
   XTile prv = cur;
+  int tprv = tcur;  // index of `prv` among this launch's tiles (ST: its slot in p.stats)
 
 #ifdef NC_S3X_STAMP
   if (p.dbg && tid == 0) p.dbg[4000 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();  // per-workgroup start / end, 100 MHz
@@ -438,7 +502,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
     };
     BAddr vo = b_addr(b_off());
+#if NC_S3X_BDEPTH == 2
+    u32x4 B[3][NT];
+#else
     u32x4 B[2][NT];
+#endif
     int since = 0;
 
     // One k-step.  Ac = this step's A fragments (requested one step ago; step 0: during the last step of the previous tile), An
@@ -456,7 +524,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       load_a(An, last ? wt_next : wt + (s + 1) * (2 * NT * 1024));  // (last step: A of step 0 of the next tile, or a dummy request)
       constexpr int PPH = PH >= 1 && PH < kStoreSteps ? PH - 1 : kStoreSteps - 1;  // the step before this one, if it stored
       constexpr int PPairs = kPairs - PPH * kPairsPerStep < kPairsPerStep ? kPairs - PPH * kPairsPerStep : kPairsPerStep;
-      wait_a(Ac, std::integral_constant<int, 4 * PPairs>{}, have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));
+      wait_a(Ac, std::integral_constant<int, 4 * PPairs + ((ST && PPH == kStoreSteps - 1) ? 1 : 0)>{},
+             have_prev && ((PH >= 1 && PH < kStoreSteps) || s == kStoreSteps));
       // brick `na` is first used by k-step s + 1 (brick 0: by step 0): it is complete in LDS for THIS wave's pieces; the barrier
       // makes that true for everybody's, and says everybody is done with brick na - 2 (last tap consumed in k-step s - 1 at the
       // latest, KS^2 > 6), whose slot the brick after `na` is requested into
@@ -479,20 +548,36 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       if constexpr (PH < kStoreSteps) {
         if (have_prev) {
           asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
+          if constexpr (ST && PH == 0) stats_zero();
           store_pairs(prv, PH * kPairsPerStep, (PH + 1) * kPairsPerStep);
+          if constexpr (ST && PH == kStoreSteps - 1) stats_flush(tprv);
         }
       }
+#if NC_S3X_BDEPTH == 2
+      (void)PAR;
+      if constexpr (PH == 0) { read_b(B[0], vo, 0); read_b(B[1], vo, 1); }
+#else
       if constexpr (PH == 0) read_b(B[PAR], vo, 0);
+#endif
       // next k-step's tap state
       tpl += 4;
       if (tpl >= T2) { tpl -= T2; sl = sl == 2 ? 0 : sl + 1; }
       const BAddr nvo = b_addr(b_off());
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
+#if NC_S3X_BDEPTH == 2
+        // fragments requested TWO column blocks ahead (three register sets in rotation; the sets of the next step's first two blocks are
+        // renamed to B[0], B[1] at the end of the step)
+        u32x4(&Bc)[NT] = B[cb % 3];
+        u32x4(&Bn)[NT] = B[(cb + 2) % 3];
+        if (cb + 2 < NCB) read_b(Bn, vo, cb + 2);
+        else if (!last) read_b(Bn, nvo, cb + 2 - NCB);
+#else
         u32x4(&Bc)[NT] = B[(cb + PAR) & 1];
         u32x4(&Bn)[NT] = B[(cb + PAR + 1) & 1];
         if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
         else if (!last) read_b(Bn, nvo, 0);
+#endif
         // six (NT = 2: three) products per (row block, column block), smallest first: (term of A, term of B)
         constexpr int NP = NT == 3 ? 6 : 3;
         constexpr int TA[6] = {NT - 1, NT == 3 ? 1 : 0, 0, 1, 0, 0};
@@ -515,13 +600,27 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           }
         } else {
+#ifdef NC_S3X_B128
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#else
           // the 4 reads of the next column block spread over this one's 6 MFMAs
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
         }
       }
+#if NC_S3X_BDEPTH == 2
+      if constexpr (NCB % 3 != 0) {
+        u32x4 t0[NT], t1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { t0[t] = B[NCB % 3][t]; t1[t] = B[(NCB + 1) % 3][t]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { B[0][t] = t0[t]; B[1][t] = t1[t]; }
+      }
+#endif
       vo = nvo;
       if (++since == p.flush || last) {
         since = 0;
@@ -550,6 +649,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       STAMP();
     }
     prv = cur;
+    tprv = tcur;
     have_prev = true;
     if (!more_tiles) break;
     ring = (ring + NB) % 3;
@@ -558,7 +658,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   }
   // the last tile's results (and the dummy request of its last step)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1])::"memory");
+  if constexpr (ST) stats_zero();
   store_pairs(prv, 0, kPairs);
+  if constexpr (ST) stats_flush(tprv);
 #ifdef NC_S3X_STAMP
   if (p.dbg && tid == 0) p.dbg[4001 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -622,21 +724,75 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
   return best;
 }
 
-template <int KS, int NCB, int NT>
+template <int KS, int NCB, int NT, bool ST = false>
 int launch_x(const XParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_s3x<KS, NCB, NT>;
+  auto kern = k_conv_s3x<KS, NCB, NT, ST>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
 }
 
-template <int KS, int NT = 3>
+template <int KS, int NT = 3, bool ST = false>
 int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
-  if (NCB == 8) return launch_x<KS, 8, NT>(p, lds, s);
-  if (NCB == 7) return launch_x<KS, 7, NT>(p, lds, s);
-  if (NCB == 6) return launch_x<KS, 6, NT>(p, lds, s);
-  if (NCB == 4) return launch_x<KS, 4, NT>(p, lds, s);
-  return launch_x<KS, 2, NT>(p, lds, s);
+  if (NCB == 8) return launch_x<KS, 8, NT, ST>(p, lds, s);
+  if (NCB == 7) return launch_x<KS, 7, NT, ST>(p, lds, s);
+  if (NCB == 6) return launch_x<KS, 6, NT, ST>(p, lds, s);
+  if (NCB == 4) return launch_x<KS, 4, NT, ST>(p, lds, s);
+  return launch_x<KS, 2, NT, ST>(p, lds, s);
+}
+
+// ---- InstanceNorm statistics from the ST epilogue: per (sample, channel) the partial sums of every (tile, wave) that holds the channel, in
+// tile order, in fp64.  One workgroup per (channel, sample).
+struct XStatsPlan {
+  int N, K, KT, TPP, D, HP;
+  long full, main_count;   // main tiles in whole rounds / tiles of the first launch (full, or all when the left-over tiles are whole tiles)
+  int fsub, PTsub;         // second launch: sub-tiles per main tile, positions per sub-tile
+};
+__global__ void __launch_bounds__(256) k_s3x_stats_finalize(const float2* __restrict__ part, XStatsPlan pl, const float* __restrict__ bias, long S,
+                                                            float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int cot = c / 64, half = (c % 64) / 32, j32 = c % 32;
+  // lane (g, m16 < 8) of a wave holds channel half*32 + 4g + 16 (m16 / 4) + m16 % 4
+  const int g = (j32 % 16) / 4, m = (j32 / 16) * 4 + j32 % 4;
+  const long per_n = (long)pl.TPP * pl.D;
+  double s = 0.0, q = 0.0;
+  // record (tile index u of this (n, cot), position group pg): 4 per main tile, 4 * fsub per left-over tile -- walked in a fixed order
+  const long nrec = per_n * 4;
+  for (long r = threadIdx.x; r < nrec; r += 256) {
+    const long u = r >> 2;
+    const int pg = (int)(r & 3);
+    const long t = ((long)n * per_n + u) * pl.KT + cot;  // main tile index (x_decode: output-channel tile fastest)
+    if (t < pl.main_count) {
+      const float2 v = part[((t * kWaves) + pg * 2 + half) * 32 + g * 8 + m];
+      s += (double)v.x; q += (double)v.y;
+    } else {
+      // the tile's in-plane index, as x_decode orders it (groups of kXGroup neighbours x planes)
+      const int full_g = (pl.TPP / kXGroup) * kXGroup * pl.D;
+      int tp;
+      if (u < full_g) { const long grp = u / (kXGroup * pl.D), rem = u - grp * (kXGroup * pl.D); tp = (int)(grp * kXGroup + (rem % kXGroup)); }
+      else { const int L = pl.TPP % kXGroup; const long v2 = u - full_g; tp = (pl.TPP / kXGroup) * kXGroup + (int)(v2 % L); }
+      for (int sub = 0; sub < pl.fsub; ++sub) {
+        if ((long)(tp * pl.fsub + sub) * pl.PTsub >= pl.HP) continue;  // a sub-tile that starts beyond the plane was never run
+        const long ti = pl.main_count + (t - pl.full) * pl.fsub + sub;
+        const float2 v = part[((ti * kWaves) + pg * 2 + half) * 32 + g * 8 + m];
+        s += (double)v.x; q += (double)v.y;
+      }
+    }
+  }
+  __shared__ double rs[256], rq[256];
+  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m0 = rs[0] / (double)S;
+    double var = rq[0] / (double)S - m0 * m0;
+    if (var < 0.0) var = 0.0;
+    mean[(long)n * pl.K + c] = (float)(m0 + (bias ? (double)bias[c] : 0.0));
+    rstd[(long)n * pl.K + c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 }  // namespace
@@ -668,10 +824,11 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
 // wp_ws >= s3x_packed_bytes(.., 2).
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
                 int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s,
-                const unsigned* guard) {
+                const unsigned* guard, float* stats_part) {
   const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
   if (!pl.ok) { set_error("conv_s3x_h2: shape not covered"); return NC_ERR_SHAPE; }
   if (split_c < Cin && (flip || !cell_b || split_c % 8)) { set_error("conv_s3x_h2: scale groups only for the forward weight layout"); return NC_ERR_ARG; }
+  if (stats_part && KS != 3) { set_error("conv_s3x_h2: epilogue statistics exist for the 3^3 layers only (the layers in front of an InstanceNorm)"); return NC_ERR_ARG; }
   const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4, T3 = KS * KS * KS;
   if (int e = h2_zero_cells(wcell, 1, s)) return e;
   const long nw = (long)Kout * Cin * T3;
@@ -694,16 +851,45 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   if (pl.full || one) {
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
     p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
-    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s);
+    p.stats = (float2*)stats_part;
+    const int e = stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s))
+                             : (KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s));
     if (e) return e;
   }
   if (pl.rem && !one) {
     p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
     p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
-    const int e = KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s);
+    p.stats = stats_part ? (float2*)stats_part + pl.full * kWaves * 32 : nullptr;
+    const int e = stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)
+                                        : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s))
+                             : (KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)
+                                        : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s));
     if (e) return e;
   }
   return NC_OK;
+}
+
+// ST epilogue (see k_conv_s3x): bytes of the partial-sum records of one two-term launch pair, and the pass that turns them into mean / rstd
+// (mean gets the bias back: the records are sums of bias-free outputs).  The geometry is recomputed from the same planner the launch used.
+size_t s3x_stats_bytes(int N, int D, int H, int W, int Kout, int KS) {
+  const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
+  if (!pl.ok) return 0;
+  const bool one = pl.rem && pl.fsub == 1;
+  const long recs = pl.full + (one ? pl.rem : pl.rem * pl.fsub);
+  return (size_t)recs * kWaves * 32 * sizeof(float2);
+}
+int s3x_stats_finalize(const float* stats_part, const float* bias, int N, int D, int H, int W, int Kout, int KS, float eps, float* mean, float* rstd,
+                       hipStream_t s) {
+  const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
+  if (!pl.ok || !stats_part) { set_error("s3x_stats_finalize: shape not covered"); return NC_ERR_SHAPE; }
+  const bool one = pl.rem && pl.fsub == 1;
+  XStatsPlan sp{};
+  sp.N = N; sp.K = Kout; sp.KT = Kout / 64; sp.TPP = pl.TPP; sp.D = D; sp.HP = pl.HP;
+  sp.full = pl.full; sp.main_count = pl.full + (one ? pl.rem : 0);
+  sp.fsub = one ? 1 : pl.fsub; sp.PTsub = 64 * pl.NCB / (one ? 1 : pl.fsub);
+  hipLaunchKernelGGL(k_s3x_stats_finalize, dim3((unsigned)Kout, (unsigned)N), dim3(256), 0, s, (const float2*)stats_part, sp, bias,
+                     (long)D * H * W, eps, mean, rstd);
+  return check_launch("s3x_stats_finalize");
 }
 
 // xs: S3 input; wp_ws: >= s3x_packed_bytes scratch for the packed weights
