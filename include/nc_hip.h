@@ -409,14 +409,20 @@ int nc_get_split_terms(void);
 /* The RANGE GUARD of the two-term form (round 5; csrc/h2.hip, csrc/common.hpp): wherever a call converts an fp32 operand ITSELF with a measured
  * power of two -- nc_conv_fwd / _dgrad / _wgrad / _bwd and every dY of the whole-network backward calls that arrives as fp32 -- the conversion
  * pass also counts the CHUNKS (64 voxels x 8 channels) whose largest magnitude lies below 2^-17 of the tensor's; when more than 1/64 of the
- * non-zero chunks do (a region of the volume far below an outlier elsewhere: the one case the two-term form degrades, see above), THAT CALL
- * runs on the exact three-term kernels instead.  The decision is taken on the device (no host synchronisation): both kernel families are
- * launched and the one whose turn it is not leaves at its first instruction.  Operands whose power of two is a bound by construction
- * (InstanceNorm outputs and the norm backward's results) are not measured and need no guard; a measured operand that is written into a
- * caller-owned buffer for later calls (the two activations deep_linear_gen keeps for its weight gradients) is counted but cannot switch.
- * nc_set_h2_guard(0) / NC_H2_GUARD=0: off (round-4 behaviour).  nc_h2_guard_stats(out, reset): out[0] = tensors measured, out[1] = calls that
- * fell back to three terms, out[2] = flagged tensors that could not switch, out[3] = the largest share of low chunks seen, in parts per
- * million; host-visible counters, readable at any time without synchronising (they trail the device by whatever is still queued). */
+ * non-zero chunks do (a region of the volume or a block of channels far below the rest: the one case the two-term form degrades, see above),
+ * THAT CALL runs on the exact three-term kernels instead.  The decision is taken on the device (no host synchronisation): both kernel
+ * families are launched and the one whose turn it is not leaves at its first instruction.  Modes (nc_set_h2_guard; NC_H2_GUARD at load
+ * time): 0 off (round-4 behaviour); 1 (default): the in-call fallback in the per-layer entry points (nc_conv_fwd / _dgrad / _wgrad / _bwd);
+ * INSIDE the whole-network calls (nc_unet_deconv_*, nc_deep_linear_*) every data-derived power of two is checked the same way -- fp32 dY
+ * tensors, the dY tensors the InstanceNorm backward writes in two-term form itself (power of two from the tensor's own per-instance maxima),
+ * the activations deep_linear_gen keeps -- but a flagged tensor is only COUNTED (the fallback would cost the training step ~65 near-empty
+ * launches, 0.5 ms of 35, for an event InstanceNorm networks do not produce); 2: in-call fallback everywhere it exists (everything but the
+ * kept activations of deep_linear_gen).  Operands whose power of two is a bound by construction (InstanceNorm
+ * outputs, ConvTranspose outputs) and WEIGHTS (one measured power of two per weight tensor: assumed well-conditioned, as any initialisation
+ * and training of this path leaves them) are not guarded.  nc_h2_guard_stats(out, reset): out[0] = tensors measured, out[1] = calls that fell
+ * back to three terms, out[2] = flagged tensors that could not switch (the Python models go to nc_set_split_terms(3) when they see one,
+ * models/base_model.py), out[3] = the largest share of low chunks seen, in parts per million; host-visible counters, readable at any time
+ * without synchronising (they trail the device by whatever is still queued). */
 void nc_set_h2_guard(int on);
 int nc_get_h2_guard(void);
 int nc_h2_guard_stats(unsigned long long* out4, int reset);

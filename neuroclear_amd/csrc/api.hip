@@ -157,7 +157,7 @@ int nc_get_conv_split(void) { return g_split; }
 void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
 int nc_get_split_terms(void) { return s3x_get_terms(); }
 void nc_set_h2_guard(int on) { h2_guard_set(on); }
-int nc_get_h2_guard(void) { return h2_guard_on() ? 1 : 0; }
+int nc_get_h2_guard(void) { return h2_guard_mode(); }
 int nc_h2_guard_stats(unsigned long long* out4, int reset) {
   if (!out4) { set_error("h2_guard_stats: null pointer"); return NC_ERR_ARG; }
   return h2_guard_read(out4, reset);
@@ -442,7 +442,7 @@ bool conv_bwd_pre_supported(int N, int C, int D, int H, int W, int K, int ks, bo
 // data (dx nullable) + weight gradient with dY ALREADY in S3 form at the start of ws (where conv_bwd_s3's conversion phase puts it);
 // xs (nullable): the layer's input in S3 form, else it is converted from x
 int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, float* dw, int N, int C, int D, int H, int W, int K, int ks,
-                 void* ws, size_t ws_bytes, void* stream) {
+                 void* ws, size_t ws_bytes, void* stream, bool dy_guarded) {
   ConvDims d;
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bwd_pre_supported(N, C, D, H, W, K, ks, dx != nullptr, ws_bytes) || !make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2)) {
@@ -452,10 +452,10 @@ int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, floa
   if ((!x && !xs) || !w || !dw || !ws) { set_error("conv_bwd_pre: null pointer"); return NC_ERR_ARG; }
   if (dx) {
     ProfScope ps(1, 9, d, 0, s);
-    if (int e = conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 1)) return e;
+    if (int e = conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 1, nullptr, dy_guarded)) return e;
   }
   ProfScope ps(2, 9, d, 0, s);
-  return conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 2, xs);
+  return conv_bwd_s3(x, nullptr, w, dx, dw, d, ws, ws_bytes, s, 2, xs, dy_guarded);
 }
 
 int conv_bwd_keep(const float* x, const void* xs, const float* dy, const float* w, float* dx, float* dw, int N, int C, int D, int H,
@@ -574,6 +574,7 @@ size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2) {
 
 int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int S0, int S1, int S2, void* ws,
                        size_t ws_bytes, void* stream) {
+  NetworkScope net_scope;
   if (!params || !x || !y) { set_error("unet_deconv_fwd: null pointer"); return NC_ERR_ARG; }
   if (N < 1 || S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) {
     set_error("unet_deconv_fwd: every edge must be a positive multiple of 4 (got %d,%d,%d): MaxPool3d floors and the "

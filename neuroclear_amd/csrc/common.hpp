@@ -191,6 +191,10 @@ int split3_into(const float* x, long xstride, void* xs, int N, int C, long S, in
 bool conv_layer_h2(const ConvDims& d);
 // the explicit S3 entry points (nc_conv_*_split, operands from nc_to_s3) are three-term by definition, whatever nc_set_split_terms says
 struct ForceThreeTerm { ForceThreeTerm(); ~ForceThreeTerm(); };
+// RAII mark of a whole-network call (gen_nets.hip, api.hip): inside one, guard mode 1 COUNTS a flagged measured tensor instead of launching the
+// three-term kernels beside the two-term ones (h2_guard_can_flip) -- ~65 near-empty launches per training step otherwise
+struct NetworkScope { NetworkScope(); ~NetworkScope(); };
+bool h2_guard_can_flip();  // mode 2, or mode 1 outside a whole-network call
 int operand_into(const ConvDims& d, const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
 int act_operand(const ConvDims& d, const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C,
                 long S, int ctot, int c0, hipStream_t s);
@@ -201,7 +205,7 @@ int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, 
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 size_t s3_bwd_ws_bytes(const ConvDims& d);
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, int phase, const void* xs = nullptr);
+                hipStream_t s, int phase, const void* xs = nullptr, bool dy_guarded = false);
 // api.hip: forward / backward of one layer for the whole-network training calls.  conv_fwd_keep: nc_conv_fwd; when the layer runs
 // on the split-operand kernels its converted input is written to xs_keep and *kept set.  conv_bwd_keep: nc_conv_bwd with that
 // tensor handed back (xs NULL: converted again).
@@ -230,7 +234,10 @@ inline unsigned* h2_cells_of(const void* t, size_t elems) { return (unsigned*)((
 int instnorm_relu_tail_sigmoid(const float* x, const float* mean, const float* rstd, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* y, int C, long S, hipStream_t s);
 int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
-                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream);
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream, unsigned* guard = nullptr);
+// conv_split.hip: where conv_bwd_s3 keeps the range guard's words of the dY operand at the head of its workspace `ws` (behind the operand's
+// S3 capacity) -- a producer that writes dY there itself (the norm backward) counts into them and conv_bwd_pre is told so (dy_guarded)
+unsigned* conv_bwd_guard_words(void* ws, int N, int K, long S);
 int maxpool2_h2(const void* in, void* out, int N, int C, int ctot, int D, int H, int W, hipStream_t s);
 int h2_zero_cells(unsigned* cells, int n, hipStream_t s);
 int h2_set_cell(unsigned* cell, float bound, hipStream_t s);
@@ -257,10 +264,11 @@ __device__ __forceinline__ bool guard_skip(const unsigned* guard, int want) {  /
 __device__ bool guard_skip(const unsigned* guard, int want);
 #endif
 bool h2_guard_on();
+int h2_guard_mode();  // 0 off; 1 (default): in-call fallback in the per-layer entry points, whole-network calls count only; 2: in-call fallback everywhere
 void h2_guard_set(int on);
 int h2_guard_read(unsigned long long* out4, int reset);
 int h2_guard_zero(unsigned* g, hipStream_t s, int nwords = 8);
-int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s);
+int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s, unsigned long long total_a = 0);
 int h2_to_s3_if(const void* xh, void* xs, int N, int C, long S, const unsigned* cells, const unsigned* guard, hipStream_t s);
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
                 int c0, float bound, unsigned* cell, unsigned* cell2, hipStream_t s);
@@ -271,7 +279,7 @@ int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, in
                  size_t ws_bytes, void* stream);
 bool conv_bwd_pre_supported(int N, int C, int D, int H, int W, int K, int ks, bool want_dx, size_t ws_bytes);
 int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, float* dw, int N, int C, int D, int H, int W, int K, int ks,
-                 void* ws, size_t ws_bytes, void* stream);
+                 void* ws, size_t ws_bytes, void* stream, bool dy_guarded = false);
 // norm_act.hip: InstanceNorm + activation backward with dx written in S3 form only
 bool instnorm_bwd_s3_supported(int N, int C, long S);
 int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,

@@ -512,7 +512,7 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
     const bool internal = !xs_pre && !xs_keep;
     const size_t p2 = s3x_packed_bytes(Cin, Kout, KS, 2), p3 = s3x_packed_bytes(Cin, Kout, KS, 3);
     const size_t xb6 = align256(ex * 6), xb4 = h2_cells_offset(ex) + 256;
-    bool dual = guard_pre || (internal && x && h2_guard_on() && wsb >= xb6 + 256 + p3 + 256);
+    bool dual = guard_pre || (internal && x && h2_guard_can_flip() && wsb >= xb6 + 256 + p3 + 256);
     if (guard_pre && wsb < 256 + p3 + 256) { set_error("conv_s3 (two-term, guarded operand): workspace too small"); return NC_ERR_WS; }
     const size_t xb = !internal ? 0 : dual ? xb6 : xb4;
     if (!ws || wsb < xb + 256 + p2 + 256) { set_error("conv_s3 (two-term): workspace too small"); return NC_ERR_WS; }
@@ -1321,7 +1321,10 @@ int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* d
   const bool y_copy = dys_pre && !dy_guard;                  // an H2 tensor we may not overwrite: its S3 form goes into the workspace
   const size_t xb6 = align256(ex * 6), yb6 = y_in_place ? 0 : align256(ey * 6);
   const size_t pbmax = pb2 > pb3 ? pb2 : pb3;
-  bool dual = (dy_guard || (measured && h2_guard_on())) && pb3 && wsb >= xb6 + yb6 + 256 + pbmax && (y_in_place ? dy != nullptr : true);
+  // (a guarded dY without its fp32 source -- written by the norm backward -- cannot be converted again here: then only ITS decision counts,
+  // and an x measured in this call is counted without a switch)
+  const bool y_fixed = y_in_place && !dy;
+  bool dual = (dy_guard || (measured && h2_guard_can_flip())) && pb3 && wsb >= xb6 + yb6 + 256 + pbmax;
   if (dy_guard && !dual) { set_error("wgrad_s3 (two-term, guarded dY): workspace too small"); return NC_ERR_WS; }
   (void)y_copy;
   const size_t xb = dual ? xb6 : (xs_pre ? 0 : h2_cells_offset(ex) + 256);
@@ -1351,7 +1354,7 @@ int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* d
     if (int e = split2h_into(dy, (long)d.K * S, dys, d.N, d.K, S, d.K, 0, yc, s, gy)) return e;
   }
   if (measured || dy_guard)
-    if (int e = h2_guard_decide(gx, gy, dy_guard, call + kGuardFlag, dual, s)) return e;
+    if (int e = h2_guard_decide(gx, gy, dy_guard, call + kGuardFlag, dual && !y_fixed, s)) return e;
   if (int e = ws_core(2, xs, dys, xc, yc, dw, d, part, s, dual ? call : nullptr)) return e;
   if (!dual) return NC_OK;
   // the flagged call: both operands as S3 tensors
@@ -1360,7 +1363,7 @@ int run_ws_h2(const float* x, const void* xs_pre, const float* dy, const void* d
   else if (int e = h2_to_s3_if(xs_pre, X, d.N, d.C, S, xc, call, s)) return e;
   const void* ys3 = y_in_place ? dys : Y;
   if (dy) { if (int e = split3_into(dy, (long)d.K * S, const_cast<void*>(ys3), d.N, d.K, S, d.K, 0, s, call)) return e; }
-  else if (int e = h2_to_s3_if(dys_pre, Y, d.N, d.K, S, yc, call, s)) return e;
+  else if (!y_fixed) { if (int e = h2_to_s3_if(dys_pre, Y, d.N, d.K, S, yc, call, s)) return e; }  // (y_fixed: the flag is dY's own, its S3 form is there)
   return ws_core(3, xs3, ys3, nullptr, nullptr, dw, d, part, s, call);
 }
 
@@ -1476,17 +1479,19 @@ size_t s3_bwd_ws_bytes(const ConvDims& d) {
   const size_t wg = s3_wgrad_ws_bytes(d) - align256((size_t)d.N * d.K * S * 6);
   return A + (dg > wg ? dg : wg);
 }
+unsigned* conv_bwd_guard_words(void* ws, int N, int K, long S) { return (unsigned*)((char*)ws + align256((size_t)N * K * S * 6)); }
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, int phase, const void* xs) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient (xs: x in S3, or NULL)
+                hipStream_t s, int phase, const void* xs, bool dy_guarded) {  // phase 0: convert dY; 1: data gradient; 2: weight gradient (xs: x in S3, or NULL)
   const long S = (long)d.D * d.H * d.W;
   const size_t A = align256((size_t)d.N * d.K * S * 6) + 256;
   if (!ws || wsb < s3_bwd_ws_bytes(d)) { set_error("conv_bwd_s3: workspace too small"); return NC_ERR_WS; }
   // dy != NULL: dY is converted here (phase 0) with a MEASURED cell -- the range guard applies (common.hpp): its words sit behind the operand
   // region, phase 0 takes the decision and, flagged, writes the S3 form over the H2 one; phases 1 and 2 launch both kernel families.
-  // dy == NULL (conv_bwd_pre): the producer (InstanceNorm backward) wrote the H2 form with a bound for a cell: no guard.
+  // dy == NULL (conv_bwd_pre): the producer (InstanceNorm backward) wrote dY there itself; dy_guarded: it also counted into the guard words,
+  // took the decision and, flagged, left the S3 form (norm_act.hip instnorm_act_bwd_dbias_h2).
   unsigned* yg = (unsigned*)((char*)ws + A - 256);
   const bool h2 = s3_layer_h2(d);
-  const bool guarded = h2 && dy && h2_guard_on();
+  const bool guarded = h2 && h2_guard_can_flip() && (dy || dy_guarded);
   if (phase == 0) {
     if (h2) {  // dY as an H2 tensor (measured cell) where the S3 tensor would stand
       const size_t ey = (size_t)d.N * d.K * S;
@@ -1495,7 +1500,7 @@ int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, floa
       if (int e = h2_zero_cells(yc, 2, s)) return e;
       if (int e = h2_absmax(dy, (long)ey, yc, s, yc + 1)) return e;
       if (int e = split2h_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, yc, s, yg)) return e;
-      if (!guarded) return NC_OK;
+      if (!guarded) return h2_guard_decide(yg, nullptr, nullptr, yg + kGuardFlag, false, s);  // (count only; a no-op with the guard off)
       if (int e = h2_guard_decide(yg, nullptr, nullptr, yg + kGuardFlag, true, s)) return e;
       return split3_into(dy, (long)d.K * S, ws, d.N, d.K, S, d.K, 0, s, yg);
     }
@@ -1559,6 +1564,10 @@ int act_operand(const ConvDims& d, const float* x, const float* mean, const floa
   return act_split2h(x, mean, rstd, slope, y, ystride, ys, N, C, S, ctot, c0, sqrtf((float)S), mine, C == ctot ? cells + 1 : nullptr, s);
 }
 bool conv_layer_h2(const ConvDims& d) { return s3_layer_h2(d); }
+static thread_local int tl_net_depth = 0;
+NetworkScope::NetworkScope() { ++tl_net_depth; }
+NetworkScope::~NetworkScope() { --tl_net_depth; }
+bool h2_guard_can_flip() { return h2_guard_mode() == 2 || (h2_guard_mode() == 1 && tl_net_depth == 0); }
 ForceThreeTerm::ForceThreeTerm() { ++tl_force3; }
 ForceThreeTerm::~ForceThreeTerm() { --tl_force3; }
 

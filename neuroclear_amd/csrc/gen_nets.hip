@@ -138,6 +138,7 @@ size_t nc_unet_deconv_train_ws_bytes(int N, int S0, int S1, int S2) {
 
 int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2,
                              void* ws, size_t ws_bytes, void* stream, unsigned* kept) {
+  NetworkScope net_scope;
   if (!params || !x || !y || !saved) { set_error("unet_deconv_train_fwd: null pointer"); return NC_ERR_ARG; }
   UPlan p;
   if (!u_plan(p, N, S0, S1, S2)) {
@@ -286,6 +287,7 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
 // real volume in the Apollo / Athena steps: its gradient -- the data gradient of the first convolution -- is skipped).
 int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, const float* saved, const float* dy, float* dx,
                        float* dparams, int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept) {
+  NetworkScope net_scope;
   if (!params || !x || !y || !saved || !dy || !dparams) { set_error("unet_deconv_bwd: null pointer"); return NC_ERR_ARG; }
   UPlan p;
   if (!u_plan(p, N, S0, S1, S2)) { set_error("unet_deconv_bwd: bad shape"); return NC_ERR_SHAPE; }
@@ -317,11 +319,12 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
     // conversion phase of the split-operand backward would put it): no fp32 tensor, no conversion pass
     if (fuse_bwd && i >= 1 && conv_bwd_pre_supported(N, b.C, d[0], d[1], d[2], b.K, 3, gin != nullptr, p.conv_ws) &&
         instnorm_bwd_s3_supported(N, b.K, Sl)) {
-      if (now_h2)
-        NC_TRY(instnorm_act_bwd_dbias_h2(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
+      if (now_h2)  // (with the range guard's words of the dY operand: the norm backward counts, decides and -- flagged -- rewrites it as S3)
+        NC_TRY(instnorm_act_bwd_dbias_h2(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream,
+                                         conv_bwd_guard_words(cws, N, b.K, Sl)));
       else
         NC_TRY(instnorm_act_bwd_dbias_s3(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, cws, DP + o.b[i], N, b.K, Sl, iws, p.in_ws, stream));
-      return conv_bwd_pre(in, xs, P + o.w[i], gin, DP + o.w[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream);
+      return conv_bwd_pre(in, xs, P + o.w[i], gin, DP + o.w[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream, now_h2 && h2_guard_can_flip());
     }
     NC_TRY(nc_instnorm_act_bwd_dbias(g, V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, draw, DP + o.b[i], N, b.K, Sl, iws,
                                      p.in_ws, stream));
@@ -439,6 +442,7 @@ size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2) {
 // saved == NULL: inference -- the intermediate activations ping-pong through the workspace instead
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2, void* ws,
                        size_t ws_bytes, void* stream, unsigned* kept) {
+  NetworkScope net_scope;
   if (!params || !x || !y) { set_error("deep_linear_fwd: null pointer"); return NC_ERR_ARG; }
   LPlan p;
   if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_fwd: bad shape"); return NC_ERR_SHAPE; }
@@ -469,6 +473,7 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
 // dx nullable; dparams overwritten
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
                        int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept) {
+  NetworkScope net_scope;
   if (!params || !x || !saved || !dy || !dparams) { set_error("deep_linear_bwd: null pointer"); return NC_ERR_ARG; }
   LPlan p;
   if (!l_plan(p, N, S0, S1, S2)) { set_error("deep_linear_bwd: bad shape"); return NC_ERR_SHAPE; }

@@ -95,15 +95,13 @@ __global__ void __launch_bounds__(256) k_split2h(const float* __restrict__ x, ui
 #pragma unroll
       for (int t = 0; t < 2; ++t) out[(ob * 2 + t) * S + v] = s3_unit(e, t);
     }
-    if (guard) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned q = (unsigned)__shfl_xor((int)m, o);
-        m = q > m ? q : m;
-      }
-      if (m) {
+    if (guard) {  // (two ballots instead of a cross-lane maximum: is any lane's value at or above the threshold / non-zero)
+      const unsigned thr = cb_bits > kGuardDrop ? cb_bits - kGuardDrop : 0u;
+      const bool any_hi = __builtin_amdgcn_ballot_w64(m >= thr && m != 0) != 0;
+      const bool any_nz = __builtin_amdgcn_ballot_w64(m != 0) != 0;
+      if (any_nz) {
         ++n_all;
-        if (cb_bits > kGuardDrop && m < cb_bits - kGuardDrop) ++n_low;
+        if (!any_hi) ++n_low;
       }
     }
   }
@@ -124,7 +122,9 @@ __global__ void __launch_bounds__(256) k_split2h(const float* __restrict__ x, ui
 // the two-term ones when it is clear); else f is only counted.  prior (nullable): the words of an operand whose decision was taken earlier
 // (conv_bwd_s3's dY): the call's flag is the OR, and the operand's own flag follows it (the caller re-converts that operand too).
 // stats: host-visible counters (nc_h2_guard_stats).
-__global__ void k_h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, int can_flip, unsigned long long* stats) {
+// total_a != 0: ga's producer counted ZERO chunks instead of non-zero ones (the norm backward: atomics only for the rare chunk): all = total_a - ga[kGuardAll]
+__global__ void k_h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, int can_flip, unsigned long long* stats,
+                                  unsigned long long total_a) {
   if (threadIdx.x || blockIdx.x) return;
   unsigned f = 0;
   unsigned long long worst = 0;
@@ -132,7 +132,7 @@ __global__ void k_h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, u
   for (unsigned* g : {ga, gb}) {
     if (!g) continue;
     ++n;
-    const unsigned long long lo = g[kGuardLow], all = g[kGuardAll];
+    const unsigned long long lo = g[kGuardLow], all = (g == ga && total_a) ? total_a - g[kGuardAll] : g[kGuardAll];
     if (all && lo * kGuardShare > all) f = 1;
     const unsigned long long ppm = all ? lo * 1000000ull / all : 0;
     worst = ppm > worst ? ppm : worst;
@@ -282,7 +282,8 @@ int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, i
 // ---- the range guard (common.hpp) -----------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_guard{getenv("NC_H2_GUARD") ? atoi(getenv("NC_H2_GUARD")) : 1};
 bool h2_guard_on() { return g_guard != 0; }
-void h2_guard_set(int on) { g_guard = on ? 1 : 0; }
+int h2_guard_mode() { return g_guard; }
+void h2_guard_set(int on) { g_guard = on == 2 ? 2 : on ? 1 : 0; }
 namespace {
 std::mutex g_stats_mu;
 unsigned long long* g_stats_host = nullptr;  // 4 counters in pinned host memory the device adds to (system-scope atomics): readable without a sync
@@ -313,9 +314,9 @@ int h2_guard_zero(unsigned* g, hipStream_t s, int nwords) {
   hipLaunchKernelGGL(k_set_cells, dim3(1), dim3(64), 0, s, g, nwords, 0u);
   return check_launch("h2_guard_zero");
 }
-int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s) {
+int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag, bool can_flip, hipStream_t s, unsigned long long total_a) {
   if (!h2_guard_on() && !prior) return NC_OK;  // (the words were zeroed: the flag reads 0)
-  hipLaunchKernelGGL(k_h2_guard_decide, dim3(1), dim3(64), 0, s, ga, gb, prior, flag, can_flip ? 1 : 0, guard_stats_dev());
+  hipLaunchKernelGGL(k_h2_guard_decide, dim3(1), dim3(64), 0, s, ga, gb, prior, flag, can_flip ? 1 : 0, guard_stats_dev(), total_a);
   return check_launch("h2_guard_decide");
 }
 int h2_to_s3_if(const void* xh, void* xs, int N, int C, long S, const unsigned* cells, const unsigned* guard, hipStream_t s) {

@@ -416,9 +416,11 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_c8(const float* __restrict
 __global__ __launch_bounds__(256) void k_in_bwd_apply_s3(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          float slope, long S, int splits, const double* __restrict__ part,
-                                                         uint4* __restrict__ dxs, int cblocks, double* __restrict__ rowpart) {
+                                                         uint4* __restrict__ dxs, int cblocks, double* __restrict__ rowpart,
+                                                         const unsigned* __restrict__ guard = nullptr) {
   __shared__ float sm[2][8];
   __shared__ double red[8][4];
+  if (guard_skip(guard, 1)) return;  // (the range guard's fallback of k_in_bwd_apply_h2: runs only for a flagged tensor)
   const long ncb = blockIdx.y;
   if (threadIdx.x < 8) {
     const long inst = ncb * 8 + threadIdx.x;
@@ -503,7 +505,8 @@ __global__ __launch_bounds__(256) void k_in_bwd_sums_h2(const float* __restrict_
 
 __global__ __launch_bounds__(256) void k_in_bwd_bound(const float* __restrict__ rstd, const unsigned* __restrict__ gmax,
                                                       const unsigned* __restrict__ xmax, int NC, unsigned* __restrict__ cell,
-                                                      unsigned* __restrict__ cell2) {
+                                                      unsigned* __restrict__ cell2, unsigned* __restrict__ guard) {
+  if (guard && threadIdx.x < 8) guard[threadIdx.x] = 0u;  // (the range guard's words of the tensor the apply pass is about to write)
   unsigned m = 0;
   for (int i = threadIdx.x; i < NC; i += 256) {
     const float bnd = rstd[i] * __uint_as_float(gmax[i]) * (2.f + __uint_as_float(xmax[i]));
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_h2(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          float slope, long S, int splits, const double* __restrict__ part,
                                                          uint4* __restrict__ dxs, int cblocks, double* __restrict__ rowpart,
-                                                         const unsigned* __restrict__ cell) {
+                                                         const unsigned* __restrict__ cell, unsigned* __restrict__ guard) {
   __shared__ float sm[2][8];
   __shared__ double red[8][4];
   const long ncb = blockIdx.y;
@@ -544,7 +547,9 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_h2(const float* __restrict
     sm[1][threadIdx.x] = (float)(s2 / (double)S);
   }
   __syncthreads();
-  const float sc = h2_scale(*cell);
+  const unsigned cbits = *cell;
+  const float sc = h2_scale(cbits);
+  unsigned n_zero = 0, n_low = 0;  // (wave-uniform: every lane counts the same chunks)
   float m[8], r[8], m1[8], m2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { m[j] = mean[ncb * 8 + j]; r[j] = rstd[ncb * 8 + j]; m1[j] = sm[0][j]; m2[j] = sm[1][j]; }
@@ -555,15 +560,32 @@ __global__ __launch_bounds__(256) void k_in_bwd_apply_h2(const float* __restrict
   for (int j = 0; j < 8; ++j) rs[j] = 0.0;
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
     unsigned short e[8][3];
+    unsigned mx = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = in_bwd_value(px[j * S + v], pg[j * S + v], m[j], r[j], m1[j], m2[j], slope);
       rs[j] += (double)t;
       asm("" : "+v"(t));
+      const unsigned b = __float_as_uint(t) & 0x7fffffffu;
+      if (b < 0x7f800000u && b > mx) mx = b;
       h2_split(t * sc, e[j]);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) dxs[(ncb * 2 + t) * S + v] = s3_unit(e, t);  // [N][C/8][2][S] units
+    // range guard (common.hpp): this wave's 64 voxels x 8 channels are one chunk.  The lanes of a wave leave the loop together except in the
+    // last iteration, so the chunk's maximum is taken over the lanes that are here; zero chunks and low chunks are the rare case: atomics
+    // only for those (guard[kGuardAll] counts ZERO chunks here, see k_h2_guard_decide's total_a)
+    if (guard) {  // (two ballots, no cross-lane reduction: "does any lane hold a value at or above the threshold / a non-zero value")
+      const unsigned thr = cbits > kGuardDrop ? cbits - kGuardDrop : 0u;
+      const bool any_hi = __builtin_amdgcn_ballot_w64(mx >= thr && mx != 0) != 0;
+      const bool any_nz = __builtin_amdgcn_ballot_w64(mx != 0) != 0;
+      if (!any_nz) ++n_zero;
+      else if (!any_hi) ++n_low;
+    }
+  }
+  if (guard && (threadIdx.x & 63) == 0) {
+    if (n_low) atomicAdd(guard + kGuardLow, n_low);
+    if (n_zero) atomicAdd(guard + kGuardAll, n_zero);
   }
   if (rowpart) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -992,7 +1014,7 @@ int instnorm_act_bwd_dbias_s3(const float* dy, const float* x, const float* mean
 // dxs: an H2 tensor [N][C/8][2][S] with its cell at byte offset h2_cells_offset(N * C * S) (cells[0] = cells[1] = the bound) and two
 // arrays of N * C words of scratch behind the cells -- all inside the N * C * S * 6 bytes an S3 tensor of the same shape takes.
 int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean, const float* rstd, float slope, void* dxs,
-                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream) {
+                              float* dbias, int N, int C, long S, void* ws, size_t ws_bytes, void* stream, unsigned* guard) {
   if (!dy || !x || !mean || !rstd || !dxs || !dbias) { set_error("instnorm_act_bwd_dbias_h2: null pointer"); return NC_ERR_ARG; }
   if (!instnorm_bwd_s3_supported(N, C, S)) { set_error("instnorm_act_bwd_dbias_h2: bad shape"); return NC_ERR_SHAPE; }
   const int NC = N * C;
@@ -1005,13 +1027,31 @@ int instnorm_act_bwd_dbias_h2(const float* dy, const float* x, const float* mean
   hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)cdiv(64 + 2 * NC, 256)), dim3(256), 0, s, cells, 64 + 2 * NC);
   const int splits = pick_splits(NC, S);
   hipLaunchKernelGGL(k_in_bwd_sums_h2, dim3(splits, NC), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits, (double*)ws, gmax, xmax);
-  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells, cells + 1);
+  hipLaunchKernelGGL(k_in_bwd_bound, dim3(1), dim3(256), 0, s, rstd, gmax, xmax, NC, cells, cells + 1, guard);
   long bx = cdiv(S, 1024);
   if (bx > 1024) bx = 1024;
   double* rowpart = (double*)((char*)ws + nc_instnorm_ws_bytes(NC, S));
+  // Range guard (common.hpp): the cell is a bound from the tensor's own per-instance maxima, i.e. data-derived like a measured one -- a block
+  // of channels or a region far below the rest loses bits the same way.  guard (nullable): the words conv_bwd_s3 reads (conv_bwd_guard_words);
+  // the apply pass counts its low chunks, the decision is taken on the device, and a flagged tensor is written AGAIN by the S3 twin of the
+  // apply pass (same values, three exact bf16 terms, over the H2 form: the buffer has the S3 capacity) for the three-term kernels
+  unsigned* g = guard && h2_guard_on() ? guard : nullptr;
   hipLaunchKernelGGL(k_in_bwd_apply_h2, dim3((unsigned)bx, (unsigned)(NC / 8)), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
-                     (const double*)ws, (uint4*)dxs, C / 8, rowpart, (const unsigned*)cells);
+                     (const double*)ws, (uint4*)dxs, C / 8, rowpart, (const unsigned*)cells, g);
   hipLaunchKernelGGL(k_in_dbias_final, dim3(C), dim3(256), 0, s, (const double*)rowpart, N, C, (int)bx, dbias);
+  if (g) {
+    // chunks: one per wave and loop iteration = (NC / 8) * sum over blocks of ceil(iterations): every 64-voxel group of every 8-channel block
+    const unsigned long long total = (unsigned long long)(NC / 8) * (unsigned long long)cdiv(S, 64);
+    // Inside a whole-network call mode 1 (default) COUNTS a flagged tensor (nc_h2_guard_stats [2]) and leaves the switch to the caller (the
+    // Python models go to the three-term form when they see it, models/base_model.py): the in-call fallback costs the training step ~65
+    // near-empty launches, 0.5 ms of 35, for an event InstanceNorm networks do not produce.  Mode 2: in-call fallback here too.
+    const bool flip = h2_guard_can_flip();
+    if (int e = h2_guard_decide(g, nullptr, nullptr, g + kGuardFlag, flip, s, total)) return e;
+    if (!flip) return check_launch("instnorm_act_bwd_dbias_h2");
+    long bx3 = bx < 128 ? bx : 128;  // (usually leaves at once; no row partials: the bias gradient is the H2 pass's)
+    hipLaunchKernelGGL(k_in_bwd_apply_s3, dim3((unsigned)bx3, (unsigned)(NC / 8)), dim3(256), 0, s, dy, x, mean, rstd, slope, S, splits,
+                       (const double*)ws, (uint4*)dxs, C / 8, (double*)nullptr, (const unsigned*)g);
+  }
   return check_launch("instnorm_act_bwd_dbias_h2");
 }
 int instnorm_relu_tail_sigmoid(const float* x, const float* mean, const float* rstd, const float* w1, const float* b1, const float* w2,

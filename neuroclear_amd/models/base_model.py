@@ -95,7 +95,30 @@ class BaseModel(ABC):
             if isinstance(name, str):
                 v = getattr(self, 'loss_' + name)
                 errors_ret[name] = float(v.detach()) if hasattr(v, 'detach') else float(v)
+        self._check_two_term_guard()
         return errors_ret
+
+    _guard_warned = False
+
+    def _check_two_term_guard(self):
+        """The range guard of the two-term convolution arithmetic (include/nc_hip.h) switches a flagged call to the exact three-term kernels by
+        itself wherever it can; tensors it can only COUNT (the norm backward's output in mode 1, the activations deep_linear_gen keeps) show up
+        in the third counter.  This is the place where the host is synchronised anyway: if any were seen, the whole process goes to the
+        three-term form from here on (1.5 x the step time, exact) and says so once."""
+        import ctypes
+        from .._lib import lib
+        L = lib()
+        if L.nc_get_split_terms() != 2 or not L.nc_get_h2_guard():
+            return
+        st = (ctypes.c_ulonglong * 4)()
+        L.nc_h2_guard_stats(st, 0)
+        if st[2] and not BaseModel._guard_warned:
+            import warnings
+            BaseModel._guard_warned = True
+            L.nc_set_split_terms(3)
+            warnings.warn('neuroclear_amd: %d tensor(s) had more than 1/64 of their 512-element chunks below 2^-17 of the tensor maximum in a place '
+                          'where the two-term convolution kernels cannot switch by themselves; nc_set_split_terms(3) is now in force (exact '
+                          'three-term form) for the rest of this process' % int(st[2]))
 
     def save_networks(self, epoch):
         os.makedirs(self.save_dir, exist_ok=True)

@@ -439,3 +439,80 @@ def test_h2_training_goldens(golden_dir, kind, size):
         gr = p_.grad.detach().cpu().numpy().ravel()
         l2 = np.sqrt((gr.astype(np.float64) ** 2).sum())
         assert abs(l2 - g['g_l2'][i]) <= tol * g['g_l2'][i] + 1e-6, (k, l2, g['g_l2'][i])
+
+
+def test_h2_forward_is_bit_identical_after_idle_gaps():
+    """The tap-stream kernel waits for its weight fragments and LDS-DMA pieces with hand-counted vmcnt values; a miscount would show as a
+    result that depends on timing.  The same layer 60 times -- every second call after an idle gap (clock and fabric ramp down), whole rounds
+    plus a left-over launch of quarter tiles (64 -> 64 at 80^3: 1040 tiles = 4 x 256 + 16) -- must give the same bits every time."""
+    import time
+    from neuroclear_amd import ops
+    L().nc_set_split_terms(2)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.rand(1, 64, 80, 80, 80, device=DEV, generator=g)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * 0.03
+    b = torch.randn(64, device=DEV, generator=g)
+    ref = ops.conv_fwd_raw(x, w, b, 1, 1).clone()
+    for it in range(60):
+        torch.cuda.synchronize()
+        if it % 2:
+            time.sleep(0.03)
+        assert torch.equal(ops.conv_fwd_raw(x, w, b, 1, 1), ref), it
+
+
+def test_h2_guard_covers_the_norm_backward_output(golden_dir):
+    """The dY of a U-Net convolution is written in H2 form by the InstanceNorm backward itself, with a cell from its own per-instance maxima --
+    data-derived like a measured one.  Here the NEXT layer ignores 16 of double_conv1's 64 output channels almost entirely (its weights on them
+    are 2^-24 of the others), so their gradients -- a block of dY channels, and with it a block of double_conv1.convolution.3's weight
+    gradient -- sit 2^-24 below the rest.  The norm backward's guard flags that tensor, rewrites it in S3 form and the layer's gradients run
+    on the three-term kernels: the dark block of the weight gradient moves an order of magnitude closer to the all-three-term run than with
+    the guard off."""
+    size = 32
+    spec = S.unet_deconv_spec()
+    sd = S.state_dict_from_seed(spec, 4, DEV)
+    w = sd['double_conv2.convolution.0.weight'].clone()
+    w[:, :16] *= 2.0 ** -24
+    sd['double_conv2.convolution.0.weight'] = w
+    # (double_conv1's output also feeds the skip connection: silence the same channels in ex_conv1_1, which reads the concatenation)
+    w2 = sd['ex_conv1_1.convolution.0.weight'].clone()
+    w2[:, :16] *= 2.0 ** -24
+    sd['ex_conv1_1.convolution.0.weight'] = w2
+    x = torch.from_numpy(rnd(7, (1, 1, size, size, size))).to(DEV)
+    r = torch.from_numpy(rnd(8, (1, 1, size, size, size))).to(DEV)
+
+    def run(terms, guard):  # guard 2: the norm backward's output switches in the call (mode 1, the default, only counts it: see below)
+        L().nc_set_split_terms(terms)
+        L().nc_set_h2_guard(guard)
+        net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+        net.load_state_dict(sd)
+        before = guard_stats()
+        y = net(x.clone().requires_grad_(True))
+        (y * r).mean().backward()
+        after = guard_stats()
+        return net.double_conv1.convolution[3].weight.grad.detach().double().clone(), after[1] - before[1], after[2] - before[2]
+    g3, _, _ = run(3, 1)
+    g2, fell, _ = run(2, 2)
+    g2off, _, _ = run(2, 0)
+    g2cnt, fell1, counted1 = run(2, 1)
+    assert fell1 == 0 and counted1 >= 1 and torch.equal(g2cnt, g2off)   # mode 1: the same tensor is reported, nothing switches in the call
+    # ... and the models act on the report where they synchronise anyway (BaseModel.get_current_losses): three-term form from then on
+    import warnings
+    from neuroclear_amd.models.base_model import BaseModel
+    L().nc_set_split_terms(2)
+    L().nc_set_h2_guard(1)
+    BaseModel._guard_warned = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        BaseModel._check_two_term_guard(None)
+    assert L().nc_get_split_terms() == 3 and any('nc_set_split_terms(3)' in str(w.message) for w in rec)
+    guard_stats(reset=True)
+    BaseModel._guard_warned = False
+    dark = lambda g: g[:16]  # noqa: E731  (output channels of double_conv1.convolution.3 = the dark dY channels)
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    print('dark block of the weight gradient vs the three-term run: guard on %.2e, off %.2e; calls that fell back: %d' % (
+        rel(dark(g2), dark(g3)), rel(dark(g2off), dark(g3)), fell))
+    # (what is left with the guard on is not dY's: the NEXT layers' weights -- one cell per weight tensor, not guarded -- carry the same 2^-24
+    # block, so the gradient that ARRIVES at the dark channels was computed from weights with ~16 bits)
+    # (and two arithmetics differ by ~1e-3 anyway where a ReLU decision falls the other way, tests/test_gpu_grad_fp64.py: no absolute bound here)
+    assert fell >= 1
+    assert rel(dark(g2off), dark(g3)) > 5 * rel(dark(g2), dark(g3))
