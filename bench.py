@@ -279,7 +279,7 @@ def run_train(args, rank, world, dev):
     top = max((t for t in stats if 'mfma' in t or '_lp_' in t or '_split_' in t), key=lambda t: stats[t][1], default=None)
     roof = None
     if top:
-        n, ms, flop = stats[top]
+        n, ms, flop, abytes = stats[top]
         ach = flop / ms / 1e9
         from neuroclear_amd._lib import lib as _l
         two = '_split_' in top and int(_l().nc_get_split_terms()) == 2   # the two-term fp16 form: 3 MFMA products per fp32 product
@@ -297,11 +297,15 @@ def run_train(args, rank, world, dev):
         roof = dict(bound='mfma', kernel=kname, kernel_class=top, achieved=round(ach, 2),
                     peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
                     traffic=pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two), traffic_source=TRAFFIC_SOURCE,
+                    algorithmic_bytes=round(abytes / n),  # per launch, measured on THIS run's launches: operands once + result + weights
+                    traffic_vs_algorithmic=(round(pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two) / (abytes / n), 3)
+                                            if pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two) else None),
                     launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
                     classes={t: dict(n=s[0], ms_per_step=round(s[1] / args.steps, 3),
-                                     tflops=round(s[2] / s[1] / 1e9, 2)) for t, s in sorted(stats.items())},
+                                     tflops=round(s[2] / s[1] / 1e9, 2), algorithmic_gb_per_s=round(s[3] / s[1] / 1e6, 1))
+                             for t, s in sorted(stats.items())},
                     conv_ms_per_step=round(conv_ms / args.steps, 2),
                     whole_network_calls={t: dict(n=c[0], ms_per_step=round(c[1] / args.steps, 3),
                                                  tflops=round(c[2] / c[1] / 1e9, 2)) for t, c in sorted(calls.items())})
@@ -396,7 +400,10 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
                                         'profiles/r04_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
-                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split, three_term=split and terms != 2), traffic_source=TRAFFIC_SOURCE, launches=len(ev),
+                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split, three_term=split and terms != 2), traffic_source=TRAFFIC_SOURCE,
+                    algorithmic_bytes=round(3192 * 140 ** 3),  # 3,192 B per voxel for a perfectly fused fp32 G_A forward
+                    traffic_vs_algorithmic=(round(pmc_traffic_cube(split, three_term=split and terms != 2) / (3192 * 140 ** 3), 3)
+                                            if pmc_traffic_cube(split, three_term=split and terms != 2) else None), launches=len(ev),
                     cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
                     event_ms_per_cube=round(ms_events / len(ev), 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))

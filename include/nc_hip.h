@@ -48,6 +48,8 @@ int nc_conv_wgrad_path(int C, int K, int kd, int kh, int kw, int stride, int pad
  * (16-bit kernel ? 1 << 16 : 0), flop = 2 C K kd kh kw x output voxels, ms = event-to-event duration.  Synchronise first. */
 void nc_prof_begin(double min_flop);
 int nc_prof_end(int max, int* cls, double* flop, float* ms);
+int nc_prof_end2(int max, int* cls, double* flop, float* ms, double* abytes); /* + the launch's algorithmic bytes: operands once (4 B; 2 B on the
+                                   * 16-bit path), result, weights */
 /* Force the direct path everywhere (tests cross-check MFMA vs direct on the GPU). 0 = auto (default), 1 = force. */
 void nc_set_force_direct(int on);
 /* The image-staged PatchGAN kernels (conv2d_img.hip) pick their tile shape per problem by timing the candidates on the

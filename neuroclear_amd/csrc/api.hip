@@ -41,7 +41,7 @@ int raise_dyn_lds(const void* kernel, int bytes, const char* who) {
 
 
 // ---- live launch profiler (bench.py): HIP events on the launch stream around every convolution entry point --------
-struct ProfRec { int cls; double flop; hipEvent_t e0, e1; };
+struct ProfRec { int cls; double flop, abytes; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;  // launches come from the main thread (forward) and the autograd engine's thread (backward)
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -59,7 +59,12 @@ ProfScope::ProfScope(int op, int path, const ConvDims& d, int lp, hipStream_t st
     if (hipEventCreate(&e) != hipSuccess) return (hipEvent_t) nullptr;
     return e;
   };
-  ProfRec r{op | (path << 4) | (d.kh << 8) | (lp ? 1 << 16 : 0), flop, get(), get()};
+  // algorithmic bytes of the launch: every operand element once (4 B: fp32, or the two-term H2 form; 2 B on the 16-bit path; the three-term
+  // form's 6 B is not the algorithm's doing) + the result + the weights
+  const double xin = (double)d.N * d.C * d.D * d.H * d.W, yout = (double)d.N * d.K * d.Do * d.Ho * d.Wo, wts = (double)d.K * d.C * d.kd * d.kh * d.kw;
+  const double eb = lp ? 2.0 : 4.0;
+  const double abytes = op == 2 ? (xin + yout) * eb + wts * 4.0 : (op == 0 ? xin * eb + yout * 4.0 : yout * eb + xin * 4.0) + wts * 4.0;
+  ProfRec r{op | (path << 4) | (d.kh << 8) | (lp ? 1 << 16 : 0), flop, abytes, get(), get()};
   if (!r.e0 || !r.e1) return;
   (void)hipEventRecord(r.e0, s);
   g_prof.push_back(r);
@@ -133,7 +138,8 @@ void nc_prof_begin(double min_flop) {
 
 // Stops recording, waits for the recorded launches and returns how many there were; the first `max` are written to
 // cls / flop / ms (cls encoding: see ProfScope).  The caller synchronises the device first.
-int nc_prof_end(int max, int* cls, double* flop, float* ms) {
+int nc_prof_end(int max, int* cls, double* flop, float* ms) { return nc_prof_end2(max, cls, flop, ms, nullptr); }
+int nc_prof_end2(int max, int* cls, double* flop, float* ms, double* abytes) {
   g_prof_on = false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   const int n = (int)g_prof.size();
@@ -142,6 +148,7 @@ int nc_prof_end(int max, int* cls, double* flop, float* ms) {
     (void)hipEventSynchronize(g_prof[i].e1);
     (void)hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
     cls[i] = g_prof[i].cls; flop[i] = g_prof[i].flop; ms[i] = t;
+    if (abytes) abytes[i] = g_prof[i].abytes;
   }
   return n;
 }

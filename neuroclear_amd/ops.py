@@ -29,22 +29,23 @@ _PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 't
 
 
 def prof_stop():
-    """-> ({tag: [launches, ms, flop]} of the convolution launches, [(tag, flop, ms)] of the whole-network calls).  The
+    """-> ({tag: [launches, ms, flop, algorithmic bytes]} of the convolution launches, [(tag, flop, ms)] of the whole-network calls).  The
     caller has synchronised the device."""
     global prof
     L = lib()
     cap = 1 << 16
-    cls, flop, ms = (ctypes.c_int * cap)(), (ctypes.c_double * cap)(), (ctypes.c_float * cap)()
-    n = min(L.nc_prof_end(I(cap), cls, flop, ms), cap)
+    cls, flop, ms, ab = (ctypes.c_int * cap)(), (ctypes.c_double * cap)(), (ctypes.c_float * cap)(), (ctypes.c_double * cap)()
+    n = min(L.nc_prof_end2(I(cap), cls, flop, ms, ab), cap)
     stats = {}
     for i in range(n):
         c = cls[i]
         op, path, k, lp = ('fwd', 'dgrad', 'wgrad')[c & 15], (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1
         tag = '%s_lp_k%d' % (op, k) if lp else '%s_%s_k%d' % (op, _PATH.get(path, '?'), k)
-        s = stats.setdefault(tag, [0, 0.0, 0.0])
+        s = stats.setdefault(tag, [0, 0.0, 0.0, 0.0])
         s[0] += 1
         s[1] += ms[i]
         s[2] += flop[i]
+        s[3] += ab[i]  # algorithmic bytes (operands once + result + weights)
     whole = [(tag, fl, e0.elapsed_time(e1)) for tag, fl, e0, e1 in (prof or [])]
     prof = None
     return stats, whole
