@@ -428,6 +428,12 @@ int nc_get_split_terms(void);
 void nc_set_h2_guard(int on);
 int nc_get_h2_guard(void);
 int nc_h2_guard_stats(unsigned long long* out4, int reset);
+/* Epilogue statistics of the inference forward (round 5; csrc/conv_s3x.hip, template parameter ST): in nc_unet_deconv_fwd's two-term mode every
+ * 3^3 convolution leaves, per (tile, wave), the sum and the sum of squares of its bias-free outputs, and a small pass adds them up in fp64 in a
+ * fixed order -- InstanceNorm (reference networks.py:513-515, nn.InstanceNorm3d after every Conv3d) needs no pass of its own over the raw
+ * output.  mean / rstd agree with the separate pass to 4e-8 relative.  1 (default; NC_EPI_STATS at load time) / 0: the separate pass. */
+void nc_set_epi_stats(int on);
+int nc_get_epi_stats(void);
 int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the
                                                        * current switches; 3: on the three-term form (or the fp32 kernels); 0: bad size */
 void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the

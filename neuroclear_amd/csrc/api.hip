@@ -163,6 +163,10 @@ void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
 void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
 int nc_get_split_terms(void) { return s3x_get_terms(); }
+static std::atomic<int> g_epi_stats{getenv("NC_EPI_STATS") ? (atoi(getenv("NC_EPI_STATS")) != 0) : 1};
+static bool epi_stats_on() { return g_epi_stats.load(std::memory_order_relaxed) != 0; }
+void nc_set_epi_stats(int on) { g_epi_stats.store(on != 0, std::memory_order_relaxed); }
+int nc_get_epi_stats(void) { return g_epi_stats.load(std::memory_order_relaxed); }
 void nc_set_h2_guard(int on) { h2_guard_set(on); }
 int nc_get_h2_guard(void) { return h2_guard_mode(); }
 int nc_h2_guard_stats(unsigned long long* out4, int reset) {
@@ -614,11 +618,9 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
                    int Wd, const unsigned* in_a = nullptr, const unsigned* in_b = nullptr, int split_c = 0,
                    const unsigned* out_cell = nullptr) -> int {
     const long Sl = (long)D * H * Wd;
-    // NC_EPI_STATS=1 (EXPERIMENT, off by default): the two-term convolution leaves the partial InstanceNorm sums of its output itself
-    // (conv_s3x.hip, ST) and k_in_stats' pass over the raw output goes away: -1.8 % per 140^3 cube, mean / rstd equal to 4e-8.  Off because on
-    // ONE box of the pool the first call after an idle gap gave different results (2 of 4 network calls, 2 of 360 single layers; 3,000 later
-    // calls on four other boxes, with and without HBM contention, gave none) and the cause was not found
-    static const bool epi = getenv("NC_EPI_STATS") && atoi(getenv("NC_EPI_STATS")) == 1;
+    // Epilogue statistics (default; NC_EPI_STATS=0 / nc_set_epi_stats(0): off): the two-term convolution leaves the partial InstanceNorm sums of
+    // its output itself (conv_s3x.hip, ST) and k_in_stats' pass over the raw output goes away: -1.8 % per 140^3 cube, mean / rstd equal to 4e-8
+    const bool epi = epi_stats_on();
     if (in3 && in_a) {
       ConvDims d;
       make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1);
@@ -724,7 +726,7 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // the last block's normalisation, the two pointwise layers and the sigmoid in one pass over its raw output (NC_INFER_TAIL=0: separately)
       static const bool tail = !(getenv("NC_INFER_TAIL") && atoi(getenv("NC_INFER_TAIL")) == 0);
       if (tail) {
-        static const bool epi9 = getenv("NC_EPI_STATS") && atoi(getenv("NC_EPI_STATS")) == 1;
+        const bool epi9 = epi_stats_on();
         {
           ConvDims d9;
           make_dims(d9, 1, 128, S0, S1, S2, 64, 3, 3, 3, 1, 1);

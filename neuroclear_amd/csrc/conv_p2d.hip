@@ -522,7 +522,12 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_p2d(const PParams p) {
     tile_offsets(cur);
   }
   // the last tile's results (and the dummy request of its last step)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1])::"memory");
+  // (A is an operand on purpose: it holds the target registers of the last step's dummy request, which must not be handed to the epilogue's
+  // temporaries before it has landed -- conv_s3x.hip's final wait has the story)
+  if constexpr (NT == 3)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1])::"memory");
   store_pairs(prv, 0, kPairs);
 }
 

@@ -657,7 +657,14 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     tcur = tnext;
   }
   // the last tile's results (and the dummy request of its last step)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1])::"memory");
+  // (A is an operand of the wait ON PURPOSE: it is the target of the last step's dummy request (NS is even: the last step reads nA and
+  // requests into A), and a register the compiler considers dead is free for whatever the epilogue computes next -- the ST accumulators were
+  // zeroed in front of the wait and a late fragment landed on top of them: wrong statistics in 20-60 % of the calls of the 20^3 level, whose
+  // last k-step is the shortest.  nA's last request was waited for by the last step itself.)
+  if constexpr (NT == 3)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2])::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1])::"memory");
   if constexpr (ST) stats_zero();
   store_pairs(prv, 0, kPairs);
   if constexpr (ST) stats_flush(tprv);

@@ -30,9 +30,11 @@ def _restore():
     prev = ops.set_conv_split(True)
     t = L().nc_get_split_terms()
     gd = L().nc_get_h2_guard()
+    ep = L().nc_get_epi_stats()
     yield
     L().nc_set_split_terms(t)
     L().nc_set_h2_guard(gd)
+    L().nc_set_epi_stats(ep)
     ops.set_conv_split(prev)
 
 
@@ -458,6 +460,40 @@ def test_h2_forward_is_bit_identical_after_idle_gaps():
         if it % 2:
             time.sleep(0.03)
         assert torch.equal(ops.conv_fwd_raw(x, w, b, 1, 1), ref), it
+
+
+@pytest.mark.parametrize('size', [80, 64, 96, 48, 140])
+def test_h2_epilogue_statistics_follow_the_separate_pass(size):
+    """nc_set_epi_stats(1): the InstanceNorm sums of the inference forward come out of the convolutions' own epilogues (conv_s3x.hip ST) instead of
+    a pass over the raw output (reference networks.py:513-515: Conv3d, InstanceNorm3d, ReLU as three modules).  Same outputs as with the separate
+    pass to fp32 rounding, and the same BITS call after call, idle gaps and other inputs in between.  80^3 is the case that found a real bug: its
+    20^3 level runs as ONE round of half tiles, whose last k-step is the shortest of all launches -- the weight fragments requested for the
+    (non-existent) next step were still in flight when the epilogue began, and the compiler had handed their registers to the accumulators of
+    the sums (5 - 14 wrong calls of 24 before the final wait named those registers)."""
+    import time
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 21, DEV))
+    L().nc_set_split_terms(2)
+    assert L().nc_unet_deconv_fwd_terms(size, size, size) == 2
+    n_in = 2 if size == 140 else 4
+    xs = [torch.from_numpy(rnd(1000 + i, (1, 1, size, size, size))).to(DEV) for i in range(n_in)]
+    L().nc_set_epi_stats(0)
+    assert L().nc_get_epi_stats() == 0
+    with torch.no_grad():
+        sep = [net(x).clone() for x in xs]
+    L().nc_set_epi_stats(1)
+    assert L().nc_get_epi_stats() == 1
+    first = [None] * n_in
+    for it in range(4 * n_in if size == 140 else 6 * n_in):
+        torch.cuda.synchronize()
+        time.sleep(0.05 * (it % 3))
+        i = it % n_in
+        with torch.no_grad():
+            y = net(xs[i])
+        assert float((y - sep[i]).abs().max()) < 2e-6, (it, float((y - sep[i]).abs().max()))
+        if first[i] is None:
+            first[i] = y.clone()
+        assert torch.equal(y, first[i]), it
 
 
 def test_h2_guard_covers_the_norm_backward_output(golden_dir):
