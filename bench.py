@@ -75,7 +75,7 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 
 # `roofline.traffic` is NOT measured in this process (counters cannot be read from inside it): it is the figure of the committed offline PMC
 # passes of the same command, on whatever box those ran on
-TRAFFIC_FILE = 'r04_pmc_traffic.json'
+TRAFFIC_FILE = 'r05_pmc_traffic.json'
 TRAFFIC_SOURCE = 'profiles/%s (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % TRAFFIC_FILE
 
 PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
@@ -89,7 +89,7 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
 
 def pmc_traffic(tag, crop=108, batch=1, three_term=False):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
-    (profiles/r04_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    (profiles/r05_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
     if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
         return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
