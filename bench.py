@@ -529,6 +529,23 @@ def main():
                                                first_step_max_rel_diff=max(abs(f1[k] - f3[k]) / max(abs(f3[k]), 1e-12) for k in f3))
             finally:
                 _lib().nc_set_split_terms(2)
+    if train_like and args.precision == 'fp32' and bool(_lib().nc_get_dl_collapse()):
+        # deep_linear_gen's layers 2 .. 5 run in collapsed form (include/nc_hip.h nc_set_dl_collapse: exact algebra of the bias-free linear
+        # tail, same outputs and gradients); the same step with the layer-by-layer evaluation, for the record
+        out['deep_linear_tail'] = dict(form='collapsed (3^3 + three 1x1 layers as one 64->1 convolution; parameter gradients from dy, act1 and the weights)')
+        if headline and world == 1:
+            import copy
+            a4 = copy.copy(args)
+            a4.steps, a4.warmup, a4.no_prof = 3, 1, True
+            _lib().nc_set_dl_collapse(0)
+            try:
+                dt4, units4, _, cfg4 = run_train(a4, rank, world, dev)
+                f1, f4 = cfg['first_step_losses'], cfg4['first_step_losses']
+                out['deep_linear_tail']['layer_by_layer'] = dict(ms_per_step=dt4 / a4.steps * 1e3, value=units4 / dt4, unit='voxels/s', steps=a4.steps,
+                                                                 first_step_losses=f4,
+                                                                 first_step_max_rel_diff=max(abs(f1[k] - f4[k]) / max(abs(f4[k]), 1e-12) for k in f4))
+            finally:
+                _lib().nc_set_dl_collapse(1)
     # CPU legs: rank 0 only, at every N (the other ranks have nothing to add to a host-core figure), and AFTER the last GPU leg and the
     # process group are done with -- no rank sits in an RCCL call while rank 0 spends a minute on its host cores
     cpu = rank == 0 and not args.no_cpu_baseline

@@ -312,6 +312,12 @@ size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2);
 size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2);
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved /* or NULL */, int N, int S0, int S1,
                        int S2, void* ws, size_t ws_bytes, void* stream, unsigned* kept /* as above */);
+/* deep_linear_gen's layers 2 .. 5 (3^3, then three 1 x 1; reference networks.py:902-911) are bias-free with nothing in between: 1 (default;
+ * NC_DL_COLLAPSE at load time) evaluates them in collapsed form -- ONE 64 -> 1 convolution forward, and backward the six parameter gradients
+ * and dL/dact1 from dy, act1 and the weights alone (csrc/gen_nets.hip, "the collapsed tail": exact algebra, weight-space products in fp64, the
+ * same outputs and gradients to fp32 rounding, 2.5 ms less per 108^3 training step); 0: layer by layer as the reference's autograd does. */
+void nc_set_dl_collapse(int on);
+int nc_get_dl_collapse(void);
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
                        int N, int S0, int S1, int S2, void* ws, size_t ws_bytes, void* stream, unsigned kept);
 

@@ -162,6 +162,8 @@ int conv_dgrad_1x1(const float* dy, const float* w, float* dx, const ConvDims& d
                    hipStream_t s);
 
 // ---- many-channels -> one channel, 7^3 (VALU), conv_c1.hip
+size_t conv_fwd_to1_k3_ws_bytes(int N, int D, int H, int W);
+int conv_fwd_to1_k3(const float* x, const float* w, float* y, int N, int C, int D, int H, int W, void* ws, size_t wsb, hipStream_t s);
 bool to1_dgrad_supported(const ConvDims& d);
 int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d, hipStream_t s);
 bool to1_mfma_supported(const ConvDims& d);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_conv_to1(const float* __restrict__ x, c
       const float* plane = lds + ((2 * tzp + pz) * PY + ty) * PITCH + xb * XB;
 #pragma unroll
       for (int dy = 0; dy < KS; ++dy) {
-        float row[XB + KS + 1];  // 16 floats = 4 aligned float4 (XB + KS - 1 = 14 used)
+        float row[16];  // 4 aligned float4 (XB + KS - 1 used: 14 at 7^3, 10 at 3^3)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
           const float4 t = *reinterpret_cast<const float4*>(plane + dy * PITCH + 4 * v4);
@@ -114,6 +114,280 @@ int conv_dgrad_to1(const float* dy, const float* w, float* dx, const ConvDims& d
   dim3 grid((unsigned)(ntx * nty * ntz), d.N);
   hipLaunchKernelGGL(k_conv_to1<7>, grid, dim3(256), 0, s, dy, w, (const float*)nullptr, dx, d.K, d.D, d.H, d.W, 1);
   return check_launch("conv_dgrad_to1");
+}
+
+// Many channels -> ONE channel, 3^3, stride 1, padding 1, no bias, y[n][0][q] = sum_c sum_t w[c][t] * x[n][c][q + t - 1]: the collapsed tail
+// of deep_linear_gen (gen_nets.hip: the 3^3 layer and the three 1 x 1 layers behind it are ONE such convolution).  2 x 27 FLOP per input
+// element: HBM-bound by a factor of ~2 if the VALU is kept fed, so the kernel is built around reading x once:
+//   * a workgroup owns 8 rows x <= 128 columns x a range of planes of the output and MARCHES over the input planes: an input plane feeds the
+//     three output planes around it, held in registers (4 columns x 3 planes per thread); the plane that just received its last addend is
+//     written -- x is read once per (8-row, plane-range) tile plus a one-row / one-plane halo;
+//   * a stage = 4 channels of one plane's 10 x 136 floats, loaded as aligned 16-byte vectors into registers while the previous stage is
+//     multiplied out of LDS (two buffers, one barrier per stage); per channel a thread reads 3 rows x (b128 + 2 x b32) and issues 108 FMAs;
+//     weights are wave-uniform scalar loads.
+constexpr int kT1TY = 8, kT1TX = 128, kT1CH = 4, kT1Rows = kT1TY + 2, kT1Pitch = kT1TX + 8, kT1F4 = kT1Pitch / 4;
+constexpr int kT1Stage = kT1CH * kT1Rows * kT1Pitch;          // floats per buffer
+constexpr int kT1Ld = (kT1CH * kT1Rows * kT1F4 + 255) / 256;  // 16-byte loads per thread and stage
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_conv_to1_k3(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int D, int H,
+                                                     int W, int nty, int ntx, int zc) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kT1Stage];
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  int b = blockIdx.x;
+  const int bx = b % ntx; b /= ntx;
+  const int by = b % nty; b /= nty;
+  const int zb = b * zc, ze = zb + zc < D ? zb + zc : D;
+  const int x0 = bx * kT1TX, y0 = by * kT1TY, n = blockIdx.y;
+  const long HW = (long)H * W, S = (long)D * HW;
+  const float* xn = x + (long)n * C * S;
+  const int z_lo = zb > 0 ? zb - 1 : 0, z_hi = ze < D ? ze + 1 : D;  // input planes [z_lo, z_hi)
+  const int ncc = C / kT1CH, nst = (z_hi - z_lo) * ncc;
+
+  // what a thread fetches per stage does not depend on the stage: element offset inside (this sample, channel block c0, plane 0).  The loads
+  // are UNCONDITIONAL (an element outside the volume reads offset 0 and is zeroed when it is written to LDS): a load inside a branch makes
+  // the compiler wait for it at the branch's end, one full memory latency per load (4.8 us per stage in the first version of this kernel)
+  float4 st[kT1Ld];
+  int off[kT1Ld];
+  unsigned okm = 0;  // 4 bits per load: which of its four columns exist
+#pragma unroll
+  for (int k = 0; k < kT1Ld; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / (kT1Rows * kT1F4), r = (e / kT1F4) % kT1Rows, j = e % kT1F4;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * j;
+    const bool rowok = c < kT1CH && (unsigned)gy < (unsigned)H;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m |= (rowok && (unsigned)(gx + i) < (unsigned)W) ? 1u << i : 0u;
+    okm |= m << (4 * k);
+    off[k] = m ? (int)((long)c * S + (long)gy * W + (VEC ? gx : 0)) : 0;  // (VEC: all four columns exist or none; else: the row's start)
+  }
+  auto fetch = [&](int s) __attribute__((always_inline)) {
+    const int zi = z_lo + s / ncc, c0 = (s % ncc) * kT1CH;
+    const float* pb = xn + (long)c0 * S + (long)zi * HW;  // (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < kT1Ld; ++k) {
+      if constexpr (VEC) {
+        st[k] = *reinterpret_cast<const float4*>(pb + off[k]);
+      } else {  // rows of any length: element by element, columns clamped into the row
+        const int gx = x0 - 4 + 4 * ((tid + 256 * k) % kT1F4);
+        const float* q = pb + off[k];
+        const int hi = W - 1;
+        st[k].x = q[min(max(gx, 0), hi)];
+        st[k].y = q[min(max(gx + 1, 0), hi)];
+        st[k].z = q[min(max(gx + 2, 0), hi)];
+        st[k].w = q[min(max(gx + 3, 0), hi)];
+      }
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < kT1Ld; ++k) {
+      const int e = tid + 256 * k;
+      const unsigned m = (okm >> (4 * k)) & 15u;
+      float4 v;
+      v.x = (m & 1u) ? st[k].x : 0.f; v.y = (m & 2u) ? st[k].y : 0.f; v.z = (m & 4u) ? st[k].z : 0.f; v.w = (m & 8u) ? st[k].w : 0.f;
+      if (e < kT1CH * kT1Rows * kT1F4) *reinterpret_cast<float4*>(lds + buf * kT1Stage + 4 * e) = v;
+    }
+  };
+
+  float acc[3][4];  // [0]: output plane zi - 1 (complete after this input plane), [1]: zi, [2]: zi + 1
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[a][i] = 0.f;
+
+  fetch(0);
+  for (int s = 0; s < nst; ++s) {
+    stash(s & 1);
+    __syncthreads();
+    if (s + 1 < nst) fetch(s + 1);
+    const int zi = z_lo + s / ncc, cc = s % ncc;
+    const float* base = lds + (s & 1) * kT1Stage + ty * kT1Pitch + 4 * tx + 3;
+#pragma unroll 1
+    for (int c = 0; c < kT1CH; ++c) {  // (not unrolled: 27 weights in scalar registers at a time, not 108)
+      const float* wc = w + (long)(cc * kT1CH + c) * 27;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* rp = base + (c * kT1Rows + dy) * kT1Pitch;
+        float row[6];
+        row[0] = rp[0];
+        const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+        row[1] = m.x; row[2] = m.y; row[3] = m.z; row[4] = m.w;
+        row[5] = rp[5];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)  // input plane zi is tap dz of output plane zi + 1 - dz: accumulator 2 - dz
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float wv = wc[(dz * 3 + dy) * 3 + dx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[2 - dz][i] = fmaf(wv, row[i + dx], acc[2 - dz][i]);
+          }
+      }
+    }
+    if (cc == ncc - 1) {  // plane zi done: output plane zi - 1 is complete (or zi itself, at the volume's last plane)
+      const int gy = y0 + ty, gx = x0 + 4 * tx;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int zo = zi - 1 + a;
+        if ((a == 0 || zi == D - 1) && zo >= zb && zo < ze && gy < H) {
+          float* yr = y + (long)n * S + (long)zo * HW + (long)gy * W;
+          if (VEC && gx + 3 < W) {
+            *reinterpret_cast<float4*>(yr + gx) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (gx + i < W) yr[gx + i] = acc[a][i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = 0.f; }
+    }
+  }
+}
+
+// The same march with the stages brought in by LDS-DMA (rows that are whole 16-byte vectors): a ring of three slots, requests two stages
+// ahead of the multiplication -- a workgroup's stages are strictly serial, so what bounds the kernel is how much memory latency one stage's
+// arithmetic (0.5 us) has to hide, and registers are too few to keep two stages in flight.  Every wave issues kT1PW one-KiB pieces per stage
+// (lanes beyond the tile or outside the volume read the zero page), so one hand-placed vmcnt(kT1PW) says "my pieces of this stage are in".
+constexpr int kT1PW = 6, kT1Slot = 4 * kT1PW * 256, kT1NB = 3;  // floats per ring slot (24 pieces of 64 x 16 B), slots
+static_assert(kT1Slot >= kT1Stage, "slot");
+__global__ __launch_bounds__(256) void k_conv_to1_k3_dma(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                         const float* __restrict__ zeros, int C, int D, int H, int W, int nty, int ntx, int zc) {
+  extern __shared__ __attribute__((aligned(1024))) float ring[];
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int bx = b % ntx; b /= ntx;
+  const int by = b % nty; b /= nty;
+  const int zb = b * zc, ze = zb + zc < D ? zb + zc : D;
+  const int x0 = bx * kT1TX, y0 = by * kT1TY, n = blockIdx.y;
+  const long HW = (long)H * W, S = (long)D * HW;
+  // blockIdx.z: a group of C / gridDim.z channels; its sum goes to partial volume blockIdx.z of y (k_to1_sum_parts adds them in group order)
+  const int cg = C / (int)gridDim.z;
+  const float* xn = x + ((long)n * C + (long)blockIdx.z * cg) * S;
+  w += (long)blockIdx.z * cg * 27;
+  y += (long)blockIdx.z * gridDim.y * S;
+  const int z_lo = zb > 0 ? zb - 1 : 0, z_hi = ze < D ? ze + 1 : D;  // input planes [z_lo, z_hi)
+  const int ncc = cg / kT1CH, nst = (z_hi - z_lo) * ncc;
+  const unsigned ring_addr = nc_lds_addr(ring);
+
+  long off[kT1PW];  // element offset of this lane's 16 bytes inside (sample, channel block c0, plane 0), or -1: zeros
+#pragma unroll
+  for (int i = 0; i < kT1PW; ++i) {
+    const int e = (wv * kT1PW + i) * 64 + lane;
+    const int c = e / (kT1Rows * kT1F4), r = (e / kT1F4) % kT1Rows, j = e % kT1F4;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * j;
+    const bool ok = c < kT1CH && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+    off[i] = ok ? (long)c * S + (long)gy * W + gx : -1;
+  }
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const int zi = z_lo + s / ncc, c0 = (s % ncc) * kT1CH;
+    const float* pb = xn + (long)c0 * S + (long)zi * HW;
+    const unsigned slot = ring_addr + (unsigned)((s % kT1NB) * kT1Slot * 4 + wv * kT1PW * 1024);
+#pragma unroll
+    for (int i = 0; i < kT1PW; ++i) nc_dma_lds16(off[i] >= 0 ? (const void*)(pb + off[i]) : (const void*)zeros, slot + i * 1024);
+  };
+
+  float acc[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[a][i] = 0.f;
+
+  issue(0);
+  if (nst > 1) issue(1);
+  for (int s = 0; s < nst; ++s) {
+    // this wave's pieces of stage s are in: everything but the youngest kT1PW requests (stage s + 1; result stores in between only make the
+    // wait cover more) -- then everybody's, and everybody is done with the slot of stage s - 1, which stage s + 2 is requested into
+    if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kT1PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s + 2 < nst) issue(s + 2);
+    const int zi = z_lo + s / ncc, cc = s % ncc;
+    const float* base = ring + (s % kT1NB) * kT1Slot + ty * kT1Pitch + 4 * tx + 3;
+#pragma unroll 1
+    for (int c = 0; c < kT1CH; ++c) {
+      const float* wc = w + (long)(cc * kT1CH + c) * 27;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* rp = base + (c * kT1Rows + dy) * kT1Pitch;
+        float row[6];
+        row[0] = rp[0];
+        const float4 m = *reinterpret_cast<const float4*>(rp + 1);
+        row[1] = m.x; row[2] = m.y; row[3] = m.z; row[4] = m.w;
+        row[5] = rp[5];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float wv1 = wc[(dz * 3 + dy) * 3 + dx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[2 - dz][i] = fmaf(wv1, row[i + dx], acc[2 - dz][i]);
+          }
+      }
+    }
+    if (cc == ncc - 1) {
+      const int gy = y0 + ty, gx = x0 + 4 * tx;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int zo = zi - 1 + a;
+        if ((a == 0 || zi == D - 1) && zo >= zb && zo < ze && gy < H && gx < W)
+          *reinterpret_cast<float4*>(y + (long)n * S + (long)zo * HW + (long)gy * W + gx) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = 0.f; }
+    }
+  }
+}
+
+__global__ void k_to1_sum_parts(const float4* __restrict__ part, float4* __restrict__ y, long n4, int G) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 a = part[i];
+    for (int g = 1; g < G; ++g) { const float4 b = part[(long)g * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    y[i] = a;
+  }
+}
+
+size_t conv_fwd_to1_k3_ws_bytes(int N, int D, int H, int W) { return (size_t)4 * N * D * H * W * sizeof(float) + 256; }
+
+int conv_fwd_to1_k3(const float* x, const float* w, float* y, int N, int C, int D, int H, int W, void* ws, size_t wsb, hipStream_t s) {
+  if (N > 65535) { set_error("conv_fwd_to1_k3: more than 65535 samples"); return NC_ERR_SHAPE; }
+  if (C % kT1CH) {  // (not the tail's shape: the general tile kernel)
+    const int ntx = (W + 63) / 64, nty = (H + 7) / 8, ntz = (D + 7) / 8;
+    hipLaunchKernelGGL(k_conv_to1<3>, dim3((unsigned)(ntx * nty * ntz), (unsigned)N), dim3(256), 0, s, x, w, (const float*)nullptr, y, C, D, H, W, 0);
+    return check_launch("conv_fwd_to1_k3");
+  }
+  const int ntx = (W + kT1TX - 1) / kT1TX, nty = (H + kT1TY - 1) / kT1TY;
+  // plane ranges: one round of the chip per channel group (measured at 108^3: 256 -> 216 us, 128 -> 264, 512 -> 245), at least 4 planes each (a
+  // range reads 2 planes more than it writes)
+  static const int want = getenv("NC_T1_WGS") ? atoi(getenv("NC_T1_WGS")) : 256;
+  int nz = (int)((want + (long)ntx * nty * N - 1) / ((long)ntx * nty * N));
+  if (nz > D / 4) nz = D / 4;
+  if (nz < 1) nz = 1;
+  const int zc = (D + nz - 1) / nz;
+  nz = (D + zc - 1) / zc;
+  const dim3 grid((unsigned)(ntx * nty * nz), (unsigned)N);
+  static const bool dma = !(getenv("NC_T1_DMA") && atoi(getenv("NC_T1_DMA")) == 0);
+  if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
+    const float* zeros = nc_zero_page();
+    if (dma && zeros) {
+      // channel groups (partial volumes, added in a fixed order): four times the workgroups without reading anything twice -- y has ONE channel
+      static const int gwant = getenv("NC_T1_G") ? atoi(getenv("NC_T1_G")) : 4;
+      int G = gwant;
+      const long n4 = (long)N * D * H * W / 4;
+      while (G > 1 && (C % (G * kT1CH) || !ws || wsb < (size_t)G * n4 * 16)) G >>= 1;
+      if (int e = raise_dyn_lds(k_conv_to1_k3_dma, kT1NB * kT1Slot * 4, "conv_fwd_to1_k3")) return e;
+      hipLaunchKernelGGL(k_conv_to1_k3_dma, dim3(grid.x, grid.y, (unsigned)G), dim3(256), kT1NB * kT1Slot * 4, s, x, w, G > 1 ? (float*)ws : y, zeros, C, D, H, W,
+                         nty, ntx, zc);
+      if (G > 1) hipLaunchKernelGGL(k_to1_sum_parts, dim3(1024), dim3(256), 0, s, (const float4*)ws, (float4*)y, n4, G);
+    } else {
+      hipLaunchKernelGGL(k_conv_to1_k3<true>, grid, dim3(256), 0, s, x, w, y, C, D, H, W, nty, ntx, zc);
+    }
+  } else {
+    hipLaunchKernelGGL(k_conv_to1_k3<false>, grid, dim3(256), 0, s, x, w, y, C, D, H, W, nty, ntx, zc);
+  }
+  return check_launch("conv_fwd_to1_k3");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 // Parameter blob = the tensors in state-dict order, packed back to back.  `saved` receives what the
 // backward needs (raw conv outputs, activations, InstanceNorm statistics); sizes from the *_saved_floats queries.
 
+#include <atomic>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -395,6 +396,104 @@ struct LPlan {
   size_t conv_ws;
 };
 
+// ---- the collapsed tail ----------------------------------------------------------------------------------------------------------------
+// Layers 2 .. 5 (3^3 64 -> 64, then 1 x 1: 64 -> 32 -> 16 -> 1; reference networks.py:902-911) have no bias and nothing between them, and the
+// 1 x 1 layers need no padding, so with  a = W5 W4 (1 x 32),  e = a W3 (1 x 64)  and  E[c][t] = sum_k e[k] W2[k][c][t]:
+//     y = E (*) act1                                   ONE 64 -> 1 convolution, 3^3, padding 1 -- exact at the borders too: the only padded
+//                                                      tensor of the four layers is act1 itself
+//     dL/dact1 = flip(E) (*) dy                        a 1 -> 64 convolution of the one-channel dy
+//     q[c][t]  = sum_v dy[v] act1[c][v + t - 1]        64 x 27 numbers: a weight gradient with ONE "output" channel
+//     dW2[k][c][t] = e[k] q[c][t];   r = sum_{c,t} W2[.][c][t] q[c][t]  (= sum_v dy[v] act2[.][v]);   dW3 = a^T r^T;   s = W3 r;
+//     dW4 = W5^T s^T;   dW5 = (W4 s)^T
+// -- the same output and the same six parameter gradients as the layer-by-layer evaluation (every product of the chain rule is there, the
+// rank-one factors are simply never expanded over the voxels), at 2 x 27 x 64 instead of 2 x (27 x 64 x 64 + 64 x 32 + 32 x 16 + 16) MACs per
+// voxel and direction, and act2 .. act4 are neither written nor read.  The weight-space products run in fp64.  Numerically this is at least
+// as close to the exact result as the fp32 chain (tests/test_gpu_nets.py: against the fp64 oracle, and against the layered path).
+// nc_set_dl_collapse(0) / NC_DL_COLLAPSE=0: the layered evaluation.  The forward records its choice in `kept` (bit 31): the backward of a
+// collapsed forward is collapsed whatever the switch says by then (act2 .. act4 do not exist).
+struct LTail {  // byte offsets into the tail scratch
+  static constexpr size_t a = 0, e = 32 * 8, r = e + 64 * 8, E = r + 64 * 8, Ef = E + 1728 * 4, q = Ef + 1728 * 4, bytes = q + 1728 * 4 + 256;
+};
+constexpr unsigned kKeptCollapsed = 1u << 31;
+
+// (8 workgroups, each derives a and e for itself and 216 of E's 1728 entries; loops unrolled so that the loads of a sum are in flight together)
+__global__ void __launch_bounds__(256) k_dl_compose(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ w4,
+                                                    const float* __restrict__ w5, char* __restrict__ tail) {
+  __shared__ double sa[32], se[64];
+  const int t = threadIdx.x;
+  if (t < 32) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += (double)w5[i] * (double)w4[i * 32 + t];
+    sa[t] = v;
+    if (blockIdx.x == 0) ((double*)(tail + LTail::a))[t] = v;
+  }
+  __syncthreads();
+  if (t < 64) {
+    double v = 0.0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) v += sa[b] * (double)w3[b * 64 + t];
+    se[t] = v;
+    if (blockIdx.x == 0) ((double*)(tail + LTail::e))[t] = v;
+  }
+  __syncthreads();
+  if (t < 216) {
+    const int i = blockIdx.x * 216 + t;  // i = c * 27 + tap
+    double v = 0.0;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) v += se[k] * (double)w2[(long)k * 1728 + i];
+    const int c = i / 27, tap = i - c * 27;
+    ((float*)(tail + LTail::E))[i] = (float)v;
+    ((float*)(tail + LTail::Ef))[c * 27 + 26 - tap] = (float)v;
+  }
+}
+
+// block k: dW2[k][.][.] and r[k].  qf = the weight gradient of the SWAPPED problem (x := dy, dY := act1): qf[c][t] = q[c][26 - t]
+__global__ void __launch_bounds__(256) k_dl_tail_w2(const float* __restrict__ w2, char* __restrict__ tail, float* __restrict__ dw2) {
+  __shared__ double red[256];
+  const int k = blockIdx.x, t = threadIdx.x;
+  const float* qf = (const float*)(tail + LTail::q);
+  const double ek = ((const double*)(tail + LTail::e))[k];
+  double part = 0.0;
+  for (int i = t; i < 1728; i += 256) {
+    const int c = i / 27, tap = i - c * 27;
+    const double q = (double)qf[c * 27 + 26 - tap];
+    dw2[(long)k * 1728 + i] = (float)(ek * q);
+    part += (double)w2[(long)k * 1728 + i] * q;
+  }
+  red[t] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) ((double*)(tail + LTail::r))[k] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_dl_tail_w345(const float* __restrict__ w3, const float* __restrict__ w4, const float* __restrict__ w5,
+                                                      const char* __restrict__ tail, float* __restrict__ dw3, float* __restrict__ dw4,
+                                                      float* __restrict__ dw5) {
+  __shared__ double ss[32];
+  const int t = threadIdx.x;
+  const double* a = (const double*)(tail + LTail::a);
+  const double* r = (const double*)(tail + LTail::r);
+  for (int i = t; i < 32 * 64; i += 256) dw3[i] = (float)(a[i / 64] * r[i % 64]);
+  if (t < 32) {
+    double v = 0.0;
+    for (int c = 0; c < 64; ++c) v += (double)w3[t * 64 + c] * r[c];
+    ss[t] = v;
+  }
+  __syncthreads();
+  for (int i = t; i < 16 * 32; i += 256) dw4[i] = (float)((double)w5[i / 32] * ss[i % 32]);
+  if (t < 16) {
+    double v = 0.0;
+    for (int b = 0; b < 32; ++b) v += (double)w4[t * 32 + b] * ss[b];
+    dw5[t] = (float)v;
+  }
+}
+
+std::atomic<int> g_dl_collapse{getenv("NC_DL_COLLAPSE") ? (atoi(getenv("NC_DL_COLLAPSE")) != 0) : 1};
+
 bool l_plan(LPlan& p, int N, int S0, int S1, int S2) {
   if (N < 1 || S0 < 1 || S1 < 1 || S2 < 1) return false;
   p = LPlan{};
@@ -416,6 +515,9 @@ bool l_plan(LPlan& p, int N, int S0, int S1, int S2) {
     const size_t b = nc_conv_ws_bytes(N, kLL[i].C, S0, S1, S2, kLL[i].K, kLL[i].k, kLL[i].k, kLL[i].k, 1, kLL[i].k / 2);
     if (b > p.conv_ws) p.conv_ws = b;
   }
+  const size_t b1 = nc_conv_ws_bytes(N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1);  // the collapsed tail's two one-channel problems
+  if (b1 > p.conv_ws) p.conv_ws = b1;
+  if (conv_fwd_to1_k3_ws_bytes(N, S0, S1, S2) > p.conv_ws) p.conv_ws = conv_fwd_to1_k3_ws_bytes(N, S0, S1, S2);
   return true;
 }
 
@@ -436,8 +538,11 @@ size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2) {
 
 size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2) {
   LPlan p;
-  return l_plan(p, N, S0, S1, S2) ? align256(p.conv_ws) + p.grads * sizeof(float) + 256 : 0;
+  return l_plan(p, N, S0, S1, S2) ? align256(p.conv_ws) + p.grads * sizeof(float) + 256 + LTail::bytes : 0;
 }
+
+void nc_set_dl_collapse(int on) { g_dl_collapse.store(on != 0, std::memory_order_relaxed); }
+int nc_get_dl_collapse(void) { return g_dl_collapse.load(std::memory_order_relaxed); }
 
 // saved == NULL: inference -- the intermediate activations ping-pong through the workspace instead
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved, int N, int S0, int S1, int S2, void* ws,
@@ -452,7 +557,17 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
   const float* in = x;
   unsigned kept_mask = 0;
   if (kept) *kept = 0;
+  const bool collapse = g_dl_collapse.load(std::memory_order_relaxed) != 0;
+  char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
+  hipStream_t hs = (hipStream_t)stream;
   for (int i = 0; i < 6; ++i) {
+    if (collapse && i == 2) {  // layers 2 .. 5 as one 64 -> 1 convolution of act1 (see "the collapsed tail" above)
+      hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
+      NC_TRY(check_launch("deep_linear_fwd: compose"));
+      NC_TRY(conv_fwd_to1_k3(in, (const float*)(tail + LTail::E), y, N, 64, S0, S1, S2, cws, p.conv_ws, hs));
+      kept_mask |= kKeptCollapsed;
+      break;
+    }
     const LLayer& l = kLL[i];
     float* out = i == 5 ? y : (saved ? saved + p.act[i] : G + p.g[i & 1]);
     bool kept = false;
@@ -482,7 +597,25 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
   float* G = (float*)((char*)ws + align256(p.conv_ws));
   const float* g = dy;
   const unsigned kept_mask = kept;
-  for (int i = 5; i >= 0; --i) {
+  int top = 5;
+  if (kept_mask & kKeptCollapsed) {  // the forward left no act2 .. act4: layers 2 .. 5 from dy, act1 and the weights alone
+    hipStream_t hs = (hipStream_t)stream;
+    char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
+    const float* act1 = saved + p.act[1];
+    hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
+    NC_TRY(check_launch("deep_linear_bwd: compose"));
+    // q (tap-flipped): the weight gradient of Conv3d(1, 64, 3) with x := dy and dY := act1
+    NC_TRY(nc_conv_wgrad(dy, act1, (float*)(tail + LTail::q), nullptr, N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    hipLaunchKernelGGL(k_dl_tail_w2, dim3(64), dim3(256), 0, hs, params + p.w[2], tail, dparams + p.w[2]);
+    hipLaunchKernelGGL(k_dl_tail_w345, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (const char*)tail, dparams + p.w[3],
+                       dparams + p.w[4], dparams + p.w[5]);
+    NC_TRY(check_launch("deep_linear_bwd: tail gradients"));
+    // dL/dact1 = flip(E) (*) dy
+    NC_TRY(nc_conv_fwd(dy, (const float*)(tail + LTail::Ef), nullptr, G + p.g[0], N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    g = G + p.g[0];
+    top = 1;
+  }
+  for (int i = top; i >= 0; --i) {
     const LLayer& l = kLL[i];
     const float* in = i == 0 ? x : saved + p.act[i - 1];
     float* gin = i == 0 ? dx : G + p.g[i & 1];

@@ -604,6 +604,58 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
     assert torch.equal(xi.grad, xa)
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 16, 16, 16), (2, 1, 9, 14, 21), (1, 1, 12, 20, 24), (1, 1, 36, 36, 36)])
+@pytest.mark.parametrize('want_dx', [False, True])
+@pytest.mark.parametrize('terms', [3, 2])
+def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, terms):
+    """nc_set_dl_collapse(1) (default): layers 2 .. 5 of deep_linear_gen (reference networks.py:902-911: Conv3d 3^3 64 -> 64, then 1 x 1
+    64 -> 32 -> 16 -> 1, no bias, nothing in between) as ONE 64 -> 1 convolution forward, and backward every parameter gradient of the four
+    layers plus dL/dact1 from dy, act1 and the weights (csrc/gen_nets.hip).  Exact algebra: output, input gradient and all six parameter
+    gradients equal the layered evaluation to fp32 rounding -- shapes the one-channel kernels cover and shapes they do not, batches, odd sizes."""
+    from neuroclear_amd._lib import lib
+    prev = lib().nc_get_split_terms(), lib().nc_get_dl_collapse()
+    lib().nc_set_split_terms(terms)
+    net = load(networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0]), S.deep_linear_spec(), 32)
+    x0 = torch.from_numpy(rnd(41, shape)).to(DEV)
+    r = torch.from_numpy(rnd(42, shape)).to(DEV)
+
+    def run(collapse):
+        lib().nc_set_dl_collapse(collapse)
+        assert lib().nc_get_dl_collapse() == collapse
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(want_dx)
+        y = net(x)
+        (y * r).sum().backward()
+        with torch.no_grad():
+            yi = net(x0)  # the inference form (saved == NULL)
+        return y.detach().clone(), yi, (x.grad.clone() if want_dx else None), [p.grad.clone() for p in net.parameters()]
+
+    try:
+        ya, ia, xa, ga = run(0)
+        yb, ib, xb, gb = run(1)
+        scale = float(ya.abs().max())
+        # (the layered fp32 chain itself is ~2e-6 of the largest output away from fp64; the collapsed form is closer: tests/test_gpu_grad_fp64.py)
+        assert float((ya - yb).abs().max()) <= 1e-5 * scale, float((ya - yb).abs().max()) / scale
+        assert torch.equal(yb, ib) and torch.equal(ya, ia)
+        if want_dx:
+            assert rel2(xb.cpu().numpy(), xa.cpu().numpy()) < 1e-5
+        for (n, _), a, b in zip(net.named_parameters(), ga, gb):
+            assert rel2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5, (n, rel2(b.cpu().numpy(), a.cpu().numpy()))
+        # the switch at backward time does not matter: the forward's choice travels with its saved tensors
+        lib().nc_set_dl_collapse(1)
+        for p in net.parameters():
+            p.grad = None
+        y = net(x0.clone().requires_grad_(False))
+        lib().nc_set_dl_collapse(0)
+        (y * r).sum().backward()
+        for (n, _), b, c in zip(net.named_parameters(), gb, [p.grad for p in net.parameters()]):
+            assert torch.equal(b, c), n
+    finally:
+        lib().nc_set_split_terms(prev[0])
+        lib().nc_set_dl_collapse(prev[1])
+
+
 @pytest.mark.parametrize('kind,shape', [('unet', (1, 1, 16, 16, 16)), ('unet', (2, 1, 12, 20, 24)), ('unet', (3, 1, 8, 8, 36)),
                                         ('linear', (1, 1, 16, 16, 16)), ('linear', (2, 1, 9, 14, 21))])
 @pytest.mark.parametrize('want_dx', [False, True])
@@ -615,8 +667,10 @@ def test_generator_whole_net_entries_match_layer_by_layer(kind, shape, want_dx, 
     BIT-identical -- batches included (per-sample sub-ranges of the concat buffers)."""
     from neuroclear_amd._lib import lib
     prev_terms = lib().nc_get_split_terms()
+    prev_collapse = lib().nc_get_dl_collapse()
     lib().nc_set_split_terms(terms)
-    request_restore = lambda: lib().nc_set_split_terms(prev_terms)
+    lib().nc_set_dl_collapse(0)  # (the collapsed tail of deep_linear_gen is the whole-network call's own arithmetic: its test is below)
+    request_restore = lambda: (lib().nc_set_split_terms(prev_terms), lib().nc_set_dl_collapse(prev_collapse))
     if kind == 'unet':
         net = load(networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0]),
                    S.unet_deconv_spec(), 31)
