@@ -749,57 +749,72 @@ int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
 }
 
 // ---- InstanceNorm statistics from the ST epilogue: per (sample, channel) the partial sums of every (tile, wave) that holds the channel, in
-// tile order, in fp64.  One workgroup per (channel, sample).
+// fp64 and in a fixed order.  A record (one wave's 32 channels x (sum, sum of squares)) is 256 contiguous bytes, read by 32 lanes: workgroup
+// (wave slice of 32 channels, sample, one of kStatChunks ranges of the records) walks its range with 8 lane groups interleaved and leaves
+// 32 x (s, q) in fp64; k_s3x_stats_final adds the chunks in order.  (First version: one workgroup per channel reading 8 bytes out of every
+// record -- 19 us per call at 140^3, a whole 64-byte sector fetched per 8 bytes used.)
+constexpr int kStatChunks = 16;
 struct XStatsPlan {
   int N, K, KT, TPP, D, HP;
   long full, main_count;   // main tiles in whole rounds / tiles of the first launch (full, or all when the left-over tiles are whole tiles)
   int fsub, PTsub;         // second launch: sub-tiles per main tile, positions per sub-tile
 };
-__global__ void __launch_bounds__(256) k_s3x_stats_finalize(const float2* __restrict__ part, XStatsPlan pl, const float* __restrict__ bias, long S,
-                                                            float eps, float* __restrict__ mean, float* __restrict__ rstd) {
-  const int c = blockIdx.x, n = blockIdx.y;
-  const int cot = c / 64, half = (c % 64) / 32, j32 = c % 32;
-  // lane (g, m16 < 8) of a wave holds channel half*32 + 4g + 16 (m16 / 4) + m16 % 4
-  const int g = (j32 % 16) / 4, m = (j32 / 16) * 4 + j32 % 4;
+__global__ void __launch_bounds__(256) k_s3x_stats_partial(const float2* __restrict__ part, XStatsPlan pl, double2* __restrict__ chunk_sums) {
+  const int slice = blockIdx.x, n = blockIdx.y, ch = blockIdx.z;  // slice = cot * 2 + half: channels slice * 32 .. + 31
+  const int cot = slice >> 1, half = slice & 1;
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;  // l: position of the channel inside the record (lane (g, m16 < 8) -> g * 8 + m16)
   const long per_n = (long)pl.TPP * pl.D;
   double s = 0.0, q = 0.0;
   // record (tile index u of this (n, cot), position group pg): 4 per main tile, 4 * fsub per left-over tile -- walked in a fixed order
-  const long nrec = per_n * 4;
-  for (long r = threadIdx.x; r < nrec; r += 256) {
+  const long nrec = per_n * 4, per = (nrec + kStatChunks - 1) / kStatChunks;
+  const long r1 = (ch + 1) * per < nrec ? (ch + 1) * per : nrec;
+  for (long r = ch * per + grp; r < r1; r += 8) {
     const long u = r >> 2;
     const int pg = (int)(r & 3);
     const long t = ((long)n * per_n + u) * pl.KT + cot;  // main tile index (x_decode: output-channel tile fastest)
     if (t < pl.main_count) {
-      const float2 v = part[((t * kWaves) + pg * 2 + half) * 32 + g * 8 + m];
+      const float2 v = part[((t * kWaves) + pg * 2 + half) * 32 + l];
       s += (double)v.x; q += (double)v.y;
     } else {
       // the tile's in-plane index, as x_decode orders it (groups of kXGroup neighbours x planes)
       const int full_g = (pl.TPP / kXGroup) * kXGroup * pl.D;
       int tp;
-      if (u < full_g) { const long grp = u / (kXGroup * pl.D), rem = u - grp * (kXGroup * pl.D); tp = (int)(grp * kXGroup + (rem % kXGroup)); }
+      if (u < full_g) { const long g4 = u / (kXGroup * pl.D), rem = u - g4 * (kXGroup * pl.D); tp = (int)(g4 * kXGroup + (rem % kXGroup)); }
       else { const int L = pl.TPP % kXGroup; const long v2 = u - full_g; tp = (pl.TPP / kXGroup) * kXGroup + (int)(v2 % L); }
       for (int sub = 0; sub < pl.fsub; ++sub) {
         if ((long)(tp * pl.fsub + sub) * pl.PTsub >= pl.HP) continue;  // a sub-tile that starts beyond the plane was never run
         const long ti = pl.main_count + (t - pl.full) * pl.fsub + sub;
-        const float2 v = part[((ti * kWaves) + pg * 2 + half) * 32 + g * 8 + m];
+        const float2 v = part[((ti * kWaves) + pg * 2 + half) * 32 + l];
         s += (double)v.x; q += (double)v.y;
       }
     }
   }
-  __shared__ double rs[256], rq[256];
-  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+  __shared__ double rs[8][32], rq[8][32];
+  rs[grp][l] = s; rq[grp][l] = q;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rq[threadIdx.x] += rq[threadIdx.x + o]; }
-    __syncthreads();
+  if (grp == 0) {
+    for (int g = 1; g < 8; ++g) { s += rs[g][l]; q += rq[g][l]; }
+    chunk_sums[(((long)n * gridDim.x + slice) * kStatChunks + ch) * 32 + l] = make_double2(s, q);
   }
-  if (threadIdx.x == 0) {
-    const double m0 = rs[0] / (double)S;
-    double var = rq[0] / (double)S - m0 * m0;
-    if (var < 0.0) var = 0.0;
-    mean[(long)n * pl.K + c] = (float)(m0 + (bias ? (double)bias[c] : 0.0));
-    rstd[(long)n * pl.K + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ void __launch_bounds__(256) k_s3x_stats_final(const double2* __restrict__ chunk_sums, int K, const float* __restrict__ bias, long S, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;  // i = slice * 32 + record position
+  if (i >= K) return;
+  const int slice = i >> 5, l = i & 31;
+  double s = 0.0, q = 0.0;
+  for (int ch = 0; ch < kStatChunks; ++ch) {
+    const double2 v = chunk_sums[(((long)n * (K / 32) + slice) * kStatChunks + ch) * 32 + l];
+    s += v.x; q += v.y;
   }
+  // record position l = g * 8 + m16 holds channel half*32 + 4g + 16 (m16 / 4) + m16 % 4 of its 64-channel tile
+  const int g4 = l >> 3, m = l & 7;
+  const int c = (slice >> 1) * 64 + (slice & 1) * 32 + 4 * g4 + 16 * (m >> 2) + (m & 3);
+  const double m0 = s / (double)S;
+  double var = q / (double)S - m0 * m0;
+  if (var < 0.0) var = 0.0;
+  mean[(long)n * K + c] = (float)(m0 + (bias ? (double)bias[c] : 0.0));
+  rstd[(long)n * K + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 }  // namespace
@@ -878,12 +893,15 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
 
 // ST epilogue (see k_conv_s3x): bytes of the partial-sum records of one two-term launch pair, and the pass that turns them into mean / rstd
 // (mean gets the bias back: the records are sums of bias-free outputs).  The geometry is recomputed from the same planner the launch used.
+static size_t s3x_record_bytes(const XPlan& pl) {
+  const bool one = pl.rem && pl.fsub == 1;
+  const long recs = pl.full + (one ? pl.rem : pl.rem * pl.fsub);
+  return ((size_t)recs * kWaves * 32 * sizeof(float2) + 255) & ~(size_t)255;
+}
 size_t s3x_stats_bytes(int N, int D, int H, int W, int Kout, int KS) {
   const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
   if (!pl.ok) return 0;
-  const bool one = pl.rem && pl.fsub == 1;
-  const long recs = pl.full + (one ? pl.rem : pl.rem * pl.fsub);
-  return (size_t)recs * kWaves * 32 * sizeof(float2);
+  return s3x_record_bytes(pl) + (size_t)N * Kout * kStatChunks * sizeof(double2);  // records, then the chunk sums of the finalisation
 }
 int s3x_stats_finalize(const float* stats_part, const float* bias, int N, int D, int H, int W, int Kout, int KS, float eps, float* mean, float* rstd,
                        hipStream_t s) {
@@ -894,8 +912,10 @@ int s3x_stats_finalize(const float* stats_part, const float* bias, int N, int D,
   sp.N = N; sp.K = Kout; sp.KT = Kout / 64; sp.TPP = pl.TPP; sp.D = D; sp.HP = pl.HP;
   sp.full = pl.full; sp.main_count = pl.full + (one ? pl.rem : 0);
   sp.fsub = one ? 1 : pl.fsub; sp.PTsub = 64 * pl.NCB / (one ? 1 : pl.fsub);
-  hipLaunchKernelGGL(k_s3x_stats_finalize, dim3((unsigned)Kout, (unsigned)N), dim3(256), 0, s, (const float2*)stats_part, sp, bias,
-                     (long)D * H * W, eps, mean, rstd);
+  double2* chunk_sums = (double2*)((char*)const_cast<float*>(stats_part) + s3x_record_bytes(pl));
+  hipLaunchKernelGGL(k_s3x_stats_partial, dim3((unsigned)(Kout / 32), (unsigned)N, kStatChunks), dim3(256), 0, s, (const float2*)stats_part, sp, chunk_sums);
+  hipLaunchKernelGGL(k_s3x_stats_final, dim3((unsigned)cdiv(Kout, 256), (unsigned)N), dim3(256), 0, s, (const double2*)chunk_sums, Kout, bias, (long)D * H * W,
+                     eps, mean, rstd);
   return check_launch("s3x_stats_finalize");
 }
 
