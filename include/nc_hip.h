@@ -414,6 +414,12 @@ int nc_get_conv_split(void);
  * forward and its backward (the backward then re-converts what the forward kept). */
 void nc_set_split_terms(int terms);
 int nc_get_split_terms(void);
+/* The PatchGAN's 4 x 4 layers at Athena's batches (csrc/conv_p2d.hip; reference networks.py:1030-1057): 1 (default; NC_P2D_TERMS at load time): the
+ * stride-1 256 -> 512 layer's forward and data gradient on the two-term form whenever nc_get_split_terms() == 2 (a measured power of two per
+ * call: results depend in the last bit on which planes share a call); 3: three-term everywhere (bit-identical however the planes are batched);
+ * 2: two-term for the stride-2 layers too (slower: their conversion dominates). */
+void nc_set_p2d_terms(int mode);
+int nc_get_p2d_terms(void);
 /* The RANGE GUARD of the two-term form (round 5; csrc/h2.hip, csrc/common.hpp): wherever a call converts an fp32 operand ITSELF with a measured
  * power of two -- nc_conv_fwd / _dgrad / _wgrad / _bwd and every dY of the whole-network backward calls that arrives as fp32 -- the conversion
  * pass also counts the CHUNKS (64 voxels x 8 channels) whose largest magnitude lies below 2^-17 of the tensor's; when more than 1/64 of the

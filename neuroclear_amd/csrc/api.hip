@@ -167,6 +167,8 @@ static std::atomic<int> g_epi_stats{getenv("NC_EPI_STATS") ? (atoi(getenv("NC_EP
 static bool epi_stats_on() { return g_epi_stats.load(std::memory_order_relaxed) != 0; }
 void nc_set_epi_stats(int on) { g_epi_stats.store(on != 0, std::memory_order_relaxed); }
 int nc_get_epi_stats(void) { return g_epi_stats.load(std::memory_order_relaxed); }
+void nc_set_p2d_terms(int mode) { p2d_set_terms(mode); }
+int nc_get_p2d_terms(void) { return p2d_get_terms(); }
 void nc_set_h2_guard(int on) { h2_guard_set(on); }
 int nc_get_h2_guard(void) { return h2_guard_mode(); }
 int nc_h2_guard_stats(unsigned long long* out4, int reset) {

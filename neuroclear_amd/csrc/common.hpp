@@ -125,6 +125,8 @@ bool sconv_fwd_supported(const ConvDims& d);
 bool sconv_dgrad_supported(const ConvDims& d);
 size_t sconv_ws_bytes(const ConvDims& d);
 // conv_p2d.hip: the PatchGAN's 4 x 4 stride-1 layer at Athena's batches on the split-operand arithmetic (forward, data gradient)
+void p2d_set_terms(int m);
+int p2d_get_terms();
 bool p2d_fwd_supported(const ConvDims& d);
 bool p2d_dgrad_supported(const ConvDims& d);
 size_t p2d_ws_bytes(const ConvDims& d);

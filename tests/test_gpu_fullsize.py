@@ -311,15 +311,33 @@ def test_athena_step_108_streams_tuner_and_shared_pass_agree(monkeypatch):
     streams vs one, (b) the tile-shape tuner on vs the fixed heuristic, (c) the shared pass over the fake planes vs both passes run.
     Every tile shape accumulates in the same order, no kernel uses atomics and the shared pass evaluates the same planes through the
     same weights, so every loss and every updated parameter must be BIT-equal -- a missing stream event, a scratch buffer shared
-    between streams or a tuner launch that leaks into results shows up here, where it cannot at the 36^3 of the golden step."""
-    base, p0 = _athena_108(monkeypatch, True, True, True)
-    assert all(np.isfinite(list(s.values())).all() for s in base)
-    for ds, ru, tu in ((False, True, True), (True, True, False), (True, False, True)):
-        other, p1 = _athena_108(monkeypatch, ds, ru, tu)
-        for it in range(2):
-            for k in base[it]:
-                assert base[it][k] == other[it][k], (ds, ru, tu, it, k, base[it][k], other[it][k])
-        assert torch.equal(p0, p1), (ds, ru, tu)
+    between streams or a tuner launch that leaks into results shows up here, where it cannot at the 36^3 of the golden step.
+    (a) and (b) hold in the default arithmetic.  (c) holds bit for bit with the PatchGAN layers on the three-term form (nc_set_p2d_terms(3));
+    the default since round 5 -- the stride-1 layer on two fp16 terms of the tensor times a power of two MEASURED per call -- sees another
+    power of two when 216 planes share the call than when 108 do: same planes, results equal to fp32 rounding."""
+    from neuroclear_amd._lib import lib
+    prev = lib().nc_get_p2d_terms()
+    try:
+        for mode in (prev, 3):
+            lib().nc_set_p2d_terms(mode)
+            base, p0 = _athena_108(monkeypatch, True, True, True)
+            assert all(np.isfinite(list(s.values())).all() for s in base)
+            cases = ((False, True, True), (True, True, False), (True, False, True)) if mode == prev else ((True, False, True),)
+            for ds, ru, tu in cases:
+                other, p1 = _athena_108(monkeypatch, ds, ru, tu)
+                exact = mode == 3 or ru
+                for it in range(2):
+                    for k in base[it]:
+                        if exact:
+                            assert base[it][k] == other[it][k], (mode, ds, ru, tu, it, k, base[it][k], other[it][k])
+                        else:
+                            assert abs(base[it][k] - other[it][k]) <= 2e-5 * max(abs(base[it][k]), 1e-3), (mode, it, k, base[it][k], other[it][k])
+                if exact:
+                    assert torch.equal(p0, p1), (mode, ds, ru, tu)
+                else:  # (Adam's first steps move every weight by ~lr whatever the gradient's size: compare in the L2 norm of the update)
+                    assert float((p0 - p1).norm()) <= 2e-2 * 1e-4 * float(p0.numel()) ** 0.5, float((p0 - p1).norm())
+    finally:
+        lib().nc_set_p2d_terms(prev)
 
 
 def test_diced_inference_slab_mode_single_rank_is_bit_identical():

@@ -32,10 +32,26 @@ CASES = [  # B, C, K, H, W, stride
 ]
 
 
+@pytest.fixture(autouse=True)
+def _restore_terms():
+    a, b = L().nc_get_p2d_terms(), L().nc_get_split_terms()
+    yield
+    L().nc_set_p2d_terms(a)
+    L().nc_set_split_terms(b)
+
+
+@pytest.mark.parametrize('mode', [3, 1, 2])
 @pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
-def test_p2d_against_fp64(case):
+def test_p2d_against_fp64(case, mode):
+    """mode (nc_set_p2d_terms): 3 = three bf16 terms, six products (rounds 3-4); 1 (default) = the stride-1 layer on two fp16 terms of the tensor
+    times a measured power of two, three products; 2 = every layer on the two-term form.  Same criteria for all."""
     from neuroclear_amd import ops
     B, C, K, H, W, st = case
+    if mode == 1 and st != 1:
+        pytest.skip('mode 1 changes the stride-1 layer only')
+    L().nc_set_split_terms(2)
+    L().nc_set_p2d_terms(mode)
+    assert L().nc_get_p2d_terms() == mode
     g = torch.Generator(device=DEV).manual_seed(11)
     x = torch.randn(B, C, H, W, device=DEV, generator=g)
     w = torch.randn(K, C, 4, 4, device=DEV, generator=g) * 0.02
