@@ -443,7 +443,8 @@ int nc_h2_guard_stats(unsigned long long* out4, int reset);
 /* Epilogue statistics of the inference forward (round 5; csrc/conv_s3x.hip, template parameter ST): in nc_unet_deconv_fwd's two-term mode every
  * 3^3 convolution leaves, per (tile, wave), the sum and the sum of squares of its bias-free outputs, and a small pass adds them up in fp64 in a
  * fixed order -- InstanceNorm (reference networks.py:513-515, nn.InstanceNorm3d after every Conv3d) needs no pass of its own over the raw
- * output.  mean / rstd agree with the separate pass to 4e-8 relative.  1 (default; NC_EPI_STATS at load time) / 0: the separate pass. */
+ * output.  mean / rstd agree with the separate pass to 4e-8 relative.  1 (default; NC_EPI_STATS at load time); 0: the separate pass; 2: also in
+ * nc_unet_deconv_train_fwd's blocks whose input arrives converted (tested; no measurable gain in the training step, hence not the default). */
 void nc_set_epi_stats(int on);
 int nc_get_epi_stats(void);
 int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the

@@ -163,10 +163,8 @@ void nc_set_s3_fusion(int on) { g_s3_fuse = on; }
 int nc_get_conv_split(void) { return g_split; }
 void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
 int nc_get_split_terms(void) { return s3x_get_terms(); }
-static std::atomic<int> g_epi_stats{getenv("NC_EPI_STATS") ? (atoi(getenv("NC_EPI_STATS")) != 0) : 1};
-static bool epi_stats_on() { return g_epi_stats.load(std::memory_order_relaxed) != 0; }
-void nc_set_epi_stats(int on) { g_epi_stats.store(on != 0, std::memory_order_relaxed); }
-int nc_get_epi_stats(void) { return g_epi_stats.load(std::memory_order_relaxed); }
+void nc_set_epi_stats(int on) { epi_stats_set(on); }
+int nc_get_epi_stats(void) { return epi_stats_mode(); }
 void nc_set_p2d_terms(int mode) { p2d_set_terms(mode); }
 int nc_get_p2d_terms(void) { return p2d_get_terms(); }
 void nc_set_h2_guard(int on) { h2_guard_set(on); }
@@ -438,12 +436,13 @@ bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks) {
 
 // forward of such a layer whose input already exists in S3 form (written by the producer: act_split3 / split3_into)
 int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks, void* ws,
-                 size_t ws_bytes, void* stream) {
+                 size_t ws_bytes, void* stream, float* stats_part) {
   ConvDims d;
   if (!xs || !w || !y) { set_error("conv_fwd_pre: null pointer"); return NC_ERR_ARG; }
   if (!make_dims(d, N, C, D, H, W, K, ks, ks, ks, 1, ks / 2) || fwd_path(d) != 9) { set_error("conv_fwd_pre: layer not on the split-operand kernels"); return NC_ERR_SHAPE; }
   ProfScope ps(0, 9, d, 0, (hipStream_t)stream);
-  return conv_fwd_s3(nullptr, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream, nullptr);
+  if (stats_part && !(conv_layer_h2(d) && ks == 3)) { set_error("conv_fwd_pre: epilogue statistics exist for the two-term 3^3 layers only"); return NC_ERR_ARG; }
+  return conv_fwd_s3(nullptr, xs, w, bias, y, d, ws, ws_bytes, (hipStream_t)stream, nullptr, stats_part);
 }
 
 // Can the backward of the layer take dY in S3 form at the head of its workspace (conv_bwd_pre)?  want_dx: the data gradient is needed too

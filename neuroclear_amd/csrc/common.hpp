@@ -205,7 +205,10 @@ int act_operand(const ConvDims& d, const float* x, const float* mean, const floa
 int act_split3(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S,
                int ctot, int c0, hipStream_t s);
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, void* xs_keep = nullptr);
+                hipStream_t s, void* xs_keep = nullptr, float* stats_part = nullptr);
+bool epi_stats_on();  // nc_set_epi_stats / NC_EPI_STATS (conv_s3x.hip)
+void epi_stats_set(int on);
+int epi_stats_mode();
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 size_t s3_bwd_ws_bytes(const ConvDims& d);
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,
@@ -279,8 +282,10 @@ int act_split2h(const float* x, const float* mean, const float* rstd, float slop
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s, const unsigned* guard = nullptr);
 bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);
+// stats_part (nullable; two-term 3^3 layers only -- conv_layer_h2): the convolution leaves the partial InstanceNorm sums of its output there
+// (s3x_stats_bytes; s3x_stats_finalize turns them into mean / rstd)
 int conv_fwd_pre(const void* xs, const float* w, const float* bias, float* y, int N, int C, int D, int H, int W, int K, int ks, void* ws,
-                 size_t ws_bytes, void* stream);
+                 size_t ws_bytes, void* stream, float* stats_part = nullptr);
 bool conv_bwd_pre_supported(int N, int C, int D, int H, int W, int K, int ks, bool want_dx, size_t ws_bytes);
 int conv_bwd_pre(const float* x, const void* xs, const float* w, float* dx, float* dw, int N, int C, int D, int H, int W, int K, int ks,
                  void* ws, size_t ws_bytes, void* stream, bool dy_guarded = false);

@@ -819,6 +819,13 @@ __global__ void __launch_bounds__(256) k_s3x_stats_final(const double2* __restri
 
 }  // namespace
 
+// 0: off; 1 (default): in the inference forward; 2: in the training forward too (measured: no gain there -- 33.95-34.08 against 33.83-34.01 ms per
+// step, the eight k_in_stats passes it removes cost what the epilogue and the two finalisation launches cost -- so it stays a tested option)
+static std::atomic<int> g_epi_stats{getenv("NC_EPI_STATS") ? atoi(getenv("NC_EPI_STATS")) : 1};
+bool epi_stats_on() { return g_epi_stats.load(std::memory_order_relaxed) != 0; }
+int epi_stats_mode() { return g_epi_stats.load(std::memory_order_relaxed); }
+void epi_stats_set(int on) { g_epi_stats.store(on < 0 ? 0 : on > 2 ? 2 : on, std::memory_order_relaxed); }
+
 size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
   const int NS = KS * KS * KS * (Cin / 8) / 4;
   return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024;

@@ -497,7 +497,8 @@ bool s3_layer_h2(const ConvDims& d);
 // xs_keep (only without xs_pre): the converted operand is written THERE instead of into the workspace -- the caller keeps it (the
 // weight gradient of the same layer wants the same S3 tensor)
 int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin, int Kout,
-           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr, bool h2 = false, unsigned* guard_pre = nullptr) {
+           long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* xs_keep = nullptr, bool h2 = false, unsigned* guard_pre = nullptr,
+           float* stats_part = nullptr) {
   const int KS = d.kd;
   const SPlan pl = s_plan(d.H, d.W, KS);
   const long S = (long)d.D * d.H * d.W;
@@ -529,8 +530,9 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
       if (dual)
         if (int e = split3_into(x, (long)Cin * S, xs, d.N, Cin, S, Cin, 0, s, gw)) return e;
     }
+    if (stats_part && dual) { set_error("conv_s3 (two-term): epilogue statistics need an operand that cannot fall back"); return NC_ERR_ARG; }
     if (int e = conv_s3x_h2(xs, cells, cells + 1, flip ? Cin : Cin / 2, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, gw + 16,
-                            (char*)ws + xb + 256, s, dual ? guard : nullptr)) return e;
+                            (char*)ws + xb + 256, s, dual ? guard : nullptr, stats_part)) return e;
     if (dual) return conv_s3x(xs, w, bias, y, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, (char*)ws + xb + 256, s, guard);
     return NC_OK;
   }
@@ -1572,9 +1574,9 @@ ForceThreeTerm::ForceThreeTerm() { ++tl_force3; }
 ForceThreeTerm::~ForceThreeTerm() { --tl_force3; }
 
 int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, float* y, const ConvDims& d, void* ws, size_t wsb,
-                hipStream_t s, void* xs_keep) {
+                hipStream_t s, void* xs_keep, float* stats_part) {
   const int T3 = d.kd * d.kh * d.kw;
-  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, xs_keep, s3_layer_h2(d));
+  return run_s3(x, xs, w, b, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, xs_keep, s3_layer_h2(d), nullptr, stats_part);
 }
 
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {

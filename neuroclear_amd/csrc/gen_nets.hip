@@ -82,6 +82,10 @@ bool u_plan(UPlan& p, int N, int S0, int S1, int S2) {
   for (int i = 0; i < 10; ++i) upd(kUB[i].C, kUB[i].K, kUB[i].lvl, 3);
   upd(64, 1, 0, 1); upd(1, 1, 0, 1);
   p.in_ws = nc_instnorm_bwd_dbias_ws_bytes(N * 256, (long)S);
+  for (int i = 1; i < 10; ++i) {  // the same region holds the partial sums of a block whose convolution takes its InstanceNorm statistics itself
+    const size_t b = s3x_stats_bytes(N, p.d[kUB[i].lvl][0], p.d[kUB[i].lvl][1], p.d[kUB[i].lvl][2], kUB[i].K, 3);
+    if (b > p.in_ws) p.in_ws = b;
+  }
   p.convT_ws = nc_convT_ws_bytes(N, 256, p.d[2][0], p.d[2][1], p.d[2][2], 128);
   const size_t c2 = nc_convT_ws_bytes(N, 128, p.d[1][0], p.d[1][1], p.d[1][2], 64);
   if (c2 > p.convT_ws) p.convT_ws = c2;
@@ -176,8 +180,13 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
     const UBlock& b = kUB[i];
     const int* d = p.d[b.lvl];
     const long S = p.S[b.lvl];
+    // Two-term form with the input already converted by its producer (a power of two known by construction: nothing can fall back): the
+    // convolution's epilogue can leave the partial InstanceNorm sums (conv_s3x.hip ST) instead of a statistics pass over its output --
+    // nc_set_epi_stats(2): an option, not the default (no measurable gain in the training step)
+    const bool epi = pre[i] && h2l[i] && epi_stats_mode() == 2 && s3x_stats_bytes(N, d[0], d[1], d[2], b.K, 3) && s3x_stats_bytes(N, d[0], d[1], d[2], b.K, 3) <= p.in_ws;
     if (pre[i]) {  // the producers left the S3 input in saved
-      NC_TRY(conv_fwd_pre(V + p.xs3[i], P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream));
+      NC_TRY(conv_fwd_pre(V + p.xs3[i], P + o.w[i], P + o.b[i], V + p.raw[i], N, b.C, d[0], d[1], d[2], b.K, 3, cws, p.conv_ws, stream,
+                          epi ? (float*)iws : nullptr));
       kept_mask |= 1u << i;
       if (h2l[i]) kept_mask |= 1u << (16 + i);  // (bits 16..: the kept copy is an H2 tensor -- a backward under another setting of the switch ignores it)
     } else {
@@ -187,7 +196,8 @@ int nc_unet_deconv_train_fwd(const float* params, const float* x, float* y, floa
       if (kept1) kept_mask |= 1u << i;
       if (kept1 && i >= 1 && conv_layer_h2(cd[i])) kept_mask |= 1u << (16 + i);
     }
-    NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
+    if (epi) NC_TRY(s3x_stats_finalize((const float*)iws, P + o.b[i], N, d[0], d[1], d[2], b.K, 3, 1e-5f, V + p.mean[i], V + p.rstd[i], hs));
+    else NC_TRY(nc_instnorm_stats(V + p.raw[i], N * b.K, S, 1e-5f, V + p.mean[i], V + p.rstd[i], iws, p.in_ws, stream));
     if (to >= 0 && use[to]) {  // fp32 (the backward of the pool / the fallback paths read it) AND the consumer's S3 operand in one pass
       NC_TRY(act_operand(cd[to], V + p.raw[i], V + p.mean[i], V + p.rstd[i], 0.f, out, (long)out_stride, V + p.xs3[to], N, b.K, S, to_ctot, 0, hs));
       if (to_ctot == b.K) pre[to] = true;  // (a concat input is complete once its second half has been converted, below)

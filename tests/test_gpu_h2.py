@@ -496,6 +496,39 @@ def test_h2_epilogue_statistics_follow_the_separate_pass(size):
         assert torch.equal(y, first[i]), it
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 32, 32, 32), (1, 1, 80, 80, 80), (2, 1, 16, 24, 40)])
+def test_h2_training_forward_takes_its_statistics_from_the_epilogue(shape):
+    """nc_unet_deconv_train_fwd, two-term form, nc_set_epi_stats(2) (an option: it buys nothing measurable in the training step): a block whose input
+    arrives converted (a power of two known by construction) lets its convolution leave the InstanceNorm sums -- eight of the ten k_in_stats passes
+    of a step go away.  Output, input gradient and
+    parameter gradients follow the separate pass to fp32 rounding (a ReLU / max-pool decision within 1e-7 of zero may fall the other way: L2
+    bounds); run to run the same bits.  80^3 includes the launch shape that exposed the register race of the first build (20^3 level)."""
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 21, DEV))
+    L().nc_set_split_terms(2)
+    x0 = torch.from_numpy(rnd(77, shape)).to(DEV)
+    r = torch.from_numpy(rnd(78, shape)).to(DEV)
+
+    def run(epi):
+        L().nc_set_epi_stats(epi)
+        for p_ in net.parameters():
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = net(x)
+        (y * r).mean().backward()
+        return y.detach().clone(), x.grad.clone(), [p_.grad.clone() for p_ in net.parameters()]
+
+    ya, xa, ga = run(1)
+    yb, xb, gb = run(2)
+    yc, xc, gc = run(2)
+    assert torch.equal(yb, yc) and torch.equal(xb, xc) and all(torch.equal(a, b) for a, b in zip(gb, gc))
+    assert float((ya - yb).abs().max()) < 2e-6
+    assert _rel2(xb.cpu().numpy(), xa.cpu().numpy()) < 2e-2
+    for (n, p_), a, b in zip(net.named_parameters(), ga, gb):
+        if p_.dim() > 1:
+            assert _rel2(b.cpu().numpy(), a.cpu().numpy()) < 2e-2, n
+
+
 def test_h2_guard_covers_the_norm_backward_output(golden_dir):
     """The dY of a U-Net convolution is written in H2 form by the InstanceNorm backward itself, with a cell from its own per-instance maxima --
     data-derived like a measured one.  Here the NEXT layer ignores 16 of double_conv1's 64 output channels almost entirely (its weights on them
