@@ -335,6 +335,17 @@ int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int 
                   void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
                     size_t wsb, hipStream_t s);
+// deep_linear_gen's collapsed tail (gen_nets.hip, "the collapsed tail"): the weight-space steps, shared with the 16-bit path.  tail: dl_tail_bytes()
+// of device scratch; compose fills E / Ef ([64][27] fp32: the 64 -> 1 kernel and its tap-flipped copy); q: [64][27], the caller's one-channel
+// weight gradient (x := dy, dY := act1); grads turns q into dW2 .. dW5
+bool dl_collapse_on();
+size_t dl_tail_bytes();
+const float* dl_tail_E(const char* tail);
+const float* dl_tail_Ef(const char* tail);
+float* dl_tail_q(char* tail);
+int dl_tail_compose(const float* w2, const float* w3, const float* w4, const float* w5, char* tail, hipStream_t s);
+int dl_tail_grads(const float* w2, const float* w3, const float* w4, const float* w5, char* tail, float* dw2, float* dw3, float* dw4, float* dw5,
+                  hipStream_t s);
 // one-channel KS^3 layers (KS = 3, 7) in "pseudo-channel" form on the 16-bit cores (conv_h.hip)
 bool c1_h_supported(int D, int H, int W, int KS);
 size_t c1_h_ws_bytes(int N, int D, int H, int W, int KS);

@@ -504,6 +504,29 @@ __global__ void __launch_bounds__(256) k_dl_tail_w345(const float* __restrict__ 
 
 std::atomic<int> g_dl_collapse{getenv("NC_DL_COLLAPSE") ? (atoi(getenv("NC_DL_COLLAPSE")) != 0) : 1};
 
+}  // namespace
+
+// the same weight-space steps for the 16-bit path (gen_nets_lp.hip)
+namespace nc {
+bool dl_collapse_on() { return g_dl_collapse.load(std::memory_order_relaxed) != 0; }
+size_t dl_tail_bytes() { return LTail::bytes; }
+const float* dl_tail_E(const char* tail) { return (const float*)(tail + LTail::E); }
+const float* dl_tail_Ef(const char* tail) { return (const float*)(tail + LTail::Ef); }
+float* dl_tail_q(char* tail) { return (float*)(tail + LTail::q); }
+int dl_tail_compose(const float* w2, const float* w3, const float* w4, const float* w5, char* tail, hipStream_t s) {
+  hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, s, w2, w3, w4, w5, tail);
+  return check_launch("deep_linear: compose");
+}
+int dl_tail_grads(const float* w2, const float* w3, const float* w4, const float* w5, char* tail, float* dw2, float* dw3, float* dw4, float* dw5,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(k_dl_tail_w2, dim3(64), dim3(256), 0, s, w2, tail, dw2);
+  hipLaunchKernelGGL(k_dl_tail_w345, dim3(1), dim3(256), 0, s, w3, w4, w5, (const char*)tail, dw3, dw4, dw5);
+  return check_launch("deep_linear: tail gradients");
+}
+}  // namespace nc
+
+namespace {
+
 bool l_plan(LPlan& p, int N, int S0, int S1, int S2) {
   if (N < 1 || S0 < 1 || S1 < 1 || S2 < 1) return false;
   p = LPlan{};

@@ -366,9 +366,10 @@ struct LLp {
   long S;
   size_t w[6];
   size_t f1h, f2h, f3h, weff, u1, saved;        // bytes into saved
-  size_t F, A, B, q, grads;                      // bytes into the scratch
+  size_t F, A, B, q, tail, grads;                // bytes into the scratch
   size_t conv_ws, f32conv_ws, o64_ws, c1_ws;
   bool ok, c1;
+  bool c3;  // the 3^3 one-channel kernels cover the shape too: layers 2 .. 5 can run in collapsed form (gen_nets.hip, "the collapsed tail")
 };
 
 bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
@@ -385,7 +386,7 @@ bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
   p.f1h = take(n * 64 * S * 2); p.f2h = take(n * 64 * S * 2); p.f3h = take(n * 64 * S * 2); p.weff = take(64 * 4); p.u1 = take(32 * 4);
   p.saved = off;
   off = 0;
-  p.F = take(n * 64 * S * 4); p.A = take(n * 64 * S * 2); p.B = take(n * 64 * S * 2); p.q = take(65 * 4);
+  p.F = take(n * 64 * S * 4); p.A = take(n * 64 * S * 2); p.B = take(n * 64 * S * 2); p.q = take(65 * 4); p.tail = take(dl_tail_bytes());
   p.grads = off;
   p.ok = true;
   for (int i = 1; i <= 2; ++i) {
@@ -399,6 +400,9 @@ bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
   p.o64_ws = c8_outer64_ws_bytes(N, p.S);
   p.c1 = c1_h_supported(S0, S1, S2, 7);
   p.c1_ws = p.c1 ? c1_h_ws_bytes(N, S0, S1, S2, 7) : 0;
+  p.c3 = p.c1 && c1_h_supported(S0, S1, S2, 3) && c1_wgrad_h_supported(N, S0, S1, S2, 3) &&
+         c1_wgrad_h_ws_bytes(N, S0, S1, S2, 3) <= (size_t)N * 64 * p.S * 4;
+  if (p.c3 && c1_h_ws_bytes(N, S0, S1, S2, 3) > p.c1_ws) p.c1_ws = c1_h_ws_bytes(N, S0, S1, S2, 3);
   return true;
 }
 
@@ -448,6 +452,14 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
   NC_TRY(conv_fwd_h_c8(V + p.f1h, params + p.w[1], nullptr, V + p.f2h, 64, 0, c5, dtype, cws, p.conv_ws, hs));
+  if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
+    // layers 2 .. 5 as ONE 64 -> 1 convolution of f2 (gen_nets.hip, "the collapsed tail"): the data-gradient form of the one-channel 3^3 kernel
+    // with the tap-flipped composed weights IS that convolution.  (The backward decides the same way: do not flip nc_set_dl_collapse between
+    // a forward and its backward on this path -- it has no `kept` word to carry the choice.)
+    char* tail = G + p.tail;
+    NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
+    return conv_c1_dgrad_h(V + p.f2h, dl_tail_Ef(tail), y, N, S0, S1, S2, 3, c1ws, p.c1_ws, hs);
+  }
   NC_TRY(conv_fwd_h_c8(V + p.f2h, params + p.w[2], nullptr, V + p.f3h, 64, 0, c3, dtype, cws, p.conv_ws, hs));
   hipLaunchKernelGGL(k_lin_tail_prep, dim3(1), dim3(64), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (float*)(V + p.weff),
                      (float*)(V + p.u1));
@@ -471,20 +483,30 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   char* G = c1ws + al(p.c1_ws);
   const char* V = (const char*)saved;
   float* q = (float*)(G + p.q);
+  ConvDims c5, c3;
+  make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
+  make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
+    // collapsed tail: q = the one-channel weight gradient with x := dy, dY := f2; dW2 .. dW5 in weight space; df2 = flip(E) (*) dy as C8
+    char* tail = G + p.tail;
+    NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
+    NC_TRY(conv_c1_wgrad_h(dy, V + p.f2h, dl_tail_q(tail), N, S0, S1, S2, 3, G + p.F, (size_t)N * 64 * p.S * 4, hs));
+    NC_TRY(dl_tail_grads(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, dparams + p.w[2], dparams + p.w[3], dparams + p.w[4],
+                         dparams + p.w[5], hs));
+    NC_TRY(conv_c1_fwd_h(dy, dl_tail_Ef(tail), nullptr, G + p.B, 64, 0, N, S0, S1, S2, 3, NC_DT_BF16, c1ws, p.c1_ws, hs));
+  } else {
   // tail: df3 = w_eff (x) dy (C8), q = sum dy f3
   NC_TRY(c8_outer64(dy, V + p.f3h, (const float*)(V + p.weff), G + p.A, q, nullptr, N, p.S, dtype, ows, p.o64_ws, hs));
   hipLaunchKernelGGL(k_lin_tail_wgrad, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5],
                      (const float*)(V + p.u1), q, dparams + p.w[3], dparams + p.w[4], dparams + p.w[5]);
   NC_TRY(check_launch("lin_tail_wgrad"));
-  ConvDims c5, c3;
-  make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
-  make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
   // 3^3 layer
   {
     ProfScope ps(2, 1, c3, 1, hs);
     NC_TRY(conv_wgrad_h(nullptr, V + p.f2h, nullptr, G + p.A, dparams + p.w[2], c3, NC_DT_BF16, cws, p.conv_ws, hs));
   }
   NC_TRY(conv_dgrad_h_c8(G + p.A, params + p.w[2], G + p.B, 64, 0, c3, NC_DT_BF16, cws, p.conv_ws, hs));
+  }
   // 5^3 layer: its data gradient feeds the fp32 one-channel 7^3 kernels, so it leaves as fp32 NCDHW
   {
     ProfScope ps(2, 1, c5, 1, hs);

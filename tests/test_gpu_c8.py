@@ -325,6 +325,50 @@ def test_whole_network_16bit_paths(kind, shape, monkeypatch):
             assert torch.isfinite(gw[n]).all()
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 24, 24, 24), (2, 1, 16, 20, 28), (1, 1, 40, 40, 40)])
+def test_deep_linear_16bit_collapsed_tail(shape):
+    """nc_deep_linear_lp_* with layers 2 .. 5 in collapsed form (nc_set_dl_collapse, default on; csrc/gen_nets_lp.hip: the 64 -> 1 convolution is
+    the data-gradient form of the one-channel 3^3 kernel with the composed weights, q its weight gradient with dy as the image, df2 its forward)
+    against the layered 16-bit evaluation and against fp32: the output within the 16-bit tolerance, EVERY parameter gradient -- the three
+    small pointwise tensors too -- as close to fp32 as the layered 16-bit path is, or closer."""
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import lib
+    _, net = _nets()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(shape, device=DEV, generator=gen)
+    r = torch.randn(shape, device=DEV, generator=gen)
+    prev = lib().nc_get_dl_collapse()
+
+    def run(prec, collapse):
+        lib().nc_set_dl_collapse(collapse)
+        ops.set_conv_precision(prec)
+        assert prec == 'fp32' or ops.gen_lp_supported('linear', x.shape)
+        for q in net.parameters():
+            q.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        (y * r).mean().backward()
+        ops.set_conv_precision('fp32')
+        return y.detach().clone(), xi.grad.clone(), {n: q.grad.clone() for n, q in net.named_parameters()}
+
+    try:
+        y32, dx32, g32 = run('fp32', 0)
+        yl, dxl, gl = run('bf16', 0)
+        yc, dxc, gc = run('bf16', 1)
+    finally:
+        lib().nc_set_dl_collapse(prev)
+        ops.set_conv_precision('fp32')
+    scale = float(y32.abs().max())
+    assert float((yc - y32).abs().max()) <= 2e-2 * scale and float((yc - y32).abs().mean()) <= 3e-3 * scale
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    print('dx: layered %.2e collapsed %.2e' % (rel(dxl, dx32), rel(dxc, dx32)))
+    assert rel(dxc, dx32) <= 1.5 * rel(dxl, dx32) + 5e-3
+    for n in g32:
+        a, b = rel(gl[n], g32[n]), rel(gc[n], g32[n])
+        print('%-24s layered %.2e collapsed %.2e' % (n, a, b))
+        assert b <= 1.5 * a + 5e-3, (n, a, b)
+
+
 @pytest.mark.parametrize('seed', [1, 2, 3, 21, 22])
 def test_deep_linear_16bit_weights_keep_the_response_to_a_constant(seed):
     """deep_linear_gen has neither biases nor norms, and for the nearly constant `fake` of the first iterations its output is a
