@@ -1466,6 +1466,13 @@ int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* d
                   hipStream_t s) {
   return run_ws(x, xs, dy, dys, dw, d, ws, wsb, s);
 }
+// The two-term weight-gradient kernel on operands of the caller's choice (x / dy fp32, or xs / dys H2 tensors with their cells): any C % 32,
+// K % 64 the plan covers -- not only the layers s3_layer_h2 admits (deep_linear_gen's collapsed backward uses C = 32, gen_nets.hip)
+bool wgrad_h2_supported(const ConvDims& d) { return s3x_get_terms() == 2 && ws_shape_ok(d) && ws_kv(d, 2) == 32 && ws_plan(d, 2).ok && ws_part_bytes(d, 2) != 0; }
+int conv_wgrad_h2(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  if (!wgrad_h2_supported(d)) { set_error("conv_wgrad_h2: shape not covered"); return NC_ERR_SHAPE; }
+  return run_ws_h2(x, xs, dy, dys, dw, d, ws, wsb, s, nullptr);
+}
 // data + weight gradient of one layer with dY converted once: [dY operand: S3 capacity | 256 B: its guard words | scratch of whichever kernel runs]
 size_t s3_bwd_ws_bytes(const ConvDims& d) {
   if (!ws_shape_ok(d)) return 0;

@@ -422,8 +422,42 @@ struct LPlan {
 // nc_set_dl_collapse(0) / NC_DL_COLLAPSE=0: the layered evaluation.  The forward records its choice in `kept` (bit 31): the backward of a
 // collapsed forward is collapsed whatever the switch says by then (act2 .. act4 do not exist).
 struct LTail {  // byte offsets into the tail scratch
-  static constexpr size_t a = 0, e = 32 * 8, r = e + 64 * 8, E = r + 64 * 8, Ef = E + 1728 * 4, q = Ef + 1728 * 4, bytes = q + 1728 * 4 + 256;
+  static constexpr size_t a = 0, e = 32 * 8, r = e + 64 * 8, E = r + 64 * 8, Ef = E + 1728 * 4, q = Ef + 1728 * 4, P = q + 1728 * 4 + 256,
+                          bytes = P + (size_t)64 * 32 * 125 * 4 + 256;
 };
+
+// ---- layer 1's weight gradient from the rank structure of its dY ---------------------------------------------------------------------------
+// With the tail collapsed, dL/dact1 = g1 is 64 channels made from ONE: g1[k][v] = sum_a E[k][a] dy[v - (a - 1)] on the volume (27 shifts a).
+// Write Dsh[a][v] = dy[v - (a - 1)] for v inside the volume (27 channels, padded to 32): g1 = E . Dsh, and the 5^3 layer's weight gradient
+//     dW1[k][c][t] = sum_v g1[k][v] act0[c][v + t - 2] = sum_a E[k][a] P[a][c][t],   P[a][c][t] = sum_v Dsh[a][v] act0[c][v + t - 2]
+// -- P is a 5^3 weight gradient between a 32- and a 64-channel tensor: HALF the matrix work of the 64 x 64 one, same kernel (k_wgrad_s3x with
+// act0's kept two-term copy in the dY role, which turns P around: Pq[c][a][t'] = P[a][c][124 - t']), then 64 x 64 x 125 x 27 MACs in weight
+// space.  Exact: the truncation of g1 to the volume is IN Dsh.  The data gradient of the layer still takes g1 itself.
+__global__ void __launch_bounds__(256) k_dl_shift27(const float* __restrict__ dy, float* __restrict__ dsh, int D, int H, int W) {
+  const long S = (long)D * H * W;
+  const int a = blockIdx.y, n = blockIdx.z;
+  float* out = dsh + ((long)n * 32 + a) * S;
+  const float* in = dy + (long)n * S;
+  const int az = a / 9 - 1, ay = (a / 3) % 3 - 1, ax = a % 3 - 1;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    float r = 0.f;
+    if (a < 27) {
+      const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+      const int sx = x - ax, sy = y - ay, sz = z - az;
+      if ((unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H && (unsigned)sz < (unsigned)D) r = in[((long)sz * H + sy) * W + sx];
+    }
+    out[v] = r;
+  }
+}
+// dW1[k][c][t] = sum_a E[k][a] Pq[c][a][124 - t]
+__global__ void __launch_bounds__(128) k_dl_w1_contract(const float* __restrict__ E, const float* __restrict__ Pq, float* __restrict__ dw1) {
+  const int k = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+  if (t >= 125) return;
+  double v = 0.0;
+#pragma unroll
+  for (int a = 0; a < 27; ++a) v += (double)E[k * 27 + a] * (double)Pq[((long)c * 32 + a) * 125 + 124 - t];
+  dw1[((long)k * 64 + c) * 125 + t] = (float)v;
+}
 constexpr unsigned kKeptCollapsed = 1u << 31;
 
 // (8 workgroups, each derives a and e for itself and 216 of E's 1728 entries; loops unrolled so that the loads of a sum are in flight together)
@@ -655,6 +689,22 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     ConvDims cdl;
     const bool now_h2 = make_dims(cdl, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2) && conv_layer_h2(cdl);
     const bool have = ((kept_mask >> i) & 1) && (((kept_mask >> (16 + i)) & 1) != 0) == now_h2;
+    ConvDims dsh;  // the 32 x 64 problem of "layer 1's weight gradient from the rank structure of its dY" (above)
+    static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
+    if (i == 1 && (kept_mask & kKeptCollapsed) && rank_on && now_h2 && have && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && wgrad_h2_supported(dsh) &&
+        s3_wgrad_ws_bytes(dsh) <= p.conv_ws) {
+      hipStream_t hs = (hipStream_t)stream;
+      char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
+      float* Dsh = G + p.g[1];  // (free until this layer's data gradient is written there, below)
+      hipLaunchKernelGGL(k_dl_shift27, dim3(256, 32, (unsigned)N), dim3(256), 0, hs, dy, Dsh, S0, S1, S2);
+      NC_TRY(check_launch("deep_linear_bwd: shifted copies of dy"));
+      NC_TRY(conv_wgrad_h2(Dsh, nullptr, nullptr, saved + p.xs3[1], (float*)(tail + LTail::P), dsh, cws, p.conv_ws, hs));
+      hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
+      NC_TRY(check_launch("deep_linear_bwd: dW1"));
+      NC_TRY(nc_conv_dgrad(g, params + p.w[i], gin, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
+      g = gin;
+      continue;
+    }
     if (l.k > 1)
       NC_TRY(conv_bwd_keep(in, have ? (const void*)(saved + p.xs3[i]) : nullptr, g, params + p.w[i], gin, dparams + p.w[i],
                            N, l.C, S0, S1, S2, l.K, l.k, cws, p.conv_ws, stream));
