@@ -551,6 +551,11 @@ int dl_tail_compose(const float* w2, const float* w3, const float* w4, const flo
   hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, s, w2, w3, w4, w5, tail);
   return check_launch("deep_linear: compose");
 }
+float* dl_tail_P(char* tail) { return (float*)(tail + LTail::P); }
+int dl_w1_contract(const char* tail, float* dw1, hipStream_t s) {
+  hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, s, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dw1);
+  return check_launch("deep_linear_bwd: dW1");
+}
 int dl_tail_grads(const float* w2, const float* w3, const float* w4, const float* w5, char* tail, float* dw2, float* dw3, float* dw4, float* dw5,
                   hipStream_t s) {
   hipLaunchKernelGGL(k_dl_tail_w2, dim3(64), dim3(256), 0, s, w2, tail, dw2);

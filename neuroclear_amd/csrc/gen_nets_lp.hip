@@ -361,6 +361,33 @@ __global__ void k_lin_tail_wgrad(const float* __restrict__ W4, const float* __re
   }
 }
 
+// Dsh[a][v] = dy[v - (a - 1)] inside the volume (27 shifts of the one-channel dy, padded to 32 channels) as a bf16 C8 tensor: the x operand of
+// layer 1's weight gradient in its rank-structured form (gen_nets.hip, "layer 1's weight gradient from the rank structure of its dY")
+__global__ void __launch_bounds__(256) k_dl_shift27_c8(const float* __restrict__ dy, uint4* __restrict__ dsh, int D, int H, int W) {
+  const long S = (long)D * H * W;
+  const int q = blockIdx.y, n = blockIdx.z;  // q: chunk of 8 shifts
+  const float* in = dy + (long)n * S;
+  uint4* out = dsh + ((long)n * 4 + q) * S;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((long)W * H));
+    unsigned short h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int a = q * 8 + j;
+      float r = 0.f;
+      if (a < 27) {
+        const int sx = x - (a % 3 - 1), sy = y - ((a / 3) % 3 - 1), sz = z - (a / 9 - 1);
+        if ((unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H && (unsigned)sz < (unsigned)D) r = in[((long)sz * H + sy) * W + sx];
+      }
+      const __bf16 b = (__bf16)r;
+      h[j] = __builtin_bit_cast(unsigned short, b);
+    }
+    uint4 o;
+    o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16); o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+    out[v] = o;
+  }
+}
+
 struct LLp {
   int N, d[3];
   long S;
@@ -486,6 +513,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   ConvDims c5, c3;
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  bool rank_w1 = false;
   if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
     // collapsed tail: q = the one-channel weight gradient with x := dy, dY := f2; dW2 .. dW5 in weight space; df2 = flip(E) (*) dy as C8
     char* tail = G + p.tail;
@@ -494,6 +522,19 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
     NC_TRY(dl_tail_grads(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, dparams + p.w[2], dparams + p.w[3], dparams + p.w[4],
                          dparams + p.w[5], hs));
     NC_TRY(conv_c1_fwd_h(dy, dl_tail_Ef(tail), nullptr, G + p.B, 64, 0, N, S0, S1, S2, 3, NC_DT_BF16, c1ws, p.c1_ws, hs));
+    // ... and the 5^3 layer's weight gradient from the rank structure of that df2 (= E . Dsh): a 32 x 64 problem, half the matrix work
+    ConvDims dsh;
+    static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
+    if (rank_on && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && c8x_wgrad_supported(dsh) && c8x_wgrad_part_bytes(dsh) <= p.conv_ws) {
+      hipLaunchKernelGGL(k_dl_shift27_c8, dim3(512, 4, (unsigned)N), dim3(256), 0, hs, dy, (uint4*)(G + p.A), S0, S1, S2);
+      NC_TRY(check_launch("deep_linear_lp_bwd: shifted copies of dy"));
+      {
+        ProfScope ps(2, 1, dsh, 1, hs);
+        NC_TRY(conv_wgrad_c8x(G + p.A, V + p.f1h, dl_tail_P(tail), dsh, NC_DT_BF16, cws, p.conv_ws, hs));
+      }
+      NC_TRY(dl_w1_contract(tail, dparams + p.w[1], hs));
+      rank_w1 = true;
+    }
   } else {
   // tail: df3 = w_eff (x) dy (C8), q = sum dy f3
   NC_TRY(c8_outer64(dy, V + p.f3h, (const float*)(V + p.weff), G + p.A, q, nullptr, N, p.S, dtype, ows, p.o64_ws, hs));
@@ -508,7 +549,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   NC_TRY(conv_dgrad_h_c8(G + p.A, params + p.w[2], G + p.B, 64, 0, c3, NC_DT_BF16, cws, p.conv_ws, hs));
   }
   // 5^3 layer: its data gradient feeds the fp32 one-channel 7^3 kernels, so it leaves as fp32 NCDHW
-  {
+  if (!rank_w1) {
     ProfScope ps(2, 1, c5, 1, hs);
     NC_TRY(conv_wgrad_h(nullptr, V + p.f1h, nullptr, G + p.B, dparams + p.w[1], c5, NC_DT_BF16, cws, p.conv_ws, hs));
   }
