@@ -423,7 +423,7 @@ struct LPlan {
 // collapsed forward is collapsed whatever the switch says by then (act2 .. act4 do not exist).
 struct LTail {  // byte offsets into the tail scratch
   static constexpr size_t a = 0, e = 32 * 8, r = e + 64 * 8, E = r + 64 * 8, Ef = E + 1728 * 4, q = Ef + 1728 * 4, P = q + 1728 * 4 + 256,
-                          bytes = P + (size_t)64 * 32 * 125 * 4 + 256;
+                          Wf = P + (size_t)64 * 32 * 125 * 4 + 256, bytes = Wf + (size_t)64 * 32 * 125 * 4 + 256;
 };
 
 // ---- layer 1's weight gradient from the rank structure of its dY ---------------------------------------------------------------------------
@@ -448,6 +448,17 @@ __global__ void __launch_bounds__(256) k_dl_shift27(const float* __restrict__ dy
     }
     out[v] = r;
   }
+}
+// The data gradient of the same layer in the same form (used where the convolution kernel takes 32 input channels: the 16-bit path):
+//     dL/dact0[c][u] = sum_{k,t} W1[k][c][t] g1[k][u - t + 2] = sum_{a,s} Wf[c][a][s] Dsh[a][u + s - 2],   Wf[c][a][s] = sum_k W1[k][c][124 - s] E[k][a]
+// -- a FORWARD 5^3 convolution 32 -> 64 of Dsh with weights composed here (zero for the five padding shifts).
+__global__ void __launch_bounds__(128) k_dl_w1_fold(const float* __restrict__ E, const float* __restrict__ w1, float* __restrict__ wf) {
+  const int c = blockIdx.x, a = blockIdx.y, sidx = threadIdx.x;
+  if (sidx >= 125) return;
+  double v = 0.0;
+  if (a < 27)
+    for (int k = 0; k < 64; ++k) v += (double)w1[((long)k * 64 + c) * 125 + 124 - sidx] * (double)E[k * 27 + a];
+  wf[((long)c * 32 + a) * 125 + sidx] = (float)v;
 }
 // dW1[k][c][t] = sum_a E[k][a] Pq[c][a][124 - t]
 __global__ void __launch_bounds__(128) k_dl_w1_contract(const float* __restrict__ E, const float* __restrict__ Pq, float* __restrict__ dw1) {
@@ -552,6 +563,10 @@ int dl_tail_compose(const float* w2, const float* w3, const float* w4, const flo
   return check_launch("deep_linear: compose");
 }
 float* dl_tail_P(char* tail) { return (float*)(tail + LTail::P); }
+const float* dl_w1_fold(char* tail, const float* w1, hipStream_t s) {  // composes Wf into the tail scratch and returns it (NULL: launch failed)
+  hipLaunchKernelGGL(k_dl_w1_fold, dim3(64, 32), dim3(128), 0, s, (const float*)(tail + LTail::E), w1, (float*)(tail + LTail::Wf));
+  return check_launch("deep_linear_bwd: composed data-gradient weights") ? nullptr : (const float*)(tail + LTail::Wf);
+}
 int dl_w1_contract(const char* tail, float* dw1, hipStream_t s) {
   hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, s, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dw1);
   return check_launch("deep_linear_bwd: dW1");
