@@ -320,6 +320,9 @@ int conv_wgrad_c8x(const void* xh, const void* dyh, float* dw, const ConvDims& d
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s);
+bool conv_fwd_h2_c32_supported(const ConvDims& d);
+size_t conv_fwd_h2_c32_ws_bytes(const ConvDims& d);
+int conv_fwd_h2_c32(const float* x, const float* w, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 bool wgrad_h2_supported(const ConvDims& d);
 int conv_wgrad_h2(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 bool h_fwd_supported(const ConvDims& d);

@@ -826,8 +826,15 @@ bool epi_stats_on() { return g_epi_stats.load(std::memory_order_relaxed) != 0; }
 int epi_stats_mode() { return g_epi_stats.load(std::memory_order_relaxed); }
 void epi_stats_set(int on) { g_epi_stats.store(on < 0 ? 0 : on > 2 ? 2 : on, std::memory_order_relaxed); }
 
+// k-steps of a tile: its KS^3 * Cin / 8 taps in fours, made EVEN (the kernel alternates two sets of weight registers per step and a tile must
+// end where it began): channels % 64 give an even count by themselves; 32 channels (two-term launches only: deep_linear_gen's rank-structured
+// data gradient, gen_nets.hip) get ONE padding step -- its packed weights are zero (k_pack_w_s3x: taps beyond the last brick), its B fragments are
+// whatever the ring slot behind the last brick holds: units of the next tile's first brick or of this tile's brick 17, finite data of the same
+// tensor times zero.  (A non-finite element there turns outputs of a neighbouring tile into NaN as well: the split rule's "only the outputs it
+// touches" holds for channels % 64 only.)
+int s3x_ksteps(int Cin, int KS) { return (KS * KS * KS * (Cin / 8) / 4 + 1) & ~1; }
 size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
-  const int NS = KS * KS * KS * (Cin / 8) / 4;
+  const int NS = s3x_ksteps(Cin, KS);
   return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024;
 }
 
@@ -858,7 +865,8 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   if (!pl.ok) { set_error("conv_s3x_h2: shape not covered"); return NC_ERR_SHAPE; }
   if (split_c < Cin && (flip || !cell_b || split_c % 8)) { set_error("conv_s3x_h2: scale groups only for the forward weight layout"); return NC_ERR_ARG; }
   if (stats_part && KS != 3) { set_error("conv_s3x_h2: epilogue statistics exist for the 3^3 layers only (the layers in front of an InstanceNorm)"); return NC_ERR_ARG; }
-  const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4, T3 = KS * KS * KS;
+  const int NCH = Cin / 8, NS = s3x_ksteps(Cin, KS), T3 = KS * KS * KS;
+  if (Cin % 32) { set_error("conv_s3x_h2: channels must be a multiple of 32"); return NC_ERR_SHAPE; }
   if (int e = h2_zero_cells(wcell, 1, s)) return e;
   const long nw = (long)Kout * Cin * T3;
   if (!cell_b) cell_b = cell_a;
@@ -931,7 +939,7 @@ int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N,
              long si, int flip, void* wp_ws, hipStream_t s, const unsigned* guard) {
   const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS);
   if (!pl.ok) { set_error("conv_s3x: shape not covered"); return NC_ERR_SHAPE; }
-  const int NCH = Cin / 8, NS = KS * KS * KS * NCH / 4;
+  const int NCH = Cin / 8, NS = s3x_ksteps(Cin, KS);
   const long total = (long)(s3x_packed_bytes(Cin, Kout, KS) / 2);
   hipLaunchKernelGGL(k_pack_w_s3x<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp_ws, NCH, KS, NS, so, si, flip,
                      total, (const unsigned*)nullptr, Cin, (const unsigned*)nullptr, (const unsigned*)nullptr);

@@ -1466,6 +1466,22 @@ int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* d
                   hipStream_t s) {
   return run_ws(x, xs, dy, dys, dw, d, ws, wsb, s);
 }
+// The two-term forward kernel on an fp32 input of 32 x n channels (converted here, measured cell, guard counted): deep_linear_gen's
+// rank-structured data gradient (gen_nets.hip) -- s3_layer_h2 admits multiples of 64 only
+bool conv_fwd_h2_c32_supported(const ConvDims& d) {
+  if (s3x_get_terms() != 2 || d.C % 32 || d.K % 64 || d.kd != d.kh || d.kd != d.kw || (d.kd != 3 && d.kd != 5)) return false;
+  if (d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != d.kd / 2 || d.ph != d.pd || d.pw != d.pd) return false;
+  return s3x_supported(d.N, 64, d.D, d.H, d.W, d.K, d.kd);  // (the planner does not look at the input channels)
+}
+size_t conv_fwd_h2_c32_ws_bytes(const ConvDims& d) {
+  const size_t ex = (size_t)d.N * d.C * d.D * d.H * d.W;
+  return align256(ex * 6) + 256 + s3x_packed_bytes(d.C, d.K, d.kd, 3) + 512;
+}
+int conv_fwd_h2_c32(const float* x, const float* w, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  if (!conv_fwd_h2_c32_supported(d)) { set_error("conv_fwd_h2_c32: shape not covered"); return NC_ERR_SHAPE; }
+  const int T3 = d.kd * d.kh * d.kw;
+  return run_s3(x, nullptr, w, nullptr, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, nullptr, true);
+}
 // The two-term weight-gradient kernel on operands of the caller's choice (x / dy fp32, or xs / dys H2 tensors with their cells): any C % 32,
 // K % 64 the plan covers -- not only the layers s3_layer_h2 admits (deep_linear_gen's collapsed backward uses C = 32, gen_nets.hip)
 bool wgrad_h2_supported(const ConvDims& d) { return s3x_get_terms() == 2 && ws_shape_ok(d) && ws_kv(d, 2) == 32 && ws_plan(d, 2).ok && ws_part_bytes(d, 2) != 0; }

@@ -685,6 +685,17 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
   const float* g = dy;
   const unsigned kept_mask = kept;
   int top = 5;
+  // layer 1's backward from the rank structure of its dY (see k_dl_shift27): decided here, because with both halves in that form dL/dact1 is
+  // never formed
+  ConvDims dsh, cd1;
+  static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
+  static const bool rank_dg_on = !(getenv("NC_DL_RANK_DGRAD") && atoi(getenv("NC_DL_RANK_DGRAD")) == 0);
+  const bool h2_1 = make_dims(cd1, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2) && conv_layer_h2(cd1);
+  const bool have1 = ((kept_mask >> 1) & 1) && ((kept_mask >> 17) & 1) != 0;
+  const bool rank_w = (kept_mask & kKeptCollapsed) && rank_on && h2_1 && have1 && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) &&
+                      wgrad_h2_supported(dsh) && s3_wgrad_ws_bytes(dsh) <= p.conv_ws;
+  const bool rank_dgrad = rank_w && rank_dg_on && conv_fwd_h2_c32_supported(dsh) && conv_fwd_h2_c32_ws_bytes(dsh) <= p.conv_ws;
+  const bool rank_all = rank_dgrad;
   if (kept_mask & kKeptCollapsed) {  // the forward left no act2 .. act4: layers 2 .. 5 from dy, act1 and the weights alone
     hipStream_t hs = (hipStream_t)stream;
     char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
@@ -697,8 +708,8 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     hipLaunchKernelGGL(k_dl_tail_w345, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (const char*)tail, dparams + p.w[3],
                        dparams + p.w[4], dparams + p.w[5]);
     NC_TRY(check_launch("deep_linear_bwd: tail gradients"));
-    // dL/dact1 = flip(E) (*) dy
-    NC_TRY(nc_conv_fwd(dy, (const float*)(tail + LTail::Ef), nullptr, G + p.g[0], N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    // dL/dact1 = flip(E) (*) dy -- unless layer 1's whole backward runs from the shifted copies of dy (below), which never looks at it
+    if (!rank_all) NC_TRY(nc_conv_fwd(dy, (const float*)(tail + LTail::Ef), nullptr, G + p.g[0], N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
     g = G + p.g[0];
     top = 1;
   }
@@ -709,10 +720,7 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     ConvDims cdl;
     const bool now_h2 = make_dims(cdl, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2) && conv_layer_h2(cdl);
     const bool have = ((kept_mask >> i) & 1) && (((kept_mask >> (16 + i)) & 1) != 0) == now_h2;
-    ConvDims dsh;  // the 32 x 64 problem of "layer 1's weight gradient from the rank structure of its dY" (above)
-    static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
-    if (i == 1 && (kept_mask & kKeptCollapsed) && rank_on && now_h2 && have && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && wgrad_h2_supported(dsh) &&
-        s3_wgrad_ws_bytes(dsh) <= p.conv_ws) {
+    if (i == 1 && rank_w && now_h2 && have) {  // the 32 x 64 problems of "layer 1's weight gradient from the rank structure of its dY" (above)
       hipStream_t hs = (hipStream_t)stream;
       char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
       float* Dsh = G + p.g[1];  // (free until this layer's data gradient is written there, below)
@@ -721,7 +729,17 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
       NC_TRY(conv_wgrad_h2(Dsh, nullptr, nullptr, saved + p.xs3[1], (float*)(tail + LTail::P), dsh, cws, p.conv_ws, hs));
       hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
       NC_TRY(check_launch("deep_linear_bwd: dW1"));
-      NC_TRY(nc_conv_dgrad(g, params + p.w[i], gin, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
+      // ... and its data gradient the same way where the planner covers it: a FORWARD 32 -> 64 convolution of Dsh with the composed weights
+      // Wf (k_dl_w1_fold) -- half the matrix work again, and g1 itself is not needed at all (rank_g1 below)
+      if (rank_dgrad) {
+        if (gin) {
+          hipLaunchKernelGGL(k_dl_w1_fold, dim3(64, 32), dim3(128), 0, hs, (const float*)(tail + LTail::E), params + p.w[1], (float*)(tail + LTail::Wf));
+          NC_TRY(check_launch("deep_linear_bwd: composed data-gradient weights"));
+          NC_TRY(conv_fwd_h2_c32(Dsh, (const float*)(tail + LTail::Wf), gin, dsh, cws, p.conv_ws, hs));  // (converts Dsh into cws first: gin may be its buffer)
+        }
+      } else {
+        NC_TRY(nc_conv_dgrad(g, params + p.w[i], gin, N, l.C, S0, S1, S2, l.K, l.k, l.k, l.k, 1, l.k / 2, cws, p.conv_ws, stream));
+      }
       g = gin;
       continue;
     }

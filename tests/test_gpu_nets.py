@@ -604,14 +604,17 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
     assert torch.equal(xi.grad, xa)
 
 
-@pytest.mark.parametrize('shape', [(1, 1, 16, 16, 16), (2, 1, 9, 14, 21), (1, 1, 12, 20, 24), (1, 1, 36, 36, 36)])
+@pytest.mark.parametrize('shape', [(1, 1, 16, 16, 16), (2, 1, 9, 14, 21), (1, 1, 12, 20, 24), (1, 1, 36, 36, 36), (1, 1, 72, 64, 80)])
 @pytest.mark.parametrize('want_dx', [False, True])
 @pytest.mark.parametrize('terms', [3, 2])
 def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, terms):
     """nc_set_dl_collapse(1) (default): layers 2 .. 5 of deep_linear_gen (reference networks.py:902-911: Conv3d 3^3 64 -> 64, then 1 x 1
     64 -> 32 -> 16 -> 1, no bias, nothing in between) as ONE 64 -> 1 convolution forward, and backward every parameter gradient of the four
-    layers plus dL/dact1 from dy, act1 and the weights (csrc/gen_nets.hip).  Exact algebra: output, input gradient and all six parameter
-    gradients equal the layered evaluation to fp32 rounding -- shapes the one-channel kernels cover and shapes they do not, batches, odd sizes."""
+    layers plus dL/dact1 from dy, act1 and the weights (csrc/gen_nets.hip).  In the two-term arithmetic the 5^3 layer's backward then runs
+    from 27 shifted copies of the one-channel dy (a 32 x 64 weight gradient and a forward 32 -> 64 convolution with composed weights: half
+    the matrix work each; the 32-channel launches carry one zero-weight padding k-step).  Exact algebra: output, input gradient and all six
+    parameter gradients equal the layered evaluation to fp32 rounding -- shapes the one-channel kernels cover and shapes they do not, batches,
+    odd sizes, several tiles per plane."""
     from neuroclear_amd._lib import lib
     prev = lib().nc_get_split_terms(), lib().nc_get_dl_collapse()
     lib().nc_set_split_terms(terms)
