@@ -3,7 +3,8 @@
 //                        by loss_G.backward() at models/axial_to_lateral_gan_apollo_model.py:283)
 //   DeepLinearGenerator  reference models/networks.py:893-917   (bias-free linear chain 7^3 / 5^3 / 3^3 / 1 / 1 / 1)
 // Same kernels in the same order as the layer-by-layer Python path (neuroclear_amd/models/networks.py), so outputs and
-// gradients are bit-identical to it; what the single call removes is ~60 autograd nodes per direction on the host, the
+// gradients are bit-identical to it (DeepLinearGenerator: with nc_set_dl_collapse(0); its default evaluation exploits the chain's linearity,
+// see "the collapsed tail" below); what the single call removes is ~60 autograd nodes per direction on the host, the
 // torch.cat copies of the two skip connections (the producers write straight into halves of the concat buffers) and the
 // at::native adds that merge the two gradients of a skip tensor (the max-pool backward adds the skip gradient itself).
 //
