@@ -136,7 +136,8 @@ def test_thirty_steps_on_structured_crops_two_term_drifts_no_faster_than_three_t
     steps on crops of the STRUCTURED volume (sparse beads and tubes on a dark background: the wide-range input of this path), the same seeds
     and crops under the two-term form (default), the three-term form and the fp32 MFMA kernels.  Three valid fp32 evaluations of the same
     training drift apart as rounding differences are amplified step by step; the two-term run must not leave the fp32-MFMA run faster than
-    the exact three-term run does: geometric mean AND median over the 30 steps of (two-term drift / three-term drift) <= 1.5.  The range guard sees every tensor the steps measure and flags none (nothing on this path needs the fallback)."""
+    the exact three-term run does: geometric mean AND median over the 30 steps of (two-term drift / three-term drift) <= 1.5 -- and the same bound
+    for deep_linear_gen's collapsed evaluation (default) against its layer-by-layer one.  The range guard sees every tensor the steps measure and flags none (nothing on this path needs the fallback)."""
     import ctypes
     from neuroclear_amd import ops
     from neuroclear_amd._lib import lib
@@ -161,7 +162,7 @@ def test_thirty_steps_on_structured_crops_two_term_drifts_no_faster_than_three_t
             model.optimize_parameters()
             out.append(dict(model.get_current_losses()))
         return out
-    prev_split, prev_terms = ops.set_conv_split(True), lib().nc_get_split_terms()
+    prev_split, prev_terms, prev_collapse = ops.set_conv_split(True), lib().nc_get_split_terms(), lib().nc_get_dl_collapse()
     try:
         gs = (ctypes.c_ulonglong * 4)()
         torch.cuda.synchronize()
@@ -170,9 +171,12 @@ def test_thirty_steps_on_structured_crops_two_term_drifts_no_faster_than_three_t
         torch.cuda.synchronize()
         lib().nc_h2_guard_stats(gs, 0)
         b, c = run(3), run(3, split=False)
+        lib().nc_set_dl_collapse(0)  # deep_linear_gen layer by layer (every run above used its default, collapsed evaluation: DESIGN.md 4.6)
+        e = run(2)
     finally:
         ops.set_conv_split(prev_split)
         lib().nc_set_split_terms(prev_terms)
+        lib().nc_set_dl_collapse(prev_collapse)
     keys = list(a[0].keys())
     ratios = []
     for it in range(steps):
@@ -188,3 +192,13 @@ def test_thirty_steps_on_structured_crops_two_term_drifts_no_faster_than_three_t
     # (a single step's ratio is the quotient of two chaotic quantities -- 0.7 .. 6 at the checkpoints of one run; the 30 steps together are the test)
     assert gmean <= 1.5 and med <= 1.5, (gmean, med, ratios)
     assert gs[0] > 0 and gs[1] == 0 and gs[2] == 0
+    # the collapsed evaluation of deep_linear_gen against the layered one, same arithmetic: two exact rearrangements of the same sums drift
+    # apart no faster than the two-term and the three-term form do
+    rc = []
+    for it in range(steps):
+        dc = max(abs(a[it][k] - e[it][k]) / max(abs(e[it][k]), 1e-12) for k in keys)
+        d23 = max(abs(a[it][k] - b[it][k]) / max(abs(b[it][k]), 1e-12) for k in keys)
+        rc.append(max(dc, 1e-7) / max(d23, 1e-7))
+    gm = float(np.exp(np.mean(np.log(rc))))
+    print('collapsed vs layered drift / two-term vs three-term drift: geometric mean %.2f, median %.2f' % (gm, float(np.median(rc))))
+    assert gm <= 1.5 and float(np.median(rc)) <= 1.5, rc
