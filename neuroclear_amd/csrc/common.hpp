@@ -355,6 +355,7 @@ int dl_tail_grads(const float* w2, const float* w3, const float* w4, const float
 float* dl_tail_P(char* tail);
 const float* dl_w1_fold(char* tail, const float* w1, hipStream_t s);  // [64][32][125]: layer 1's data gradient as a forward convolution of Dsh
 int dl_w1_contract(const char* tail, float* dw1, hipStream_t s);
+int dl_q_from_p(char* tail, const float* w1, hipStream_t s);  // q (tap-flipped, into the tail scratch) as a contraction of P and W1
 // one-channel KS^3 layers (KS = 3, 7) in "pseudo-channel" form on the 16-bit cores (conv_h.hip)
 bool c1_h_supported(int D, int H, int W, int KS);
 size_t c1_h_ws_bytes(int N, int D, int H, int W, int KS);

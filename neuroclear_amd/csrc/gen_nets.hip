@@ -461,6 +461,24 @@ __global__ void __launch_bounds__(128) k_dl_w1_fold(const float* __restrict__ E,
     for (int k = 0; k < 64; ++k) v += (double)w1[((long)k * 64 + c) * 125 + 124 - sidx] * (double)E[k * 27 + a];
   wf[((long)c * 32 + a) * 125 + sidx] = (float)v;
 }
+// q itself is a contraction of the same P: q[c'][t] = sum_{c,s} W1[c'][c][s] P[t][c][s] (act1 = W1 (*) act0, and the shift a = t of dy IS the
+// mask "v + t - 1 inside the volume") -- no pass over act1.  Written tap-flipped, as k_dl_tail_w2 reads it.  Block (c', t), fixed-order tree.
+__global__ void __launch_bounds__(256) k_dl_q_from_p(const float* __restrict__ w1, const float* __restrict__ Pq, float* __restrict__ qf) {
+  __shared__ double red[256];
+  const int cp = blockIdx.x, t = blockIdx.y, th = threadIdx.x;
+  double v = 0.0;
+  for (int i = th; i < 64 * 125; i += 256) {
+    const int c = i / 125, sidx = i - c * 125;
+    v += (double)w1[((long)cp * 64 + c) * 125 + sidx] * (double)Pq[((long)c * 32 + t) * 125 + 124 - sidx];
+  }
+  red[th] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (th < o) red[th] += red[th + o];
+    __syncthreads();
+  }
+  if (th == 0) qf[cp * 27 + 26 - t] = (float)red[0];
+}
 // dW1[k][c][t] = sum_a E[k][a] Pq[c][a][124 - t]
 __global__ void __launch_bounds__(128) k_dl_w1_contract(const float* __restrict__ E, const float* __restrict__ Pq, float* __restrict__ dw1) {
   const int k = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
@@ -567,6 +585,10 @@ float* dl_tail_P(char* tail) { return (float*)(tail + LTail::P); }
 const float* dl_w1_fold(char* tail, const float* w1, hipStream_t s) {  // composes Wf into the tail scratch and returns it (NULL: launch failed)
   hipLaunchKernelGGL(k_dl_w1_fold, dim3(64, 32), dim3(128), 0, s, (const float*)(tail + LTail::E), w1, (float*)(tail + LTail::Wf));
   return check_launch("deep_linear_bwd: composed data-gradient weights") ? nullptr : (const float*)(tail + LTail::Wf);
+}
+int dl_q_from_p(char* tail, const float* w1, hipStream_t s) {
+  hipLaunchKernelGGL(k_dl_q_from_p, dim3(64, 27), dim3(256), 0, s, w1, (const float*)(tail + LTail::P), (float*)(tail + LTail::q));
+  return check_launch("deep_linear_bwd: q");
 }
 int dl_w1_contract(const char* tail, float* dw1, hipStream_t s) {
   hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, s, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dw1);
@@ -703,8 +725,19 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     const float* act1 = saved + p.act[1];
     hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
     NC_TRY(check_launch("deep_linear_bwd: compose"));
-    // q (tap-flipped): the weight gradient of Conv3d(1, 64, 3) with x := dy and dY := act1
-    NC_TRY(nc_conv_wgrad(dy, act1, (float*)(tail + LTail::q), nullptr, N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    if (rank_w) {
+      // the 32 x 64 weight gradient P between the 27 shifted copies of dy and act0 (see k_dl_shift27): dW1 and q are both contractions of it
+      float* Dsh = G + p.g[1];  // (free until layer 1's data gradient is written there, below)
+      hipLaunchKernelGGL(k_dl_shift27, dim3(256, 32, (unsigned)N), dim3(256), 0, hs, dy, Dsh, S0, S1, S2);
+      NC_TRY(check_launch("deep_linear_bwd: shifted copies of dy"));
+      NC_TRY(conv_wgrad_h2(Dsh, nullptr, nullptr, saved + p.xs3[1], (float*)(tail + LTail::P), dsh, cws, p.conv_ws, hs));
+      hipLaunchKernelGGL(k_dl_q_from_p, dim3(64, 27), dim3(256), 0, hs, params + p.w[1], (const float*)(tail + LTail::P), (float*)(tail + LTail::q));
+      hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
+      NC_TRY(check_launch("deep_linear_bwd: q, dW1"));
+    } else {
+      // q (tap-flipped): the weight gradient of Conv3d(1, 64, 3) with x := dy and dY := act1
+      NC_TRY(nc_conv_wgrad(dy, act1, (float*)(tail + LTail::q), nullptr, N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
+    }
     hipLaunchKernelGGL(k_dl_tail_w2, dim3(64), dim3(256), 0, hs, params + p.w[2], tail, dparams + p.w[2]);
     hipLaunchKernelGGL(k_dl_tail_w345, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (const char*)tail, dparams + p.w[3],
                        dparams + p.w[4], dparams + p.w[5]);
@@ -724,12 +757,7 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
     if (i == 1 && rank_w && now_h2 && have) {  // the 32 x 64 problems of "layer 1's weight gradient from the rank structure of its dY" (above)
       hipStream_t hs = (hipStream_t)stream;
       char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
-      float* Dsh = G + p.g[1];  // (free until this layer's data gradient is written there, below)
-      hipLaunchKernelGGL(k_dl_shift27, dim3(256, 32, (unsigned)N), dim3(256), 0, hs, dy, Dsh, S0, S1, S2);
-      NC_TRY(check_launch("deep_linear_bwd: shifted copies of dy"));
-      NC_TRY(conv_wgrad_h2(Dsh, nullptr, nullptr, saved + p.xs3[1], (float*)(tail + LTail::P), dsh, cws, p.conv_ws, hs));
-      hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
-      NC_TRY(check_launch("deep_linear_bwd: dW1"));
+      float* Dsh = G + p.g[1];  // (dW1 came out of P in the prologue; the shifted copies are still there)
       // ... and its data gradient the same way where the planner covers it: a FORWARD 32 -> 64 convolution of Dsh with the composed weights
       // Wf (k_dl_w1_fold) -- half the matrix work again, and g1 itself is not needed at all (rank_g1 below)
       if (rank_dgrad) {

@@ -515,31 +515,38 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
   bool rank_w1 = false;
   if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
-    // collapsed tail: q = the one-channel weight gradient with x := dy, dY := f2; dW2 .. dW5 in weight space; df2 = flip(E) (*) dy as C8
+    // collapsed tail (gen_nets.hip): dW2 .. dW5 in weight space from q[c][t] = sum_v dy[v] f2[c][v + t - 1]; the 5^3 layer's backward from the rank
+    // structure of df2 = E . Dsh (Dsh: 27 shifted copies of dy as a bf16 C8 tensor): its weight gradient a 32 x 64 problem P, its data gradient
+    // a forward convolution 32 -> 64 of Dsh with composed weights -- half the matrix work each; q is a contraction of the same P, and df2
+    // itself is never written
     char* tail = G + p.tail;
     NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
-    NC_TRY(conv_c1_wgrad_h(dy, V + p.f2h, dl_tail_q(tail), N, S0, S1, S2, 3, G + p.F, (size_t)N * 64 * p.S * 4, hs));
-    NC_TRY(dl_tail_grads(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, dparams + p.w[2], dparams + p.w[3], dparams + p.w[4],
-                         dparams + p.w[5], hs));
-    // ... and the 5^3 layer's backward from the rank structure of df2 = E . Dsh (gen_nets.hip): its weight gradient a 32 x 64 problem, its data
-    // gradient a forward convolution 32 -> 64 of Dsh with composed weights -- half the matrix work each, and df2 itself is never written
     ConvDims dsh;
     static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
-    if (rank_on && p.c1 && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && c8x_wgrad_supported(dsh) && c8x_wgrad_part_bytes(dsh) <= p.conv_ws &&
-        h_fwd_supported(dsh) && h_ws_bytes(dsh) <= p.conv_ws) {
+    const bool rank = rank_on && p.c1 && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && c8x_wgrad_supported(dsh) &&
+                      c8x_wgrad_part_bytes(dsh) <= p.conv_ws && h_fwd_supported(dsh) && h_ws_bytes(dsh) <= p.conv_ws;
+    if (rank) {
       hipLaunchKernelGGL(k_dl_shift27_c8, dim3(512, 4, (unsigned)N), dim3(256), 0, hs, dy, (uint4*)(G + p.B), S0, S1, S2);
       NC_TRY(check_launch("deep_linear_lp_bwd: shifted copies of dy"));
       {
         ProfScope ps(2, 1, dsh, 1, hs);
         NC_TRY(conv_wgrad_c8x(G + p.B, V + p.f1h, dl_tail_P(tail), dsh, NC_DT_BF16, cws, p.conv_ws, hs));
       }
+      NC_TRY(dl_q_from_p(tail, params + p.w[1], hs));
+    } else {
+      // q = the one-channel weight gradient with x := dy, dY := f2
+      NC_TRY(conv_c1_wgrad_h(dy, V + p.f2h, dl_tail_q(tail), N, S0, S1, S2, 3, G + p.F, (size_t)N * 64 * p.S * 4, hs));
+    }
+    NC_TRY(dl_tail_grads(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, dparams + p.w[2], dparams + p.w[3], dparams + p.w[4],
+                         dparams + p.w[5], hs));
+    if (rank) {
       NC_TRY(dl_w1_contract(tail, dparams + p.w[1], hs));
       const float* wf = dl_w1_fold(tail, params + p.w[1], hs);
       if (!wf) return NC_ERR_HIP;
       NC_TRY(conv_fwd_h_c8(G + p.B, wf, nullptr, G + p.A, 64, 0, dsh, NC_DT_BF16, cws, p.conv_ws, hs));
       rank_w1 = true;
     } else {
-      NC_TRY(conv_c1_fwd_h(dy, dl_tail_Ef(tail), nullptr, G + p.B, 64, 0, N, S0, S1, S2, 3, NC_DT_BF16, c1ws, p.c1_ws, hs));
+      NC_TRY(conv_c1_fwd_h(dy, dl_tail_Ef(tail), nullptr, G + p.B, 64, 0, N, S0, S1, S2, 3, NC_DT_BF16, c1ws, p.c1_ws, hs));  // df2 = flip(E) (*) dy as C8
     }
   } else {
   // tail: df3 = w_eff (x) dy (C8), q = sum dy f3
