@@ -532,7 +532,10 @@ def main():
     if train_like and args.precision == 'fp32' and bool(_lib().nc_get_dl_collapse()):
         # deep_linear_gen's layers 2 .. 5 run in collapsed form (include/nc_hip.h nc_set_dl_collapse: exact algebra of the bias-free linear
         # tail, same outputs and gradients); the same step with the layer-by-layer evaluation, for the record
-        out['deep_linear_tail'] = dict(form='collapsed (3^3 + three 1x1 layers as one 64->1 convolution; parameter gradients from dy, act1 and the weights)')
+        out['deep_linear_tail'] = dict(form='collapsed: the 3^3 + three 1x1 layers of deep_linear_gen as ONE 64->1 convolution, their parameter gradients in weight '
+                                            'space, the 5^3 layer\'s backward from 27 shifted copies of the one-channel dy (32 x 64 problems); exact algebra, every '
+                                            'output and gradient of the reference step is produced (DESIGN.md 4.6, tests/test_collapse_algebra.py); '
+                                            'layer_by_layer = the same step with nc_set_dl_collapse(0)')
         if headline and world == 1:
             import copy
             a4 = copy.copy(args)
