@@ -753,7 +753,7 @@ int launch_x_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
 // (wave slice of 32 channels, sample, one of kStatChunks ranges of the records) walks its range with 8 lane groups interleaved and leaves
 // 32 x (s, q) in fp64; k_s3x_stats_final adds the chunks in order.  (First version: one workgroup per channel reading 8 bytes out of every
 // record -- 19 us per call at 140^3, a whole 64-byte sector fetched per 8 bytes used.)
-constexpr int kStatChunks = 16;
+constexpr int kStatChunks = 64;  // (16: 33 us per call at 140^3 -- 32 workgroups of 170 dependent iterations; measured with the one-stream profile)
 struct XStatsPlan {
   int N, K, KT, TPP, D, HP;
   long full, main_count;   // main tiles in whole rounds / tiles of the first launch (full, or all when the left-over tiles are whole tiles)
@@ -768,6 +768,7 @@ __global__ void __launch_bounds__(256) k_s3x_stats_partial(const float2* __restr
   // record (tile index u of this (n, cot), position group pg): 4 per main tile, 4 * fsub per left-over tile -- walked in a fixed order
   const long nrec = per_n * 4, per = (nrec + kStatChunks - 1) / kStatChunks;
   const long r1 = (ch + 1) * per < nrec ? (ch + 1) * per : nrec;
+#pragma unroll 4
   for (long r = ch * per + grp; r < r1; r += 8) {
     const long u = r >> 2;
     const int pg = (int)(r & 3);

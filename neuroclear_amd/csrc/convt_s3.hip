@@ -203,19 +203,27 @@ __global__ void __launch_bounds__(kTThreads, 1) k_convT_s3(const TParams3 p) {
 // |y[co]| <= max over (co, tap) of sum_ci |w[ci][co][tap]| * max|x| + max|b|.  With x an InstanceNorm output (max|x| <= sqrt(S)) the bound is
 // loose by 2^7-2^9 against typical values -- inside what fp16's exponent range forgives (s3_common.hpp) -- and it lets the kernel write the
 // H2 form of its output itself.  cell (zeroed by the caller) <- float bits of the bound, atomicMax over the blocks.
+// (64 columns x 4 slices of the input channels per workgroup, loads of a slice in flight together: the first version walked all C channels in
+// one dependent chain per thread -- 75 us for a 262k-element weight tensor, twice per inference cube and per training step)
 __global__ void __launch_bounds__(256) k_convT_bound(const float* __restrict__ w, const float* __restrict__ bias, int C, int K, float in_bound,
                                                      unsigned* __restrict__ cell) {
-  __shared__ float red[256];
-  const int kq = blockIdx.x * 256 + threadIdx.x;  // one (output channel, tap) column per thread: coalesced over the columns
-  float v = 0.f;
+  __shared__ float part[4][64];
+  __shared__ float red[64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int kq = blockIdx.x * 64 + col;  // one (output channel, tap) column: coalesced over the columns
+  float sabs = 0.f;
   if (kq < K * 8) {
-    float sabs = 0.f;
-    for (int ci = 0; ci < C; ++ci) sabs += fabsf(w[(long)ci * K * 8 + kq]);
-    v = sabs * in_bound + (bias ? fabsf(bias[kq >> 3]) : 0.f);
+#pragma unroll 8
+    for (int ci = sl; ci < C; ci += 4) sabs += fabsf(w[(long)ci * K * 8 + kq]);
   }
-  red[threadIdx.x] = v;
+  part[sl][col] = sabs;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  if (sl == 0) {
+    const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    red[col] = kq < K * 8 ? t * in_bound + (bias ? fabsf(bias[kq >> 3]) : 0.f) : 0.f;
+  }
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
     __syncthreads();
   }
@@ -237,7 +245,7 @@ size_t convT_s3x_ws_bytes(int C, int K) { return (size_t)C * K * 8 * 3 * 2 + 256
 
 // xs: the input in S3 form; y (nullable) fp32 output; ys (nullable) channels [c0, c0 + K) of a ctot-channel S3 tensor; ws: packed weights
 int convT_h2_bound(const float* w, const float* bias, int C, int K, float in_bound, unsigned* cell, hipStream_t s) {
-  hipLaunchKernelGGL(k_convT_bound, dim3((unsigned)cdiv((long)K * 8, 256)), dim3(256), 0, s, w, bias, C, K, in_bound, cell);
+  hipLaunchKernelGGL(k_convT_bound, dim3((unsigned)cdiv((long)K * 8, 64)), dim3(256), 0, s, w, bias, C, K, in_bound, cell);
   return check_launch("convT_h2_bound");
 }
 
