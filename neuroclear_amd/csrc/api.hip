@@ -552,6 +552,8 @@ UnetWs unet_ws(int S0, int S1, int S2) {
     size_t sb = 0;
     auto upds = [&](int D, int H, int W, int K) { const size_t b = s3x_stats_bytes(1, D, H, W, K, 3); if (b > sb) sb = b; };
     upds(S0, S1, S2, 64); upds(S0 / 2, S1 / 2, S2 / 2, 128); upds(S0 / 4, S1 / 4, S2 / 4, 256);
+    ConvDims d0;
+    if (make_dims(d0, 1, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1) && c1k3_stats_bytes(d0) > sb) sb = c1k3_stats_bytes(d0);  // (the first block's own kernel)
     u.stats = take(sb / 4 + 64);
   }
   u.total = off;
@@ -642,6 +644,15 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       ProfScope ps(0, 9, d, 0, hs);
       NC_TRY(conv_fwd_s3(nullptr, in3, P + o.w[id], P + o.b[id], W + u.raw, d, cws, u.conv_ws_bytes, hs));
     } else {
+      ConvDims d1;
+      if (epi && C == 1 && !g_force_direct && make_dims(d1, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1) && c1k3_stats_bytes(d1)) {
+        // the first block: the one-channel kernel leaves its InstanceNorm sums too (conv_c1k3.hip ST)
+        NC_TRY(conv_fwd_c1k3(in, P + o.w[id], P + o.b[id], W + u.raw, d1, hs, W + u.stats));
+        NC_TRY(c1k3_stats_finalize(W + u.stats, P + o.b[id], d1, 1e-5f, mean, rstd, hs));
+        if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs);
+        if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
+        return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+      }
       NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
     }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));

@@ -96,7 +96,10 @@ static constexpr size_t kBiasGradWsBytes = 64 * 1024 * sizeof(double);  // K * s
 bool mfma_fwd_supported(const ConvDims& d);
 // conv_c1k3.hip: 1 -> K channels, 3^3, stride 1, padding 1 forward (the U-Net's first layer)
 bool c1k3_fwd_supported(const ConvDims& d);
-int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s);
+int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s, float* stats_part = nullptr);
+// (stats_part: the kernel also leaves partial InstanceNorm sums of its bias-free output, N == 1; c1k3_stats_finalize turns them into mean / rstd)
+size_t c1k3_stats_bytes(const ConvDims& d);
+int c1k3_stats_finalize(const float* stats_part, const float* bias, const ConvDims& d, float eps, float* mean, float* rstd, hipStream_t s);
 bool mfma_dgrad_supported(const ConvDims& d);
 bool mfma_wgrad_supported(const ConvDims& d);
 size_t mfma_ws_bytes(const ConvDims& d);

@@ -19,6 +19,7 @@ struct C1Params {
   const float* w;     // [K][1][3][3][3]
   const float* bias;  // nullable
   float* y;           // [N][K][D][H][W]
+  float2* stats;      // ST: [gridDim.x][K / 64][wave][64 channels] (sum, sum of squares) of this wave's bias-free outputs (N = 1 launches only)
   int N, D, H, W, K;
   int R;              // output rows per workgroup
   int P;              // W + 2
@@ -28,6 +29,10 @@ struct C1Params {
 
 constexpr int kC1Waves = 4;
 
+// ST: the wave also leaves the sum and the sum of squares of its 64 channels' outputs WITHOUT the bias (as conv_s3x.hip's ST epilogue does for the
+// 64-channel layers): the InstanceNorm of the U-Net's first block then needs no pass over the 64-channel output (k_in_stats: 0.2 ms of a
+// 140^3 inference cube).  fp32 per lane (a few dozen values), fp64 across waves and workgroups in c1k3_stats_finalize, fixed order.
+template <bool ST>
 __global__ void __launch_bounds__(kC1Waves * 64) k_conv_c1k3(const C1Params p) {
   extern __shared__ float xt[];  // [3][R + 2][P]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -59,6 +64,13 @@ __global__ void __launch_bounds__(kC1Waves * 64) k_conv_c1k3(const C1Params p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[a][e] = p.bias ? p.bias[kt * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh] : 0.f;
 
+  float ss[2][16], sq[2][16];
+  if constexpr (ST) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { ss[a][e] = 0.f; sq[a][e] = 0.f; }
+  }
   for (long grp = blockIdx.x; grp < p.ngroups; grp += gridDim.x) {
     const int yb = (int)(grp % p.YB);
     const int z = (int)((grp / p.YB) % p.D);
@@ -98,9 +110,51 @@ __global__ void __launch_bounds__(kC1Waves * 64) k_conv_c1k3(const C1Params p) {
           const long ro = (long)((e & 3) + 8 * (e >> 2)) * S;
           yo[ro] = acc0[e] + bv[0][e];
           yo[ro + 32 * S] = acc1[e] + bv[1][e];
+          if constexpr (ST) {
+            ss[0][e] += acc0[e]; sq[0][e] = fmaf(acc0[e], acc0[e], sq[0][e]);
+            ss[1][e] += acc1[e]; sq[1][e] = fmaf(acc1[e], acc1[e], sq[1][e]);
+          }
         }
       }
     }
+  }
+  if constexpr (ST) {
+    // the 32 lanes of a half (same kh) hold the same 32 channels at different positions: butterfly over them, lane col == 0 writes
+    float2* rec = p.stats + (((long)blockIdx.x * gridDim.y + kt) * kC1Waves + wave) * 64;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float u = ss[a][e], v = sq[a][e];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { u += __shfl_xor(u, o); v += __shfl_xor(v, o); }
+        if (col == 0) rec[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh] = make_float2(u, v);
+      }
+  }
+}
+
+// one workgroup per channel: the records of every (workgroup, wave) in index order, fp64
+__global__ void __launch_bounds__(256) k_c1k3_stats_final(const float2* __restrict__ part, int nrec, int K, const float* __restrict__ bias, long S, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double rs[256], rq[256];
+  const int c = blockIdx.x, kt = c >> 6, ci = c & 63, t = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int r = t; r < nrec; r += 256) {  // r = workgroup * kC1Waves + wave
+    const float2 v = part[(((long)(r / kC1Waves) * (K / 64) + kt) * kC1Waves + r % kC1Waves) * 64 + ci];
+    s += (double)v.x; q += (double)v.y;
+  }
+  rs[t] = s; rq[t] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { rs[t] += rs[t + o]; rq[t] += rq[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double m0 = rs[0] / (double)S;
+    double var = rq[0] / (double)S - m0 * m0;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)(m0 + (bias ? (double)bias[c] : 0.0));
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -115,9 +169,30 @@ bool c1k3_fwd_supported(const ConvDims& d) {
   return d.W >= 8 && (long)d.N * d.K * d.D * d.H * d.W < (1L << 40);
 }
 
-int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s) {
+static long c1k3_grid(const ConvDims& d, int& R) {
+  R = (512 + d.W - 1) / d.W;
+  if (R < 1) R = 1;
+  if (R > d.H) R = d.H;
+  while (R > 1 && (size_t)3 * (R + 2) * (d.W + 2) * sizeof(float) > 48 * 1024) --R;
+  const long ngroups = (long)d.N * d.D * ((d.H + R - 1) / R);
+  return ngroups < 2048 ? ngroups : 2048;
+}
+size_t c1k3_stats_bytes(const ConvDims& d) {
+  int R;
+  return d.N == 1 && c1k3_fwd_supported(d) ? (size_t)c1k3_grid(d, R) * (d.K / 64) * kC1Waves * 64 * sizeof(float2) + 256 : 0;
+}
+int c1k3_stats_finalize(const float* stats_part, const float* bias, const ConvDims& d, float eps, float* mean, float* rstd, hipStream_t s) {
+  int R;
+  if (!c1k3_stats_bytes(d) || !stats_part) { set_error("c1k3_stats_finalize: shape not covered"); return NC_ERR_SHAPE; }
+  hipLaunchKernelGGL(k_c1k3_stats_final, dim3((unsigned)d.K), dim3(256), 0, s, (const float2*)stats_part, (int)c1k3_grid(d, R) * kC1Waves, d.K, bias,
+                     (long)d.D * d.H * d.W, eps, mean, rstd);
+  return check_launch("c1k3_stats_finalize");
+}
+
+int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, hipStream_t s, float* stats_part) {
   C1Params p{};
-  p.x = x; p.w = w; p.bias = bias; p.y = y;
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.stats = (float2*)stats_part;
+  if (stats_part && d.N != 1) { set_error("conv_c1k3: epilogue statistics for one sample per call only"); return NC_ERR_ARG; }
   p.N = d.N; p.D = d.D; p.H = d.H; p.W = d.W; p.K = d.K;
   p.P = d.W + 2;
   // rows per workgroup: ~512 positions, and the tile within 48 KB of LDS
@@ -130,7 +205,8 @@ int conv_fwd_c1k3(const float* x, const float* w, const float* bias, float* y, c
   p.ngroups = (long)d.N * d.D * p.YB;
   const size_t lds = (size_t)3 * (R + 2) * p.P * sizeof(float);
   long gx = p.ngroups < 2048 ? p.ngroups : 2048;
-  hipLaunchKernelGGL(k_conv_c1k3, dim3((unsigned)gx, (unsigned)(d.K / 64)), dim3(kC1Waves * 64), lds, s, p);
+  if (stats_part) hipLaunchKernelGGL(k_conv_c1k3<true>, dim3((unsigned)gx, (unsigned)(d.K / 64)), dim3(kC1Waves * 64), lds, s, p);
+  else hipLaunchKernelGGL(k_conv_c1k3<false>, dim3((unsigned)gx, (unsigned)(d.K / 64)), dim3(kC1Waves * 64), lds, s, p);
   return check_launch("conv_c1k3");
 }
 
