@@ -619,8 +619,18 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
   unsigned* cells = (unsigned*)(W + u.cells);
   auto block = [&](int id, const float* in, const void* in3, float* out, void* out3, int ctot, int c0, int C, int K, int D, int H,
                    int Wd, const unsigned* in_a = nullptr, const unsigned* in_b = nullptr, int split_c = 0,
-                   const unsigned* out_cell = nullptr) -> int {
+                   const unsigned* out_cell = nullptr, void* pooled = nullptr) -> int {
     const long Sl = (long)D * H * Wd;
+    // normalise + ReLU + conversion of the raw output (and, pooled != NULL: the 2 x 2 x 2 max-pool of the H2 result in the same pass)
+    auto finish = [&]() -> int {
+      if (out3 && out_cell && pooled && !out) return act_split2h_pool(W + u.raw, mean, rstd, 0.f, out3, pooled, 1, K, D, H, Wd, ctot, c0, sqrtf((float)Sl), nullptr, hs);
+      if (out3 && out_cell) {
+        NC_TRY(act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs));
+        return pooled ? maxpool2_h2(out3, pooled, 1, K, ctot, D, H, Wd, hs) : NC_OK;
+      }
+      if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
+      return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+    };
     // Epilogue statistics (default; NC_EPI_STATS=0 / nc_set_epi_stats(0): off): the two-term convolution leaves the partial InstanceNorm sums of
     // its output itself (conv_s3x.hip, ST) and k_in_stats' pass over the raw output goes away: -1.8 % per 140^3 cube, mean / rstd equal to 4e-8
     const bool epi = epi_stats_on();
@@ -634,9 +644,7 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       }
       if (epi) {
         NC_TRY(s3x_stats_finalize(W + u.stats, P + o.b[id], 1, D, H, Wd, K, 3, 1e-5f, mean, rstd, hs));
-        if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs);
-        if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
-        return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+        return finish();
       }
     } else if (in3) {
       ConvDims d;
@@ -649,16 +657,12 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
         // the first block: the one-channel kernel leaves its InstanceNorm sums too (conv_c1k3.hip ST)
         NC_TRY(conv_fwd_c1k3(in, P + o.w[id], P + o.b[id], W + u.raw, d1, hs, W + u.stats));
         NC_TRY(c1k3_stats_finalize(W + u.stats, P + o.b[id], d1, 1e-5f, mean, rstd, hs));
-        if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs);
-        if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
-        return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+        return finish();
       }
       NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
     }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
-    if (out3 && out_cell) return act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs);
-    if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
-    return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
+    return finish();
   };
   const bool f1 = split_in(64, 64, S0, S1, S2), f9 = split_in(128, 64, S0, S1, S2);
   const bool f3 = split_in(128, 128, h0, h1, h2), f7 = split_in(256, 128, h0, h1, h2), f8 = f3;
@@ -683,16 +687,21 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it).  NC_POOL_H2=0: fp32 pool + conversion (A/B)
       static const bool pool_h2 = !(getenv("NC_POOL_H2") && atoi(getenv("NC_POOL_H2")) == 0);
       void* p1h = W + u.s_cat2 + 128 * Sh;
-      NC_TRY(block(1, nullptr, W + u.s_a1, pool_h2 ? nullptr : W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0));
-      if (pool_h2) {
+      // (NC_POOL_FUSE=0: the pool as a pass of its own over the H2 tensor)
+      static const bool pool_fuse = pool_h2 && !(getenv("NC_POOL_FUSE") && atoi(getenv("NC_POOL_FUSE")) == 0);
+      NC_TRY(block(1, nullptr, W + u.s_a1, pool_h2 ? nullptr : W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0, pool_fuse ? p1h : nullptr));
+      if (pool_fuse) {
+      } else if (pool_h2) {
         NC_TRY(maxpool2_h2(W + u.s_cat1, p1h, 1, 64, 128, S0, S1, S2, hs));
       } else {
         NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
         NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, 1, 64, Sh, 64, 0, c0, hs));
       }
       NC_TRY(block(2, nullptr, p1h, nullptr, W + u.s_a2, 128, 0, 64, 128, h0, h1, h2, c0, nullptr, 0, c1));
-      NC_TRY(block(3, nullptr, W + u.s_a2, pool_h2 ? nullptr : W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1));
-      if (pool_h2) {
+      NC_TRY(block(3, nullptr, W + u.s_a2, pool_h2 ? nullptr : W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1,
+                   pool_fuse ? (void*)(W + u.s_b2) : nullptr));
+      if (pool_fuse) {
+      } else if (pool_h2) {
         NC_TRY(maxpool2_h2(W + u.s_cat2, W + u.s_b2, 1, 128, 256, h0, h1, h2, hs));
       } else {
         NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));

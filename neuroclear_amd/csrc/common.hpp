@@ -282,6 +282,8 @@ int h2_guard_decide(unsigned* ga, unsigned* gb, unsigned* prior, unsigned* flag,
 int h2_to_s3_if(const void* xh, void* xs, int N, int C, long S, const unsigned* cells, const unsigned* guard, hipStream_t s);
 int act_split2h(const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C, long S, int ctot,
                 int c0, float bound, unsigned* cell, unsigned* cell2, hipStream_t s);
+int act_split2h_pool(const float* x, const float* mean, const float* rstd, float slope, void* ys, void* pooled, int N, int C, int D, int H, int W,
+                     int ctot, int c0, float bound, unsigned* cell, hipStream_t s);
 int conv_s3x(const void* xs, const float* w, const float* bias, float* y, int N, int Cin, int D, int H, int W, int Kout, int KS, long so,
              long si, int flip, void* wp_ws, hipStream_t s, const unsigned* guard = nullptr);
 bool conv_keep_supported(int N, int C, int D, int H, int W, int K, int ks);
