@@ -325,6 +325,9 @@ int conv_wgrad_c8x(const void* xh, const void* dyh, float* dw, const ConvDims& d
 size_t s3_wgrad_ws_bytes(const ConvDims& d);
 int conv_wgrad_s3(const float* x, const void* xs, const float* dy, const void* dys, float* dw, const ConvDims& d, void* ws, size_t wsb,
                   hipStream_t s);
+bool s3x_k32_supported(int N, int D, int H, int W);
+bool conv_fwd_h2_k32_supported(const ConvDims& d);
+int conv_fwd_h2_k32_keep(const float* x, const float* w, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s, void* xs_keep);
 bool conv_fwd_h2_c32_supported(const ConvDims& d);
 size_t conv_fwd_h2_c32_ws_bytes(const ConvDims& d);
 int conv_fwd_h2_c32(const float* x, const float* w, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);

@@ -206,15 +206,19 @@ __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
 // sums of bias-free convolution outputs cancel far less) -- so that InstanceNorm needs no pass of its own over the raw output
 // (k_in_stats read 2.9 GB per 140^3 cube: 0.6 of 11.1 ms).  fp32 within a tile (128 values per channel: 8 per lane, then a butterfly over the
 // 16 lanes of a column block row), fp64 across tiles in s3x_stats_finalize (fixed order: deterministic).
-template <int KS, int NCB, int NT, bool ST = false>
+// K32: ONE 32-channel output slice per tile instead of two -- the eight waves are eight position groups of NCB column blocks (a tile of 128 NCB
+// positions) and all read the weights of "half 0".  For convolutions onto 32 output channels (deep_linear_gen's collapsed forward, gen_nets.hip):
+// on the 64-channel tile half of the MFMAs would multiply zero weights.
+template <int KS, int NCB, int NT, bool ST = false, bool K32 = false>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-  constexpr int PAD = KS / 2, T2 = KS * KS, PT = 64 * NCB;
+  constexpr int PAD = KS / 2, T2 = KS * KS, PT = (K32 ? 128 : 64) * NCB;
+  static_assert(!(K32 && ST), "no epilogue statistics on 32-channel tiles");
   if (guard_skip(p.guard, NT == 3)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
-  const int half = wave & 1, pg = wave >> 1;
+  const int half = K32 ? 0 : wave & 1, pg = K32 ? wave : wave >> 1;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
   const int NB = p.NCH * KS;     // bricks per tile
   const int BB = p.npb * 1024;   // bytes per ring slot
@@ -299,7 +303,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     wrsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
   }
   const int wvoff = lane * 16;
-  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((cot * 2 + half) * p.NS) * (2 * NT * 1024); };
+  auto wtile = [&](int cot) __attribute__((always_inline)) { return ((K32 ? cot : cot * 2 + half) * p.NS) * (2 * NT * 1024); };
   auto load_a = [&](u32x4 (&A)[2][NT], int soff) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -694,7 +698,7 @@ int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round
   return m;
 }
 
-XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
+XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = false) {
   XPlan best{};
   double best_cost = 1e30;
   const int P = W + KS - 1;
@@ -702,11 +706,12 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
   static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
   for (int NCB : {8, 7, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
+    if (k32 && NCB != 4 && NCB != 2) continue;  // (32-channel tiles: the instantiated shapes; a tile is 128 NCB positions)
     static const int odd_ok = getenv("NC_S3X_NCB7") ? atoi(getenv("NC_S3X_NCB7")) : 1;  // NC_S3X_NCB7=0: even column-block counts only (A/B)
     if ((NCB & 1) && !odd_ok) continue;
     XPlan pl{};
     pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
-    const int PT = 64 * NCB;
+    const int PT = (k32 ? 128 : 64) * NCB;
     if (!x_brick(PT, P, KS, NT, pl.UB, pl.npb, pl.lds)) continue;
     pl.TPP = (int)((HP + PT - 1) / PT);
     const long ntiles = (long)N * D * pl.TPP * KT;
@@ -722,6 +727,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
         if (pl.rem * (NCB / 2) <= 256) f = NCB / 2;
         else if (NCB == 8 && pl.rem * 2 <= 256) f = 2;
       }
+      if (k32 && f > 2) f = 2;
       pl.fsub = f;
       cost += PT / f + fixed;
     }
@@ -731,9 +737,9 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3) {
   return best;
 }
 
-template <int KS, int NCB, int NT, bool ST = false>
+template <int KS, int NCB, int NT, bool ST = false, bool K32 = false>
 int launch_x(const XParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_s3x<KS, NCB, NT, ST>;
+  auto kern = k_conv_s3x<KS, NCB, NT, ST, K32>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
@@ -836,7 +842,7 @@ void epi_stats_set(int on) { g_epi_stats.store(on < 0 ? 0 : on > 2 ? 2 : on, std
 int s3x_ksteps(int Cin, int KS) { return (KS * KS * KS * (Cin / 8) / 4 + 1) & ~1; }
 size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
   const int NS = s3x_ksteps(Cin, KS);
-  return (size_t)(Kout / 64) * 2 * NS * 2 * NT * 1024;
+  return (size_t)(Kout / 32) * NS * 2 * NT * 1024;  // (32-channel slices: two per 64-channel tile)
 }
 
 // NC_SPLIT_TERMS / nc_set_split_terms: which form of the split the fp32 3^3 / 5^3 layers use -- the two-term fp16 form (three MFMA products per
@@ -847,6 +853,7 @@ static std::atomic<int> g_terms{getenv("NC_SPLIT_TERMS") ? atoi(getenv("NC_SPLIT
 void s3x_set_terms(int t) { g_terms = (t == 0 || t == 3) ? t : 2; }
 int s3x_get_terms() { return g_terms; }
 
+bool s3x_k32_supported(int N, int D, int H, int W) { return x_plan(N, D, H, W, 1, 5, 2, true).ok && (long)32 * D * H * W * 4 < (1l << 31); }
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
   if (KS != 3 && KS != 5) return false;
   if (Cin % 64 || Kout % 64) return false;  // an even number of whole k-steps: (Cin / 8) * KS^3 taps in fours
@@ -862,7 +869,9 @@ bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {
 int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, int split_c, const float* w, const float* bias, float* y, int N,
                 int Cin, int D, int H, int W, int Kout, int KS, long so, long si, int flip, unsigned* wcell, void* wp_ws, hipStream_t s,
                 const unsigned* guard, float* stats_part) {
-  const XPlan pl = x_plan(N, D, H, W, Kout / 64, KS, 2);
+  const bool k32 = Kout == 32;  // one 32-channel slice per tile (k_conv_s3x K32): 5^3, no epilogue statistics
+  if (k32 && (KS != 5 || stats_part || guard)) { set_error("conv_s3x_h2: 32 output channels for unguarded 5^3 launches only"); return NC_ERR_SHAPE; }
+  const XPlan pl = x_plan(N, D, H, W, k32 ? 1 : Kout / 64, KS, 2, k32);
   if (!pl.ok) { set_error("conv_s3x_h2: shape not covered"); return NC_ERR_SHAPE; }
   if (split_c < Cin && (flip || !cell_b || split_c % 8)) { set_error("conv_s3x_h2: scale groups only for the forward weight layout"); return NC_ERR_ARG; }
   if (stats_part && KS != 3) { set_error("conv_s3x_h2: epilogue statistics exist for the 3^3 layers only (the layers in front of an InstanceNorm)"); return NC_ERR_ARG; }
@@ -881,7 +890,7 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   XParams p{};
   p.xs = (const uint4*)xs; p.wp = (const uint4*)wp_ws; p.bias = bias; p.y = y; p.amax_x = cell_a; p.amax_w = wcell; p.guard = guard;
   p.N = N; p.NCH = NCH; p.D = D; p.H = H; p.W = W; p.K = Kout;
-  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = Kout / 64;
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = k32 ? 1 : Kout / 64;
   p.NS = NS; p.mP = magic(pl.P);
   static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 4;
   p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
@@ -890,7 +899,8 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
     p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
     p.stats = (float2*)stats_part;
-    const int e = stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s))
+    const int e = k32 ? (pl.NCB == 4 ? launch_x<5, 4, 2, false, true>(p, pl.lds + kOffTab, s) : launch_x<5, 2, 2, false, true>(p, pl.lds + kOffTab, s))
+                  : stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s))
                              : (KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s));
     if (e) return e;
   }
@@ -898,7 +908,8 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
     p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
     p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
     p.stats = stats_part ? (float2*)stats_part + pl.full * kWaves * 32 : nullptr;
-    const int e = stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)
+    const int e = k32 ? (pl.NCB / pl.fsub == 4 ? launch_x<5, 4, 2, false, true>(p, pl.ldst + kOffTab, s) : launch_x<5, 2, 2, false, true>(p, pl.ldst + kOffTab, s))
+                  : stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)
                                         : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s))
                              : (KS == 3 ? launch_x_ncb<3, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)
                                         : launch_x_ncb<5, 2>(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s));

@@ -1482,6 +1482,17 @@ int conv_fwd_h2_c32(const float* x, const float* w, float* y, const ConvDims& d,
   const int T3 = d.kd * d.kh * d.kw;
   return run_s3(x, nullptr, w, nullptr, y, d, d.C, d.K, (long)d.C * T3, T3, 0, ws, wsb, s, nullptr, true);
 }
+// The two-term 5^3 forward onto 32 output channels (k_conv_s3x K32), x converted into xs_keep as conv_fwd_keep does (measured cell, guard
+// counted, no fallback): deep_linear_gen's collapsed forward, which wants 27 channels of layer 1's output space and never the 64 (gen_nets.hip)
+bool conv_fwd_h2_k32_supported(const ConvDims& d) {
+  if (s3x_get_terms() != 2 || d.C % 64 || d.K != 32 || d.kd != 5 || d.kh != 5 || d.kw != 5 || d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 2 || d.ph != 2 || d.pw != 2)
+    return false;
+  return s3x_k32_supported(d.N, d.D, d.H, d.W);
+}
+int conv_fwd_h2_k32_keep(const float* x, const float* w, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s, void* xs_keep) {
+  if (!conv_fwd_h2_k32_supported(d) || !xs_keep) { set_error("conv_fwd_h2_k32_keep: shape not covered"); return NC_ERR_SHAPE; }
+  return run_s3(x, nullptr, w, nullptr, y, d, d.C, d.K, (long)d.C * 125, 125, 0, ws, wsb, s, xs_keep, true);
+}
 // The two-term weight-gradient kernel on operands of the caller's choice (x / dy fp32, or xs / dys H2 tensors with their cells): any C % 32,
 // K % 64 the plan covers -- not only the layers s3_layer_h2 admits (deep_linear_gen's collapsed backward uses C = 32, gen_nets.hip)
 bool wgrad_h2_supported(const ConvDims& d) { return s3x_get_terms() == 2 && ws_shape_ok(d) && ws_kv(d, 2) == 32 && ws_plan(d, 2).ok && ws_part_bytes(d, 2) != 0; }

@@ -461,6 +461,36 @@ __global__ void __launch_bounds__(128) k_dl_w1_fold(const float* __restrict__ E,
     for (int k = 0; k < 64; ++k) v += (double)w1[((long)k * 64 + c) * 125 + 124 - sidx] * (double)E[k * 27 + a];
   wf[((long)c * 32 + a) * 125 + sidx] = (float)v;
 }
+// ---- the forward without act1 ---------------------------------------------------------------------------------------------------------------
+// Once the backward takes q from P, act1 is wanted by ONE consumer: y = E (*) act1.  With F_t[c][s] = sum_c' E[c'][t] W1[c'][c][s] (27 kernels
+// 64 -> 1, 5^3):   y[v] = sum_t [v + t - 1 inside the volume] Z_t[v + t - 1],   Z_t = F_t (*) act0  on the volume
+// -- a 5^3 convolution 64 -> 27 (padded to 32: k_conv_s3x K32, half the matrix work of 64 -> 64) and a 27-term shifted sum; the bracket IS
+// the zero padding of act1.  act1 is never written; the backward (rank forms above) does not miss it.
+__global__ void __launch_bounds__(128) k_dl_fold_fwd(const float* __restrict__ E, const float* __restrict__ w1, float* __restrict__ F) {
+  const int t = blockIdx.x, c = blockIdx.y, sidx = threadIdx.x;
+  if (sidx >= 125) return;
+  double v = 0.0;
+  if (t < 27)
+    for (int cp = 0; cp < 64; ++cp) v += (double)E[cp * 27 + t] * (double)w1[((long)cp * 64 + c) * 125 + sidx];
+  F[((long)t * 64 + c) * 125 + sidx] = (float)v;
+}
+__global__ void __launch_bounds__(256) k_dl_combine27(const float* __restrict__ Z, float* __restrict__ y, int D, int H, int W) {
+  const long S = (long)D * H * W;
+  const int n = blockIdx.y;
+  const float* z = Z + (long)n * 32 * S;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
+    const int x = (int)(v % W), yy = (int)((v / W) % H), zz = (int)(v / ((long)W * H));
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+      if ((unsigned)(x + dx) < (unsigned)W && (unsigned)(yy + dy) < (unsigned)H && (unsigned)(zz + dz) < (unsigned)D)
+        acc += z[(long)t * S + v + ((long)dz * H + dy) * W + dx];
+    }
+    y[(long)n * S + v] = acc;
+  }
+}
+
 // q itself is a contraction of the same P: q[c'][t] = sum_{c,s} W1[c'][c][s] P[t][c][s] (act1 = W1 (*) act0, and the shift a = t of dy IS the
 // mask "v + t - 1 inside the volume") -- no pass over act1.  Written tap-flipped, as k_dl_tail_w2 reads it.  Block (c', t), fixed-order tree.
 __global__ void __launch_bounds__(256) k_dl_q_from_p(const float* __restrict__ w1, const float* __restrict__ Pq, float* __restrict__ qf) {
@@ -489,6 +519,7 @@ __global__ void __launch_bounds__(128) k_dl_w1_contract(const float* __restrict_
   dw1[((long)k * 64 + c) * 125 + t] = (float)v;
 }
 constexpr unsigned kKeptCollapsed = 1u << 31;
+constexpr unsigned kKeptNoAct1 = 1u << 30;  // ... and layer 1 ran in its 64 -> 27 form: act1 was never written ("the forward without act1")
 
 // (8 workgroups, each derives a and e for itself and 216 of E's 1728 entries; loops unrolled so that the loads of a sum are in flight together)
 __global__ void __launch_bounds__(256) k_dl_compose(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ w4,
@@ -670,7 +701,22 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
   const bool collapse = g_dl_collapse.load(std::memory_order_relaxed) != 0;
   char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
   hipStream_t hs = (hipStream_t)stream;
+  static const bool k32_on = !(getenv("NC_DL_K32") && atoi(getenv("NC_DL_K32")) == 0);
   for (int i = 0; i < 6; ++i) {
+    ConvDims dk;
+    if (collapse && i == 1 && saved && k32_on && make_dims(dk, N, 64, S0, S1, S2, 32, 5, 5, 5, 1, 2) && conv_fwd_h2_k32_supported(dk) &&
+        (size_t)256 + s3x_packed_bytes(64, 32, 5, 2) + 512 <= p.conv_ws) {
+      // layers 1 .. 5 without act1 ("the forward without act1" above): Z = the 64 -> 27 convolution of act0, y = its shifted sum
+      hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
+      hipLaunchKernelGGL(k_dl_fold_fwd, dim3(32, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), params + p.w[1], (float*)(tail + LTail::Wf));
+      NC_TRY(check_launch("deep_linear_fwd: composed forward weights"));
+      float* Z = saved + p.act[1];  // (the slot act1 would take: 32 of its 64 channels)
+      NC_TRY(conv_fwd_h2_k32_keep(in, (const float*)(tail + LTail::Wf), Z, dk, cws, p.conv_ws, hs, saved + p.xs3[1]));
+      hipLaunchKernelGGL(k_dl_combine27, dim3(1024, (unsigned)N), dim3(256), 0, hs, (const float*)Z, y, S0, S1, S2);
+      NC_TRY(check_launch("deep_linear_fwd: shifted sum"));
+      kept_mask |= kKeptCollapsed | kKeptNoAct1 | (1u << 1) | (1u << 17);
+      break;
+    }
     if (collapse && i == 2) {  // layers 2 .. 5 as one 64 -> 1 convolution of act1 (see "the collapsed tail" above)
       hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
       NC_TRY(check_launch("deep_linear_fwd: compose"));
@@ -722,7 +768,7 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
   if (kept_mask & kKeptCollapsed) {  // the forward left no act2 .. act4: layers 2 .. 5 from dy, act1 and the weights alone
     hipStream_t hs = (hipStream_t)stream;
     char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
-    const float* act1 = saved + p.act[1];
+    const float* act1 = saved + p.act[1];  // (kKeptNoAct1: not there)
     hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
     NC_TRY(check_launch("deep_linear_bwd: compose"));
     if (rank_w) {
@@ -735,6 +781,10 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
       hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
       NC_TRY(check_launch("deep_linear_bwd: q, dW1"));
     } else {
+      if (kept_mask & kKeptNoAct1) {  // (the forward never wrote act1 and the switches changed since: form it now, in a gradient buffer)
+        NC_TRY(nc_conv_fwd(saved + p.act[0], params + p.w[1], nullptr, G + p.g[1], N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2, cws, p.conv_ws, stream));
+        act1 = G + p.g[1];
+      }
       // q (tap-flipped): the weight gradient of Conv3d(1, 64, 3) with x := dy and dY := act1
       NC_TRY(nc_conv_wgrad(dy, act1, (float*)(tail + LTail::q), nullptr, N, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1, cws, p.conv_ws, stream));
     }

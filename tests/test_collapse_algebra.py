@@ -5,7 +5,8 @@ against torch autograd of the layer-by-layer chain -- independent of any kernel 
   * layers 2 .. 5 are ONE 64 -> 1 convolution of act1 with E[c][t] = sum_k e[k] W2[k][c][t], e = W5 W4 W3 -- exact at the faces too;
   * dW2 .. dW5 and dL/dact1 follow from dy, act1 and the weights (q[c][t] = sum_v dy[v] act1[c][v + t - 1]);
   * the 5^3 layer's two gradients follow from 27 shifted copies of the one-channel dy, Dsh[a][v] = dy[v - (a - 1)] inside the volume:
-    dW1 = E . P with P a weight gradient between Dsh and act0, dL/dact0 = a forward convolution of Dsh with composed weights Wf.
+    dW1 = E . P with P a weight gradient between Dsh and act0, dL/dact0 = a forward convolution of Dsh with composed weights Wf;
+  * act1 itself is needed by nobody: y is a shifted sum of a 64 -> 27 convolution of act0, q a contraction of P.
 Odd, unequal extents on purpose: every face, edge and corner of the volume is a different case of the padding argument."""
 import numpy as np
 import torch
@@ -70,6 +71,12 @@ def test_collapsed_tail_and_rank_forms_equal_the_layered_chain():
         Wf = torch.einsum('kcdhw,ka->cadhw', W[1].flip(2, 3, 4), Ef)                        # [64][27][5][5][5]
         g0 = F.conv3d(Dsh[None], Wf, padding=2)
         assert torch.allclose(g0, a0.grad, rtol=0, atol=1e-11)
+        # the forward without act1: Z_t = F_t (*) act0 (a 64 -> 27 convolution), y[v] = sum_t [v + t - 1 inside] Z_t[v + t - 1]
+        Ft = torch.einsum('ka,kcdhw->acdhw', Ef, W[1])                                      # [27][64][5][5][5]
+        Z = F.conv3d(a0, Ft, padding=2)[0]
+        Zp = F.pad(Z, (1, 1, 1, 1, 1, 1))
+        ysum = sum(Zp[(tz * 3 + ty) * 3 + tx, tz:tz + D, ty:ty + H, tx:tx + Wd] for tz in range(3) for ty in range(3) for tx in range(3))
+        assert torch.allclose(ysum[None, None], y, rtol=0, atol=1e-11)
         # ... and q itself is a contraction of the same P (no pass over act1 is needed for it)
         assert torch.allclose(torch.einsum('kcdhw,acdhw->ka', W[1], P).reshape(64, 3, 3, 3), q, rtol=0, atol=1e-11)
 
