@@ -315,9 +315,9 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
 /* deep_linear_gen's layers 2 .. 5 (3^3, then three 1 x 1; reference networks.py:902-911) are bias-free with nothing in between: 1 (default;
  * NC_DL_COLLAPSE at load time) evaluates them in collapsed form -- ONE 64 -> 1 convolution forward, and backward the six parameter gradients
  * and dL/dact1 from dy, act1 and the weights alone (csrc/gen_nets.hip, "the collapsed tail"), and the 5^3 layer's two gradients from 27 shifted
- * copies of the one-channel dy (half the matrix work each: "layer 1's weight gradient from the rank structure of its dY") -- exact algebra,
- * weight-space products in fp64, the same outputs and gradients to fp32 rounding (closer to an fp64 evaluation than the fp32 chain), 6 ms less
- * per 108^3 training step; 0: layer by layer as the reference's autograd does.  nc_deep_linear_lp_* follows the same switch (do not change it
+ * copies of the one-channel dy (half the matrix work each: "layer 1's weight gradient from the rank structure of its dY"), and the forward of
+ * the 5^3 layer as a 64 -> 27 convolution plus a shifted sum ("the forward without act1") -- exact algebra, weight-space products in fp64, the
+ * same outputs and gradients to fp32 rounding (closer to an fp64 evaluation than the fp32 chain), 8 ms less per 108^3 training step; 0: layer by layer as the reference's autograd does.  nc_deep_linear_lp_* follows the same switch (do not change it
  * between a forward and its backward there; nc_deep_linear_fwd / _bwd carry the forward's choice in `kept`). */
 void nc_set_dl_collapse(int on);
 int nc_get_dl_collapse(void);
