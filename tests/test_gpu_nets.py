@@ -659,6 +659,33 @@ def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, ter
         lib().nc_set_dl_collapse(prev[1])
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 48, 48, 48), (1, 1, 80, 72, 64)])
+def test_deep_linear_default_path_is_bit_identical_run_to_run(shape):
+    """The default evaluation of deep_linear_gen launches k_conv_s3x in two shapes nothing else uses -- 32-channel output tiles (K32) and
+    32-channel inputs with a zero-weight padding k-step that multiplies whatever the LDS ring holds -- next to hand-counted vmcnt waits: twelve
+    forward + backward passes, every other one after an idle gap, must give the same bits (a timing dependence would show here)."""
+    import time
+    net = load(networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0]), S.deep_linear_spec(), 32)
+    x0 = torch.from_numpy(rnd(41, shape)).to(DEV)
+    r = torch.from_numpy(rnd(42, shape)).to(DEV)
+    ref = None
+    for it in range(12):
+        torch.cuda.synchronize()
+        if it % 2:
+            time.sleep(0.03)
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = net(x)
+        (y * r).sum().backward()
+        got = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        assert all(bool(torch.isfinite(t).all()) for t in got)
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), it
+
+
 @pytest.mark.parametrize('kind,shape', [('unet', (1, 1, 16, 16, 16)), ('unet', (2, 1, 12, 20, 24)), ('unet', (3, 1, 8, 8, 36)),
                                         ('linear', (1, 1, 16, 16, 16)), ('linear', (2, 1, 9, 14, 21))])
 @pytest.mark.parametrize('want_dx', [False, True])
