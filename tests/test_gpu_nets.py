@@ -659,6 +659,38 @@ def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, ter
         lib().nc_set_dl_collapse(prev[1])
 
 
+def test_deep_linear_backward_survives_a_switch_of_arithmetic_after_the_forward():
+    """The default forward of deep_linear_gen never writes act1 (csrc/gen_nets.hip, "the forward without act1") and its backward takes q from the
+    32 x 64 weight gradient P -- in the two-term arithmetic.  A caller who switches to the three-term form BETWEEN a forward and its backward
+    (include/nc_hip.h advises against it) must still get the right gradients: the backward sees in `kept` that act1 is missing, forms it in a
+    gradient buffer and walks the first-stage collapsed path."""
+    from neuroclear_amd._lib import lib
+    prev = lib().nc_get_split_terms()
+    net = load(networks.define_G(1, 1, 64, 'deep_linear_gen', 'instance', False, 'kaiming', 0.02, [0]), S.deep_linear_spec(), 32)
+    shape = (1, 1, 36, 36, 36)
+    x0 = torch.from_numpy(rnd(41, shape)).to(DEV)
+    r = torch.from_numpy(rnd(42, shape)).to(DEV)
+
+    def run(switch):
+        lib().nc_set_split_terms(2)
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = net(x)
+        if switch:
+            lib().nc_set_split_terms(3)
+        (y * r).sum().backward()
+        return x.grad.clone(), [p.grad.clone() for p in net.parameters()]
+    try:
+        xa, ga = run(False)
+        xb, gb = run(True)
+    finally:
+        lib().nc_set_split_terms(prev)
+    assert rel2(xb.cpu().numpy(), xa.cpu().numpy()) < 1e-5
+    for (n, _), a, b in zip(net.named_parameters(), ga, gb):
+        assert rel2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5, n
+
+
 @pytest.mark.parametrize('shape', [(1, 1, 48, 48, 48), (1, 1, 80, 72, 64)])
 def test_deep_linear_default_path_is_bit_identical_run_to_run(shape):
     """The default evaluation of deep_linear_gen launches k_conv_s3x in two shapes nothing else uses -- 32-channel output tiles (K32) and
