@@ -308,11 +308,22 @@ def run_train(args, rank, world, dev):
                              for t, s in sorted(stats.items())},
                     conv_ms_per_step=round(conv_ms / args.steps, 2),
                     whole_network_calls={t: dict(n=c[0], ms_per_step=round(c[1] / args.steps, 3),
-                                                 tflops=round(c[2] / c[1] / 1e9, 2)) for t, c in sorted(calls.items())})
+                                                 tflops=round(c[2] / c[1] / 1e9, 2), **_dl_note(t, c[2] / c[1] / 1e9, args))
+                                         for t, c in sorted(calls.items())})
     losses = {k: round(v, 5) for k, v in model.get_current_losses().items()}
     return dt, crop ** 3 * args.batch * args.steps * world, roof, dict(
         workload='%s_train_step_%dcube_bs%d' % (args.model, crop, args.batch), crop=crop, batch_size=args.batch,
         parallelism='dp%d' % world, gan_mode='lsgan', norm='instance', data=args.data, first_step_losses=dict(first), losses=losses)
+
+
+def _dl_note(tag, tflops, args):
+    """deep_linear_gen's whole-network calls are counted with the REFERENCE's FLOPs (layer by layer: 647,120 MAC per voxel forward, twice that
+    backward); the default evaluation executes 277,979 / 555,904 of them where the two-term kernels cover the shape."""
+    from neuroclear_amd._lib import lib
+    if not tag.startswith('deep_linear') or args.precision != 'fp32' or not lib().nc_get_dl_collapse() or lib().nc_get_split_terms() != 2:
+        return {}
+    share = 277979.0 / 647120.0 if tag.endswith('fwd') else 555904.0 / 1294240.0
+    return dict(tflops_is='on the reference\'s layer-by-layer FLOP count', tflops_executed=round(tflops * share, 2), executed_share_of_reference_flops=round(share, 4))
 
 
 GA_FWD_FLOP_PER_VOXEL = 1.327618e6  # unet_deconv forward, dense count (BASELINE.md 2 / SURVEY.md 8d)
