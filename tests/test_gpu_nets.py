@@ -604,7 +604,7 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
     assert torch.equal(xi.grad, xa)
 
 
-@pytest.mark.parametrize('shape', [(1, 1, 16, 16, 16), (2, 1, 9, 14, 21), (1, 1, 12, 20, 24), (1, 1, 36, 36, 36), (1, 1, 72, 64, 80)])
+@pytest.mark.parametrize('shape', [(1, 1, 16, 16, 16), (2, 1, 9, 14, 21), (1, 1, 12, 20, 24), (1, 1, 36, 36, 36), (1, 1, 72, 64, 80), (3, 1, 24, 28, 32)])
 @pytest.mark.parametrize('want_dx', [False, True])
 @pytest.mark.parametrize('terms', [3, 2])
 def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, terms):
