@@ -346,6 +346,7 @@ int conv_wgrad_h(const float* x, const void* xh, const float* dy, const void* dy
                  void* ws, size_t wsb, hipStream_t s);
 int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int ctot, int c0, const ConvDims& d, int dt,
                   void* ws, size_t wsb, hipStream_t s);
+int conv_fwd_h_na1(const void* xh, const float* w, float* y, const ConvDims& d, int dt, void* ws, size_t wsb, hipStream_t s);
 int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,
                     size_t wsb, hipStream_t s);
 // deep_linear_gen's collapsed tail (gen_nets.hip, "the collapsed tail"): the weight-space steps, shared with the 16-bit path.  tail: dl_tail_bytes()
@@ -363,7 +364,9 @@ int dl_tail_grads(const float* w2, const float* w3, const float* w4, const float
 float* dl_tail_P(char* tail);
 const float* dl_w1_fold(char* tail, const float* w1, hipStream_t s);  // [64][32][125]: layer 1's data gradient as a forward convolution of Dsh
 int dl_w1_contract(const char* tail, float* dw1, hipStream_t s);
-int dl_q_from_p(char* tail, const float* w1, hipStream_t s);  // q (tap-flipped, into the tail scratch) as a contraction of P and W1
+int dl_q_from_p(char* tail, const float* w1, hipStream_t s);
+const float* dl_fold_fwd64(char* tail, const float* w1, hipStream_t s);  // F[t][c][s] = sum_c' E[c'][t] W1[c'][c][s] as [64][64][125], rows >= 27 zero
+int dl_combine27(const float* Z, float* y, int N, int D, int H, int W, int zch, hipStream_t s);  // y[v] = sum_t [v + t - 1 inside] Z[t][v + t - 1]  // q (tap-flipped, into the tail scratch) as a contraction of P and W1
 // one-channel KS^3 layers (KS = 3, 7) in "pseudo-channel" form on the 16-bit cores (conv_h.hip)
 bool c1_h_supported(int D, int H, int W, int KS);
 size_t c1_h_ws_bytes(int N, int D, int H, int W, int KS);

@@ -563,7 +563,7 @@ int launch_h_vb(int VB, const HParams& p, int lds, hipStream_t s) {
 template <int DT>
 int run_h(const float* x, const void* xh_pre, const float* w, const float* bias, float* y, const ConvDims& d, int Cin,
           int Kout, long so, long si, int flip, void* ws, size_t wsb, hipStream_t s, void* yh = nullptr, int ctot = 0,
-          int c0 = 0) {
+          int c0 = 0, bool na1 = false) {  // na1: only output channels 0 .. 31 of the (one) 64-channel tile are computed (5^3, fp32 output)
   const int KS = d.kd, T3 = KS * KS * KS;
   const HPlan pl = h_plan(d);
   const long S = (long)d.D * d.H * d.W;
@@ -579,7 +579,7 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
     if (int e = check_launch("to_c8")) return e;
   }
   // the tap-stream kernel (conv_c8x.hip) wherever it covers the shape and its 512-position tiles quantise well; NC_C8X=0: never
-  if (c8x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS, yh == nullptr) && wb >= c8x_packed_bytes(Cin, Kout, KS))
+  if (!na1 && c8x_supported(d.N, Cin, d.D, d.H, d.W, Kout, KS, yh == nullptr) && wb >= c8x_packed_bytes(Cin, Kout, KS))
     return conv_c8x(xh, w, bias, yh ? nullptr : y, yh, ctot, c0, d.N, Cin, d.D, d.H, d.W, Kout, KS, so, si, flip, g_wdiffuse, DT, wp, s);
   const long total = (long)(packed_bytes(Cin, Kout, KS) / 2);
   if (g_wdiffuse)
@@ -604,6 +604,10 @@ int run_h(const float* x, const void* xh_pre, const float* w, const float* bias,
   static const int ablate = getenv("NC_H_ABLATE") ? atoi(getenv("NC_H_ABLATE")) : 0;
   p.ablate = ablate;
   const int lds = 2 * pl.SB;
+  if (na1) {
+    if (KS != 5 || Kout != 64 || yh) { set_error("conv_h: the 32-channel form exists for 5^3, one 64-channel tile, fp32 output"); return NC_ERR_SHAPE; }
+    return launch_h_vb<DT, 5, 5, 5, true, 1>(pl.VB, p, lds, s);
+  }
   if (KS == 3) return launch_h_vb<DT, 3, 3, 3, false, 2>(pl.VB, p, lds, s);
   return launch_h_vb<DT, 5, 5, 5, true, 2>(pl.VB, p, lds, s);
 }
@@ -1105,6 +1109,16 @@ int conv_fwd_h_c8(const void* xh, const float* w, const float* b, void* yh, int 
   ProfScope ps(0, 1, d, 1, s);
   if (dt == NC_DT_F16) return run_h<NC_DT_F16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
   return run_h<NC_DT_BF16>(nullptr, xh, w, b, nullptr, d, d.C, d.K, d.C * T3, T3, 0, ws, wsb, s, yh, ctot, c0);
+}
+
+// 5^3 forward from a C8 input onto the FIRST 32 output channels of a [64][Cin][125] weight tensor (rows 32 .. 63 are not read by the matrix
+// instructions), fp32 output y[n][64][S] of which channels 0 .. 31 are written: half the matrix work of the 64-channel layer.  deep_linear_gen's
+// forward without act1 on the 16-bit path (gen_nets_lp.hip).
+int conv_fwd_h_na1(const void* xh, const float* w, float* y, const ConvDims& d, int dt, void* ws, size_t wsb, hipStream_t s) {
+  if (dt != NC_DT_BF16 || d.K != 64 || d.kd != 5 || !h_fwd_supported(d)) { set_error("conv_fwd_h_na1: shape not covered"); return NC_ERR_SHAPE; }
+  ConvDims dh = d;
+  ProfScope ps(0, 1, dh, 1, s);
+  return run_h<NC_DT_BF16>(nullptr, xh, w, nullptr, y, d, d.C, d.K, (long)d.C * 125, 125, 0, ws, wsb, s, nullptr, 0, 0, true);
 }
 
 int conv_dgrad_h_c8(const void* dyh, const float* w, void* dxh, int ctot, int c0, const ConvDims& d, int dt, void* ws,

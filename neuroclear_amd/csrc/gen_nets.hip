@@ -474,10 +474,10 @@ __global__ void __launch_bounds__(128) k_dl_fold_fwd(const float* __restrict__ E
     for (int cp = 0; cp < 64; ++cp) v += (double)E[cp * 27 + t] * (double)w1[((long)cp * 64 + c) * 125 + sidx];
   F[((long)t * 64 + c) * 125 + sidx] = (float)v;
 }
-__global__ void __launch_bounds__(256) k_dl_combine27(const float* __restrict__ Z, float* __restrict__ y, int D, int H, int W) {
+__global__ void __launch_bounds__(256) k_dl_combine27(const float* __restrict__ Z, float* __restrict__ y, int D, int H, int W, int zch) {
   const long S = (long)D * H * W;
   const int n = blockIdx.y;
-  const float* z = Z + (long)n * 32 * S;
+  const float* z = Z + (long)n * zch * S;  // (zch: channels per sample of the Z tensor, 32 or 64; the first 27 are read)
   for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < S; v += (long)gridDim.x * 256) {
     const int x = (int)(v % W), yy = (int)((v / W) % H), zz = (int)(v / ((long)W * H));
     float acc = 0.f;
@@ -617,6 +617,19 @@ const float* dl_w1_fold(char* tail, const float* w1, hipStream_t s) {  // compos
   hipLaunchKernelGGL(k_dl_w1_fold, dim3(64, 32), dim3(128), 0, s, (const float*)(tail + LTail::E), w1, (float*)(tail + LTail::Wf));
   return check_launch("deep_linear_bwd: composed data-gradient weights") ? nullptr : (const float*)(tail + LTail::Wf);
 }
+// the forward without act1 for the 16-bit path: F as a [64][64][125] tensor (rows 27 .. 63 zero) in the tail scratch (the P and Wf regions,
+// adjacent, 2 MB + 512 B; free in a forward), and the shifted sum over a Z tensor of `zch` channels per sample
+const float* dl_fold_fwd64(char* tail, const float* w1, hipStream_t s) {
+  static_assert(LTail::Wf == LTail::P + (size_t)64 * 32 * 125 * 4 + 256, "P and Wf adjacent");
+  float* F = (float*)(tail + LTail::P);
+  if (hipMemsetAsync(F + (size_t)32 * 64 * 125, 0, (size_t)32 * 64 * 125 * 4, s) != hipSuccess) return nullptr;
+  hipLaunchKernelGGL(k_dl_fold_fwd, dim3(32, 64), dim3(128), 0, s, (const float*)(tail + LTail::E), w1, F);
+  return check_launch("deep_linear_fwd: composed forward weights") ? nullptr : F;
+}
+int dl_combine27(const float* Z, float* y, int N, int D, int H, int W, int zch, hipStream_t s) {
+  hipLaunchKernelGGL(k_dl_combine27, dim3(1024, (unsigned)N), dim3(256), 0, s, Z, y, D, H, W, zch);
+  return check_launch("deep_linear_fwd: shifted sum");
+}
 int dl_q_from_p(char* tail, const float* w1, hipStream_t s) {
   hipLaunchKernelGGL(k_dl_q_from_p, dim3(64, 27), dim3(256), 0, s, w1, (const float*)(tail + LTail::P), (float*)(tail + LTail::q));
   return check_launch("deep_linear_bwd: q");
@@ -712,7 +725,7 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
       NC_TRY(check_launch("deep_linear_fwd: composed forward weights"));
       float* Z = saved + p.act[1];  // (the slot act1 would take: 32 of its 64 channels)
       NC_TRY(conv_fwd_h2_k32_keep(in, (const float*)(tail + LTail::Wf), Z, dk, cws, p.conv_ws, hs, saved + p.xs3[1]));
-      hipLaunchKernelGGL(k_dl_combine27, dim3(1024, (unsigned)N), dim3(256), 0, hs, (const float*)Z, y, S0, S1, S2);
+      hipLaunchKernelGGL(k_dl_combine27, dim3(1024, (unsigned)N), dim3(256), 0, hs, (const float*)Z, y, S0, S1, S2, 32);
       NC_TRY(check_launch("deep_linear_fwd: shifted sum"));
       kept_mask |= kKeptCollapsed | kKeptNoAct1 | (1u << 1) | (1u << 17);
       break;

@@ -433,6 +433,14 @@ bool llp_plan(LLp& p, int N, int S0, int S1, int S2) {
   return true;
 }
 
+// the rank-structured backward of the 5^3 layer (gen_nets.hip) is available at this shape: 32-channel shapes of the weight-gradient and
+// forward kernels fit the plan's workspace
+bool llp_rank_ok(const LLp& p, ConvDims& dsh) {
+  static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
+  return rank_on && p.c1 && p.c3 && make_dims(dsh, p.N, 32, p.d[0], p.d[1], p.d[2], 64, 5, 5, 5, 1, 2) && c8x_wgrad_supported(dsh) &&
+         c8x_wgrad_part_bytes(dsh) <= p.conv_ws && h_fwd_supported(dsh) && h_ws_bytes(dsh) <= p.conv_ws;
+}
+
 size_t llp_ws_bytes(const LLp& p) { return al(p.conv_ws) + al(p.f32conv_ws) + al(p.o64_ws) + al(p.c1_ws) + p.grads + 256; }
 
 }  // namespace
@@ -478,6 +486,18 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
   ConvDims c5, c3;
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+  ConvDims dshf;
+  static const bool k32_on = !(getenv("NC_DL_K32") && atoi(getenv("NC_DL_K32")) == 0);
+  if (k32_on && dl_collapse_on() && c1_wgrad_on() && llp_rank_ok(p, dshf)) {
+    // layers 1 .. 5 without f2 (gen_nets.hip, "the forward without act1"): Z = F (*) f1 on the first 32 channels of a 64-channel tile (half the
+    // matrix work of the 5^3 layer), y = its 27-term shifted sum.  The backward in its rank form does not miss f2 (q comes from P).
+    char* tail = G + p.tail;
+    NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
+    const float* F = dl_fold_fwd64(tail, params + p.w[1], hs);
+    if (!F) return NC_ERR_HIP;
+    NC_TRY(conv_fwd_h_na1(V + p.f1h, F, Ff, c5, dtype, cws, p.conv_ws, hs));
+    return dl_combine27(Ff, y, N, S0, S1, S2, 64, hs);
+  }
   NC_TRY(conv_fwd_h_c8(V + p.f1h, params + p.w[1], nullptr, V + p.f2h, 64, 0, c5, dtype, cws, p.conv_ws, hs));
   if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
     // layers 2 .. 5 as ONE 64 -> 1 convolution of f2 (gen_nets.hip, "the collapsed tail"): the data-gradient form of the one-channel 3^3 kernel
@@ -522,9 +542,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
     char* tail = G + p.tail;
     NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
     ConvDims dsh;
-    static const bool rank_on = !(getenv("NC_DL_RANK_WGRAD") && atoi(getenv("NC_DL_RANK_WGRAD")) == 0);
-    const bool rank = rank_on && p.c1 && make_dims(dsh, N, 32, S0, S1, S2, 64, 5, 5, 5, 1, 2) && c8x_wgrad_supported(dsh) &&
-                      c8x_wgrad_part_bytes(dsh) <= p.conv_ws && h_fwd_supported(dsh) && h_ws_bytes(dsh) <= p.conv_ws;
+    const bool rank = llp_rank_ok(p, dsh);
     if (rank) {
       hipLaunchKernelGGL(k_dl_shift27_c8, dim3(512, 4, (unsigned)N), dim3(256), 0, hs, dy, (uint4*)(G + p.B), S0, S1, S2);
       NC_TRY(check_launch("deep_linear_lp_bwd: shifted copies of dy"));
