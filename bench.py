@@ -145,8 +145,9 @@ def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
     ncores = min(os.cpu_count() or 1, 64)
     model, real = _oracle_apollo(crop, ncores)
     t0 = time.time()
-    model.step(real)
+    first = model.step(real)  # the FIRST step from the seeded weights: what gpu_parity_train() is compared with (parity_vs_cpu_oracle)
     warm = time.time() - t0
+    parity_ref = dict(losses=dict(first), fake=model.fake.detach().numpy().copy(), rec=model.rec.detach().numpy().copy())
     reps = max(1, min(reps, int((budget_s - warm) / max(warm, 1e-3))))
     ts = []
     for _ in range(reps):
@@ -161,7 +162,7 @@ def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
     m1.step(r1)
     t1 = time.time() - t0
     torch.set_num_threads(ncores)
-    return dict(value=crop ** 3 / med, unit='voxels/s', cores=ncores, kind='port',
+    return dict(value=crop ** 3 / med, unit='voxels/s', cores=ncores, kind='port', _parity_ref=parity_ref,
                 sample='Apollo optimize_parameters() on a %d^3 crop (oracle/apollo.py, torch-CPU fp32): 1 warm-up (%.1f s) + '
                        'median of %d steps = %.2f s/step on %d threads' % (crop, warm, reps, med, ncores),
                 one_thread=dict(value=36 ** 3 / t1, unit='voxels/s', cores=1, workload='apollo_train_step_36cube_bs1',
@@ -170,40 +171,132 @@ def cpu_baseline_train(crop=108, reps=3, budget_s=75.0):
                                        'thread takes minutes); the per-voxel rate of the small crop stands in for the 108^3 one' % t1))
 
 
+PARITY_SLAB_SHAPE = (100, 80, 80)  # pads to (225, 120, 120) at dice 120 / overlap 15: TWO 140^3 cubes stacked in z, overlapping by 15 planes
+PARITY_NET_SEED, PARITY_VOL_SEED = 3, 21
+
+
 def cpu_baseline_infer(budget_s=25.0, max_cubes=8):
     """configs[2] on the host cores: 140^3 cubes of the 900^3 / dice 120 / overlap 15 / border 10 geometry through the
     oracle's unet_deconv (oracle/nets.py) and overlap-add (oracle/dice.py) until max_cubes or budget_s, then scaled
-    linearly to the 729 cubes of the volume (EXTRAPOLATED -- stated in `sample`)."""
+    linearly to the 729 cubes of the volume (EXTRAPOLATED -- stated in `sample`).  The first two cubes are the two cubes of the
+    parity slab (PARITY_SLAB_SHAPE) through the oracle's whole dice pipeline -- pad, reflect, cut, normalise, network, overlap-add,
+    finalise (oracle/dice.py) -- and are what gpu_parity_infer() is compared with; the others are random cubes."""
     import torch
     from neuroclear_amd.util import seed as S
+    from oracle import dice as odice
     from oracle import nets as onets
     ncores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(ncores)
-    sd = onets.to_torch(S.weights_from_seed(S.unet_deconv_spec(), 3))
-    E, R, b, n_total = 140, 120, 10, 729
+    sd = onets.to_torch(S.weights_from_seed(S.unet_deconv_spec(), PARITY_NET_SEED))
+    E, R, ov, b, n_total = 140, 120, 15, 10, 729
+    vol = S.random_volume(PARITY_VOL_SEED, PARITY_SLAB_SHAPE)
+    padded = odice.pad_for_dicing(vol, R, ov)
+    steps = odice.grid_steps(padded.shape, R, ov)
+    refl = odice.reflect_pad(padded, b)
+    assert steps == (2, 1, 1)
     acc = np.zeros((R + 105, R, R), np.float32)
     rng = np.random.default_rng(0)
     done, t_net, t_asm = 0, 0.0, 0.0
+    slab_cubes = []
     with torch.no_grad():
         onets.unet_deconv(sd, torch.zeros(1, 1, 32, 32, 32))  # thread-pool warm-up
         t_start = time.time()
-        while done < max_cubes and (done == 0 or (time.time() - t_start) * (done + 1) / done < budget_s):
-            cube = (rng.integers(0, 65536, (E, E, E), dtype=np.uint16).astype(np.float64) / 65535.0).astype(np.float32)
+        while done < max_cubes and (done < 2 or (time.time() - t_start) * (done + 1) / done < budget_s):
+            if done < 2:
+                cube = odice.normalize(odice.cut_cube(refl, done, steps, R, ov, b))
+            else:
+                cube = (rng.integers(0, 65536, (E, E, E), dtype=np.uint16).astype(np.float64) / 65535.0).astype(np.float32)
             t0 = time.time()
-            y = onets.unet_deconv(sd, torch.from_numpy(cube)[None, None]).numpy()[0, 0]
+            y = onets.unet_deconv(sd, torch.from_numpy(np.ascontiguousarray(cube))[None, None]).numpy()[0, 0]
             t_net += time.time() - t0
             t0 = time.time()
             z0 = 105 * (done % 2)
             acc[z0:z0 + R] += y[b:-b, b:-b, b:-b] / 8  # the assembler's per-cube work (util/assemble_dice.py:167-173)
             t_asm += time.time() - t0
+            if done < 2:
+                slab_cubes.append(y.copy())
             done += 1
+    slab = odice.assemble(slab_cubes, padded.shape, vol.shape, R, ov, b, 'uint16')
     per_cube = (t_net + t_asm) / done
     total = per_cube * n_total
     return dict(value=900 ** 3 / total, unit='useful voxels/s', computed_voxels_per_s=n_total * E ** 3 / total,
-                cores=ncores, kind='port',
+                cores=ncores, kind='port', _parity_ref=dict(cubes=slab_cubes, slab=slab),
                 sample='%d cubes of 140^3 through oracle/nets.py::unet_deconv + overlap-add on %d threads: %.2f s/cube '
                        '(network %.2f, assemble %.3f), EXTRAPOLATED linearly to 729 cubes = %.0f s per 900^3 volume'
                        % (done, ncores, per_cube, t_net / done, t_asm / done, total))
+
+
+# ---- parity_vs_cpu_oracle: the HIP path on the SAME weights and inputs the CPU legs above run on, at the sizes the metric is quoted on
+PARITY_BOUNDS = dict(first_step_losses_max_rel=2e-5, fake_max_abs=2e-5, rec_max_rel=2e-4, cube_max_abs=2e-5, slab_max_lsb=2)
+
+
+def gpu_parity_train(dev, crop=108):
+    """One optimize_parameters() of the Apollo model on the GPU from the weights, crop and np.random draws of _oracle_apollo()
+    (reference axial_to_lateral_gan_apollo_model.py:285-307): unrounded first-step losses, fake and rec."""
+    import contextlib
+    import io
+    import torch
+    from neuroclear_amd.models import create_model
+    from neuroclear_amd.util import seed as S
+    from oracle import apollo as oapollo  # (names of the discriminators only)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(apollo_opt(dev.index))
+    specs = [('G_A', S.unet_deconv_spec()), ('G_B', S.deep_linear_spec())] + [(n, S.patchgan_spec(2)) for n in oapollo.APOLLO_D]
+    for i, (n, sp) in enumerate(specs):
+        getattr(model, 'net' + n).load_state_dict(S.state_dict_from_seed(sp, 7 + i, dev, bias_scale=0.0))
+    real = torch.from_numpy((S.random_volume(11, crop).astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev)
+    np.random.seed(0)
+    model.set_input({'A': real, 'A_paths': 'synthetic'})
+    model.optimize_parameters()
+    out = dict(losses={k: float(v) for k, v in model.get_current_losses().items()},
+               fake=model.fake.detach().float().cpu().numpy(), rec=model.rec.detach().float().cpu().numpy())
+    del model
+    return out
+
+
+def gpu_parity_infer(dev):
+    """The parity slab (two 140^3 cubes) through the product's diced inference (reference test_dice.py:107-118): the two raw network
+    outputs and the assembled uint16 volume."""
+    import torch
+    from neuroclear_amd.models import networks
+    from neuroclear_amd.test_dice import diced_inference
+    from neuroclear_amd.util import seed as S
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [dev.index])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), PARITY_NET_SEED, dev))
+    vol = S.random_volume(PARITY_VOL_SEED, PARITY_SLAB_SHAPE)
+    opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[dev.index], skip_real=True,
+                    data_type='uint16', histogram_match=False, normalize_intensity=False)
+    cubes = []
+
+    def on_cube(fn):
+        y = fn()
+        cubes.append(y)
+        return y
+    slab = diced_inference(net, vol, opt, 0, 1, assemble='gather', broadcast=False, on_cube=on_cube)
+    torch.cuda.synchronize()
+    return dict(cubes=[c.detach().float().reshape(140, 140, 140).cpu().numpy() for c in cubes], slab=np.asarray(slab))
+
+
+def parity_train(gpu, ref):
+    rel = {k: abs(gpu['losses'][k] - v) / max(abs(v), 1e-12) for k, v in ref['losses'].items()}
+    f = float(np.abs(gpu['fake'].astype(np.float64) - ref['fake']).max())
+    r = float(np.abs(gpu['rec'].astype(np.float64) - ref['rec']).max() / max(float(np.abs(ref['rec']).max()), 1e-30))
+    B = PARITY_BOUNDS
+    return dict(workload='apollo_train_step_108cube_bs1: first optimize_parameters() from the same seeded weights, crop and np.random draws',
+                first_step_losses_max_rel_diff=max(rel.values()), n_losses=len(rel), fake_max_abs_diff=f, rec_max_rel_diff=r,
+                bounds=dict(first_step_losses_max_rel_diff=B['first_step_losses_max_rel'], fake_max_abs_diff=B['fake_max_abs'], rec_max_rel_diff=B['rec_max_rel']),
+                ok=bool(max(rel.values()) <= B['first_step_losses_max_rel'] and f <= B['fake_max_abs'] and r <= B['rec_max_rel']))
+
+
+def parity_infer(gpu, ref):
+    d = [float(np.abs(a.astype(np.float64) - b).max()) for a, b in zip(gpu['cubes'], ref['cubes'])]
+    lsb = int(np.abs(gpu['slab'].astype(np.int64) - ref['slab'].astype(np.int64)).max())
+    B = PARITY_BOUNDS
+    return dict(workload='two 140^3 cubes of a %dx%dx%d uint16 volume (dice 120, overlap 15, border 10): network output after the sigmoid per cube, '
+                         'assembled uint16 slab' % PARITY_SLAB_SHAPE, cube_max_abs_diff=max(d), cubes=len(d),
+                slab_max_lsb_diff=lsb, slab_equal_share=float((gpu['slab'] == ref['slab']).mean()),
+                bounds=dict(cube_max_abs_diff=B['cube_max_abs'], slab_max_lsb_diff=B['slab_max_lsb']),
+                ok=bool(len(d) == 2 and max(d) <= B['cube_max_abs'] and lsb <= B['slab_max_lsb']))
 
 
 def run_train(args, rank, world, dev):
@@ -346,6 +439,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
     slabs are gathered on rank 0 (neuroclear_amd/test_dice.py, assemble='slab')."""
     import torch
     import torch.distributed as dist
+    from neuroclear_amd import test_dice as _td
     from neuroclear_amd.test_dice import diced_inference
     from neuroclear_amd.models import networks
     from neuroclear_amd.util import seed as S
@@ -420,11 +514,63 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
     return dt, L ** 3 * steps, roof, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
                                           parallelism=('contiguous cube ranges over %d ranks' % world) if world > 1 else 'cubes%1', cubes=ncubes,
-                                          assemble='slab (owned z-slabs exchanged point to point, finalised per rank, uint16 slabs gathered)'
+                                          assemble={'slab': 'slab (owned z-slabs exchanged point to point, finalised per rank, uint16 slabs gathered)',
+                                                    'reduce': 'reduce (per-rank accumulators, one reduce(sum) to rank 0; NC_ASSEMBLE or the point-to-point '
+                                                              'self-check of neuroclear_amd/test_dice.py chose it)',
+                                                    'gather': 'gather (lock-step rounds, tiles to rank 0)'}[_td.LAST['assemble']]
                                           if world > 1 else 'in-order',
                                           computed_voxels_per_s=round(computed * steps / dt),
                                           seconds_per_volume=dict(median=float(np.median(per_volume)), min=min(per_volume),
                                                                   max=max(per_volume), n=len(per_volume)))
+
+
+class _LineGuard:
+    """Keeps the measured train line printable while the inference leg runs.  rank 0 owns the line.  fail(msg): print the line with
+    `inference: {error: msg}` and leave with code 3 (a failing rank > 0 only reports on stderr and leaves: the launcher then terminates
+    the others).  SIGTERM (the launcher's reaction to another rank's death) and the timeout reach a helper THREAD through
+    signal.set_wakeup_fd -- Python-level handlers only run between bytecodes of the main thread, which may be blocked inside RCCL."""
+
+    def __init__(self, out, rank, world, timeout_s):
+        import signal
+        import threading
+        self.out, self.rank, self.done = out, rank, threading.Event()
+        self.r, self.w = os.pipe()
+        os.set_blocking(self.w, False)
+        self.old_fd = None
+        if rank == 0 and world > 1:
+            signal.signal(signal.SIGTERM, lambda *a: None)  # (a handler must exist for the wake-up fd to be written; the thread does the work)
+            self.old_fd = signal.set_wakeup_fd(self.w, warn_on_full_buffer=False)
+            self.thread = threading.Thread(target=self._watch, args=(timeout_s,), daemon=True)
+            self.thread.start()
+
+    def _watch(self, timeout_s):
+        import select
+        ready, _, _ = select.select([self.r], [], [], timeout_s)
+        if self.done.is_set():
+            return
+        self._emit('terminated during the inference leg (another rank failed)' if ready else
+                   'inference leg exceeded %.0f s (NC_BENCH_INFER_TIMEOUT): hang cut by the watchdog' % timeout_s)
+        os._exit(3)
+
+    def _emit(self, msg):
+        self.out['inference'] = dict(error=msg)
+        sys.stdout.write(json.dumps(self.out) + '\n')
+        sys.stdout.flush()
+
+    def fail(self, msg):
+        self.done.set()
+        print('bench.py: ' + msg, file=sys.stderr, flush=True)
+        if self.rank == 0:
+            self._emit(msg)
+        os._exit(3)  # no destroy_process_group(): the other ranks may sit in a collective this rank will never join
+
+    def disarm(self):
+        import signal
+        self.done.set()
+        if self.old_fd is not None:
+            signal.set_wakeup_fd(self.old_fd)
+            signal.signal(signal.SIGTERM, signal.SIG_DFL)
+            os.write(self.w, b'x')  # wakes the thread, which sees `done`
 
 
 def main():
@@ -572,7 +718,18 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         isteps = 3  # three whole volumes: the boxes of this pool differ by ~8 % and one volume has no spread to show
-        idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=isteps, warmup=1)
+        # The train line above is measured; nothing the inference leg does may lose it (N > 1: the first real multi-GPU run of the slab
+        # exchange happens on the driver's box).  An exception here prints the train line with `inference: {error}` and leaves non-zero; a
+        # rank that dies elsewhere makes the launcher SIGTERM rank 0, and a hang is cut by the watchdog -- both print the same line
+        # (_LineGuard: a helper thread, because the main thread may sit inside a collective when the signal arrives).
+        guard = _LineGuard(out, rank, world, timeout_s=float(os.environ.get('NC_BENCH_INFER_TIMEOUT', '900')))
+        try:
+            if os.environ.get('NC_BENCH_FAIL_INFER') == '1':  # test hook: the injected failure of tests/test_bench_guard.py
+                raise RuntimeError('injected inference failure (NC_BENCH_FAIL_INFER=1)')
+            idt, iunits, iroof, icfg = run_infer(args, rank, world, dev, steps=isteps, warmup=1)
+        except Exception as e:
+            guard.fail('inference leg raised on rank %d: %r' % (rank, e))  # does not return
+        guard.disarm()
         inf = dict(metric='voxels/sec (useful output voxels of the %d^3 volume, assemble included)' % args.volume,
                    value=iunits / idt, unit='voxels/s', seconds_per_volume=idt / isteps, steps=isteps,
                    seconds_per_volume_spread=icfg.pop('seconds_per_volume'), n_gpus=world, scaling='strong',
@@ -582,24 +739,45 @@ def main():
         if iroof:
             inf['roofline'] = iroof
         out['inference'] = inf
+    # parity_vs_cpu_oracle, GPU side: the product path on the weights / inputs / np.random draws the CPU legs below run on (rank 0 alone,
+    # no collective: the other ranks wait at the barrier)
+    gp_train = gp_infer = None
+    if cpu and headline:
+        try:
+            gp_train = gpu_parity_train(dev)
+        except Exception as e:
+            gp_train = dict(error=repr(e))
+    if cpu and (headline or args.workload == 'infer'):
+        try:
+            gp_infer = gpu_parity_infer(dev)
+        except Exception as e:
+            gp_infer = dict(error=repr(e))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    parity = {}
     if cpu and train_like:
         try:
             out['cpu_baseline'] = cpu_baseline_train()
+            ref = out['cpu_baseline'].pop('_parity_ref')
+            if gp_train is not None:
+                parity['train'] = gp_train if 'error' in gp_train else parity_train(gp_train, ref)
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out['cpu_baseline'] = dict(error=str(e))
-    if cpu and args.workload == 'infer':
+    if cpu and (args.workload == 'infer' or inf is not None):
+        tgt = out if args.workload == 'infer' else inf
         try:
-            out['cpu_baseline'] = cpu_baseline_infer()
+            tgt['cpu_baseline'] = cpu_baseline_infer()
+            ref = tgt['cpu_baseline'].pop('_parity_ref')
+            if gp_infer is not None:
+                parity['infer'] = gp_infer if 'error' in gp_infer else parity_infer(gp_infer, ref)
         except Exception as e:
-            out['cpu_baseline'] = dict(error=str(e))
-    if cpu and inf is not None:
-        try:
-            inf['cpu_baseline'] = cpu_baseline_infer()
-        except Exception as e:
-            inf['cpu_baseline'] = dict(error=str(e))
+            tgt['cpu_baseline'] = dict(error=str(e))
+    if parity:
+        # the HIP path against the CPU oracle at the sizes the metric is quoted on, SAME weights, inputs and random draws on both sides
+        # (tests/test_gpu_fullsize.py asserts the same bounds)
+        parity['ok'] = all(v.get('ok', False) for v in parity.values())
+        out['parity_vs_cpu_oracle'] = parity
     if rank == 0:
         print(json.dumps(out), flush=True)
 

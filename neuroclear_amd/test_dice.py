@@ -174,10 +174,70 @@ def broadcast_parameters(net, src=0):
 def default_assemble(world, with_real=False, normalize_intensity=False):
     """The assembly mode diced_inference picks when the caller names none: in-order on one rank; 'slab' on several -- unless something
     needs the WHOLE volume on one rank (the percentiles of --normalize_intensity, the second visual of with_real): 'slab' finalises per
-    rank, so those take the one-reduce form.  Only an explicit assemble='slab' together with them raises."""
+    rank, so those take the one-reduce form.  Only an explicit assemble='slab' together with them raises.
+    NC_ASSEMBLE=slab|reduce|gather overrides the default of world > 1: 'reduce' and 'gather' use collectives only."""
     if world <= 1:
         return 'gather'
+    env = os.environ.get('NC_ASSEMBLE', '')
+    if env in ('reduce', 'gather'):
+        return env
+    if env not in ('', 'slab'):
+        raise ValueError("NC_ASSEMBLE must be 'slab', 'reduce' or 'gather'")
     return 'reduce' if (with_real or normalize_intensity) else 'slab'
+
+
+_P2P_OK = {}
+LAST = {'assemble': None}  # the mode the last diced_inference() of this process took (bench.py reports it)
+
+
+def p2p_selfcheck(rank, world, device):
+    """assemble='slab' is the one mode whose transport is point to point (`dist.batch_isend_irecv`, slab_exchange): every other exchange
+    of this package is a collective.  Before the first cube of the first sharded run, a 1 KiB ring among the ranks through the same call
+    (rank r sends to r + 1, receives from r - 1) says whether that transport works in THIS process group; the verdict is made common by
+    an all_reduce(MIN) -- a collective -- so that every rank takes the same branch, and is remembered per (world, device).  False: the
+    caller takes assemble='reduce' (collectives only; +-1 LSB like 'slab').  NC_TEST_FAIL_P2P=1 injects a failure (tests)."""
+    import sys
+    import torch.distributed as dist
+    from .util.dist import p2p_fence
+    key = (world, str(device))
+    if key in _P2P_OK:
+        return _P2P_OK[key]
+    ok, why = 1, ''
+    try:
+        if os.environ.get('NC_TEST_FAIL_P2P') == '1':
+            raise RuntimeError('injected point-to-point failure (NC_TEST_FAIL_P2P=1)')
+        send = torch.full((256,), float(rank), dtype=torch.float32, device=device)
+        recv = torch.full((256,), -1.0, dtype=torch.float32, device=device)
+        p2p_fence(send)
+        ops = [dist.P2POp(dist.isend, send, (rank + 1) % world), dist.P2POp(dist.irecv, recv, (rank - 1) % world)]
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get('NC_P2P_CHECK_TIMEOUT', '30')))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait(tmo)  # (a peer whose transport raised never posts its half: do not wait for it for ever)
+        p2p_fence(recv)
+        if not bool((recv == float((rank - 1) % world)).all()):
+            ok, why = 0, 'the ring delivered wrong bytes'
+    except Exception as e:  # noqa: BLE001 -- whatever the backend raises: the answer is "do not use it"
+        ok, why = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    good = bool(int(flag.item()))
+    if not good and (why or rank == 0):
+        print("neuroclear_amd.test_dice: point-to-point self-check failed on rank %d (%s): assemble='slab' -> 'reduce'"
+              % (rank, why or 'another rank reported the failure'), file=sys.stderr, flush=True)
+    _P2P_OK[key] = good
+    return good
+
+
+def resolve_assemble(assemble, rank, world, device, with_real=False, normalize_intensity=False):
+    """The mode a sharded run really takes: the caller's (or the default / NC_ASSEMBLE), with 'slab' replaced by 'reduce' when the
+    point-to-point self-check fails.  Same answer on every rank."""
+    import torch.distributed as dist
+    if assemble is None:
+        assemble = default_assemble(world, with_real, normalize_intensity)
+    if assemble == 'slab' and world > 1 and dist.is_available() and dist.is_initialized() and not p2p_selfcheck(rank, world, device):
+        assemble = 'reduce'
+    return assemble
 
 
 def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble=None, broadcast=True, on_cube=None,
@@ -196,6 +256,8 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     if broadcast:
         broadcast_parameters(netG, 0)  # (a no-op without a process group of > 1 rank: util.dist.exchange_active)
     ds = DiceImageDataSet(opt, volume=volume)
+    assemble = resolve_assemble(assemble, rank, world, ds.device)  # 'slab' -> 'reduce' when point to point does not work in this group
+    LAST['assemble'] = assemble
     n = len(ds) if max_cubes is None else min(len(ds), max_cubes)
     local_acc = assemble in ('reduce', 'slab') or rank == 0
     if with_real and assemble == 'gather' and world > 1:

@@ -324,3 +324,47 @@ def test_default_assemble_mode():
     assert default_assemble(1) == 'gather' and default_assemble(1, normalize_intensity=True) == 'gather'
     assert default_assemble(8) == 'slab'
     assert default_assemble(8, normalize_intensity=True) == 'reduce' and default_assemble(2, with_real=True) == 'reduce'
+
+
+def _p2p_check_worker(rank, world, port, out_path, inject):
+    _init(rank, world, port)
+    if inject == 'env':
+        os.environ['NC_TEST_FAIL_P2P'] = '1'
+    from neuroclear_amd import test_dice as td
+    dev = torch.device('cpu')
+    mode = td.resolve_assemble(None, rank, world, dev)
+    again = td.resolve_assemble('slab', rank, world, dev)  # remembered per (world, device): no second ring
+    explicit_reduce = td.resolve_assemble('reduce', rank, world, dev)
+    got = [None] * world
+    dist.all_gather_object(got, (mode, again, explicit_reduce))
+    if rank == 0:
+        np.save(out_path, np.array([[m == 'slab', a == 'slab', e == 'reduce'] for m, a, e in got], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('inject,expect_slab', [('none', 1), ('env', 0)])
+def test_p2p_selfcheck_falls_back_to_reduce_on_every_rank(tmp_path, inject, expect_slab):
+    """the 1 KiB batch_isend_irecv ring in front of the first sharded run.  Working transport: 'slab' stays.  A transport
+    that raises sends EVERY rank to assemble='reduce' (collectives only, the path tests/test_gpu_rccl.py has proven on RCCL; its schedule is
+    test_sharded_dice_loop_reduce above).  (A transport that fails on ONE side only leaves the peer waiting: the ring's waits carry a timeout,
+    NC_P2P_CHECK_TIMEOUT, after which that rank raises -- gloo closes the pair then, so no common verdict is possible; bench.py's guard turns
+    that into a printed train line.)"""
+    out = str(tmp_path / 'p.npy')
+    mp.spawn(_p2p_check_worker, args=(2, _free_port(), out, inject), nprocs=2, join=True)
+    r = np.load(out)
+    assert r.shape == (2, 3)
+    assert (r[:, 0] == expect_slab).all() and (r[:, 1] == expect_slab).all() and (r[:, 2] == 1).all(), r
+
+
+def test_nc_assemble_override(monkeypatch):
+    from neuroclear_amd.test_dice import default_assemble
+    monkeypatch.setenv('NC_ASSEMBLE', 'reduce')
+    assert default_assemble(8) == 'reduce' and default_assemble(1) == 'gather'
+    monkeypatch.setenv('NC_ASSEMBLE', 'gather')
+    assert default_assemble(2) == 'gather'
+    monkeypatch.setenv('NC_ASSEMBLE', 'slab')
+    assert default_assemble(8) == 'slab' and default_assemble(8, normalize_intensity=True) == 'reduce'
+    monkeypatch.setenv('NC_ASSEMBLE', 'bogus')
+    with pytest.raises(ValueError):
+        default_assemble(8)

@@ -81,6 +81,54 @@ def test_two_ranks_on_one_gpu_diced_inference(tmp_path):
     assert norm_lsb <= 2, norm_lsb  # (percentiles of a volume that differs by 1 ulp here and there, then a second truncating cast)
 
 
+
+def _dice_fallback_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    _init(rank, world, port)
+    os.environ['NC_TEST_FAIL_P2P'] = '1'  # the point-to-point transport "does not work" in this group
+    from neuroclear_amd import test_dice as td
+    from neuroclear_amd.models import networks
+    from neuroclear_amd.util import seed as S
+    vol = S.structured_volume(13, (150, 96, 110))
+    opt = Namespace(dice_size=[48] * 3, overlap=8, border_cut=4, gpu_ids=[0], skip_real=True, data_type='uint16', histogram_match=False,
+                    normalize_intensity=False)
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict({k: torch.from_numpy(v).cuda() for k, v in S.weights_from_seed(S.unet_deconv_spec(), 22 + rank).items()})
+    dflt = td.diced_inference(net, vol, opt, rank, world)  # default of world > 1: 'slab' -> self-check fails -> 'reduce'
+    mode = td.LAST['assemble']
+    red = td.diced_inference(net, vol, opt, rank, world, assemble='reduce')
+    if rank == 0:
+        one = td.diced_inference(net, vol, opt, 0, 1, assemble='gather', broadcast=False)
+        d = np.abs(dflt.astype(np.int64) - one.astype(np.int64))
+        np.save(out_path, np.array([int(mode == 'reduce'), int(np.array_equal(dflt, red)), int(d.max())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_p2p_failure_falls_back_to_reduce(tmp_path):
+    """VERDICT r5 item 5b on the device: with the slab exchange's transport failing its start-up self-check, the default sharded run
+    takes assemble='reduce' on both ranks and returns the volume of an explicit 'reduce' run bit for bit (+-1 LSB of the single-rank order)."""
+    out = str(tmp_path / 'f.npy')
+    mp.spawn(_dice_fallback_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    took_reduce, equal_reduce, max_lsb = np.load(out)
+    assert took_reduce == 1 and equal_reduce == 1 and max_lsb <= 1
+
+
+def test_bench_line_survives_an_inference_failure():
+    """`python bench.py` whose inference leg raises still prints the measured train line, with inference.error, and
+    leaves non-zero."""
+    env = dict(os.environ, NC_BENCH_FAIL_INFER='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['config']['workload'] == 'apollo_train_step_108cube_bs1' and j['value'] > 0 and 'roofline' in j
+    assert 'injected' in j['inference']['error']
+
 def _apollo_worker(rank, world, port, out_path, which='apollo'):
     import torch.distributed as dist
     _init(rank, world, port)

@@ -2,6 +2,7 @@
 seconds): adjointness of fwd / dgrad / wgrad of the MFMA convolutions at 108^3, linearity of deep_linear_gen at 108^3,
 whole-network C entry point vs the layer-by-layer path at 140^3, and the dice -> identity -> assemble round trip on a
 900^3 uint16 volume (729 cubes of 140^3, the reference screenshot's geometry)."""
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -359,3 +360,50 @@ def test_diced_inference_slab_mode_single_rank_is_bit_identical():
     plan = slab_plan(U.grid_steps(padded, 120, 15), 105, 120, padded[0], 8)
     assert sorted({c[1] - c[0] for c in plan['cubes']}) == [91, 92] and max(z[1] - z[0] for z in plan['local']) <= 330
     assert [o[1] - o[0] for o in plan['own']] == [120] * 8
+
+
+# ---- full-size comparisons WITH the oracle (round 6): the same functions bench.py prints as `parity_vs_cpu_oracle`, same bounds
+
+def _bench():
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    return importlib.import_module('bench')
+
+
+def test_apollo_step_108_against_the_oracle():
+    """The first optimize_parameters() at 108^3 (BASELINE configs[1]) from the same seeded weights, crop and np.random draws as
+    oracle/apollo.py (reference axial_to_lateral_gan_apollo_model.py:285-307): all 11 losses to 2e-5, `fake` after the sigmoid to 2e-5
+    absolute, `rec` to 2e-4 of its largest magnitude.  The oracle's step takes ~11 s on the GPU box's host cores."""
+    B = _bench()
+    dev = torch.device('cuda', 0)
+    gpu = B.gpu_parity_train(dev, 108)
+    model, real = B._oracle_apollo(108, min(os.cpu_count() or 1, 64))
+    ref_losses = model.step(real)
+    ref = dict(losses=dict(ref_losses), fake=model.fake.detach().numpy(), rec=model.rec.detach().numpy())
+    r = B.parity_train(gpu, ref)
+    print(r)
+    assert r['n_losses'] == 11
+    assert r['first_step_losses_max_rel_diff'] <= 2e-5
+    assert r['fake_max_abs_diff'] <= 2e-5
+    assert r['rec_max_rel_diff'] <= 2e-4
+    assert r['ok']
+
+
+def test_two_cubes_140_and_their_slab_against_the_oracle():
+    """Two 140^3 cubes (BASELINE configs[2]'s cube: dice 120 / overlap 15 / border 10) of a small uint16 volume through the product's
+    diced inference and through oracle/dice.py + oracle/nets.py (reference test_dice.py:107-118, util/assemble_dice.py:130-213): network
+    outputs after the sigmoid to 2e-5, the assembled uint16 slab to 2 LSB (the truncating cast turns 1e-5 into one count)."""
+    B = _bench()
+    dev = torch.device('cuda', 0)
+    gpu = B.gpu_parity_infer(dev)
+    ref = B.cpu_baseline_infer(budget_s=0.0, max_cubes=2)['_parity_ref']
+    r = B.parity_infer(gpu, ref)
+    print(r)
+    assert r['cubes'] == 2
+    assert r['cube_max_abs_diff'] <= 2e-5
+    assert r['slab_max_lsb_diff'] <= 2
+    assert r['slab_equal_share'] > 0.9
+    assert r['ok']
