@@ -317,8 +317,8 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
  * and dL/dact1 from dy, act1 and the weights alone (csrc/gen_nets.hip, "the collapsed tail"), and the 5^3 layer's two gradients from 27 shifted
  * copies of the one-channel dy (half the matrix work each: "layer 1's weight gradient from the rank structure of its dY"), and the forward of
  * the 5^3 layer as a 64 -> 27 convolution plus a shifted sum ("the forward without act1") -- exact algebra, weight-space products in fp64, the
- * same outputs and gradients to fp32 rounding (closer to an fp64 evaluation than the fp32 chain), 8 ms less per 108^3 training step; 0: layer by layer as the reference's autograd does.  nc_deep_linear_lp_* follows the same switch (do not change it
- * between a forward and its backward there; nc_deep_linear_fwd / _bwd carry the forward's choice in `kept`). */
+ * same outputs and gradients to fp32 rounding (closer to an fp64 evaluation than the fp32 chain), 8 ms less per 108^3 training step; 0: layer by layer as the reference's autograd does.  nc_deep_linear_lp_* follows the same switch; both
+ * pairs carry the forward's choice in `kept`, so the switch may move between a forward and its backward. */
 void nc_set_dl_collapse(int on);
 int nc_get_dl_collapse(void);
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
@@ -389,10 +389,13 @@ int nc_unet_deconv_lp_bwd(const float* params, const float* x, const float* y, c
 int nc_deep_linear_lp_supported(int N, int S0, int S1, int S2, int dtype);
 size_t nc_deep_linear_lp_saved_bytes(int N, int S0, int S1, int S2);
 size_t nc_deep_linear_lp_ws_bytes(int N, int S0, int S1, int S2);
+/* `kept` (round 6, as nc_deep_linear_fwd / _bwd): the form the forward took (layered / collapsed tail / without f2 -- it depends on
+ * nc_set_dl_collapse at forward time and decides what `saved` holds); the caller hands it to the backward, which follows it whatever the
+ * switches say by then (a value the forward cannot return: NC_ERR_ARG). */
 int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
-                          void* ws, size_t ws_bytes, void* stream);
+                          void* ws, size_t ws_bytes, void* stream, unsigned* kept);
 int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved, const float* dy, float* dx, float* dparams,
-                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream);
+                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream, unsigned kept);
 
 /* ---- fp32 3^3 / 5^3 convolutions on the 16-bit matrix cores (csrc/conv_split.hip): an fp32 value is exactly the sum of three
  *      bf16 terms; the six products a_i b_j with i + j <= 2 are bf16 MFMAs on one fp32 accumulator (what is dropped is below

@@ -160,7 +160,9 @@ struct XParams {
   int tiles_per_xcd;
   int flush;           // k-steps between two accumulator restarts
   const unsigned *amax_x, *amax_w;  // NT = 2: the cells of the input and of the weights (the result is scaled back by 2^-(kx + kw))
-  long long* dbg;      // NC_S3X_STAMP builds: s_memtime stamps of workgroup 0 / wave 0 (timing experiments only)
+#ifdef NC_S3X_STAMP
+  long long* dbg;      // timing-experiment builds only (tools/s3x_variant.sh stamp -DNC_S3X_STAMP): s_memtime stamps of workgroup 0 / wave 0
+#endif
   const unsigned* guard;  // nullable: the range guard's words (common.hpp); the kernel leaves at once unless the flag says it is this form's turn
   float2* stats;       // ST launches: [tile of this launch][wave][32 channels] (sum, sum of squares) of the tile's bias-free outputs (see s3x_stats_finalize)
 };
@@ -450,9 +452,6 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     __builtin_amdgcn_raw_buffer_store_b64(pk, rs, off, 0, 0);
   };
 
-#ifdef NC_S3X_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(NC_S3X_PRIO);  // (experiment: static priority for the younger half)
-#endif
   // ---- prologue: brick 0 and the first A fragments of the first tile
   int ring = 0;  // ring slot of brick 0 of the current tile
   issue_brick(cur, 0, 0, false);

@@ -460,9 +460,15 @@ size_t nc_deep_linear_lp_ws_bytes(int N, int S0, int S1, int S2) {
   return llp_plan(p, N, S0, S1, S2) && p.ok ? llp_ws_bytes(p) : 0;
 }
 
+// `kept` (out, as on the fp32 path): which FORM this forward took -- it depends on the process-wide switches at forward time (nc_set_dl_collapse,
+// the one-channel weight-gradient switch) and decides what `saved` holds: kLpLayered (f1, f2, f3, w_eff, u1), kLpCollapsed (f1, f2) or
+// kLpNoF2 (f1 only).  The backward follows `kept`, not the switches of its own moment.
+enum : unsigned { kLpLayered = 0, kLpCollapsed = 1, kLpNoF2 = 2 };
+
 int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* saved, int N, int S0, int S1, int S2, int dtype,
-                          void* ws, size_t ws_bytes, void* stream) {
-  if (!params || !x || !y || !saved) { set_error("deep_linear_lp_fwd: null pointer"); return NC_ERR_ARG; }
+                          void* ws, size_t ws_bytes, void* stream, unsigned* kept) {
+  if (!params || !x || !y || !saved || !kept) { set_error("deep_linear_lp_fwd: null pointer"); return NC_ERR_ARG; }
+  *kept = kLpLayered;
   if (dtype != NC_DT_BF16) { set_error("deep_linear_lp_fwd: dtype must be NC_DT_BF16"); return NC_ERR_ARG; }
   LLp p;
   if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_fwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
@@ -496,15 +502,16 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
     const float* F = dl_fold_fwd64(tail, params + p.w[1], hs);
     if (!F) return NC_ERR_HIP;
     NC_TRY(conv_fwd_h_na1(V + p.f1h, F, Ff, c5, dtype, cws, p.conv_ws, hs));
+    *kept = kLpNoF2;
     return dl_combine27(Ff, y, N, S0, S1, S2, 64, hs);
   }
   NC_TRY(conv_fwd_h_c8(V + p.f1h, params + p.w[1], nullptr, V + p.f2h, 64, 0, c5, dtype, cws, p.conv_ws, hs));
   if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
     // layers 2 .. 5 as ONE 64 -> 1 convolution of f2 (gen_nets.hip, "the collapsed tail"): the data-gradient form of the one-channel 3^3 kernel
-    // with the tap-flipped composed weights IS that convolution.  (The backward decides the same way: do not flip nc_set_dl_collapse between
-    // a forward and its backward on this path -- it has no `kept` word to carry the choice.)
+    // with the tap-flipped composed weights IS that convolution.
     char* tail = G + p.tail;
     NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
+    *kept = kLpCollapsed;
     return conv_c1_dgrad_h(V + p.f2h, dl_tail_Ef(tail), y, N, S0, S1, S2, 3, c1ws, p.c1_ws, hs);
   }
   NC_TRY(conv_fwd_h_c8(V + p.f2h, params + p.w[2], nullptr, V + p.f3h, 64, 0, c3, dtype, cws, p.conv_ws, hs));
@@ -515,8 +522,9 @@ int nc_deep_linear_lp_fwd(const float* params, const float* x, float* y, void* s
 }
 
 int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved, const float* dy, float* dx, float* dparams,
-                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                          int N, int S0, int S1, int S2, int dtype, void* ws, size_t ws_bytes, void* stream, unsigned kept) {
   if (!params || !x || !saved || !dy || !dparams) { set_error("deep_linear_lp_bwd: null pointer"); return NC_ERR_ARG; }
+  if (kept > kLpNoF2) { set_error("deep_linear_lp_bwd: `kept` is not a value nc_deep_linear_lp_fwd returns"); return NC_ERR_ARG; }
   if (dtype != NC_DT_BF16) { set_error("deep_linear_lp_bwd: dtype must be NC_DT_BF16"); return NC_ERR_ARG; }
   LLp p;
   if (!llp_plan(p, N, S0, S1, S2) || !p.ok) { set_error("deep_linear_lp_bwd: shape not covered by the 16-bit kernels"); return NC_ERR_SHAPE; }
@@ -534,7 +542,8 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
   make_dims(c5, N, 64, S0, S1, S2, 64, 5, 5, 5, 1, 2);
   make_dims(c3, N, 64, S0, S1, S2, 64, 3, 3, 3, 1, 1);
   bool rank_w1 = false;
-  if (p.c3 && dl_collapse_on() && c1_wgrad_on()) {
+  if (kept != kLpLayered) {  // what the FORWARD took (the switches may have moved since)
+    if (!p.c3) { set_error("deep_linear_lp_bwd: `kept` names a form this shape has no kernels for"); return NC_ERR_ARG; }
     // collapsed tail (gen_nets.hip): dW2 .. dW5 in weight space from q[c][t] = sum_v dy[v] f2[c][v + t - 1]; the 5^3 layer's backward from the rank
     // structure of df2 = E . Dsh (Dsh: 27 shifted copies of dy as a bf16 C8 tensor): its weight gradient a 32 x 64 problem P, its data gradient
     // a forward convolution 32 -> 64 of Dsh with composed weights -- half the matrix work each; q is a contraction of the same P, and df2
@@ -543,6 +552,7 @@ int nc_deep_linear_lp_bwd(const float* params, const float* x, const void* saved
     NC_TRY(dl_tail_compose(params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail, hs));
     ConvDims dsh;
     const bool rank = llp_rank_ok(p, dsh);
+    if (!rank && kept == kLpNoF2) { set_error("deep_linear_lp_bwd: the forward kept no f2, and the rank forms that do without it are off"); return NC_ERR_ARG; }
     if (rank) {
       hipLaunchKernelGGL(k_dl_shift27_c8, dim3(512, 4, (unsigned)N), dim3(256), 0, hs, dy, (uint4*)(G + p.B), S0, S1, S2);
       NC_TRY(check_launch("deep_linear_lp_bwd: shifted copies of dy"));

@@ -338,7 +338,10 @@ int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, i
 static std::atomic<int> g_guard{getenv("NC_H2_GUARD") ? atoi(getenv("NC_H2_GUARD")) : 1};
 bool h2_guard_on() { return g_guard != 0; }
 int h2_guard_mode() { return g_guard; }
-void h2_guard_set(int on) { g_guard = on == 2 ? 2 : on ? 1 : 0; }
+namespace { unsigned long long* guard_stats_dev(); }
+// (the pinned counter block is allocated HERE, off the launch path -- a first allocation inside h2_guard_decide could land in a stream capture
+// and invalidate it -- and portable, so that every device of the process sees it)
+void h2_guard_set(int on) { g_guard = on == 2 ? 2 : on ? 1 : 0; if (on) (void)guard_stats_dev(); }
 namespace {
 std::mutex g_stats_mu;
 unsigned long long* g_stats_host = nullptr;  // 4 counters in pinned host memory the device adds to (system-scope atomics): readable without a sync
@@ -347,7 +350,7 @@ unsigned long long* guard_stats_dev() {
   std::lock_guard<std::mutex> lk(g_stats_mu);
   if (!g_stats_host) {
     void* h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     __builtin_memset(h, 0, 64);
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
@@ -360,8 +363,9 @@ unsigned long long* guard_stats_dev() {
 int h2_guard_read(unsigned long long* out4, int reset) {
   std::lock_guard<std::mutex> lk(g_stats_mu);
   for (int i = 0; i < 4; ++i) {
-    out4[i] = g_stats_host ? __atomic_load_n(g_stats_host + i, __ATOMIC_RELAXED) : 0;
-    if (reset && g_stats_host) __atomic_store_n(g_stats_host + i, 0ull, __ATOMIC_RELAXED);
+    // reset = one exchange: an increment a queued kernel lands between a load and a separate store would be lost
+    if (!g_stats_host) out4[i] = 0;
+    else out4[i] = reset ? __atomic_exchange_n(g_stats_host + i, 0ull, __ATOMIC_RELAXED) : __atomic_load_n(g_stats_host + i, __ATOMIC_RELAXED);
   }
   return NC_OK;
 }

@@ -98,27 +98,37 @@ class BaseModel(ABC):
         self._check_two_term_guard()
         return errors_ret
 
-    _guard_warned = False
-
     def _check_two_term_guard(self):
         """The range guard of the two-term convolution arithmetic (include/nc_hip.h) switches a flagged call to the exact three-term kernels by
         itself wherever it can; tensors it can only COUNT (the norm backward's output in mode 1, the activations deep_linear_gen keeps) show up
-        in the third counter.  This is the place where the host is synchronised anyway: if any were seen, the whole process goes to the
-        three-term form from here on (1.5 x the step time, exact) and says so once."""
+        in the third counter.  This is the place where the host is synchronised anyway: if any were seen since the last look, the process goes
+        to the three-term form (1.5 x the step time, exact) and THIS model says so.  What it does not do: the steps taken since the last look --
+        with the reference's --print_freq up to hundreds -- were applied with the flagged operands as they were; nothing is recomputed.
+        The counters are read WITH reset, so a caller that goes back to nc_set_split_terms(2) later is protected again; the switch itself is
+        process-wide (one library, one arithmetic), which is why every model that observes a flag repeats the warning instead of inheriting the
+        state silently.  Data-parallel runs: the flag is all-reduced (MAX) so that every rank switches at the same step -- every rank has to
+        call get_current_losses() at the same iterations (train_onecube.py and bench.py do)."""
         import ctypes
         from .._lib import lib
         L = lib()
-        if L.nc_get_split_terms() != 2 or not L.nc_get_h2_guard():
-            return
+        two_term = L.nc_get_split_terms() == 2 and bool(L.nc_get_h2_guard())
         st = (ctypes.c_ulonglong * 4)()
-        L.nc_h2_guard_stats(st, 0)
-        if st[2] and not BaseModel._guard_warned:
+        if two_term:
+            L.nc_h2_guard_stats(st, 1)
+        flagged = int(st[2])
+        from ..util.dist import exchange_active
+        if exchange_active():
+            import torch.distributed as dist
+            dev = torch.device('cuda', self.gpu_ids[0]) if dist.get_backend() == 'nccl' else torch.device('cpu')
+            t = torch.tensor([flagged if two_term else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            flagged = int(t.item())
+        if flagged and L.nc_get_split_terms() == 2:
             import warnings
-            BaseModel._guard_warned = True
             L.nc_set_split_terms(3)
             warnings.warn('neuroclear_amd: %d tensor(s) had more than 1/64 of their 512-element chunks below 2^-17 of the tensor maximum in a place '
-                          'where the two-term convolution kernels cannot switch by themselves; nc_set_split_terms(3) is now in force (exact '
-                          'three-term form) for the rest of this process' % int(st[2]))
+                          'where the two-term convolution kernels cannot switch by themselves; nc_set_split_terms(3) is in force from here on (exact '
+                          'three-term form, process-wide; the steps since the last get_current_losses() are not recomputed)' % flagged)
 
     def save_networks(self, epoch):
         os.makedirs(self.save_dir, exist_ok=True)

@@ -106,6 +106,10 @@ def workspace(nbytes, device, tag='ws'):
     key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if not _ws_cache:
+            # first allocation of the process: also the moment the library takes its pinned counter block of the range guard (a hipHostMalloc
+            # that must not happen on the launch path, where it could land inside a stream capture: csrc/h2.hip)
+            lib().nc_set_h2_guard(lib().nc_get_h2_guard())
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -1352,8 +1356,11 @@ class _GenLp(torch.autograd.Function):
         dt = _DT['bf16']
         flop = 2.0 * (663809 if kind == 'unet' else 647120) * x.numel()
         e0 = _prof_begin()
+        kept = ctypes.c_uint(0)  # deep_linear_gen: the form the forward took (the backward follows it, not the switches of its own moment)
+        extra = (ctypes.byref(kept),) if kind != 'unet' else ()
         check(getattr(L, pre + '_fwd')(_ptr(packed), _ptr(x), _ptr(y), _ptr(saved), *dims, I(dt), _ptr(ws), Z(ws.numel()),
-                                       _stream()), pre + '_fwd')
+                                       _stream(), *extra), pre + '_fwd')
+        ctx.kept = kept.value
         if e0 is not None:
             _prof_end(e0, ('unet' if kind == 'unet' else 'deep_linear') + '_lp_fwd', flop)
         ctx.save_for_backward(x, y, saved)
@@ -1382,7 +1389,7 @@ class _GenLp(torch.autograd.Function):
                                           I(dt), _ptr(ws), Z(ws.numel()), _stream()), pre + '_bwd')
         else:
             check(L.nc_deep_linear_lp_bwd(_ptr(ctx.packed), _ptr(x), _ptr(saved), _ptr(dy), _ptr(dx), _ptr(dpar), *dims, I(dt),
-                                          _ptr(ws), Z(ws.numel()), _stream()), pre + '_bwd')
+                                          _ptr(ws), Z(ws.numel()), _stream(), ctypes.c_uint(ctx.kept)), pre + '_bwd')
         if e0 is not None:
             mac = (2 * 663809 - 1728) if kind == 'unet' else 2 * 647120
             _prof_end(e0, ('unet' if kind == 'unet' else 'deep_linear') + '_lp_bwd', 2.0 * mac * x.numel())

@@ -369,6 +369,58 @@ def test_deep_linear_16bit_collapsed_tail(shape):
         assert b <= 1.5 * a + 5e-3, (n, a, b)
 
 
+@pytest.mark.parametrize('fwd_collapse', [1, 0])
+def test_deep_linear_16bit_backward_follows_its_forward_when_the_switch_moves(fwd_collapse):
+    """nc_deep_linear_lp_fwd hands the form it took to the caller (`kept`), nc_deep_linear_lp_bwd follows it: with
+    nc_set_dl_collapse flipped BETWEEN a forward and its backward, every gradient is bit-identical to the run where the switch stood still
+    (before round 6 the backward read buffers its forward had never written).  A `kept` the forward cannot return is refused."""
+    from neuroclear_amd import ops
+    from neuroclear_amd._lib import lib
+    _, net = _nets()
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    shape = (1, 1, 24, 24, 24)
+    x = torch.rand(shape, device=DEV, generator=gen)
+    r = torch.randn(shape, device=DEV, generator=gen)
+    prev = lib().nc_get_dl_collapse()
+
+    def run(flip):
+        lib().nc_set_dl_collapse(fwd_collapse)
+        ops.set_conv_precision('bf16')
+        assert ops.gen_lp_supported('linear', x.shape)
+        for q in net.parameters():
+            q.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = net(xi)
+        if flip:
+            lib().nc_set_dl_collapse(1 - fwd_collapse)
+        (y * r).mean().backward()
+        ops.set_conv_precision('fp32')
+        return xi.grad.clone(), {n: q.grad.clone() for n, q in net.named_parameters()}
+
+    try:
+        dx0, g0 = run(False)
+        dx1, g1 = run(True)
+    finally:
+        lib().nc_set_dl_collapse(prev)
+        ops.set_conv_precision('fp32')
+    assert torch.equal(dx0, dx1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+        assert float(g0[n].abs().max()) > 0
+    # raw C ABI: an impossible `kept`
+    L = lib()
+    I, Z = ctypes.c_int, ctypes.c_size_t
+    dims = (I(1), I(24), I(24), I(24))
+    packed = torch.cat([q.detach().reshape(-1) for q in net.parameters()]).contiguous()
+    saved = torch.empty(L.nc_deep_linear_lp_saved_bytes(*dims), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(L.nc_deep_linear_lp_ws_bytes(*dims), dtype=torch.uint8, device=DEV)
+    dpar, dxb = torch.zeros_like(packed), torch.empty_like(x)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = L.nc_deep_linear_lp_bwd(p(packed), p(x), p(saved), p(r), p(dxb), p(dpar), *dims, I(ops._DT['bf16']), p(ws), Z(ws.numel()),
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_uint(7))
+    assert rc != 0
+
+
 @pytest.mark.parametrize('seed', [1, 2, 3, 21, 22])
 def test_deep_linear_16bit_weights_keep_the_response_to_a_constant(seed):
     """deep_linear_gen has neither biases nor norms, and for the nearly constant `fake` of the first iterations its output is a

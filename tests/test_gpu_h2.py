@@ -569,13 +569,24 @@ def test_h2_guard_covers_the_norm_backward_output(golden_dir):
     from neuroclear_amd.models.base_model import BaseModel
     L().nc_set_split_terms(2)
     L().nc_set_h2_guard(1)
-    BaseModel._guard_warned = False
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter('always')
         BaseModel._check_two_term_guard(None)
     assert L().nc_get_split_terms() == 3 and any('nc_set_split_terms(3)' in str(w.message) for w in rec)
+    # the look reset the counters: a caller that goes back to the two-term form is protected again, and is told again
+    assert guard_stats()[2] == 0
+    L().nc_set_split_terms(2)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        BaseModel._check_two_term_guard(None)
+    assert L().nc_get_split_terms() == 2 and not rec      # nothing new was flagged: nothing happens
+    run(2, 1)                                             # the same tensor again ...
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        BaseModel._check_two_term_guard(None)
+    assert L().nc_get_split_terms() == 3 and len(rec) == 1  # ... is acted on again (no process-wide latch)
+    L().nc_set_split_terms(2)
     guard_stats(reset=True)
-    BaseModel._guard_warned = False
     dark = lambda g: g[:16]  # noqa: E731  (output channels of double_conv1.convolution.3 = the dark dY channels)
     rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
     print('dark block of the weight gradient vs the three-term run: guard on %.2e, off %.2e; calls that fell back: %d' % (
