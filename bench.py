@@ -274,7 +274,8 @@ def gpu_parity_infer(dev):
         return y
     slab = diced_inference(net, vol, opt, 0, 1, assemble='gather', broadcast=False, on_cube=on_cube)
     torch.cuda.synchronize()
-    return dict(cubes=[c.detach().float().reshape(140, 140, 140).cpu().numpy() for c in cubes], slab=np.asarray(slab))
+    outs = [c for y in cubes for c in y.detach().float().reshape(-1, 140, 140, 140).cpu().numpy()]  # (a call may carry several cubes: NC_INFER_BATCH)
+    return dict(cubes=outs, slab=np.asarray(slab))
 
 
 def parity_train(gpu, ref):
@@ -451,9 +452,10 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
     vol = S.random_volume(5, L)
     opt = Namespace(dice_size=[120] * 3, overlap=15, border_cut=10, gpu_ids=[dev.index], skip_real=True,
                     data_type='uint16', histogram_match=False, normalize_intensity=False)
-    in_flight = max(int(os.environ.get('NC_INFER_STREAMS', '3')), 1)
-    for _ in range(max(warmup, 1)):  # every stream of the cubes in flight gets its workspace and its first launches here
-        diced_inference(net, vol, opt, rank, world, max_cubes=max(2, in_flight) * world)
+    in_flight = max(int(os.environ.get('NC_INFER_STREAMS', '2')), 1)
+    nbatch = max(1, int(os.environ.get('NC_INFER_BATCH', '5')))
+    for _ in range(max(warmup, 1)):  # every stream of the cubes in flight gets its workspace and its first launches (of a full batch) here
+        diced_inference(net, vol, opt, rank, world, max_cubes=max(2, in_flight * nbatch) * world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -489,11 +491,18 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
     if ev:
         # Cubes overlap on NC_INFER_STREAMS HIP streams (test_dice.py), so the per-call event intervals overlap too: the rate is
         # taken over the wall time of the timed region (all cubes' FLOP / dt); avg_launch_ms = wall time per cube.
-        in_flight = int(os.environ.get('NC_INFER_STREAMS', '3'))
+        in_flight = int(os.environ.get('NC_INFER_STREAMS', '2'))
         ms_events = sum(a.elapsed_time(b) for a, b in ev)
         ms = dt * 1e3 if in_flight > 1 else ms_events
         flop = GA_FWD_FLOP_PER_VOXEL * 140 ** 3
-        ach = flop * len(ev) / ms / 1e9
+        batch = max(1, int(os.environ.get('NC_INFER_BATCH', '5')))  # cubes per network call (neuroclear_amd/test_dice.py)
+        ncalls = len(ev)
+        my_cubes = ncubes * steps if world == 1 else None  # cubes THIS rank ran in the timed region (sharded: its share, counted below)
+        if my_cubes is None:
+            from neuroclear_amd.test_dice import slab_plan
+            a_, b_ = slab_plan(U.grid_steps(padded, 120, 15), 105, 120, padded[0], world)['cubes'][rank]
+            my_cubes = (b_ - a_) * steps if _td.LAST['assemble'] == 'slab' else len(range(rank, ncubes, world)) * steps
+        ach = flop * my_cubes / ms / 1e9
         from neuroclear_amd._lib import lib
         split = bool(lib().nc_get_conv_split())
         terms = int(lib().nc_unet_deconv_fwd_terms(140, 140, 140)) if split else 0  # 2: the two-term fp16 form (3 products), 3: three-term bf16 (6)
@@ -508,9 +517,10 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                     frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split, three_term=split and terms != 2), traffic_source=TRAFFIC_SOURCE,
                     algorithmic_bytes=round(3192 * 140 ** 3),  # 3,192 B per voxel for a perfectly fused fp32 G_A forward
                     traffic_vs_algorithmic=(round(pmc_traffic_cube(split, three_term=split and terms != 2) / (3192 * 140 ** 3), 3)
-                                            if pmc_traffic_cube(split, three_term=split and terms != 2) else None), launches=len(ev),
-                    cubes_in_flight=in_flight, avg_launch_ms=round(ms / len(ev), 3), gflop_per_launch=round(flop / 1e9, 1),
-                    event_ms_per_cube=round(ms_events / len(ev), 3),
+                                            if pmc_traffic_cube(split, three_term=split and terms != 2) else None), launches=my_cubes,
+                    network_calls=ncalls, cubes_per_call=batch, streams=in_flight,
+                    cubes_in_flight=in_flight * batch, avg_launch_ms=round(ms / my_cubes, 3), gflop_per_launch=round(flop / 1e9, 1),
+                    event_ms_per_cube=round(ms_events / my_cubes, 3),
                     whole_volume_tflops=round(GA_FWD_FLOP_PER_VOXEL * computed * steps / dt / 1e12, 2))
     return dt, L ** 3 * steps, roof, dict(workload='diced_inference_%dcube_dice120_ov15_b10' % L,
                                           parallelism=('contiguous cube ranges over %d ranks' % world) if world > 1 else 'cubes%1', cubes=ncubes,

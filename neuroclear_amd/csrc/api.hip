@@ -524,15 +524,19 @@ struct UnetWs {
   size_t stats;  // H2 mode: partial InstanceNorm sums written by the convolutions' own epilogues (conv_s3x.hip ST), largest layer
   size_t in_ws_bytes, conv_ws_bytes;
 };
-UnetWs unet_ws(int S0, int S1, int S2) {
-  const size_t S = (size_t)S0 * S1 * S2, Sh = S / 8, Sq = S / 64;
+// NB samples per pass: the two-term (H2) forward runs a whole batch through every launch (round 6: three 140^3 cubes per call fill the
+// persistent 256-workgroup launches of the 70^3 / 35^3 levels -- 1.64 rounds of tiles become 4.92 -- 5 % of the convolution time); the other
+// forms walk the samples one by one through buffers of one sample (NB = 1).
+UnetWs unet_ws(int S0, int S1, int S2, int NB = 1) {
+  const size_t S1v = (size_t)S0 * S1 * S2;
+  const size_t S = S1v * NB, Sh = S / 8, Sq = S / 64;  // (per-batch element counts: every activation buffer holds NB samples)
   UnetWs u{};
   size_t off = 0;
   auto take = [&](size_t n) { size_t r = off; off += (n + 63) & ~(size_t)63; return r; };
   u.raw = take(64 * S); u.cat1 = take(128 * S); u.a1 = take(64 * S); u.p1 = take(64 * Sh); u.cat2 = take(256 * Sh);
   u.a2 = take(128 * Sh); u.a2b = take(128 * Sh); u.p2 = take(128 * Sq); u.b1 = take(256 * Sq); u.b2 = take(256 * Sq);
-  u.t1 = take(S); u.t2 = take(S); u.mean = take(256); u.rstd = take(256);
-  u.in_ws_bytes = nc_instnorm_ws_bytes(256, (long)S);
+  u.t1 = take(S); u.t2 = take(S); u.mean = take(256 * (size_t)NB); u.rstd = take(256 * (size_t)NB);
+  u.in_ws_bytes = nc_instnorm_ws_bytes(256, (long)S1v);
   u.in_ws = take(u.in_ws_bytes / 4);
   size_t cw = 0;
   auto upd = [&](int C, int D, int H, int W, int K) {
@@ -550,7 +554,7 @@ UnetWs unet_ws(int S0, int S1, int S2) {
   u.cells = take(64);
   {
     size_t sb = 0;
-    auto upds = [&](int D, int H, int W, int K) { const size_t b = s3x_stats_bytes(1, D, H, W, K, 3); if (b > sb) sb = b; };
+    auto upds = [&](int D, int H, int W, int K) { const size_t b = s3x_stats_bytes(NB, D, H, W, K, 3); if (b > sb) sb = b; };
     upds(S0, S1, S2, 64); upds(S0 / 2, S1 / 2, S2 / 2, 128); upds(S0 / 4, S1 / 4, S2 / 4, 256);
     ConvDims d0;
     if (make_dims(d0, 1, 1, S0, S1, S2, 64, 3, 3, 3, 1, 1) && c1k3_stats_bytes(d0) > sb) sb = c1k3_stats_bytes(d0);  // (the first block's own kernel)
@@ -578,10 +582,16 @@ int nc_unet_deconv_fwd_terms(int S0, int S1, int S2) {
   return f && unet_h2_ok(S0, S1, S2, unet_ws(S0, S1, S2).conv_ws_bytes) ? 2 : 3;
 }
 
+// samples per pass of the whole-network forward: the whole batch in the two-term mode (NC_INFER_BATCHED=0: one by one, A/B), else one
+static int unet_fwd_batch(int N, int S0, int S1, int S2) {
+  static const bool batched = !(getenv("NC_INFER_BATCHED") && atoi(getenv("NC_INFER_BATCHED")) == 0);
+  if (N <= 1 || !batched || nc_unet_deconv_fwd_terms(S0, S1, S2) != 2) return 1;
+  return N;
+}
+
 size_t nc_unet_deconv_fwd_ws_bytes(int N, int S0, int S1, int S2) {
-  (void)N;
-  if (S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return 0;
-  return unet_ws(S0, S1, S2).total * sizeof(float);
+  if (N < 1 || S0 < 4 || S1 < 4 || S2 < 4 || (S0 & 3) || (S1 & 3) || (S2 & 3)) return 0;
+  return unet_ws(S0, S1, S2, unet_fwd_batch(N, S0, S1, S2)).total * sizeof(float);
 }
 
 #define NC_TRY(expr) do { int e_ = (expr); if (e_) return e_; } while (0)
@@ -595,7 +605,8 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
               "skip concat would not line up (reference networks.py:526,531)", S0, S1, S2);
     return NC_ERR_SHAPE;
   }
-  const UnetWs u = unet_ws(S0, S1, S2);
+  const int NB = unet_fwd_batch(N, S0, S1, S2);  // NB = N: the two-term mode below takes the whole batch through every launch
+  const UnetWs u = unet_ws(S0, S1, S2, NB);
   if (!ws || ws_bytes < u.total * sizeof(float)) { set_error("unet_deconv_fwd: workspace too small"); return NC_ERR_WS; }
   const UnetOff o = unet_offsets();
   float* W = (float*)ws;
@@ -617,16 +628,17 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
   // H2 mode: in3 / out3 are H2 tensors (two fp16 terms of the tensor times a power of two, h2.hip); in_a / in_b: the cells of the input's
   // channels [0, split_c) / [split_c, C) (a concatenation), out_cell: the cell the output is converted with
   unsigned* cells = (unsigned*)(W + u.cells);
+  int bn = 1;  // samples per pass of `block`: NB in the batched two-term mode, 1 in the per-sample loop
   auto block = [&](int id, const float* in, const void* in3, float* out, void* out3, int ctot, int c0, int C, int K, int D, int H,
                    int Wd, const unsigned* in_a = nullptr, const unsigned* in_b = nullptr, int split_c = 0,
                    const unsigned* out_cell = nullptr, void* pooled = nullptr) -> int {
     const long Sl = (long)D * H * Wd;
     // normalise + ReLU + conversion of the raw output (and, pooled != NULL: the 2 x 2 x 2 max-pool of the H2 result in the same pass)
     auto finish = [&]() -> int {
-      if (out3 && out_cell && pooled && !out) return act_split2h_pool(W + u.raw, mean, rstd, 0.f, out3, pooled, 1, K, D, H, Wd, ctot, c0, sqrtf((float)Sl), nullptr, hs);
+      if (out3 && out_cell && pooled && !out) return act_split2h_pool(W + u.raw, mean, rstd, 0.f, out3, pooled, bn, K, D, H, Wd, ctot, c0, sqrtf((float)Sl), nullptr, hs);
       if (out3 && out_cell) {
-        NC_TRY(act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs));
-        return pooled ? maxpool2_h2(out3, pooled, 1, K, ctot, D, H, Wd, hs) : NC_OK;
+        NC_TRY(act_split2h(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, bn, K, Sl, ctot, c0, sqrtf((float)Sl), nullptr, nullptr, hs));
+        return pooled ? maxpool2_h2(out3, pooled, bn, K, ctot, D, H, Wd, hs) : NC_OK;
       }
       if (out3) return act_split3(W + u.raw, mean, rstd, 0.f, out, (long)K * Sl, out3, 1, K, Sl, ctot, c0, hs);
       return nc_instnorm_act_fwd(W + u.raw, mean, rstd, 0.f, out, K, Sl, stream);
@@ -636,14 +648,19 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     const bool epi = epi_stats_on();
     if (in3 && in_a) {
       ConvDims d;
-      make_dims(d, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1);
+      make_dims(d, bn, C, D, H, Wd, K, 3, 3, 3, 1, 1);
       {
         ProfScope ps(0, 9, d, 0, hs);
-        NC_TRY(conv_s3x_h2(in3, in_a, in_b, in_b ? split_c : C, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, (long)C * 27, 27, 0,
+        NC_TRY(conv_s3x_h2(in3, in_a, in_b, in_b ? split_c : C, P + o.w[id], P + o.b[id], W + u.raw, bn, C, D, H, Wd, K, 3, (long)C * 27, 27, 0,
                            (unsigned*)cws, (char*)cws + 256, hs, nullptr, epi ? W + u.stats : nullptr));
       }
       if (epi) {
-        NC_TRY(s3x_stats_finalize(W + u.stats, P + o.b[id], 1, D, H, Wd, K, 3, 1e-5f, mean, rstd, hs));
+        NC_TRY(s3x_stats_finalize(W + u.stats, P + o.b[id], bn, D, H, Wd, K, 3, 1e-5f, mean, rstd, hs));
+        return finish();
+      }
+      if (bn > 1) {  // (statistics pass per sample: mean / rstd are [sample][channel])
+        for (int n = 0; n < bn; ++n)
+          NC_TRY(nc_instnorm_stats(W + u.raw + (long)n * K * Sl, K, Sl, 1e-5f, mean + (long)n * K, rstd + (long)n * K, iws, u.in_ws_bytes, stream));
         return finish();
       }
     } else if (in3) {
@@ -654,12 +671,19 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     } else {
       ConvDims d1;
       if (epi && C == 1 && !g_force_direct && make_dims(d1, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1) && c1k3_stats_bytes(d1)) {
-        // the first block: the one-channel kernel leaves its InstanceNorm sums too (conv_c1k3.hip ST)
-        NC_TRY(conv_fwd_c1k3(in, P + o.w[id], P + o.b[id], W + u.raw, d1, hs, W + u.stats));
-        NC_TRY(c1k3_stats_finalize(W + u.stats, P + o.b[id], d1, 1e-5f, mean, rstd, hs));
+        // the first block: the one-channel kernel leaves its InstanceNorm sums too (conv_c1k3.hip ST) -- one sample per launch, then ONE
+        // normalise + convert pass over the batch
+        for (int n = 0; n < bn; ++n) {
+          NC_TRY(conv_fwd_c1k3(in + (long)n * Sl, P + o.w[id], P + o.b[id], W + u.raw + (long)n * K * Sl, d1, hs, W + u.stats));
+          NC_TRY(c1k3_stats_finalize(W + u.stats, P + o.b[id], d1, 1e-5f, mean + (long)n * K, rstd + (long)n * K, hs));
+        }
         return finish();
       }
-      NC_TRY(nc_conv_fwd(in, P + o.w[id], P + o.b[id], W + u.raw, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
+      for (int n = 0; n < bn; ++n) {
+        NC_TRY(nc_conv_fwd(in + (long)n * C * Sl, P + o.w[id], P + o.b[id], W + u.raw + (long)n * K * Sl, 1, C, D, H, Wd, K, 3, 3, 3, 1, 1, cws, u.conv_ws_bytes, stream));
+        if (bn > 1) NC_TRY(nc_instnorm_stats(W + u.raw + (long)n * K * Sl, K, Sl, 1e-5f, mean + (long)n * K, rstd + (long)n * K, iws, u.in_ws_bytes, stream));
+      }
+      if (bn > 1) return finish();
     }
     NC_TRY(nc_instnorm_stats(W + u.raw, K, Sl, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
     return finish();
@@ -675,10 +699,12 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
     NC_TRY(h2_set_cell(cells + 1, sqrtf((float)Sh), hs));
     NC_TRY(h2_set_cell(cells + 2, sqrtf((float)Sq), hs));
   }
-  for (int n = 0; n < N; ++n) {
+  bn = use_h2 ? NB : 1;
+  for (int n = 0; n < N; n += bn) {
     const float* xn = x + (long)n * S;
     float* yn = y + (long)n * S;
     if (use_h2) {
+      // (bn samples per launch from here on: every activation buffer is [bn][channels][voxels], the pooled / half-resolution offsets scale with bn)
       const unsigned *c0 = cells, *c1 = cells + 1, *c2 = cells + 2;
       NC_TRY(h2_zero_cells(cells + 3, 2, hs));
       NC_TRY(block(0, xn, nullptr, nullptr, W + u.s_a1, 64, 0, 1, 64, S0, S1, S2, nullptr, nullptr, 0, c0));
@@ -686,33 +712,33 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // and 3 write NO fp32 activation, and nothing is converted.  The pooled tensors go into slots nobody needs yet (the upper half of
       // s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it).  NC_POOL_H2=0: fp32 pool + conversion (A/B)
       static const bool pool_h2 = !(getenv("NC_POOL_H2") && atoi(getenv("NC_POOL_H2")) == 0);
-      void* p1h = W + u.s_cat2 + 128 * Sh;
+      void* p1h = W + u.s_cat2 + 128 * Sh * bn;
       // (NC_POOL_FUSE=0: the pool as a pass of its own over the H2 tensor)
       static const bool pool_fuse = pool_h2 && !(getenv("NC_POOL_FUSE") && atoi(getenv("NC_POOL_FUSE")) == 0);
       NC_TRY(block(1, nullptr, W + u.s_a1, pool_h2 ? nullptr : W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0, pool_fuse ? p1h : nullptr));
       if (pool_fuse) {
       } else if (pool_h2) {
-        NC_TRY(maxpool2_h2(W + u.s_cat1, p1h, 1, 64, 128, S0, S1, S2, hs));
+        NC_TRY(maxpool2_h2(W + u.s_cat1, p1h, bn, 64, 128, S0, S1, S2, hs));
       } else {
-        NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64, S0, S1, S2, stream));
-        NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, 1, 64, Sh, 64, 0, c0, hs));
+        NC_TRY(nc_maxpool2_fwd(W + u.cat1, W + u.p1, 64 * bn, S0, S1, S2, stream));  // (the fp32 pool works per (sample, channel) plane)
+        NC_TRY(split2h_into(W + u.p1, 64 * Sh, p1h, bn, 64, Sh, 64, 0, c0, hs));
       }
       NC_TRY(block(2, nullptr, p1h, nullptr, W + u.s_a2, 128, 0, 64, 128, h0, h1, h2, c0, nullptr, 0, c1));
       NC_TRY(block(3, nullptr, W + u.s_a2, pool_h2 ? nullptr : W + u.cat2, W + u.s_cat2, 256, 0, 128, 128, h0, h1, h2, c1, nullptr, 0, c1,
                    pool_fuse ? (void*)(W + u.s_b2) : nullptr));
       if (pool_fuse) {
       } else if (pool_h2) {
-        NC_TRY(maxpool2_h2(W + u.s_cat2, W + u.s_b2, 1, 128, 256, h0, h1, h2, hs));
+        NC_TRY(maxpool2_h2(W + u.s_cat2, W + u.s_b2, bn, 128, 256, h0, h1, h2, hs));
       } else {
-        NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128, h0, h1, h2, stream));
-        NC_TRY(split2h_into(W + u.p2, 128 * Sq, W + u.s_b2, 1, 128, Sq, 128, 0, c1, hs));
+        NC_TRY(nc_maxpool2_fwd(W + u.cat2, W + u.p2, 128 * bn, h0, h1, h2, stream));
+        NC_TRY(split2h_into(W + u.p2, 128 * Sq, W + u.s_b2, bn, 128, Sq, 128, 0, c1, hs));
       }
       NC_TRY(block(4, nullptr, W + u.s_b2, nullptr, W + u.s_b1, 256, 0, 128, 256, q0, q1, q2, c1, nullptr, 0, c2));
       NC_TRY(block(5, nullptr, W + u.s_b1, nullptr, W + u.s_b2, 256, 0, 256, 256, q0, q1, q2, c2, nullptr, 0, c2));
       // the transposed convolutions keep their three-term S3 input (small tensors) and write fp32; their halves of the concatenations
       // are measured and converted, the ratio of the two halves' powers of two goes into the consumer's weights
-      const bool t10 = convT_s3x_supported(1, 256, q0, q1, q2, 128) && u.conv_ws_bytes >= convT_s3x_ws_bytes(256, 128);
-      const bool t11 = convT_s3x_supported(1, 128, h0, h1, h2, 64) && u.conv_ws_bytes >= convT_s3x_ws_bytes(128, 64);
+      const bool t10 = convT_s3x_supported(bn, 256, q0, q1, q2, 128) && u.conv_ws_bytes >= convT_s3x_ws_bytes(256, 128);
+      const bool t11 = convT_s3x_supported(bn, 128, h0, h1, h2, 64) && u.conv_ws_bytes >= convT_s3x_ws_bytes(128, 64);
       static const bool ct_h2 = !(getenv("NC_CONVT_H2") && atoi(getenv("NC_CONVT_H2")) == 0);  // 0: three-term input, fp32 output measured and converted (A/B)
       const bool t10h = t10 && ct_h2, t11h = t11 && ct_h2;  // the two-term transposed convolution: H2 in (the block's output, bound sqrt(S)), H2 out
       NC_TRY(block(6, nullptr, W + u.s_b2, t10 ? nullptr : W + u.b1, t10 ? W + u.s_b1 : nullptr, 256, 0, 256, 256, q0, q1, q2, c2, nullptr, 0,
@@ -721,28 +747,30 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // voxel gets one tap per input channel, convt_s3.hip; the fp32 kernel's output is measured and converted)
       if (t10h) {
         NC_TRY(convT_h2_bound(P + o.w[10], P + o.b[10], 256, 128, sqrtf((float)Sq), cells + 3, hs));
-        NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], nullptr, W + u.s_cat2, 256, 128, 1, 256, q0, q1, q2, 128, cws, u.conv_ws_bytes, hs,
+        NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], nullptr, W + u.s_cat2, 256, 128, bn, 256, q0, q1, q2, 128, cws, u.conv_ws_bytes, hs,
                              cells + 3, c2));
       } else {
-        if (t10) NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, nullptr, 256, 128, 1, 256, q0, q1, q2, 128, cws,
-                                      u.conv_ws_bytes, hs));
-        else NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], W + u.cat2 + 128 * Sh, 1, 256, q0, q1, q2, 128, stream));
-        NC_TRY(h2_absmax(W + u.cat2 + 128 * Sh, 128 * Sh, cells + 3, hs));
-        NC_TRY(split2h_into(W + u.cat2 + 128 * Sh, 128 * Sh, W + u.s_cat2, 1, 128, Sh, 256, 128, cells + 3, hs));
+        // (A/B and fallback forms: the transposed convolution's fp32 output as a dense [bn][128] tensor in the upper half of cat2, measured and
+        // converted into channels 128 .. 255 of the concatenation)
+        float* up2 = W + u.cat2 + 128 * Sh * bn;
+        if (t10) NC_TRY(convT_fwd_s3x(W + u.s_b1, P + o.w[10], P + o.b[10], up2, nullptr, 128, 0, bn, 256, q0, q1, q2, 128, cws, u.conv_ws_bytes, hs));
+        else NC_TRY(nc_convT_k2s2_fwd(W + u.b1, P + o.w[10], P + o.b[10], up2, bn, 256, q0, q1, q2, 128, stream));
+        NC_TRY(h2_absmax(up2, 128 * Sh * bn, cells + 3, hs));
+        NC_TRY(split2h_into(up2, 128 * Sh, W + u.s_cat2, bn, 128, Sh, 256, 128, cells + 3, hs));
       }
       NC_TRY(block(7, nullptr, W + u.s_cat2, nullptr, W + u.s_a2, 128, 0, 256, 128, h0, h1, h2, c1, cells + 3, 128, c1));
       NC_TRY(block(8, nullptr, W + u.s_a2, t11 ? nullptr : W + u.a2b, t11 ? W + u.s_cat2 : nullptr, 128, 0, 128, 128, h0, h1, h2, c1, nullptr, 0,
                    t11h ? c1 : nullptr));
       if (t11h) {
         NC_TRY(convT_h2_bound(P + o.w[11], P + o.b[11], 128, 64, sqrtf((float)Sh), cells + 4, hs));
-        NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], nullptr, W + u.s_cat1, 128, 64, 1, 128, h0, h1, h2, 64, cws, u.conv_ws_bytes, hs,
+        NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], nullptr, W + u.s_cat1, 128, 64, bn, 128, h0, h1, h2, 64, cws, u.conv_ws_bytes, hs,
                              cells + 4, c1));
       } else {
-        if (t11) NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, nullptr, 128, 64, 1, 128, h0, h1, h2, 64, cws,
-                                      u.conv_ws_bytes, hs));
-        else NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], W + u.cat1 + 64 * S, 1, 128, h0, h1, h2, 64, stream));
-        NC_TRY(h2_absmax(W + u.cat1 + 64 * S, 64 * S, cells + 4, hs));
-        NC_TRY(split2h_into(W + u.cat1 + 64 * S, 64 * S, W + u.s_cat1, 1, 64, S, 128, 64, cells + 4, hs));
+        float* up1 = W + u.cat1 + 64 * S * bn;
+        if (t11) NC_TRY(convT_fwd_s3x(W + u.s_cat2, P + o.w[11], P + o.b[11], up1, nullptr, 64, 0, bn, 128, h0, h1, h2, 64, cws, u.conv_ws_bytes, hs));
+        else NC_TRY(nc_convT_k2s2_fwd(W + u.a2b, P + o.w[11], P + o.b[11], up1, bn, 128, h0, h1, h2, 64, stream));
+        NC_TRY(h2_absmax(up1, 64 * S * bn, cells + 4, hs));
+        NC_TRY(split2h_into(up1, 64 * S, W + u.s_cat1, bn, 64, S, 128, 64, cells + 4, hs));
       }
       // the last block's normalisation, the two pointwise layers and the sigmoid in one pass over its raw output (NC_INFER_TAIL=0: separately)
       static const bool tail = !(getenv("NC_INFER_TAIL") && atoi(getenv("NC_INFER_TAIL")) == 0);
@@ -750,20 +778,23 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
         const bool epi9 = epi_stats_on();
         {
           ConvDims d9;
-          make_dims(d9, 1, 128, S0, S1, S2, 64, 3, 3, 3, 1, 1);
+          make_dims(d9, bn, 128, S0, S1, S2, 64, 3, 3, 3, 1, 1);
           ProfScope ps(0, 9, d9, 0, hs);
-          NC_TRY(conv_s3x_h2(W + u.s_cat1, c0, cells + 4, 64, P + o.w[9], P + o.b[9], W + u.raw, 1, 128, S0, S1, S2, 64, 3, (long)128 * 27, 27, 0,
+          NC_TRY(conv_s3x_h2(W + u.s_cat1, c0, cells + 4, 64, P + o.w[9], P + o.b[9], W + u.raw, bn, 128, S0, S1, S2, 64, 3, (long)128 * 27, 27, 0,
                              (unsigned*)cws, (char*)cws + 256, hs, nullptr, epi9 ? W + u.stats : nullptr));
         }
-        if (epi9) NC_TRY(s3x_stats_finalize(W + u.stats, P + o.b[9], 1, S0, S1, S2, 64, 3, 1e-5f, mean, rstd, hs));
-        else NC_TRY(nc_instnorm_stats(W + u.raw, 64, S, 1e-5f, mean, rstd, iws, u.in_ws_bytes, stream));
-        NC_TRY(instnorm_relu_tail_sigmoid(W + u.raw, mean, rstd, P + o.w[12], P + o.b[12], P + o.w[13], P + o.b[13], yn, 64, S, hs));
+        if (epi9) NC_TRY(s3x_stats_finalize(W + u.stats, P + o.b[9], bn, S0, S1, S2, 64, 3, 1e-5f, mean, rstd, hs));
+        for (int i = 0; i < bn; ++i) {  // (the fused tail is a per-sample pass: 0.13 ms per 140^3 cube)
+          if (!epi9) NC_TRY(nc_instnorm_stats(W + u.raw + (long)i * 64 * S, 64, S, 1e-5f, mean + i * 64, rstd + i * 64, iws, u.in_ws_bytes, stream));
+          NC_TRY(instnorm_relu_tail_sigmoid(W + u.raw + (long)i * 64 * S, mean + i * 64, rstd + i * 64, P + o.w[12], P + o.b[12], P + o.w[13], P + o.b[13],
+                                            yn + (long)i * S, 64, S, hs));
+        }
         continue;
       }
       NC_TRY(block(9, nullptr, W + u.s_cat1, W + u.a1, nullptr, 0, 0, 128, 64, S0, S1, S2, c0, cells + 4, 64));
-      NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, 1, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
-      NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, 1, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
-      NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S, stream));
+      NC_TRY(nc_conv_fwd(W + u.a1, P + o.w[12], P + o.b[12], W + u.t1, bn, 64, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
+      NC_TRY(nc_conv_fwd(W + u.t1, P + o.w[13], P + o.b[13], W + u.t2, bn, 1, S0, S1, S2, 1, 1, 1, 1, 1, 0, cws, u.conv_ws_bytes, stream));
+      NC_TRY(nc_sigmoid_fwd(W + u.t2, yn, S * bn, stream));
       continue;
     }
     NC_TRY(block(0, xn, nullptr, f1 ? nullptr : W + u.a1, f1 ? W + u.s_a1 : nullptr, 64, 0, 1, 64, S0, S1, S2));

@@ -279,13 +279,13 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
     E = opt.dice_size[0] + 2 * opt.border_cut
     hm = bool(getattr(opt, 'histogram_match', False))  # the producing rank matches its own cube (it holds the input)
 
-    # Three cubes in flight (NC_INFER_STREAMS, default 3): cube i is cut and run through the network on HIP stream i % 3, the
+    # Cubes in flight (NC_INFER_STREAMS streams, default 2; round 6: each carries a BATCH of cubes, below): a batch is cut and run through the network on its stream, the
     # overlap-adds stay on the calling stream in cube order (each waits for its cube's event) -- so the result is the one-stream
     # result bit for bit, while the second stream's kernels fill the CUs the first one's kernels leave idle at their tails (the
     # persistent convolution kernels own whole CUs; a 35^3 layer fills 256 CUs 1.64 times).  Measured at 480^3: 1 stream 2.86 s,
     # 2: 2.87, 3: 2.69, 4: 2.70, 6: 3.61 (the working sets of six cubes no longer share the caches).  Not in the lock-step gather
     # rounds of world > 1 (the tiles go straight into a collective there).
-    nstreams = int(os.environ.get('NC_INFER_STREAMS', '3'))
+    nstreams = int(os.environ.get('NC_INFER_STREAMS', '2'))
     piped = ds.device.type == 'cuda' and nstreams > 1 and (world == 1 or assemble in ('reduce', 'slab'))
     main = torch.cuda.current_stream(ds.device) if piped else None
     side = _side_streams(ds.device, nstreams) if piped else []
@@ -293,27 +293,60 @@ def diced_inference(netG, volume, opt, rank=0, world=1, max_cubes=None, assemble
         st.wait_stream(main)  # the volume upload and the parameter broadcast were enqueued on the calling stream
     issued = [0]
 
-    def run_cube(i):
-        x = ds[i]['A'].unsqueeze(0)
-        y = (netG(x) if on_cube is None else on_cube(lambda: netG(x))).reshape(E, E, E)
-        if hm:
-            y = match_cube(y, x, opt.dice_size[0], opt.border_cut, ds.device)
-        return x, y
+    # Round 6: NC_INFER_BATCH (default 5) cubes per network call on NC_INFER_STREAMS (default 2) streams.  The persistent 256-workgroup
+    # convolution launches of the 70^3 / 35^3 levels hold 1.64-6.6 rounds of tiles for one 140^3 cube: batched launches fill their last
+    # round (convolutions alone: -5 % at three cubes per call), and weight packs / statistics finalisations are shared by the batch.  In the
+    # volume: 1.333 s (1 x 3) -> 1.308 (3 x 2) -> 1.295 (5 x 2) per 480^3, same-box alternation (profiles/r06_ab_infer_batch.txt).  A cube's result does not depend on its batch mates (InstanceNorm is per
+    # sample) beyond fp32 rounding of the statistics' partial sums (their grouping follows the launch's tile plan): run-to-run bit-identical,
+    # within 1 LSB of the one-cube-per-call order.  NC_INFER_BATCH=1: one cube per call (the reference's batch size, test_dice.py:66).
+    # The batches follow the order in which THIS rank will ask for its cubes.
+    nbatch = max(1, int(os.environ.get('NC_INFER_BATCH', '5')))
+    if assemble == 'gather' and world > 1:
+        nbatch = 1  # the verification mode keeps the reference's arithmetic cube by cube: bit-identical to a one-cube-per-call single-rank run
+    if assemble == 'slab':
+        my_cubes = list(range(*plan['cubes'][rank]))
+    elif assemble == 'reduce':
+        my_cubes = list(range(rank, n, world))
+    else:
+        my_cubes = [t * world + rank for t in range((n + world - 1) // world) if t * world + rank < n]
+    pos_of = {c: k for k, c in enumerate(my_cubes)}
+    ready = {}
+
+    def run_batch(idx):
+        xs = [ds[i]['A'] for i in idx]
+        x = torch.stack(xs, 0)
+        y = netG(x) if on_cube is None else on_cube(lambda: netG(x))
+        outs = []
+        for k in range(len(idx)):
+            yk = y[k].reshape(E, E, E)
+            if hm:
+                yk = match_cube(yk, xs[k].unsqueeze(0), opt.dice_size[0], opt.border_cut, ds.device)
+            outs.append((xs[k].unsqueeze(0), yk))
+        return outs
 
     def produce(i):
+        if i not in ready:
+            k = pos_of[i]
+            idx = my_cubes[k:k + nbatch]
+            if not piped:
+                for c, (x, y) in zip(idx, run_batch(idx)):
+                    ready[c] = (x, y, None)
+            else:
+                st = side[issued[0] % nstreams]
+                issued[0] += 1
+                with torch.cuda.stream(st):
+                    outs = run_batch(idx)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                for c, (x, y) in zip(idx, outs):
+                    y.record_stream(main)
+                    x.record_stream(main)
+                    ready[c] = (x, y, ev)
+        x, y, ev = ready.pop(i)
         if not piped:
-            x, y = run_cube(i)
             if with_real:
                 asm.add_cube('real', x.reshape(E, E, E), i)
             return y
-        st = side[issued[0] % nstreams]
-        issued[0] += 1
-        with torch.cuda.stream(st):
-            x, y = run_cube(i)
-            ev = torch.cuda.Event()
-            ev.record(st)
-        y.record_stream(main)
-        x.record_stream(main)
         return (x, y, ev)
 
     def add_fake(j, tile):

@@ -50,13 +50,15 @@ def _dice_worker(rank, world, port, out_path):
     # rank 1 starts from OTHER weights: only the broadcast in front of the loop can make the sharded result right
     net.load_state_dict({k: torch.from_numpy(v).cuda() for k, v in S.weights_from_seed(S.unet_deconv_spec(), 22 + rank).items()})
     slab = diced_inference(net, vol, opt, rank, world, assemble='slab')
-    gath = diced_inference(net, vol, opt, rank, world, assemble='gather')
+    gath = diced_inference(net, vol, opt, rank, world, assemble='gather')  # (the verification mode: one cube per network call)
     dflt = diced_inference(net, vol, opt, rank, world)  # the default of world > 1 is 'slab'
     o2 = Namespace(**vars(opt))
     o2.normalize_intensity, o2.sat_level = True, [0.25, 99.75]
     norm = diced_inference(net, vol, o2, rank, world)  # ... unless the whole volume is needed on rank 0: 'reduce' 
     if rank == 0:
+        os.environ['NC_INFER_BATCH'] = '1'  # the single-rank reference of the bit-for-bit claim: the reference's batch size (one cube per call)
         one = diced_inference(net, vol, opt, 0, 1, assemble='gather', broadcast=False)
+        os.environ.pop('NC_INFER_BATCH')
         norm1 = diced_inference(net, vol, o2, 0, 1, broadcast=False)
         d = np.abs(slab.astype(np.int64) - one.astype(np.int64))
         dn = np.abs(norm.astype(np.int64) - norm1.astype(np.int64))

@@ -407,3 +407,31 @@ def test_two_cubes_140_and_their_slab_against_the_oracle():
     assert r['slab_max_lsb_diff'] <= 2
     assert r['slab_equal_share'] > 0.9
     assert r['ok']
+
+
+def test_batched_cubes_per_call_match_one_cube_per_call(monkeypatch):
+    """Round 6: diced inference hands NC_INFER_BATCH cubes to each nc_unet_deconv_fwd call (the two-term mode runs the whole batch through every
+    launch).  A cube's output may differ from its one-cube-per-call value only by the fp32 rounding of the InstanceNorm partial sums (their
+    grouping follows the launch's tile plan): <= 5e-7 after the sigmoid, the assembled uint16 volume within 1 LSB, and run-to-run identical.
+    Also the raw C entry point: N = 3 in one call against three N = 1 calls."""
+    from neuroclear_amd.test_dice import diced_inference
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 6, DEV))
+    x = torch.rand((3, 1, 80, 72, 64), generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        y3, y3b = net(x), net(x)
+        y1 = torch.cat([net(x[i:i + 1]) for i in range(3)])
+    assert torch.equal(y3, y3b)
+    assert float((y3 - y1).abs().max()) <= 5e-7
+    vol = S.random_volume(29, (200, 150, 130))
+    opt = Namespace(dice_size=[64] * 3, overlap=8, border_cut=8, gpu_ids=[0], skip_real=True, data_type='uint16',
+                    histogram_match=False, normalize_intensity=False)
+    out = {}
+    for b, st in (('1', '1'), ('5', '2'), ('3', '3'), ('5', '2')):
+        monkeypatch.setenv('NC_INFER_BATCH', b)
+        monkeypatch.setenv('NC_INFER_STREAMS', st)
+        out.setdefault((b, st), []).append(diced_inference(net, vol, opt))
+    assert np.array_equal(out[('5', '2')][0], out[('5', '2')][1])
+    for k in (('5', '2'), ('3', '3')):
+        d = np.abs(out[k][0].astype(np.int64) - out[('1', '1')][0].astype(np.int64))
+        assert int(d.max()) <= 1 and float((d > 0).mean()) < 0.02, (k, int(d.max()), float((d > 0).mean()))
