@@ -96,12 +96,14 @@ static int fwd_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
   if (g_split && p2d_fwd_supported(d)) return 10;
+  if (g_split && c1k7_h2_supported(d)) return 11;  // Conv3d(1, 64, 7) in pseudo-channel form on the two-term kernels (conv_s3x.hip)
   return (c1k3_fwd_supported(d) || mfma_fwd_supported(d)) ? 1 : flat_1x1_supported(d) ? 3 : k1_fwd_supported(d) ? 5 : pg1_on(d) ? 8 : sconv_on(d, 0) ? 7 : gemm_fwd_supported(d) ? 2 : 0;
 }
 static int dgrad_path(const ConvDims& d) {
   if (g_force_direct) return 0;
   if (g_split && s3_dgrad_supported(d)) return 9;
   if (g_split && p2d_dgrad_supported(d)) return 10;
+  if (g_split && c1k7_h2_supported(d)) return 11;  // Conv3d(1, 64, 7): two-term pseudo-channel form + fold (conv_s3x.hip)
   return mfma_dgrad_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : to1_mfma_supported(d) ? 6 : to1_dgrad_supported(d) ? 0
                                                                                               : pg1_on(d)             ? 8
                                                                                               : sconv_on(d, 1)        ? 7
@@ -186,6 +188,7 @@ int nc_conv_fwd_path(int C, int K, int kd, int kh, int kw, int stride, int pad) 
   if (!make_dims(d, 1, C, kd > 1 ? 32 : 1, e, e, K, kd, kh, kw, stride, pad)) return -1;
   if (g_force_direct) return 0;
   if (g_split && s3_fwd_supported(d)) return 9;
+  if (g_split && c1k7_h2_supported(d)) return 11;  // Conv3d(1, 64, 7) on the two-term kernels in pseudo-channel form (round 6)
   return mfma_fwd_supported(d) ? 1 : flat_1x1_supported(d) ? 3 : pg1_on(d) ? 8 : gemm_fwd_supported(d) ? 2 : 0;  // (the K = 1
   // reduction kernel of the PatchGAN head and the image-staged kernels depend on the batch, which this query does not take:
   // reported as 2)
@@ -234,6 +237,8 @@ size_t nc_conv_ws_bytes(int N, int C, int D, int H, int W, int K, int kd, int kh
     const size_t sc = s3_ws_bytes(d);
     if (sc > b) b = sc;
   }
+  if (g_split && c1k7_h2_ws_bytes(d) > b) b = c1k7_h2_ws_bytes(d);
+  if (g_split && c1k7_h2_dgrad_ws_bytes(d) > b) b = c1k7_h2_dgrad_ws_bytes(d);
   if (g_split && s3_wgrad_supported(d)) {
     size_t sc = s3_wgrad_ws_bytes(d);
     if (sc > b) b = sc;
@@ -264,6 +269,7 @@ int nc_conv_fwd(const float* x, const float* w, const float* bias, float* y, int
   ProfScope ps(0, path, d, 0, s);
   if (path == 9) return conv_fwd_s3(x, nullptr, w, bias, y, d, ws, ws_bytes, s);
   if (path == 10) return conv_fwd_p2d(x, w, bias, y, d, ws, ws_bytes, s);
+  if (path == 11 && ws && ws_bytes >= c1k7_h2_ws_bytes(d)) return conv_c1k7_h2(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && c1k3_fwd_supported(d)) return conv_fwd_c1k3(x, w, bias, y, d, s);  // 1 -> K channels, 3^3: its own fp32 MFMA kernel
   if (!g_force_direct && mfma_fwd_supported(d)) return conv_fwd_mfma(x, w, bias, y, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_fwd_1x1(x, w, bias, y, d, ws, ws_bytes, s);
@@ -283,6 +289,7 @@ int nc_conv_dgrad(const float* dy, const float* w, float* dx, int N, int C, int 
   ProfScope ps(1, path, d, 0, s);
   if (path == 9) return conv_dgrad_s3(dy, nullptr, w, dx, d, ws, ws_bytes, s);
   if (path == 10) return conv_dgrad_p2d(dy, w, dx, d, ws, ws_bytes, s);
+  if (path == 11 && ws && ws_bytes >= c1k7_h2_dgrad_ws_bytes(d)) return conv_c1k7_h2_dgrad(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && mfma_dgrad_supported(d)) return conv_dgrad_mfma(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && flat_1x1_supported(d)) return conv_dgrad_1x1(dy, w, dx, d, ws, ws_bytes, s);
   if (!g_force_direct && to1_mfma_supported(d)) return conv_dgrad_to1_mfma(dy, w, dx, d, ws, ws_bytes, s);

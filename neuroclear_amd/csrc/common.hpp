@@ -236,6 +236,12 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
 size_t s3x_stats_bytes(int N, int D, int H, int W, int Kout, int KS);
 int s3x_stats_finalize(const float* stats_part, const float* bias, int N, int D, int H, int W, int Kout, int KS, float eps, float* mean, float* rstd,
                        hipStream_t s);
+// conv_s3x.hip: Conv3d(1, 64, 7, padding 3) forward in pseudo-channel form on the two-term kernels (x fp32, measured cell, guard counted)
+bool c1k7_h2_supported(const ConvDims& d);
+size_t c1k7_h2_ws_bytes(const ConvDims& d);
+int conv_c1k7_h2(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
+size_t c1k7_h2_dgrad_ws_bytes(const ConvDims& d);
+int conv_c1k7_h2_dgrad(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 // h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
 // an H2 tensor of `elems` elements = elems * 4 bytes of units + (at this byte offset) 256 bytes of cells: [0] the cell of the channels' first
 // half, [1] of the second half (a concatenation converted in two parts; equal to [0] otherwise) -- inside the elems * 6 bytes of an S3 tensor

@@ -142,6 +142,132 @@ __global__ void __launch_bounds__(256) k_absmax_w(const float* __restrict__ w, l
   }
 }
 
+// ---- the pseudo-channel form of a one-input-channel 7^3 layer (k_conv_s3x PC)
+// Packed weights, same fragment layout as k_pack_w_s3x with ONE 8-"channel" block: lane (g, m) of k-step s holds output channel co at tap
+// T = 4 s + g of the (dz, dy) stream (brick dz = T / 8, in-plane tap dy = T % 8, the eighth slot empty); element j = the dx tap j (odd lane
+// groups: (j + 4) % 8), zero for j = 7.  flip: the data-gradient orientation (w[co][0][342 - tap]) -- not used yet.
+__global__ void __launch_bounds__(256) k_pack_w_c1k7(const float* __restrict__ w, unsigned short* __restrict__ wp, int NS, long total,
+                                                     const unsigned* __restrict__ amax) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int lane = (int)(q & 63); q >>= 6;
+  const int f = (int)(q & 3); q >>= 2;  // rb * 2 + term
+  const int s = (int)(q % NS); q /= NS;
+  const int half = (int)(q & 1);
+  const int rb = f >> 1, term = f & 1;
+  const int g = lane >> 4, m = lane & 15;
+  const int T = 4 * s + g;
+  unsigned short t[3] = {0, 0, 0};
+  const int jj = (g & 1) ? ((j + 4) & 7) : j;
+  const int dz = T >> 3, dy = T & 7;  // eight tap slots per (dz) brick, the eighth empty (see k_conv_s3x PC)
+  if (dz < 7 && dy < 7 && jj < 7) {
+    const int co = half * 32 + rb * 16 + m;
+    h2_split(w[(long)co * 343 + (dz * 7 + dy) * 7 + jj] * h2_scale(*amax), t);
+  }
+  wp[i] = t[term];
+}
+
+// x fp32 [N][1][D][H][W] -> the H2 tensor [N][1 block][2 terms][voxels][8]: element j of voxel (z, y, x) = x[z][y][x + j - 3] (zero outside the
+// row and for j = 7), times the power of two of the measured cell.  guard (nullable): the range guard's chunk counts (h2.hip k_split2h: a wave's
+// 64 voxels are one chunk, judged by the largest magnitude of their OWN elements).
+__global__ void __launch_bounds__(256) k_build_x8_h2(const float* __restrict__ x, uint4* __restrict__ out, long S, int W, const unsigned* __restrict__ cell,
+                                                     unsigned* __restrict__ guard) {
+  const unsigned cb_bits = *cell;
+  const float sc = h2_scale(cb_bits);
+  const int n = blockIdx.y;
+  unsigned n_all = 0, n_low = 0;
+  for (long v0 = (long)blockIdx.x * 256; v0 < S; v0 += (long)gridDim.x * 256) {
+    const long v = v0 + threadIdx.x;
+    unsigned m = 0;
+    if (v < S) {
+      const int xx = (int)(v % W);
+      const float* row = x + (long)n * S + (v - xx);
+      unsigned short e[8][3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int xs = xx + j - 3;
+        const float f = (j < 7 && (unsigned)xs < (unsigned)W) ? row[xs] : 0.f;
+        if (j == 3) { const unsigned b = __float_as_uint(f) & 0x7fffffffu; if (b < 0x7f800000u) m = b; }
+        h2_split(f * sc, e[j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) out[((long)n * 2 + t) * S + v] = s3_unit(e, t);
+    }
+    if (guard) {
+      const unsigned thr = cb_bits > kGuardDrop ? cb_bits - kGuardDrop : 0u;
+      const bool any_hi = __builtin_amdgcn_ballot_w64(m >= thr && m != 0) != 0;
+      const bool any_nz = __builtin_amdgcn_ballot_w64(m != 0) != 0;
+      if (any_nz) {
+        ++n_all;
+        if (!any_hi) ++n_low;
+      }
+    }
+  }
+  if (!guard) return;
+  __shared__ unsigned cnt[2];
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    if (n_all) atomicAdd(&cnt[kGuardAll], n_all);
+    if (n_low) atomicAdd(&cnt[kGuardLow], n_low);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(guard + threadIdx.x, cnt[threadIdx.x]);
+}
+
+// PC = 2 (the data gradient): row co = dz * 7 + dx of the 64-row tile (rows 49 .. 63 empty), lane (g, m) of k-step s at slot T = 4 s + g: brick
+// T / 8 = the 8-channel block of dY, in-plane slot tau = T % 8 reads dY's row y + tau - 3, which meets the kernel row dy = 6 - tau (dX[u] = sum w[k][t]
+// dY[k][u + 3 - t]); element j = channel block * 8 + j (odd lane groups: (j + 4) % 8).
+__global__ void __launch_bounds__(256) k_pack_w_c1k7d(const float* __restrict__ w, unsigned short* __restrict__ wp, int NS, long total,
+                                                      const unsigned* __restrict__ amax) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  long q = i >> 3;
+  const int lane = (int)(q & 63); q >>= 6;
+  const int f = (int)(q & 3); q >>= 2;
+  const int s = (int)(q % NS); q /= NS;
+  const int half = (int)(q & 1);
+  const int rb = f >> 1, term = f & 1;
+  const int g = lane >> 4, m = lane & 15;
+  const int T = 4 * s + g;
+  const int blk = T >> 3, tau = T & 7;
+  const int co = half * 32 + rb * 16 + m;
+  const int jj = (g & 1) ? ((j + 4) & 7) : j;
+  unsigned short t[3] = {0, 0, 0};
+  if (blk < 8 && tau < 7 && co < 49) {
+    const int k = blk * 8 + jj, dz = co / 7, dx = co - dz * 7, dy = 6 - tau;
+    h2_split(w[(long)k * 343 + (dz * 7 + dy) * 7 + dx] * h2_scale(*amax), t);
+  }
+  wp[i] = t[term];
+}
+
+// dX[n][z][y][x] = sum over (dz, dx) of Z[n][dz * 7 + dx][z + 3 - dz][y][x + 3 - dx] where that voxel exists, in (dz, dx) order: every element of Z
+// is read once (247 MB at 108^3)
+__global__ void __launch_bounds__(256) k_fold_c1k7(const float* __restrict__ Z, float* __restrict__ dx, int D, int H, int W) {
+  const long HW = (long)H * W, S = (long)D * HW;
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= S) return;
+  const int n = blockIdx.y;
+  const int x = (int)(v % W), z = (int)(v / HW);
+  const float* Zn = Z + (long)n * 49 * S;
+  float acc = 0.f;
+#pragma unroll
+  for (int dz = 0; dz < 7; ++dz) {
+    const int zz = z + 3 - dz;
+    if ((unsigned)zz >= (unsigned)D) continue;
+    const float* zp = Zn + (long)dz * 7 * S + v + (long)(3 - dz) * HW;
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+      const int xx = x + 3 - d;
+      if ((unsigned)xx < (unsigned)W) acc += zp[(long)d * S + 3 - d];
+    }
+  }
+  dx[(long)n * S + v] = acc;
+}
+
 struct XParams {
   const uint4* xs;     // S3 input [N][C/8][3][D][H][W] units
   const uint4* wp;     // packed weights
@@ -211,18 +337,30 @@ __device__ __forceinline__ XTile x_decode(const XParams& p, int idx) {
 // K32: ONE 32-channel output slice per tile instead of two -- the eight waves are eight position groups of NCB column blocks (a tile of 128 NCB
 // positions) and all read the weights of "half 0".  For convolutions onto 32 output channels (deep_linear_gen's collapsed forward, gen_nets.hip):
 // on the 64-channel tile half of the MFMAs would multiply zero weights.
-template <int KS, int NCB, int NT, bool ST = false, bool K32 = false>
+// PC (round 6, KS = 7): the PSEUDO-CHANNEL form of a one-input-channel 7^3 layer (deep_linear_gen's first layer, networks.py:899): the input is
+// an H2 tensor of ONE 8-channel block whose "channels" are the voxel's row shifted by -3 .. +4 (the seven dx taps and a zero: k_build_x8_h2),
+// so the kernel's taps are (dz, dy) only -- 7 bricks of 7 in-plane taps (+ one empty slot: two k-steps per brick), row pitch W (no pad columns),
+// 14 k-steps.  Same tap stream, same ring, same epilogue: the 55 GFLOP of the layer run at the two-term rate instead of on the fp32
+// matrix instruction (0.67 ms at 108^3).
+// PC = 2: the same in-plane geometry (seven row taps + an empty slot per brick, pitch W) with NO plane taps -- a brick per 8-channel block: the
+// data gradient of that layer as Z[(dz, dx)][v] = sum_k sum_dy w[k][dz][dy][dx] dY[k][v + (3 - dy) W] on a 64-channel tile (49 rows used),
+// folded into dX by k_fold_c1k7 (conv_c1k7_h2_dgrad below).
+template <int KS, int NCB, int NT, bool ST = false, bool K32 = false, int PC = 0>
 __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
-  constexpr int PAD = KS / 2, T2 = KS * KS, PT = (K32 ? 128 : 64) * NCB;
+  // (PC: EIGHT tap slots per brick, the eighth a zero-weight dummy that re-reads row 6 -- a brick is then exactly two k-steps: with seven, brick 1
+  // would be wanted by the read-ahead at the end of k-step 0, one step before its arrival barrier)
+  constexpr int PAD = KS / 2, KX = PC ? 1 : KS, PADX = PC ? 0 : PAD, T2 = PC ? 8 : KS * KX, PT = (K32 ? 128 : 64) * NCB;
+  constexpr int KZ = PC == 2 ? 1 : KS, PADZ = PC == 2 ? 0 : PAD;  // plane taps
   static_assert(!(K32 && ST), "no epilogue statistics on 32-channel tiles");
+  static_assert(!PC || (KS == 7 && NT == 2 && !ST && !K32), "the pseudo-channel form: 7 x 7 x 1 taps, two-term operands");
   if (guard_skip(p.guard, NT == 3)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, g = lane >> 4;
   const int half = K32 ? 0 : wave & 1, pg = K32 ? wave : wave >> 1;
   const long HW = (long)p.H * p.W, S = (long)p.D * HW;
-  const int NB = p.NCH * KS;     // bricks per tile
+  const int NB = p.NCH * KZ;     // bricks per tile
   const int BB = p.npb * 1024;   // bytes per ring slot
 
   const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -256,8 +394,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
   const unsigned otab = (unsigned)(unsigned long long)(lptr_t)lds_raw + (unsigned)(3 * BB + ((wave * kPW) * 64 + lane) * 4);  // [wave][piece i][lane]
   auto issue_brick = [&](const XTile& t, int bi, int slot, bool kept) __attribute__((always_inline)) {
     if (wave >= kDmaWaves) return;
-    const int chunk = bi / KS, dz = bi - chunk * KS;
-    const int zz = t.z + dz - PAD;
+    const int chunk = bi / KZ, dz = bi - chunk * KZ;
+    const int zz = t.z + dz - PADZ;
     const bool zok = (unsigned)zz < (unsigned)p.D;
     const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * NT * S;
     // a plane outside the volume: an empty descriptor, every lane reads zeros
@@ -285,7 +423,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
       const unsigned term = fdiv(u, p.mUB);
       const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
       const unsigned rr = fdiv(F, p.mP);
-      const int xx = (int)(F - rr * p.P) - PAD;
+      const int xx = (int)(F - rr * p.P) - PADX;
       const int yy = (int)rr - PAD;
       const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
@@ -487,7 +625,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
         const unsigned term = fdiv(u, p.mUB);
         const unsigned F = (unsigned)cur.q0 + (u - term * p.UB);
         const unsigned rr = fdiv(F, p.mP);
-        const int xx = (int)(F - rr * p.P) - PAD;
+        const int xx = (int)(F - rr * p.P) - PADX;
         const int yy = (int)rr - PAD;
         const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
         *(lds32_t)(otab + i * 256) = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
@@ -500,8 +638,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
     // per-lane tap state: lane group g is at tap tpl of the brick in slot sl
     int tpl = g, sl = ring;
     auto b_off = [&]() __attribute__((always_inline)) {
-      const int dy = KS == 3 ? (tpl * 11) >> 5 : (tpl * 13) >> 6;
-      const int dx = tpl - dy * KS;
+      const int dy = PC ? (tpl < 6 ? tpl : 6) : KS == 3 ? (tpl * 11) >> 5 : (tpl * 13) >> 6;
+      const int dx = PC ? 0 : tpl - dy * KX;  // (PC: the empty eighth slot re-reads row 6 itself, not its neighbour -- zero weights, but 0 x inf is NaN)
       return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
     };
     BAddr vo = b_addr(b_off());
@@ -684,8 +822,8 @@ struct XPlan {
 };
 
 constexpr int kOffTab = 8192;  // two-term launches: the DMA offset table behind the ring, [4 issuing waves][8 pieces][64 lanes] words
-bool x_brick(int PT, int P, int KS, int NT, int& UB, int& npb, int& lds) {
-  const int U = PT + (KS - 1) * (P + 1);
+bool x_brick(int PT, int P, int KS, int NT, int& UB, int& npb, int& lds, bool pc = false) {
+  const int U = PT + (KS - 1) * (pc ? P : P + 1);  // (pseudo-channel form: in-plane taps are rows only)
   UB = (U + 63) / 64 * 64;
   npb = NT * UB / 64;
   lds = 3 * npb * 1024;
@@ -697,10 +835,10 @@ int x_tail_mode() {  // NC_S3X_TAIL=0: the left-over tiles run as one more round
   return m;
 }
 
-XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = false) {
+XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = false, bool pc = false) {
   XPlan best{};
   double best_cost = 1e30;
-  const int P = W + KS - 1;
+  const int P = pc ? W : W + KS - 1;
   const long HP = (long)H * P;
   static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
   for (int NCB : {8, 7, 6, 4, 2}) {
@@ -711,7 +849,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = 
     XPlan pl{};
     pl.NCB = NCB; pl.P = P; pl.HP = (int)HP;
     const int PT = (k32 ? 128 : 64) * NCB;
-    if (!x_brick(PT, P, KS, NT, pl.UB, pl.npb, pl.lds)) continue;
+    if (!x_brick(PT, P, KS, NT, pl.UB, pl.npb, pl.lds, pc)) continue;
     pl.TPP = (int)((HP + PT - 1) / PT);
     const long ntiles = (long)N * D * pl.TPP * KT;
     pl.full = ntiles / 256 * 256;
@@ -730,15 +868,15 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = 
       pl.fsub = f;
       cost += PT / f + fixed;
     }
-    if (!x_brick(PT / pl.fsub, P, KS, NT, pl.UBt, pl.npbt, pl.ldst)) continue;
+    if (!x_brick(PT / pl.fsub, P, KS, NT, pl.UBt, pl.npbt, pl.ldst, pc)) continue;
     if (cost < best_cost) { best_cost = cost; best = pl; best.ok = true; }
   }
   return best;
 }
 
-template <int KS, int NCB, int NT, bool ST = false, bool K32 = false>
+template <int KS, int NCB, int NT, bool ST = false, bool K32 = false, int PC = 0>
 int launch_x(const XParams& p, int lds, hipStream_t s) {
-  auto kern = k_conv_s3x<KS, NCB, NT, ST, K32>;
+  auto kern = k_conv_s3x<KS, NCB, NT, ST, K32, PC>;
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
@@ -915,6 +1053,137 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
     if (e) return e;
   }
   return NC_OK;
+}
+
+// ---- Conv3d(1, 64, 7, padding 3) forward on the two-term kernels (k_conv_s3x PC).  Workspace: [256 B cells: x, w | 256 B guard words | X8 in H2
+// form | packed weights].  The input's cell is MEASURED (k_absmax), so the range guard counts its chunks; a flagged tensor cannot switch kernels
+// here (there is no three-term pseudo-channel kernel): it is reported in nc_h2_guard_stats [2] like every counted-only tensor, and callers that
+// act on the report (BaseModel.get_current_losses -> nc_set_split_terms(3)) send this layer back to the fp32 matrix kernel.
+static size_t c1k7_al(size_t b) { return (b + 255) & ~(size_t)255; }
+static constexpr int kC1k7Steps = 14;  // 7 bricks of eight (dz, dy) tap slots, in fours
+static size_t c1k7_packed_bytes() { return (size_t)2 * kC1k7Steps * 4 * 1024; }
+bool c1k7_h2_supported(const ConvDims& d) {
+  static const int on = getenv("NC_C1K7_H2") ? atoi(getenv("NC_C1K7_H2")) : 1;  // NC_C1K7_H2=0: the fp32 matrix kernel (A/B)
+  if (!on || s3x_get_terms() != 2) return false;
+  if (d.C != 1 || d.K != 64 || d.kd != 7 || d.kh != 7 || d.kw != 7 || d.sd != 1 || d.sh != 1 || d.sw != 1 || d.pd != 3 || d.ph != 3 || d.pw != 3) return false;
+  const long S = (long)d.D * d.H * d.W;
+  if (d.W < 4 || (long)64 * S * 4 >= (1l << 31) || S * 32 >= (1l << 31)) return false;
+  return x_plan(d.N, d.D, d.H, d.W, 1, 7, 2, false, true).ok;
+}
+size_t c1k7_h2_ws_bytes(const ConvDims& d) {
+  if (!c1k7_h2_supported(d)) return 0;
+  return 512 + c1k7_al((size_t)d.N * d.D * d.H * d.W * 32) + c1k7_al(c1k7_packed_bytes());
+}
+template <int NCB>
+static int launch_pc(const XParams& p, int lds, hipStream_t s) { return launch_x<7, NCB, 2, false, false, 1>(p, lds, s); }
+static int launch_pc_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
+  if (NCB == 8) return launch_pc<8>(p, lds, s);
+  if (NCB == 7) return launch_pc<7>(p, lds, s);
+  if (NCB == 6) return launch_pc<6>(p, lds, s);
+  if (NCB == 4) return launch_pc<4>(p, lds, s);
+  return launch_pc<2>(p, lds, s);
+}
+int conv_c1k7_h2(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  if (!c1k7_h2_supported(d)) { set_error("conv_c1k7_h2: shape not covered"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < c1k7_h2_ws_bytes(d)) { set_error("conv_c1k7_h2: workspace too small"); return NC_ERR_WS; }
+  const XPlan pl = x_plan(d.N, d.D, d.H, d.W, 1, 7, 2, false, true);
+  const long S = (long)d.D * d.H * d.W;
+  unsigned* cells = (unsigned*)ws;                 // [0] x, [1] w
+  unsigned* gw = (unsigned*)((char*)ws + 256);     // guard words of x
+  uint4* x8 = (uint4*)((char*)ws + 512);
+  void* wp = (char*)x8 + c1k7_al((size_t)d.N * S * 32);
+  if (int e = h2_zero_cells(cells, 2, s)) return e;
+  if (int e = h2_absmax(x, (long)d.N * S, cells, s)) return e;
+  if (int e = h2_absmax(w, (long)64 * 343, cells + 1, s)) return e;
+  const bool guard = h2_guard_on();
+  if (guard) if (int e = h2_guard_zero(gw, s, 4)) return e;
+  {
+    long bx = cdiv(S, 256);
+    if (guard && bx * d.N > 4096) bx = cdiv(4096, d.N);  // (few atomics: h2.hip split2h_into)
+    hipLaunchKernelGGL(k_build_x8_h2, dim3((unsigned)bx, (unsigned)d.N), dim3(256), 0, s, x, x8, S, d.W, (const unsigned*)cells, guard ? gw : nullptr);
+  }
+  if (guard) if (int e = h2_guard_decide(gw, nullptr, nullptr, gw + kGuardFlag, false, s)) return e;  // counted, never switched (see above)
+  const long total = (long)(c1k7_packed_bytes() / 2);
+  hipLaunchKernelGGL(k_pack_w_c1k7, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp, kC1k7Steps, total, (const unsigned*)(cells + 1));
+  if (int e = check_launch("conv_c1k7_h2 prep")) return e;
+  XParams p{};
+  p.xs = x8; p.wp = (const uint4*)wp; p.bias = bias; p.y = y; p.amax_x = cells; p.amax_w = cells + 1; p.guard = nullptr;
+  p.N = d.N; p.NCH = 1; p.D = d.D; p.H = d.H; p.W = d.W; p.K = 64;
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = 1;
+  p.NS = kC1k7Steps; p.mP = magic(pl.P);
+  p.flush = 4;
+  const bool one = pl.rem && pl.fsub == 1;
+  if (pl.full || one) {
+    p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
+    p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    if (int e = launch_pc_ncb(pl.NCB, p, pl.lds + kOffTab, s)) return e;
+  }
+  if (pl.rem && !one) {
+    p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
+    p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    if (int e = launch_pc_ncb(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)) return e;
+  }
+  return NC_OK;
+}
+
+// ---- the data gradient of that layer: dX from the fp32 dY [N][64][voxels] (converted here: measured cell, guard counted as above).
+// Workspace: [256 B cells: dY, w | 256 B guard words | dY in H2 form | packed weights | Z: 49 planes per sample, fp32].
+static constexpr int kC1k7dSteps = 16;  // 8 channel blocks x eight row-tap slots, in fours
+static size_t c1k7d_packed_bytes() { return (size_t)2 * kC1k7dSteps * 4 * 1024; }
+size_t c1k7_h2_dgrad_ws_bytes(const ConvDims& d) {
+  if (!c1k7_h2_supported(d)) return 0;
+  const size_t S = (size_t)d.D * d.H * d.W;
+  return 512 + c1k7_al((size_t)d.N * 64 * S * 4) + c1k7_al(c1k7d_packed_bytes()) + c1k7_al((size_t)d.N * 49 * S * 4);
+}
+template <int NCB>
+static int launch_pcd(const XParams& p, int lds, hipStream_t s) { return launch_x<7, NCB, 2, false, false, 2>(p, lds, s); }
+static int launch_pcd_ncb(int NCB, const XParams& p, int lds, hipStream_t s) {
+  if (NCB == 8) return launch_pcd<8>(p, lds, s);
+  if (NCB == 7) return launch_pcd<7>(p, lds, s);
+  if (NCB == 6) return launch_pcd<6>(p, lds, s);
+  if (NCB == 4) return launch_pcd<4>(p, lds, s);
+  return launch_pcd<2>(p, lds, s);
+}
+int conv_c1k7_h2_dgrad(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s) {
+  if (!c1k7_h2_supported(d)) { set_error("conv_c1k7_h2_dgrad: shape not covered"); return NC_ERR_SHAPE; }
+  if (!ws || wsb < c1k7_h2_dgrad_ws_bytes(d)) { set_error("conv_c1k7_h2_dgrad: workspace too small"); return NC_ERR_WS; }
+  const XPlan pl = x_plan(d.N, d.D, d.H, d.W, 1, 7, 2, false, true);
+  const long S = (long)d.D * d.H * d.W;
+  unsigned* cells = (unsigned*)ws;
+  unsigned* gw = (unsigned*)((char*)ws + 256);
+  char* dyh = (char*)ws + 512;
+  char* wp = dyh + c1k7_al((size_t)d.N * 64 * S * 4);
+  float* Z = (float*)(wp + c1k7_al(c1k7d_packed_bytes()));
+  if (int e = h2_zero_cells(cells, 2, s)) return e;
+  if (int e = h2_absmax(dy, (long)d.N * 64 * S, cells, s)) return e;
+  if (int e = h2_absmax(w, (long)64 * 343, cells + 1, s)) return e;
+  const bool guard = h2_guard_on();
+  if (guard) if (int e = h2_guard_zero(gw, s, 4)) return e;
+  if (int e = split2h_into(dy, 64 * S, dyh, d.N, 64, S, 64, 0, cells, s, guard ? gw : nullptr)) return e;
+  if (guard) if (int e = h2_guard_decide(gw, nullptr, nullptr, gw + kGuardFlag, false, s)) return e;  // counted, never switched
+  const long total = (long)(c1k7d_packed_bytes() / 2);
+  hipLaunchKernelGGL(k_pack_w_c1k7d, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (unsigned short*)wp, kC1k7dSteps, total, (const unsigned*)(cells + 1));
+  if (int e = check_launch("conv_c1k7_h2_dgrad prep")) return e;
+  XParams p{};
+  p.xs = (const uint4*)dyh; p.wp = (const uint4*)wp; p.bias = nullptr; p.y = Z; p.amax_x = cells; p.amax_w = cells + 1; p.guard = nullptr;
+  p.N = d.N; p.NCH = 8; p.D = d.D; p.H = d.H; p.W = d.W;
+  p.K = 49;  // (rows 49 .. 63 of the tile store beyond the descriptor's range: dropped by the hardware)
+  p.P = pl.P; p.HP = pl.HP; p.TPP = pl.TPP; p.KT = 1;
+  p.NS = kC1k7dSteps; p.mP = magic(pl.P);
+  p.flush = 4;
+  const bool one = pl.rem && pl.fsub == 1;
+  if (pl.full || one) {
+    p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
+    p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    if (int e = launch_pcd_ncb(pl.NCB, p, pl.lds + kOffTab, s)) return e;
+  }
+  if (pl.rem && !one) {
+    p.fsub = pl.fsub; p.UB = pl.UBt; p.npb = pl.npbt; p.mUB = magic(pl.UBt);
+    p.t_begin = (int)pl.full; p.t_count = (int)(pl.rem * pl.fsub); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
+    if (int e = launch_pcd_ncb(pl.NCB / pl.fsub, p, pl.ldst + kOffTab, s)) return e;
+  }
+  hipLaunchKernelGGL(k_fold_c1k7, dim3((unsigned)cdiv(S, 256), (unsigned)d.N), dim3(256), 0, s, (const float*)Z, dx, d.D, d.H, d.W);
+  return check_launch("conv_c1k7_h2_dgrad fold");
 }
 
 // ST epilogue (see k_conv_s3x): bytes of the partial-sum records of one two-term launch pair, and the pass that turns them into mean / rstd

@@ -104,7 +104,7 @@ class BaseModel(ABC):
         in the third counter.  This is the place where the host is synchronised anyway: if any were seen since the last look, the process goes
         to the three-term form (1.5 x the step time, exact) and THIS model says so.  What it does not do: the steps taken since the last look --
         with the reference's --print_freq up to hundreds -- were applied with the flagged operands as they were; nothing is recomputed.
-        The counters are read WITH reset, so a caller that goes back to nc_set_split_terms(2) later is protected again; the switch itself is
+        Counters that carry a flag are taken WITH reset, so a caller that goes back to nc_set_split_terms(2) later is protected again; the switch itself is
         process-wide (one library, one arithmetic), which is why every model that observes a flag repeats the warning instead of inheriting the
         state silently.  Data-parallel runs: the flag is all-reduced (MAX) so that every rank switches at the same step -- every rank has to
         call get_current_losses() at the same iterations (train_onecube.py and bench.py do)."""
@@ -114,7 +114,9 @@ class BaseModel(ABC):
         two_term = L.nc_get_split_terms() == 2 and bool(L.nc_get_h2_guard())
         st = (ctypes.c_ulonglong * 4)()
         if two_term:
-            L.nc_h2_guard_stats(st, 1)
+            L.nc_h2_guard_stats(st, 0)
+            if st[2]:  # acting on them: take the counters WITH reset (one exchange per counter), so that the same flags are not acted on twice
+                L.nc_h2_guard_stats(st, 1)
         flagged = int(st[2])
         from ..util.dist import exchange_active
         if exchange_active():

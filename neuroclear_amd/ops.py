@@ -25,7 +25,7 @@ def prof_start(min_flop=0.0):
     lib().nc_prof_begin(ctypes.c_double(min_flop))
 
 
-_PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 'to1', 7: 'img', 8: 'pg1', 9: 'split', 10: 'split2d'}
+_PATH = {0: 'direct', 1: 'mfma', 2: 'gemm', 3: 'flat', 4: 'taps', 5: 'k1', 6: 'to1', 7: 'img', 8: 'pg1', 9: 'split', 10: 'split2d', 11: 'split'}
 
 
 def prof_stop():
