@@ -75,7 +75,7 @@ KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
 
 # `roofline.traffic` is NOT measured in this process (counters cannot be read from inside it): it is the figure of the committed offline PMC
 # passes of the same command, on whatever box those ran on
-TRAFFIC_FILE = 'r05_pmc_traffic.json'
+TRAFFIC_FILE = 'r06_pmc_traffic.json'
 TRAFFIC_SOURCE = 'profiles/%s (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % TRAFFIC_FILE
 
 PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fwd_mfma_k5': 'conv_mfma_k5',
@@ -89,7 +89,7 @@ PMC_CLASS = {'fwd_mfma_k3': 'conv_mfma_k3', 'dgrad_mfma_k3': 'conv_mfma_k3', 'fw
 
 def pmc_traffic(tag, crop=108, batch=1, three_term=False):
     """HBM bytes per launch of the kernel class, from the committed PMC passes of this same command
-    (profiles/r05_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
+    (profiles/r06_pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters cannot be
     read from inside the process).  None when the file or the class is missing."""
     if '_lp_' in tag and not (tag.endswith('k5') and crop == 148 and batch == 4):
         return None  # the 16-bit classes were counted on one shape only; a class of mixed shapes gets no figure
@@ -388,12 +388,12 @@ def run_train(args, rank, world, dev):
         if two:
             kname = kname.replace('k_conv_s3x<3,*>', 'k_conv_s3x<3,*,2>').replace('k_conv_s3x<5,*>', 'k_conv_s3x<5,*,2>').replace(
                 'k_wgrad_s3x<3>', 'k_wgrad_s3x<3,2,f16>').replace('k_wgrad_s3x<5>', 'k_wgrad_s3x<5,2,f16>')
+        traffic = pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two)
         roof = dict(bound='mfma', kernel=kname, kernel_class=top, achieved=round(ach, 2),
                     peak=round(peak, 2), unit='TFLOP/s', frac=round(ach / peak, 4), **extra,
-                    traffic=pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two), traffic_source=TRAFFIC_SOURCE,
+                    traffic=traffic, traffic_source=TRAFFIC_SOURCE,
                     algorithmic_bytes=round(abytes / n),  # per launch, measured on THIS run's launches: operands once + result + weights
-                    traffic_vs_algorithmic=(round(pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two) / (abytes / n), 3)
-                                            if pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two) else None),
+                    traffic_vs_algorithmic=round(traffic / (abytes / n), 3) if traffic else None,
                     launches=n, avg_launch_ms=round(ms / n, 4),
                     gflop_per_launch=round(flop / n / 1e9, 2),
                     share_of_step=round(ms / (dt * 1e3), 4),
@@ -416,6 +416,8 @@ def _dl_note(tag, tflops, args):
     from neuroclear_amd._lib import lib
     if not tag.startswith('deep_linear') or args.precision != 'fp32' or not lib().nc_get_dl_collapse() or lib().nc_get_split_terms() != 2:
         return {}
+    if args.crop != 108 or args.batch != 1:
+        return {}  # (the shares below are the headline shape's, where every collapsed / rank-structured plan applies; other shapes may take fewer of them)
     share = 277979.0 / 647120.0 if tag.endswith('fwd') else 555904.0 / 1294240.0
     return dict(tflops_is='on the reference\'s layer-by-layer FLOP count', tflops_executed=round(tflops * share, 2), executed_share_of_reference_flops=round(share, 4))
 
@@ -511,13 +513,13 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
         extra = dict(peak_is='%s dense MFMA peak %.0f / %d MFMA products per fp32 product' % ('fp16' if terms == 2 else 'bf16', MFMA_16BIT_PEAK_TFLOPS, products),
                      split_terms=terms, frac_of_six_product_roof=round(ach / MFMA_SPLIT_PEAK_TFLOPS, 4),
                      vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4)) if split else {}
+        cube_traffic = pmc_traffic_cube(split, three_term=split and terms != 2)
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
-                                        'profiles/r04_infer_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
+                                        'profiles/r06_infer480_one_stream_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
-                    frac=round(ach / peak, 4), **extra, traffic=pmc_traffic_cube(split, three_term=split and terms != 2), traffic_source=TRAFFIC_SOURCE,
+                    frac=round(ach / peak, 4), **extra, traffic=cube_traffic, traffic_source=TRAFFIC_SOURCE,
                     algorithmic_bytes=round(3192 * 140 ** 3),  # 3,192 B per voxel for a perfectly fused fp32 G_A forward
-                    traffic_vs_algorithmic=(round(pmc_traffic_cube(split, three_term=split and terms != 2) / (3192 * 140 ** 3), 3)
-                                            if pmc_traffic_cube(split, three_term=split and terms != 2) else None), launches=my_cubes,
+                    traffic_vs_algorithmic=round(cube_traffic / (3192 * 140 ** 3), 3) if cube_traffic else None, launches=my_cubes,
                     network_calls=ncalls, cubes_per_call=batch, streams=in_flight,
                     cubes_in_flight=in_flight * batch, avg_launch_ms=round(ms / my_cubes, 3), gflop_per_launch=round(flop / 1e9, 1),
                     event_ms_per_cube=round(ms_events / my_cubes, 3),
@@ -703,8 +705,10 @@ def main():
                                             'space, the 5^3 layer\'s backward from 27 shifted copies of the one-channel dy (32 x 64 problems); exact algebra, every '
                                             'output and gradient of the reference step is produced (DESIGN.md 4.6, tests/test_collapse_algebra.py); '
                                             'layer_by_layer = the same step with nc_set_dl_collapse(0)',
-                                       macs_per_voxel_reference_fwd_bwd=3 * 647120, macs_per_voxel_executed_fwd_bwd=833900,
-                                       note='the reference-count 9.904 TFLOP per step include 2.79 TFLOP this evaluation does not execute')
+                                       macs_per_voxel_reference_fwd_bwd=3 * 647120)
+        if args.crop == 108 and args.batch == 1 and args.model == 'apollo':  # (figures of the headline shape, where every plan of DESIGN.md 4.6 applies)
+            out['deep_linear_tail'].update(macs_per_voxel_executed_fwd_bwd=833900,
+                                           note='the reference-count 9.904 TFLOP per step include 2.79 TFLOP this evaluation does not execute')
         if headline and world == 1:
             import copy
             a4 = copy.copy(args)

@@ -718,10 +718,10 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
       // The max-pools work on the H2 tensors themselves (the winner's two terms are the pooled element's terms, same cell: h2.hip): blocks 1
       // and 3 write NO fp32 activation, and nothing is converted.  The pooled tensors go into slots nobody needs yet (the upper half of
       // s_cat2 until the transposed convolution's output arrives; s_b2 until block 5 writes it).  NC_POOL_H2=0: fp32 pool + conversion (A/B)
-      static const bool pool_h2 = !(getenv("NC_POOL_H2") && atoi(getenv("NC_POOL_H2")) == 0);
+      static const bool pool_h2 = true;
       void* p1h = W + u.s_cat2 + 128 * Sh * bn;
       // (NC_POOL_FUSE=0: the pool as a pass of its own over the H2 tensor)
-      static const bool pool_fuse = pool_h2 && !(getenv("NC_POOL_FUSE") && atoi(getenv("NC_POOL_FUSE")) == 0);
+      static const bool pool_fuse = pool_h2 && true;
       NC_TRY(block(1, nullptr, W + u.s_a1, pool_h2 ? nullptr : W + u.cat1, W + u.s_cat1, 128, 0, 64, 64, S0, S1, S2, c0, nullptr, 0, c0, pool_fuse ? p1h : nullptr));
       if (pool_fuse) {
       } else if (pool_h2) {
@@ -780,7 +780,7 @@ int nc_unet_deconv_fwd(const float* params, const float* x, float* y, int N, int
         NC_TRY(split2h_into(up1, 64 * S, W + u.s_cat1, bn, 64, S, 128, 64, cells + 4, hs));
       }
       // the last block's normalisation, the two pointwise layers and the sigmoid in one pass over its raw output (NC_INFER_TAIL=0: separately)
-      static const bool tail = !(getenv("NC_INFER_TAIL") && atoi(getenv("NC_INFER_TAIL")) == 0);
+      static const bool tail = true;
       if (tail) {
         const bool epi9 = epi_stats_on();
         {

@@ -273,13 +273,13 @@ struct SPlan {
 // Below this many tiles the problem does not fill the chip (a workgroup walks its whole reduction alone): the gather GEMM,
 // which splits the reduction over grid.z, serves such small batches (the Apollo step's 1-4 planes per discriminator)
 static long min_tiles() {
-  static const long v = getenv("NC_SCONV_MINTILES") ? atol(getenv("NC_SCONV_MINTILES")) : 192;
+  static const long v = 192;
   return v;
 }
 // LDS per workgroup is capped well below the CU's 160 KB so that two workgroups (of this launch, or of the launches of other
 // discriminators on other streams) can share a CU: one's barrier / staging phase hides under the other's MFMAs
 static long lds_cap() {
-  static const long v = getenv("NC_SCONV_LDS_KB") ? atol(getenv("NC_SCONV_LDS_KB")) * 1024 : 80 * 1024;
+  static const long v = 80 * 1024;
   return v < kLds ? v : kLds;
 }
 struct SCfg { int WM, WN, VB; };
@@ -646,7 +646,7 @@ WPlan plan_swgrad(const ConvDims& d) {
   const int urows = (kWNJ + d.Wo - 1) / d.Wo + 1;
   const int rows = (urows - 1) * s + 2 * 4 + s;
   const int CS = rows * pitch + 16;  // (+16: two channels of an n-tile on different bank groups when rows * pitch is a multiple of 32)
-  static const int only = getenv("NC_SWGRAD_NTW") ? atoi(getenv("NC_SWGRAD_NTW")) : 0;
+  static const int only = 0;
   for (int NTW : {4, 2}) {
     if (only && NTW != only) continue;
     const int NCW = 4 * NTW;
@@ -657,7 +657,7 @@ WPlan plan_swgrad(const ConvDims& d) {
     w.ngroups = d.C / NCW; w.mtiles = d.K / 128;
     const long nst = cdiv((long)d.N * HW, kWNJ);
     const long tiles = (long)w.ngroups * w.mtiles;
-    static const long target = getenv("NC_SWGRAD_TARGET") ? atol(getenv("NC_SWGRAD_TARGET")) : 512;
+    static const long target = 512;
     long splits = cdiv(target, tiles);  // 2 resident workgroups per CU, one round (measured: 512 beats 256 / 1024)
     if (splits > nst) splits = nst;
     if (splits > 256) splits = 256;
@@ -676,7 +676,7 @@ bool sconv_wgrad_supported(const ConvDims& d) {
   if ((long)d.N * d.C * d.H * d.W >= (1L << 30) || (long)d.N * d.K * d.Ho * d.Wo >= (1L << 30)) return false;
   const WPlan w = plan_swgrad(d);
   // worth it once the reduction is long (batched planes); a few planes stay on the gather GEMM
-  static const long mincol = getenv("NC_SWGRAD_MINCOL") ? atol(getenv("NC_SWGRAD_MINCOL")) : 4096;
+  static const long mincol = 4096;
   return w.ok && (long)d.N * d.Ho * d.Wo >= mincol;
 }
 size_t sconv_wgrad_ws_bytes(const ConvDims& d) {

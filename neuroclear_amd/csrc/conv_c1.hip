@@ -361,19 +361,19 @@ int conv_fwd_to1_k3(const float* x, const float* w, float* y, int N, int C, int 
   const int ntx = (W + kT1TX - 1) / kT1TX, nty = (H + kT1TY - 1) / kT1TY;
   // plane ranges: one round of the chip per channel group (measured at 108^3: 256 -> 216 us, 128 -> 264, 512 -> 245), at least 4 planes each (a
   // range reads 2 planes more than it writes)
-  static const int want = getenv("NC_T1_WGS") ? atoi(getenv("NC_T1_WGS")) : 256;
+  static const int want = 256;
   int nz = (int)((want + (long)ntx * nty * N - 1) / ((long)ntx * nty * N));
   if (nz > D / 4) nz = D / 4;
   if (nz < 1) nz = 1;
   const int zc = (D + nz - 1) / nz;
   nz = (D + zc - 1) / zc;
   const dim3 grid((unsigned)(ntx * nty * nz), (unsigned)N);
-  static const bool dma = !(getenv("NC_T1_DMA") && atoi(getenv("NC_T1_DMA")) == 0);
+  static const bool dma = true;
   if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
     const float* zeros = nc_zero_page();
     if (dma && zeros) {
       // channel groups (partial volumes, added in a fixed order): four times the workgroups without reading anything twice -- y has ONE channel
-      static const int gwant = getenv("NC_T1_G") ? atoi(getenv("NC_T1_G")) : 4;
+      static const int gwant = 4;
       int G = gwant;
       const long n4 = (long)N * D * H * W / 4;
       while (G > 1 && (C % (G * kT1CH) || !ws || wsb < (size_t)G * n4 * 16)) G >>= 1;

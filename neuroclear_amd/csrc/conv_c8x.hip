@@ -696,7 +696,7 @@ int conv_c8x(const void* xh, const float* w, const float* bias, float* y, void* 
 #endif
   auto launch = [&](auto kern) -> int {
     if (int e = raise_dyn_lds(kern, kLdsWG, "conv_c8x")) return e;
-    static const int grid = getenv("NC_C8X_GRID") ? atoi(getenv("NC_C8X_GRID")) : 512;  // (timing experiments: 256 = one workgroup per CU)
+    static const int grid = 512;  // (timing experiments: 256 = one workgroup per CU)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreadsC), pl.lds, s, p);
     return check_launch("conv_c8x");
   };

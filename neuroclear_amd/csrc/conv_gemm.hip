@@ -441,8 +441,7 @@ size_t gemm_ws_bytes(const ConvDims& d) {
 // rows of the output tile: 256 / 128 when the GEMM has that many rows and is large enough to fill the chip with such
 // tiles (>= 1.5 / 2 workgroups per CU), else 64
 static int tile_rows(const GemmParams& p) {
-  const char* e = getenv("NC_GEMM_TM");  // A/B switch for timing experiments: cap on the tile rows
-  const int cap = e ? atoi(e) : 256;
+  constexpr int cap = 256;
   const int ncls = p.ptaps ? p.d.sd * p.d.sh * p.d.sw : 1;
   const long cols = cdiv(p.N, 64) * p.splits * ncls;
   if (cap >= 256 && p.M >= 256 && cdiv(p.M, 256) * cols >= 384) return 256;
@@ -453,11 +452,8 @@ template <int MODE>
 static void launch_gemm(const GemmParams& p, unsigned gz, hipStream_t s) {
   const int tm = tile_rows(p);
   dim3 grid((unsigned)cdiv(p.N, 64), (unsigned)cdiv(p.M, tm), gz);
-  static const bool kg1 = getenv("NC_GEMM_KG1") != nullptr;  // A/B switch for timing experiments
-  if (tm == 256 && !kg1) hipLaunchKernelGGL((k_conv_gemm<MODE, 256, 2>), grid, dim3(512), 0, s, p);
-  else if (tm == 256) hipLaunchKernelGGL((k_conv_gemm<MODE, 256, 1>), grid, dim3(256), 0, s, p);
-  else if (tm == 128 && !kg1) hipLaunchKernelGGL((k_conv_gemm<MODE, 128, 2>), grid, dim3(512), 0, s, p);
-  else if (tm == 128) hipLaunchKernelGGL((k_conv_gemm<MODE, 128, 1>), grid, dim3(256), 0, s, p);
+  if (tm == 256) hipLaunchKernelGGL((k_conv_gemm<MODE, 256, 2>), grid, dim3(512), 0, s, p);
+  else if (tm == 128) hipLaunchKernelGGL((k_conv_gemm<MODE, 128, 2>), grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL((k_conv_gemm<MODE, 64, 1>), grid, dim3(256), 0, s, p);
 }
 

@@ -549,7 +549,7 @@ long p2_q(long f, int HoWo, int Wo, int PP, int Wp) {
 P2Plan p2_plan(long npos, int Ho, int Wo, int PP, int Wp, int KT, int tapext, int nsub, int NT = 3) {
   P2Plan best{};
   double best_cost = 1e30;
-  static const int ncb_max = getenv("NC_P2D_NCB") ? atoi(getenv("NC_P2D_NCB")) : 8;
+  static const int ncb_max = 8;
   for (int NCB : {8, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
     const int PT = 64 * NCB;
@@ -663,7 +663,7 @@ bool p2_shape(const ConvDims& d, int dgrad) {
   if (!(on & (d.sh == 1 ? 1 : 2))) return false;
   const P2Geom g = p2_geom(d, dgrad);
   if (g.Kout % 64 || g.Cin % (g.kind == 0 ? 64 : 16) || g.NS < 8 || (g.NS & 1)) return false;
-  static const long minpos = getenv("NC_P2D_MIN") ? atol(getenv("NC_P2D_MIN")) : 8192;
+  static const long minpos = 8192;
   if ((long)g.B * g.Ho * g.Wo < (g.kind == 2 ? minpos / 2 : minpos)) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
   if (3 * g.nsub * g.TOT * 16 >= (1l << 31) || (long)d.N * d.K * d.Ho * d.Wo * 4 >= (1l << 31) || (long)d.N * d.C * d.H * d.W * 4 >= (1l << 31)) return false;
   return p2_plan((long)g.B * g.Ho * g.Wo, g.Ho, g.Wo, g.PP, g.Wp, g.Kout / 64, g.tapext, g.nsub).ok;
@@ -698,7 +698,7 @@ int run_p2d(const float* in, const float* w, const float* bias, float* out, cons
   const long total = (long)(p2_packed_bytes(g.NS, g.Kout, NT) / 2);
   // forward: w[co][ci][tap]; data gradients: w[co as ci][ci as co][..] (ConvDims: weights are [d.K][d.C][4][4])
   const long so = dgrad ? 16 : (long)d.C * 16, si = dgrad ? (long)d.C * 16 : 16;
-  static const int flush = getenv("NC_P2D_FLUSH") ? atoi(getenv("NC_P2D_FLUSH")) : 4;
+  static const int flush = 4;
   const int nclass = g.kind == 2 ? 4 : 1;
   for (int cls = 0; cls < nclass; ++cls) {
     const int ry = cls >> 1, rx = cls & 1;

@@ -840,7 +840,7 @@ XPlan x_plan(int N, int D, int H, int W, int KT, int KS, int NT = 3, bool k32 = 
   double best_cost = 1e30;
   const int P = pc ? W : W + KS - 1;
   const long HP = (long)H * P;
-  static const int ncb_max = getenv("NC_S3X_NCB") ? atoi(getenv("NC_S3X_NCB")) : 8;
+  static const int ncb_max = 8;
   for (int NCB : {8, 7, 6, 4, 2}) {
     if (NCB > ncb_max) continue;
     if (k32 && NCB != 4 && NCB != 2) continue;  // (32-channel tiles: the instantiated shapes; a tile is 128 NCB positions)

@@ -563,7 +563,7 @@ int run_s3(const float* x, const void* xs_pre, const float* w, const float* bias
   p.npb = pl.npb;
   p.ntiles = (long)d.N * d.D * pl.TPP * p.KT;
   p.tiles_per_xcd = (int)cdiv(p.ntiles, 8);
-  static const int flush = getenv("NC_SPLIT_FLUSH") ? atoi(getenv("NC_SPLIT_FLUSH")) : 1;
+  static const int flush = 1;
   p.flush = flush;
   if (KS == 3) return pl.VB == 2 ? launch_s3<3, 2>(p, pl.lds, s) : launch_s3<3, 1>(p, pl.lds, s);
   return pl.VB == 2 ? launch_s3<5, 2>(p, pl.lds, s) : launch_s3<5, 1>(p, pl.lds, s);
@@ -1222,12 +1222,12 @@ bool ws_shape_ok(const ConvDims& d) {
 }
 
 int ws_flush_steps() {
-  static const int f = getenv("NC_SPLIT_WFLUSH") ? atoi(getenv("NC_SPLIT_WFLUSH")) : 64;
+  static const int f = 64;
   return f > 0 ? f : 1 << 30;
 }
 // two-term operands: three MFMA roundings of an accumulator per k-step instead of six -- twice the steps give the same number per partial sum
 int ws_flush_steps2() {
-  static const int f = getenv("NC_SPLIT_WFLUSH2") ? atoi(getenv("NC_SPLIT_WFLUSH2")) : 128;
+  static const int f = 128;
   return f > 0 ? f : 1 << 30;
 }
 int ws_nf(long steps, int nwp, int F = 0) {  // partial slots per workgroup: ceil(most steps of a workgroup / F)

@@ -271,7 +271,7 @@ static int convT_check(const char* what, int N, int C, int D, int H, int W, int 
 namespace nc {
 // Can the transposed convolution write the S3 form of its output itself (convT_fwd_s3)?  Only the matrix-core kernel does.
 bool convT_fwd_s3_supported(int N, int C, int D, int H, int W, int K) {
-  static const bool mfma_on = !(getenv("NC_CONVT_MFMA") && atoi(getenv("NC_CONVT_MFMA")) == 0);
+  static const bool mfma_on = true;
   const long S = (long)D * H * W;
   return mfma_on && !g_force_direct && K % 32 == 0 && C == 128 && (long)N * K * 8 * S < (1L << 40);
 }
@@ -298,7 +298,7 @@ static int nc::convT_fwd_impl(const float* x, const float* w, const float* bias,
   if (int e = convT_check("convT_fwd", N, C, D, H, W, K)) return e;
   const long S = (long)D * H * W;
   hipStream_t s = (hipStream_t)stream;
-  static const bool mfma_on = !(getenv("NC_CONVT_MFMA") && atoi(getenv("NC_CONVT_MFMA")) == 0);  // A/B switch
+  static const bool mfma_on = true;  // A/B switch
   // (measured: 128 -> 64 at 70^3 0.77 -> 0.55 ms, at 54^3 0.34 -> 0.28; 256 -> 128 at 35^3 0.30 -> 0.36: the VALU kernel keeps it)
   if (mfma_on && !g_force_direct && K % 32 == 0 && C == 128 && (long)N * K * 8 * S < (1L << 40)) {
     long gx = cdiv(cdiv(S, 32) * N, 4);

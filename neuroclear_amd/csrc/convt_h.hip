@@ -514,10 +514,10 @@ int convT_wgrad_h(const void* x, const void* dy, int dctot, int dc0, float* dw, 
   p.x = (const unsigned short*)x; p.dy = (const unsigned short*)dy; p.part = part;
   p.N = N; p.C = C; p.K = K; p.Dc = D; p.Hc = H; p.Wc = W; p.dctot8 = dctot / 8; p.dc08 = dc0 / 8; p.splits = splits;
   p.Sc = (long)D * H * W;
-  static const bool shared_dy = !(getenv("NC_CONVT_WGRAD_SHARED") && atoi(getenv("NC_CONVT_WGRAD_SHARED")) == 0);  // A/B switch
+  static const bool shared_dy = true;  // A/B switch
   const int NW = C / 32;
   if (shared_dy && (NW == 1 || NW == 2 || NW == 4 || NW == 8)) {
-    static const int vs = getenv("NC_CONVT_WGRAD_VS") ? atoi(getenv("NC_CONVT_WGRAD_VS")) : 1;  // (2 = 32 voxels per barrier: measured 40 % slower)
+    static const int vs = 1;  // (2 = 32 voxels per barrier: measured 40 % slower)
     if (vs == 2) {
       const size_t lds = (size_t)(NW * 4 * 36 + 2 * 8 * 4 * 36) * 16;
       hipLaunchKernelGGL((k_convT_wgrad_h2<NC_DT_BF16, 2>), dim3(K / 32, splits), dim3(64 * NW), lds, s, p);

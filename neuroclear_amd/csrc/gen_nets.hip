@@ -317,7 +317,7 @@ int nc_unet_deconv_bwd(const float* params, const float* x, const float* y, cons
   const int *d0 = p.d[0], *d1 = p.d[1], *d2 = p.d[2];
   const unsigned kept_mask = kept;
   static const bool fuse_bwd = !(getenv("NC_S3_TRAIN_FUSE") && atoi(getenv("NC_S3_TRAIN_FUSE")) == 0) &&
-                               !(getenv("NC_S3_TRAIN_FUSE_BWD") && atoi(getenv("NC_S3_TRAIN_FUSE_BWD")) == 0);
+                               true;
   // backward of block i: g = gradient at the block's (post-ReLU) output, dense [N][K][S]; `in` = the block's input.
   // draw <- InstanceNorm/ReLU backward (+ the conv's bias gradient); dW <- wgrad; gin (nullable) <- dgrad
   auto block_bwd = [&](int i, const float* g, const float* in, float* draw, float* gin) -> int {

@@ -338,7 +338,7 @@ struct QPlan {
 int pad_4mod8(int v) { return v + ((4 - (v & 7)) & 7); }  // sub-block stride that keeps the transposed reads conflict-free
 
 int q_flush_steps() {
-  static const int f = getenv("NC_P2D_WFLUSH") ? atoi(getenv("NC_P2D_WFLUSH")) : 128;
+  static const int f = 128;
   return f > 0 ? f : 1 << 30;
 }
 
@@ -383,7 +383,7 @@ bool q_shape(const ConvDims& d) {
   if (!(on & 4)) return false;
   if (d.D != 1 || d.kd != 1 || d.kh != 4 || d.kw != 4 || d.sh != 1 || d.sw != 1 || d.ph != 1 || d.pw != 1) return false;
   if (d.C % 32 || d.K % 64 || (d.K / 64) * (d.C / 32) > 256) return false;
-  static const long minpos = getenv("NC_P2D_MIN") ? atol(getenv("NC_P2D_MIN")) : 8192;
+  static const long minpos = 8192;
   if ((long)d.N * d.Ho * d.Wo < minpos) return false;  // small batches (Apollo's 1-4 planes per discriminator) stay where they are
   const QPlan pl = q_plan(d);
   if (!pl.ok) return false;

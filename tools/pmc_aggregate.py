@@ -21,6 +21,14 @@ def kernel_class(name):
         return 'wgrad_mfma_k3'
     if 'k_wgrad_mfma<5' in name or 'k_wgrad_dma<5' in name:
         return 'wgrad_mfma_k5'
+    if 'k_conv_s3x<7' in name:  # round 6: Conv3d(1, 64, 7) in pseudo-channel form (last template argument: 1 forward, 2 data gradient)
+        return 'conv_c1k7_fwd' if name.split('>')[0].rstrip().endswith('1') else 'conv_c1k7_dgrad'
+    if 'k_conv_s3x<5, 4, 2, false, true' in name or 'k_conv_s3x<5, 2, 2, false, true' in name:
+        return 'conv_split_k5_k32'   # the 32-output-channel tile (deep_linear_gen's forward without act1)
+    if 'k_wgrad_c1<7' in name:
+        return 'wgrad_c1_k7'
+    if 'k_fold_c1k7' in name:
+        return 'fold_c1k7'
     for kern, cls in (('k_conv_s3x<3, 8', 'conv_split_k3'), ('k_conv_s3x<3, 7', 'conv_split_k3'), ('k_conv_s3x<5, 7', 'conv_split_k5'), ('k_conv_s3x<3, 6', 'conv_split_k3_small'), ('k_conv_s3x<3, 4', 'conv_split_k3_small'),
                       ('k_conv_s3x<3, 2', 'conv_split_k3_tail'), ('k_conv_s3x<5, 8', 'conv_split_k5'), ('k_conv_s3x<5', 'conv_split_k5_tail'),
                       ('k_conv_s3<3', 'conv_split_k3'), ('k_conv_s3<5', 'conv_split_k5'), ('k_wgrad_s3x<3', 'wgrad_split_k3'),
