@@ -713,6 +713,7 @@ def main():
             import copy
             a4 = copy.copy(args)
             a4.steps, a4.warmup, a4.no_prof = 3, 1, True
+            prev_mode = int(_lib().nc_get_dl_collapse())  # (2: the position-typed 7^3 form of round 6; 1: the collapsed tail + rank forms of round 5)
             _lib().nc_set_dl_collapse(0)
             try:
                 dt4, units4, _, cfg4 = run_train(a4, rank, world, dev)
@@ -721,7 +722,7 @@ def main():
                                                                  first_step_losses=f4,
                                                                  first_step_max_rel_diff=max(abs(f1[k] - f4[k]) / max(abs(f4[k]), 1e-12) for k in f4))
             finally:
-                _lib().nc_set_dl_collapse(1)
+                _lib().nc_set_dl_collapse(prev_mode)
     # CPU legs: rank 0 only, at every N (the other ranks have nothing to add to a host-core figure), and AFTER the last GPU leg and the
     # process group are done with -- no rank sits in an RCCL call while rank 0 spends a minute on its host cores
     cpu = rank == 0 and not args.no_cpu_baseline

@@ -401,6 +401,7 @@ int nc_conv_bwd(const float* x, const float* dy, const float* w, float* dx, floa
   if (int e = conv_args("conv_bwd", d, x, dy, dw, N, C, D, H, W, K, kd, kh, kw, stride, pad)) return e;
   if (!w) { set_error("conv_bwd: null pointer"); return NC_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
+  SwitchScope switches_;  // the three phases below see ONE value of every arithmetic switch
   if (dx && dgrad_path(d) == 9 && wgrad_path(d) == 9 && ws && s3_bwd_ws_bytes(d) && ws_bytes >= s3_bwd_ws_bytes(d)) {
     {
       ProfScope ps(1, 9, d, 0, s);

@@ -201,6 +201,15 @@ struct ForceThreeTerm { ForceThreeTerm(); ~ForceThreeTerm(); };
 // RAII mark of a whole-network call (gen_nets.hip, api.hip): inside one, guard mode 1 COUNTS a flagged measured tensor instead of launching the
 // three-term kernels beside the two-term ones (h2_guard_can_flip) -- ~65 near-empty launches per training step otherwise
 struct NetworkScope { NetworkScope(); ~NetworkScope(); };
+// RAII: the process-wide arithmetic switches (nc_set_split_terms, nc_set_h2_guard) as THIS call sees them -- sampled once when the outermost scope
+// of the thread opens, so that the phases of one call (conversion / data gradient / weight gradient of conv_bwd_s3, the layers of a whole-network
+// call) cannot be desynchronised by another thread moving a switch in between.  NetworkScope opens one; the per-layer entry points
+// with more than one phase open their own.
+struct SwitchScope { SwitchScope(); ~SwitchScope(); };
+// RAII: this thread sees nc_set_split_terms(2) while it lives (kernels that exist in the two-term form only and convert their fp32 operands themselves)
+struct ForceTwoTerm { ForceTwoTerm(); ~ForceTwoTerm(); int prev_terms, prev_depth; };
+int frozen_terms();  // -1: no scope open on this thread
+int frozen_guard();
 bool h2_guard_can_flip();  // mode 2, or mode 1 outside a whole-network call
 int operand_into(const ConvDims& d, const float* x, long xstride, void* xs, int N, int C, long S, int ctot, int c0, hipStream_t s);
 int act_operand(const ConvDims& d, const float* x, const float* mean, const float* rstd, float slope, float* y, long ystride, void* ys, int N, int C,
@@ -241,6 +250,15 @@ bool c1k7_h2_supported(const ConvDims& d);
 size_t c1k7_h2_ws_bytes(const ConvDims& d);
 int conv_c1k7_h2(const float* x, const float* w, const float* bias, float* y, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 size_t c1k7_h2_dgrad_ws_bytes(const ConvDims& d);
+// dl_typed.hip: deep_linear_gen's layers 1 .. 5 as one position-typed 7^3 kernel (the boundary voxels' kernels and the weight-space steps)
+bool dl_typed_supported(int N, int D, int H, int W);
+size_t dl_typed_bytes(int N, int D, int H, int W);
+const float* dl_typed_wp(const char* scratch, int N, int D, int H, int W);
+float* dl_typed_dwsw(char* scratch, int N, int D, int H, int W);
+int dl_typed_compose(const float* F, char* scratch, int N, int D, int H, int W, hipStream_t s);
+int dl_typed_fwd_boundary(const float* act0, float* y, char* scratch, int N, int D, int H, int W, hipStream_t s);
+int dl_typed_dgrad_boundary(const float* act0, const float* dy, float* g, char* scratch, int N, int D, int H, int W, hipStream_t s);
+int dl_typed_p(const float* act0, const float* dy, float* Pq, char* scratch, int N, int D, int H, int W, hipStream_t s);
 int conv_c1k7_h2_dgrad(const float* dy, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 // h2.hip: the H2 operand form (two fp16 terms of the tensor times a power of two taken from a cell)
 // an H2 tensor of `elems` elements = elems * 4 bytes of units + (at this byte offset) 256 bytes of cells: [0] the cell of the channels' first

@@ -988,7 +988,7 @@ size_t s3x_packed_bytes(int Cin, int Kout, int KS, int NT) {
 // inference forward nc_unet_deconv_fwd only.  The explicit S3 entry points (nc_conv_*_split, nc_to_s3) are three-term by definition.
 static std::atomic<int> g_terms{getenv("NC_SPLIT_TERMS") ? atoi(getenv("NC_SPLIT_TERMS")) : 2};
 void s3x_set_terms(int t) { g_terms = (t == 0 || t == 3) ? t : 2; }
-int s3x_get_terms() { return g_terms; }
+int s3x_get_terms() { const int f = frozen_terms(); return f >= 0 ? f : g_terms.load(); }  // (inside a call: the value sampled when the call began)
 
 bool s3x_k32_supported(int N, int D, int H, int W) { return x_plan(N, D, H, W, 1, 5, 2, true).ok && (long)32 * D * H * W * 4 < (1l << 31); }
 bool s3x_supported(int N, int Cin, int D, int H, int W, int Kout, int KS) {

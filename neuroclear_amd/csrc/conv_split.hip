@@ -1601,8 +1601,19 @@ int act_operand(const ConvDims& d, const float* x, const float* mean, const floa
 }
 bool conv_layer_h2(const ConvDims& d) { return s3_layer_h2(d); }
 static thread_local int tl_net_depth = 0;
-NetworkScope::NetworkScope() { ++tl_net_depth; }
-NetworkScope::~NetworkScope() { --tl_net_depth; }
+static thread_local int tl_sw_depth = 0, tl_sw_terms = -1, tl_sw_guard = -1;
+SwitchScope::SwitchScope() {
+  if (tl_sw_depth++ == 0) { tl_sw_terms = s3x_get_terms(); tl_sw_guard = h2_guard_mode(); }
+}
+SwitchScope::~SwitchScope() {
+  if (--tl_sw_depth == 0) { tl_sw_terms = -1; tl_sw_guard = -1; }
+}
+ForceTwoTerm::ForceTwoTerm() : prev_terms(tl_sw_terms), prev_depth(tl_sw_depth) { tl_sw_terms = 2; ++tl_sw_depth; }
+ForceTwoTerm::~ForceTwoTerm() { tl_sw_terms = prev_terms; --tl_sw_depth; if (tl_sw_depth == 0) { tl_sw_terms = -1; tl_sw_guard = -1; } }
+int frozen_terms() { return tl_sw_terms; }
+int frozen_guard() { return tl_sw_guard; }
+NetworkScope::NetworkScope() { ++tl_net_depth; if (tl_sw_depth++ == 0) { tl_sw_terms = s3x_get_terms(); tl_sw_guard = h2_guard_mode(); } }
+NetworkScope::~NetworkScope() { --tl_net_depth; if (--tl_sw_depth == 0) { tl_sw_terms = -1; tl_sw_guard = -1; } }
 bool h2_guard_can_flip() { return h2_guard_mode() == 2 || (h2_guard_mode() == 1 && tl_net_depth == 0); }
 ForceThreeTerm::ForceThreeTerm() { ++tl_force3; }
 ForceThreeTerm::~ForceThreeTerm() { --tl_force3; }

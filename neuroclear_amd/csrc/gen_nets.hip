@@ -519,7 +519,8 @@ __global__ void __launch_bounds__(128) k_dl_w1_contract(const float* __restrict_
   dw1[((long)k * 64 + c) * 125 + t] = (float)v;
 }
 constexpr unsigned kKeptCollapsed = 1u << 31;
-constexpr unsigned kKeptNoAct1 = 1u << 30;  // ... and layer 1 ran in its 64 -> 27 form: act1 was never written ("the forward without act1")
+constexpr unsigned kKeptNoAct1 = 1u << 30;
+constexpr unsigned kKeptTyped = 1u << 29;  // ... layers 1 .. 5 ran as ONE position-typed 7^3 kernel (dl_typed.hip): neither act1 nor a two-term copy of act0 exists  // ... and layer 1 ran in its 64 -> 27 form: act1 was never written ("the forward without act1")
 
 // (8 workgroups, each derives a and e for itself and 216 of E's 1728 entries; loops unrolled so that the loads of a sum are in flight together)
 __global__ void __launch_bounds__(256) k_dl_compose(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ w4,
@@ -597,7 +598,9 @@ __global__ void __launch_bounds__(256) k_dl_tail_w345(const float* __restrict__ 
   }
 }
 
-std::atomic<int> g_dl_collapse{getenv("NC_DL_COLLAPSE") ? (atoi(getenv("NC_DL_COLLAPSE")) != 0) : 1};
+// 0: layer by layer; 1: the collapsed tail + the rank forms of the 5^3 layer (round 5); 2 (default): layers 1 .. 5 as one position-typed 7^3 kernel
+// where the shape admits it (dl_typed.hip), else as 1
+std::atomic<int> g_dl_collapse{getenv("NC_DL_COLLAPSE") ? (atoi(getenv("NC_DL_COLLAPSE")) < 0 ? 0 : atoi(getenv("NC_DL_COLLAPSE")) > 2 ? 2 : atoi(getenv("NC_DL_COLLAPSE"))) : 2};
 
 }  // namespace
 
@@ -692,10 +695,10 @@ size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2) {
 
 size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2) {
   LPlan p;
-  return l_plan(p, N, S0, S1, S2) ? align256(p.conv_ws) + p.grads * sizeof(float) + 256 + LTail::bytes : 0;
+  return l_plan(p, N, S0, S1, S2) ? align256(p.conv_ws) + p.grads * sizeof(float) + 256 + align256(LTail::bytes) + dl_typed_bytes(N, S0, S1, S2) : 0;
 }
 
-void nc_set_dl_collapse(int on) { g_dl_collapse.store(on != 0, std::memory_order_relaxed); }
+void nc_set_dl_collapse(int on) { g_dl_collapse.store(on < 0 ? 0 : on > 2 ? 2 : on, std::memory_order_relaxed); }
 int nc_get_dl_collapse(void) { return g_dl_collapse.load(std::memory_order_relaxed); }
 
 // saved == NULL: inference -- the intermediate activations ping-pong through the workspace instead
@@ -715,8 +718,25 @@ int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* sav
   char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
   hipStream_t hs = (hipStream_t)stream;
   static const bool k32_on = !(getenv("NC_DL_K32") && atoi(getenv("NC_DL_K32")) == 0);
+  char* typed = tail + align256(LTail::bytes);
+  ConvDims d0;
+  // layers 1 .. 5 as ONE position-typed 7^3 convolution 64 -> 1 of act0 (dl_typed.hip): the interior kernel on the two-term
+  // pseudo-channel kernel of Conv3d(1, 64, 7)'s data gradient, the voxels on a face recomputed with their own kernels
+  const bool typed_ok = g_dl_collapse.load(std::memory_order_relaxed) == 2 && saved && dl_typed_supported(N, S0, S1, S2) && make_dims(d0, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3) && c1k7_h2_supported(d0) &&
+                        c1_wgrad_supported(d0) && c1k7_h2_dgrad_ws_bytes(d0) <= p.conv_ws && c1k7_h2_ws_bytes(d0) <= p.conv_ws &&
+                        c1_wgrad_ws_bytes(d0) <= p.conv_ws;
   for (int i = 0; i < 6; ++i) {
     ConvDims dk;
+    if (typed_ok && i == 1) {
+      hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
+      hipLaunchKernelGGL(k_dl_fold_fwd, dim3(32, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), params + p.w[1], (float*)(tail + LTail::Wf));
+      NC_TRY(check_launch("deep_linear_fwd: composed kernels"));
+      NC_TRY(dl_typed_compose((const float*)(tail + LTail::Wf), typed, N, S0, S1, S2, hs));
+      NC_TRY(conv_c1k7_h2_dgrad(in, dl_typed_wp(typed, N, S0, S1, S2), y, d0, cws, p.conv_ws, hs));
+      NC_TRY(dl_typed_fwd_boundary(in, y, typed, N, S0, S1, S2, hs));
+      kept_mask |= kKeptCollapsed | kKeptNoAct1 | kKeptTyped;
+      break;
+    }
     if (collapse && i == 1 && saved && k32_on && make_dims(dk, N, 64, S0, S1, S2, 32, 5, 5, 5, 1, 2) && conv_fwd_h2_k32_supported(dk) &&
         (size_t)256 + s3x_packed_bytes(64, 32, 5, 2) + 512 <= p.conv_ws) {
       // layers 1 .. 5 without act1 ("the forward without act1" above): Z = the 64 -> 27 convolution of act0, y = its shifted sum
@@ -778,7 +798,40 @@ int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, 
                       wgrad_h2_supported(dsh) && s3_wgrad_ws_bytes(dsh) <= p.conv_ws;
   const bool rank_dgrad = rank_w && rank_dg_on && conv_fwd_h2_c32_supported(dsh) && conv_fwd_h2_c32_ws_bytes(dsh) <= p.conv_ws;
   const bool rank_all = rank_dgrad;
-  if (kept_mask & kKeptCollapsed) {  // the forward left no act2 .. act4: layers 2 .. 5 from dy, act1 and the weights alone
+  if (kept_mask & kKeptTyped) {  // layers 1 .. 5 ran as one position-typed 7^3 kernel (dl_typed.hip): their whole backward from dy, act0 and the weights
+    hipStream_t hs = (hipStream_t)stream;
+    char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
+    char* typed = tail + align256(LTail::bytes);
+    ConvDims d0;
+    // (its kernels exist in the two-term form only and convert their fp32 operands themselves: a caller who moved nc_set_split_terms after the
+    // forward still gets this form's backward)
+    ForceTwoTerm two_;
+    if (!dl_typed_supported(N, S0, S1, S2) || !make_dims(d0, N, 1, S0, S1, S2, 64, 7, 7, 7, 1, 3) || !c1k7_h2_supported(d0) || !c1_wgrad_supported(d0)) {
+      set_error("deep_linear_bwd: the forward ran the position-typed form, which this shape does not admit");
+      return NC_ERR_ARG;
+    }
+    const float* act0 = saved + p.act[0];
+    hipLaunchKernelGGL(k_dl_compose, dim3(8), dim3(256), 0, hs, params + p.w[2], params + p.w[3], params + p.w[4], params + p.w[5], tail);
+    hipLaunchKernelGGL(k_dl_fold_fwd, dim3(32, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), params + p.w[1], (float*)(tail + LTail::Wf));
+    NC_TRY(check_launch("deep_linear_bwd: composed kernels"));
+    NC_TRY(dl_typed_compose((const float*)(tail + LTail::Wf), typed, N, S0, S1, S2, hs));
+    // dL/dact0: the 1 -> 64 convolution of dy with the interior kernel (the pseudo-channel forward kernel), then the boundary voxels' differences
+    float* g0 = G + p.g[1];
+    NC_TRY(conv_c1k7_h2(dy, dl_typed_wp(typed, N, S0, S1, S2), nullptr, g0, d0, cws, p.conv_ws, hs));
+    NC_TRY(dl_typed_dgrad_boundary(act0, dy, g0, typed, N, S0, S1, S2, hs));
+    // every parameter gradient through dH: the full correlation of dy and act0 (the one-channel 7^3 weight gradient with the operands' roles swapped)
+    // and the boundary types' sums -> P, then weight space as in the rank forms
+    NC_TRY(conv_wgrad_c1(dy, act0, dl_typed_dwsw(typed, N, S0, S1, S2), d0, cws, p.conv_ws, hs));
+    NC_TRY(dl_typed_p(act0, dy, (float*)(tail + LTail::P), typed, N, S0, S1, S2, hs));
+    hipLaunchKernelGGL(k_dl_q_from_p, dim3(64, 27), dim3(256), 0, hs, params + p.w[1], (const float*)(tail + LTail::P), (float*)(tail + LTail::q));
+    hipLaunchKernelGGL(k_dl_w1_contract, dim3(64, 64), dim3(128), 0, hs, (const float*)(tail + LTail::E), (const float*)(tail + LTail::P), dparams + p.w[1]);
+    hipLaunchKernelGGL(k_dl_tail_w2, dim3(64), dim3(256), 0, hs, params + p.w[2], tail, dparams + p.w[2]);
+    hipLaunchKernelGGL(k_dl_tail_w345, dim3(1), dim3(256), 0, hs, params + p.w[3], params + p.w[4], params + p.w[5], (const char*)tail, dparams + p.w[3],
+                       dparams + p.w[4], dparams + p.w[5]);
+    NC_TRY(check_launch("deep_linear_bwd: typed parameter gradients"));
+    g = g0;
+    top = 0;
+  } else if (kept_mask & kKeptCollapsed) {  // the forward left no act2 .. act4: layers 2 .. 5 from dy, act1 and the weights alone
     hipStream_t hs = (hipStream_t)stream;
     char* tail = (char*)ws + align256(p.conv_ws) + p.grads * sizeof(float) + 256;
     const float* act1 = saved + p.act[1];  // (kKeptNoAct1: not there)

@@ -336,8 +336,8 @@ int split2h_into(const float* x, long xstride, void* xs, int N, int C, long S, i
 
 // ---- the range guard (common.hpp) -----------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_guard{getenv("NC_H2_GUARD") ? atoi(getenv("NC_H2_GUARD")) : 1};
-bool h2_guard_on() { return g_guard != 0; }
-int h2_guard_mode() { return g_guard; }
+int h2_guard_mode() { const int f = frozen_guard(); return f >= 0 ? f : g_guard.load(); }  // (inside a call: the value sampled when the call began)
+bool h2_guard_on() { return h2_guard_mode() != 0; }
 namespace { unsigned long long* guard_stats_dev(); }
 // (the pinned counter block is allocated HERE, off the launch path -- a first allocation inside h2_guard_decide could land in a stream capture
 // and invalidate it -- and portable, so that every device of the process sees it)

@@ -97,3 +97,103 @@ def test_composing_layers_0_and_1_is_not_exact_at_the_faces():
         d = (comp - a1).abs()[0].amax(0)
         assert float(d[2:-2, 2:-2, 2:-2].max()) < 1e-11
         assert float(d.max()) > 1e-3
+
+
+def _types(D, H, Wd):
+    """Per voxel, per axis: 0 on the low face, 2 on the high face, 1 inside (extents >= 2)."""
+    def ax(L):
+        t = torch.ones(L, dtype=torch.long)
+        t[0], t[L - 1] = 0, 2
+        return t
+    tz, ty, tx = ax(D), ax(H), ax(Wd)
+    return (tz[:, None, None] * 9 + ty[None, :, None] * 3 + tx[None, None, :]).expand(D, H, Wd)   # type index 0 .. 26, 13 = interior
+
+
+def _allowed(tau):
+    """Taps t of the 3^3 kernel that stay inside the volume at a voxel of type tau: per axis, a low-face voxel cannot use t = 0, a high-face one t = 2."""
+    m = torch.ones(3, 3, 3, dtype=torch.float64)
+    for axis, ta in enumerate((tau // 9, (tau // 3) % 3, tau % 3)):
+        if ta == 0:
+            m.index_fill_(axis, torch.tensor([0]), 0.0)
+        if ta == 2:
+            m.index_fill_(axis, torch.tensor([2]), 0.0)
+    return m
+
+
+def test_layers_1_to_5_as_one_position_typed_7x7x7_kernel():
+    """Round 6: layers 1 .. 5 -- the 5^3 64 -> 64 layer AND the collapsed tail -- are ONE 64 -> 1 convolution of act0 with a 7^3
+    kernel that depends only on the voxel's POSITION TYPE (27 types: per axis low face / inside / high face): H_tau = sum over the taps t the
+    type allows of E[., t] composed with W1.  The 3^3 kernel E reaches one voxel, so the zero padding of act1 only matters ON the faces, and
+    there it just removes the taps that point outside: exact everywhere (faces, edges, corners), and the 64 x 64 x 125 products per voxel of the
+    5^3 layer become 64 x 343.  Backward: dL/dact0 = sum_v dy[v] H_tau(v) shifted; every parameter gradient passes through
+    dH_tau[c][d] = sum over the voxels of type tau of dy[v] act0[c][v + d - 3] and weight-space contractions."""
+    torch.manual_seed(1)
+    D, H, Wd = 5, 6, 7
+    W = _weights(5)
+    x = torch.randn(1, 1, D, H, Wd, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(1, 1, D, H, Wd, dtype=torch.float64)
+    y, a0, a1 = _chain(x, W)
+    a0.retain_grad()
+    a1.retain_grad()
+    (y * dy).sum().backward()
+    with torch.no_grad():
+        w1, w2, w3, w4, w5 = W[1], W[2], W[3][:, :, 0, 0, 0], W[4][:, :, 0, 0, 0], W[5][:, :, 0, 0, 0]
+        e = (w5 @ w4) @ w3
+        E = torch.einsum('k,kcdhw->cdhw', e[0], w2)                                           # [64 c'][3][3][3]
+        typ = _types(D, H, Wd)
+
+        def compose(Em):  # H[c][d] = sum_{c', t, s: t + s = d} Em[c'][t] W1[c'][c][s]: a full 3-D convolution of the two kernels per (c', c)
+            Hk = torch.zeros(64, 7, 7, 7, dtype=torch.float64)
+            for tz in range(3):
+                for ty in range(3):
+                    for tx in range(3):
+                        Hk[:, tz:tz + 5, ty:ty + 5, tx:tx + 5] += torch.einsum('k,kcdhw->cdhw', Em[:, tz, ty, tx], w1)
+            return Hk
+        Hs = torch.stack([compose(E * _allowed(tau)[None]) for tau in range(27)])              # [27][64][7][7][7]
+        a0p = F.pad(a0[0], (3, 3, 3, 3, 3, 3))
+        # forward: the interior kernel everywhere (ONE convolution), the boundary voxels recomputed with their own type's kernel
+        y13 = F.conv3d(a0, Hs[13][None], padding=3)[0, 0]
+        yt = y13.clone()
+        for z in range(D):
+            for yy in range(H):
+                for xx in range(Wd):
+                    tau = int(typ[z, yy, xx])
+                    if tau != 13:
+                        yt[z, yy, xx] = (Hs[tau] * a0p[:, z:z + 7, yy:yy + 7, xx:xx + 7]).sum()
+        assert torch.allclose(yt[None, None], y, rtol=0, atol=1e-11)
+        interior = typ == 13
+        assert torch.allclose(y13[interior], y[0, 0][interior], rtol=0, atol=1e-11) and not torch.allclose(y13, y[0, 0], rtol=0, atol=1e-6)
+        # dL/dact0 = the 1 -> 64 convolution of dy with the flipped interior kernel + the boundary voxels' difference kernels scattered
+        g0 = F.conv3d(dy, Hs[13].flip(1, 2, 3)[:, None], padding=3)[0]
+        g0p = F.pad(torch.zeros_like(g0), (3, 3, 3, 3, 3, 3))
+        for z in range(D):
+            for yy in range(H):
+                for xx in range(Wd):
+                    tau = int(typ[z, yy, xx])
+                    if tau != 13:
+                        g0p[:, z:z + 7, yy:yy + 7, xx:xx + 7] += dy[0, 0, z, yy, xx] * (Hs[tau] - Hs[13])
+        g0 = g0 + g0p[:, 3:3 + D, 3:3 + H, 3:3 + Wd]
+        assert torch.allclose(g0[None], a0.grad, rtol=0, atol=1e-11)
+        # parameter gradients: dH_tau, then weight space
+        dH = torch.zeros(27, 64, 7, 7, 7, dtype=torch.float64)
+        for z in range(D):
+            for yy in range(H):
+                for xx in range(Wd):
+                    dH[int(typ[z, yy, xx])] += dy[0, 0, z, yy, xx] * a0p[:, z:z + 7, yy:yy + 7, xx:xx + 7]
+        q = torch.zeros(64, 3, 3, 3, dtype=torch.float64)
+        dw1 = torch.zeros_like(w1)
+        for tau in range(27):
+            al = _allowed(tau)
+            for tz in range(3):
+                for ty in range(3):
+                    for tx in range(3):
+                        if al[tz, ty, tx] == 0:
+                            continue
+                        sl = dH[tau][:, tz:tz + 5, ty:ty + 5, tx:tx + 5]                       # [c][s]
+                        q[:, tz, ty, tx] += torch.einsum('cdhw,kcdhw->k', sl, w1)
+                        dw1 += torch.einsum('k,cdhw->kcdhw', E[:, tz, ty, tx], sl)
+        assert torch.allclose(dw1, W[1].grad, rtol=0, atol=1e-11)
+        a1p = F.pad(a1[0], (1, 1, 1, 1, 1, 1))
+        q_ref = torch.stack([torch.stack([torch.stack([(a1p[:, tz:tz + D, ty:ty + H, tx:tx + Wd] * dy[0]).sum((1, 2, 3)) for tx in range(3)], -1)
+                                          for ty in range(3)], -2) for tz in range(3)], -3)
+        assert torch.allclose(q, q_ref, rtol=0, atol=1e-11)   # (dW2 .. dW5 follow from q as in the test above)

@@ -608,7 +608,7 @@ def test_patchgan_whole_net_entry_matches_op_by_op(dim, shape, nl, monkeypatch):
 @pytest.mark.parametrize('want_dx', [False, True])
 @pytest.mark.parametrize('terms', [3, 2])
 def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, terms):
-    """nc_set_dl_collapse(1) (default): layers 2 .. 5 of deep_linear_gen (reference networks.py:902-911: Conv3d 3^3 64 -> 64, then 1 x 1
+    """nc_set_dl_collapse(1): layers 2 .. 5 of deep_linear_gen (reference networks.py:902-911: Conv3d 3^3 64 -> 64, then 1 x 1
     64 -> 32 -> 16 -> 1, no bias, nothing in between) as ONE 64 -> 1 convolution forward, and backward every parameter gradient of the four
     layers plus dL/dact1 from dy, act1 and the weights (csrc/gen_nets.hip).  In the two-term arithmetic the 5^3 layer's backward then runs
     from 27 shifted copies of the one-channel dy (a 32 x 64 weight gradient and a forward 32 -> 64 convolution with composed weights: half
@@ -636,24 +636,30 @@ def test_deep_linear_collapsed_tail_equals_the_layered_chain(shape, want_dx, ter
 
     try:
         ya, ia, xa, ga = run(0)
-        yb, ib, xb, gb = run(1)
         scale = float(ya.abs().max())
-        # (the layered fp32 chain itself is ~2e-6 of the largest output away from fp64; the collapsed form is closer: tests/test_gpu_grad_fp64.py)
-        assert float((ya - yb).abs().max()) <= 1e-5 * scale, float((ya - yb).abs().max()) / scale
-        assert torch.equal(yb, ib) and torch.equal(ya, ia)
-        if want_dx:
-            assert rel2(xb.cpu().numpy(), xa.cpu().numpy()) < 1e-5
-        for (n, _), a, b in zip(net.named_parameters(), ga, gb):
-            assert rel2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5, (n, rel2(b.cpu().numpy(), a.cpu().numpy()))
-        # the switch at backward time does not matter: the forward's choice travels with its saved tensors
-        lib().nc_set_dl_collapse(1)
-        for p in net.parameters():
-            p.grad = None
-        y = net(x0.clone().requires_grad_(False))
-        lib().nc_set_dl_collapse(0)
-        (y * r).sum().backward()
-        for (n, _), b, c in zip(net.named_parameters(), gb, [p.grad for p in net.parameters()]):
-            assert torch.equal(b, c), n
+        assert torch.equal(ya, ia)
+        # mode 1: round 5's collapsed tail + rank forms; mode 2 (default, round 6): layers 1 .. 5 as one position-typed 7^3 kernel where the shape
+        # admits it (extents >= 8, W % 4 == 0, two-term arithmetic: csrc/dl_typed.hip), else as mode 1
+        for mode in (1, 2):
+            yb, ib, xb, gb = run(mode)
+            # (the layered fp32 chain itself is ~2e-6 of the largest output away from fp64; the collapsed forms are closer: tests/test_gpu_grad_fp64.py)
+            assert float((ya - yb).abs().max()) <= 1e-5 * scale, (mode, float((ya - yb).abs().max()) / scale)
+            assert float((ib - yb).abs().max()) <= 1e-5 * scale  # (the inference form: saved == NULL takes the collapsed tail of mode 1)
+            if mode == 1:
+                assert torch.equal(yb, ib)
+            if want_dx:
+                assert rel2(xb.cpu().numpy(), xa.cpu().numpy()) < 1e-5, mode
+            for (n, _), a, b in zip(net.named_parameters(), ga, gb):
+                assert rel2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5, (mode, n, rel2(b.cpu().numpy(), a.cpu().numpy()))
+            # the switch at backward time does not matter: the forward's choice travels with its saved tensors
+            lib().nc_set_dl_collapse(mode)
+            for p in net.parameters():
+                p.grad = None
+            y = net(x0.clone().requires_grad_(False))
+            lib().nc_set_dl_collapse(0)
+            (y * r).sum().backward()
+            for (n, _), b, c in zip(net.named_parameters(), gb, [p.grad for p in net.parameters()]):
+                assert torch.equal(b, c), (mode, n)
     finally:
         lib().nc_set_split_terms(prev[0])
         lib().nc_set_dl_collapse(prev[1])
