@@ -30,7 +30,10 @@ __host__ __device__ inline bool tap_ok(int ta, int t) { return !((ta == 0 && t =
 
 // ---- weight space: the 27 typed kernels.  Hc[tau][d][c] (c fastest), Hd = Hc - Hc[13], Wp[c][t] = H_13[c][6 - t] (the weights the
 // pseudo-channel kernels take: conv_c1k7_h2_dgrad as the forward, conv_c1k7_h2 as the data gradient).  F[t][c][s] from k_dl_fold_fwd.
-__global__ void __launch_bounds__(64) k_dl_h_from_f(const float* __restrict__ F, float* __restrict__ Hc, float* __restrict__ Hd, float* __restrict__ Wp) {
+// Hr[tau][dz][dy][c][8]: the seven dx taps of a channel side by side (the rows' forward: one 32-byte scalar load per channel), Hx[tau][dz][dx][c][8]: the
+// seven dy taps (the x faces' forward)
+__global__ void __launch_bounds__(64) k_dl_h_from_f(const float* __restrict__ F, float* __restrict__ Hc, float* __restrict__ Hd, float* __restrict__ Wp,
+                                                    float* __restrict__ Hr, float* __restrict__ Hx) {
   const int tau = blockIdx.x, d = blockIdx.y, c = threadIdx.x;
   const int dz = d / 49, dy = (d / 7) % 7, dx = d % 7;
   const int tz_ = tau / 9, ty_ = (tau / 3) % 3, tx_ = tau % 3;
@@ -53,6 +56,12 @@ __global__ void __launch_bounds__(64) k_dl_h_from_f(const float* __restrict__ F,
   Hc[((long)tau * kD7 + d) * kC + c] = (float)v;
   Hd[((long)tau * kD7 + d) * kC + c] = (float)(v - v13);
   if (tau == 13) Wp[(long)c * kD7 + ((6 - dz) * 7 + (6 - dy)) * 7 + (6 - dx)] = (float)v;
+  float* hr = Hr + ((((long)tau * 7 + dz) * 7 + dy) * kC + c) * 8;
+  float* hx = Hx + ((((long)tau * 7 + dz) * 7 + dx) * kC + c) * 8;
+  hr[dx] = (float)v;
+  hx[dy] = (float)v;
+  if (dx == 6) hr[7] = 0.f;
+  if (dy == 6) hx[7] = 0.f;
 }
 
 // Pq[c][a][124 - s] (the layout k_dl_q_from_p / k_dl_w1_contract read; a = 27 .. 31 zero) = sum_tau [tau allows a] dH_tau[c][a + s]
@@ -105,91 +114,85 @@ __device__ inline void row_decode(int r, int D, int H, int& z, int& y) {
 }
 __host__ inline int n_bnd_rows(int D, int H) { return 2 * H + 2 * (D - 2); }
 
-// ---- forward: y[v] for the boundary voxels.  Seven waves = the seven kernel planes dz, a lane = a voxel, all 64 channels per lane with four
-// independent sums; the type is wave-uniform (scalar weight loads) -- in the X set the two lanes at the ends of the y line run a second pass
-// with their own type.  XF = false: block = (row of R, 64-voxel segment of x = 1 .. W - 2, sample); XF = true: block = (plane z, side, segment of y).
+// ---- forward: y[v] for the boundary voxels.  Seven waves = the seven kernel planes dz; a wave = 58 voxels of a line plus three halo lanes on either
+// side: ONE coalesced load per (channel, line of the 7 x 7 window) and lane, the seven shifts along the line by DPP (wave_shr / wave_shl), weights
+// wave-uniform (scalar loads).  XF = false: the lines are rows, block = (row of R, 58-voxel segment of x = 1 .. W - 2, sample); XF = true: the lines
+// run along y through AX, block = (plane z, side, segment of y = 0 .. H - 1); the voxels at the two ends of a y line have their own types: the
+// waves that hold one run a second pass for it.
+__device__ __forceinline__ float dpp_prev(float v) {  // lane i <- lane i - 1 (lane 0: 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_next(float v) {  // lane i <- lane i + 1 (lane 63: 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+constexpr int kSeg = 58;
 template <bool XF>
-__global__ void __launch_bounds__(448) k_dl_bnd_fwd(const float* __restrict__ src, const float* __restrict__ Hc, float* __restrict__ y, int D, int H, int W) {
+__global__ void __launch_bounds__(448) k_dl_bnd_fwd(const float* __restrict__ src, const float* __restrict__ Hl, float* __restrict__ y, int D, int H, int W) {
   __shared__ float red[7][64];
   const int lane = threadIdx.x & 63, dz = threadIdx.x >> 6, n = blockIdx.z;
   const long HW = (long)H * W, S = (long)D * HW;
-  float acc = 0.f;
-  int z, yy, x;
-  bool valid;
-  if constexpr (!XF) {
-    row_decode(blockIdx.x, D, H, z, yy);
-    x = 1 + blockIdx.y * 64 + lane;
-    valid = x <= W - 2;
-    const int tau = (axis_type(z, D) * 3 + axis_type(yy, H)) * 3 + 1;
-    const int zz = z + dz - 3;
-    if (valid && (unsigned)zz < (unsigned)D) {
-      const float* ab = src + (long)n * kC * S + (long)zz * HW;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int dy = 0; dy < 7; ++dy) {
-        const int y2 = yy + dy - 3;
+  // geometry of this block's line: L = its length, p = this lane's position on it (the wave covers p0 - 3 .. p0 + 60), first / last voxel of the set
+  int z, side = 0, seg, L, lo, hi, fix;  // fix: the other in-plane coordinate (y for rows, -) ...
+  if constexpr (!XF) { row_decode(blockIdx.x, D, H, z, fix); seg = blockIdx.y; L = W; lo = 1; hi = W - 2; }
+  else { z = blockIdx.x; side = blockIdx.y & 1; seg = blockIdx.y >> 1; L = H; lo = 0; hi = H - 1; fix = 0; }
+  const int p = lo + seg * kSeg + lane - 3;
+  const bool mine = lane >= 3 && lane < 3 + kSeg && p <= hi;  // this lane owns an output voxel
+  const bool inl = (unsigned)p < (unsigned)L;                  // ... or at least a position on the line (halo)
+  const int zz = z + dz - 3;
+  const long cs = XF ? (long)D * 4 * H : S;  // channel stride of the source
+  // one pass with a wave-uniform type; `act`: the lanes whose sum counts
+  auto pass = [&](int tau) __attribute__((always_inline)) {
+    float a0 = 0.f, a1 = 0.f;
+    if ((unsigned)zz >= (unsigned)D) return 0.f;
+    for (int k = 0; k < (XF ? 4 : 7); ++k) {  // the other window axis: dy (rows) / the four columns next to the face (x faces)
+      const float* line;
+      int dq;  // the tap index along that axis
+      if constexpr (!XF) {
+        const int y2 = fix + k - 3;
         if ((unsigned)y2 >= (unsigned)H) continue;
-        const float* row = ab + (long)y2 * W;
-        for (int dx = 0; dx < 7; ++dx) {
-          const int x2 = x + dx - 3;
-          const bool in = (unsigned)x2 < (unsigned)W;
-          const float* h = Hc + ((long)tau * kD7 + (dz * 7 + dy) * 7 + dx) * kC;  // wave-uniform
-          const float* ap = row + (in ? x2 : 0);
-#pragma unroll
-          for (int c = 0; c < kC; c += 4) {
-            a0 = __builtin_fmaf(h[c], in ? ap[(long)c * S] : 0.f, a0);
-            a1 = __builtin_fmaf(h[c + 1], in ? ap[(long)(c + 1) * S] : 0.f, a1);
-            a2 = __builtin_fmaf(h[c + 2], in ? ap[(long)(c + 2) * S] : 0.f, a2);
-            a3 = __builtin_fmaf(h[c + 3], in ? ap[(long)(c + 3) * S] : 0.f, a3);
-          }
-        }
+        line = src + (long)n * kC * S + (long)zz * HW + (long)y2 * W;
+        dq = k;
+      } else {
+        line = src + ((long)n * 2 + side) * kC * cs + ((long)zz * 4 + k) * H;
+        dq = side ? k : k + 3;  // side 0: x' = dx - 3 = k; side 1: x' = W - 4 + dx, k = dx
       }
-      acc = (a0 + a1) + (a2 + a3);
+      // the 7 taps along the line of channel c: 8 consecutive floats (Hr: (dz, dy = dq) x dx; Hx: (dz, dx = dq) x dy), wave-uniform
+      const float4* h = reinterpret_cast<const float4*>(Hl + (((long)tau * 7 + dz) * 7 + dq) * kC * 8);
+#pragma unroll 4
+      for (int c = 0; c < kC; ++c) {
+        const float v = inl ? line[(long)c * cs + p] : 0.f;
+        const float m1 = dpp_prev(v), m2 = dpp_prev(m1), m3 = dpp_prev(m2);
+        const float p1 = dpp_next(v), p2 = dpp_next(p1), p3 = dpp_next(p2);
+        const float4 w0 = h[2 * c], w1 = h[2 * c + 1];
+        a0 = __builtin_fmaf(w0.x, m3, a0);
+        a1 = __builtin_fmaf(w0.y, m2, a1);
+        a0 = __builtin_fmaf(w0.z, m1, a0);
+        a1 = __builtin_fmaf(w0.w, v, a1);
+        a0 = __builtin_fmaf(w1.x, p1, a0);
+        a1 = __builtin_fmaf(w1.y, p2, a1);
+        a0 = __builtin_fmaf(w1.z, p3, a0);
+      }
     }
+    return a0 + a1;
+  };
+  float acc;
+  if constexpr (!XF) {
+    acc = pass((axis_type(z, D) * 3 + axis_type(fix, H)) * 3 + 1);
   } else {
-    const int side = blockIdx.y & 1, seg = blockIdx.y >> 1;
-    z = blockIdx.x;
-    yy = seg * 64 + lane;
-    x = side ? W - 1 : 0;
-    valid = yy < H;
     const int tzx = axis_type(z, D) * 9 + (side ? 2 : 0);
-    const long cs = (long)D * 4 * H;  // channel stride of AX
-    const int zz = z + dz - 3;
-    const float* ab = src + ((long)n * 2 + side) * kC * cs + (long)zz * 4 * H;
-    auto pass = [&](int ty, bool active) __attribute__((always_inline)) {
-      const int tau = tzx + ty * 3;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (int dxr = 0; dxr < 4; ++dxr) {
-        const int dx = side ? dxr : dxr + 3;  // side 0: x' = dx - 3 = xr; side 1: x' = W - 4 + dx, xr = dx
-        for (int dy = 0; dy < 7; ++dy) {
-          const int y2 = yy + dy - 3;
-          const bool in = active && (unsigned)y2 < (unsigned)H;
-          const float* h = Hc + ((long)tau * kD7 + (dz * 7 + dy) * 7 + dx) * kC;
-          const float* ap = ab + (long)dxr * H + (in ? y2 : 0);
-#pragma unroll
-          for (int c = 0; c < kC; c += 4) {
-            a0 = __builtin_fmaf(h[c], in ? ap[(long)c * cs] : 0.f, a0);
-            a1 = __builtin_fmaf(h[c + 1], in ? ap[(long)(c + 1) * cs] : 0.f, a1);
-            a2 = __builtin_fmaf(h[c + 2], in ? ap[(long)(c + 2) * cs] : 0.f, a2);
-            a3 = __builtin_fmaf(h[c + 3], in ? ap[(long)(c + 3) * cs] : 0.f, a3);
-          }
-        }
-      }
-      return (a0 + a1) + (a2 + a3);
-    };
-    if ((unsigned)zz < (unsigned)D) {
-      const int tyl = axis_type(yy < H ? yy : 1, H);
-      acc = pass(1, valid && tyl == 1);
-      if (__builtin_amdgcn_ballot_w64(valid && tyl == 0) != 0) { const float v = pass(0, valid && tyl == 0); if (tyl == 0) acc = v; }
-      if (__builtin_amdgcn_ballot_w64(valid && tyl == 2) != 0) { const float v = pass(2, valid && tyl == 2); if (tyl == 2) acc = v; }
-    }
+    acc = pass(tzx + 3);
+    const int tyl = mine ? axis_type(p, H) : 1;
+    if (__builtin_amdgcn_ballot_w64(tyl == 0) != 0) { const float v = pass(tzx); if (tyl == 0) acc = v; }
+    if (__builtin_amdgcn_ballot_w64(tyl == 2) != 0) { const float v = pass(tzx + 6); if (tyl == 2) acc = v; }
   }
   red[dz][lane] = acc;
   __syncthreads();
-  if (dz == 0 && valid) {
+  if (dz == 0 && mine) {
     float v = red[0][lane];
 #pragma unroll
     for (int k = 1; k < 7; ++k) v += red[k][lane];
-    y[(long)n * S + (long)z * HW + (long)yy * W + x] = v;
+    const long o = XF ? (long)z * HW + (long)p * W + (side ? W - 1 : 0) : (long)z * HW + (long)fix * W + p;
+    y[(long)n * S + o] = v;
   }
 }
 
@@ -397,7 +400,7 @@ size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- host side.  Scratch layout (dl_typed_bytes): Hc | Hd | Wp | dWsw | dHb | AX | dyX | partA | partB
 struct DlTyped {
-  size_t Hc, Hd, Wp, dWsw, dHb, AX, dyX, partA, partB, total;
+  size_t Hc, Hd, Wp, dWsw, dHb, AX, dyX, partA, partB, Hr, Hx, total;
   int nrows;
 };
 static DlTyped dl_typed_plan(int N, int D, int H, int W) {
@@ -408,6 +411,7 @@ static DlTyped dl_typed_plan(int N, int D, int H, int W) {
   t.Hc = take((size_t)kT * kD7 * kC * 4); t.Hd = take((size_t)kT * kD7 * kC * 4); t.Wp = take((size_t)kC * kD7 * 4); t.dWsw = take((size_t)kC * kD7 * 4);
   t.dHb = take((size_t)kT * kD7 * kC * 4);
   t.AX = take((size_t)N * 2 * kC * D * 4 * H * 4); t.dyX = take((size_t)N * 2 * D * H * 4);
+  t.Hr = take((size_t)kT * 49 * kC * 8 * 4); t.Hx = take((size_t)kT * 49 * kC * 8 * 4);
   t.partA = take((size_t)N * t.nrows * kD7 * kC * 4); t.partB = take((size_t)3 * N * 2 * D * kD7 * kC * 4);
   t.total = off;
   return t;
@@ -422,7 +426,8 @@ float* dl_typed_dwsw(char* scratch, int N, int D, int H, int W) { return (float*
 // the typed kernels from F (k_dl_fold_fwd's 27 composed 5^3 kernels)
 int dl_typed_compose(const float* F, char* scratch, int N, int D, int H, int W, hipStream_t s) {
   const DlTyped t = dl_typed_plan(N, D, H, W);
-  hipLaunchKernelGGL(k_dl_h_from_f, dim3(kT, kD7), dim3(64), 0, s, F, (float*)(scratch + t.Hc), (float*)(scratch + t.Hd), (float*)(scratch + t.Wp));
+  hipLaunchKernelGGL(k_dl_h_from_f, dim3(kT, kD7), dim3(64), 0, s, F, (float*)(scratch + t.Hc), (float*)(scratch + t.Hd), (float*)(scratch + t.Wp), (float*)(scratch + t.Hr),
+                     (float*)(scratch + t.Hx));
   return check_launch("deep_linear: typed kernels");
 }
 // y's boundary voxels, recomputed with their own kernels (y holds the interior kernel's result everywhere)
@@ -430,8 +435,8 @@ int dl_typed_fwd_boundary(const float* act0, float* y, char* scratch, int N, int
   const DlTyped t = dl_typed_plan(N, D, H, W);
   float* AX = (float*)(scratch + t.AX);
   hipLaunchKernelGGL(k_dl_gather_x, dim3((unsigned)D, kC, (unsigned)(N * 2)), dim3(128), 0, s, act0, AX, (const float*)nullptr, (float*)nullptr, D, H, W);
-  hipLaunchKernelGGL(k_dl_bnd_fwd<false>, dim3((unsigned)t.nrows, (unsigned)cdiv(W - 2, 64), (unsigned)N), dim3(448), 0, s, act0, (const float*)(scratch + t.Hc), y, D, H, W);
-  hipLaunchKernelGGL(k_dl_bnd_fwd<true>, dim3((unsigned)D, (unsigned)(2 * cdiv(H, 64)), (unsigned)N), dim3(448), 0, s, (const float*)AX, (const float*)(scratch + t.Hc), y, D, H,
+  hipLaunchKernelGGL(k_dl_bnd_fwd<false>, dim3((unsigned)t.nrows, (unsigned)cdiv(W - 2, kSeg), (unsigned)N), dim3(448), 0, s, act0, (const float*)(scratch + t.Hr), y, D, H, W);
+  hipLaunchKernelGGL(k_dl_bnd_fwd<true>, dim3((unsigned)D, (unsigned)(2 * cdiv(H, kSeg)), (unsigned)N), dim3(448), 0, s, (const float*)AX, (const float*)(scratch + t.Hx), y, D, H,
                      W);
   return check_launch("deep_linear: typed forward, boundary");
 }
