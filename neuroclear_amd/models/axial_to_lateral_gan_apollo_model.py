@@ -229,8 +229,17 @@ class AxialToLateralGANApolloModel(BaseModel):
             self.projection_depth = np.random.randint(max(2, self.min_projection_depth),
                                                       self.max_projection_depth + 1)
 
+    _early_DA = os.environ.get('NC_D_EARLY', '0') != '0'
+
     def forward(self):
         self.fake = self.netG_A(self.real)
+        # the generator-loss passes of D_A only need `fake`: NC_D_EARLY=1 starts them under G_B's forward instead of behind it.  Measured twice, slower
+        # both times (round 5, under G_B's persistent 5^3 kernel: +0.6 ms; round 6, under its 0.8 ms of 7^3 launches: 24.98 against 24.64 ms, same-box
+        # alternation profiles/r06_ab_d_early.txt): small kernels under a persistent one cost it more than the idle time they fill.  Default off
+        self._fake_done = None
+        if self.real.is_cuda and self._d_streams_on and self._early_DA and self.isTrain:
+            self._fake_done = torch.cuda.Event()
+            self._fake_done.record()
         self.rec = self.netG_B(self.fake)
 
     # -- Volume.get_slice / get_projection (apollo:322-351); num_slice = shape[-1] for every axis (:325).
@@ -278,8 +287,9 @@ class AxialToLateralGANApolloModel(BaseModel):
         out = []
         for i, (net, fn) in enumerate(jobs):
             st = self._d_streams[i]
-            if after is not None:
-                st.wait_event(after)
+            ev = after[i] if isinstance(after, (list, tuple)) else after
+            if ev is not None:
+                st.wait_event(ev)
             else:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
@@ -355,8 +365,9 @@ class AxialToLateralGANApolloModel(BaseModel):
             if i % 2 == 0:
                 return g(p[0], True) * self.lambda_plane_target
             return g(p[0], True) * self.lambda_slice + g(p[1], True) * self.lambda_slice
+        fd = getattr(self, '_fake_done', None)
         (self.loss_G_A_lateral, self.loss_G_A_axial, self.loss_G_B_lateral, self.loss_G_B_axial) = \
-            self._D_many(jobs, loss)
+            self._D_many(jobs, loss, after=[fd, fd, None, None] if fd is not None else None)
         self.loss_G_A = self.loss_G_A_lateral + self.loss_G_A_axial * 0.5
         self.loss_G_B = self.loss_G_B_lateral + self.loss_G_B_axial * 0.5
         self.loss_cycle = self.criterionCycle(self.rec, self.real) * lambda_A
