@@ -312,13 +312,19 @@ size_t nc_deep_linear_saved_floats(int N, int S0, int S1, int S2);
 size_t nc_deep_linear_ws_bytes(int N, int S0, int S1, int S2);
 int nc_deep_linear_fwd(const float* params, const float* x, float* y, float* saved /* or NULL */, int N, int S0, int S1,
                        int S2, void* ws, size_t ws_bytes, void* stream, unsigned* kept /* as above */);
-/* deep_linear_gen's layers 2 .. 5 (3^3, then three 1 x 1; reference networks.py:902-911) are bias-free with nothing in between: 1 (default;
- * NC_DL_COLLAPSE at load time) evaluates them in collapsed form -- ONE 64 -> 1 convolution forward, and backward the six parameter gradients
- * and dL/dact1 from dy, act1 and the weights alone (csrc/gen_nets.hip, "the collapsed tail"), and the 5^3 layer's two gradients from 27 shifted
- * copies of the one-channel dy (half the matrix work each: "layer 1's weight gradient from the rank structure of its dY"), and the forward of
- * the 5^3 layer as a 64 -> 27 convolution plus a shifted sum ("the forward without act1") -- exact algebra, weight-space products in fp64, the
- * same outputs and gradients to fp32 rounding (closer to an fp64 evaluation than the fp32 chain), 8 ms less per 108^3 training step; 0: layer by layer as the reference's autograd does.  nc_deep_linear_lp_* follows the same switch; both
- * pairs carry the forward's choice in `kept`, so the switch may move between a forward and its backward. */
+/* deep_linear_gen's layers 1 .. 5 (5^3, 3^3, then three 1 x 1; reference networks.py:900-911) are bias-free with nothing in between.  Level of
+ * nc_set_dl_collapse (NC_DL_COLLAPSE at load time):
+ *   0  layer by layer, as the reference's autograd does;
+ *   1  (round 5) layers 2 .. 5 in collapsed form -- ONE 64 -> 1 convolution forward, and backward the six parameter gradients and dL/dact1 from
+ *      dy, act1 and the weights alone (csrc/gen_nets.hip, "the collapsed tail") -- and the 5^3 layer's two gradients from 27 shifted copies of the
+ *      one-channel dy, its forward as a 64 -> 27 convolution plus a shifted sum ("the forward without act1");
+ *   2  (default, round 6) layers 1 .. 5 as ONE position-typed 7^3 convolution 64 -> 1 of act0 (csrc/dl_typed.hip): the zero padding of
+ *      act1 only matters ON the faces, where it removes the taps of the 3^3 kernel that point outside -- 27 composed kernels, one per position
+ *      type; the interior one runs everywhere on the two-term matrix kernels, the voxels on a face are recomputed / corrected with their own.  The
+ *      5^3 convolution is not executed at all.  Where the shape does not admit it (an extent below 8, W % 4 != 0, nc_set_split_terms(3)): as 1.
+ * Exact algebra in every level (weight-space products in fp64; tests/test_collapse_algebra.py in fp64 against autograd), the same outputs and
+ * gradients to fp32 rounding, each level closer to an fp64 evaluation than the one before.  nc_deep_linear_lp_* follows the switch as 0 / non-zero.
+ * Both pairs carry the forward's choice in `kept`, so the switch may move between a forward and its backward. */
 void nc_set_dl_collapse(int on);
 int nc_get_dl_collapse(void);
 int nc_deep_linear_bwd(const float* params, const float* x, const float* saved, const float* dy, float* dx, float* dparams,
