@@ -117,8 +117,8 @@ __host__ inline int n_bnd_rows(int D, int H) { return 2 * H + 2 * (D - 2); }
 // ---- forward: y[v] for the boundary voxels.  Seven waves = the seven kernel planes dz; a wave = 58 voxels of a line plus three halo lanes on either
 // side: ONE coalesced load per (channel, line of the 7 x 7 window) and lane, the seven shifts along the line by DPP (wave_shr / wave_shl), weights
 // wave-uniform (scalar loads).  XF = false: the lines are rows, block = (row of R, 58-voxel segment of x = 1 .. W - 2, sample); XF = true: the lines
-// run along y through AX, block = (plane z, side, segment of y = 0 .. H - 1); the voxels at the two ends of a y line have their own types: the
-// waves that hold one run a second pass for it.
+// run along y through AX, block = (plane z, side, segment of y = 1 .. H - 2); the voxels at the two ends of a y line (the volume's four vertical
+// edges, their own types) are k_dl_bnd_fwd_ends'.
 __device__ __forceinline__ float dpp_prev(float v) {  // lane i <- lane i - 1 (lane 0: 0)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(448) k_dl_bnd_fwd(const float* __restrict__ sr
   // geometry of this block's line: L = its length, p = this lane's position on it (the wave covers p0 - 3 .. p0 + 60), first / last voxel of the set
   int z, side = 0, seg, L, lo, hi, fix;  // fix: the other in-plane coordinate (y for rows, -) ...
   if constexpr (!XF) { row_decode(blockIdx.x, D, H, z, fix); seg = blockIdx.y; L = W; lo = 1; hi = W - 2; }
-  else { z = blockIdx.x; side = blockIdx.y & 1; seg = blockIdx.y >> 1; L = H; lo = 0; hi = H - 1; fix = 0; }
+  else { z = blockIdx.x; side = blockIdx.y & 1; seg = blockIdx.y >> 1; L = H; lo = 1; hi = H - 2; fix = 0; }
   const int p = lo + seg * kSeg + lane - 3;
   const bool mine = lane >= 3 && lane < 3 + kSeg && p <= hi;  // this lane owns an output voxel
   const bool inl = (unsigned)p < (unsigned)L;                  // ... or at least a position on the line (halo)
@@ -158,33 +158,33 @@ __global__ void __launch_bounds__(448) k_dl_bnd_fwd(const float* __restrict__ sr
       }
       // the 7 taps along the line of channel c: 8 consecutive floats (Hr: (dz, dy = dq) x dx; Hx: (dz, dx = dq) x dy), wave-uniform
       const float4* h = reinterpret_cast<const float4*>(Hl + (((long)tau * 7 + dz) * 7 + dq) * kC * 8);
-#pragma unroll 4
-      for (int c = 0; c < kC; ++c) {
-        const float v = inl ? line[(long)c * cs + p] : 0.f;
-        const float m1 = dpp_prev(v), m2 = dpp_prev(m1), m3 = dpp_prev(m2);
-        const float p1 = dpp_next(v), p2 = dpp_next(p1), p3 = dpp_next(p2);
-        const float4 w0 = h[2 * c], w1 = h[2 * c + 1];
-        a0 = __builtin_fmaf(w0.x, m3, a0);
-        a1 = __builtin_fmaf(w0.y, m2, a1);
-        a0 = __builtin_fmaf(w0.z, m1, a0);
-        a1 = __builtin_fmaf(w0.w, v, a1);
-        a0 = __builtin_fmaf(w1.x, p1, a0);
-        a1 = __builtin_fmaf(w1.y, p2, a1);
-        a0 = __builtin_fmaf(w1.z, p3, a0);
+      // sixteen channels per trip: their loads are in flight together (the kernel is latency-bound, not instruction-bound: ~6 waves per SIMD)
+      for (int c0 = 0; c0 < kC; c0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = inl ? line[(long)(c0 + i) * cs + p] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float m1 = dpp_prev(v[i]), m2 = dpp_prev(m1), m3 = dpp_prev(m2);
+          const float p1 = dpp_next(v[i]), p2 = dpp_next(p1), p3 = dpp_next(p2);
+          const float4 w0 = h[2 * (c0 + i)], w1 = h[2 * (c0 + i) + 1];
+          float& a = (i & 1) ? a1 : a0;
+          float& b = (i & 1) ? a0 : a1;
+          a = __builtin_fmaf(w0.x, m3, a);
+          b = __builtin_fmaf(w0.y, m2, b);
+          a = __builtin_fmaf(w0.z, m1, a);
+          b = __builtin_fmaf(w0.w, v[i], b);
+          a = __builtin_fmaf(w1.x, p1, a);
+          b = __builtin_fmaf(w1.y, p2, b);
+          a = __builtin_fmaf(w1.z, p3, a);
+        }
       }
     }
     return a0 + a1;
   };
   float acc;
-  if constexpr (!XF) {
-    acc = pass((axis_type(z, D) * 3 + axis_type(fix, H)) * 3 + 1);
-  } else {
-    const int tzx = axis_type(z, D) * 9 + (side ? 2 : 0);
-    acc = pass(tzx + 3);
-    const int tyl = mine ? axis_type(p, H) : 1;
-    if (__builtin_amdgcn_ballot_w64(tyl == 0) != 0) { const float v = pass(tzx); if (tyl == 0) acc = v; }
-    if (__builtin_amdgcn_ballot_w64(tyl == 2) != 0) { const float v = pass(tzx + 6); if (tyl == 2) acc = v; }
-  }
+  if constexpr (!XF) acc = pass((axis_type(z, D) * 3 + axis_type(fix, H)) * 3 + 1);
+  else acc = pass(axis_type(z, D) * 9 + 3 + (side ? 2 : 0));  // (the two ends of the y line -- the volume's vertical edges -- are k_dl_bnd_fwd_ends')
   red[dz][lane] = acc;
   __syncthreads();
   if (dz == 0 && mine) {
@@ -194,6 +194,38 @@ __global__ void __launch_bounds__(448) k_dl_bnd_fwd(const float* __restrict__ sr
     const long o = XF ? (long)z * HW + (long)p * W + (side ? W - 1 : 0) : (long)z * HW + (long)fix * W + p;
     y[(long)n * S + o] = v;
   }
+}
+
+// the 4 D voxels of the volume's vertical edges (x = 0 / W - 1 and y = 0 / H - 1): block = (z, side * 2 + yend, sample); threads = 64 channels x 4
+// groups of kernel planes; fixed-order reduction through LDS
+__global__ void __launch_bounds__(256) k_dl_bnd_fwd_ends(const float* __restrict__ ax, const float* __restrict__ Hc, float* __restrict__ y, int D, int H, int W) {
+  __shared__ float red[256];
+  const int th = threadIdx.x, c = th & 63, part = th >> 6;
+  const int z = blockIdx.x, side = blockIdx.y >> 1, ye = blockIdx.y & 1, n = blockIdx.z;
+  const int yy = ye ? H - 1 : 0;
+  const int tau = (axis_type(z, D) * 3 + (ye ? 2 : 0)) * 3 + (side ? 2 : 0);
+  const long cs = (long)D * 4 * H;
+  const float* a = ax + (((long)n * 2 + side) * kC + c) * cs;
+  float acc = 0.f;
+  for (int dz = part; dz < 7; dz += 4) {
+    const int zz = z + dz - 3;
+    if ((unsigned)zz >= (unsigned)D) continue;
+    for (int dxr = 0; dxr < 4; ++dxr) {
+      const int dx = side ? dxr : dxr + 3;
+      for (int dy = 0; dy < 7; ++dy) {
+        const int y2 = yy + dy - 3;
+        if ((unsigned)y2 >= (unsigned)H) continue;
+        acc = __builtin_fmaf(Hc[((long)tau * kD7 + (dz * 7 + dy) * 7 + dx) * kC + c], a[((long)zz * 4 + dxr) * H + y2], acc);
+      }
+    }
+  }
+  red[th] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (th < o) red[th] += red[th + o];
+    __syncthreads();
+  }
+  if (th == 0) y[(long)n * D * H * W + (long)z * H * W + (long)yy * W + (side ? W - 1 : 0)] = red[0];
 }
 
 // ---- dL/dact0 += the boundary voxels' difference kernels (Hd = Hc - Hc[13]).  One thread owns (u, 16 channels): plain read-modify-write, the two
@@ -271,9 +303,7 @@ __global__ void __launch_bounds__(256) k_dl_bnd_dgrad(const float* __restrict__ 
         }
       }
     };
-    pass(1);
-    if (__builtin_amdgcn_ballot_w64(valid && uy <= 3) != 0) pass(0);
-    if (__builtin_amdgcn_ballot_w64(valid && uy >= H - 4) != 0) pass(2);
+    pass(1);  // (the sources at the two ends of the y line -- the vertical edges -- are k_dl_bnd_dgrad_ends')
     if (valid) {
       float4* o = reinterpret_cast<float4*>(g + ((long)n * kC + q * 16) * S + (long)uz * HW + (long)uy * W + (side ? W - 4 : 0));
 #pragma unroll
@@ -284,6 +314,30 @@ __global__ void __launch_bounds__(256) k_dl_bnd_dgrad(const float* __restrict__ 
       }
     }
   }
+}
+
+// the sources on the volume's vertical edges (x = 0 / W - 1 and y = 0 / H - 1) through dyX: block = (uz, side * 2 + yend, sample): 4 rows uy x 4 columns x
+// 64 channels of outputs, four per thread
+__global__ void __launch_bounds__(256) k_dl_bnd_dgrad_ends(const float* __restrict__ dyx, const float* __restrict__ Hd, float* __restrict__ g, int D, int H, int W) {
+  const int th = threadIdx.x, c = th & 63, r = th >> 6;  // r: which of the four output rows
+  const int uz = blockIdx.x, side = blockIdx.y >> 1, ye = blockIdx.y & 1, n = blockIdx.z;
+  const int vy = ye ? H - 1 : 0, uy = ye ? H - 4 + r : r, dy = uy - vy + 3;
+  const long HW = (long)H * W, S = (long)D * HW;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int dz = 0; dz < 7; ++dz) {
+    const int vz = uz - dz + 3;
+    if ((unsigned)vz >= (unsigned)D) continue;
+    const int tau = (axis_type(vz, D) * 3 + (ye ? 2 : 0)) * 3 + (side ? 2 : 0);
+    const float w = dyx[(((long)n * 2 + side) * D + vz) * H + vy];
+#pragma unroll
+    for (int xr = 0; xr < 4; ++xr) {
+      const int dx = side ? xr : xr + 3;
+      acc[xr] = __builtin_fmaf(w, Hd[((long)tau * kD7 + (dz * 7 + dy) * 7 + dx) * kC + c], acc[xr]);
+    }
+  }
+  float* o = g + ((long)n * kC + c) * S + (long)uz * HW + (long)uy * W + (side ? W - 4 : 0);
+#pragma unroll
+  for (int xr = 0; xr < 4; ++xr) o[xr] += acc[xr];
 }
 
 // ---- the boundary types' dH.  Threads (k, c), k = dx (R set) / dy (X set), c = channel; per staged line of act0 (LDS, 64 channels) every thread
@@ -436,8 +490,9 @@ int dl_typed_fwd_boundary(const float* act0, float* y, char* scratch, int N, int
   float* AX = (float*)(scratch + t.AX);
   hipLaunchKernelGGL(k_dl_gather_x, dim3((unsigned)D, kC, (unsigned)(N * 2)), dim3(128), 0, s, act0, AX, (const float*)nullptr, (float*)nullptr, D, H, W);
   hipLaunchKernelGGL(k_dl_bnd_fwd<false>, dim3((unsigned)t.nrows, (unsigned)cdiv(W - 2, kSeg), (unsigned)N), dim3(448), 0, s, act0, (const float*)(scratch + t.Hr), y, D, H, W);
-  hipLaunchKernelGGL(k_dl_bnd_fwd<true>, dim3((unsigned)D, (unsigned)(2 * cdiv(H, kSeg)), (unsigned)N), dim3(448), 0, s, (const float*)AX, (const float*)(scratch + t.Hx), y, D, H,
-                     W);
+  hipLaunchKernelGGL(k_dl_bnd_fwd<true>, dim3((unsigned)D, (unsigned)(2 * cdiv(H - 2, kSeg)), (unsigned)N), dim3(448), 0, s, (const float*)AX, (const float*)(scratch + t.Hx), y,
+                     D, H, W);
+  hipLaunchKernelGGL(k_dl_bnd_fwd_ends, dim3((unsigned)D, 4, (unsigned)N), dim3(256), 0, s, (const float*)AX, (const float*)(scratch + t.Hc), y, D, H, W);
   return check_launch("deep_linear: typed forward, boundary");
 }
 // the backward's boundary pieces: g (= dL/dact0 from the interior kernel) += the boundary voxels' difference kernels, and Pq (the rank form's P,
@@ -450,6 +505,7 @@ int dl_typed_dgrad_boundary(const float* act0, const float* dy, float* g, char* 
   hipLaunchKernelGGL(k_dl_bnd_dgrad<false>, dim3((unsigned)(D * H), (unsigned)cdiv(W, 64), (unsigned)N), dim3(256), 0, s, dy, (const float*)(scratch + t.Hd), g, D, H, W, 1);
   const int nseg = (int)cdiv(H, 64);
   hipLaunchKernelGGL(k_dl_bnd_dgrad<true>, dim3((unsigned)D, 2, (unsigned)(N * nseg)), dim3(256), 0, s, (const float*)dyX, (const float*)(scratch + t.Hd), g, D, H, W, nseg);
+  hipLaunchKernelGGL(k_dl_bnd_dgrad_ends, dim3((unsigned)D, 4, (unsigned)N), dim3(256), 0, s, (const float*)dyX, (const float*)(scratch + t.Hd), g, D, H, W);
   return check_launch("deep_linear: typed data gradient, boundary");
 }
 // Pq (the rank form's P, k_dl_q_from_p's layout) from dWsw (the swapped-role 7^3 correlation of dy and act0, already in the scratch) and the boundary
