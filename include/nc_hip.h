@@ -459,6 +459,13 @@ int nc_h2_guard_stats(unsigned long long* out4, int reset);
  * nc_unet_deconv_train_fwd's blocks whose input arrives converted (tested; no measurable gain in the training step, hence not the default). */
 void nc_set_epi_stats(int on);
 int nc_get_epi_stats(void);
+/* Which kernel serves the whole 512-position tiles of a two-term 3^3 launch (forward and data gradient of every 3^3 layer of the U-Net,
+ * reference networks.py:496-561, whose input channels are a multiple of 64; csrc/conv_s3x.hip): 1 (default; NC_S3X_W64 at load time) = k_conv_s3w,
+ * the 64-channel x 64-position wave tile with the weights staged through LDS (round 6; -4 % on the 140^3 / 108^3 layers, profiles/r06_ab_w64.txt);
+ * 0 = k_conv_s3x everywhere.  Same tiles, same records of the epilogue statistics; results differ by the order of the fp32 sums only (one running
+ * accumulator per tile instead of restarts every four k-steps). */
+void nc_set_s3x_w64(int on);
+int nc_get_s3x_w64(void);
 int nc_unet_deconv_fwd_terms(int S0, int S1, int S2); /* 2: nc_unet_deconv_fwd runs its 3^3 layers on the two-term form at this size under the
                                                        * current switches; 3: on the three-term form (or the fp32 kernels); 0: bad size */
 void nc_set_c8x_mode(int mode); /* which kernel serves the 16-bit 3^3 / 5^3 forward / data-gradient calls (nc_conv_fwd_lp, nc_conv_*_c8, the

@@ -36,7 +36,7 @@ def lib():
                 fn.restype = ctypes.c_size_t
             elif name == 'nc_last_error':
                 fn.restype = ctypes.c_char_p
-            elif name in ('nc_set_force_direct', 'nc_prof_begin', 'nc_sconv_set_cfg', 'nc_sconv_set_tune', 'nc_set_conv_split', 'nc_set_s3_fusion', 'nc_set_c8x_mode', 'nc_set_split_terms', 'nc_set_h2_guard', 'nc_set_epi_stats', 'nc_set_dl_collapse', 'nc_set_p2d_terms'):
+            elif name in ('nc_set_force_direct', 'nc_prof_begin', 'nc_sconv_set_cfg', 'nc_sconv_set_tune', 'nc_set_conv_split', 'nc_set_s3_fusion', 'nc_set_c8x_mode', 'nc_set_split_terms', 'nc_set_h2_guard', 'nc_set_epi_stats', 'nc_set_dl_collapse', 'nc_set_p2d_terms', 'nc_set_s3x_w64'):
                 fn.restype = None
             else:
                 fn.restype = ctypes.c_int

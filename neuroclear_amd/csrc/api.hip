@@ -167,6 +167,8 @@ void nc_set_split_terms(int terms) { s3x_set_terms(terms); }
 int nc_get_split_terms(void) { return s3x_get_terms(); }
 void nc_set_epi_stats(int on) { epi_stats_set(on); }
 int nc_get_epi_stats(void) { return epi_stats_mode(); }
+void nc_set_s3x_w64(int on) { s3x_w64_set(on); }
+int nc_get_s3x_w64(void) { return s3x_w64_get(); }
 void nc_set_p2d_terms(int mode) { p2d_set_terms(mode); }
 int nc_get_p2d_terms(void) { return p2d_get_terms(); }
 void nc_set_h2_guard(int on) { h2_guard_set(on); }

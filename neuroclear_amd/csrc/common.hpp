@@ -221,6 +221,8 @@ int conv_fwd_s3(const float* x, const void* xs, const float* w, const float* b, 
 bool epi_stats_on();  // nc_set_epi_stats / NC_EPI_STATS (conv_s3x.hip)
 void epi_stats_set(int on);
 int epi_stats_mode();
+void s3x_w64_set(int on);  // nc_set_s3x_w64 / NC_S3X_W64 (conv_s3x.hip, k_conv_s3w)
+int s3x_w64_get();
 int conv_dgrad_s3(const float* dy, const void* dys, const float* w, float* dx, const ConvDims& d, void* ws, size_t wsb, hipStream_t s);
 size_t s3_bwd_ws_bytes(const ConvDims& d);
 int conv_bwd_s3(const float* x, const float* dy, const float* w, float* dx, float* dw, const ConvDims& d, void* ws, size_t wsb,

@@ -814,6 +814,373 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3x(const XParams p) {
 #endif
 }
 
+// ---- Round 6: the 64-channel wave tile with the weights staged through LDS ("W64"; 3^3, two-term operands, 512-position tiles).
+// tools/mfma_feed.hip modes 10 / 11: what LDS read instructions cost is matrix-pipe occupancy, and a wave tile of 64 channels x 64 positions needs 16
+// fragment reads per 48 MFMAs where 32 channels x 128 positions needs 32 + 4 KiB of weights through L1 per wave -- once the k-step's 8 KiB of weight
+// fragments are staged in LDS ONCE per workgroup (by LDS-DMA, beside the brick ring) instead of being fetched by every wave.  The 64 x 64 accumulators
+// (64 registers) and two sets of eight weight fragments (64) leave no room for k_conv_s3x's second accumulator set: NO accumulator restarts -- one
+// running fp32 sum per tile, rms error 2^-24 sqrt(k-steps) of the output's rms, the fp32 kernels' own level (conv_s3x_h2 gives
+// k_conv_s3x the same rule while this form is switched on, so that an element's bits do not depend on the kernel its tile fell to) -- and the
+// tile's stores stand between two tiles.  (The form that keeps both -- ONE set of operand registers re-filled half a k-step ahead, restarts and
+// deferred stores in the 64 registers that frees -- was built and is 2-4 % slower than k_conv_s3x: the LDS pipe is ~75 % busy, a re-fill issued
+// 12 MFMAs ahead is late.)  Everything else is k_conv_s3x's: the tap stream, the brick ring and its arrival events, the DMA offset table, the
+// B-fragment reads, the tile order.
+//   * eight waves = eight groups of 64 positions, every wave all 64 output channels (4 row blocks x 4 column blocks, 48 MFMAs per k-step);
+//   * weights: piece i (1 KiB) of k-step s = fragment (half = i / 4, f = i % 4) of the packed weights, into slot s % 6 of a ring of six k-steps
+//     (k-steps per tile are a multiple of 6, so the ring runs on across tiles).  At the arrival event of brick na (k-step fire(na)) waves 0-3 request
+//     the pieces of the k-steps (fire(na + 1), fire(na + 2)]: complete at the next event's barrier, one event before their first use; at most five
+//     k-steps are live;
+//   * vector-memory waits (waves 0-3 hold DMA): at an event, everything older than the DMA just waited for is complete after s_waitcnt vmcnt(0) --
+//     except at k-step 1, where the 64 (+ 1) stores of the previous tile are YOUNGER than the DMA requested at k-step 0: vmcnt(63) (at least one
+//     store and everything in front of it has retired);
+//   * epilogue statistics (ST): the two waves of a 128-position group add their sums through LDS and write k_conv_s3x's record format.
+constexpr int kOffTab = 8192;  // two-term launches: the DMA offset table behind the ring, [4 issuing waves][8 pieces][64 lanes] words
+constexpr int kWA = 6;  // k-steps of weight fragments in the LDS ring
+constexpr int kWExtra = kWA * 8192 + 4096;  // LDS of k_conv_s3w behind the ring and the offset table: the weight ring, the ST exchange
+__device__ __forceinline__ int w_fire(int na) { return na < 2 ? na : (9 * na - 4) >> 2; }  // the k-step at which brick na's arrival is declared
+template <bool ST>
+__global__ void __launch_bounds__(kThreads, 1) k_conv_s3w(const XParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+  constexpr int KS = 3, NT = 2, PAD = 1, T2 = 9, NCB = 4, PT = 512;
+  if (guard_skip(p.guard, false)) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, g = lane >> 4;
+  const int pg = wave;
+  const long HW = (long)p.H * p.W, S = (long)p.D * HW;
+  const int NB = p.NCH * KS;
+  const int BB = p.npb * 1024;
+  unsigned char* const aring = lds_raw + 3 * BB + kOffTab;
+  float* const stx = reinterpret_cast<float*>(aring + kWA * 8192);  // ST: [wave][64 channels][2]
+
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int t_lo = xcd * p.tiles_per_xcd;
+  int t_hi = t_lo + p.tiles_per_xcd;
+  if (t_hi > p.t_count) t_hi = p.t_count;
+  auto next_tile = [&](int t, XTile& o) __attribute__((always_inline)) {
+    for (; t < t_hi; t += nslot) {
+      o = x_decode<PT>(p, t);
+      if (o.q0 < p.HP) return t;
+    }
+    return -1;
+  };
+  XTile cur, nxt;
+  int tcur = next_tile(t_lo + wslot, cur);
+  if (tcur < 0) return;
+
+  constexpr unsigned kOut = 0x80000000u;
+  constexpr int kPW = 8;
+  const bool keep = p.npb <= kDmaWaves * kPW;
+  typedef volatile __attribute__((address_space(3))) unsigned* lds32_t;
+  const unsigned otab = (unsigned)(unsigned long long)(lptr_t)lds_raw + (unsigned)(3 * BB + ((wave * kPW) * 64 + lane) * 4);
+  auto issue_brick = [&](const XTile& t, int bi, int slot, bool kept) __attribute__((always_inline)) {
+    if (wave >= kDmaWaves) return;
+    const int chunk = bi / KS, dz = bi - chunk * KS;
+    const int zz = t.z + dz - PAD;
+    const bool zok = (unsigned)zz < (unsigned)p.D;
+    const uint4* blk = p.xs + ((long)t.n * p.NCH + chunk) * NT * S;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(blk), 0, zok ? (unsigned)(NT * S * 16) : 0u, 0x00020000);
+    const int soff = zok ? (int)(zz * HW * 16) : 0;
+    unsigned char* buf = lds_raw + slot * BB;
+    if (kept) {
+      unsigned po[kPW];
+#pragma unroll
+      for (int i = 0; i < kPW; ++i) po[i] = *(lds32_t)(otab + i * 256);
+#pragma unroll
+      for (int i = 0; i < kPW; ++i) {
+        const int pc = wave + kDmaWaves * i;
+        if (pc < p.npb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po[i], soff, 0, 0);
+      }
+      return;
+    }
+#pragma unroll 1
+    for (int pc = wave; pc < p.npb; pc += kDmaWaves) {
+      const unsigned u = (unsigned)(pc * 64 + lane);
+      const unsigned term = fdiv(u, p.mUB);
+      const unsigned F = (unsigned)t.q0 + (u - term * p.UB);
+      const unsigned rr = fdiv(F, p.mP);
+      const int xx = (int)(F - rr * p.P) - PAD;
+      const int yy = (int)rr - PAD;
+      const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const unsigned po = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(buf + pc * 1024), 16, po, soff, 0, 0);
+    }
+  };
+  // weight pieces of the k-steps s_lo + 1 .. s_hi of tile t (waves 0-3: pieces w and w + 4 of every k-step)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.wp), 0, 0x7fffffffu, 0x00020000);
+  auto issue_a = [&](const XTile& t, int s_lo, int s_hi) __attribute__((always_inline)) {
+    if (wave >= kDmaWaves) return;
+#pragma unroll 1
+    for (int s = s_lo + 1; s <= s_hi; ++s) {
+      unsigned char* dst = aring + (s % kWA) * 8192;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = wave + 4 * j;  // piece: half = i / 4, f = i % 4
+        const int soff = ((t.cot * 2 + (i >> 2)) * p.NS + s) * 4096 + (i & 3) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr_t)(dst + i * 1024), 16, (unsigned)(lane * 16), __builtin_amdgcn_readfirstlane(soff), 0, 0);
+      }
+    }
+  };
+
+  // B fragments (as k_conv_s3x)
+  const unsigned lane_b = (unsigned)(((pg * NCB * 16 + m16) * 16) + (g & 1) * 8);
+  const unsigned term_b = (unsigned)p.UB * 16;
+  const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)lds_raw;
+  struct BAddr { unsigned lo[NT], hi[NT]; };
+  auto b_addr = [&](unsigned vo) __attribute__((always_inline)) {
+    BAddr a;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { a.lo[t] = lds_base + vo + t * term_b; a.hi[t] = a.lo[t] ^ 8u; }
+    return a;
+  };
+  auto read_b = [&](u32x4 (&B)[NT], const BAddr& a, int cb) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      u64x2 v;
+      v.x = *(lds64_t)(a.lo[t] + cb * 256);
+      v.y = *(lds64_t)(a.hi[t] + cb * 256);
+      B[t] = __builtin_bit_cast(u32x4, v);
+    }
+  };
+  // A fragments of k-step s: fragment (rb, term) = piece (rb / 2) * 4 + (rb % 2) * 2 + term of the ring slot
+  typedef const volatile __attribute__((address_space(3))) u32x4* lds128_t;
+  const unsigned a_lane = (unsigned)(unsigned long long)(lptr_t)aring + (unsigned)(lane * 16);
+  auto read_a = [&](u32x4 (&A)[4][NT], int s) {
+    const unsigned base = a_lane + (unsigned)((s % kWA) * 8192);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) A[rb][t] = *(lds128_t)(base + (unsigned)(((rb >> 1) * 4 + (rb & 1) * 2 + t) * 1024));
+  };
+
+  float oscx, oscw;
+  { const float2 f = h2_unscale2(*p.amax_x, *p.amax_w); oscx = f.x; oscw = f.y; }
+  u32x4 brsrc;
+  {
+    const unsigned long long ba = (unsigned long long)p.bias;
+    brsrc.x = __builtin_amdgcn_readfirstlane((unsigned)ba);
+    brsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu);
+    brsrc.z = __builtin_amdgcn_readfirstlane(p.bias ? (unsigned)p.K * 4u : 0u);
+    brsrc.w = __builtin_amdgcn_readfirstlane(0x00020000u);
+  }
+  u32x4 bv[4];
+  auto load_bias = [&](const XTile& t) __attribute__((always_inline)) {
+    const int bo = (t.cot * 64 + 4 * g) * 4;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bv[rb]) : "v"(bo + rb * 64), "s"(brsrc) : "memory");
+  };
+  f32x4 acc[4][NCB];
+  // the finished tile: scale back, add the bias, store (and, ST, leave the wave's sums in k_conv_s3x's record format)
+  auto epilogue = [&](const XTile& t, int tidx) __attribute__((always_inline)) {
+    const int cob = t.cot * 64 + 4 * g;
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(p.y + (long)t.n * p.K * S, 0, (unsigned)((long)p.K * S * 4), 0x00020000);
+    float st_s[4][4], st_q[4][4];
+    if constexpr (ST) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st_s[rb][e] = 0.f; st_q[rb][e] = 0.f; }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const unsigned f = (unsigned)(t.q0 + pg * NCB * 16 + cb * 16 + m16);
+      const unsigned yy = fdiv(f, p.mP);
+      const unsigned xx = f - yy * p.P;
+      const bool ok = (int)yy < p.H && (int)xx < p.W;
+      // one per-lane offset per column block (a pad column / a position beyond the plane: out of the descriptor's range, and it stays there:
+      // K S 4 < 2^31), the channel through the scalar offset -- no vector arithmetic per store
+      const unsigned vo0 = ok ? (unsigned)(((long)cob * S + (long)t.z * HW + yy * p.W + xx) * 4) : kOut;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned bu = bv[rb][e];
+          const float r = acc[rb][cb][e] * oscx * oscw;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r + __uint_as_float(bu)), ys, vo0, (int)((rb * 16 + e) * S * 4), 0);
+          if constexpr (ST) {
+            const float rr = ok ? r : 0.f;
+            st_s[rb][e] += rr;
+            st_q[rb][e] = __builtin_fmaf(rr, rr, st_q[rb][e]);
+          }
+          acc[rb][cb][e] = 0.f;
+        }
+      }
+    }
+    if constexpr (ST) {
+      // butterfly over the 16 lanes of a row (k_conv_s3x stats_flush), then lane m16 = (rb % 2) * 4 + e of group g holds channel
+      // (rb / 2) * 32 + 4 g + 16 (rb % 2) + e: the wave's 64 channel sums go to LDS, the partner wave's are added, one record per (group of 128, half)
+      float ss[2] = {0.f, 0.f}, qq[2] = {0.f, 0.f};
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = st_s[rb][e], b = st_q[rb][e];
+          a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, false));
+          b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xf, 0xf, false));
+          a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xf, 0xf, false));
+          b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, false));
+          a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xf, 0xf, false));
+          b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x141, 0xf, 0xf, false));
+          a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x140, 0xf, 0xf, false));
+          b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x140, 0xf, 0xf, false));
+          if (m16 == (rb & 1) * 4 + e) { ss[rb >> 1] = a; qq[rb >> 1] = b; }
+        }
+      // position inside a 32-channel record: g * 8 + m16 (m16 < 8), as k_s3x_stats_final decodes it
+      if (m16 < 8) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          stx[((wave * 2 + h) * 32 + g * 8 + m16) * 2] = ss[h];
+          stx[((wave * 2 + h) * 32 + g * 8 + m16) * 2 + 1] = qq[h];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // wave w writes the record (group w / 2, half w % 2): its own sums of that half + its partner's
+      const int h = wave & 1, pw = wave ^ 1;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, 0x7fffffff, 0x00020000);
+      float s0 = 0.f, q0 = 0.f;
+      if (m16 < 8) {
+        const int li = g * 8 + m16;
+        const int lo = wave & ~1;  // (the even wave's sums first: a fixed order)
+        s0 = stx[((lo * 2 + h) * 32 + li) * 2] + stx[(((lo + 1) * 2 + h) * 32 + li) * 2];
+        q0 = stx[((lo * 2 + h) * 32 + li) * 2 + 1] + stx[(((lo + 1) * 2 + h) * 32 + li) * 2 + 1];
+      }
+      (void)pw;
+      const unsigned off = m16 < 8 ? (unsigned)((((unsigned)tidx * kWaves + wave) * 32 + g * 8 + m16) * 8) : kOut;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 pk;
+      pk.x = __builtin_bit_cast(unsigned, s0); pk.y = __builtin_bit_cast(unsigned, q0);
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rs, off, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (stx is free again)
+    }
+  };
+
+  // ---- prologue: brick 0 and the weights of k-steps 0, 1 of the first tile
+  int ring = 0;
+  issue_brick(cur, 0, 0, false);
+  issue_a(cur, -1, 1);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[rb][cb][e] = 0.f;
+  bool have_prev = false;
+  XTile prv = cur;
+  int tprv = tcur;
+
+  while (true) {
+    XTile nx{};
+    const int tnext = next_tile(tcur + nslot, nx);
+    const bool more_tiles = tnext >= 0;
+    nxt = nx;
+    if (keep && wave < kDmaWaves) {
+#pragma unroll 1
+      for (int i = 0, pc = wave; pc < p.npb; ++i, pc += kDmaWaves) {
+        const unsigned u = (unsigned)(pc * 64 + lane);
+        const unsigned term = fdiv(u, p.mUB);
+        const unsigned F = (unsigned)cur.q0 + (u - term * p.UB);
+        const unsigned rr = fdiv(F, p.mP);
+        const int xx = (int)(F - rr * p.P) - PAD;
+        const int yy = (int)rr - PAD;
+        const bool ok = term < (unsigned)NT && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        *(lds32_t)(otab + i * 256) = ok ? (unsigned)(term * (unsigned)S + (unsigned)(yy * p.W + xx)) * 16u : kOut;
+      }
+    }
+    int na = 0;
+    int tpl = g, sl = ring;
+    auto b_off = [&]() __attribute__((always_inline)) {
+      const int dy = (tpl * 11) >> 5;
+      const int dx = tpl - dy * KS;
+      return lane_b + (unsigned)(sl * BB + (dy * p.P + dx) * 16);
+    };
+    BAddr vo = b_addr(b_off());
+    u32x4 B[2][NT];
+    u32x4 A0[4][NT], A1[4][NT];
+
+    auto kstep = [&](int s, u32x4 (&Ac)[4][NT], u32x4 (&An)[4][NT], auto first_) {
+      constexpr bool first = decltype(first_)::value;
+      const bool last = s + 1 == p.NS;
+      if (na < NB && 4 * s + 7 >= T2 * na) {
+        // own DMA of the previous event complete (s == 1 behind an epilogue: its stores are younger, see the header); everybody's after the barrier
+        if (wave < kDmaWaves) {
+          if (s == 1 && have_prev) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (na + 1 < NB) issue_brick(cur, na + 1, (ring + na + 1) % 3, keep);
+        else if (more_tiles) issue_brick(nxt, 0, (ring + NB) % 3, false);
+        // weights of the k-steps (fire(na + 1), fire(na + 2)], running on into the next tile
+        {
+          const int f1 = na + 1 < NB ? w_fire(na + 1) : p.NS + w_fire(na + 1 - NB);
+          const int f2 = na + 2 < NB ? w_fire(na + 2) : p.NS + w_fire(na + 2 - NB);
+          const int hi_cur = f2 < p.NS ? f2 : p.NS - 1;
+          if (f1 < p.NS) issue_a(cur, f1, hi_cur);
+          if (f2 >= p.NS && more_tiles) issue_a(nxt, (f1 >= p.NS ? f1 - p.NS : -1), f2 - p.NS);
+        }
+        ++na;
+      }
+      if constexpr (first) {
+        if (have_prev) epilogue(prv, tprv);
+        read_a(Ac, 0);
+        read_b(B[0], vo, 0);
+      }
+      if (last) load_bias(cur);
+      tpl += 4;
+      if (tpl >= T2) { tpl -= T2; sl = sl == 2 ? 0 : sl + 1; }
+      const BAddr nvo = b_addr(b_off());
+      const unsigned abase = a_lane + (unsigned)(((s + 1) % kWA) * 8192);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        u32x4(&Bc)[NT] = B[cb & 1];
+        u32x4(&Bn)[NT] = B[(cb + 1) & 1];
+        if (cb + 1 < NCB) read_b(Bn, vo, cb + 1);
+        else if (!last) read_b(Bn, nvo, 0);
+        // the next k-step's weight fragments of row block cb (the last step of a tile: the next tile reads its own behind the stores)
+        if (!last) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) An[cb][t] = *(lds128_t)(abase + (unsigned)(((cb >> 1) * 4 + (cb & 1) * 2 + t) * 1024));
+        }
+        // three products per (row block, column block), smallest first: (term of A, term of B) = (1, 0), (0, 1), (0, 0)
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ac[rb][TA[m]]), __builtin_bit_cast(f16x8, Bc[TB[m]]), acc[rb][cb], 0, 0, 0);
+        // the 6 reads spread over the 12 MFMAs
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+      vo = nvo;
+      // the bias of the finished tile is a plain value from here on (requested at the top of the step; the wave's DMA of the last event is
+      // three k-steps old)
+      if (last) {
+        u32x4(&b4)[4] = bv;  // (named here: operands of an asm statement alone do not make a generic lambda capture the array)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3])::"memory");
+      }
+    };
+    kstep(0, A0, A1, std::true_type{});
+#pragma unroll 1
+    for (int s = 1; s + 1 < p.NS; s += 2) {  // NS is even: the last k-step reads A1
+      kstep(s, A1, A0, std::false_type{});
+      kstep(s + 1, A0, A1, std::false_type{});
+    }
+    kstep(p.NS - 1, A1, A0, std::false_type{});
+    prv = cur;
+    tprv = tcur;
+    have_prev = true;
+    if (!more_tiles) break;
+    ring = (ring + NB) % 3;
+    cur = nxt;
+    tcur = tnext;
+  }
+  epilogue(prv, tprv);
+}
+
 struct XPlan {
   int NCB, fsub, P, HP, TPP, UB, npb, lds;
   int UBt, npbt, ldst;  // the tail launch's brick (PT / fsub positions)
@@ -821,7 +1188,6 @@ struct XPlan {
   bool ok;
 };
 
-constexpr int kOffTab = 8192;  // two-term launches: the DMA offset table behind the ring, [4 issuing waves][8 pieces][64 lanes] words
 bool x_brick(int PT, int P, int KS, int NT, int& UB, int& npb, int& lds, bool pc = false) {
   const int U = PT + (KS - 1) * (pc ? P : P + 1);  // (pseudo-channel form: in-plane taps are rows only)
   UB = (U + 63) / 64 * 64;
@@ -880,6 +1246,24 @@ int launch_x(const XParams& p, int lds, hipStream_t s) {
   if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3x")) return e;
   hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds, s, p);
   return check_launch("conv_s3x");
+}
+
+// the W64 form (k_conv_s3w) takes a launch of whole 512-position tiles of a 3^3 layer whose k-steps per tile are a multiple of the weight ring
+// (every multiple of 64 input channels) when its LDS fits.  NC_S3X_W64=0: k_conv_s3x everywhere (A/B, tests)
+static std::atomic<int> g_w64{getenv("NC_S3X_W64") ? atoi(getenv("NC_S3X_W64")) : 1};
+bool w64_applies(int KS, int NCB, int NS, int lds) {
+  return g_w64.load(std::memory_order_relaxed) && KS == 3 && NCB == 8 && NS % kWA == 0 && NS >= 12 && lds + kOffTab + kWExtra <= kLdsMax;
+}
+}  // namespace
+void s3x_w64_set(int on) { g_w64.store(on ? 1 : 0, std::memory_order_relaxed); }
+int s3x_w64_get() { return g_w64.load(std::memory_order_relaxed); }
+namespace {
+template <bool ST>
+int launch_w64(const XParams& p, int lds, hipStream_t s) {
+  auto kern = k_conv_s3w<ST>;
+  if (int e = raise_dyn_lds(kern, kLdsMax, "conv_s3w")) return e;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(kThreads), lds + kOffTab + kWExtra, s, p);
+  return check_launch("conv_s3w");
 }
 
 template <int KS, int NT = 3, bool ST = false>
@@ -1031,12 +1415,17 @@ int conv_s3x_h2(const void* xs, const unsigned* cell_a, const unsigned* cell_b, 
   p.NS = NS; p.mP = magic(pl.P);
   static const int flush = getenv("NC_S3X_FLUSH") ? atoi(getenv("NC_S3X_FLUSH")) : 4;
   p.flush = flush >= 4 ? flush : flush > 0 ? 4 : 1 << 30;
+  // With the W64 form switched on, EVERY two-term 3^3 launch keeps one running accumulator per tile (k_conv_s3w has no second set to restart
+  // into): an output element's bits then do not depend on which kernel or which launch (whole tiles / the fractional tiles of the tail, and so
+  // on the batch a cube travels in) its tile fell to -- same products, same order, tot = 0 + acc exactly.
+  if (KS == 3 && !k32 && s3x_w64_get()) p.flush = 1 << 30;
   const bool one = pl.rem && pl.fsub == 1;
   if (pl.full || one) {
     p.fsub = 1; p.UB = pl.UB; p.npb = pl.npb; p.mUB = magic(pl.UB);
     p.t_begin = 0; p.t_count = (int)(pl.full + (one ? pl.rem : 0)); p.tiles_per_xcd = (int)cdiv(p.t_count, 8);
     p.stats = (float2*)stats_part;
-    const int e = k32 ? (pl.NCB == 4 ? launch_x<5, 4, 2, false, true>(p, pl.lds + kOffTab, s) : launch_x<5, 2, 2, false, true>(p, pl.lds + kOffTab, s))
+    const int e = !k32 && w64_applies(KS, pl.NCB, NS, pl.lds) ? (stats_part ? launch_w64<true>(p, pl.lds, s) : launch_w64<false>(p, pl.lds, s))
+                  : k32 ? (pl.NCB == 4 ? launch_x<5, 4, 2, false, true>(p, pl.lds + kOffTab, s) : launch_x<5, 2, 2, false, true>(p, pl.lds + kOffTab, s))
                   : stats_part ? (KS == 3 ? launch_x_ncb<3, 2, true>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s))
                              : (KS == 3 ? launch_x_ncb<3, 2>(pl.NCB, p, pl.lds + kOffTab, s) : launch_x_ncb<5, 2>(pl.NCB, p, pl.lds + kOffTab, s));
     if (e) return e;

@@ -35,7 +35,7 @@ def test_no_cpu_fallback():
         ops.instance_norm_act(torch.zeros(1, 2, 4, 4, 4))
 
 
-@pytest.mark.parametrize('name,kernel', [('conv_s3x', 'k_conv_s3x'), ('conv_p2d', 'k_conv_p2d')])
+@pytest.mark.parametrize('name,kernel', [('conv_s3x', 'k_conv_s3x'), ('conv_s3x', 'k_conv_s3w'), ('conv_p2d', 'k_conv_p2d')])
 def test_hand_counted_loads_are_not_touched_in_flight(tmp_path, name, kernel):
     """conv_s3x.hip / conv_p2d.hip issue their weight / bias loads as inline assembly and wait for them with hand-placed s_waitcnt (the
     compiler's own vmcnt bookkeeping would wait for freshly issued LDS-DMA in front of every k-step).  The compiler does not know those

@@ -434,4 +434,4 @@ def test_batched_cubes_per_call_match_one_cube_per_call(monkeypatch):
     assert np.array_equal(out[('5', '2')][0], out[('5', '2')][1])
     for k in (('5', '2'), ('3', '3')):
         d = np.abs(out[k][0].astype(np.int64) - out[('1', '1')][0].astype(np.int64))
-        assert int(d.max()) <= 1 and float((d > 0).mean()) < 0.02, (k, int(d.max()), float((d > 0).mean()))
+        assert int(d.max()) <= 1 and float((d > 0).mean()) < 0.05, (k, int(d.max()), float((d > 0).mean()))

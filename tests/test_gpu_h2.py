@@ -31,7 +31,9 @@ def _restore():
     t = L().nc_get_split_terms()
     gd = L().nc_get_h2_guard()
     ep = L().nc_get_epi_stats()
+    w64 = L().nc_get_s3x_w64()
     yield
+    L().nc_set_s3x_w64(w64)
     L().nc_set_split_terms(t)
     L().nc_set_h2_guard(gd)
     L().nc_set_epi_stats(ep)
@@ -60,8 +62,20 @@ CASES = [(1, 64, 64, 32, 3, 'relu'), (1, 64, 64, 32, 3, 'grad'), (1, 64, 64, 32,
          (1, 64, 64, 24, 5, 'randn'), (1, 256, 256, 12, 3, 'relu')]
 
 
+def running_sum_rms(channels):
+    """nc_set_s3x_w64(1) (default): the two-term 3^3 tiles keep ONE running fp32 accumulator over their k-steps (k_conv_s3w has no registers for
+    a second set; k_conv_s3x follows, so that an element's bits do not depend on the kernel its tile fell to).  The error of a running fp32
+    sum of k-steps 32-term blocks: rms = 2^-24 sqrt(k-steps) of the output's rms -- measured 1.00 of that at 64, 128 and 256 channels; the level
+    of the fp32 tap-stream kernels (and of any fp32 reference), 2.7 x the restarted form's at 64 channels."""
+    return 2.0 ** -24 * (27 * (channels // 8) / 4) ** 0.5
+
+
+@pytest.mark.parametrize('w64', [1, 0])
 @pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
-def test_h2_layer_against_fp64(case):
+def test_h2_layer_against_fp64(case, w64):
+    """Forward and data gradient of one layer against fp64: the fp32 kernels, the three-term and the two-term form.
+    nc_set_s3x_w64(0): every two-term tile restarts its accumulators every four k-steps -- closer to fp64 than the fp32 kernels' running sums.
+    nc_set_s3x_w64(1): running_sum_rms above for the 3^3 layers; 5^3 tiles restart either way."""
     from neuroclear_amd import ops
     N, C, K, E, ks, kind = case
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -71,6 +85,7 @@ def test_h2_layer_against_fp64(case):
     ref = F.conv3d(x.double(), w.double(), b.double(), padding=ks // 2)
     dy = data(kind if kind.startswith('grad') else 'randn', tuple(ref.shape), g)
     refd = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=ks // 2)
+    L().nc_set_s3x_w64(w64)
     res = {}
     for name, split, terms in (('fp32', False, 3), ('t3', True, 3), ('t2', True, 2)):
         ops.set_conv_split(split)
@@ -80,11 +95,17 @@ def test_h2_layer_against_fp64(case):
         if name == 't2':
             assert torch.equal(y, ops.conv_fwd_raw(x, w, b, 1, ks // 2)) and torch.equal(dx, ops.conv_dgrad_raw(dy, w, x.shape, 1, ks // 2))
         res[name] = (err(y, ref), err(dx, refd))
+    running = w64 == 1 and ks == 3
     for i, what in enumerate(('fwd', 'dgrad')):
         (m32, r32), (m3, r3), (m2, r2) = res['fp32'][i], res['t3'][i], res['t2'][i]
-        print(case, what, 'fp32 %.2e/%.2e  three-term %.2e/%.2e  two-term %.2e/%.2e' % (m32, r32, m3, r3, m2, r2))
-        assert r2 <= 1.3 * r32 + 2e-8 and m2 <= 2.0 * m32 + 2e-7, (what, m2, r2, m32, r32)
-        assert r2 <= 1.3 * r3 + 2e-8, (what, r2, r3)
+        print(case, 'w64', w64, what, 'fp32 %.2e/%.2e  three-term %.2e/%.2e  two-term %.2e/%.2e' % (m32, r32, m3, r3, m2, r2))
+        if running:
+            lim = running_sum_rms((C, K)[i])
+            # (the largest errors of the gradient-like tensors sit where outputs cancel: their maximum is held to the fp32 kernels')
+            assert r2 <= 1.3 * lim + 2e-8 and m2 <= max(24 * lim, 3.0 * m32 + 2e-7), (what, m2, r2, m32, lim)
+        else:
+            assert r2 <= 1.3 * r32 + 2e-8 and m2 <= 2.0 * m32 + 2e-7, (what, m2, r2, m32, r32)
+            assert r2 <= 1.3 * r3 + 2e-8, (what, r2, r3)
 
 
 @pytest.mark.parametrize('scale', [1e-30, 1e-12, 1e12, 1e30])
@@ -104,7 +125,7 @@ def test_h2_range(scale):
     assert torch.equal(y2, y1 * s2)
     assert torch.equal(yw, y1 * 2.0 ** -40)
     ref = F.conv3d(x.double() * scale, w.double(), padding=1)
-    assert err(ys, ref)[1] < 3e-7
+    assert err(ys, ref)[1] < 1.3 * running_sum_rms(64)  # (4.4e-7 measured; 1.6e-7 with nc_set_s3x_w64(0))
     z = ops.conv_fwd_raw(torch.zeros_like(x), w, None, 1, 1)
     assert float(z.abs().max()) == 0.0
     # an input that is a view at an odd float offset of a larger buffer (4-byte aligned only): the measuring pass must not care
@@ -353,7 +374,10 @@ def test_h2_random_shapes():
         ops.set_conv_split(True)
         L().nc_set_split_terms(2)
         for i, what in enumerate(('fwd', 'dgrad', 'wgrad')):
-            assert res['t2'][i] <= 1.3 * max(res['t3'][i], res['fp32'][i]) + 2e-8, (case, what, (N, C, K, D, H, W, ks), res)
+            lim = max(res['t3'][i], res['fp32'][i])
+            if ks == 3 and what != 'wgrad':
+                lim = max(lim, running_sum_rms(C if what == 'fwd' else K))
+            assert res['t2'][i] <= 1.3 * lim + 2e-8, (case, what, (N, C, K, D, H, W, ks), res)
 
 
 def rnd(seed, shape):
@@ -494,6 +518,74 @@ def test_h2_epilogue_statistics_follow_the_separate_pass(size):
         if first[i] is None:
             first[i] = y.clone()
         assert torch.equal(y, first[i]), it
+
+
+W64_CASES = [(1, 64, 64, (64, 64, 64)), (1, 128, 64, (40, 60, 108)), (2, 64, 128, (48, 48, 48)), (1, 192, 64, (33, 70, 62))]
+
+
+@pytest.mark.parametrize('case', W64_CASES, ids=[str(c) for c in W64_CASES])
+def test_h2_w64_tile_against_fp64_and_the_first_kernel(case):
+    """nc_set_s3x_w64: the whole 512-position tiles of a two-term 3^3 launch on k_conv_s3w (64 channels x 64 positions per wave, weights staged
+    through LDS, one running accumulator) or on k_conv_s3x with its accumulator restarts (conv_s3x.hip).  Same operands, same products; the fp32
+    sums are taken in another order, so the two agree to fp32 rounding, not bit for bit -- and they do differ somewhere, which is how this test
+    knows the switch reached the launch.  Each is held to its error model against fp64 and repeats its own bits.  With the switch on, the
+    fractional tiles of the tail launch (k_conv_s3x) sum the same way: a sample's bits do not depend on the batch it travels in (whole-tile /
+    tail membership changes with the batch)."""
+    import time
+    from neuroclear_amd import ops
+    N, C, K, dims = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = data('relu', (N, C) + dims, g)
+    w = torch.randn(K, C, 3, 3, 3, device=DEV, generator=g) * (2.0 / (C * 27)) ** 0.5
+    b = torch.randn(K, device=DEV, generator=g) * 0.1
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    dy = data('randn', tuple(ref.shape), g)
+    refd = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=1)
+    ops.set_conv_split(False)
+    m32, r32 = err(ops.conv_fwd_raw(x, w, b, 1, 1), ref)
+    ops.set_conv_split(True)
+    L().nc_set_split_terms(2)
+    out = {}
+    for on in (0, 1):
+        L().nc_set_s3x_w64(on)
+        assert L().nc_get_s3x_w64() == on
+        y = ops.conv_fwd_raw(x, w, b, 1, 1)
+        for it in range(4):
+            time.sleep(0.02 * it)
+            assert torch.equal(ops.conv_fwd_raw(x, w, b, 1, 1), y), (on, it)
+        m2, r2 = err(y, ref)
+        dx = ops.conv_dgrad_raw(dy, w, x.shape, 1, 1)
+        md, rd = err(dx, refd)
+        print(case, 'w64', on, 'fwd %.2e/%.2e (fp32 %.2e/%.2e) dgrad %.2e/%.2e' % (m2, r2, m32, r32, md, rd))
+        lim, limd = (running_sum_rms(C), running_sum_rms(K)) if on else (2.2e-7, 2.2e-7)  # (restarted sums: 1.6-1.9e-7 measured)
+        assert r2 <= 1.3 * lim + 2e-8 and m2 <= 24 * lim, (on, m2, r2, lim)
+        assert rd <= 1.3 * limd + 2e-8 and md <= 24 * limd, (on, md, rd, limd)
+        assert torch.equal(ops.conv_dgrad_raw(dy, w, x.shape, 1, 1), dx)
+        out[on] = (y, dx)
+        if on and N > 1:  # a sample alone (other tiles, other whole-tile / tail membership): the same bits
+            assert torch.equal(ops.conv_fwd_raw(x[1:2].contiguous(), w, b, 1, 1), y[1:2])
+    d = (out[0][0] - out[1][0]).abs().max().item() / ref.abs().max().item()
+    assert 0 < d < 4e-6, d
+
+
+def test_h2_w64_epilogue_statistics_match_the_first_kernels(golden_dir):
+    """The ST records of k_conv_s3w (two waves of a 128-position group add their sums through LDS) are k_conv_s3x's: the inference forward at 96^3
+    and 140^3 (whole-tile launches of 512 positions at the 48^3 level / at 140^3 and 70^3) with either kernel, against each other and against the separate statistics pass."""
+    net = networks.define_G(1, 1, 64, 'unet_deconv', 'instance', False, 'kaiming', 0.02, [0])
+    net.load_state_dict(S.state_dict_from_seed(S.unet_deconv_spec(), 21, DEV))
+    L().nc_set_split_terms(2)
+    for size in (96, 140):
+        x = torch.from_numpy(rnd(2000 + size, (1, 1, size, size, size))).to(DEV)
+        ys = {}
+        for on, epi in ((0, 1), (1, 1), (1, 0)):
+            L().nc_set_s3x_w64(on)
+            L().nc_set_epi_stats(epi)
+            with torch.no_grad():
+                ys[(on, epi)] = net(x).clone()
+                assert torch.equal(net(x), ys[(on, epi)])
+        assert float((ys[(1, 1)] - ys[(0, 1)]).abs().max()) < 2e-6
+        assert float((ys[(1, 1)] - ys[(1, 0)]).abs().max()) < 2e-6
+        assert not torch.equal(ys[(1, 1)], ys[(0, 1)])
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 32, 32, 32), (1, 1, 80, 80, 80), (2, 1, 16, 24, 40)])
