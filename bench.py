@@ -59,13 +59,15 @@ ARITHMETIC = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as
 # per fp32 product (csrc/conv_s3x.hip NT = 2, csrc/h2.hip, k_wgrad_s3x<KS, 2, f16>).  Its roofline is the 16-bit dense peak / 3; the
 # three-term step is timed next to it (`three_term_split`), as the fp32 MFMA kernels' is (`fp32_mfma_kernels`).
 ARITHMETIC_H2 = ('fp32 operands, fp32 accumulation; 3^3/5^3 convolution products as 3 fp16 MFMA products of a 2-term operand split of the tensor times '
-                 'a per-tensor power of two (csrc/conv_s3x.hip NT = 2, csrc/h2.hip; error vs fp64 <= the three-term form\'s and the fp32 MFMA '
-                 'kernels\': tests/test_gpu_h2.py); NC_SPLIT_TERMS=3 = the three-term bf16 form (6 products), NC_CONV_SPLIT=0 = fp32 MFMA kernels')
+                 'a per-tensor power of two (csrc/conv_s3x.hip NT = 2, csrc/h2.hip; error vs fp64: the 3^3 forward / data-gradient tiles keep one running fp32 '
+                 'accumulator (k_conv_s3w, NC_S3X_W64=1): 2^-24 sqrt(k-steps) rms, the fp32 MFMA kernels\' level; 5^3 layers, weight gradients and '
+                 'NC_S3X_W64=0 restart their accumulators: <= the three-term form\'s, below the fp32 kernels\'; tests/test_gpu_h2.py); '
+                 'NC_SPLIT_TERMS=3 = the three-term bf16 form (6 products), NC_CONV_SPLIT=0 = fp32 MFMA kernels')
 KERNEL_OF = {  # profiler tag -> HIP kernel name to look for in profiles/*.csv
     'fwd_mfma_k3': 'k_conv_mfma<3,*>', 'dgrad_mfma_k3': 'k_conv_mfma<3,*>', 'fwd_mfma_k5': 'k_conv_mfma<5,*>',
     'dgrad_mfma_k5': 'k_conv_mfma<5,*>', 'wgrad_mfma_k3': 'k_wgrad_dma<3,2> (108^3) + k_wgrad_rows<3> (54^3, 27^3)',
     'wgrad_mfma_k5': 'k_wgrad_dma<5,1>',
-    'fwd_split_k3': 'k_conv_s3x<3,*>', 'dgrad_split_k3': 'k_conv_s3x<3,*>', 'fwd_split_k5': 'k_conv_s3x<5,*>',
+    'fwd_split_k3': 'k_conv_s3x<3,*>', 'dgrad_split_k3': 'k_conv_s3x<3,*>',  # (two-term, whole 512-position tiles: k_conv_s3w, see below) 'fwd_split_k5': 'k_conv_s3x<5,*>',
     'dgrad_split_k5': 'k_conv_s3x<5,*>', 'wgrad_split_k3': 'k_wgrad_s3x<3>', 'wgrad_split_k5': 'k_wgrad_s3x<5>',
     'fwd_lp_k3': 'k_conv_c8x<*,3> (k_conv_h<*,3,3,3,*> for launches of a few planes)', 'dgrad_lp_k3': 'k_conv_c8x<*,3>',
     'fwd_lp_k5': 'k_conv_h<*,5,5,5,*>', 'dgrad_lp_k5': 'k_conv_h<*,5,5,5,*>', 'wgrad_lp_k3': 'k_wgrad_s3x<3,1,*>', 'wgrad_lp_k5': 'k_wgrad_s3x<5,1,*>',
@@ -386,7 +388,8 @@ def run_train(args, rank, world, dev):
                          frac_of_six_product_roof=round(ach / MFMA_SPLIT_PEAK_TFLOPS, 4), vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
         kname = KERNEL_OF.get(top, top)
         if two:
-            kname = kname.replace('k_conv_s3x<3,*>', 'k_conv_s3x<3,*,2>').replace('k_conv_s3x<5,*>', 'k_conv_s3x<5,*,2>').replace(
+            w64 = bool(_l().nc_get_s3x_w64())
+            kname = kname.replace('k_conv_s3x<3,*>', 'k_conv_s3w + k_conv_s3x<3,*,2> (fractional tiles, 54^3 / 27^3)' if w64 else 'k_conv_s3x<3,*,2>').replace('k_conv_s3x<5,*>', 'k_conv_s3x<5,*,2>').replace(
                 'k_wgrad_s3x<3>', 'k_wgrad_s3x<3,2,f16>').replace('k_wgrad_s3x<5>', 'k_wgrad_s3x<5,2,f16>')
         traffic = pmc_traffic(top, crop, args.batch, three_term='_split_' in top and not two)
         roof = dict(bound='mfma', kernel=kname, kernel_class=top, achieved=round(ach, 2),
@@ -515,7 +518,7 @@ def run_infer(args, rank, world, dev, steps=None, warmup=None):
                      vs_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 4)) if split else {}
         cube_traffic = pmc_traffic_cube(split, three_term=split and terms != 2)
         roof = dict(bound='mfma', kernel='nc_unet_deconv_fwd: all kernels of one 140^3 cube forward (dominant: %s, '
-                                        'profiles/r06_infer480_one_stream_kernel_stats.csv)' % ('k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3) if split else 'k_conv_mfma<3,*>'),
+                                        'profiles/r06_infer480_one_stream_kernel_stats.csv)' % (('k_conv_s3w<ST>' if terms == 2 and lib().nc_get_s3x_w64() else 'k_conv_s3x<3,*,%d>' % (2 if terms == 2 else 3)) if split else 'k_conv_mfma<3,*>'),
                     achieved=round(ach, 2), peak=round(peak, 2), unit='TFLOP/s',
                     frac=round(ach / peak, 4), **extra, traffic=cube_traffic, traffic_source=TRAFFIC_SOURCE,
                     algorithmic_bytes=round(3192 * 140 ** 3),  # 3,192 B per voxel for a perfectly fused fp32 G_A forward

@@ -29,7 +29,7 @@ def kernel_class(name):
         return 'wgrad_c1_k7'
     if 'k_fold_c1k7' in name:
         return 'fold_c1k7'
-    for kern, cls in (('k_conv_s3x<3, 8', 'conv_split_k3'), ('k_conv_s3x<3, 7', 'conv_split_k3'), ('k_conv_s3x<5, 7', 'conv_split_k5'), ('k_conv_s3x<3, 6', 'conv_split_k3_small'), ('k_conv_s3x<3, 4', 'conv_split_k3_small'),
+    for kern, cls in (('k_conv_s3w<', 'conv_split_k3'), ('k_conv_s3x<3, 8', 'conv_split_k3'), ('k_conv_s3x<3, 7', 'conv_split_k3'), ('k_conv_s3x<5, 7', 'conv_split_k5'), ('k_conv_s3x<3, 6', 'conv_split_k3_small'), ('k_conv_s3x<3, 4', 'conv_split_k3_small'),
                       ('k_conv_s3x<3, 2', 'conv_split_k3_tail'), ('k_conv_s3x<5, 8', 'conv_split_k5'), ('k_conv_s3x<5', 'conv_split_k5_tail'),
                       ('k_conv_s3<3', 'conv_split_k3'), ('k_conv_s3<5', 'conv_split_k5'), ('k_wgrad_s3x<3', 'wgrad_split_k3'),
                       ('k_wgrad_s3x<5', 'wgrad_split_k5'), ('k_wgrad_s3<3', 'wgrad_split_k3'), ('k_wgrad_s3<5', 'wgrad_split_k5'),

@@ -8,9 +8,9 @@ rm -rf $O; mkdir -p $O
 T="timeout 900"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 $T rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/sqt -o t -- python3 bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/sqt.log 2>&1
-python3 tools/pmc_group.py $O/sqt $O/train_sq_counters.csv k_conv_s3x k_wgrad_s3x k_conv_mfma k_wgrad_c1 k_dgrad_to1 k_conv_gemm k_convT > /dev/null
+python3 tools/pmc_group.py $O/sqt $O/train_sq_counters.csv k_conv_s3w k_conv_s3x k_wgrad_s3x k_conv_mfma k_wgrad_c1 k_dgrad_to1 k_conv_gemm k_convT > /dev/null
 NC_INFER_STREAMS=1 $T rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/sqi -o t -- python3 bench.py --workload infer --volume 300 --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $O/sqi.log 2>&1
-python3 tools/pmc_group.py $O/sqi $O/infer_sq_counters.csv k_conv_s3x k_convT k_conv_c1k3 > /dev/null
+python3 tools/pmc_group.py $O/sqi $O/infer_sq_counters.csv k_conv_s3w k_conv_s3x k_convT k_conv_c1k3 > /dev/null
 rm -rf $O/sqt $O/sqi
 $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/tf -o t -- python3 bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-prof > $O/tf.log 2>&1
 $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/tw -o t -- python3 bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --no-prof > $O/tw.log 2>&1
