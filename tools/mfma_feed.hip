@@ -111,12 +111,13 @@ void run(const char* name, const uint4* in, float* out) {
 // ---- round 6: wave tiles with BOTH operands from LDS, with and without the LDS-DMA staging + barrier that feeds them
 // RB row blocks x NCB column blocks per wave; ASRC 0 = registers, 1 = global (per wave), 2 = LDS; STAGE = DMA pieces per two k-steps (0: none)
 // LDS: [0, 80K) B image (term stride 40 KiB), [80K, 112K) A ring (4 k-steps x 8 KiB), [112K, 160K) landing area of the brick pieces
-template <int RB, int NCB, int ASRC, int STAGE>
-__global__ void __launch_bounds__(512, 1) k2(const uint4* __restrict__ in, float* __restrict__ out, int ksteps) {
+// WAVES = 4 (modes 19, 20): ONE wave per SIMD with the whole register file (512) -- the 64 x 128 wave tile WITH room for a second accumulator set
+template <int RB, int NCB, int ASRC, int STAGE, int WAVES = 8>
+__global__ void __launch_bounds__(WAVES * 64, 1) k2(const uint4* __restrict__ in, float* __restrict__ out, int ksteps) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   constexpr int NA = RB * 2;  // A fragments per k-step and wave
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m16 = lane & 15, g = lane >> 4;
-  for (int i = tid; i < 163840 / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = in[(blockIdx.x * 1536 + i) & 65535];
+  for (int i = tid; i < 163840 / 16; i += WAVES * 64) reinterpret_cast<uint4*>(lds)[i] = in[(blockIdx.x * 1536 + i) & 65535];
   __syncthreads();
   const unsigned base = (unsigned)(unsigned long long)(lptr_t)lds;
   // position group: RB = 4 -> every wave its own NCB * 16 positions; RB = 2 -> waves 2p, 2p + 1 share a group (the two channel halves)
@@ -190,23 +191,23 @@ __global__ void __launch_bounds__(512, 1) k2(const uint4* __restrict__ in, float
   out[blockIdx.x * 512 + tid] = sum;
 }
 
-template <int RB, int NCB, int ASRC, int STAGE>
+template <int RB, int NCB, int ASRC, int STAGE, int WAVES = 8>
 void run2(const char* name, const uint4* in, float* out) {
   const int ksteps = 4000, grid = 256;
-  auto kern = k2<RB, NCB, ASRC, STAGE>;
+  auto kern = k2<RB, NCB, ASRC, STAGE, WAVES>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, 0, in, out, ksteps);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 163840, 0, in, out, ksteps);
   hipEventRecord(e0);
   const int reps = 8;
-  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 163840, 0, in, out, ksteps);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 163840, 0, in, out, ksteps);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  const double flop = 2.0 * 16 * 16 * 32 * 3 * RB * NCB * (double)ksteps * grid * 8;
+  const double flop = 2.0 * 16 * 16 * 32 * 3 * RB * NCB * (double)ksteps * grid * WAVES;
   printf("{\"mode\": \"%s\", \"ms\": %.3f, \"mfma_tflops\": %.0f, \"fp32_equiv_tflops\": %.0f}\n", name, ms, flop / (ms * 1e-3) / 1e12, flop / 3 / (ms * 1e-3) / 1e12);
 }
 
@@ -341,6 +342,8 @@ int main() {
     run3<2, 2, 2, 37>("16 32x32x16: 64ch x 64pos, A and B from LDS, staging (mode 11's structure)", in, out);
     run3<2, 4, 2, 56>("17 32x32x16: 64ch x 128pos, A and B from LDS, staging (mode 12's structure)", in, out);
     run3<2, 4, 0, 0>("18 32x32x16: 64ch x 128pos, B from LDS, A in registers", in, out);
+    run2<4, 8, 2, 0, 4>("19 FOUR waves (one per SIMD) x 64ch x 128pos, B and A from LDS", in, out);
+    run2<4, 8, 2, 37, 4>("20 mode 19 + staging of bricks and A (37 pieces + barrier / 2 k-steps): a 512-position tile", in, out);
   }
   return 0;
 }
