@@ -1,7 +1,10 @@
+# same-box timing of k_conv_s3w variants (tools/s3x_variant.sh): default (16-byte stores) / tr0 (64 one-dword stores) / nostore (timing only)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r06w; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_h2.py -q -m gpu -x -k "w64 or layer_against or epilogue" > $O/tests2.log 2>&1; tail -5 $O/tests2.log
+A=$GRAFT_REPO_ROOT/neuroclear_amd/csrc/abl
+timeout 900 python -m pytest tests/test_gpu_h2.py -q -m gpu -x -k "w64 or epilogue or layer_against" > $O/tests3.log 2>&1; tail -3 $O/tests3.log
 for i in 1 2; do
-NC_S3X_W64=0 timeout 300 python tools/h2_time.py 2 2>&1 | tail -1
-NC_S3X_W64=1 timeout 300 python tools/h2_time.py 2 2>&1 | tail -1
-done | tee $O/h2_time.log
+for v in default tr0 nostore; do
+  if [ $v = default ]; then unset NC_HIP_LIB; else export NC_HIP_LIB=$A/libnc_hip_s3x_$v.so; fi
+  timeout 300 python tools/h2_time.py 2 2>&1 | tail -1 | sed "s/^/$v /"
+done; done | tee $O/h2_time_variants.log

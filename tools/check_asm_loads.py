@@ -1,4 +1,4 @@
-"""Sanity check of a hipcc -save-temps .s file: registers written by (hand-placed, inline-asm) buffer_load_dwordx4 instructions must not
+"""Sanity check of a hipcc -save-temps .s file: registers written by (hand-placed, inline-asm) buffer_load_dword[x2|x3|x4] instructions must not
 be touched before the next s_waitcnt vmcnt in program text order -- the compiler does not know these loads are asynchronous.
 usage: python tools/check_asm_loads.py <file.s> [kernel substring]"""
 import re
@@ -37,7 +37,7 @@ def main(path, flt=''):
             queue = []
             continue
         pending = set().union(*queue) if queue else set()
-        if code.startswith('buffer_load_dwordx4') and ' lds' not in code:
+        if re.match(r'buffer_load_dword(x[234])?\s', code) and ' lds' not in code:
             ops = code.split(None, 1)[1].split(',')
             if regs(','.join(ops[1:])) & pending:
                 print('%s:%d address uses pending register: %s' % (kern[:50], ln, code)); bad += 1
