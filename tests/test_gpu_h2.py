@@ -568,6 +568,40 @@ def test_h2_w64_tile_against_fp64_and_the_first_kernel(case):
     assert 0 < d < 4e-6, d
 
 
+def test_h2_w64_random_shapes_with_whole_tiles():
+    """Random plane shapes large enough for launches of whole 512-position tiles (odd extents, pad columns inside a tile, several samples,
+    64 .. 192 input channels, one or two 64-channel output tiles, with and without bias): k_conv_s3w against k_conv_s3x with restarts to fp32
+    rounding, each sample of a batch bit-identical to the same sample alone (other whole-tile / tail membership), forward and data gradient."""
+    import random
+    from neuroclear_amd import ops
+    rng = random.Random(17)
+    L().nc_set_split_terms(2)
+    for case in range(10):
+        C, K = rng.choice([64, 128, 192]), rng.choice([64, 128])
+        N = rng.choice([1, 2, 3])
+        D, H, W = rng.randint(9, 40), rng.randint(40, 110), rng.randint(40, 120)
+        g = torch.Generator(device=DEV).manual_seed(3000 + case)
+        x = data(rng.choice(['randn', 'relu']), (N, C, D, H, W), g)
+        w = torch.randn(K, C, 3, 3, 3, device=DEV, generator=g) * (2.0 / (C * 27)) ** 0.5
+        b = torch.randn(K, device=DEV, generator=g) * 0.1 if case % 2 else None
+        dy = torch.randn(N, K, D, H, W, device=DEV, generator=g)
+        out = {}
+        for on in (0, 1):
+            L().nc_set_s3x_w64(on)
+            out[on] = (ops.conv_fwd_raw(x, w, b, 1, 1), ops.conv_dgrad_raw(dy, w, x.shape, 1, 1))
+        for i in range(2):
+            sc = out[0][i].abs().max().item()
+            d = (out[0][i] - out[1][i]).abs().max().item() / sc
+            assert d < 4e-6, (case, i, (N, C, K, D, H, W), d)
+        if N > 1:
+            n = rng.randrange(N)
+            assert torch.equal(ops.conv_fwd_raw(x[n:n + 1].contiguous(), w, b, 1, 1), out[1][0][n:n + 1]), (case, (N, C, K, D, H, W))
+            assert torch.equal(ops.conv_dgrad_raw(dy[n:n + 1].contiguous(), w, (1,) + tuple(x.shape[1:]), 1, 1), out[1][1][n:n + 1]), case
+        ref = F.conv3d(x[:1].double(), w.double(), None if b is None else b.double(), padding=1)
+        m2, r2 = err(out[1][0][:1], ref)
+        assert r2 <= 1.3 * running_sum_rms(C) + 2e-8, (case, r2)
+
+
 def test_h2_w64_epilogue_statistics_match_the_first_kernels(golden_dir):
     """The ST records of k_conv_s3w (two waves of a 128-position group add their sums through LDS) are k_conv_s3x's: the inference forward at 96^3
     and 140^3 (whole-tile launches of 512 positions at the 48^3 level / at 140^3 and 70^3) with either kernel, against each other and against the separate statistics pass."""
