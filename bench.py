@@ -42,6 +42,8 @@ from argparse import Namespace
 
 import numpy as np
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '4')  # (neuroclear_amd/__init__.py says why; here too, in front of the first HIP call of this process)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

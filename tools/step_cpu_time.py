@@ -1,5 +1,5 @@
 """How long does the HOST take to enqueue one Apollo step (no synchronisation inside), against the step's GPU time?  If the enqueue time of a stretch
-of the step exceeds the GPU time of the kernels in front of it, the main stream starves there.  usage: python tools/step_cpu_time.py"""
+of the step exceeds the GPU time of the kernels in front of it, the main stream starves there.  usage: python tools/step_cpu_time.py [apollo|athena]"""
 import contextlib, io, sys, time
 import numpy as np
 import torch
@@ -11,7 +11,7 @@ from neuroclear_amd.util import seed as S
 dev = torch.device('cuda', 0)
 torch.manual_seed(1234); np.random.seed(1234)
 with contextlib.redirect_stdout(io.StringIO()):
-    model = create_model(bench.apollo_opt(0))
+    model = create_model(bench.apollo_opt(0, sys.argv[1] if len(sys.argv) > 1 else 'apollo'))
 real = torch.from_numpy((S.random_volume(101, 108).astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev)
 data = {'A': real, 'A_paths': 'x'}
 for _ in range(4):
@@ -25,7 +25,7 @@ def wrap(name):
     def g(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); marks.setdefault(name, []).append(time.perf_counter() - t); return r
     setattr(model, name, g)
-for nm in ('forward', 'backward_G', 'backward_D_all') :
+for nm in ('forward', 'backward_G', 'backward_D_all', 'backward_D_basic'):
     if hasattr(model, nm): wrap(nm)
 cpu, tot = [], []
 for _ in range(10):
