@@ -166,6 +166,7 @@ class AxialToLateralGANApolloModel(BaseModel):
         return parser
 
     _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+    _d_nstreams = int(os.environ.get('NC_D_NSTREAMS', '4'))  # side streams the discriminator jobs are dealt onto (job i -> stream i % n)
 
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
@@ -282,11 +283,12 @@ class AxialToLateralGANApolloModel(BaseModel):
         if not self._d_streams_on or not self.real.is_cuda:
             return [run(i, net, fn) for i, (net, fn) in enumerate(jobs)]
         main = torch.cuda.current_stream()
-        while len(self._d_streams) < len(jobs):
+        ns = min(len(jobs), self._d_nstreams)
+        while len(self._d_streams) < ns:
             self._d_streams.append(torch.cuda.Stream(device=self.device))
         out = []
         for i, (net, fn) in enumerate(jobs):
-            st = self._d_streams[i]
+            st = self._d_streams[i % ns]
             ev = after[i] if isinstance(after, (list, tuple)) else after
             if ev is not None:
                 st.wait_event(ev)
@@ -294,7 +296,7 @@ class AxialToLateralGANApolloModel(BaseModel):
                 st.wait_stream(main)
             with torch.cuda.stream(st):
                 out.append(run(i, net, fn))
-        for i in range(len(jobs)):
+        for i in range(ns):
             main.wait_stream(self._d_streams[i])
         return out
 

@@ -82,6 +82,7 @@ class AxialToLateralGANAthenaModel(BaseModel):
     # the stream of its forward, so the backward chains overlap too).  One batched PatchGAN pass keeps the matrix pipe
     # ~45 % busy (profiles/README.md); two or three side by side fill the gaps.  NC_D_STREAMS=0: one stream.
     _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+    _d_nstreams = int(os.environ.get('NC_D_NSTREAMS', '6'))  # side streams the six jobs are dealt onto (job i -> stream i % n)
     # backward_G's discriminator passes over the slices of fake / rec are kept and reused by backward_D_basic, which runs
     # the same planes through the same (not yet updated) weights (ops.PatchGANShare).  NC_D_REUSE=0: both passes are run.
     _reuse_on = os.environ.get('NC_D_REUSE', '1') != '0'
@@ -95,18 +96,21 @@ class AxialToLateralGANAthenaModel(BaseModel):
             return [f() for f in fns]
         if not hasattr(self, '_d_streams'):
             self._d_streams = []
-        while len(self._d_streams) < len(fns):
+        ns = min(len(fns), self._d_nstreams)
+        while len(self._d_streams) < ns:
             self._d_streams.append(torch.cuda.Stream(device=self.device))
         main = torch.cuda.current_stream()
         out = []
-        for st, f in zip(self._d_streams, fns):
-            if after is not None:
-                st.wait_event(after)
-            else:
-                st.wait_stream(main)
+        for i, f in enumerate(fns):
+            st = self._d_streams[i % ns]
+            if i < ns:
+                if after is not None:
+                    st.wait_event(after)
+                else:
+                    st.wait_stream(main)
             with torch.cuda.stream(st):
                 out.append(f())
-        for st in self._d_streams[:len(fns)]:
+        for st in self._d_streams[:ns]:
             main.wait_stream(st)
         return out
 
