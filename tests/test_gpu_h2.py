@@ -269,6 +269,28 @@ def test_h2_guard_mixed_magnitudes_fall_back_to_three_terms(kind):
     assert guard_stats()[1] == after[1] + 1                                              # one decision (dY's), taken once for both gradients
 
 
+def test_h2_guard_skips_the_w64_kernel_too():
+    """The range guard at a size whose two-term launch is k_conv_s3w's (whole 512-position tiles, 64^3): a flagged input makes that kernel leave
+    at once like k_conv_s3x (guard_skip), the three-term kernels produce the result -- bit for bit nc_set_split_terms(3)'s -- and an ordinary
+    tensor of the same shape still runs two-term (no fallback counted, result differs from the three-term one)."""
+    from neuroclear_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(41)
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV, generator=g) * (2.0 / (64 * 27)) ** 0.5
+    for kind, flagged in (('dark_half', True), ('relu', False)):
+        x = mixed(kind, (1, 64, 64, 64, 64), g) if flagged else data(kind, (1, 64, 64, 64, 64), g)
+        L().nc_set_split_terms(3)
+        t3 = (ops.conv_fwd_raw(x, w, None, 1, 1), ops.conv_dgrad_raw(x, w, x.shape, 1, 1))
+        L().nc_set_split_terms(2)
+        L().nc_set_s3x_w64(1)
+        before = guard_stats()
+        t2 = (ops.conv_fwd_raw(x, w, None, 1, 1), ops.conv_dgrad_raw(x, w, x.shape, 1, 1))
+        after = guard_stats()
+        assert after[1] - before[1] == (2 if flagged else 0), (kind, before, after)
+        assert all(torch.equal(a, b) for a, b in zip(t2, t3)) == flagged, kind
+        ref = F.conv3d(x.double(), w.double(), padding=1)
+        assert err(t2[0], ref)[1] < 1e-6
+
+
 @pytest.mark.parametrize('kind', ['relu', 'randn', 'grad', 'grad4', 'outlier'])
 def test_h2_guard_leaves_ordinary_tensors_alone(kind):
     """Heavy tails WITHOUT spatial structure (log-normal magnitudes up to sigma = 4, an element 900 sigma out) are the two-term form's home
