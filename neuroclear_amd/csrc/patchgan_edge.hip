@@ -214,6 +214,68 @@ __global__ void __launch_bounds__(256) k_pg1_dgrad(const Pg1 p) {
   }
 }
 
+// The same data gradient for a FEW planes (Apollo: one to four planes of 108^2 per discriminator pass -- 46 workgroups of the kernel above, each
+// thread walking all 64 channels: 105 us, half of the chain of small kernels the generators' backward waits for).  A workgroup = 32 pixel
+// blocks x 8 channel groups: a thread sums its K / 8 channels, the eight partial sums of a pixel block are added through LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_pg1_dgrad_few(const Pg1 p) {
+  __shared__ float ws[kMaxK * 16];
+  __shared__ float red[4][8][32];
+  for (int i = threadIdx.x; i < p.K * 16; i += 256) ws[i] = p.w[i];
+  __syncthreads();
+  const int Hu = (p.H + 1) / 2, Wu = (p.W + 1) / 2;
+  const long nthr = (long)p.B * Hu * Wu;
+  const int pl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const long j = (long)blockIdx.x * 32 + pl;
+  const bool in = j < nthr;
+  const long jj = in ? j : 0;
+  const int b = (int)(jj / ((long)Hu * Wu));
+  const int r = (int)(jj - (long)b * Hu * Wu);
+  const int u = r / Wu, v = r - u * Wu;
+  const int So = p.Ho * p.Wo;
+  float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+  const long gb = (long)b * p.K * So;
+  bool oky[3], okx[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    oky[d] = in && (unsigned)(u - 1 + d) < (unsigned)p.Ho;
+    okx[d] = (unsigned)(v - 1 + d) < (unsigned)p.Wo;
+  }
+  const int k0 = kg * p.K / 8, k1 = (kg + 1) * p.K / 8;
+  for (int k = k0; k < k1; ++k) {
+    const float* wk = ws + k * 16;
+    float n[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        float gv = 0.f;
+        if (oky[dy] && okx[dx]) {
+          const long o = gb + (long)k * So + (long)(u - 1 + dy) * p.Wo + (v - 1 + dx);
+          gv = p.g[o];
+          if (p.act) gv = p.act[o] > 0.f ? gv : gv * p.slope;
+        }
+        n[dy][dx] = gv;
+      }
+    a00 = fmaf(wk[1 * 4 + 1], n[1][1], a00); a00 = fmaf(wk[1 * 4 + 3], n[1][0], a00);
+    a00 = fmaf(wk[3 * 4 + 1], n[0][1], a00); a00 = fmaf(wk[3 * 4 + 3], n[0][0], a00);
+    a01 = fmaf(wk[1 * 4 + 0], n[1][2], a01); a01 = fmaf(wk[1 * 4 + 2], n[1][1], a01);
+    a01 = fmaf(wk[3 * 4 + 0], n[0][2], a01); a01 = fmaf(wk[3 * 4 + 2], n[0][1], a01);
+    a10 = fmaf(wk[0 * 4 + 1], n[2][1], a10); a10 = fmaf(wk[0 * 4 + 3], n[2][0], a10);
+    a10 = fmaf(wk[2 * 4 + 1], n[1][1], a10); a10 = fmaf(wk[2 * 4 + 3], n[1][0], a10);
+    a11 = fmaf(wk[0 * 4 + 0], n[2][2], a11); a11 = fmaf(wk[0 * 4 + 2], n[2][1], a11);
+    a11 = fmaf(wk[2 * 4 + 0], n[1][2], a11); a11 = fmaf(wk[2 * 4 + 2], n[1][1], a11);
+  }
+  red[0][kg][pl] = a00; red[1][kg][pl] = a01; red[2][kg][pl] = a10; red[3][kg][pl] = a11;
+  __syncthreads();
+  if (kg >= 4 || !in) return;  // channel group q < 4 adds up and stores output q of the pixel block
+  float a = red[kg][0][pl];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) a += red[kg][q][pl];
+  float* xo = p.dx + (long)b * p.H * p.W;
+  const int iy = 2 * u + (kg >> 1), ix = 2 * v + (kg & 1);
+  if (iy < p.H && ix < p.W) xo[(long)iy * p.W + ix] = a;
+}
+
 Pg1 make(const ConvDims& d) {
   Pg1 p{};
   p.B = d.N; p.K = d.K; p.H = d.H; p.W = d.W; p.Ho = d.Ho; p.Wo = d.Wo;
@@ -259,7 +321,9 @@ int conv_dgrad_pg1(const float* g, const float* act, float slope, const float* w
   Pg1 p = make(d);
   p.g = g; p.act = act; p.slope = slope; p.w = w; p.dx = dx;
   const long nthr = (long)d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2);
-  hipLaunchKernelGGL(k_pg1_dgrad, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, p);
+  static const int few = getenv("NC_PG1_FEW") ? atoi(getenv("NC_PG1_FEW")) : 1;  // A/B: 0 = the one-thread-per-pixel-block kernel at every size
+  if (few && nthr < 128 * 256) hipLaunchKernelGGL(k_pg1_dgrad_few, dim3((unsigned)cdiv(nthr, 32)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_pg1_dgrad, dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, p);
   return check_launch("conv_dgrad_pg1");
 }
 
