@@ -166,6 +166,7 @@ class AxialToLateralGANApolloModel(BaseModel):
         return parser
 
     _d_streams_on = os.environ.get('NC_D_STREAMS', '1') != '0'
+    _d_on_main = os.environ.get('NC_D_MAIN', '1') != '0'
     _d_nstreams = int(os.environ.get('NC_D_NSTREAMS', '4'))  # side streams the discriminator jobs are dealt onto (job i -> stream i % n)
 
     def __init__(self, opt):
@@ -283,11 +284,16 @@ class AxialToLateralGANApolloModel(BaseModel):
         if not self._d_streams_on or not self.real.is_cuda:
             return [run(i, net, fn) for i, (net, fn) in enumerate(jobs)]
         main = torch.cuda.current_stream()
-        ns = min(len(jobs), self._d_nstreams)
+        # The runtime maps a process's streams onto FOUR hardware queues (neuroclear_amd/__init__.py): the calling stream's and three others.
+        # Four side streams therefore share three queues, and the two chains that share one run one after the other -- while the calling
+        # stream has nothing to do but wait for them.  So the LAST job runs on the calling stream itself (NC_D_MAIN=0: on a side stream).
+        on_main = self._d_on_main and len(jobs) > 3 and not backward  # (the discriminators' own update overlaps the next step's forward: not there)
+        nside = len(jobs) - 1 if on_main else len(jobs)
+        ns = min(nside, self._d_nstreams)
         while len(self._d_streams) < ns:
             self._d_streams.append(torch.cuda.Stream(device=self.device))
         out = []
-        for i, (net, fn) in enumerate(jobs):
+        for i, (net, fn) in enumerate(jobs[:nside]):
             st = self._d_streams[i % ns]
             ev = after[i] if isinstance(after, (list, tuple)) else after
             if ev is not None:
@@ -296,6 +302,8 @@ class AxialToLateralGANApolloModel(BaseModel):
                 st.wait_stream(main)
             with torch.cuda.stream(st):
                 out.append(run(i, net, fn))
+        if on_main:
+            out.append(run(nside, *jobs[nside]))
         for i in range(ns):
             main.wait_stream(self._d_streams[i])
         return out
