@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3w(const XParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       // wave w writes the record (group w / 2, half w % 2): its own sums of that half + its partner's
-      const int h = wave & 1, pw = wave ^ 1;
+      const int h = wave & 1;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, 0x7fffffff, 0x00020000);
       float s0 = 0.f, q0 = 0.f;
       if (m16 < 8) {
@@ -1045,7 +1045,6 @@ __global__ void __launch_bounds__(kThreads, 1) k_conv_s3w(const XParams p) {
         s0 = stx[((lo * 2 + h) * 32 + li) * 2] + stx[(((lo + 1) * 2 + h) * 32 + li) * 2];
         q0 = stx[((lo * 2 + h) * 32 + li) * 2 + 1] + stx[(((lo + 1) * 2 + h) * 32 + li) * 2 + 1];
       }
-      (void)pw;
       const unsigned off = m16 < 8 ? (unsigned)((((unsigned)tidx * kWaves + wave) * 32 + g * 8 + m16) * 8) : kOut;
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       u32x2 pk;
