@@ -411,10 +411,11 @@ def test_image_staged_configs_agree(B, C, K, H, W, s):
     assert n[0] >= 4 and n[1] >= 4, n
 
 
-@pytest.mark.parametrize('B,K,H,W', [(108, 64, 108, 108), (7, 64, 37, 53), (3, 48, 20, 21), (216, 64, 36, 36), (1, 8, 5, 4)])
+@pytest.mark.parametrize('B,K,H,W', [(108, 64, 108, 108), (7, 64, 37, 53), (3, 48, 20, 21), (216, 64, 36, 36), (1, 8, 5, 4), (4, 64, 108, 108), (2, 20, 9, 31)])
 def test_patchgan_first_layer_kernels(B, K, H, W):
     """patchgan_edge.hip: Conv2d(1 -> K, k 4, s 2, p 1) forward, weight + bias gradient (MFMA over the pixel axis, the bias as
-    a column of ones) and data gradient (2 x 2 input blocks), against torch fp32 -- Athena's batch, odd planes, K < 64."""
+    a column of ones) and data gradient (2 x 2 input blocks; below 128 workgroups of pixel blocks the few-planes kernel: 8 channel groups per
+    workgroup, K not a multiple of 8 included), against torch fp32 -- Athena's batch, Apollo's one to four planes, odd planes, K < 64."""
     import torch.nn.functional as F
     from neuroclear_amd._lib import lib
     g = torch.Generator(device=DEV).manual_seed(B * 100 + H)
