@@ -170,28 +170,42 @@ class AxialToLateralGANAthenaModel(BaseModel):
         self.loss_G = self.loss_G_A + self.loss_G_B + self.loss_cycle_A
         self.loss_G.backward()
 
+    # The discriminators' own update only needs real / fake / rec (detached), the planes' activations kept by backward_G's passes and the
+    # discriminators' parameters -- nothing the generators' backward or optimizer_G.step touch.  Its six jobs therefore wait for the END OF
+    # forward() only (an event), not for everything the calling stream has queued: behind the data-gradient chains of the generator loss on
+    # their streams they run UNDERNEATH the generators' backward (19 ms of the calling stream) instead of behind it.  Round 2 measured no gain
+    # from this (167.3 vs 167.8 ms: every kernel filled the chip then); round 6: the update was 20.6 ms of a 50.9 ms step with the calling stream idle
+    # (tools/athena_phases.py).  NC_ATHENA_D_EARLY=0: behind the generators' optimizer step, as the reference orders it.
+    _d_early = os.environ.get('NC_ATHENA_D_EARLY', '1') != '0'
+
     def optimize_parameters(self):
         """athena:262-283"""
         Ds = [self.netD_A_xy, self.netD_A_yz, self.netD_A_xz, self.netD_B_xy, self.netD_B_yz, self.netD_B_xz]
         t, s, r = self.target_sl_axis, self.source_sl_axis, self.remain_sl_axis
         self.forward()
+        fwd_done = None
+        if self._d_early and self._d_streams_on and self.real.is_cuda:
+            fwd_done = torch.cuda.Event()
+            fwd_done.record()
         self.set_requires_grad(Ds, False)
         self.optimizer_G.zero_grad()
         self.backward_G()
         self.optimizer_G.all_reduce_mean()
         self.optimizer_G.step()
         self.set_requires_grad(Ds, True)
-        # (measured: starting these six jobs right after forward(), underneath the generators' backward pass as the Apollo
-        # model does, gains nothing here -- 167.3 vs 167.8 ms: the batched discriminator GEMMs need the whole chip)
-        self.optimizer_D.zero_grad()
+        # early start: the flat gradient buffer was zeroed right after the previous optimizer_D.step (below) -- zeroing it here, on the calling
+        # stream, would run AFTER the early jobs have written their gradients
+        self.optimizer_D.zero_grad(fill=fwd_done is None)
         bd = self.backward_D_basic
         (self.loss_D_A_xy, self.loss_D_A_yz, self.loss_D_A_xz, self.loss_D_B_xy, self.loss_D_B_yz,
          self.loss_D_B_xz) = self._on_streams([
              lambda: bd(self.netD_A_xy, self.real, self.fake, t, t), lambda: bd(self.netD_A_yz, self.real, self.fake, t, s),
              lambda: bd(self.netD_A_xz, self.real, self.fake, t, r), lambda: bd(self.netD_B_xy, self.real, self.rec, t, t),
-             lambda: bd(self.netD_B_yz, self.real, self.rec, s, s), lambda: bd(self.netD_B_xz, self.real, self.rec, r, r)])
+             lambda: bd(self.netD_B_yz, self.real, self.rec, s, s), lambda: bd(self.netD_B_xz, self.real, self.rec, r, r)], after=fwd_done)
         for sh in self._shares.values():
             sh.release()
         self._shares = {}
         self.optimizer_D.all_reduce_mean()
         self.optimizer_D.step()
+        if fwd_done is not None:
+            self.optimizer_D.grad.zero_()
