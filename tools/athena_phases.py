@@ -1,5 +1,5 @@
 """GPU time of the phases of one Athena (or Apollo) step, by events on the calling stream: forward | discriminator passes of the generator loss |
-generators' backward | optimizer_G | discriminators' update | optimizer_D.  usage: python tools/athena_phases.py [athena|apollo]"""
+generators' backward | optimizer_G | discriminators' update | optimizer_D.  usage: python tools/athena_phases.py [athena|apollo] [crop batch precision]"""
 import contextlib, io, sys
 import numpy as np
 import torch
@@ -9,11 +9,16 @@ from neuroclear_amd.models import create_model
 from neuroclear_amd.util import seed as S
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'athena'
+crop, batch = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (108, 1)
+precision = sys.argv[4] if len(sys.argv) > 4 else 'fp32'
 dev = torch.device('cuda', 0)
 torch.manual_seed(1234); np.random.seed(1234)
 with contextlib.redirect_stdout(io.StringIO()):
-    model = create_model(bench.apollo_opt(0, which))
-real = torch.from_numpy((S.random_volume(101, 108).astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev)
+    o = bench.apollo_opt(0, which)
+    if precision != 'fp32':
+        o.precision = precision
+    model = create_model(o)
+real = torch.from_numpy((S.random_volume(101, crop).astype(np.float64) / 65535.0).astype(np.float32))[None, None].to(dev).repeat(batch, 1, 1, 1, 1)
 data = {'A': real, 'A_paths': 'x'}
 for _ in range(4):
     model.set_input(data); model.optimize_parameters()
